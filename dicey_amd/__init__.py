@@ -1,0 +1,176 @@
+"""dicey_amd — MI355X-native in-silico-PCR search path (drop-in for the `dicey hunt` hot path).
+
+Thin Python mirror of the C ABI in include/dicey_gpu.h.  Names follow the reference's seam
+(SURVEY.md §8(b)): an `FmIndex` is what `load_from_checked_file(csa_wt<>)` gives the reference
+(src/hunter.h:253-256); `count` / `locate` / `extract` are sdsl's free functions the reference calls
+(src/hunter.h:353,355,371); `hunt` is the per-query loop of src/hunter.h:291-437 for a whole batch.
+All compute happens in hand-written HIP kernels inside libdiceygpu.so — there is no fallback path.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+from . import _capi
+from ._capi import DgError, DG_Q_DIST_ADJUSTED, DG_Q_MAX_MATCHES, DG_Q_NBHD_EXCEEDED, DG_Q_TOO_SHORT
+
+__all__ = ["FmIndex", "DnaHit", "QueryResult", "HuntBatch", "build_index", "DgError"]
+
+
+@dataclass
+class DnaHit:  # src/hunter.h:53-66
+    score: int
+    chr: int
+    start: int
+    strand: str
+    refalign: str
+    queryalign: str
+
+
+@dataclass
+class QueryResult:
+    sequence: str  # upper-cased, non-ACGT replaced by N (src/hunter.h:306-307)
+    distance: int  # after the clamp of src/hunter.h:312-315
+    flags: int
+    nondna: int
+    hits: List[DnaHit] = field(default_factory=list)  # reference PUSH order (before std::sort, src/hunter.h:440)
+
+    def messages(self, max_locations: int, max_neighborhood: int) -> List[str]:
+        """The msg vector of src/hunter.h:296-437 in the order the reference pushes it."""
+        if self.flags & DG_Q_TOO_SHORT:
+            return ["Error: Input sequence is shorter than 10 nucleotides!"]
+        m = ["Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!"] * self.nondna
+        if self.flags & DG_Q_DIST_ADJUSTED:
+            m.append("Warning: Distance was adjusted to sequence length!")
+        if self.flags & DG_Q_NBHD_EXCEEDED:
+            m.append(f"Warning: Neighborhood size exceeds {max_neighborhood} candidates. Only first {max_neighborhood} "
+                     "neighbors are searched, results are likely incomplete!")
+        if self.flags & DG_Q_MAX_MATCHES:
+            m.append(f"Warning: More than {max_locations} matches found. Only first {max_locations} matches are "
+                     "reported, results are likely incomplete!")
+        return m
+
+
+@dataclass
+class HuntBatch:
+    queries: List[QueryResult]
+    counters: dict
+    timings_ms: dict
+
+
+def _pack(items: Sequence[bytes]):
+    off = (C.c_uint64 * (len(items) + 1))()
+    t = 0
+    for i, b in enumerate(items):
+        off[i] = t
+        t += len(b)
+    off[len(items)] = t
+    return b"".join(items), off
+
+
+class FmIndex:
+    """The FM-index `dicey index` wrote, resident in one GPU's HBM."""
+
+    def __init__(self, fm9_path: str, device: int = 0, selfcheck: bool = True, _lib=None):
+        self._L = _lib or _capi.load()
+        self._h = C.c_void_p()
+        flags = 0 if selfcheck else _capi.DG_OPEN_NO_SELFCHECK
+        _capi.check(self._L, self._L.dg_index_open(fm9_path.encode(), device, flags, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.dg_index_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def stats(self) -> dict:
+        s = _capi.IndexStats()
+        _capi.check(self._L, self._L.dg_index_stats(self._h, C.byref(s)))
+        return {"n": s.n, "sigma": s.sigma, "file_bytes": s.file_bytes, "hbm_bytes": s.hbm_bytes,
+                "load_seconds": s.load_seconds, "derive_seconds": s.derive_seconds,
+                "code_len": {b: s.code_len[b] for b in range(256) if s.code_len[b]}}
+
+    def size(self) -> int:  # fm_index.size(), src/hunter.h:368
+        return self.stats()["n"]
+
+    def count(self, patterns: Sequence[bytes]) -> List[int]:
+        buf, off = _pack(patterns)
+        out = (C.c_uint64 * max(1, len(patterns)))()
+        _capi.check(self._L, self._L.dg_count(self._h, buf, off, len(patterns), out))
+        return list(out[:len(patterns)])
+
+    def locate(self, patterns: Sequence[bytes]) -> List[List[int]]:
+        buf, off = _pack(patterns)
+        lp = C.POINTER(_capi.Locations)()
+        _capi.check(self._L, self._L.dg_locate(self._h, buf, off, len(patterns), C.byref(lp)))
+        try:
+            L = lp.contents
+            return [list(L.pos[L.off[i]:L.off[i + 1]]) for i in range(len(patterns))]
+        finally:
+            self._L.dg_locations_free(lp)
+
+    def extract(self, ranges: Sequence[tuple]) -> List[bytes]:
+        n = len(ranges)
+        lo = (C.c_uint64 * max(1, n))(*[r[0] for r in ranges])
+        hi = (C.c_uint64 * max(1, n))(*[r[1] for r in ranges])
+        off = (C.c_uint64 * max(1, n))()
+        t = 0
+        for i, (a, b) in enumerate(ranges):
+            off[i] = t
+            t += b - a + 1
+        out = C.create_string_buffer(max(1, t))
+        _capi.check(self._L, self._L.dg_extract(self._h, lo, hi, n, out, off))
+        raw = out.raw
+        return [raw[off[i]:off[i] + (ranges[i][1] - ranges[i][0] + 1)] for i in range(n)]
+
+    def _unpack(self, rp) -> HuntBatch:
+        R = rp.contents
+        qs = []
+        seqbuf = C.string_at(R.qseq, R.qoff[R.nq]) if R.nq else b""
+        st = R.aln_stride
+        for i in range(R.nq):
+            q = QueryResult(seqbuf[R.qoff[i]:R.qoff[i + 1]].decode("latin-1"), R.qdistance[i], R.qflags[i], R.qnondna[i])
+            for h in range(R.hit_off[i], R.hit_off[i + 1]):
+                H = R.hits[h]
+                ra = C.string_at(C.addressof(R.refalign.contents) + h * st, H.aln_len).decode("latin-1")
+                qa = C.string_at(C.addressof(R.queryalign.contents) + h * st, H.aln_len).decode("latin-1")
+                q.hits.append(DnaHit(H.score, H.chr, H.start, chr(H.strand), ra, qa))
+            qs.append(q)
+        ctr = {"ext_steps": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa_reads": R.ctr_sa_reads,
+               "win_bytes": R.ctr_win_bytes, "nhits": R.nhits}
+        tm = {"total": R.ms_total, "search": R.ms_search, "select": R.ms_select, "locate": R.ms_locate,
+              "verify": R.ms_verify}
+        return HuntBatch(qs, ctr, tm)
+
+    def hunt(self, queries: Sequence[str], seqlen: Sequence[int], distance: int = 1, hamming: bool = False,
+             forward_only: bool = False, max_locations: int = 1000, max_neighborhood: int = 10000) -> HuntBatch:
+        """seqlen[i] = faidx length + 1 (src/util.h:201)."""
+        buf, off = _pack([q.encode("latin-1") if isinstance(q, str) else q for q in queries])
+        sl = (C.c_uint32 * len(seqlen))(*seqlen)
+        p = _capi.HuntParams(distance, int(hamming), int(forward_only), max_locations, max_neighborhood)
+        rp = C.POINTER(_capi.HuntResult)()
+        _capi.check(self._L, self._L.dg_hunt(self._h, C.byref(p), sl, len(seqlen), buf, off, len(queries), C.byref(rp)))
+        try:
+            return self._unpack(rp)
+        finally:
+            self._L.dg_hunt_result_free(rp)
+
+
+def build_index(text: bytes, out_fm9: str, device: int = 0, _lib=None):
+    """GPU counterpart of `dicey index` (src/index.h:97-123): text = SEQ1\\nSEQ2\\n...SEQk\\n, upper-case."""
+    L = _lib or _capi.load()
+    _capi.check(L, L.dg_index_build(text, len(text), device, out_fm9.encode()))

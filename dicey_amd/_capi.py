@@ -1,0 +1,96 @@
+"""ctypes binding of libdiceygpu.so (include/dicey_gpu.h).
+
+The library is hand-written HIP for gfx950 and is the ONLY compute path of this package: if it is missing, or no
+HIP device is present, every call fails loudly.  There is no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiceygpu.so")
+
+DG_OK = 0
+DG_OPEN_NO_SELFCHECK = 1
+DG_Q_TOO_SHORT, DG_Q_DIST_ADJUSTED, DG_Q_MAX_MATCHES, DG_Q_NBHD_EXCEEDED = 1, 2, 4, 8
+
+
+class DgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libdiceygpu error {code}: {msg}")
+        self.code = code
+
+
+class IndexStats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("sigma", C.c_uint32), ("code_len", C.c_uint32 * 256), ("file_bytes", C.c_uint64),
+                ("hbm_bytes", C.c_uint64), ("load_seconds", C.c_double), ("derive_seconds", C.c_double)]
+
+
+class HuntParams(C.Structure):
+    _fields_ = [("distance", C.c_uint32), ("hamming", C.c_int32), ("forward_only", C.c_int32),
+                ("max_locations", C.c_uint64), ("max_neighborhood", C.c_uint32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("score", C.c_int32), ("chr", C.c_uint32), ("start", C.c_uint32), ("query", C.c_uint32),
+                ("aln_len", C.c_uint16), ("strand", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class HuntResult(C.Structure):
+    _fields_ = [("nq", C.c_size_t), ("nhits", C.c_uint64), ("hit_off", C.POINTER(C.c_uint64)), ("hits", C.POINTER(Hit)),
+                ("aln_stride", C.c_uint32), ("refalign", C.POINTER(C.c_char)), ("queryalign", C.POINTER(C.c_char)),
+                ("qflags", C.POINTER(C.c_uint32)), ("qdistance", C.POINTER(C.c_uint32)), ("qnondna", C.POINTER(C.c_uint32)),
+                ("qseq", C.POINTER(C.c_uint8)), ("qoff", C.POINTER(C.c_uint64)),
+                ("ctr_ext_steps", C.c_uint64), ("ctr_leaves", C.c_uint64), ("ctr_sa_reads", C.c_uint64),
+                ("ctr_win_bytes", C.c_uint64), ("ms_total", C.c_double), ("ms_search", C.c_double),
+                ("ms_select", C.c_double), ("ms_locate", C.c_double), ("ms_verify", C.c_double)]
+
+
+class Locations(C.Structure):
+    _fields_ = [("npat", C.c_size_t), ("off", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_uint64))]
+
+
+# every symbol include/dicey_gpu.h declares; tests/test_capi_symbols.py checks the list against the header
+SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_locate", "dg_locations_free",
+           "dg_extract", "dg_hunt", "dg_hunt_result_free", "dg_hunt_device", "dg_index_build",
+           "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count"]
+
+_lib = None
+
+
+def load(path=None):
+    """Load libdiceygpu.so (built by __graft_entry__.build() / `make -C dicey_amd/csrc`). Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). dicey_amd has no CPU fallback.")
+    L = C.CDLL(p)
+    vp, u64p, u8p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    L.dg_last_error.restype = C.c_char_p
+    L.dg_index_open.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(vp)]
+    L.dg_index_close.argtypes = [vp]
+    L.dg_index_close.restype = None
+    L.dg_index_stats.argtypes = [vp, C.POINTER(IndexStats)]
+    L.dg_count.argtypes = [vp, C.c_char_p, u64p, C.c_size_t, u64p]
+    L.dg_locate.argtypes = [vp, C.c_char_p, u64p, C.c_size_t, C.POINTER(C.POINTER(Locations))]
+    L.dg_locations_free.argtypes = [C.POINTER(Locations)]
+    L.dg_locations_free.restype = None
+    L.dg_extract.argtypes = [vp, u64p, u64p, C.c_size_t, C.c_char_p, u64p]
+    L.dg_hunt.argtypes = [vp, C.POINTER(HuntParams), u32p, C.c_uint32, C.c_char_p, u64p, C.c_size_t,
+                          C.POINTER(C.POINTER(HuntResult))]
+    L.dg_hunt_device.argtypes = [vp, C.POINTER(HuntParams), u32p, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int,
+                                 C.POINTER(C.POINTER(HuntResult))]
+    L.dg_hunt_result_free.argtypes = [C.POINTER(HuntResult)]
+    L.dg_hunt_result_free.restype = None
+    L.dg_index_build.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p]
+    L.dg_index_build_device.argtypes = [vp, C.c_uint64, C.c_int, C.c_char_p]
+    if path is None:
+        _lib = L
+    return L
+
+
+def check(L, rc):
+    if rc != DG_OK:
+        raise DgError(rc, (L.dg_last_error() or b"").decode(errors="replace"))

@@ -1,0 +1,186 @@
+// Device-side view of the FM-index in HBM and the rank/LF primitives every kernel shares.
+//
+// Two layers live side by side in HBM:
+//  (1) the sdsl sections exactly as `dicey index` wrote them (wavelet-tree bit vector, rank_support_v words,
+//      byte_tree, bit-packed SA/ISA samples) — used at load time to derive layer 2, and at query time only for
+//      symbols outside {A,C,G,T};
+//  (2) derived at load: 64-byte Occ blocks (128 BWT symbols as three bit planes + cumulative A/C/G/T counts),
+//      the full suffix array (u32) and a byte copy of the text.  One backward-search step = two 64-byte reads.
+//
+// sdsl arithmetic restated here (rank_support_v::rank, wt_pc::rank / inverse_select) follows SURVEY.md App. A.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dg {
+
+using u8 = uint8_t;
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+
+#define DG_DEV __device__ __forceinline__
+
+// One 64-byte line: counts of A,C,G,T in BWT[0, 128*blk) and the 3-bit codes of BWT[128*blk, 128*blk+128)
+// as bit planes (plane b, word w, bit j  <->  bit b of the code at 128*blk + 64*w + j).
+// codes: 0..3 = A,C,G,T   4 = N   5 = '\n'   6 = sentinel 0   7 = any other byte (resolved through the wavelet tree)
+struct alignas(64) OccBlock {
+  u32 cnt[4];
+  u64 pl[3][2];
+};
+static_assert(sizeof(OccBlock) == 64, "Occ block must be one 64-byte line");
+
+enum : u32 { CODE_N = 4, CODE_NL = 5, CODE_NUL = 6, CODE_OTHER = 7 };
+
+struct WtTables {  // small, read with scalar loads
+  u64 node_pos[512];
+  u64 node_rank[512];  // leaf: the symbol
+  u16 child[512][2];
+  u64 path[256];  // path>>56 = code length, low bits consumed LSB first
+  u16 c_to_leaf[256];
+  u64 C[257];
+  u8 char2comp[256];
+  u8 comp2char[256];
+  u32 sigma;
+};
+
+struct FmView {
+  u64 n;  // text length + 1
+  // sdsl sections
+  const u64* bv;
+  const u64* rk;
+  const WtTables* wt;
+  const u64* sa_samp;
+  const u64* isa_samp;
+  u32 samp_width;
+  u64 n_sa_samp, n_isa_samp;
+  // derived
+  const OccBlock* occ;
+  const u32* sa;   // SA[i], i < n
+  const u8* text;  // T[0..n), text[n-1] = 0
+  u32 C4[4];       // C[] of A,C,G,T (0 and never matching if the symbol is absent)
+  u8 sym_of_code[8];
+};
+
+DG_DEV u64 packed_get(const u64* w, u32 width, u64 i) {
+  u64 b = i * width, q = b >> 6, o = b & 63;
+  u64 v = w[q] >> o;
+  if (o + width > 64) v |= w[q + 1] << (64 - o);
+  return width == 64 ? v : (v & ((1ULL << width) - 1));
+}
+
+// ---- sdsl rank_support_v<1,1>::rank ----
+DG_DEV u64 sdsl_rank1(const FmView& f, u64 idx) {
+  const u64* p = f.rk + ((idx >> 8) & ~1ULL);
+  u64 r = p[0] + ((p[1] >> (63 - 9 * ((idx & 0x1FF) >> 6))) & 0x1FF);
+  if (idx & 63) r += (u64)__popcll(f.bv[idx >> 6] & ((1ULL << (idx & 63)) - 1));
+  return r;
+}
+// ---- wt_pc::rank(i, c) ----
+DG_DEV u64 wt_rank(const FmView& f, u64 i, u32 c) {
+  const WtTables* t = f.wt;
+  if (t->c_to_leaf[c] == 0xFFFF) return 0;
+  u64 p = t->path[c];
+  u32 len = (u32)(p >> 56), v = 0;
+  u64 res = i;
+  for (u32 l = 0; l < len && res; ++l, p >>= 1) {
+    u64 ones = sdsl_rank1(f, t->node_pos[v] + res) - t->node_rank[v];
+    res = (p & 1) ? ones : res - ones;
+    v = t->child[v][p & 1];
+  }
+  return res;
+}
+// ---- wt_pc::inverse_select(i) -> rank of BWT[i] among equal symbols before i; symbol returned through sym ----
+DG_DEV u64 wt_inverse_select(const FmView& f, u64 i, u32& sym) {
+  const WtTables* t = f.wt;
+  u32 v = 0;
+  while (t->child[v][0] != 0xFFFF) {
+    u64 pos = t->node_pos[v] + i;
+    u64 ones = sdsl_rank1(f, pos) - t->node_rank[v];
+    bool b = (f.bv[pos >> 6] >> (pos & 63)) & 1;
+    i = b ? ones : i - ones;
+    v = t->child[v][b];
+  }
+  sym = (u32)t->node_rank[v];
+  return i;
+}
+
+// ---- Occ blocks ----
+struct OccLine {  // one block held in registers
+  u32 cnt[4];
+  u64 p0[2], p1[2], p2[2];
+};
+DG_DEV OccLine occ_load(const OccBlock* occ, u64 blk) {
+  const uint4* q = reinterpret_cast<const uint4*>(occ + blk);
+  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  OccLine L;
+  L.cnt[0] = a.x; L.cnt[1] = a.y; L.cnt[2] = a.z; L.cnt[3] = a.w;
+  L.p0[0] = ((u64)b.y << 32) | b.x; L.p0[1] = ((u64)b.w << 32) | b.z;
+  L.p1[0] = ((u64)c.y << 32) | c.x; L.p1[1] = ((u64)c.w << 32) | c.z;
+  L.p2[0] = ((u64)d.y << 32) | d.x; L.p2[1] = ((u64)d.w << 32) | d.z;
+  return L;
+}
+// occurrences of code c (0..3) in the first r (0..127) symbols of the block, plus the block's running count
+DG_DEV u32 occ_in_line(const OccLine& L, u32 r, u32 c) {
+  u64 m0 = r >= 64 ? ~0ULL : ((1ULL << r) - 1);
+  u64 m1 = r > 64 ? ((1ULL << (r - 64)) - 1) : 0ULL;
+  u64 x0 = (c & 1) ? L.p0[0] : ~L.p0[0], x1 = (c & 1) ? L.p0[1] : ~L.p0[1];
+  u64 y0 = (c & 2) ? L.p1[0] : ~L.p1[0], y1 = (c & 2) ? L.p1[1] : ~L.p1[1];
+  return L.cnt[c] + (u32)__popcll(x0 & y0 & ~L.p2[0] & m0) + (u32)__popcll(x1 & y1 & ~L.p2[1] & m1);
+}
+DG_DEV u32 occ_rank(const FmView& f, u64 i, u32 c) {  // #code c in BWT[0,i), i <= n
+  OccLine L = occ_load(f.occ, i >> 7);
+  return occ_in_line(L, (u32)(i & 127), c);
+}
+DG_DEV u32 code_in_line(const OccLine& L, u32 r) {
+  u32 w = r >> 6, j = r & 63;
+  return (u32)((L.p0[w] >> j) & 1) | ((u32)((L.p1[w] >> j) & 1) << 1) | ((u32)((L.p2[w] >> j) & 1) << 2);
+}
+
+// LF(i) and BWT[i] through the Occ blocks; symbols outside A,C,G,T fall back to the wavelet tree.
+DG_DEV u64 lf_step(const FmView& f, u64 i, u32& sym) {
+  OccLine L = occ_load(f.occ, i >> 7);
+  u32 r = (u32)(i & 127);
+  u32 code = code_in_line(L, r);
+  if (code < 4) {
+    sym = f.sym_of_code[code];
+    return (u64)f.C4[code] + occ_in_line(L, r, code);
+  }
+  if (code != CODE_OTHER) {
+    sym = f.sym_of_code[code];
+    return f.wt->C[f.wt->char2comp[sym]] + wt_rank(f, i, sym);
+  }
+  u64 rk = wt_inverse_select(f, i, sym);
+  return f.wt->C[f.wt->char2comp[sym]] + rk;
+}
+
+// One backward-search step on the half-open SA interval [lo,hi): prepend byte `sym`.
+// (sdsl backward_search, suffix_array_algorithm.hpp; call sites hunter.h:353, silica.h:470)
+DG_DEV void bs_extend_code(const FmView& f, u32& lo, u32& hi, u32 code) {  // code in 0..3
+  OccLine A = occ_load(f.occ, lo >> 7);
+  OccLine B = occ_load(f.occ, hi >> 7);
+  lo = f.C4[code] + occ_in_line(A, lo & 127, code);
+  hi = f.C4[code] + occ_in_line(B, hi & 127, code);
+}
+DG_DEV void bs_extend_sym(const FmView& f, u32& lo, u32& hi, u32 sym, u32 code) {
+  if (code < 4) {
+    bs_extend_code(f, lo, hi, code);
+    return;
+  }
+  const WtTables* t = f.wt;
+  u32 cc = t->char2comp[sym];
+  if (cc == 0 && sym > 0) {  // byte not in the alphabet
+    lo = hi = 0;
+    return;
+  }
+  u64 cb = t->C[cc];
+  lo = (u32)(cb + wt_rank(f, lo, sym));
+  hi = (u32)(cb + wt_rank(f, hi, sym));
+}
+
+DG_DEV u32 code_of_byte(u32 b) {
+  return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : b == 'N' ? 4u : b == '\n' ? 5u : b == 0 ? 6u : 7u;
+}
+
+}  // namespace dg

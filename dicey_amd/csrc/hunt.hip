@@ -1,0 +1,844 @@
+// dg_hunt / dg_hunt_device: the per-query loop of `dicey hunt` (reference src/hunter.h:291-437) for a whole batch,
+// entirely on the GPU.  Five kernels on the index stream:
+//
+//   k_prepare  upper-case, non-ACGT -> N, reverse complement, distance clamp      hunter.h:299-315, util.h:110,208
+//   k_search   neighbourhood enumeration fused with backward search: one lane per (query, strand) walks the trie of
+//              edit paths right-to-left, carrying the SA interval; dead branches stop at the first empty interval.
+//              Emits every OCCURRING string of the <=d-edit language                neighbors.h:47-83 + hunter.h:353
+//   k_select   per query: duplicates out, substring-minimal strings only (= neighbors.h:29-45 restricted to strings
+//              that occur), std::set order, max_locations gating                    hunter.h:349-357
+//   k_locate   the `take` smallest suffix-array values of each kept interval        hunter.h:355-357
+//   k_verify   chromosome lookup, context window, '\n' trimming, Needleman-Wunsch with the reference's tie rules,
+//              lead/trail gap stripping -> DnaHit records in reference push order   hunter.h:358-429, needle.h:59-138
+//
+// Why enumerating only occurring strings is exact: the reference searches the substring-minimal subset M of the
+// language L.  A non-minimal string that occurs implies its minimal substring occurs too, hence
+// M ∩ Occ = minimal elements of (L ∩ Occ); and every string reachable with fewer than d edits is dominated by the
+// same string minus its first character, so only cost-exactly-d leaves can be minimal (DESIGN.md §"neighbourhood").
+// This holds while the maxNeighborhood cap cannot fire; dg_hunt refuses (DG_ELIMIT) inputs where it could.
+#include <algorithm>
+#include <chrono>
+
+#include "devfm.hpp"
+#include "index_internal.hpp"
+
+namespace dg {
+
+static constexpr u32 DMAX = 4;          // largest supported distance
+static constexpr u32 MAX_QLEN = 255;    // longest supported query
+enum : u32 { OP_S = 0, OP_I = 1, OP_D = 2 };
+
+struct Leaf {
+  u32 qs;    // 2*query + strand
+  u32 slot;  // running number within its (query,strand) group
+  u32 lo, hi;
+  u32 nops;
+  u32 ops[DMAX];  // pos<<4 | kind<<2 | code, in right-to-left order of application
+};
+
+struct Sel {  // a kept neighbourhood string, in search order
+  u32 lo, hi;
+  u32 len;    // string length
+  u32 take;   // how many of its occurrences become hits
+  u32 hbase;  // first hit slot, relative to the query's first hit
+};
+
+struct Batch {  // device pointers of one batch
+  const u8* qbytes;
+  const u64* qoff;
+  u64 nq;
+  u8* fw;    // codes 0..4 (A,C,G,T,N), same offsets as qbytes
+  u8* rv;    // reverse complement
+  u8* qseq;  // normalised ASCII
+  u32* qlen;
+  u32* qdist;
+  u32* qflags;
+  u32* qnondna;
+  u32 distance;
+  u32 indel, reverse;
+  u64 max_locations;
+};
+
+DG_DEV u32 ascii_rank(u32 code) { return code == 3 ? 4u : code == 4 ? 3u : code; }  // 'A'<'C'<'G'<'N'<'T'
+DG_DEV u8 ascii_of(u32 code) { return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : 'N'; }
+
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_prepare(Batch b) {
+  u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq) return;
+  u64 s = b.qoff[q], e = b.qoff[q + 1];
+  u32 m = (u32)(e - s), bad = 0, flags = 0;
+  for (u32 i = 0; i < m; ++i) {
+    u32 ch = b.qbytes[s + i];
+    if (ch >= 'a' && ch <= 'z') ch -= 32;  // boost::to_upper_copy, hunter.h:306
+    u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+    bad += (code == 4);  // every replaced character raises one warning (util.h:214); a literal 'N' is replaced too
+    b.fw[s + i] = (u8)code;
+    b.qseq[s + i] = ascii_of(code);
+    b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);  // util.h:54-91,110-114
+  }
+  u32 d = b.distance;
+  if (m < 10) flags |= DG_Q_TOO_SHORT;  // hunter.h:299
+  else if (d >= m) {                    // hunter.h:312-315
+    d = m - 1;
+    flags |= DG_Q_DIST_ADJUSTED;
+  }
+  b.qlen[q] = m;
+  b.qdist[q] = d;
+  b.qflags[q] = flags;
+  b.qnondna[q] = bad;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Search.  State machine: every loop iteration performs at most one interval extension (two Occ-block reads),
+// whatever trie level the lane is on, so a wavefront stays converged on the memory operation.
+struct Frame {
+  u32 pos;  // query characters still to consume (q[0..pos))
+  u32 lo, hi;
+  u32 op;   // next edit operation to try at this node
+};
+
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_search(FmView f, Batch b, Leaf* leaves, u64 leaf_cap, unsigned long long* leaf_count,
+                                                 u32* grp_cnt, unsigned long long* ext_steps) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.nq * 2) return;
+  u64 q = t >> 1;
+  u32 strand = (u32)(t & 1);
+  grp_cnt[t] = 0;
+  if ((strand && !b.reverse) || (b.qflags[q] & DG_Q_TOO_SHORT)) return;
+  const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
+  const u32 m = b.qlen[q], d = b.qdist[q];
+  constexpr u32 NOPS = INDEL ? 9u : 4u;  // INDEL: D, S(A,C,G,T), I(A,C,G,T);  Hamming: S(A,C,G,T)
+  Frame fr[DMAX + 1];
+  u32 ops[DMAX];
+  u32 L = 0, nleaf = 0;
+  u64 steps = 0;
+  fr[0].pos = m;
+  fr[0].lo = 0;
+  fr[0].hi = (u32)f.n;
+  fr[0].op = 0;
+  for (;;) {
+    const u32 budget = d - L;
+    if (fr[L].pos == 0) {
+      // a complete neighbourhood string whose interval is non-empty (empty intervals never get here)
+      if (!INDEL || budget == 0) {
+        u64 at = atomicAdd(leaf_count, 1ULL);
+        if (at < leaf_cap) {
+          Leaf lf;
+          lf.qs = (u32)t;
+          lf.slot = nleaf;
+          lf.lo = fr[L].lo;
+          lf.hi = fr[L].hi;
+          lf.nops = L;
+          for (u32 k = 0; k < DMAX; ++k) lf.ops[k] = k < L ? ops[k] : 0;
+          leaves[at] = lf;
+        }
+        ++nleaf;
+      }
+      if (L == 0) break;
+      --L;
+      continue;
+    }
+    const u32 pos = fr[L].pos;
+    const u32 here = seq[pos - 1];
+    if (budget > 0 && fr[L].op < NOPS) {
+      const u32 op = fr[L].op++;
+      u32 kind, c;
+      if (INDEL) {
+        kind = op == 0 ? OP_D : (op <= 4 ? OP_S : OP_I);
+        c = op == 0 ? 0u : (op - 1) & 3;
+      } else {
+        kind = OP_S;
+        c = op;
+      }
+      if (kind == OP_S && c == here) continue;             // a substitution changes the character (neighbors.h:63)
+      if (kind == OP_I && L == 0 && pos == m) continue;     // nothing may be inserted after the last character (neighbors.h:51)
+      u32 lo = fr[L].lo, hi = fr[L].hi;
+      if (kind != OP_D) {
+        bs_extend_code(f, lo, hi, c);
+        ++steps;
+        if (lo >= hi) continue;
+      }
+      ops[L] = (pos << 4) | (kind << 2) | c;
+      ++L;
+      fr[L].pos = kind == OP_I ? pos : pos - 1;
+      fr[L].lo = lo;
+      fr[L].hi = hi;
+      fr[L].op = 0;
+      continue;
+    }
+    // keep the query character
+    u32 lo = fr[L].lo, hi = fr[L].hi;
+    bs_extend_sym(f, lo, hi, ascii_of(here), here);
+    ++steps;
+    if (lo >= hi) {
+      if (L == 0) break;
+      --L;
+      continue;
+    }
+    fr[L].pos = pos - 1;
+    fr[L].lo = lo;
+    fr[L].hi = hi;
+    fr[L].op = 0;
+  }
+  grp_cnt[t] = nleaf;
+  atomicAdd(ext_steps, (unsigned long long)steps);
+}
+
+// group leaves by (query,strand): dst = grp_off[qs] + slot
+__global__ void k_group(const Leaf* in, u64 nleaf, const u64* grp_off, Leaf* out) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nleaf) return;
+  Leaf lf = in[t];
+  out[grp_off[lf.qs] + lf.slot] = lf;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Left-to-right reader of the string a leaf stands for (query + recorded edits).
+struct LeafReader {
+  const u8* seq;
+  u32 m;
+  const u32* ops;
+  int k;     // next op (they were recorded right-to-left, so read from the last one)
+  u32 qpos;  // next query index to output
+  DG_DEV void init(const u8* s, u32 m_, const Leaf& lf) {
+    seq = s;
+    m = m_;
+    ops = lf.ops;
+    k = (int)lf.nops - 1;
+    qpos = 0;
+  }
+  DG_DEV int next() {  // code 0..4, or -1 at the end
+    for (;;) {
+      if (k < 0) return qpos < m ? (int)seq[qpos++] : -1;
+      u32 op = ops[k], p = op >> 4, kind = (op >> 2) & 3, c = op & 3;
+      u32 upto = kind == OP_I ? p : p - 1;
+      if (qpos < upto) return (int)seq[qpos++];
+      --k;
+      qpos = p;
+      if (kind != OP_D) return (int)c;
+    }
+  }
+};
+DG_DEV u32 leaf_len(u32 m, const Leaf& lf) {
+  u32 len = m;
+  for (u32 k = 0; k < lf.nops; ++k) {
+    u32 kind = (lf.ops[k] >> 2) & 3;
+    len += (kind == OP_I);
+    len -= (kind == OP_D);
+  }
+  return len;
+}
+// is string(b) found inside string(a)?  (std::string::find, neighbors.h:37,39)
+DG_DEV bool leaf_contains(const u8* seq, u32 m, const Leaf& a, u32 la, const Leaf& b, u32 lb) {
+  if (lb > la) return false;
+  for (u32 o = 0; o + lb <= la; ++o) {
+    LeafReader ra, rb;
+    ra.init(seq, m, a);
+    rb.init(seq, m, b);
+    for (u32 i = 0; i < o; ++i) (void)ra.next();
+    bool same = true;
+    for (u32 i = 0; i < lb; ++i)
+      if (ra.next() != rb.next()) {
+        same = false;
+        break;
+      }
+    if (same) return true;
+  }
+  return false;
+}
+// std::string operator< on the ASCII strings
+DG_DEV bool leaf_less(const u8* seq, u32 m, const Leaf& a, const Leaf& b) {
+  LeafReader ra, rb;
+  ra.init(seq, m, a);
+  rb.init(seq, m, b);
+  for (;;) {
+    int x = ra.next(), y = rb.next();
+    if (x < 0 || y < 0) return x < 0 && y >= 0;
+    if (x != y) return ascii_rank((u32)x) < ascii_rank((u32)y);
+  }
+}
+
+// One lane per query.  Works in place on the grouped leaf array: `keep` marks survivors, `order` their rank.
+__global__ void k_select(Batch b, const Leaf* grouped, const u64* grp_off, Sel* sel, u32* nsel /*[2nq]*/, u32* qhits,
+                         u8* scratch_keep, u32* scratch_rank) {
+  u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq) return;
+  const u32 m = b.qlen[q];
+  u64 hits = 0;
+  for (u32 strand = 0; strand < 2; ++strand) {
+    const u64 g0 = grp_off[2 * q + strand], g1 = grp_off[2 * q + strand + 1];
+    const u32 k = (u32)(g1 - g0);
+    nsel[2 * q + strand] = 0;
+    if (!k) continue;
+    const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
+    const Leaf* G = grouped + g0;
+    u8* keep = scratch_keep + g0;
+    u32* rank = scratch_rank + g0;
+    // keep[i] <=> no other occurring string is a proper substring of it, and it is the first copy of itself
+    for (u32 i = 0; i < k; ++i) {
+      u32 li = leaf_len(m, G[i]);
+      bool alive = true;
+      if (b.indel) {
+        for (u32 j = 0; j < k && alive; ++j) {
+          if (j == i) continue;
+          u32 lj = leaf_len(m, G[j]);
+          if (lj > li) continue;
+          if (leaf_contains(seq, m, G[i], li, G[j], lj)) alive = (lj == li) && (i < j);  // equal strings: lowest slot stays
+        }
+      }
+      keep[i] = alive;
+    }
+    // rank among survivors in std::set order
+    u32 ns = 0;
+    for (u32 i = 0; i < k; ++i) {
+      if (!keep[i]) continue;
+      u32 r = 0;
+      for (u32 j = 0; j < k; ++j)
+        if (j != i && keep[j] && leaf_less(seq, m, G[j], G[i])) ++r;
+      rank[i] = r;
+      ++ns;
+    }
+    Sel* S = sel + g0;
+    for (u32 i = 0; i < k; ++i)
+      if (keep[i]) {
+        Sel s;
+        s.lo = G[i].lo;
+        s.hi = G[i].hi;
+        s.len = leaf_len(m, G[i]);
+        s.take = 0;
+        s.hbase = 0;
+        S[rank[i]] = s;
+      }
+    // hunter.h:350,357: strings in set order while hits < max_locations; per string min(occs, max_locations) positions
+    for (u32 r = 0; r < ns; ++r) {
+      u64 occs = (u64)S[r].hi - S[r].lo;
+      u64 take = 0;
+      if (hits < b.max_locations) take = occs < b.max_locations - hits ? occs : b.max_locations - hits;
+      S[r].take = (u32)take;
+      S[r].hbase = (u32)hits;
+      hits += take;
+    }
+    nsel[2 * q + strand] = ns;
+  }
+  qhits[q] = (u32)hits;
+  if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Locate: the `take` smallest SA values of [lo,hi), ascending (locate + std::sort + first min(occs,max) entries).
+struct HitSeed {
+  u32 pos;  // text position of the neighbourhood string
+  u32 qs;
+  u32 len;  // its length
+};
+__global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32* nsel, u64 ngroups, const u64* hit_off,
+                         HitSeed* seeds, unsigned long long* sa_reads) {
+  u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // g = 2*query + strand
+  if (g >= ngroups) return;
+  const Sel* S = sel + grp_off[g];
+  const u32 ns = nsel[g];
+  u64 reads = 0;
+  for (u32 r = 0; r < ns; ++r) {
+    const u32 take = S[r].take;
+    if (!take) continue;
+    const u32 lo = S[r].lo, occs = S[r].hi - S[r].lo;
+    HitSeed* out = seeds + hit_off[g >> 1] + S[r].hbase;
+    if (occs <= 24) {
+      u32 v[24];
+      for (u32 i = 0; i < occs; ++i) {  // insertion sort of a handful of values
+        u32 x = f.sa[lo + i], j = i;
+        while (j > 0 && v[j - 1] > x) {
+          v[j] = v[j - 1];
+          --j;
+        }
+        v[j] = x;
+      }
+      reads += occs;
+      for (u32 i = 0; i < take; ++i) out[i] = HitSeed{v[i], (u32)g, S[r].len};
+    } else {
+      // repeat-rich string: selection by repeated minimum above the previous pick (positions are distinct)
+      u64 prev = 0;
+      bool first = true;
+      for (u32 i = 0; i < take; ++i) {
+        u32 best = 0xFFFFFFFFu;
+        for (u32 j = 0; j < occs; ++j) {
+          u32 x = f.sa[lo + j];
+          if ((first || x > prev) && x < best) best = x;
+        }
+        reads += occs;
+        out[i] = HitSeed{best, (u32)g, S[r].len};
+        prev = best;
+        first = false;
+      }
+    }
+  }
+  if (reads) atomicAdd(sa_reads, (unsigned long long)reads);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Verify: one lane per hit.
+struct VerifyArgs {
+  const HitSeed* seeds;
+  u64 nhits;
+  const u64* cum;  // cum[r] = sum of seqlen[0..r)
+  u32 nseq;
+  dg_hit* hits;
+  char* refalign;
+  char* queryalign;
+  u32 stride;
+};
+
+template <u32 TRACE_WORDS>
+__global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a, unsigned long long* win_bytes) {
+  u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= a.nhits) return;
+  const HitSeed sd = a.seeds[h];
+  const u64 q = sd.qs >> 1;
+  const u32 strand = sd.qs & 1;
+  const u8* qseq = (strand ? b.rv : b.fw) + b.qoff[q];
+  const u32 n = b.qlen[q];  // columns: the query
+  const u64 loc = sd.pos;
+  const u32 mlen = sd.len;
+  // hunter.h:358-362: text position -> (refIndex, chrpos)
+  u32 lo_r = 0, hi_r = a.nseq - 1;
+  while (lo_r < hi_r) {  // largest r with cum[r] <= loc, capped at nseq-1
+    u32 mid = (lo_r + hi_r + 1) >> 1;
+    if (a.cum[mid] <= loc) lo_r = mid;
+    else hi_r = mid - 1;
+  }
+  const u32 ref = lo_r;
+  u32 chrpos = (u32)(loc - a.cum[ref]);
+  // hunter.h:363-378: context, clipped to the text, cut at sequence separators
+  u64 pre = b.indel ? b.qdist[q] : 0, post = pre;
+  if (pre > loc) pre = loc;
+  if (loc + mlen + post > f.n) post = f.n - loc - mlen;
+  u32 pre_eff = 0;
+  for (u32 i = 1; i <= pre; ++i) {
+    if (f.text[loc - i] == '\n') break;
+    pre_eff = i;
+  }
+  u32 post_eff = 0;
+  for (u32 i = 0; i < post; ++i) {
+    if (f.text[loc + mlen + i] == '\n') break;
+    post_eff = i + 1;
+  }
+  const u8* g = f.text + (loc - pre_eff);  // genomicseq
+  const u32 mg = pre_eff + mlen + post_eff;  // rows
+  if (pre_eff < chrpos) chrpos -= pre_eff;   // hunter.h:382 (strict <)
+  char* ra = a.refalign + h * a.stride;
+  char* qa = a.queryalign + h * a.stride;
+  dg_hit out;
+  out.chr = ref;
+  out.query = (u32)q;
+  out.strand = strand ? '-' : '+';
+  out.reserved = 0;
+  atomicAdd(win_bytes, (unsigned long long)(pre + mlen + post));
+  if (!b.indel) {
+    // hunter.h:79-88,404-405: score = -(mismatches), alignment rows are the raw strings
+    int sc = 0;
+    u32 k = mg < n ? mg : n;
+    for (u32 i = 0; i < k; ++i) sc -= (g[i] != ascii_of(qseq[i]));
+    for (u32 i = 0; i < mg; ++i) ra[i] = (char)g[i];
+    for (u32 i = 0; i < n; ++i) qa[i] = (char)ascii_of(qseq[i]);
+    out.score = sc;
+    out.start = chrpos + 1;
+    out.aln_len = (u16)(mg > n ? mg : n);  // both rows have the same length here (mg == n)
+    a.hits[h] = out;
+    return;
+  }
+  // needle.h:59-138 with AlignConfig<false,true> and DnaScore(0,-1,-1,-1) (hunter.h:383-389):
+  // horizontal (gap in the reference row) costs 1 everywhere; vertical (gap in the query row) is free in
+  // column 0 and column n; ties prefer horizontal, then vertical, then diagonal.
+  int s[MAX_QLEN + 1];
+  u64 trace[TRACE_WORDS];  // 2 bits per cell: 1 = horizontal, 2 = vertical
+  const u32 mf = n + 1;
+  for (u32 w = 0; w < TRACE_WORDS; ++w) trace[w] = 0;
+  auto set_tr = [&](u32 cell, u64 v) { trace[cell >> 5] |= v << ((cell & 31) * 2); };
+  s[0] = 0;
+  for (u32 col = 1; col <= n; ++col) {
+    s[col] = -(int)col;
+    set_tr(col, 1);
+  }
+  for (u32 row = 1; row <= mg; ++row) {
+    int diag = s[0];  // cell (row-1, 0) == 0
+    s[0] = 0;
+    set_tr(row * mf, 2);
+    const u8 gc = g[row - 1];
+    for (u32 col = 1; col <= n; ++col) {
+      int up = s[col];
+      int dsc = diag + (gc == ascii_of(qseq[col - 1]) ? 0 : -1);
+      int vsc = up + (col == n ? 0 : -1);
+      int hsc = s[col - 1] - 1;
+      int best = dsc > vsc ? dsc : vsc;
+      best = best > hsc ? best : hsc;
+      s[col] = best;
+      if (best == hsc) set_tr(row * mf + col, 1);
+      else if (best == vsc) set_tr(row * mf + col, 2);
+      diag = up;
+    }
+  }
+  out.score = s[n];
+  // traceback, columns produced last-to-first; written from the end of the row buffers
+  u32 row = mg, col = n, tl = 0;
+  const u32 S = a.stride;
+  while (row > 0 || col > 0) {
+    u32 cell = row * mf + col;
+    u32 tr = (u32)(trace[cell >> 5] >> ((cell & 31) * 2)) & 3;
+    char r0, r1;
+    if (tr == 1) {
+      --col;
+      r0 = '-';
+      r1 = (char)ascii_of(qseq[col]);
+    } else if (tr == 2) {
+      --row;
+      r0 = (char)g[row];
+      r1 = '-';
+    } else {
+      --row;
+      --col;
+      r0 = (char)g[row];
+      r1 = (char)ascii_of(qseq[col]);
+    }
+    ++tl;
+    ra[S - tl] = r0;
+    qa[S - tl] = r1;
+  }
+  // hunter.h:391-401 + _trailGap :69-77: drop leading columns whose query row is a gap (each advances chrpos)
+  // and the trailing run of such columns
+  const u32 base = S - tl;
+  u32 lead = 0;
+  while (lead < tl && qa[base + lead] == '-') ++lead;
+  u32 last = tl - 1;  // _trailGap initialises lastAlignedPos to the last column
+  for (u32 j = 0; j < tl; ++j)
+    if (qa[base + j] != '-') last = j;
+  u32 stop = last + 1;  // exclusive
+  u32 len = 0;
+  for (u32 j = 0; j < stop; ++j) {
+    if (j < lead) continue;
+    char x = ra[base + j], y = qa[base + j];
+    ra[len] = x;
+    qa[len] = y;
+    ++len;
+  }
+  chrpos += lead < stop ? lead : stop;
+  out.start = chrpos + 1;
+  out.aln_len = (u16)len;
+  a.hits[h] = out;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Host orchestration
+// ------------------------------------------------------------------------------------------------------------
+enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR };
+
+static double ev_ms(hipEvent_t a, hipEvent_t b) {
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, a, b);
+  return ms;
+}
+
+// Largest number of distinct strings neighbors() can hold for a query of length m; used to prove that the
+// maxNeighborhood early return (neighbors.h:50) cannot fire.  Returns ~0 when no such proof is available.
+static u64 neighbourhood_bound(u32 m, u32 d, bool indel) {
+  auto binom = [](u64 n, u64 k) {
+    u64 r = 1;
+    for (u64 i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return r;
+  };
+  if (!indel) {
+    u64 t = 0, p = 1;
+    for (u32 i = 0; i <= d && i <= m; ++i) {
+      t += binom(m, i) * p;
+      p *= 3;
+      if (t > (1ULL << 40)) return ~0ULL;
+    }
+    return t;
+  }
+  if (d == 0) return 1;
+  if (d == 1) return 7ULL * m + 5;  // 1 + 3m substitutions + m deletions + (3m+4) insertions
+  if (d == 2) {
+    u64 ss = binom(m, 2) * 9, dd = binom(m, 2), ii = 1 + 3ULL * (m + 2) + 9 * binom(m + 2, 2);
+    u64 sd = 3ULL * m * (m - 1), si = 3ULL * m * (3ULL * m + 4), di = (u64)m * (3ULL * (m - 1) + 4);
+    return ss + dd + ii + sd + si + di + 7ULL * m + 5;
+  }
+  return ~0ULL;
+}
+
+static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
+                     const void* d_qoff, size_t nq, u64 total, u32 maxlen, u32 minlen, int fetch, const u8* h_qbytes_unused,
+                     dg_hunt_result** out) {
+  (void)h_qbytes_unused;
+  if (!p->max_locations) return fail(DG_EINVAL, "max_locations must be positive");
+  if (nseq == 0) return fail(DG_EINVAL, "no reference sequences");
+  const bool indel = !p->hamming;
+  if (maxlen > MAX_QLEN) return fail(DG_ELIMIT, "query of %u nt exceeds the supported maximum of %u", maxlen, MAX_QLEN);
+  u32 dmax_eff = p->distance;
+  if (maxlen >= 1 && dmax_eff >= maxlen) dmax_eff = maxlen - 1;
+  if (dmax_eff > DMAX) return fail(DG_ELIMIT, "distance %u exceeds the supported maximum of %u", p->distance, DMAX);
+  if (maxlen >= 10) {
+    u64 bound = neighbourhood_bound(maxlen, dmax_eff, indel);
+    if (bound >= p->max_neighborhood)
+      return fail(DG_ELIMIT,
+                  "cannot prove that the maxNeighborhood cap (%u) stays silent for %u-mers at distance %u (bound %llu); "
+                  "the reference's capped enumeration is order dependent and is not reproduced by this build",
+                  p->max_neighborhood, maxlen, dmax_eff, (unsigned long long)bound);
+  }
+  (void)minlen;
+  DG_HIP(hipSetDevice(ix->device));
+  hipStream_t st = ix->stream;
+  for (int i = 0; i < 8; ++i)
+    if (!ix->ev[i]) DG_HIP(hipEventCreate(&ix->ev[i]));
+  auto& ws = ix->ws;
+  const u64 ngrp = 2 * (u64)nq;
+  DG_TRY(ws[WS_FW].reserve(total + 8));
+  DG_TRY(ws[WS_RV].reserve(total + 8));
+  DG_TRY(ws[WS_QSEQ].reserve(total + 8));
+  DG_TRY(ws[WS_QMETA].reserve(nq * 16 + 64));
+  DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + ngrp * 4 * 2 + nq * 4 + (nq + 1) * 8 + 256));
+  DG_TRY(ws[WS_MISC].reserve(256));
+  DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
+  Batch b;
+  b.qbytes = (const u8*)d_qbytes;
+  b.qoff = (const u64*)d_qoff;
+  b.nq = nq;
+  b.fw = ws[WS_FW].as<u8>();
+  b.rv = ws[WS_RV].as<u8>();
+  b.qseq = ws[WS_QSEQ].as<u8>();
+  u32* meta = ws[WS_QMETA].as<u32>();
+  b.qlen = meta;
+  b.qdist = meta + nq;
+  b.qflags = meta + 2 * nq;
+  b.qnondna = meta + 3 * nq;
+  b.distance = p->distance;
+  b.indel = indel;
+  b.reverse = !p->forward_only;
+  b.max_locations = p->max_locations;
+  // group bookkeeping carved out of one buffer
+  u8* gp = ws[WS_GRP].as<u8>();
+  u64* grp_off = (u64*)gp;
+  gp += (ngrp + 1) * 8;
+  u64* hit_off = (u64*)gp;
+  gp += (nq + 1) * 8;
+  u32* grp_cnt = (u32*)gp;
+  gp += ngrp * 4;
+  u32* nsel = (u32*)gp;
+  gp += ngrp * 4;
+  u32* qhits = (u32*)gp;
+  unsigned long long* ctr = ws[WS_MISC].as<unsigned long long>();  // [0] leaf_count [1] ext_steps [2] sa_reads [3] win_bytes
+  std::vector<u64> cum(nseq);
+  u64 run = 0;
+  for (u32 r = 0; r < nseq; ++r) {
+    cum[r] = run;
+    run += seqlen[r];
+  }
+  DG_HIP(hipMemcpyAsync(ws[WS_CUM].p, cum.data(), (u64)nseq * 8, hipMemcpyHostToDevice, st));
+  DG_HIP(hipMemsetAsync(ctr, 0, 64, st));
+
+  const u32 TB = 256;
+  DG_HIP(hipEventRecord(ix->ev[0], st));
+  hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b);
+  // ---- search (retry with a larger leaf buffer if the estimate was too small)
+  u64 leaf_cap = std::max<u64>(4096, 8 * (u64)nq);
+  u64 nleaf = 0;
+  for (int attempt = 0;; ++attempt) {
+    DG_TRY(ws[WS_LEAF].reserve(leaf_cap * sizeof(Leaf)));
+    DG_HIP(hipMemsetAsync(ctr, 0, 16, st));
+    DG_HIP(hipEventRecord(ix->ev[1], st));
+    if (indel)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<true>), dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, b,
+                         ws[WS_LEAF].as<Leaf>(), leaf_cap, ctr, grp_cnt, ctr + 1);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<false>), dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, b,
+                         ws[WS_LEAF].as<Leaf>(), leaf_cap, ctr, grp_cnt, ctr + 1);
+    DG_HIP(hipEventRecord(ix->ev[2], st));
+    unsigned long long hc = 0;
+    DG_HIP(hipMemcpyAsync(&hc, ctr, 8, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipStreamSynchronize(st));
+    DG_HIP(hipGetLastError());
+    nleaf = hc;
+    if (nleaf <= leaf_cap) break;
+    if (attempt > 2) return fail(DG_ENOMEM, "leaf buffer overflow persists (%llu leaves)", hc);
+    leaf_cap = nleaf + nleaf / 8 + 1024;
+  }
+  // ---- group by (query,strand): host exclusive scan of the group sizes
+  std::vector<u32> hcnt(ngrp);
+  std::vector<u64> hoff(ngrp + 1);
+  DG_HIP(hipMemcpyAsync(hcnt.data(), grp_cnt, ngrp * 4, hipMemcpyDeviceToHost, st));
+  DG_HIP(hipStreamSynchronize(st));
+  hoff[0] = 0;
+  for (u64 g = 0; g < ngrp; ++g) hoff[g + 1] = hoff[g] + hcnt[g];
+  if (hoff[ngrp] != nleaf) return fail(DG_EHIP, "internal: leaf accounting mismatch (%llu vs %llu)", (unsigned long long)hoff[ngrp], (unsigned long long)nleaf);
+  DG_HIP(hipMemcpyAsync(grp_off, hoff.data(), (ngrp + 1) * 8, hipMemcpyHostToDevice, st));
+  DG_TRY(ws[WS_LEAFG].reserve((nleaf + 1) * sizeof(Leaf)));
+  DG_TRY(ws[WS_SEL].reserve((nleaf + 1) * sizeof(Sel)));
+  DG_TRY(ws[WS_SCR].reserve((nleaf + 1) * 5 + 64));
+  DG_HIP(hipEventRecord(ix->ev[3], st));
+  if (nleaf)
+    hipLaunchKernelGGL(k_group, dim3(ceil_div(nleaf, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), nleaf, grp_off,
+                       ws[WS_LEAFG].as<Leaf>());
+  u32* scr_rank = ws[WS_SCR].as<u32>();
+  u8* scr_keep = (u8*)(scr_rank + nleaf + 1);
+  hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, ws[WS_SEL].as<Sel>(),
+                     nsel, qhits, scr_keep, scr_rank);
+  DG_HIP(hipEventRecord(ix->ev[4], st));
+  std::vector<u32> hq(nq);
+  DG_HIP(hipMemcpyAsync(hq.data(), qhits, nq * 4, hipMemcpyDeviceToHost, st));
+  DG_HIP(hipStreamSynchronize(st));
+  DG_HIP(hipGetLastError());
+  dg_hunt_result* R = new dg_hunt_result;
+  std::memset(R, 0, sizeof *R);
+  R->nq = nq;
+  R->hit_off = new uint64_t[nq + 1];
+  R->hit_off[0] = 0;
+  for (size_t q = 0; q < nq; ++q) R->hit_off[q + 1] = R->hit_off[q] + hq[q];
+  const u64 nhits = R->hit_off[nq];
+  R->nhits = nhits;
+  *out = R;
+  DG_HIP(hipMemcpyAsync(hit_off, R->hit_off, (nq + 1) * 8, hipMemcpyHostToDevice, st));
+  // ---- locate + verify
+  const u32 stride = ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
+  R->aln_stride = stride;
+  DG_TRY(ws[WS_SEEDS].reserve((nhits + 1) * sizeof(HitSeed)));
+  DG_TRY(ws[WS_HITS].reserve((nhits + 1) * sizeof(dg_hit)));
+  DG_TRY(ws[WS_ALN].reserve((nhits + 1) * 2 * (u64)stride));
+  DG_HIP(hipEventRecord(ix->ev[5], st));
+  if (nhits) {
+    hipLaunchKernelGGL(k_locate, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, ws[WS_SEL].as<Sel>(), grp_off, nsel, ngrp,
+                       hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr + 2);
+  }
+  DG_HIP(hipEventRecord(ix->ev[6], st));
+  if (nhits) {
+    VerifyArgs va;
+    va.seeds = ws[WS_SEEDS].as<HitSeed>();
+    va.nhits = nhits;
+    va.cum = ws[WS_CUM].as<u64>();
+    va.nseq = nseq;
+    va.hits = ws[WS_HITS].as<dg_hit>();
+    va.refalign = ws[WS_ALN].as<char>();
+    va.queryalign = ws[WS_ALN].as<char>() + (nhits + 1) * (u64)stride;
+    va.stride = stride;
+    const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
+    const u32 VT = 128;
+    if (cells <= 32 * 32)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<32>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr + 3);
+    else if (cells <= 32 * 160)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr + 3);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr + 3);
+  }
+  DG_HIP(hipEventRecord(ix->ev[7], st));
+  unsigned long long hctr[4] = {0, 0, 0, 0};
+  DG_HIP(hipMemcpyAsync(hctr, ctr, 32, hipMemcpyDeviceToHost, st));
+  // per-query metadata always comes back (small)
+  R->qflags = new uint32_t[nq];
+  R->qdistance = new uint32_t[nq];
+  R->qnondna = new uint32_t[nq];
+  DG_HIP(hipMemcpyAsync(R->qdistance, b.qdist, nq * 4, hipMemcpyDeviceToHost, st));
+  DG_HIP(hipMemcpyAsync(R->qflags, b.qflags, nq * 4, hipMemcpyDeviceToHost, st));
+  DG_HIP(hipMemcpyAsync(R->qnondna, b.qnondna, nq * 4, hipMemcpyDeviceToHost, st));
+  if (fetch) {
+    R->hits = new dg_hit[nhits ? nhits : 1];
+    R->refalign = new char[(nhits ? nhits : 1) * (u64)stride];
+    R->queryalign = new char[(nhits ? nhits : 1) * (u64)stride];
+    R->qseq = new uint8_t[total ? total : 1];
+    R->qoff = new uint64_t[nq + 1];
+    if (nhits) {
+      DG_HIP(hipMemcpyAsync(R->hits, ws[WS_HITS].p, nhits * sizeof(dg_hit), hipMemcpyDeviceToHost, st));
+      DG_HIP(hipMemcpyAsync(R->refalign, ws[WS_ALN].p, nhits * (u64)stride, hipMemcpyDeviceToHost, st));
+      DG_HIP(hipMemcpyAsync(R->queryalign, ws[WS_ALN].as<char>() + (nhits + 1) * (u64)stride, nhits * (u64)stride,
+                            hipMemcpyDeviceToHost, st));
+    }
+    if (total) DG_HIP(hipMemcpyAsync(R->qseq, b.qseq, total, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(R->qoff, d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
+  }
+  DG_HIP(hipStreamSynchronize(st));
+  DG_HIP(hipGetLastError());
+  R->ctr_leaves = nleaf;
+  R->ctr_ext_steps = hctr[1];
+  R->ctr_sa_reads = hctr[2];
+  R->ctr_win_bytes = hctr[3];
+  R->ms_total = ev_ms(ix->ev[0], ix->ev[7]);
+  R->ms_search = ev_ms(ix->ev[1], ix->ev[2]);
+  R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);
+  R->ms_locate = ev_ms(ix->ev[5], ix->ev[6]);
+  R->ms_verify = ev_ms(ix->ev[6], ix->ev[7]);
+  return DG_OK;
+}
+
+}  // namespace dg
+
+using namespace dg;
+
+extern "C" {
+
+void dg_hunt_result_free(dg_hunt_result* r) {
+  if (!r) return;
+  delete[] r->hit_off;
+  delete[] r->hits;
+  delete[] r->refalign;
+  delete[] r->queryalign;
+  delete[] r->qflags;
+  delete[] r->qdistance;
+  delete[] r->qnondna;
+  delete[] r->qseq;
+  delete[] r->qoff;
+  delete r;
+}
+
+int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
+            const uint64_t* qoff, size_t nq, dg_hunt_result** out) {
+  if (!ix || !p || !seqlen || !qoff || !out || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_hunt: null argument");
+  *out = nullptr;
+  if (!nq) return fail(DG_EINVAL, "dg_hunt: empty batch");
+  u64 total = qoff[nq];
+  u32 maxlen = 0, minlen = ~0u;
+  for (size_t i = 0; i < nq; ++i) {
+    if (qoff[i + 1] < qoff[i]) return fail(DG_EINVAL, "dg_hunt: qoff must be non-decreasing");
+    u64 l = qoff[i + 1] - qoff[i];
+    if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "query %zu is too long", i);
+    maxlen = std::max<u32>(maxlen, (u32)l);
+    minlen = std::min<u32>(minlen, (u32)l);
+  }
+  DG_HIP(hipSetDevice(ix->device));
+  DG_TRY(ix->ws[WS_QB].reserve(total + 8));
+  DG_TRY(ix->ws[WS_QOFF].reserve((nq + 1) * 8));
+  if (total) DG_HIP(hipMemcpyAsync(ix->ws[WS_QB].p, qbytes, total, hipMemcpyHostToDevice, ix->stream));
+  DG_HIP(hipMemcpyAsync(ix->ws[WS_QOFF].p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+  int rc = run_batch(ix, p, seqlen, nseq, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, minlen, 1, qbytes, out);
+  if (rc != DG_OK && *out) {
+    dg_hunt_result_free(*out);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
+                   const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out) {
+  if (!ix || !p || !seqlen || !d_qbytes || !d_qoff || !out) return fail(DG_EINVAL, "dg_hunt_device: null argument");
+  *out = nullptr;
+  if (!nq) return fail(DG_EINVAL, "dg_hunt_device: empty batch");
+  DG_HIP(hipSetDevice(ix->device));
+  // query lengths are needed on the host only to size buffers and to check the supported envelope
+  std::vector<u64> hoff(nq + 1);
+  DG_HIP(hipMemcpyAsync(hoff.data(), d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+  DG_HIP(hipStreamSynchronize(ix->stream));
+  if (hoff[nq] != total_qbytes) return fail(DG_EINVAL, "dg_hunt_device: total_qbytes does not match qoff[nq]");
+  u32 maxlen = 0, minlen = ~0u;
+  for (size_t i = 0; i < nq; ++i) {
+    if (hoff[i + 1] < hoff[i]) return fail(DG_EINVAL, "dg_hunt_device: qoff must be non-decreasing");
+    u64 l = hoff[i + 1] - hoff[i];
+    if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "query %zu is too long", i);
+    maxlen = std::max<u32>(maxlen, (u32)l);
+    minlen = std::min<u32>(minlen, (u32)l);
+  }
+  int rc = run_batch(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, maxlen, minlen, fetch, nullptr, out);
+  if (rc != DG_OK && *out) {
+    dg_hunt_result_free(*out);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,360 @@
+// dg_index_open / dg_index_close / dg_index_stats: load the sdsl csa_wt<> file unchanged into HBM and derive the
+// search layouts on the device.  Replaces load_from_checked_file (reference src/hunter.h:253-260, src/silica.h:340-347).
+#include <chrono>
+
+#include "devfm.hpp"
+#include "index_internal.hpp"
+#include "sdsl_file.hpp"
+
+namespace dg {
+
+std::string& last_error() {
+  static thread_local std::string e;
+  return e;
+}
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Derivation kernels (load time).  All are one-thread-one-chain; no inter-thread communication.
+// ------------------------------------------------------------------------------------------------------------
+
+// Thread h decodes BWT[64h, 64h+64) through the wavelet tree into three plane words and per-symbol counts.
+__global__ void k_decode_bwt(FmView f, OccBlock* occ, u32* half_cnt, u64 nhalf) {
+  u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= nhalf) return;
+  u64 p0 = 0, p1 = 0, p2 = 0;
+  u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  u64 base = h << 6;
+  for (u32 j = 0; j < 64; ++j) {
+    u64 i = base + j;
+    if (i >= f.n) break;
+    u32 sym;
+    (void)wt_inverse_select(f, i, sym);
+    u32 code = code_of_byte(sym);
+    p0 |= (u64)(code & 1) << j;
+    p1 |= (u64)((code >> 1) & 1) << j;
+    p2 |= (u64)(code >> 2) << j;
+    c0 += code == 0;
+    c1 += code == 1;
+    c2 += code == 2;
+    c3 += code == 3;
+  }
+  OccBlock* b = occ + (h >> 1);
+  u32 w = (u32)(h & 1);
+  b->pl[0][w] = p0;
+  b->pl[1][w] = p1;
+  b->pl[2][w] = p2;
+  half_cnt[h] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);  // each <= 64
+}
+
+// Thread t sums HALF_PER_CHUNK half-block counts -> chunk totals (host scans the chunk totals).
+static constexpr u32 HALF_PER_CHUNK = 64;
+__global__ void k_chunk_totals(const u32* half_cnt, u64 nhalf, u32* chunk_tot /*[nchunk][4]*/, u64 nchunk) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunk) return;
+  u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  u64 b = t * HALF_PER_CHUNK, e = b + HALF_PER_CHUNK < nhalf ? b + HALF_PER_CHUNK : nhalf;
+  for (u64 h = b; h < e; ++h) {
+    u32 v = half_cnt[h];
+    s0 += v & 255;
+    s1 += (v >> 8) & 255;
+    s2 += (v >> 16) & 255;
+    s3 += v >> 24;
+  }
+  chunk_tot[t * 4 + 0] = s0;
+  chunk_tot[t * 4 + 1] = s1;
+  chunk_tot[t * 4 + 2] = s2;
+  chunk_tot[t * 4 + 3] = s3;
+}
+// chunk_base = exclusive scan of chunk_tot; writes the running counts into every block header
+__global__ void k_block_counts(const u32* half_cnt, u64 nhalf, const u32* chunk_base, u64 nchunk, OccBlock* occ,
+                               u64 nblk) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunk) return;
+  u32 s0 = chunk_base[t * 4], s1 = chunk_base[t * 4 + 1], s2 = chunk_base[t * 4 + 2], s3 = chunk_base[t * 4 + 3];
+  u64 b = t * HALF_PER_CHUNK, e = b + HALF_PER_CHUNK;
+  for (u64 h = b; h < e; ++h) {
+    if (!(h & 1) && (h >> 1) < nblk) {
+      OccBlock* ob = occ + (h >> 1);
+      ob->cnt[0] = s0;
+      ob->cnt[1] = s1;
+      ob->cnt[2] = s2;
+      ob->cnt[3] = s3;
+    }
+    if (h < nhalf) {
+      u32 v = half_cnt[h];
+      s0 += v & 255;
+      s1 += (v >> 8) & 255;
+      s2 += (v >> 16) & 255;
+      s3 += v >> 24;
+    }
+  }
+}
+
+// Text from ISA samples: sample k is ISA[64k]; walking LF from it yields T[64k-1], T[64k-2], ...
+// Thread 0 starts at ISA[0] and therefore produces the tail T[n-1] .. T[64*(ns-1)].
+__global__ void k_derive_text(FmView f, u8* text) {
+  u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= f.n_isa_samp) return;
+  u64 i = packed_get(f.isa_samp, f.samp_width, k);
+  u64 hi, lo;  // writes text[lo, hi)
+  if (k == 0) {
+    hi = f.n;
+    lo = (f.n_isa_samp - 1) * 64;
+  } else {
+    hi = k * 64;
+    lo = hi - 64;
+  }
+  for (u64 p = hi; p > lo;) {
+    u32 sym;
+    i = lf_step(f, i, sym);
+    text[--p] = (u8)sym;
+  }
+}
+
+// Full SA from SA samples: SA[LF(i)] = SA[i] - 1.  Thread j owns the LF chain that leaves index 32j and stops at
+// the next index that is itself sampled; LF is a permutation, so every unsampled index is written exactly once.
+__global__ void k_derive_sa(FmView f, u32* sa) {
+  u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= f.n_sa_samp) return;
+  u64 v = packed_get(f.sa_samp, f.samp_width, j);
+  u64 i = j * 32;
+  sa[i] = (u32)v;
+  for (;;) {
+    u32 sym;
+    i = lf_step(f, i, sym);
+    if ((i & 31) == 0) break;
+    v = v ? v - 1 : f.n - 1;
+    sa[i] = (u32)v;
+  }
+}
+
+// Self-check on a pseudo-random sample of SA indices: BWT[i] == T[SA[i]-1], and suffix SA[i] <= suffix SA[i+1]
+// on their first 48 bytes.  Catches a mis-parsed file before any query is answered.
+__global__ void k_selfcheck(FmView f, u64 nsample, u32* bad) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nsample) return;
+  u64 x = (t + 1) * 0x9E3779B97F4A7C15ULL;
+  x ^= x >> 29;
+  x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 32;
+  u64 i = x % f.n;
+  u32 sym;
+  (void)lf_step(f, i, sym);
+  u64 p = f.sa[i];
+  u64 prev = p ? p - 1 : f.n - 1;
+  bool ok = f.text[prev] == (u8)sym && p < f.n;
+  if (i + 1 < f.n) {
+    u64 q = f.sa[i + 1];
+    for (u32 k = 0; k < 48; ++k) {
+      u64 a = p + k, b = q + k;
+      if (a >= f.n || b >= f.n) break;
+      u8 ca = f.text[a], cb = f.text[b];
+      if (ca != cb) {
+        ok = ok && ca < cb;
+        break;
+      }
+    }
+  }
+  if (!ok) atomicAdd(bad, 1u);
+}
+
+static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
+  FmView& f = ix->view;
+  const u64 n = f.n;
+  const u64 nblk = (n >> 7) + 1, nhalf = nblk * 2;
+  const u64 nchunk = (nhalf + HALF_PER_CHUNK - 1) / HALF_PER_CHUNK;
+  OccBlock* occ = nullptr;
+  u32 *half_cnt = nullptr, *chunk = nullptr, *sa = nullptr, *bad = nullptr;
+  u8* text = nullptr;
+  DG_HIP(hipMalloc((void**)&occ, nblk * sizeof(OccBlock)));
+  ix->owned.push_back(occ);
+  DG_HIP(hipMemsetAsync(occ, 0, nblk * sizeof(OccBlock), ix->stream));
+  DG_HIP(hipMalloc((void**)&half_cnt, nhalf * 4));
+  DG_HIP(hipMalloc((void**)&chunk, nchunk * 16));
+  const u32 TB = 256;
+  hipLaunchKernelGGL(k_decode_bwt, dim3(ceil_div(nhalf, TB)), dim3(TB), 0, ix->stream, f, occ, half_cnt, nhalf);
+  hipLaunchKernelGGL(k_chunk_totals, dim3(ceil_div(nchunk, TB)), dim3(TB), 0, ix->stream, half_cnt, nhalf, chunk, nchunk);
+  std::vector<u32> tot(nchunk * 4);
+  DG_HIP(hipMemcpyAsync(tot.data(), chunk, nchunk * 16, hipMemcpyDeviceToHost, ix->stream));
+  DG_HIP(hipStreamSynchronize(ix->stream));
+  u64 run[4] = {0, 0, 0, 0};
+  for (u64 t = 0; t < nchunk; ++t)
+    for (int s = 0; s < 4; ++s) {
+      u32 v = tot[t * 4 + s];
+      tot[t * 4 + s] = (u32)run[s];
+      run[s] += v;
+    }
+  // C[] of the file must agree with what the decoded BWT holds
+  static const u8 acgt[4] = {'A', 'C', 'G', 'T'};
+  for (int s = 0; s < 4; ++s) {
+    u32 cc = c.char2comp[acgt[s]];
+    u64 expect = cc ? c.C[cc + 1] - c.C[cc] : 0;  // comp 0 is the sentinel: the byte is absent
+    if (run[s] != expect)
+      return fail(DG_EFORMAT, "index self-check: decoded BWT holds %llu '%c' but C[] says %llu", (unsigned long long)run[s],
+                  acgt[s], (unsigned long long)expect);
+    f.C4[s] = cc ? (u32)c.C[cc] : 0u;
+  }
+  DG_HIP(hipMemcpyAsync(chunk, tot.data(), nchunk * 16, hipMemcpyHostToDevice, ix->stream));
+  hipLaunchKernelGGL(k_block_counts, dim3(ceil_div(nchunk, TB)), dim3(TB), 0, ix->stream, half_cnt, nhalf, chunk, nchunk, occ,
+                     nblk);
+  f.occ = occ;
+  DG_HIP(hipStreamSynchronize(ix->stream));
+  DG_HIP(hipFree(half_cnt));
+  DG_HIP(hipFree(chunk));
+
+  DG_HIP(hipMalloc((void**)&text, n + 64));
+  ix->owned.push_back(text);
+  DG_HIP(hipMalloc((void**)&sa, n * 4 + 64));
+  ix->owned.push_back(sa);
+  hipLaunchKernelGGL(k_derive_text, dim3(ceil_div(f.n_isa_samp, TB)), dim3(TB), 0, ix->stream, f, text);
+  hipLaunchKernelGGL(k_derive_sa, dim3(ceil_div(f.n_sa_samp, TB)), dim3(TB), 0, ix->stream, f, sa);
+  f.text = text;
+  f.sa = sa;
+  DG_HIP(hipStreamSynchronize(ix->stream));
+  DG_HIP(hipGetLastError());
+  if (!(flags & DG_OPEN_NO_SELFCHECK)) {
+    DG_HIP(hipMalloc((void**)&bad, 4));
+    DG_HIP(hipMemsetAsync(bad, 0, 4, ix->stream));
+    u64 ns = n < (1u << 20) ? n : (1u << 20);
+    hipLaunchKernelGGL(k_selfcheck, dim3(ceil_div(ns, TB)), dim3(TB), 0, ix->stream, f, ns, bad);
+    u32 hbad = 0;
+    DG_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ix->stream));
+    DG_HIP(hipStreamSynchronize(ix->stream));
+    DG_HIP(hipFree(bad));
+    if (hbad) return fail(DG_EFORMAT, "index self-check failed on %u of %llu sampled suffixes", hbad, (unsigned long long)ns);
+  }
+  ix->hbm_bytes += nblk * sizeof(OccBlock) + n + 64 + n * 4 + 64;
+  return DG_OK;
+}
+
+template <class T>
+static int upload(dg_index* ix, const void* src, size_t bytes, const T** dst) {
+  void* d = nullptr;
+  DG_HIP(hipMalloc(&d, bytes + 64));  // +64: packed_get may touch one word past the last element
+  ix->owned.push_back(d);
+  DG_HIP(hipMemsetAsync((char*)d + bytes, 0, 64, ix->stream));
+  DG_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ix->stream));
+  ix->hbm_bytes += bytes + 64;
+  *dst = (const T*)d;
+  return DG_OK;
+}
+
+static int open_impl(const char* path, int device, u32 flags, dg_index* ix) {
+  auto t0 = std::chrono::steady_clock::now();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DG_ENODEV, "no HIP device available");
+  if (device < 0 || device >= ndev) return fail(DG_EINVAL, "device %d out of range (have %d)", device, ndev);
+  DG_HIP(hipSetDevice(device));
+  ix->device = device;
+  DG_HIP(hipStreamCreate(&ix->stream));
+  SdslCsa c;
+  DG_TRY(sdsl_open(path, c));
+  if (c.n > 0xFFFFFFFFULL) return fail(DG_ELIMIT, "index has %llu symbols; this build keeps 32-bit suffix-array entries", (unsigned long long)c.n);
+  ix->file_bytes = c.len;
+  FmView& f = ix->view;
+  std::memset(&f, 0, sizeof f);
+  f.n = c.n;
+  DG_TRY(upload(ix, c.bv.w, c.bv.nwords * 8, &f.bv));
+  DG_TRY(upload(ix, c.rank.w, c.rank.nwords * 8, &f.rk));
+  DG_TRY(upload(ix, c.sa_samples.w, c.sa_samples.nwords * 8, &f.sa_samp));
+  DG_TRY(upload(ix, c.isa_samples.w, c.isa_samples.nwords * 8, &f.isa_samp));
+  f.samp_width = c.sa_samples.width;
+  f.n_sa_samp = c.sa_samples.bits / c.sa_samples.width;
+  f.n_isa_samp = c.isa_samples.bits / c.isa_samples.width;
+  WtTables* t = new WtTables;
+  std::memset(t, 0, sizeof *t);
+  for (size_t v = 0; v < c.nodes.size(); ++v) {
+    t->node_pos[v] = c.nodes[v].bv_pos;
+    t->node_rank[v] = c.nodes[v].bv_pos_rank;
+    t->child[v][0] = c.nodes[v].child[0];
+    t->child[v][1] = c.nodes[v].child[1];
+  }
+  std::memcpy(t->path, c.path, sizeof t->path);
+  std::memcpy(t->c_to_leaf, c.c_to_leaf, sizeof t->c_to_leaf);
+  for (size_t i = 0; i < c.C.size(); ++i) t->C[i] = c.C[i];
+  std::memcpy(t->char2comp, c.char2comp, 256);
+  for (size_t i = 0; i < c.comp2char.size(); ++i) t->comp2char[i] = c.comp2char[i];
+  t->sigma = c.sigma;
+  int rc = upload(ix, t, sizeof *t, &f.wt);
+  for (int b = 0; b < 256; ++b) ix->code_len[b] = (c.c_to_leaf[b] == 0xFFFF) ? 0u : (u32)(c.path[b] >> 56);
+  ix->sigma = c.sigma;
+  if (rc != DG_OK) {
+    delete t;
+    return rc;
+  }
+  DG_HIP(hipStreamSynchronize(ix->stream));
+  delete t;
+  static const u8 soc[8] = {'A', 'C', 'G', 'T', 'N', '\n', 0, 0};
+  std::memcpy(f.sym_of_code, soc, 8);
+  auto t1 = std::chrono::steady_clock::now();
+  DG_TRY(derive_layouts(ix, c, flags));
+  auto t2 = std::chrono::steady_clock::now();
+  ix->derive_seconds = std::chrono::duration<double>(t2 - t1).count();
+  ix->load_seconds = std::chrono::duration<double>(t2 - t0).count();
+  return DG_OK;
+}
+
+}  // namespace dg
+
+using namespace dg;
+
+dg_index::~dg_index() {
+  for (void* p : owned) (void)hipFree(p);
+  for (auto& w : ws) w.release();
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+extern "C" {
+
+const char* dg_last_error(void) { return dg::last_error().c_str(); }
+int dg_abi_version(void) { return DG_ABI_VERSION; }
+int dg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int dg_index_open(const char* fm9_path, int device, uint32_t flags, dg_index** out) {
+  if (!fm9_path || !out) return fail(DG_EINVAL, "dg_index_open: null argument");
+  *out = nullptr;
+  dg_index* ix = new dg_index;
+  int rc = open_impl(fm9_path, device, flags, ix);
+  if (rc != DG_OK) {
+    delete ix;
+    return rc;
+  }
+  *out = ix;
+  return DG_OK;
+}
+
+void dg_index_close(dg_index* ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  delete ix;
+}
+
+int dg_index_stats(const dg_index* ix, dg_index_stats_t* out) {
+  if (!ix || !out) return fail(DG_EINVAL, "dg_index_stats: null argument");
+  std::memset(out, 0, sizeof *out);
+  out->n = ix->view.n;
+  out->sigma = ix->sigma;
+  std::memcpy(out->code_len, ix->code_len, sizeof out->code_len);
+  out->file_bytes = ix->file_bytes;
+  out->hbm_bytes = ix->hbm_bytes;
+  out->load_seconds = ix->load_seconds;
+  out->derive_seconds = ix->derive_seconds;
+  return DG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,20 @@
+// The object behind the opaque dg_index handle.
+#pragma once
+#include "common.hpp"
+#include "devfm.hpp"
+
+struct dg_index {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  dg::FmView view;
+  std::vector<void*> owned;  // device allocations that live as long as the index
+  uint32_t sigma = 0;
+  uint32_t code_len[256] = {0};
+  uint64_t file_bytes = 0, hbm_bytes = 0;
+  double load_seconds = 0, derive_seconds = 0;
+  // grow-only batch workspaces (see hunt.hip / seam.hip for the slot meaning)
+  static constexpr int NWS = 16;
+  dg::DevBuf ws[NWS];
+  hipEvent_t ev[8] = {nullptr};
+  ~dg_index();
+};

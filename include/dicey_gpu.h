@@ -1,0 +1,158 @@
+/* dicey_gpu.h — C ABI of libdiceygpu.so: the MI355X (gfx950) in-silico-PCR search path.
+ *
+ * gear-genomics/dicey has no plugin/FFI interface.  The seam this library replaces is the set of
+ * calls `dicey hunt` makes into sdsl-lite and into its own helper headers:
+ *
+ *   reference call (file:line)                              entry point here
+ *   ------------------------------------------------------  ---------------------------------
+ *   load_from_checked_file(csa_wt<>&, path)  hunter.h:253-256, silica.h:340-343   dg_index_open
+ *   fm_index.size()                          hunter.h:368-369                     dg_index_stats
+ *   sdsl::count(fm_index, b, e)              hunter.h:353, silica.h:470           dg_count
+ *   sdsl::locate(...) + std::sort            hunter.h:355-356, silica.h:472-473   dg_locate
+ *   sdsl::extract(fm_index, lo, hi)          hunter.h:371, silica.h:490           dg_extract
+ *   neighbors() -> count -> locate -> extract -> needle()/needleScore -> DnaHit push
+ *                                            hunter.h:291-437 (whole per-query loop)  dg_hunt
+ *   sdsl::construct + store_to_checked_file  index.h:121-122                      dg_index_build
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative DG_E* code and
+ * leaves a message retrievable with dg_last_error() (thread-local); objects returned through `out`
+ * parameters are released with the paired *_free / *_close; no exceptions cross the boundary; one
+ * HIP stream per dg_index; a dg_index may be used by one thread at a time (distinct handles are
+ * independent — one handle per GPU for multi-GPU).  There is NO CPU fallback: without a HIP device
+ * every compute entry point fails with DG_ENODEV.
+ */
+#ifndef DICEY_GPU_H
+#define DICEY_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_ABI_VERSION 1
+
+enum {
+  DG_OK = 0,
+  DG_EINVAL = -1,   /* bad argument */
+  DG_EIO = -2,      /* file cannot be read / written */
+  DG_EFORMAT = -3,  /* not an sdsl csa_wt<> file (byte accounting failed) */
+  DG_ENODEV = -4,   /* no usable HIP device */
+  DG_EHIP = -5,     /* HIP runtime error */
+  DG_ENOMEM = -6,
+  DG_ELIMIT = -7    /* input outside the supported envelope (see DESIGN.md "limits") */
+};
+
+typedef struct dg_index dg_index;
+
+/* flags for dg_index_open */
+#define DG_OPEN_DEFAULT 0u
+#define DG_OPEN_NO_SELFCHECK 1u /* skip the load-time self validation (C[] vs Occ totals, SA permutation spot checks) */
+
+/* Parses the file written by `dicey index` (sdsl store_to_checked_file of csa_wt<>) unchanged, uploads it to
+ * HBM on `device`, and derives the search layouts there (Occ blocks, full suffix array, text copy). */
+int dg_index_open(const char* fm9_path, int device, uint32_t flags, dg_index** out);
+void dg_index_close(dg_index* ix);
+
+typedef struct {
+  uint64_t n;              /* fm_index.size(): text length + 1 (sentinel) */
+  uint32_t sigma;          /* alphabet size incl. sentinel */
+  uint32_t code_len[256];  /* Huffman code length of each byte in the loaded wavelet tree (0 = absent) */
+  uint64_t file_bytes;     /* size of the .fm9 */
+  uint64_t hbm_bytes;      /* device memory held by this index (raw sections + derived layouts) */
+  double load_seconds;     /* file read + upload + derivation */
+  double derive_seconds;   /* derivation kernels only */
+} dg_index_stats_t;
+int dg_index_stats(const dg_index* ix, dg_index_stats_t* out);
+
+/* ---- sdsl seam, batched.  Patterns are raw bytes, concatenated; pattern i = pat[off[i] .. off[i+1]). ---- */
+int dg_count(dg_index* ix, const uint8_t* pat, const uint64_t* off, size_t npat, uint64_t* counts /* [npat] */);
+
+typedef struct {
+  size_t npat;
+  uint64_t* off; /* [npat+1] */
+  uint64_t* pos; /* positions of pattern i, ascending: pos[off[i] .. off[i+1]) */
+} dg_locations;
+int dg_locate(dg_index* ix, const uint8_t* pat, const uint64_t* off, size_t npat, dg_locations** out);
+void dg_locations_free(dg_locations* l);
+
+/* text[lo[i] .. hi[i]] inclusive (hi < n), written to out + out_off[i] */
+int dg_extract(dg_index* ix, const uint64_t* lo, const uint64_t* hi, size_t nrange, uint8_t* out, const uint64_t* out_off);
+
+/* ---- hunt ---- */
+typedef struct {
+  uint32_t distance;         /* -d  (hunter.h:188, default 1) */
+  int32_t hamming;           /* -n  (hunter.h:189): substitutions only, no context, no alignment */
+  int32_t forward_only;      /* -f  (hunter.h:190) */
+  uint64_t max_locations;    /* -m  (hunter.h:186, default 1000) */
+  uint32_t max_neighborhood; /* -x  (hunter.h:187, default 10000) */
+} dg_hunt_params;
+
+/* per-query flag bits */
+#define DG_Q_TOO_SHORT 1u     /* < 10 nt: "Error: Input sequence is shorter than 10 nucleotides!" (hunter.h:299-303) */
+#define DG_Q_DIST_ADJUSTED 2u /* hunter.h:312-315 */
+#define DG_Q_MAX_MATCHES 4u   /* hits >= max_locations (hunter.h:434-437) */
+#define DG_Q_NBHD_EXCEEDED 8u /* hunter.h:342-345; never set inside the supported envelope */
+
+typedef struct {
+  int32_t score;     /* DnaHit::score (0, -1, ...) */
+  uint32_t chr;      /* refIndex */
+  uint32_t start;    /* 1-based (chrpos+1, hunter.h:402) */
+  uint32_t query;    /* index into the batch */
+  uint16_t aln_len;  /* columns in refalign/queryalign */
+  uint8_t strand;    /* '+' or '-' */
+  uint8_t reserved;
+} dg_hit;
+
+typedef struct {
+  size_t nq;
+  uint64_t nhits;
+  uint64_t* hit_off;      /* [nq+1]: hits of query i = hits[hit_off[i] .. hit_off[i+1]) in REFERENCE PUSH ORDER (pre-sort) */
+  dg_hit* hits;           /* [nhits] */
+  uint32_t aln_stride;    /* bytes reserved per alignment row */
+  char* refalign;         /* row of hit h: refalign + h*aln_stride, aln_len bytes */
+  char* queryalign;       /* likewise */
+  uint32_t* qflags;       /* [nq] DG_Q_* */
+  uint32_t* qdistance;    /* [nq] effective (clamped) distance */
+  uint32_t* qnondna;      /* [nq] number of characters replaced by 'N' (one warning each, util.h:214) */
+  uint8_t* qseq;          /* normalised (upper-cased, non-ACGT -> N) queries, concatenated like the input */
+  uint64_t* qoff;         /* [nq+1] */
+  /* measurement: exact op counters of the executed device algorithm (DESIGN.md "algorithmic bytes") */
+  uint64_t ctr_ext_steps; /* interval extensions (2 Occ-block reads each) */
+  uint64_t ctr_leaves;    /* occurring neighbourhood strings emitted by the search kernel */
+  uint64_t ctr_sa_reads;  /* suffix-array entries read by locate */
+  uint64_t ctr_win_bytes; /* text window bytes read */
+  double ms_total;        /* device time of the whole batch (HIP events on the index stream) */
+  double ms_search;       /* of which: neighbourhood/backward-search kernel */
+  double ms_select;       /* minimal-set + ordering kernel */
+  double ms_locate;
+  double ms_verify;       /* window fetch + Needleman-Wunsch */
+} dg_hunt_result;
+
+/* Host-buffer entry point: queries are raw bytes as read from the FASTA/argv (any case), concatenated.
+ * seqlen[i] = faidx length of sequence i + 1 (util.h:201), nseq sequences. */
+int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
+            const uint64_t* qoff, size_t nq, dg_hunt_result** out);
+void dg_hunt_result_free(dg_hunt_result* r);
+
+/* Device-resident entry point used by bench.py: d_qbytes / d_qoff are HIP device pointers on the index's device.
+ * The result stays in HBM; only the counters/timings and nhits are copied back.  `fetch` != 0 additionally
+ * copies hits to host like dg_hunt. */
+int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
+                   const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out);
+
+/* ---- index construction on the GPU (what `dicey index` does with sdsl::construct, index.h:97-123) ---- */
+/* text = SEQ1 '\n' SEQ2 '\n' ... SEQk '\n' (upper-cased), no NUL inside.  Writes sdsl csa_wt<> layout. */
+int dg_index_build(const uint8_t* text, uint64_t len, int device, const char* out_fm9_path);
+/* same, text already in HBM (bench: synthetic genome generated on device) */
+int dg_index_build_device(const void* d_text, uint64_t len, int device, const char* out_fm9_path);
+
+const char* dg_last_error(void);
+int dg_abi_version(void);
+int dg_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

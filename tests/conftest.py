@@ -1,0 +1,86 @@
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def make_genome(seed, nchr, length, nrate=0.002, repeats=True, iupac=False):
+    """Small synthetic multi-chromosome genome with N runs, copied segments and homopolymers."""
+    rng = random.Random(seed)
+    seqs = []
+    for _ in range(nchr):
+        s = []
+        while len(s) < length:
+            r = rng.random()
+            if r < nrate:
+                s.extend("N" * rng.randint(1, 150))
+            elif repeats and r < nrate + 0.001 and len(s) > 200:
+                a = rng.randrange(len(s) - 100)
+                s.extend(s[a:a + rng.randint(20, 100)])
+            elif repeats and r < nrate + 0.0015:
+                s.extend(rng.choice("ACGT") * rng.randint(5, 40))
+            elif iupac and r < nrate + 0.002:
+                s.append(rng.choice("RYKMSW"))
+            else:
+                s.append(rng.choice("ACGT"))
+        seqs.append("".join(s[:length]))
+    return seqs
+
+
+def genome_text(seqs):
+    """The text `dicey index` feeds to sdsl::construct (src/index.h:105-113)."""
+    return ("\n".join(seqs) + "\n").encode()
+
+
+def revcomp(s):
+    return s.upper().translate(str.maketrans("ACGTN", "TGCAN"))[::-1]
+
+
+def make_queries(seed, text, n, lens=(20,), p_genome=0.8):
+    """SURVEY §8(d) C2 recipe: mostly genome-sampled (half of them with one random edit), some random."""
+    rng = random.Random(seed)
+    t = text.decode()
+    out = []
+    while len(out) < n:
+        m = rng.choice(lens)
+        if rng.random() < p_genome:
+            p = rng.randrange(len(t) - m)
+            q = t[p:p + m]
+            if "\n" in q:
+                continue
+            if rng.random() < 0.5:
+                k = rng.randrange(len(q))
+                r = rng.random()
+                if r < 1 / 3:
+                    q = q[:k] + rng.choice("ACGT") + q[k + 1:]
+                elif r < 2 / 3:
+                    q = q[:k] + q[k + 1:]
+                else:
+                    q = q[:k] + rng.choice("ACGT") + q[k:]
+            if rng.random() < 0.3:
+                q = revcomp(q)
+        else:
+            q = "".join(rng.choice("ACGT") for _ in range(m))
+        out.append(q)
+    return out
+
+
+@pytest.fixture(scope="session")
+def small_genome(tmp_path_factory):
+    import oracle_lib as O
+    seqs = make_genome(101, 3, 30000, iupac=True)
+    text = genome_text(seqs)
+    path = str(tmp_path_factory.mktemp("fm") / "small.fm9")
+    O.build_fm9(text, path)
+    return {"seqs": seqs, "text": text, "fm9": path, "seqlen": [len(s) + 1 for s in seqs],
+            "names": ["chr%d" % (i + 1) for i in range(len(seqs))]}

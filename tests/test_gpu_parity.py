@@ -1,0 +1,135 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of libdiceygpu.so and is
+compared bit for bit with the oracle on the same seeded inputs."""
+import random
+import zlib
+
+import pytest
+
+import oracle_lib as O
+from conftest import genome_text, make_genome, make_queries
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_small(small_genome):
+    import dicey_amd
+    ix = dicey_amd.FmIndex(small_genome["fm9"], device=0)
+    yield ix
+    ix.close()
+
+
+def test_native_library_is_the_loaded_one():
+    from dicey_amd import _capi
+    L = _capi.load()
+    assert L.dg_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libdiceygpu.so" in maps and "hostemu" not in maps
+
+
+def test_index_stats(gpu_small, small_genome):
+    st = gpu_small.stats()
+    assert st["n"] == len(small_genome["text"]) + 1
+    assert st["hbm_bytes"] > st["n"] * 5
+
+
+def test_count_locate_extract_match_bruteforce(gpu_small, small_genome):
+    text = small_genome["text"]
+    rng = random.Random(17)
+    pats = []
+    for _ in range(3000):
+        if rng.random() < 0.7:
+            p = rng.randrange(len(text) - 14)
+            pats.append(text[p:p + rng.randint(1, 14)])
+        else:
+            pats.append("".join(rng.choice("ACGTNRY") for _ in range(rng.randint(1, 8))).encode())
+    pats += [b"\n", b"N" * 30, b"A", text[:40], text[-40:]]
+    want = [O.bf_locate(text, p) for p in pats]
+    assert gpu_small.count(pats) == [len(w) for w in want]
+    assert gpu_small.locate(pats) == want
+    full = text + b"\0"
+    rs = []
+    for _ in range(500):
+        b = rng.randrange(len(text))
+        rs.append((b, min(len(text), b + rng.randint(0, 60))))
+    rs += [(0, 0), (len(text), len(text)), (0, len(text))]
+    assert gpu_small.extract(rs) == [full[a:b + 1] for a, b in rs]
+
+
+def _compare(ix, orc, g, qs, **kw):
+    got = ix.hunt(qs, g["seqlen"], **kw)
+    _, hits = orc.hunt(g["seqlen"], g["names"], qs, want_hits=True, **kw)
+    per = {}
+    for h in hits:
+        per.setdefault(h[0], []).append(h[1:])
+    for qi, qr in enumerate(got.queries):
+        a = [(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in qr.hits]
+        assert a == per.get(qi, []), (qi, qs[qi], kw)
+    return got
+
+
+@pytest.mark.parametrize("kw,nq,lens", [
+    (dict(distance=1), 1500, (20,)),
+    (dict(distance=0), 300, (18, 20)),
+    (dict(distance=1, hamming=True), 500, (20, 15)),
+    (dict(distance=2, hamming=True), 200, (20,)),
+    (dict(distance=1, forward_only=True), 300, (12, 25, 31)),
+    (dict(distance=1, max_locations=3), 400, (10, 11, 12)),
+])
+def test_hunt_hits_equal_oracle_push_order(gpu_small, small_genome, kw, nq, lens):
+    orc = O.Index(small_genome["fm9"])
+    qs = make_queries(zlib.crc32(str(sorted(kw.items())).encode()) % 1000, small_genome["text"], nq, lens)
+    _compare(gpu_small, orc, small_genome, qs, **kw)
+
+
+def test_hunt_edge_cases(gpu_small, small_genome):
+    g = small_genome
+    orc = O.Index(g["fm9"])
+    s = g["seqs"]
+    qs = [s[0][:20], s[0][-20:], s[1][:19], s[2][-21:], s[1][1:21], s[2][:10], s[0][-10:],  # chromosome starts / ends
+          "acgtnacgtacgtacgtacg", "ACGU" * 5, "A" * 20, "N" * 20, "ACGTAC", "", "ACGTACGTA",  # non-DNA, too short, empty
+          s[0][5000:5060], s[1][300:400]]  # long queries
+    got = _compare(gpu_small, orc, g, qs, distance=1)
+    from dicey_amd import DG_Q_TOO_SHORT
+    assert [bool(q.flags & DG_Q_TOO_SHORT) for q in got.queries[11:14]] == [True, True, True]
+    assert got.queries[7].sequence == "ACGTNACGTACGTACGTACG" and got.queries[7].nondna == 1
+    assert got.queries[8].nondna == 5
+    _compare(gpu_small, orc, g, qs, distance=1, hamming=True)
+
+
+def test_unsupported_envelope_fails_loudly(gpu_small, small_genome):
+    import dicey_amd
+    with pytest.raises(dicey_amd.DgError):
+        gpu_small.hunt(["ACGT" * 5], small_genome["seqlen"], distance=2)  # cap cannot be proven silent -> DG_ELIMIT
+    with pytest.raises(dicey_amd.DgError):
+        gpu_small.hunt(["ACGTACGTACGT"], small_genome["seqlen"], distance=30)
+
+
+def test_larger_genome_roundtrip_properties():
+    """Size-independent properties on a multi-megabase genome: every genome-sampled query is found at its origin with
+    distance 0, and locate() positions really spell the pattern."""
+    import dicey_amd
+    import tempfile, os
+    seqs = make_genome(5, 4, 400000, repeats=False)
+    text = genome_text(seqs)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "big.fm9")
+        O.build_fm9(text, path)
+        with dicey_amd.FmIndex(path) as ix:
+            rng = random.Random(1)
+            seqlen = [len(s) + 1 for s in seqs]
+            qs, origin = [], []
+            while len(qs) < 5000:
+                c = rng.randrange(4)
+                p = rng.randrange(len(seqs[c]) - 20)
+                q = seqs[c][p:p + 20]
+                if "N" in q:
+                    continue
+                qs.append(q)
+                origin.append((c, p + 1))
+            got = ix.hunt(qs, seqlen, distance=1)
+            for q, (c, p), r in zip(qs, origin, got.queries):
+                assert any(h.score == 0 and h.chr == c and h.start == p and h.strand == "+" and h.refalign == q for h in r.hits)
+            locs = ix.locate([q.encode() for q in qs[:500]])
+            for q, ps in zip(qs, locs):
+                assert ps and all(text[x:x + 20] == q.encode() for x in ps)

@@ -1,0 +1,6 @@
+// DEVELOPMENT TOOL: the GPU index builder is not emulated (rocPRIM, wave collectives).
+#include <cstdint>
+extern "C" {
+int dg_index_build(const uint8_t*, uint64_t, int, const char*) { return -7; }
+int dg_index_build_device(const void*, uint64_t, int, const char*) { return -7; }
+}

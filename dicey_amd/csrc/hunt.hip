@@ -755,6 +755,9 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   }
   DG_HIP(hipStreamSynchronize(st));
   DG_HIP(hipGetLastError());
+  R->d_hits = ws[WS_HITS].p;
+  R->d_refalign = ws[WS_ALN].p;
+  R->d_queryalign = ws[WS_ALN].as<char>() + (nhits + 1) * (u64)stride;
   R->ctr_leaves = nleaf;
   R->ctr_ext_steps = hctr[1];
   R->ctr_sa_reads = hctr[2];

@@ -128,6 +128,11 @@ typedef struct {
   double ms_select;       /* minimal-set + ordering kernel */
   double ms_locate;
   double ms_verify;       /* window fetch + Needleman-Wunsch */
+  /* device-resident copies (HIP pointers on the index's device), valid until the next call on this index:
+   * what a multi-GPU driver hands to RCCL to gather hit lists without a host round trip */
+  const void* d_hits;       /* dg_hit[nhits] */
+  const void* d_refalign;   /* nhits * aln_stride bytes */
+  const void* d_queryalign; /* nhits * aln_stride bytes */
 } dg_hunt_result;
 
 /* Host-buffer entry point: queries are raw bytes as read from the FASTA/argv (any case), concatenated.

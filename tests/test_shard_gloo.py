@@ -1,0 +1,50 @@
+"""N>1 path on CPU: world_size-2 gloo run of the shard/gather helpers bench.py uses over RCCL."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dicey_amd.shard import gather_bytes, shard_range
+
+
+def test_shard_range_covers_batch_in_order():
+    for nq in (0, 1, 7, 100000, 100001):
+        for world in (1, 2, 4, 8):
+            parts = [shard_range(nq, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == nq
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            assert all(hi - lo <= (nq + world - 1) // world for lo, hi in parts)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nq = 11
+    lo, hi = shard_range(nq, rank, world)
+    # fake per-rank hit list: one 16-byte record per query plus a rank-dependent tail
+    local = torch.tensor([(q * 7 + b) % 256 for q in range(lo, hi) for b in range(16)] + [rank] * (rank * 5), dtype=torch.uint8)
+    got = gather_bytes(local, dst=0)
+    if rank == 0:
+        torch.save([g.clone() for g in got], out)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_bytes_world2_gloo(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert len(got) == 2
+    for rank, g in enumerate(got):
+        lo, hi = shard_range(11, rank, 2)
+        want = [(q * 7 + b) % 256 for q in range(lo, hi) for b in range(16)] + [rank] * (rank * 5)
+        assert g.tolist() == want

@@ -1,0 +1,557 @@
+// `dicey` host binary for the MI355X search path: keeps the command line and the JSON of the reference's
+// `dicey hunt` (reference src/dicey.cpp:35-76 dispatch, src/hunter.h:177-447) and calls the HIP kernels through the
+// C ABI of libdiceygpu.so.  `dicey index` is provided as well (src/index.h:34-141) so that a genome can be prepared
+// without the reference binary; everything else the reference offers (search, padlock, ...) is out of scope here.
+//
+// Host-side work that must stay on the host for bit-identical output: the hit vector arrives in the
+// reference's push order and is sorted with libstdc++ std::sort under the reference's comparator (hunter.h:63-65,440).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "../../include/dicey_gpu.h"
+
+namespace {
+
+const char* kVersion = "0.5.1";  // src/version.h:8 — goes into meta.version
+
+// ------------------------------------------------------------------------------------------------ small utilities
+bool file_nonempty(const std::string& p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
+}
+bool is_regular(const std::string& p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+// boost::filesystem parent_path()/stem() of the genome path (hunter.h:254-255): "dir/hg19.fa.gz" -> "dir/hg19.fa"
+std::string strip_last_extension(const std::string& p) {
+  size_t slash = p.find_last_of('/');
+  size_t start = slash == std::string::npos ? 0 : slash + 1;
+  std::string name = p.substr(start);
+  size_t dot = name.find_last_of('.');
+  if (dot != std::string::npos && dot != 0 && name != "..") name = name.substr(0, dot);
+  return p.substr(0, start) + name;
+}
+bool is_gz(const std::string& p) {  // util.h:21-33
+  std::ifstream f(p.c_str(), std::ios::binary);
+  char a = 0, b = 0;
+  f.read(&a, 1);
+  f.read(&b, 1);
+  return a == '\x1F' && b == '\x8B';
+}
+// reads a (b)gzip or plain file line by line
+struct LineReader {
+  gzFile g = nullptr;
+  std::string buf;
+  explicit LineReader(const std::string& p) { g = gzopen(p.c_str(), "rb"); if (g) gzbuffer(g, 1 << 20); }
+  ~LineReader() { if (g) gzclose(g); }
+  bool ok() const { return g != nullptr; }
+  bool next(std::string& line) {
+    line.clear();
+    char tmp[1 << 16];
+    bool any = false;
+    while (gzgets(g, tmp, sizeof tmp)) {
+      any = true;
+      size_t n = std::strlen(tmp);
+      if (n && tmp[n - 1] == '\n') {
+        line.append(tmp, n - 1);
+        return true;
+      }
+      line.append(tmp, n);
+    }
+    return any;
+  }
+};
+bool is_fasta(const std::string& p) {  // util.h:35-52: first line starts with '>'
+  LineReader r(p);
+  std::string line;
+  if (!r.ok() || !r.next(line)) return false;
+  return !line.empty() && line[0] == '>';
+}
+
+// sequence names and lengths as htslib's faidx reports them (util.h:183-206): from <genome>.fai when present,
+// otherwise by scanning the FASTA.  Name = header up to the first whitespace.
+bool seq_len_name(const std::string& genome, std::vector<uint32_t>& seqlen, std::vector<std::string>& seqname) {
+  std::ifstream fai((genome + ".fai").c_str());
+  if (fai) {
+    std::string line;
+    while (std::getline(fai, line)) {
+      if (line.empty()) continue;
+      std::istringstream ss(line);
+      std::string name;
+      unsigned long long len = 0;
+      if (!std::getline(ss, name, '\t') || !(ss >> len)) return false;
+      seqname.push_back(name);
+      seqlen.push_back((uint32_t)len + 1);  // util.h:201
+    }
+    return !seqlen.empty();
+  }
+  LineReader r(genome);
+  if (!r.ok()) return false;
+  std::string line;
+  bool have = false;
+  uint64_t len = 0;
+  while (r.next(line)) {
+    if (!line.empty() && line[0] == '>') {
+      if (have) seqlen.push_back((uint32_t)len + 1);
+      size_t e = line.find_first_of(" \t\r", 1);
+      seqname.push_back(line.substr(1, e == std::string::npos ? std::string::npos : e - 1));
+      have = true;
+      len = 0;
+    } else if (have) {
+      for (char c : line) len += !(c == '\r' || c == ' ' || c == '\t');
+    }
+  }
+  if (have) seqlen.push_back((uint32_t)len + 1);
+  return !seqlen.empty();
+}
+
+// ------------------------------------------------------------------------------------------------ JSON (nlohmann 3.5.0 dump())
+std::string jstr(const std::string& s) {
+  static const char* hex = "0123456789abcdef";
+  std::string o = "\"";
+  for (unsigned char c : s) {
+    if (c == '"') o += "\\\"";
+    else if (c == '\\') o += "\\\\";
+    else if (c == '\b') o += "\\b";
+    else if (c == '\f') o += "\\f";
+    else if (c == '\n') o += "\\n";
+    else if (c == '\r') o += "\\r";
+    else if (c == '\t') o += "\\t";
+    else if (c < 0x20) {
+      o += "\\u00";
+      o.push_back(hex[c >> 4]);
+      o.push_back(hex[c & 15]);
+    } else o.push_back((char)c);
+  }
+  o.push_back('"');
+  return o;
+}
+
+struct DnaHit {  // hunter.h:53-66
+  int32_t score;
+  uint32_t chr, start;
+  char strand;
+  std::string refalign, queryalign;
+  bool operator<(const DnaHit& b) const {
+    return ((score > b.score) || ((score == b.score) && (chr < b.chr)) || ((score == b.score) && (chr == b.chr) && (start < b.start)));
+  }
+};
+
+struct Config {
+  std::string genome, outfile, input;
+  bool has_outfile = false, hamming = false, forward = false, help = false;
+  uint64_t max_locations = 1000;
+  uint32_t max_neighborhood = 10000, distance = 1;
+};
+
+// hunter.h:99-160
+std::string hunt_json(const Config& c, uint32_t distance, const std::string& sequence, const std::string& qname,
+                      const std::vector<std::string>& seqname, const std::vector<DnaHit>& ht, const std::vector<std::string>& msg) {
+  std::string o = "{\"errors\": [";
+  bool errors = false;
+  for (size_t i = 0; i < msg.size(); ++i) {
+    bool err = msg[i].compare(0, 5, "Error") == 0;
+    errors = errors || err;
+    if (i) o.push_back(',');
+    o += "{\"title\":" + jstr(msg[i]) + ",\"type\":" + (err ? "\"error\"" : "\"warning\"") + "}";
+  }
+  o.push_back(']');
+  if (!errors) {
+    o += ",\"meta\":{\"distance\":" + std::to_string(distance);
+    o += std::string(",\"forwardonly\":") + (c.forward ? "true" : "false");
+    o += ",\"genome\":" + jstr(c.genome);
+    o += std::string(",\"hamming\":") + (c.hamming ? "true" : "false");
+    o += ",\"maxmatches\":" + std::to_string(c.max_locations);
+    if (!qname.empty()) o += ",\"name\":" + jstr(qname);
+    o += ",\"outfile\":" + jstr(c.outfile);
+    o += ",\"sequence\":" + jstr(sequence);
+    o += std::string(",\"subcommand\":\"hunt\",\"version\":\"") + kVersion + "\"},\"data\":[";
+    uint32_t oldchr = 999999, oldstart = 0;
+    bool first = true;
+    for (const DnaHit& h : ht) {
+      if (oldchr != h.chr || oldstart != h.start) {
+        if (!first) o.push_back(',');
+        first = false;
+        uint32_t nuc = 0;
+        for (char ch : h.refalign) nuc += ch != '-';
+        o += "{\"chr\":" + jstr(seqname[h.chr]) + ",\"distance\":" + std::to_string(std::abs(h.score));
+        o += ",\"end\":" + std::to_string(h.start + nuc - 1) + ",\"queryalign\":" + jstr(h.queryalign);
+        o += ",\"refalign\":" + jstr(h.refalign) + ",\"start\":" + std::to_string(h.start);
+        o += ",\"strand\":" + jstr(std::string(1, h.strand)) + "}";
+      }
+      oldchr = h.chr;
+      oldstart = h.start;
+    }
+    o.push_back(']');
+  }
+  o += "}\n";
+  return o;
+}
+
+// one gzip member per call, appended (hunter.h:162-170: gzip_compressor + file_sink(app))
+bool append_gzip_member(const std::string& path, const std::string& data) {
+  FILE* f = std::fopen(path.c_str(), "ab");
+  if (!f) return false;
+  static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+  std::fwrite(hdr, 1, 10, f);
+  z_stream zs;
+  std::memset(&zs, 0, sizeof zs);
+  deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+  std::vector<unsigned char> out(deflateBound(&zs, data.size()) + 64);
+  zs.next_in = (Bytef*)data.data();
+  zs.avail_in = (uInt)data.size();
+  zs.next_out = out.data();
+  zs.avail_out = (uInt)out.size();
+  deflate(&zs, Z_FINISH);
+  std::fwrite(out.data(), 1, zs.total_out, f);
+  deflateEnd(&zs);
+  uint32_t crc = (uint32_t)crc32(0L, (const Bytef*)data.data(), (uInt)data.size()), isz = (uint32_t)data.size();
+  std::fwrite(&crc, 4, 1, f);
+  std::fwrite(&isz, 4, 1, f);
+  return std::fclose(f) == 0;
+}
+
+void emit(const Config& c, const std::string& json) {
+  if (c.has_outfile) append_gzip_member(c.outfile, json);
+  else {
+    std::fwrite(json.data(), 1, json.size(), stdout);
+    std::fflush(stdout);  // std::endl in the reference
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ options (boost::program_options subset)
+struct OptSpec {
+  const char* lname;
+  char sname;
+  bool takes_arg;
+};
+const OptSpec kHuntOpts[] = {{"help", '?', false}, {"genome", 'g', true}, {"outfile", 'o', true}, {"maxmatches", 'm', true},
+                             {"maxNeighborhood", 'x', true}, {"distance", 'd', true}, {"hamming", 'n', false}, {"forward", 'f', false},
+                             {"input-file", 0, true}};
+struct Parsed {
+  std::vector<std::pair<std::string, std::string>> kv;
+  std::vector<std::string> positional;
+  std::string error;
+};
+Parsed parse_options(int argc, char** argv, const OptSpec* specs, size_t nspec) {
+  Parsed p;
+  auto find_long = [&](const std::string& n) -> const OptSpec* {
+    const OptSpec* exact = nullptr;
+    const OptSpec* pref = nullptr;
+    int npref = 0;
+    for (size_t i = 0; i < nspec; ++i) {
+      if (n == specs[i].lname) exact = &specs[i];
+      else if (std::string(specs[i].lname).compare(0, n.size(), n) == 0) {
+        pref = &specs[i];
+        ++npref;
+      }
+    }
+    if (exact) return exact;
+    return npref == 1 ? pref : nullptr;  // unambiguous prefixes are accepted, as program_options does
+  };
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+      std::string name = a.substr(2), val;
+      bool has_val = false;
+      size_t eq = name.find('=');
+      if (eq != std::string::npos) {
+        val = name.substr(eq + 1);
+        name = name.substr(0, eq);
+        has_val = true;
+      }
+      const OptSpec* s = find_long(name);
+      if (!s) {
+        p.error = "unrecognised option '" + a + "'";
+        return p;
+      }
+      if (s->takes_arg && !has_val) {
+        if (i + 1 >= argc) {
+          p.error = std::string("the required argument for option '--") + s->lname + "' is missing";
+          return p;
+        }
+        val = argv[++i];
+      }
+      p.kv.emplace_back(s->lname, val);
+    } else if (a.size() >= 2 && a[0] == '-' && a != "--") {
+      size_t k = 1;
+      while (k < a.size()) {
+        const OptSpec* s = nullptr;
+        for (size_t j = 0; j < nspec; ++j)
+          if (specs[j].sname && specs[j].sname == a[k]) s = &specs[j];
+        if (!s) {
+          p.error = "unrecognised option '" + a + "'";
+          return p;
+        }
+        if (s->takes_arg) {
+          std::string val = a.substr(k + 1);
+          if (val.empty()) {
+            if (i + 1 >= argc) {
+              p.error = std::string("the required argument for option '--") + s->lname + "' is missing";
+              return p;
+            }
+            val = argv[++i];
+          }
+          p.kv.emplace_back(s->lname, val);
+          break;
+        }
+        p.kv.emplace_back(s->lname, "");
+        ++k;
+      }
+    } else if (a == "--") {
+      for (++i; i < argc; ++i) p.positional.push_back(argv[i]);
+    } else p.positional.push_back(a);
+  }
+  return p;
+}
+
+void hunt_usage(const char* sub) {
+  std::cout << "Usage: dicey " << sub << " [OPTIONS] -g Danio_rerio.fa.gz CATTACTAACATCAGT" << std::endl;
+  std::cout << "       dicey " << sub << " [OPTIONS] -g Danio_rerio.fa.gz sequences.fasta" << std::endl;
+  std::cout << "Generic options:\n"
+               "  -? [ --help ]                      show help message\n"
+               "  -g [ --genome ] arg                genome file\n"
+               "  -o [ --outfile ] arg               gzipped output file\n"
+               "  -m [ --maxmatches ] arg (=1000)    max. number of matches\n"
+               "  -x [ --maxNeighborhood ] arg (=10000)\n"
+               "                                     max. neighborhood size\n"
+               "  -d [ --distance ] arg (=1)         neighborhood distance\n"
+               "  -n [ --hamming ]                   use hamming neighborhood instead of edit \n"
+               "                                     distance\n"
+               "  -f [ --forward ]                   only forward matches\n"
+               "\n";
+}
+
+int device_from_env() {
+  const char* e = std::getenv("DICEY_DEVICE");
+  return e ? std::atoi(e) : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ hunt (hunter.h:177-447)
+int hunter(int argc, char** argv) {
+  Config c;
+  Parsed p = parse_options(argc, argv, kHuntOpts, sizeof kHuntOpts / sizeof kHuntOpts[0]);
+  if (!p.error.empty()) {  // program_options throws; the reference does not catch -> terminate
+    std::cerr << "terminate called after throwing an instance of 'boost::program_options::error'\n  what():  " << p.error << std::endl;
+    std::abort();
+  }
+  bool have_genome = false, have_input = false;
+  for (auto& kv : p.kv) {
+    const std::string& k = kv.first;
+    if (k == "help") c.help = true;
+    else if (k == "genome") { c.genome = kv.second; have_genome = true; }
+    else if (k == "outfile") { c.outfile = kv.second; c.has_outfile = true; }
+    else if (k == "maxmatches") c.max_locations = std::strtoull(kv.second.c_str(), nullptr, 10);
+    else if (k == "maxNeighborhood") c.max_neighborhood = (uint32_t)std::strtoul(kv.second.c_str(), nullptr, 10);
+    else if (k == "distance") c.distance = (uint32_t)std::strtoul(kv.second.c_str(), nullptr, 10);
+    else if (k == "hamming") c.hamming = true;
+    else if (k == "forward") c.forward = true;
+    else if (k == "input-file") { c.input = kv.second; have_input = true; }
+  }
+  if (!p.positional.empty()) {
+    c.input = p.positional.back();
+    have_input = true;
+  }
+  if (c.help || !have_input || !have_genome) {
+    hunt_usage(argv[0]);
+    return -1;
+  }
+  std::vector<DnaHit> none;
+  std::vector<std::string> msg;
+  std::vector<uint32_t> seqlen;
+  std::vector<std::string> seqname;
+  if (c.has_outfile) {  // hunter.h:232-235
+    std::ofstream trunc(c.outfile.c_str(), std::ios_base::out | std::ios_base::binary | std::ios_base::trunc);
+  }
+  if (!file_nonempty(c.genome)) {
+    msg.push_back("Error: Genome does not exist!");
+    emit(c, hunt_json(c, c.distance, c.input, "", seqname, none, msg));
+    return 1;
+  }
+  if (!seq_len_name(c.genome, seqlen, seqname)) {
+    msg.push_back("Error: Could not retrieve sequence lengths!");
+    emit(c, hunt_json(c, c.distance, c.input, "", seqname, none, msg));
+    return 1;
+  }
+  std::string index_file = strip_last_extension(c.genome) + ".fm9";
+  dg_index* ix = nullptr;
+  if (dg_index_open(index_file.c_str(), device_from_env(), DG_OPEN_DEFAULT, &ix) != DG_OK) {
+    std::cerr << "dicey: " << dg_last_error() << std::endl;
+    msg.push_back("Error: FM-Index cannot be loaded!");
+    emit(c, hunt_json(c, c.distance, c.input, "", seqname, none, msg));
+    return 1;
+  }
+  // hunter.h:262-287: a FASTA file of queries, or the literal sequence
+  std::vector<std::pair<std::string, std::string>> queries;
+  if (is_regular(c.input)) {
+    if (!is_fasta(c.input)) {
+      msg.push_back("Error: Input file is not in FASTA format!");
+      emit(c, hunt_json(c, c.distance, c.input, "", seqname, none, msg));
+      dg_index_close(ix);
+      return 1;
+    }
+    std::ifstream fa(c.input.c_str());
+    std::string line, fan, faseq;
+    while (std::getline(fa, line)) {
+      if (line.empty()) continue;
+      if (line[0] == '>') {
+        if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
+        faseq.clear();
+        fan = line.substr(1);
+      } else faseq += line;
+    }
+    if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
+  } else queries.emplace_back(std::string(), c.input);
+
+  dg_hunt_params hp;
+  hp.distance = c.distance;
+  hp.hamming = c.hamming;
+  hp.forward_only = c.forward;
+  hp.max_locations = c.max_locations;
+  hp.max_neighborhood = c.max_neighborhood;
+  const size_t CHUNK = 1u << 20;
+  int rc_all = 0;
+  for (size_t q0 = 0; q0 < queries.size(); q0 += CHUNK) {
+    size_t q1 = std::min(queries.size(), q0 + CHUNK), nq = q1 - q0;
+    std::string qb;
+    std::vector<uint64_t> off(nq + 1, 0);
+    for (size_t i = 0; i < nq; ++i) {
+      qb += queries[q0 + i].second;
+      off[i + 1] = qb.size();
+    }
+    dg_hunt_result* R = nullptr;
+    if (dg_hunt(ix, &hp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), nq, &R) != DG_OK) {
+      std::cerr << "dicey: " << dg_last_error() << std::endl;  // outside the supported envelope: say so, never guess
+      rc_all = 2;
+      break;
+    }
+    for (size_t i = 0; i < nq; ++i) {
+      std::vector<std::string> m;
+      std::vector<DnaHit> ht;
+      const std::string& qname = queries[q0 + i].first;
+      if (R->qflags[i] & DG_Q_TOO_SHORT) {
+        m.push_back("Error: Input sequence is shorter than 10 nucleotides!");
+        emit(c, hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m));
+        continue;
+      }
+      for (uint32_t k = 0; k < R->qnondna[i]; ++k) m.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
+      if (R->qflags[i] & DG_Q_DIST_ADJUSTED) m.push_back("Warning: Distance was adjusted to sequence length!");
+      if (R->qflags[i] & DG_Q_NBHD_EXCEEDED) {
+        std::string x = std::to_string(c.max_neighborhood);
+        m.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x + " neighbors are searched, results are likely incomplete!");
+      }
+      for (uint64_t h = R->hit_off[i]; h < R->hit_off[i + 1]; ++h) {
+        const dg_hit& H = R->hits[h];
+        ht.push_back(DnaHit{H.score, H.chr, H.start, (char)H.strand, std::string(R->refalign + h * R->aln_stride, H.aln_len),
+                            std::string(R->queryalign + h * R->aln_stride, H.aln_len)});
+      }
+      if (R->qflags[i] & DG_Q_MAX_MATCHES) {
+        std::string x = std::to_string(c.max_locations);
+        m.push_back("Warning: More than " + x + " matches found. Only first " + x + " matches are reported, results are likely incomplete!");
+      }
+      std::sort(ht.begin(), ht.end());  // hunter.h:440 — same comparator, same libstdc++ algorithm, same input order
+      std::string seq((const char*)R->qseq + R->qoff[i], R->qoff[i + 1] - R->qoff[i]);
+      emit(c, hunt_json(c, R->qdistance[i], seq, qname, seqname, ht, m));
+    }
+    dg_hunt_result_free(R);
+  }
+  dg_index_close(ix);
+  return rc_all;
+}
+
+// ------------------------------------------------------------------------------------------------ index (index.h:34-141)
+int indexer(int argc, char** argv) {
+  std::string genome, outfile;
+  bool out_given = false, help = false;
+  const OptSpec specs[] = {{"help", '?', false}, {"output", 'o', true}, {"input-file", 0, true}};
+  Parsed p = parse_options(argc, argv, specs, 3);
+  if (!p.error.empty()) {
+    std::cerr << p.error << std::endl;
+    std::abort();
+  }
+  for (auto& kv : p.kv) {
+    if (kv.first == "help") help = true;
+    else if (kv.first == "output") { outfile = kv.second; out_given = true; }
+    else if (kv.first == "input-file") genome = kv.second;
+  }
+  if (!p.positional.empty()) genome = p.positional.back();
+  if (help || genome.empty()) {
+    std::cout << "Usage: dicey " << argv[0] << " [OPTIONS] genome.fa.gz" << std::endl;
+    std::cout << "Generic options:\n  -? [ --help ]                    show help message\n  -o [ --output ] arg (=genome.fm9) output file\n\n";
+    return -1;
+  }
+  if (!out_given) outfile = strip_last_extension(genome) + ".fm9";  // index.h:67-69
+  std::ifstream probe(genome.c_str(), std::ios::binary);
+  if (!probe.is_open()) {
+    std::cerr << "Error: " << genome << " cannot be opened!" << std::endl;
+    return -1;
+  }
+  probe.close();
+  if (!is_gz(genome)) {
+    std::cerr << "Error: Please compress " << genome << " with bgzip." << std::endl;
+    return -1;
+  }
+  // index.h:97-115: header lines become '\n' (except before the first sequence), sequence lines are upper-cased
+  std::string text, line;
+  LineReader r(genome);
+  bool first = true;
+  while (r.next(line)) {
+    if (!line.empty() && line[0] == '>') {
+      if (!first) text.push_back('\n');
+      else first = false;
+    } else {
+      for (char ch : line) text.push_back((char)std::toupper((unsigned char)ch));
+    }
+  }
+  text.push_back('\n');
+  if (dg_index_build((const uint8_t*)text.data(), text.size(), device_from_env(), outfile.c_str()) != DG_OK) {
+    std::cerr << "dicey: " << dg_last_error() << std::endl;
+    return 1;
+  }
+  std::cout << "Done." << std::endl;
+  return 0;
+}
+
+void display_usage() {  // dicey.cpp:19-33 (only the subcommands this build carries)
+  std::cout << "Usage: dicey <command> <arguments>" << std::endl;
+  std::cout << std::endl;
+  std::cout << "    index        index FASTA reference file (GPU builder)" << std::endl;
+  std::cout << "    hunt         search DNA sequences (MI355X search path)" << std::endl;
+  std::cout << std::endl;
+  std::cout << "search, padlock, chop and mappability are not part of this build; use the reference binary for them." << std::endl;
+  std::cout << std::endl;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    display_usage();
+    return 0;
+  }
+  std::string cmd = argv[1];
+  if (cmd == "version" || cmd == "--version" || cmd == "-v") {
+    std::cout << "Dicey version: v" << kVersion << " (MI355X search path, libdiceygpu ABI " << dg_abi_version() << ")" << std::endl;
+    return 0;
+  }
+  if (cmd == "help" || cmd == "--help" || cmd == "-h" || cmd == "-?") {
+    display_usage();
+    return 0;
+  }
+  if (cmd == "hunt") return hunter(argc - 1, argv + 1);
+  if (cmd == "index") return indexer(argc - 1, argv + 1);
+  std::cerr << "Unrecognized command " << cmd << std::endl;
+  return 1;
+}

@@ -1,0 +1,91 @@
+"""Process seam: the `dicey` binary of this repo — same argv surface, same JSON — against the
+oracle's restatement of hunter.h:99-160,291-444, byte for byte."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import oracle_lib as O
+from conftest import genome_text, make_genome, make_queries
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DICEY = os.path.join(ROOT, "dicey_amd", "dicey")
+
+
+@pytest.fixture(scope="module")
+def cli_genome(tmp_path_factory):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dicey_amd", "cli"), "-s"])
+    d = tmp_path_factory.mktemp("cli")
+    seqs = make_genome(55, 3, 20000)
+    names = ["chr1", "chr2 some description", "scaffold_3"]
+    fa = d / "genome.fa.gz"
+    with gzip.open(fa, "wt") as f:
+        for n, s in zip(names, seqs):
+            f.write(">" + n + "\n")
+            for i in range(0, len(s), 60):
+                f.write(s[i:i + 60].lower() if i % 120 else s[i:i + 60])
+                f.write("\n")
+    r = subprocess.run([DICEY, "index", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fm9 = str(d / "genome.fa.fm9")  # genome.parent_path()/stem + ".fm9" (hunter.h:254-255)
+    assert os.path.exists(fm9)
+    # the GPU-built file must equal the oracle's construction on the text index.h:97-115 defines
+    ref = str(d / "oracle.fm9")
+    O.build_fm9(genome_text(seqs), ref)
+    assert open(fm9, "rb").read() == open(ref, "rb").read()
+    return {"fa": str(fa), "fm9": fm9, "seqs": seqs, "names": ["chr1", "chr2", "scaffold_3"], "dir": d,
+            "seqlen": [len(s) + 1 for s in seqs], "text": genome_text(seqs)}
+
+
+def _oracle_json(g, queries, qnames, **kw):
+    ix = O.Index(g["fm9"])
+    js, _ = ix.hunt(g["seqlen"], g["names"], queries, qnames=qnames, genome=g["fa"], **kw)
+    return js
+
+
+def test_hunt_literal_sequence_json_identical(cli_genome):
+    g = cli_genome
+    q = g["seqs"][1][500:520]
+    r = subprocess.run([DICEY, "hunt", "-g", g["fa"], q], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == _oracle_json(g, [q], [""], distance=1)
+    # option forms program_options accepts: -d0, --distance=0, long-option prefix, switches
+    for extra, kw in [(["-d0"], dict(distance=0)), (["--distance=0", "-n"], dict(distance=0, hamming=True)),
+                      (["--dist", "1", "--forward", "-m", "2"], dict(distance=1, forward_only=True, max_locations=2))]:
+        r = subprocess.run([DICEY, "hunt", *extra, "-g", g["fa"], q], capture_output=True, text=True)
+        assert r.stdout == _oracle_json(g, [q], [""], **kw), extra
+
+
+def test_hunt_fasta_batch_and_gz_outfile(cli_genome):
+    g = cli_genome
+    qs = make_queries(8, g["text"], 200) + ["ACGTAC", "acgtnnacgtacgtacgtac", g["seqs"][0][:20], g["seqs"][2][-20:]]
+    names = ["q%d extra words" % i for i in range(len(qs))]
+    fa = g["dir"] / "queries.fa"
+    with open(fa, "w") as f:
+        for n, s in zip(names, qs):
+            f.write(">%s\n%s\n\n%s\n" % (n, s[:7], s[7:]))
+    want = _oracle_json(g, qs, names, distance=1)
+    r = subprocess.run([DICEY, "hunt", "-g", g["fa"], str(fa)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want
+    out = g["dir"] / "hits.json.gz"
+    r = subprocess.run([DICEY, "hunt", "-o", str(out), "-g", g["fa"], str(fa)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == ""
+    ix = O.Index(g["fm9"])
+    want_o, _ = ix.hunt(g["seqlen"], g["names"], qs, qnames=names, genome=g["fa"], outfile=str(out), distance=1)
+    assert gzip.open(out, "rt").read() == want_o  # one gzip member per query, concatenated (hunter.h:169)
+
+
+def test_error_paths_match_reference_messages(cli_genome):
+    g = cli_genome
+    r = subprocess.run([DICEY, "hunt", "-g", "/no/such/genome.fa.gz", "ACGTACGTACGT"], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert r.stdout == '{"errors": [{"title":"Error: Genome does not exist!","type":"error"}]}\n'
+    r = subprocess.run([DICEY, "hunt", "ACGTACGTACGT"], capture_output=True, text=True)
+    assert r.returncode == 255 and r.stdout.startswith("Usage: dicey hunt [OPTIONS] -g Danio_rerio.fa.gz CATTACTAACATCAGT")
+    notfa = g["dir"] / "notfasta.txt"
+    notfa.write_text("hello\n")
+    r = subprocess.run([DICEY, "hunt", "-g", g["fa"], str(notfa)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Error: Input file is not in FASTA format!" in r.stdout

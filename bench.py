@@ -31,6 +31,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 OCC_LINE_BYTES = 64    # one Occ block
 BYTES_PER_EXT = 2 * OCC_LINE_BYTES  # an interval extension reads the block of each interval end
+BYTES_PER_TAB_READ = 8  # one K-mer jump-table entry (lo, hi)
 GRCH38_FREQ = (0.295, 0.205, 0.205, 0.295)  # A C G T
 
 
@@ -189,7 +190,7 @@ def main():
         _capi.check(L, L.dg_hunt_device(ix.handle, C.byref(p), sl, len(seqlen), C.c_void_p(d_q.data_ptr()),
                                         C.c_void_p(d_off.data_ptr()), nq, len(qbytes), fetch, C.byref(rp)))
         R = rp.contents
-        res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes,
+        res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes, "tab": R.ctr_tab_reads,
                "ms_total": R.ms_total, "ms_search": R.ms_search, "ms_select": R.ms_select, "ms_locate": R.ms_locate,
                "ms_verify": R.ms_verify}
         if world > 1:  # hit lists to rank 0 over RCCL/xGMI
@@ -252,7 +253,8 @@ def main():
         ms_step = elapsed / a.steps * 1e3
         ext = float(np.mean([r["ext"] for r in acc]))
         ms_search = float(np.mean([r["ms_search"] for r in acc]))
-        alg_bytes = ext * BYTES_PER_EXT
+        tab = float(np.mean([r["tab"] for r in acc]))
+        alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ
         achieved = alg_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_k_search.json")
@@ -276,10 +278,12 @@ def main():
                                  f"frequencies, 5% N runs, seed 1 (no real genome is available offline)",
                        "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
                        "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_search<true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_search<true,1>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "ext_steps_per_launch": ext,
-                         "bytes_per_ext_step": BYTES_PER_EXT, "kernel_ms": ms_search},
+                         "bytes_per_ext_step": BYTES_PER_EXT, "table_reads_per_launch": tab,
+                         "bytes_per_table_read": BYTES_PER_TAB_READ, "kernel_ms": ms_search,
+                         "index_lines_per_s": (2 * ext + tab) / (ms_search * 1e-3) if ms_search > 0 else 0.0},
             "cpu_baseline": cpu,
             "parity_sample": parity,
             "phases_ms": {k: float(np.mean([r[k] for r in acc])) for k in ("ms_total", "ms_search", "ms_select", "ms_locate", "ms_verify")},

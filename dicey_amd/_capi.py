@@ -41,7 +41,7 @@ class HuntResult(C.Structure):
                 ("qflags", C.POINTER(C.c_uint32)), ("qdistance", C.POINTER(C.c_uint32)), ("qnondna", C.POINTER(C.c_uint32)),
                 ("qseq", C.POINTER(C.c_uint8)), ("qoff", C.POINTER(C.c_uint64)),
                 ("ctr_ext_steps", C.c_uint64), ("ctr_leaves", C.c_uint64), ("ctr_sa_reads", C.c_uint64),
-                ("ctr_win_bytes", C.c_uint64), ("ms_total", C.c_double), ("ms_search", C.c_double),
+                ("ctr_win_bytes", C.c_uint64), ("ctr_tab_reads", C.c_uint64), ("ms_total", C.c_double), ("ms_search", C.c_double),
                 ("ms_select", C.c_double), ("ms_locate", C.c_double), ("ms_verify", C.c_double),
                 ("d_hits", C.c_void_p), ("d_refalign", C.c_void_p), ("d_queryalign", C.c_void_p)]
 

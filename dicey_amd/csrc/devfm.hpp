@@ -61,6 +61,11 @@ struct FmView {
   const u8* text;  // T[0..n), text[n-1] = 0
   u32 C4[4];       // C[] of A,C,G,T (0 and never matching if the symbol is absent)
   u8 sym_of_code[8];
+  // K-mer jump table (derived at load): SA interval [lo,hi) of every A/C/G/T K-mer, (0,0) when it does not occur.
+  // code = sum over t of code(kmer[K-1-t]) << 2t, i.e. the LAST character sits in the lowest bits — the order in which
+  // backward search meets the characters.
+  const uint2* ktab;
+  u32 K;  // 0 = no table
 };
 
 DG_DEV u64 packed_get(const u64* w, u32 width, u64 i) {
@@ -121,21 +126,24 @@ DG_DEV OccLine occ_load(const OccBlock* occ, u64 blk) {
   L.p2[0] = ((u64)d.y << 32) | d.x; L.p2[1] = ((u64)d.w << 32) | d.z;
   return L;
 }
+// dynamic indexing of small register arrays would send them to scratch: select instead
+DG_DEV u32 sel4(u32 c, u32 a0, u32 a1, u32 a2, u32 a3) { return c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3; }
 // occurrences of code c (0..3) in the first r (0..127) symbols of the block, plus the block's running count
 DG_DEV u32 occ_in_line(const OccLine& L, u32 r, u32 c) {
   u64 m0 = r >= 64 ? ~0ULL : ((1ULL << r) - 1);
   u64 m1 = r > 64 ? ((1ULL << (r - 64)) - 1) : 0ULL;
   u64 x0 = (c & 1) ? L.p0[0] : ~L.p0[0], x1 = (c & 1) ? L.p0[1] : ~L.p0[1];
   u64 y0 = (c & 2) ? L.p1[0] : ~L.p1[0], y1 = (c & 2) ? L.p1[1] : ~L.p1[1];
-  return L.cnt[c] + (u32)__popcll(x0 & y0 & ~L.p2[0] & m0) + (u32)__popcll(x1 & y1 & ~L.p2[1] & m1);
+  return sel4(c, L.cnt[0], L.cnt[1], L.cnt[2], L.cnt[3]) + (u32)__popcll(x0 & y0 & ~L.p2[0] & m0) + (u32)__popcll(x1 & y1 & ~L.p2[1] & m1);
 }
 DG_DEV u32 occ_rank(const FmView& f, u64 i, u32 c) {  // #code c in BWT[0,i), i <= n
   OccLine L = occ_load(f.occ, i >> 7);
   return occ_in_line(L, (u32)(i & 127), c);
 }
 DG_DEV u32 code_in_line(const OccLine& L, u32 r) {
-  u32 w = r >> 6, j = r & 63;
-  return (u32)((L.p0[w] >> j) & 1) | ((u32)((L.p1[w] >> j) & 1) << 1) | ((u32)((L.p2[w] >> j) & 1) << 2);
+  u32 j = r & 63;
+  u64 a = r < 64 ? L.p0[0] : L.p0[1], b = r < 64 ? L.p1[0] : L.p1[1], c = r < 64 ? L.p2[0] : L.p2[1];
+  return (u32)((a >> j) & 1) | ((u32)((b >> j) & 1) << 1) | ((u32)((c >> j) & 1) << 2);
 }
 
 // LF(i) and BWT[i] through the Occ blocks; symbols outside A,C,G,T fall back to the wavelet tree.
@@ -144,11 +152,11 @@ DG_DEV u64 lf_step(const FmView& f, u64 i, u32& sym) {
   u32 r = (u32)(i & 127);
   u32 code = code_in_line(L, r);
   if (code < 4) {
-    sym = f.sym_of_code[code];
-    return (u64)f.C4[code] + occ_in_line(L, r, code);
+    sym = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
+    return (u64)sel4(code, f.C4[0], f.C4[1], f.C4[2], f.C4[3]) + occ_in_line(L, r, code);
   }
   if (code != CODE_OTHER) {
-    sym = f.sym_of_code[code];
+    sym = code == CODE_N ? 'N' : code == CODE_NL ? '\n' : 0u;
     return f.wt->C[f.wt->char2comp[sym]] + wt_rank(f, i, sym);
   }
   u64 rk = wt_inverse_select(f, i, sym);
@@ -160,8 +168,9 @@ DG_DEV u64 lf_step(const FmView& f, u64 i, u32& sym) {
 DG_DEV void bs_extend_code(const FmView& f, u32& lo, u32& hi, u32 code) {  // code in 0..3
   OccLine A = occ_load(f.occ, lo >> 7);
   OccLine B = occ_load(f.occ, hi >> 7);
-  lo = f.C4[code] + occ_in_line(A, lo & 127, code);
-  hi = f.C4[code] + occ_in_line(B, hi & 127, code);
+  const u32 c4 = sel4(code, f.C4[0], f.C4[1], f.C4[2], f.C4[3]);
+  lo = c4 + occ_in_line(A, lo & 127, code);
+  hi = c4 + occ_in_line(B, hi & 127, code);
 }
 DG_DEV void bs_extend_sym(const FmView& f, u32& lo, u32& hi, u32 sym, u32 code) {
   if (code < 4) {

@@ -90,49 +90,143 @@ __global__ void k_prepare(Batch b) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Search.  State machine: every loop iteration performs at most one interval extension (two Occ-block reads),
-// whatever trie level the lane is on, so a wavefront stays converged on the memory operation.
+// Search.  State machine: every loop iteration performs at most one index access (an interval extension = two
+// Occ-block reads, or one K-mer table read), whatever trie level the lane is on, so a wavefront stays converged on the
+// memory operation.  Frames live in registers (fully unrolled selects over the <= D+1 levels, no scratch).
+//
+// K-mer table ("window mode"): while fewer than K characters have been emitted the lane only accumulates their 2-bit
+// codes; the K-th character turns the code into an SA interval with ONE table read, replacing K extensions.  Once a
+// branch has spent its whole budget the rest of the window is copied from the query in O(1).  Lanes whose strings may
+// be shorter than K, or whose query holds an N, run the same loop in interval mode from the start.
 struct Frame {
   u32 pos;  // query characters still to consume (q[0..pos))
-  u32 lo, hi;
-  u32 op;   // next edit operation to try at this node
+  u32 lo;   // interval mode: SA interval [lo,hi);  window mode: lo = accumulated code, hi unused
+  u32 hi;
+  u32 st;   // bits 0-3 next edit operation, bits 4-8 emitted count (window mode), bit 9 window mode
+};
+enum : u32 { ST_WIN = 1u << 9 };
+
+template <int D>
+struct FrameStack {
+  Frame fr[D + 1];
+  DG_DEV Frame get(u32 L) const {
+    Frame f = fr[0];
+#pragma unroll
+    for (int k = 1; k <= D; ++k)
+      if (L == (u32)k) f = fr[k];
+    return f;
+  }
+  DG_DEV void set(u32 L, const Frame& f) {
+#pragma unroll
+    for (int k = 0; k <= D; ++k)
+      if (L == (u32)k) fr[k] = f;
+  }
+};
+template <int D>
+struct OpStack {
+  u32 v[D > 0 ? D : 1] = {0};
+  DG_DEV void set(u32 L, u32 x) {
+#pragma unroll
+    for (int k = 0; k < (D > 0 ? D : 1); ++k)
+      if (L == (u32)k) v[k] = x;
+  }
 };
 
-template <bool INDEL>
-__global__ void __launch_bounds__(256) k_search(FmView f, Batch b, Leaf* leaves, u64 leaf_cap, unsigned long long* leaf_count,
-                                                 u32* grp_cnt, unsigned long long* ext_steps) {
+struct SearchOut {
+  Leaf* leaves;
+  u64 leaf_cap;
+  unsigned long long* leaf_count;
+  u32* grp_cnt;
+  unsigned long long* ext_steps;
+  unsigned long long* tab_reads;
+};
+
+// emit one character (code 0..3) in front of what the frame stands for; returns false when the branch is dead
+DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& lookups) {
+  if (fr.st & ST_WIN) {
+    u32 e = (fr.st >> 4) & 31;
+    fr.lo |= c << (2 * e);
+    ++e;
+    if (e == f.K) {
+      uint2 iv = f.ktab[fr.lo];
+      ++lookups;
+      fr.lo = iv.x;
+      fr.hi = iv.y;
+      fr.st &= ~(ST_WIN | (31u << 4));
+      return iv.x < iv.y;
+    }
+    fr.st = (fr.st & ~(31u << 4)) | (e << 4);
+    return true;
+  }
+  bs_extend_code(f, fr.lo, fr.hi, c);
+  ++steps;
+  return fr.lo < fr.hi;
+}
+// window mode with no budget left: the remaining K-e characters are the query's own; one table read
+DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m, u64 qpk, u64& lookups) {
+  const u32 e = (fr.st >> 4) & 31, need = f.K - e;
+  u32 code = fr.lo;
+  if (m <= 32) {  // qpk holds q[i] at bits 2(m-1-i): the next character to emit is at the bottom after the shift
+    u64 w = qpk >> (2 * (m - fr.pos));
+    u64 mask = need >= 32 ? ~0ULL : ((1ULL << (2 * need)) - 1);
+    code |= (u32)((w & mask) << (2 * e));
+  } else {
+    for (u32 t = 0; t < need; ++t) code |= (u32)seq[fr.pos - 1 - t] << (2 * (e + t));
+  }
+  fr.pos -= need;
+  uint2 iv = f.ktab[code];
+  ++lookups;
+  fr.lo = iv.x;
+  fr.hi = iv.y;
+  fr.st &= ~(ST_WIN | (31u << 4));
+  return iv.x < iv.y;
+}
+
+template <bool INDEL, int D>
+__global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= b.nq * 2) return;
   u64 q = t >> 1;
   u32 strand = (u32)(t & 1);
-  grp_cnt[t] = 0;
+  o.grp_cnt[t] = 0;
   if ((strand && !b.reverse) || (b.qflags[q] & DG_Q_TOO_SHORT)) return;
   const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
-  const u32 m = b.qlen[q], d = b.qdist[q];
+  const u32 m = b.qlen[q];
+  u32 d = b.qdist[q];
+  if (d > (u32)D) d = D;  // cannot happen: the host instantiates D >= the largest effective distance
   constexpr u32 NOPS = INDEL ? 9u : 4u;  // INDEL: D, S(A,C,G,T), I(A,C,G,T);  Hamming: S(A,C,G,T)
-  Frame fr[DMAX + 1];
-  u32 ops[DMAX];
+  const bool use_win = f.K != 0 && m >= f.K + d && b.qnondna[q] == 0;
+  u64 qpk = 0;
+  if (use_win && m <= 32)
+    for (u32 i = 0; i < m; ++i) qpk |= (u64)seq[i] << (2 * (m - 1 - i));
+  FrameStack<D> S;
+  OpStack<D> ops;
   u32 L = 0, nleaf = 0;
-  u64 steps = 0;
-  fr[0].pos = m;
-  fr[0].lo = 0;
-  fr[0].hi = (u32)f.n;
-  fr[0].op = 0;
+  u64 steps = 0, lookups = 0;
+  {
+    Frame r;
+    r.pos = m;
+    r.lo = 0;
+    r.hi = use_win ? 0u : (u32)f.n;
+    r.st = use_win ? ST_WIN : 0u;
+    S.set(0, r);
+  }
   for (;;) {
+    Frame F = S.get(L);
     const u32 budget = d - L;
-    if (fr[L].pos == 0) {
-      // a complete neighbourhood string whose interval is non-empty (empty intervals never get here)
+    if (F.pos == 0) {
+      // a complete neighbourhood string whose interval is non-empty (strings are never shorter than K in window mode)
       if (!INDEL || budget == 0) {
-        u64 at = atomicAdd(leaf_count, 1ULL);
-        if (at < leaf_cap) {
-          Leaf lf;
-          lf.qs = (u32)t;
-          lf.slot = nleaf;
-          lf.lo = fr[L].lo;
-          lf.hi = fr[L].hi;
-          lf.nops = L;
-          for (u32 k = 0; k < DMAX; ++k) lf.ops[k] = k < L ? ops[k] : 0;
-          leaves[at] = lf;
+        u64 at = atomicAdd(o.leaf_count, 1ULL);
+        if (at < o.leaf_cap) {
+          Leaf* lf = o.leaves + at;
+          lf->qs = (u32)t;
+          lf->slot = nleaf;
+          lf->lo = F.lo;
+          lf->hi = F.hi;
+          lf->nops = L;
+#pragma unroll
+          for (int k = 0; k < (int)DMAX; ++k) lf->ops[k] = (k < D && (u32)k < L) ? ops.v[k < D ? k : 0] : 0u;
         }
         ++nleaf;
       }
@@ -140,10 +234,12 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, Leaf* leaves,
       --L;
       continue;
     }
-    const u32 pos = fr[L].pos;
+    const u32 pos = F.pos;
     const u32 here = seq[pos - 1];
-    if (budget > 0 && fr[L].op < NOPS) {
-      const u32 op = fr[L].op++;
+    const u32 op = F.st & 15;
+    if (budget > 0 && op < NOPS) {
+      F.st += 1;  // next operation of this node
+      S.set(L, F);
       u32 kind, c;
       if (INDEL) {
         kind = op == 0 ? OP_D : (op <= 4 ? OP_S : OP_I);
@@ -152,38 +248,41 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, Leaf* leaves,
         kind = OP_S;
         c = op;
       }
-      if (kind == OP_S && c == here) continue;             // a substitution changes the character (neighbors.h:63)
-      if (kind == OP_I && L == 0 && pos == m) continue;     // nothing may be inserted after the last character (neighbors.h:51)
-      u32 lo = fr[L].lo, hi = fr[L].hi;
-      if (kind != OP_D) {
-        bs_extend_code(f, lo, hi, c);
-        ++steps;
-        if (lo >= hi) continue;
-      }
-      ops[L] = (pos << 4) | (kind << 2) | c;
+      if (kind == OP_S && c == here) continue;           // a substitution changes the character (neighbors.h:63)
+      if (kind == OP_I && L == 0 && pos == m) continue;   // nothing may be inserted after the last character (neighbors.h:51)
+      Frame ch = F;
+      ch.st &= ~15u;
+      if (kind != OP_D && !frame_emit(f, ch, c, steps, lookups)) continue;
+      ch.pos = kind == OP_I ? pos : pos - 1;
+      if (budget == 1 && (ch.st & ST_WIN) && !frame_finish_window(f, ch, seq, m, qpk, lookups)) continue;
+      ops.set(L, (pos << 4) | (kind << 2) | c);
       ++L;
-      fr[L].pos = kind == OP_I ? pos : pos - 1;
-      fr[L].lo = lo;
-      fr[L].hi = hi;
-      fr[L].op = 0;
+      S.set(L, ch);
       continue;
     }
-    // keep the query character
-    u32 lo = fr[L].lo, hi = fr[L].hi;
-    bs_extend_sym(f, lo, hi, ascii_of(here), here);
-    ++steps;
-    if (lo >= hi) {
+    // keep the query character(s)
+    bool alive;
+    if (budget == 0 && (F.st & ST_WIN)) alive = frame_finish_window(f, F, seq, m, qpk, lookups);  // only the d = 0 root
+    else {
+      F.st &= ~15u;
+      if (here < 4) alive = frame_emit(f, F, here, steps, lookups);
+      else {  // an N in the query (never in window mode): through the wavelet tree like sdsl
+        bs_extend_sym(f, F.lo, F.hi, 'N', here);
+        ++steps;
+        alive = F.lo < F.hi;
+      }
+      F.pos = pos - 1;
+    }
+    if (!alive) {
       if (L == 0) break;
       --L;
       continue;
     }
-    fr[L].pos = pos - 1;
-    fr[L].lo = lo;
-    fr[L].hi = hi;
-    fr[L].op = 0;
+    S.set(L, F);
   }
-  grp_cnt[t] = nleaf;
-  atomicAdd(ext_steps, (unsigned long long)steps);
+  o.grp_cnt[t] = nleaf;
+  atomicAdd(o.ext_steps, (unsigned long long)steps);
+  if (lookups) atomicAdd(o.tab_reads, (unsigned long long)lookups);
 }
 
 // group leaves by (query,strand): dst = grp_off[qs] + slot
@@ -258,6 +357,135 @@ DG_DEV bool leaf_less(const u8* seq, u32 m, const Leaf& a, const Leaf& b) {
     if (x < 0 || y < 0) return x < 0 && y >= 0;
     if (x != y) return ascii_rank((u32)x) < ascii_rank((u32)y);
   }
+}
+
+// ---- packed strings: the common case (string length <= 42) keeps every neighbourhood string in 128 bits ----
+// 3 bits per character, code = ASCII rank + 1 (A1 C2 G3 N4 T5), first character in the top bits, zero padded: unsigned
+// 128-bit comparison == std::string operator<, substring tests are shifts and masks.
+static constexpr u32 PACK_MAX_LEN = 42;
+struct PLeaf {
+  u64 hi, lo;  // the 128-bit packed string
+  u32 len;
+  u32 sa_lo, sa_hi;
+  u32 pad;
+};
+DG_DEV void p128_shl(u64& hi, u64& lo, u32 s) {  // s < 128
+  if (s >= 64) {
+    hi = lo << (s - 64);
+    lo = 0;
+  } else if (s) {
+    hi = (hi << s) | (lo >> (64 - s));
+    lo <<= s;
+  }
+}
+DG_DEV void p128_topmask(u64& hi, u64& lo, u32 nbits) {  // keep the top nbits (<= 128)
+  if (nbits >= 128) return;
+  if (nbits >= 64) {
+    u32 r = nbits - 64;
+    lo &= r ? ~0ULL << (64 - r) : 0ULL;
+  } else {
+    lo = 0;
+    hi &= nbits ? ~0ULL << (64 - nbits) : 0ULL;
+  }
+}
+// group leaves by (query,strand) and pack their strings: dst = grp_off[qs] + slot
+__global__ void k_group_pack(Batch b, const Leaf* in, u64 nleaf, const u64* grp_off, PLeaf* out) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nleaf) return;
+  Leaf lf = in[t];
+  const u64 q = lf.qs >> 1;
+  const u8* seq = ((lf.qs & 1) ? b.rv : b.fw) + b.qoff[q];
+  const u32 m = b.qlen[q];
+  LeafReader r;
+  r.init(seq, m, lf);
+  u64 hi = 0, lo = 0;
+  u32 len = 0;
+  for (int c = r.next(); c >= 0; c = r.next()) {
+    u64 code = ascii_rank((u32)c) + 1;
+    u32 sh = 125 - 3 * len;  // character i occupies bits [125-3i, 127-3i]
+    if (sh >= 64) hi |= code << (sh - 64);
+    else if (sh >= 62) {  // straddles the two words (sh = 62 or 63)
+      lo |= code << sh;
+      hi |= code >> (64 - sh);
+    } else lo |= code << sh;
+    ++len;
+  }
+  PLeaf p;
+  p.hi = hi;
+  p.lo = lo;
+  p.len = len;
+  p.sa_lo = lf.lo;
+  p.sa_hi = lf.hi;
+  p.pad = 0;
+  out[grp_off[lf.qs] + lf.slot] = p;
+}
+DG_DEV bool pleaf_contains(const PLeaf& a, const PLeaf& x) {  // is x inside a?  (std::string::find)
+  if (x.len > a.len) return false;
+  for (u32 o = 0; o + x.len <= a.len; ++o) {
+    u64 hi = a.hi, lo = a.lo;
+    p128_shl(hi, lo, 3 * o);
+    p128_topmask(hi, lo, 3 * x.len);
+    if (hi == x.hi && lo == x.lo) return true;
+  }
+  return false;
+}
+DG_DEV bool pleaf_less(const PLeaf& a, const PLeaf& x) { return a.hi < x.hi || (a.hi == x.hi && a.lo < x.lo); }
+
+// One lane per query, packed strings.  Same contract as k_select below.
+__global__ void k_select_packed(Batch b, const PLeaf* grouped, const u64* grp_off, Sel* sel, u32* nsel, u32* qhits) {
+  u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq) return;
+  u64 hits = 0;
+  for (u32 strand = 0; strand < 2; ++strand) {
+    const u64 g0 = grp_off[2 * q + strand], g1 = grp_off[2 * q + strand + 1];
+    const u32 k = (u32)(g1 - g0);
+    u32 ns = 0;
+    const PLeaf* G = grouped + g0;
+    Sel* S = sel + g0;
+    // pass 1: survivors (no proper substring among the group, first copy of equal strings); pass 2: rank + emit
+    for (u32 i = 0; i < k; ++i) {
+      const PLeaf a = G[i];
+      bool alive = true;
+      if (b.indel)
+        for (u32 j = 0; j < k && alive; ++j) {
+          if (j == i) continue;
+          const PLeaf x = G[j];
+          if (x.len > a.len) continue;
+          if (pleaf_contains(a, x)) alive = (x.len == a.len) && (i < j);
+        }
+      S[i].take = alive;  // scratch use of the output slot until pass 2 has read it
+      ns += alive;
+    }
+    // rank among survivors (std::set order); survivors are few, so recompute liveness flags from S[].take
+    // pass 2 writes into sel in rank order; to stay in place it first collects ranks in S[i].hbase
+    for (u32 i = 0; i < k; ++i) {
+      if (!S[i].take) continue;
+      const PLeaf a = G[i];
+      u32 r = 0;
+      for (u32 j = 0; j < k; ++j)
+        if (j != i && S[j].take && pleaf_less(G[j], a)) ++r;
+      S[i].hbase = r;
+    }
+    // permute: position r receives the survivor whose rank is r (lo/hi/len fields are free until now)
+    for (u32 i = 0; i < k; ++i)
+      if (S[i].take) {
+        u32 r = S[i].hbase;
+        S[r].lo = G[i].sa_lo;
+        S[r].hi = G[i].sa_hi;
+        S[r].len = G[i].len;
+      }
+    for (u32 r = 0; r < ns; ++r) {  // hunter.h:350,357
+      u64 occs = (u64)S[r].hi - S[r].lo;
+      u64 take = 0;
+      if (hits < b.max_locations) take = occs < b.max_locations - hits ? occs : b.max_locations - hits;
+      S[r].take = (u32)take;
+      S[r].hbase = (u32)hits;
+      hits += take;
+    }
+    nsel[2 * q + strand] = ns;
+  }
+  qhits[q] = (u32)hits;
+  if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;
 }
 
 // One lane per query.  Works in place on the grouped leaf array: `keep` marks survivors, `order` their rank.
@@ -626,7 +854,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   u32* nsel = (u32*)gp;
   gp += ngrp * 4;
   u32* qhits = (u32*)gp;
-  unsigned long long* ctr = ws[WS_MISC].as<unsigned long long>();  // [0] leaf_count [1] ext_steps [2] sa_reads [3] win_bytes
+  unsigned long long* ctr = ws[WS_MISC].as<unsigned long long>();  // [0] leaf_count [1] ext_steps [2] sa_reads [3] win_bytes [4] tab_reads
   std::vector<u64> cum(nseq);
   u64 run = 0;
   for (u32 r = 0; r < nseq; ++r) {
@@ -645,13 +873,31 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   for (int attempt = 0;; ++attempt) {
     DG_TRY(ws[WS_LEAF].reserve(leaf_cap * sizeof(Leaf)));
     DG_HIP(hipMemsetAsync(ctr, 0, 16, st));
+    DG_HIP(hipMemsetAsync(ctr + 4, 0, 8, st));
     DG_HIP(hipEventRecord(ix->ev[1], st));
-    if (indel)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<true>), dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, b,
-                         ws[WS_LEAF].as<Leaf>(), leaf_cap, ctr, grp_cnt, ctr + 1);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<false>), dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, b,
-                         ws[WS_LEAF].as<Leaf>(), leaf_cap, ctr, grp_cnt, ctr + 1);
+    {
+      SearchOut so;
+      so.leaves = ws[WS_LEAF].as<Leaf>();
+      so.leaf_cap = leaf_cap;
+      so.leaf_count = ctr;
+      so.grp_cnt = grp_cnt;
+      so.ext_steps = ctr + 1;
+      so.tab_reads = ctr + 4;
+      const dim3 grid(ceil_div(ngrp, TB)), block(TB);
+#define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so)
+      if (indel) {
+        if (dmax_eff == 0) DG_LAUNCH_SEARCH(true, 0);
+        else if (dmax_eff == 1) DG_LAUNCH_SEARCH(true, 1);
+        else if (dmax_eff == 2) DG_LAUNCH_SEARCH(true, 2);
+        else DG_LAUNCH_SEARCH(true, 4);
+      } else {
+        if (dmax_eff == 0) DG_LAUNCH_SEARCH(false, 0);
+        else if (dmax_eff == 1) DG_LAUNCH_SEARCH(false, 1);
+        else if (dmax_eff == 2) DG_LAUNCH_SEARCH(false, 2);
+        else DG_LAUNCH_SEARCH(false, 4);
+      }
+#undef DG_LAUNCH_SEARCH
+    }
     DG_HIP(hipEventRecord(ix->ev[2], st));
     unsigned long long hc = 0;
     DG_HIP(hipMemcpyAsync(&hc, ctr, 8, hipMemcpyDeviceToHost, st));
@@ -671,17 +917,26 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   for (u64 g = 0; g < ngrp; ++g) hoff[g + 1] = hoff[g] + hcnt[g];
   if (hoff[ngrp] != nleaf) return fail(DG_EHIP, "internal: leaf accounting mismatch (%llu vs %llu)", (unsigned long long)hoff[ngrp], (unsigned long long)nleaf);
   DG_HIP(hipMemcpyAsync(grp_off, hoff.data(), (ngrp + 1) * 8, hipMemcpyHostToDevice, st));
-  DG_TRY(ws[WS_LEAFG].reserve((nleaf + 1) * sizeof(Leaf)));
+  const bool packed = maxlen + dmax_eff <= PACK_MAX_LEN;  // every neighbourhood string fits 128 bits
+  DG_TRY(ws[WS_LEAFG].reserve((nleaf + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
   DG_TRY(ws[WS_SEL].reserve((nleaf + 1) * sizeof(Sel)));
-  DG_TRY(ws[WS_SCR].reserve((nleaf + 1) * 5 + 64));
   DG_HIP(hipEventRecord(ix->ev[3], st));
-  if (nleaf)
-    hipLaunchKernelGGL(k_group, dim3(ceil_div(nleaf, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), nleaf, grp_off,
-                       ws[WS_LEAFG].as<Leaf>());
-  u32* scr_rank = ws[WS_SCR].as<u32>();
-  u8* scr_keep = (u8*)(scr_rank + nleaf + 1);
-  hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, ws[WS_SEL].as<Sel>(),
-                     nsel, qhits, scr_keep, scr_rank);
+  if (packed) {
+    if (nleaf)
+      hipLaunchKernelGGL(k_group_pack, dim3(ceil_div(nleaf, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(), nleaf, grp_off,
+                         ws[WS_LEAFG].as<PLeaf>());
+    hipLaunchKernelGGL(k_select_packed, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<PLeaf>(), grp_off,
+                       ws[WS_SEL].as<Sel>(), nsel, qhits);
+  } else {
+    DG_TRY(ws[WS_SCR].reserve((nleaf + 1) * 5 + 64));
+    if (nleaf)
+      hipLaunchKernelGGL(k_group, dim3(ceil_div(nleaf, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), nleaf, grp_off,
+                         ws[WS_LEAFG].as<Leaf>());
+    u32* scr_rank = ws[WS_SCR].as<u32>();
+    u8* scr_keep = (u8*)(scr_rank + nleaf + 1);
+    hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, ws[WS_SEL].as<Sel>(),
+                       nsel, qhits, scr_keep, scr_rank);
+  }
   DG_HIP(hipEventRecord(ix->ev[4], st));
   std::vector<u32> hq(nq);
   DG_HIP(hipMemcpyAsync(hq.data(), qhits, nq * 4, hipMemcpyDeviceToHost, st));
@@ -729,8 +984,8 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr + 3);
   }
   DG_HIP(hipEventRecord(ix->ev[7], st));
-  unsigned long long hctr[4] = {0, 0, 0, 0};
-  DG_HIP(hipMemcpyAsync(hctr, ctr, 32, hipMemcpyDeviceToHost, st));
+  unsigned long long hctr[5] = {0, 0, 0, 0, 0};
+  DG_HIP(hipMemcpyAsync(hctr, ctr, 40, hipMemcpyDeviceToHost, st));
   // per-query metadata always comes back (small)
   R->qflags = new uint32_t[nq];
   R->qdistance = new uint32_t[nq];
@@ -762,6 +1017,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   R->ctr_ext_steps = hctr[1];
   R->ctr_sa_reads = hctr[2];
   R->ctr_win_bytes = hctr[3];
+  R->ctr_tab_reads = hctr[4];
   R->ms_total = ev_ms(ix->ev[0], ix->ev[7]);
   R->ms_search = ev_ms(ix->ev[1], ix->ev[2]);
   R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);

@@ -167,6 +167,29 @@ __global__ void k_selfcheck(FmView f, u64 nsample, u32* bad) {
   if (!ok) atomicAdd(bad, 1u);
 }
 
+// K-mer table: thread i looks at the K-mer that starts suffix SA[i]; the first / last suffix of each run of equal K-mers
+// writes the interval bounds.  K-mers that run into a separator, an N or the end of the text have no entry.
+DG_DEV u64 kmer_code_at(const FmView& f, u64 p, u32 K) {  // bit 63 set = not an A/C/G/T K-mer
+  if (p + K > f.n - 1) return 1ULL << 63;
+  u64 code = 0;
+  for (u32 t = 0; t < K; ++t) {
+    u32 c = code_of_byte(f.text[p + K - 1 - t]);
+    if (c > 3) return 1ULL << 63;
+    code |= (u64)c << (2 * t);
+  }
+  return code;
+}
+__global__ void k_kmer_table(FmView f, uint2* tab, u32 K) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f.n) return;
+  u64 me = kmer_code_at(f, f.sa[i], K);
+  if (me >> 63) return;
+  u64 prev = i ? kmer_code_at(f, f.sa[i - 1], K) : (1ULL << 63);
+  u64 next = i + 1 < f.n ? kmer_code_at(f, f.sa[i + 1], K) : (1ULL << 63);
+  if (prev != me) tab[me].x = (u32)i;
+  if (next != me) tab[me].y = (u32)(i + 1);
+}
+
 static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
   FmView& f = ix->view;
   const u64 n = f.n;
@@ -221,6 +244,23 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
   f.sa = sa;
   DG_HIP(hipStreamSynchronize(ix->stream));
   DG_HIP(hipGetLastError());
+  if (!(flags & DG_OPEN_NO_KMER_TABLE)) {
+    // K = ceil(log4 n) clamped to [8,16]: about one expected occurrence per K-mer; 16 -> 34 GB, which is what the
+    // 288 GB of HBM are for
+    u32 K = 8;
+    while (K < 16 && (1ULL << (2 * K)) < n) ++K;
+    uint2* tab = nullptr;
+    u64 entries = 1ULL << (2 * K);
+    DG_HIP(hipMalloc((void**)&tab, entries * sizeof(uint2)));
+    ix->owned.push_back(tab);
+    DG_HIP(hipMemsetAsync(tab, 0, entries * sizeof(uint2), ix->stream));
+    hipLaunchKernelGGL(k_kmer_table, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K);
+    DG_HIP(hipStreamSynchronize(ix->stream));
+    DG_HIP(hipGetLastError());
+    f.ktab = tab;
+    f.K = K;
+    ix->hbm_bytes += entries * sizeof(uint2);
+  }
   if (!(flags & DG_OPEN_NO_SELFCHECK)) {
     DG_HIP(hipMalloc((void**)&bad, 4));
     DG_HIP(hipMemsetAsync(bad, 0, 4, ix->stream));

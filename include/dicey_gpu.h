@@ -49,6 +49,7 @@ typedef struct dg_index dg_index;
 /* flags for dg_index_open */
 #define DG_OPEN_DEFAULT 0u
 #define DG_OPEN_NO_SELFCHECK 1u /* skip the load-time self validation (C[] vs Occ totals, SA permutation spot checks) */
+#define DG_OPEN_NO_KMER_TABLE 2u /* do not derive the K-mer jump table (saves up to 34 GB of HBM; search is slower) */
 
 /* Parses the file written by `dicey index` (sdsl store_to_checked_file of csa_wt<>) unchanged, uploads it to
  * HBM on `device`, and derives the search layouts there (Occ blocks, full suffix array, text copy). */
@@ -123,6 +124,7 @@ typedef struct {
   uint64_t ctr_leaves;    /* occurring neighbourhood strings emitted by the search kernel */
   uint64_t ctr_sa_reads;  /* suffix-array entries read by locate */
   uint64_t ctr_win_bytes; /* text window bytes read */
+  uint64_t ctr_tab_reads; /* K-mer jump-table entries read (8 B each) */
   double ms_total;        /* device time of the whole batch (HIP events on the index stream) */
   double ms_search;       /* of which: neighbourhood/backward-search kernel */
   double ms_select;       /* minimal-set + ordering kernel */

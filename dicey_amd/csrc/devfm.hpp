@@ -188,6 +188,15 @@ DG_DEV void bs_extend_sym(const FmView& f, u32& lo, u32& hi, u32 sym, u32 code) 
   hi = (u32)(cb + wt_rank(f, hi, sym));
 }
 
+// Add per-lane counters with one atomic per wavefront.  (tools/hostemu pre-defines DG_HAVE_WAVE_ADD with a per-thread
+// version because it runs lanes one at a time.)
+#ifndef DG_HAVE_WAVE_ADD
+DG_DEV void wave_add(unsigned long long* p, u64 v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, (unsigned long long)v);
+}
+#endif
+
 DG_DEV u32 code_of_byte(u32 b) {
   return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : b == 'N' ? 4u : b == '\n' ? 5u : b == 0 ? 6u : 7u;
 }

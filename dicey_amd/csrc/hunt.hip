@@ -100,7 +100,7 @@ __global__ void k_prepare(Batch b) {
 // be shorter than K, or whose query holds an N, run the same loop in interval mode from the start.
 struct Frame {
   u32 pos;  // query characters still to consume (q[0..pos))
-  u32 lo;   // interval mode: SA interval [lo,hi);  window mode: lo = accumulated code, hi unused
+  u32 lo;   // interval mode: SA interval [lo,hi);  window mode: (hi:lo) = accumulated 2-bit codes (up to 34 bits)
   u32 hi;
   u32 st;   // bits 0-3 next edit operation, bits 4-8 emitted count (window mode), bit 9 window mode
 };
@@ -132,23 +132,30 @@ struct OpStack {
   }
 };
 
+// Counters and the leaf allocator are sharded by workgroup: a single hot word serialises at ~11 ns per atomic, which
+// is milliseconds once hundreds of thousands of wavefronts report.
+static constexpr u32 NSHARD = 1024;
+struct Counters {
+  u32 leaf_cnt[NSHARD];  // leaves allocated in each shard's region of the leaf buffer
+  unsigned long long steps[NSHARD], lookups[NSHARD], sa_reads[NSHARD], win_bytes[NSHARD];
+};
 struct SearchOut {
-  Leaf* leaves;
-  u64 leaf_cap;
-  unsigned long long* leaf_count;
+  Leaf* leaves;   // NSHARD regions of shard_cap entries
+  u32 shard_cap;
+  Counters* ctr;
   u32* grp_cnt;
-  unsigned long long* ext_steps;
-  unsigned long long* tab_reads;
 };
 
 // emit one character (code 0..3) in front of what the frame stands for; returns false when the branch is dead
 DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& lookups) {
   if (fr.st & ST_WIN) {
     u32 e = (fr.st >> 4) & 31;
-    fr.lo |= c << (2 * e);
+    u64 code = ((u64)fr.hi << 32 | fr.lo) | ((u64)c << (2 * e));
+    fr.lo = (u32)code;
+    fr.hi = (u32)(code >> 32);
     ++e;
     if (e == f.K) {
-      uint2 iv = f.ktab[fr.lo];
+      uint2 iv = f.ktab[code];
       ++lookups;
       fr.lo = iv.x;
       fr.hi = iv.y;
@@ -165,13 +172,13 @@ DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& looku
 // window mode with no budget left: the remaining K-e characters are the query's own; one table read
 DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m, u64 qpk, u64& lookups) {
   const u32 e = (fr.st >> 4) & 31, need = f.K - e;
-  u32 code = fr.lo;
+  u64 code = (u64)fr.hi << 32 | fr.lo;
   if (m <= 32) {  // qpk holds q[i] at bits 2(m-1-i): the next character to emit is at the bottom after the shift
     u64 w = qpk >> (2 * (m - fr.pos));
     u64 mask = need >= 32 ? ~0ULL : ((1ULL << (2 * need)) - 1);
-    code |= (u32)((w & mask) << (2 * e));
+    code |= (w & mask) << (2 * e);
   } else {
-    for (u32 t = 0; t < need; ++t) code |= (u32)seq[fr.pos - 1 - t] << (2 * (e + t));
+    for (u32 t = 0; t < need; ++t) code |= (u64)seq[fr.pos - 1 - t] << (2 * (e + t));
   }
   fr.pos -= need;
   uint2 iv = f.ktab[code];
@@ -182,113 +189,157 @@ DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m
   return iv.x < iv.y;
 }
 
+// Work split: with the table, the root level of the trie is cut into independent items — one lane per
+// (query, strand, window offset j of the first edit, operation), plus one "rest" lane that owns the unedited window and
+// every first edit to the left of it.  An item lane jumps straight to its node (the j characters right of the edit are
+// the query's own), applies its single operation and explores that subtree only.  ~K*NOPS+1 times more lanes, each with
+// a handful of dependent index reads instead of hundreds: the kernel becomes throughput- instead of latency-bound.
 template <bool INDEL, int D>
-__global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o) {
+__global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, u32 items) {
+  // lane layout: the long-running "rest" lanes come first, packed densely (a rest lane among 63 short item lanes
+  // would pin its whole wavefront); item lanes follow, (items-1) consecutive lanes per (query, strand)
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= b.nq * 2) return;
-  u64 q = t >> 1;
-  u32 strand = (u32)(t & 1);
-  o.grp_cnt[t] = 0;
-  if ((strand && !b.reverse) || (b.qflags[q] & DG_Q_TOO_SHORT)) return;
-  const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
-  const u32 m = b.qlen[q];
-  u32 d = b.qdist[q];
-  if (d > (u32)D) d = D;  // cannot happen: the host instantiates D >= the largest effective distance
-  constexpr u32 NOPS = INDEL ? 9u : 4u;  // INDEL: D, S(A,C,G,T), I(A,C,G,T);  Hamming: S(A,C,G,T)
-  const bool use_win = f.K != 0 && m >= f.K + d && b.qnondna[q] == 0;
-  u64 qpk = 0;
-  if (use_win && m <= 32)
-    for (u32 i = 0; i < m; ++i) qpk |= (u64)seq[i] << (2 * (m - 1 - i));
-  FrameStack<D> S;
-  OpStack<D> ops;
-  u32 L = 0, nleaf = 0;
+  const u64 ngrp = b.nq * 2;
+  u64 gid;   // 2*query + strand
+  u32 item;  // items-1 = the rest lane
+  if (t < ngrp || items == 1) {
+    gid = t;
+    item = items - 1;
+  } else {
+    gid = (t - ngrp) / (items - 1);
+    item = (u32)((t - ngrp) % (items - 1));
+  }
   u64 steps = 0, lookups = 0;
-  {
-    Frame r;
-    r.pos = m;
-    r.lo = 0;
-    r.hi = use_win ? 0u : (u32)f.n;
-    r.st = use_win ? ST_WIN : 0u;
-    S.set(0, r);
-  }
-  for (;;) {
-    Frame F = S.get(L);
-    const u32 budget = d - L;
-    if (F.pos == 0) {
-      // a complete neighbourhood string whose interval is non-empty (strings are never shorter than K in window mode)
-      if (!INDEL || budget == 0) {
-        u64 at = atomicAdd(o.leaf_count, 1ULL);
-        if (at < o.leaf_cap) {
-          Leaf* lf = o.leaves + at;
-          lf->qs = (u32)t;
-          lf->slot = nleaf;
-          lf->lo = F.lo;
-          lf->hi = F.hi;
-          lf->nops = L;
-#pragma unroll
-          for (int k = 0; k < (int)DMAX; ++k) lf->ops[k] = (k < D && (u32)k < L) ? ops.v[k < D ? k : 0] : 0u;
+  constexpr u32 NOPS = INDEL ? 9u : 4u;  // INDEL: D, S(A,C,G,T), I(A,C,G,T);  Hamming: S(A,C,G,T)
+  bool active = gid < ngrp;
+  u64 q = gid >> 1;
+  u32 strand = (u32)(gid & 1);
+  if (active && ((strand && !b.reverse) || (b.qflags[q] & DG_Q_TOO_SHORT))) active = false;
+  if (active) {
+    const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
+    const u32 m = b.qlen[q];
+    u32 d = b.qdist[q];
+    if (d > (u32)D) d = D;  // cannot happen: the host instantiates D >= the largest effective distance
+    const bool use_win = f.K != 0 && m >= f.K + d && b.qnondna[q] == 0;
+    const bool rest = item == items - 1;
+    // lanes of a split launch: without the table (or without budget) only the rest lane works, as a full search
+    if (!rest && (!use_win || d == 0)) active = false;
+    if (active) {
+      u64 qpk = 0;
+      if (use_win && m <= 32)
+        for (u32 i = 0; i < m; ++i) qpk |= (u64)seq[i] << (2 * (m - 1 - i));
+      FrameStack<D> S;
+      OpStack<D> ops;
+      u32 L = 0;
+      bool single = false;  // an item lane: exactly one root operation
+      u32 single_op = 0;
+      {
+        Frame r;
+        r.pos = m;
+        r.lo = 0;
+        r.hi = use_win ? 0u : (u32)f.n;
+        r.st = use_win ? ST_WIN : 0u;
+        if (use_win && items > 1) {
+          if (rest) {
+            // the unedited window in one table read; first edits left of the window follow in interval mode
+            if (!frame_finish_window(f, r, seq, m, qpk, lookups)) active = false;
+          } else {
+            const u32 j = item / NOPS;  // characters right of the edit
+            single_op = item % NOPS;
+            single = true;
+            u64 code = 0;
+            if (m <= 32) code = qpk & (j >= 32 ? ~0ULL : ((1ULL << (2 * j)) - 1));
+            else
+              for (u32 k = 0; k < j; ++k) code |= (u64)seq[m - 1 - k] << (2 * k);
+            r.pos = m - j;
+            r.lo = (u32)code;
+            r.hi = (u32)(code >> 32);
+            r.st = ST_WIN | (j << 4) | single_op;
+          }
         }
-        ++nleaf;
+        S.set(0, r);
       }
-      if (L == 0) break;
-      --L;
-      continue;
-    }
-    const u32 pos = F.pos;
-    const u32 here = seq[pos - 1];
-    const u32 op = F.st & 15;
-    if (budget > 0 && op < NOPS) {
-      F.st += 1;  // next operation of this node
-      S.set(L, F);
-      u32 kind, c;
-      if (INDEL) {
-        kind = op == 0 ? OP_D : (op <= 4 ? OP_S : OP_I);
-        c = op == 0 ? 0u : (op - 1) & 3;
-      } else {
-        kind = OP_S;
-        c = op;
+      while (active) {
+        Frame F = S.get(L);
+        const u32 budget = d - L;
+        if (F.pos == 0) {
+          // a complete neighbourhood string whose interval is non-empty (strings are never shorter than K in window mode)
+          if (!INDEL || budget == 0) {
+            const u32 shard = blockIdx.x & (NSHARD - 1);
+            u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+            u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+            if (at < o.shard_cap) {
+              Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+              lf->qs = (u32)gid;
+              lf->slot = slot;
+              lf->lo = F.lo;
+              lf->hi = F.hi;
+              lf->nops = L;
+#pragma unroll
+              for (int k = 0; k < (int)DMAX; ++k) lf->ops[k] = (k < D && (u32)k < L) ? ops.v[k < D ? k : 0] : 0u;
+            }
+          }
+          if (L == 0) break;
+          --L;
+          continue;
+        }
+        const u32 pos = F.pos;
+        const u32 here = seq[pos - 1];
+        const u32 op = F.st & 15;
+        if (single && L == 0 && op != single_op) break;  // the item's one operation has been explored
+        if (budget > 0 && op < NOPS) {
+          F.st += 1;  // next operation of this node
+          S.set(L, F);
+          u32 kind, c;
+          if (INDEL) {
+            kind = op == 0 ? OP_D : (op <= 4 ? OP_S : OP_I);
+            c = op == 0 ? 0u : (op - 1) & 3;
+          } else {
+            kind = OP_S;
+            c = op;
+          }
+          if (kind == OP_S && c == here) continue;           // a substitution changes the character (neighbors.h:63)
+          if (kind == OP_I && L == 0 && pos == m) continue;   // nothing may be inserted after the last character (neighbors.h:51)
+          Frame ch = F;
+          ch.st &= ~15u;
+          if (kind != OP_D && !frame_emit(f, ch, c, steps, lookups)) continue;
+          ch.pos = kind == OP_I ? pos : pos - 1;
+          if (budget == 1 && (ch.st & ST_WIN) && !frame_finish_window(f, ch, seq, m, qpk, lookups)) continue;
+          ops.set(L, (pos << 4) | (kind << 2) | c);
+          ++L;
+          S.set(L, ch);
+          continue;
+        }
+        // keep the query character(s)
+        bool alive;
+        if (budget == 0 && (F.st & ST_WIN)) alive = frame_finish_window(f, F, seq, m, qpk, lookups);  // only a d = 0 root
+        else {
+          F.st &= ~15u;
+          if (here < 4) alive = frame_emit(f, F, here, steps, lookups);
+          else {  // an N in the query (never in window mode): through the wavelet tree like sdsl
+            bs_extend_sym(f, F.lo, F.hi, 'N', here);
+            ++steps;
+            alive = F.lo < F.hi;
+          }
+          F.pos = pos - 1;
+        }
+        if (!alive) {
+          if (L == 0) break;
+          --L;
+          continue;
+        }
+        S.set(L, F);
       }
-      if (kind == OP_S && c == here) continue;           // a substitution changes the character (neighbors.h:63)
-      if (kind == OP_I && L == 0 && pos == m) continue;   // nothing may be inserted after the last character (neighbors.h:51)
-      Frame ch = F;
-      ch.st &= ~15u;
-      if (kind != OP_D && !frame_emit(f, ch, c, steps, lookups)) continue;
-      ch.pos = kind == OP_I ? pos : pos - 1;
-      if (budget == 1 && (ch.st & ST_WIN) && !frame_finish_window(f, ch, seq, m, qpk, lookups)) continue;
-      ops.set(L, (pos << 4) | (kind << 2) | c);
-      ++L;
-      S.set(L, ch);
-      continue;
     }
-    // keep the query character(s)
-    bool alive;
-    if (budget == 0 && (F.st & ST_WIN)) alive = frame_finish_window(f, F, seq, m, qpk, lookups);  // only the d = 0 root
-    else {
-      F.st &= ~15u;
-      if (here < 4) alive = frame_emit(f, F, here, steps, lookups);
-      else {  // an N in the query (never in window mode): through the wavelet tree like sdsl
-        bs_extend_sym(f, F.lo, F.hi, 'N', here);
-        ++steps;
-        alive = F.lo < F.hi;
-      }
-      F.pos = pos - 1;
-    }
-    if (!alive) {
-      if (L == 0) break;
-      --L;
-      continue;
-    }
-    S.set(L, F);
   }
-  o.grp_cnt[t] = nleaf;
-  atomicAdd(o.ext_steps, (unsigned long long)steps);
-  if (lookups) atomicAdd(o.tab_reads, (unsigned long long)lookups);
+  wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
+  wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
 }
 
 // group leaves by (query,strand): dst = grp_off[qs] + slot
-__global__ void k_group(const Leaf* in, u64 nleaf, const u64* grp_off, Leaf* out) {
+__global__ void k_group(const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, Leaf* out) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nleaf) return;
+  if (t >= (u64)NSHARD * shard_cap || (u32)(t % shard_cap) >= ctr->leaf_cnt[t / shard_cap]) return;
   Leaf lf = in[t];
   out[grp_off[lf.qs] + lf.slot] = lf;
 }
@@ -389,9 +440,9 @@ DG_DEV void p128_topmask(u64& hi, u64& lo, u32 nbits) {  // keep the top nbits (
   }
 }
 // group leaves by (query,strand) and pack their strings: dst = grp_off[qs] + slot
-__global__ void k_group_pack(Batch b, const Leaf* in, u64 nleaf, const u64* grp_off, PLeaf* out) {
+__global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, PLeaf* out) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nleaf) return;
+  if (t >= (u64)NSHARD * shard_cap || (u32)(t % shard_cap) >= ctr->leaf_cnt[t / shard_cap]) return;
   Leaf lf = in[t];
   const u64 q = lf.qs >> 1;
   const u8* seq = ((lf.qs & 1) ? b.rv : b.fw) + b.qoff[q];
@@ -562,12 +613,12 @@ struct HitSeed {
   u32 len;  // its length
 };
 __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32* nsel, u64 ngroups, const u64* hit_off,
-                         HitSeed* seeds, unsigned long long* sa_reads) {
+                         HitSeed* seeds, Counters* ctr) {
   u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // g = 2*query + strand
   if (g >= ngroups) return;
   const Sel* S = sel + grp_off[g];
-  const u32 ns = nsel[g];
   u64 reads = 0;
+  const u32 ns = nsel[g];
   for (u32 r = 0; r < ns; ++r) {
     const u32 take = S[r].take;
     if (!take) continue;
@@ -602,7 +653,7 @@ __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32
       }
     }
   }
-  if (reads) atomicAdd(sa_reads, (unsigned long long)reads);
+  if (reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -619,7 +670,7 @@ struct VerifyArgs {
 };
 
 template <u32 TRACE_WORDS>
-__global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a, unsigned long long* win_bytes) {
+__global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a, Counters* ctr) {
   u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= a.nhits) return;
   const HitSeed sd = a.seeds[h];
@@ -662,7 +713,7 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
   out.query = (u32)q;
   out.strand = strand ? '-' : '+';
   out.reserved = 0;
-  atomicAdd(win_bytes, (unsigned long long)(pre + mlen + post));
+  atomicAdd(&ctr->win_bytes[blockIdx.x & (NSHARD - 1)], (unsigned long long)(pre + mlen + post));
   if (!b.indel) {
     // hunter.h:79-88,404-405: score = -(mismatches), alignment rows are the raw strings
     int sc = 0;
@@ -825,7 +876,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   DG_TRY(ws[WS_QSEQ].reserve(total + 8));
   DG_TRY(ws[WS_QMETA].reserve(nq * 16 + 64));
   DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + ngrp * 4 * 2 + nq * 4 + (nq + 1) * 8 + 256));
-  DG_TRY(ws[WS_MISC].reserve(256));
+  DG_TRY(ws[WS_MISC].reserve(sizeof(Counters)));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   Batch b;
   b.qbytes = (const u8*)d_qbytes;
@@ -854,7 +905,9 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   u32* nsel = (u32*)gp;
   gp += ngrp * 4;
   u32* qhits = (u32*)gp;
-  unsigned long long* ctr = ws[WS_MISC].as<unsigned long long>();  // [0] leaf_count [1] ext_steps [2] sa_reads [3] win_bytes [4] tab_reads
+  Counters* ctr = ws[WS_MISC].as<Counters>();
+  std::vector<Counters> hctr_store(1);
+  Counters& hctr = hctr_store[0];
   std::vector<u64> cum(nseq);
   u64 run = 0;
   for (u32 r = 0; r < nseq; ++r) {
@@ -862,29 +915,29 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
     run += seqlen[r];
   }
   DG_HIP(hipMemcpyAsync(ws[WS_CUM].p, cum.data(), (u64)nseq * 8, hipMemcpyHostToDevice, st));
-  DG_HIP(hipMemsetAsync(ctr, 0, 64, st));
+  DG_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
 
   const u32 TB = 256;
   DG_HIP(hipEventRecord(ix->ev[0], st));
   hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b);
-  // ---- search (retry with a larger leaf buffer if the estimate was too small)
-  u64 leaf_cap = std::max<u64>(4096, 8 * (u64)nq);
+  // ---- search (retry with larger leaf regions if a shard overflowed)
+  u32 shard_cap = (u32)std::max<u64>(64, (16 * (u64)nq) / NSHARD);
   u64 nleaf = 0;
   for (int attempt = 0;; ++attempt) {
-    DG_TRY(ws[WS_LEAF].reserve(leaf_cap * sizeof(Leaf)));
-    DG_HIP(hipMemsetAsync(ctr, 0, 16, st));
-    DG_HIP(hipMemsetAsync(ctr + 4, 0, 8, st));
+    DG_TRY(ws[WS_LEAF].reserve((u64)NSHARD * shard_cap * sizeof(Leaf)));
+    DG_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
     DG_HIP(hipEventRecord(ix->ev[1], st));
     {
       SearchOut so;
       so.leaves = ws[WS_LEAF].as<Leaf>();
-      so.leaf_cap = leaf_cap;
-      so.leaf_count = ctr;
+      so.shard_cap = shard_cap;
+      so.ctr = ctr;
       so.grp_cnt = grp_cnt;
-      so.ext_steps = ctr + 1;
-      so.tab_reads = ctr + 4;
-      const dim3 grid(ceil_div(ngrp, TB)), block(TB);
-#define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so)
+      // root-level work split (see k_search): only with the table and with at least one edit to place
+      const u32 items = (ix->view.K && dmax_eff >= 1) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
+      DG_HIP(hipMemsetAsync(grp_cnt, 0, ngrp * 4, st));
+      const dim3 grid(ceil_div(ngrp * items, TB)), block(TB);
+#define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so, items)
       if (indel) {
         if (dmax_eff == 0) DG_LAUNCH_SEARCH(true, 0);
         else if (dmax_eff == 1) DG_LAUNCH_SEARCH(true, 1);
@@ -899,14 +952,18 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
 #undef DG_LAUNCH_SEARCH
     }
     DG_HIP(hipEventRecord(ix->ev[2], st));
-    unsigned long long hc = 0;
-    DG_HIP(hipMemcpyAsync(&hc, ctr, 8, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(hctr.leaf_cnt, ctr->leaf_cnt, sizeof hctr.leaf_cnt, hipMemcpyDeviceToHost, st));
     DG_HIP(hipStreamSynchronize(st));
     DG_HIP(hipGetLastError());
-    nleaf = hc;
-    if (nleaf <= leaf_cap) break;
-    if (attempt > 2) return fail(DG_ENOMEM, "leaf buffer overflow persists (%llu leaves)", hc);
-    leaf_cap = nleaf + nleaf / 8 + 1024;
+    nleaf = 0;
+    u32 worst = 0;
+    for (u32 k = 0; k < NSHARD; ++k) {
+      nleaf += hctr.leaf_cnt[k];
+      worst = std::max(worst, hctr.leaf_cnt[k]);
+    }
+    if (worst <= shard_cap) break;
+    if (attempt > 2) return fail(DG_ENOMEM, "leaf buffer overflow persists (%llu leaves)", (unsigned long long)nleaf);
+    shard_cap = worst + worst / 4 + 64;
   }
   // ---- group by (query,strand): host exclusive scan of the group sizes
   std::vector<u32> hcnt(ngrp);
@@ -923,15 +980,15 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   DG_HIP(hipEventRecord(ix->ev[3], st));
   if (packed) {
     if (nleaf)
-      hipLaunchKernelGGL(k_group_pack, dim3(ceil_div(nleaf, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(), nleaf, grp_off,
-                         ws[WS_LEAFG].as<PLeaf>());
+      hipLaunchKernelGGL(k_group_pack, dim3(ceil_div((u64)NSHARD * shard_cap, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(),
+                         shard_cap, ctr, grp_off, ws[WS_LEAFG].as<PLeaf>());
     hipLaunchKernelGGL(k_select_packed, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<PLeaf>(), grp_off,
                        ws[WS_SEL].as<Sel>(), nsel, qhits);
   } else {
     DG_TRY(ws[WS_SCR].reserve((nleaf + 1) * 5 + 64));
     if (nleaf)
-      hipLaunchKernelGGL(k_group, dim3(ceil_div(nleaf, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), nleaf, grp_off,
-                         ws[WS_LEAFG].as<Leaf>());
+      hipLaunchKernelGGL(k_group, dim3(ceil_div((u64)NSHARD * shard_cap, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap,
+                         ctr, grp_off, ws[WS_LEAFG].as<Leaf>());
     u32* scr_rank = ws[WS_SCR].as<u32>();
     u8* scr_keep = (u8*)(scr_rank + nleaf + 1);
     hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, ws[WS_SEL].as<Sel>(),
@@ -961,7 +1018,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   DG_HIP(hipEventRecord(ix->ev[5], st));
   if (nhits) {
     hipLaunchKernelGGL(k_locate, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, ws[WS_SEL].as<Sel>(), grp_off, nsel, ngrp,
-                       hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr + 2);
+                       hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr);
   }
   DG_HIP(hipEventRecord(ix->ev[6], st));
   if (nhits) {
@@ -977,15 +1034,14 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
     const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
     const u32 VT = 128;
     if (cells <= 32 * 32)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<32>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr + 3);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<32>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
     else if (cells <= 32 * 160)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr + 3);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr + 3);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
   }
   DG_HIP(hipEventRecord(ix->ev[7], st));
-  unsigned long long hctr[5] = {0, 0, 0, 0, 0};
-  DG_HIP(hipMemcpyAsync(hctr, ctr, 40, hipMemcpyDeviceToHost, st));
+  DG_HIP(hipMemcpyAsync(&hctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
   // per-query metadata always comes back (small)
   R->qflags = new uint32_t[nq];
   R->qdistance = new uint32_t[nq];
@@ -1014,10 +1070,12 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   R->d_refalign = ws[WS_ALN].p;
   R->d_queryalign = ws[WS_ALN].as<char>() + (nhits + 1) * (u64)stride;
   R->ctr_leaves = nleaf;
-  R->ctr_ext_steps = hctr[1];
-  R->ctr_sa_reads = hctr[2];
-  R->ctr_win_bytes = hctr[3];
-  R->ctr_tab_reads = hctr[4];
+  for (u32 k = 0; k < NSHARD; ++k) {
+    R->ctr_ext_steps += hctr.steps[k];
+    R->ctr_tab_reads += hctr.lookups[k];
+    R->ctr_sa_reads += hctr.sa_reads[k];
+    R->ctr_win_bytes += hctr.win_bytes[k];
+  }
   R->ms_total = ev_ms(ix->ev[0], ix->ev[7]);
   R->ms_search = ev_ms(ix->ev[1], ix->ev[2]);
   R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);

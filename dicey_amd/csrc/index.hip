@@ -249,6 +249,18 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
     // 288 GB of HBM are for
     u32 K = 8;
     while (K < 16 && (1ULL << (2 * K)) < n) ++K;
+    // one character more (4x the table, 137 GB at K = 17) when the device has room to spare: a random 17-mer of a
+    // 3.1 Gb genome occurs with p = 0.17 instead of 0.51, so far fewer branches survive the table read
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (1ULL << (2 * K)) < n * 2 &&
+          free_b > ((8ULL << (2 * (K + 1))) + (48ULL << 30)))
+        ++K;
+    }
+    if (const char* ek = std::getenv("DICEY_KMER_K")) {  // tuning knob: force the table order (8..17)
+      int v = std::atoi(ek);
+      if (v >= 8 && v <= 17) K = (u32)v;
+    }
     uint2* tab = nullptr;
     u64 entries = 1ULL << (2 * K);
     DG_HIP(hipMalloc((void**)&tab, entries * sizeof(uint2)));

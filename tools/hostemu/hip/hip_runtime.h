@@ -124,3 +124,7 @@ inline void hostemu_launch(K kernel, dim3 grid, dim3 block, A... args) {
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hostemu_launch(kernel, grid, block, __VA_ARGS__)
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+// lanes run one at a time here: every thread adds its own value
+#define DG_HAVE_WAVE_ADD 1
+namespace dg { inline void wave_add(unsigned long long* p, uint64_t v) { if (v) __atomic_fetch_add(p, (unsigned long long)v, __ATOMIC_RELAXED); } }

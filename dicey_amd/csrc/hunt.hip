@@ -669,7 +669,9 @@ struct VerifyArgs {
   u32 stride;
 };
 
-template <u32 TRACE_WORDS>
+// SMALL = true (all queries of the batch <= 32 nt): the DP row lives in registers (columns fully unrolled) and each
+// row's trace is one 64-bit word (2 bits per column 1..32; column 0 is implied: vertical below the origin).
+template <u32 TRACE_WORDS, bool SMALL>
 __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a, Counters* ctr) {
   u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= a.nhits) return;
@@ -730,6 +732,66 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
   // needle.h:59-138 with AlignConfig<false,true> and DnaScore(0,-1,-1,-1) (hunter.h:383-389):
   // horizontal (gap in the reference row) costs 1 everywhere; vertical (gap in the query row) is free in
   // column 0 and column n; ties prefer horizontal, then vertical, then diagonal.
+  u32 tl = 0;
+  const u32 S = a.stride;
+  if (SMALL) {
+    constexpr int NC = 32;
+    int s[NC + 1];
+    u8 qc[NC];
+    u64 tr[NC + 3 * DMAX + 2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) qc[c] = (u32)c < n ? ascii_of(qseq[c]) : 0;
+#pragma unroll
+    for (int c = 0; c <= NC; ++c) s[c] = -c;
+    for (u32 row = 1; row <= mg; ++row) {
+      const u8 gc = g[row - 1];
+      int diag = 0;  // cell (row-1, 0); s[0] stays 0: vertical gaps are free in column 0
+      u64 bits = 0;
+#pragma unroll
+      for (int c = 1; c <= NC; ++c) {
+        if ((u32)c <= n) {
+          int up = s[c];
+          int dsc = diag + (gc == qc[c - 1] ? 0 : -1);
+          int vsc = up + ((u32)c == n ? 0 : -1);
+          int hsc = s[c - 1] - 1;
+          int best = dsc > vsc ? dsc : vsc;
+          best = best > hsc ? best : hsc;
+          s[c] = best;
+          u64 code = best == hsc ? 1ULL : (best == vsc ? 2ULL : 0ULL);
+          bits |= code << (2 * (c - 1));
+          diag = up;
+        }
+      }
+      tr[row] = bits;
+    }
+    int fin = 0;
+#pragma unroll
+    for (int c = 0; c <= NC; ++c)
+      if ((u32)c == n) fin = s[c];
+    out.score = fin;
+    u32 row = mg, col = n;
+    while (row > 0 || col > 0) {
+      u32 code = col == 0 ? 2u : (row == 0 ? 1u : (u32)(tr[row] >> (2 * (col - 1))) & 3u);
+      char r0, r1;
+      if (code == 1) {
+        --col;
+        r0 = '-';
+        r1 = (char)ascii_of(qseq[col]);
+      } else if (code == 2) {
+        --row;
+        r0 = (char)g[row];
+        r1 = '-';
+      } else {
+        --row;
+        --col;
+        r0 = (char)g[row];
+        r1 = (char)ascii_of(qseq[col]);
+      }
+      ++tl;
+      ra[S - tl] = r0;
+      qa[S - tl] = r1;
+    }
+  } else {
   int s[MAX_QLEN + 1];
   u64 trace[TRACE_WORDS];  // 2 bits per cell: 1 = horizontal, 2 = vertical
   const u32 mf = n + 1;
@@ -760,8 +822,7 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
   }
   out.score = s[n];
   // traceback, columns produced last-to-first; written from the end of the row buffers
-  u32 row = mg, col = n, tl = 0;
-  const u32 S = a.stride;
+  u32 row = mg, col = n;
   while (row > 0 || col > 0) {
     u32 cell = row * mf + col;
     u32 tr = (u32)(trace[cell >> 5] >> ((cell & 31) * 2)) & 3;
@@ -783,6 +844,7 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
     ++tl;
     ra[S - tl] = r0;
     qa[S - tl] = r1;
+  }
   }
   // hunter.h:391-401 + _trailGap :69-77: drop leading columns whose query row is a gap (each advances chrpos)
   // and the trailing run of such columns
@@ -1033,12 +1095,12 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
     va.stride = stride;
     const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
     const u32 VT = 128;
-    if (cells <= 32 * 32)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<32>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
+    if (maxlen <= 32)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
     else if (cells <= 32 * 160)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
   }
   DG_HIP(hipEventRecord(ix->ev[7], st));
   DG_HIP(hipMemcpyAsync(&hctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));

@@ -136,6 +136,8 @@ struct OpStack {
 // is milliseconds once hundreds of thousands of wavefronts report.
 static constexpr u32 NSHARD = 1024;
 struct Counters {
+  u32 overflow;          // set by k_leaf_overflow when a shard's region was too small: later kernels do nothing
+  u32 pad_[15];
   u32 leaf_cnt[NSHARD];  // leaves allocated in each shard's region of the leaf buffer
   unsigned long long steps[NSHARD], lookups[NSHARD], sa_reads[NSHARD], win_bytes[NSHARD];
 };
@@ -336,10 +338,16 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
 }
 
+__global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap) {
+  if (blockIdx.x || threadIdx.x) return;
+  u32 bad = 0;
+  for (u32 k = 0; k < NSHARD; ++k) bad |= ctr->leaf_cnt[k] > shard_cap;
+  ctr->overflow = bad;
+}
 // group leaves by (query,strand): dst = grp_off[qs] + slot
 __global__ void k_group(const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, Leaf* out) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (u64)NSHARD * shard_cap || (u32)(t % shard_cap) >= ctr->leaf_cnt[t / shard_cap]) return;
+  if (ctr->overflow || t >= (u64)NSHARD * shard_cap || (u32)(t % shard_cap) >= ctr->leaf_cnt[t / shard_cap]) return;
   Leaf lf = in[t];
   out[grp_off[lf.qs] + lf.slot] = lf;
 }
@@ -418,7 +426,7 @@ struct PLeaf {
   u64 hi, lo;  // the 128-bit packed string
   u32 len;
   u32 sa_lo, sa_hi;
-  u32 pad;
+  u32 qs;  // 2*query + strand
 };
 DG_DEV void p128_shl(u64& hi, u64& lo, u32 s) {  // s < 128
   if (s >= 64) {
@@ -442,7 +450,7 @@ DG_DEV void p128_topmask(u64& hi, u64& lo, u32 nbits) {  // keep the top nbits (
 // group leaves by (query,strand) and pack their strings: dst = grp_off[qs] + slot
 __global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, PLeaf* out) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (u64)NSHARD * shard_cap || (u32)(t % shard_cap) >= ctr->leaf_cnt[t / shard_cap]) return;
+  if (ctr->overflow || t >= (u64)NSHARD * shard_cap || (u32)(t % shard_cap) >= ctr->leaf_cnt[t / shard_cap]) return;
   Leaf lf = in[t];
   const u64 q = lf.qs >> 1;
   const u8* seq = ((lf.qs & 1) ? b.rv : b.fw) + b.qoff[q];
@@ -467,7 +475,7 @@ __global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Count
   p.len = len;
   p.sa_lo = lf.lo;
   p.sa_hi = lf.hi;
-  p.pad = 0;
+  p.qs = lf.qs;
   out[grp_off[lf.qs] + lf.slot] = p;
 }
 DG_DEV bool pleaf_contains(const PLeaf& a, const PLeaf& x) {  // is x inside a?  (std::string::find)
@@ -482,50 +490,60 @@ DG_DEV bool pleaf_contains(const PLeaf& a, const PLeaf& x) {  // is x inside a? 
 }
 DG_DEV bool pleaf_less(const PLeaf& a, const PLeaf& x) { return a.hi < x.hi || (a.hi == x.hi && a.lo < x.lo); }
 
-// One lane per query, packed strings.  Same contract as k_select below.
-__global__ void k_select_packed(Batch b, const PLeaf* grouped, const u64* grp_off, Sel* sel, u32* nsel, u32* qhits) {
+// Minimal-set filter and ordering with one lane per LEAF (any group size stays parallel):
+//   k_leaf_alive  leaf survives unless another string of its group is a proper substring, or an equal one has a lower slot
+//   k_leaf_rank   rank among the survivors in std::set order -> Sel written at its sorted position
+//   k_take        per query: hunter.h:350,357 gating over forward then reverse strings
+__global__ void k_leaf_alive(const PLeaf* G, const u64* grp_off, u64 nq2, u32 indel, u8* alive, const Counters* ctr) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctr->overflow || t >= grp_off[nq2]) return;
+  bool ok = true;
+  if (indel) {
+    const PLeaf a = G[t];
+    const u64 g0 = grp_off[a.qs], g1 = grp_off[a.qs + 1];
+    for (u64 j = g0; j < g1 && ok; ++j) {
+      if (j == t) continue;
+      const PLeaf x = G[j];
+      if (x.len > a.len) continue;
+      if (pleaf_contains(a, x)) ok = (x.len == a.len) && (t < j);
+    }
+  }
+  alive[t] = ok;
+}
+__global__ void k_leaf_rank(const PLeaf* G, const u64* grp_off, u64 nq2, const u8* alive, Sel* sel, u32* nsel,
+                            const Counters* ctr) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctr->overflow || t >= grp_off[nq2]) return;
+  const PLeaf a = G[t];
+  const u64 g0 = grp_off[a.qs], g1 = grp_off[a.qs + 1];
+  u32 r = 0, ns = 0;
+  for (u64 j = g0; j < g1; ++j) {
+    if (!alive[j]) continue;
+    ++ns;
+    if (j != t && pleaf_less(G[j], a)) ++r;
+  }
+  if (t == g0) nsel[a.qs] = ns;  // groups without leaves keep the 0 of the memset
+  if (!alive[t]) return;
+  Sel s;
+  s.lo = a.sa_lo;
+  s.hi = a.sa_hi;
+  s.len = a.len;
+  s.take = 0;
+  s.hbase = 0;
+  sel[g0 + r] = s;
+}
+__global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u32* qhits, const Counters* ctr) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
+  if (ctr->overflow) {
+    qhits[q] = 0;
+    return;
+  }
   u64 hits = 0;
   for (u32 strand = 0; strand < 2; ++strand) {
-    const u64 g0 = grp_off[2 * q + strand], g1 = grp_off[2 * q + strand + 1];
-    const u32 k = (u32)(g1 - g0);
-    u32 ns = 0;
-    const PLeaf* G = grouped + g0;
-    Sel* S = sel + g0;
-    // pass 1: survivors (no proper substring among the group, first copy of equal strings); pass 2: rank + emit
-    for (u32 i = 0; i < k; ++i) {
-      const PLeaf a = G[i];
-      bool alive = true;
-      if (b.indel)
-        for (u32 j = 0; j < k && alive; ++j) {
-          if (j == i) continue;
-          const PLeaf x = G[j];
-          if (x.len > a.len) continue;
-          if (pleaf_contains(a, x)) alive = (x.len == a.len) && (i < j);
-        }
-      S[i].take = alive;  // scratch use of the output slot until pass 2 has read it
-      ns += alive;
-    }
-    // rank among survivors (std::set order); survivors are few, so recompute liveness flags from S[].take
-    // pass 2 writes into sel in rank order; to stay in place it first collects ranks in S[i].hbase
-    for (u32 i = 0; i < k; ++i) {
-      if (!S[i].take) continue;
-      const PLeaf a = G[i];
-      u32 r = 0;
-      for (u32 j = 0; j < k; ++j)
-        if (j != i && S[j].take && pleaf_less(G[j], a)) ++r;
-      S[i].hbase = r;
-    }
-    // permute: position r receives the survivor whose rank is r (lo/hi/len fields are free until now)
-    for (u32 i = 0; i < k; ++i)
-      if (S[i].take) {
-        u32 r = S[i].hbase;
-        S[r].lo = G[i].sa_lo;
-        S[r].hi = G[i].sa_hi;
-        S[r].len = G[i].len;
-      }
-    for (u32 r = 0; r < ns; ++r) {  // hunter.h:350,357
+    Sel* S = sel + grp_off[2 * q + strand];
+    const u32 ns = nsel[2 * q + strand];
+    for (u32 r = 0; r < ns; ++r) {
       u64 occs = (u64)S[r].hi - S[r].lo;
       u64 take = 0;
       if (hits < b.max_locations) take = occs < b.max_locations - hits ? occs : b.max_locations - hits;
@@ -533,17 +551,71 @@ __global__ void k_select_packed(Batch b, const PLeaf* grouped, const u64* grp_of
       S[r].hbase = (u32)hits;
       hits += take;
     }
-    nsel[2 * q + strand] = ns;
   }
   qhits[q] = (u32)hits;
-  if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;
+  if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
+}
+
+// Exclusive prefix sum of n 32-bit counts into 64-bit offsets (out[n] = total), lane-independent three-level scheme so
+// that no host round trip is needed between the kernels of a batch.
+static constexpr u32 SCAN_CHUNK = 64;
+__global__ void k_scan_sum(const u32* in, u64 n, u64* part) {  // part[c] = sum of chunk c
+  u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 b0 = c * SCAN_CHUNK;
+  if (b0 >= n) return;
+  u64 e = b0 + SCAN_CHUNK < n ? b0 + SCAN_CHUNK : n, s = 0;
+  for (u64 i = b0; i < e; ++i) s += in[i];
+  part[c] = s;
+}
+__global__ void k_scan_sum64(const u64* in, u64 n, u64* part) {
+  u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 b0 = c * SCAN_CHUNK;
+  if (b0 >= n) return;
+  u64 e = b0 + SCAN_CHUNK < n ? b0 + SCAN_CHUNK : n, s = 0;
+  for (u64 i = b0; i < e; ++i) s += in[i];
+  part[c] = s;
+}
+__global__ void k_scan_top(u64* part, u64 n, u64* total) {  // one lane: exclusive scan of <= a few thousand values
+  if (blockIdx.x || threadIdx.x) return;
+  u64 run = 0;
+  for (u64 i = 0; i < n; ++i) {
+    u64 v = part[i];
+    part[i] = run;
+    run += v;
+  }
+  *total = run;
+}
+__global__ void k_scan_apply64(u64* vals, u64 n, const u64* base) {  // vals: chunk sums -> exclusive offsets
+  u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 b0 = c * SCAN_CHUNK;
+  if (b0 >= n) return;
+  u64 e = b0 + SCAN_CHUNK < n ? b0 + SCAN_CHUNK : n, run = base[c];
+  for (u64 i = b0; i < e; ++i) {
+    u64 v = vals[i];
+    vals[i] = run;
+    run += v;
+  }
+}
+__global__ void k_scan_apply(const u32* in, u64 n, const u64* base, u64* out) {
+  u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 b0 = c * SCAN_CHUNK;
+  if (b0 >= n) return;
+  u64 e = b0 + SCAN_CHUNK < n ? b0 + SCAN_CHUNK : n, run = base[c];
+  for (u64 i = b0; i < e; ++i) {
+    out[i] = run;
+    run += in[i];
+  }
 }
 
 // One lane per query.  Works in place on the grouped leaf array: `keep` marks survivors, `order` their rank.
 __global__ void k_select(Batch b, const Leaf* grouped, const u64* grp_off, Sel* sel, u32* nsel /*[2nq]*/, u32* qhits,
-                         u8* scratch_keep, u32* scratch_rank) {
+                         u8* scratch_keep, u32* scratch_rank, const Counters* ctr) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
+  if (ctr->overflow) {
+    qhits[q] = 0;
+    return;
+  }
   const u32 m = b.qlen[q];
   u64 hits = 0;
   for (u32 strand = 0; strand < 2; ++strand) {
@@ -613,9 +685,9 @@ struct HitSeed {
   u32 len;  // its length
 };
 __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32* nsel, u64 ngroups, const u64* hit_off,
-                         HitSeed* seeds, Counters* ctr) {
+                         HitSeed* seeds, Counters* ctr, u64 hit_cap) {
   u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // g = 2*query + strand
-  if (g >= ngroups) return;
+  if (g >= ngroups || ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
   const Sel* S = sel + grp_off[g];
   u64 reads = 0;
   const u32 ns = nsel[g];
@@ -660,7 +732,8 @@ __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32
 // Verify: one lane per hit.
 struct VerifyArgs {
   const HitSeed* seeds;
-  u64 nhits;
+  const u64* nhits;  // on the device: hit_off[nq]
+  u64 hit_cap;
   const u64* cum;  // cum[r] = sum of seqlen[0..r)
   u32 nseq;
   dg_hit* hits;
@@ -674,7 +747,8 @@ struct VerifyArgs {
 template <u32 TRACE_WORDS, bool SMALL>
 __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a, Counters* ctr) {
   u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= a.nhits) return;
+  const u64 nh = *a.nhits;
+  if (ctr->overflow || nh > a.hit_cap || h >= nh) return;
   const HitSeed sd = a.seeds[h];
   const u64 q = sd.qs >> 1;
   const u32 strand = sd.qs & 1;
@@ -907,10 +981,24 @@ static u64 neighbourhood_bound(u32 m, u32 d, bool indel) {
   return ~0ULL;
 }
 
+static int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* tmp) {
+  const u64 n1 = (n + SCAN_CHUNK - 1) / SCAN_CHUNK, n2 = (n1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  u64* p1 = tmp;
+  u64* p2 = tmp + n1;
+  const u32 TB = 128;
+  hipLaunchKernelGGL(k_scan_sum, dim3(ceil_div(n1, TB)), dim3(TB), 0, st, in, n, p1);
+  hipLaunchKernelGGL(k_scan_sum64, dim3(ceil_div(n2, TB)), dim3(TB), 0, st, (const u64*)p1, n1, p2);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, st, p2, n2, out + n);
+  hipLaunchKernelGGL(k_scan_apply64, dim3(ceil_div(n2, TB)), dim3(TB), 0, st, p1, n1, (const u64*)p2);
+  hipLaunchKernelGGL(k_scan_apply, dim3(ceil_div(n1, TB)), dim3(TB), 0, st, in, n, (const u64*)p1, out);
+  return DG_OK;
+}
+
+// One batch through the five kernels.  All sizes that are only known on the device (number of leaves, number of hits)
+// are handled with capacity guesses that the kernels check themselves; the host synchronises ONCE at the end, and
+// repeats the batch with larger buffers in the rare case a capacity was exceeded.
 static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
-                     const void* d_qoff, size_t nq, u64 total, u32 maxlen, u32 minlen, int fetch, const u8* h_qbytes_unused,
-                     dg_hunt_result** out) {
-  (void)h_qbytes_unused;
+                     const void* d_qoff, size_t nq, u64 total, u32 maxlen, int fetch, dg_hunt_result** out) {
   if (!p->max_locations) return fail(DG_EINVAL, "max_locations must be positive");
   if (nseq == 0) return fail(DG_EINVAL, "no reference sequences");
   const bool indel = !p->hamming;
@@ -926,18 +1014,21 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
                   "the reference's capped enumeration is order dependent and is not reproduced by this build",
                   p->max_neighborhood, maxlen, dmax_eff, (unsigned long long)bound);
   }
-  (void)minlen;
   DG_HIP(hipSetDevice(ix->device));
   hipStream_t st = ix->stream;
   for (int i = 0; i < 8; ++i)
     if (!ix->ev[i]) DG_HIP(hipEventCreate(&ix->ev[i]));
   auto& ws = ix->ws;
   const u64 ngrp = 2 * (u64)nq;
+  const u32 TB = 256;
+  const bool packed = maxlen + dmax_eff <= PACK_MAX_LEN;  // every neighbourhood string fits 128 bits
+  const u32 stride = ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
+  const u64 scan_tmp = ngrp / SCAN_CHUNK + ngrp / (SCAN_CHUNK * SCAN_CHUNK) + 64;
   DG_TRY(ws[WS_FW].reserve(total + 8));
   DG_TRY(ws[WS_RV].reserve(total + 8));
   DG_TRY(ws[WS_QSEQ].reserve(total + 8));
   DG_TRY(ws[WS_QMETA].reserve(nq * 16 + 64));
-  DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + ngrp * 4 * 2 + nq * 4 + (nq + 1) * 8 + 256));
+  DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 2 + nq * 4 + scan_tmp * 8 + 256));
   DG_TRY(ws[WS_MISC].reserve(sizeof(Counters)));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   Batch b;
@@ -956,12 +1047,13 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   b.indel = indel;
   b.reverse = !p->forward_only;
   b.max_locations = p->max_locations;
-  // group bookkeeping carved out of one buffer
   u8* gp = ws[WS_GRP].as<u8>();
   u64* grp_off = (u64*)gp;
   gp += (ngrp + 1) * 8;
   u64* hit_off = (u64*)gp;
   gp += (nq + 1) * 8;
+  u64* scan_buf = (u64*)gp;
+  gp += scan_tmp * 8;
   u32* grp_cnt = (u32*)gp;
   gp += ngrp * 4;
   u32* nsel = (u32*)gp;
@@ -977,17 +1069,28 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
     run += seqlen[r];
   }
   DG_HIP(hipMemcpyAsync(ws[WS_CUM].p, cum.data(), (u64)nseq * 8, hipMemcpyHostToDevice, st));
-  DG_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
 
-  const u32 TB = 256;
-  DG_HIP(hipEventRecord(ix->ev[0], st));
-  hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b);
-  // ---- search (retry with larger leaf regions if a shard overflowed)
-  u32 shard_cap = (u32)std::max<u64>(64, (16 * (u64)nq) / NSHARD);
-  u64 nleaf = 0;
+  u32 shard_cap = std::max<u32>(ix->shard_cap_hint, (u32)std::max<u64>(64, (16 * (u64)nq) / NSHARD));
+  u64 hit_cap = std::max<u64>(ix->hit_cap_hint, 4 * (u64)nq + 1024);
+  if (const char* e = std::getenv("DICEY_DEBUG_CAPS")) {  // tests: start from tiny capacities to exercise the retry path
+    shard_cap = (u32)std::max(1, std::atoi(e));
+    hit_cap = (u64)std::max(1, std::atoi(e));
+  }
+  u64 nleaf = 0, nhits = 0;
   for (int attempt = 0;; ++attempt) {
-    DG_TRY(ws[WS_LEAF].reserve((u64)NSHARD * shard_cap * sizeof(Leaf)));
+    if (attempt > 4) return fail(DG_ENOMEM, "buffer overflow persists (%llu leaves, %llu hits)", (unsigned long long)nleaf, (unsigned long long)nhits);
+    const u64 leaf_slots = (u64)NSHARD * shard_cap;
+    DG_TRY(ws[WS_LEAF].reserve(leaf_slots * sizeof(Leaf)));
+    DG_TRY(ws[WS_LEAFG].reserve((leaf_slots + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
+    DG_TRY(ws[WS_SEL].reserve((leaf_slots + 1) * sizeof(Sel)));
+    DG_TRY(ws[WS_SCR].reserve((leaf_slots + 1) * 5 + 64));
+    DG_TRY(ws[WS_SEEDS].reserve((hit_cap + 1) * sizeof(HitSeed)));
+    DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
+    DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
     DG_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
+    DG_HIP(hipMemsetAsync(grp_cnt, 0, ngrp * 4 * 2, st));  // grp_cnt and nsel are adjacent
+    DG_HIP(hipEventRecord(ix->ev[0], st));
+    hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b);
     DG_HIP(hipEventRecord(ix->ev[1], st));
     {
       SearchOut so;
@@ -997,7 +1100,6 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
       so.grp_cnt = grp_cnt;
       // root-level work split (see k_search): only with the table and with at least one edit to place
       const u32 items = (ix->view.K && dmax_eff >= 1) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
-      DG_HIP(hipMemsetAsync(grp_cnt, 0, ngrp * 4, st));
       const dim3 grid(ceil_div(ngrp * items, TB)), block(TB);
 #define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so, items)
       if (indel) {
@@ -1014,8 +1116,54 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
 #undef DG_LAUNCH_SEARCH
     }
     DG_HIP(hipEventRecord(ix->ev[2], st));
-    DG_HIP(hipMemcpyAsync(hctr.leaf_cnt, ctr->leaf_cnt, sizeof hctr.leaf_cnt, hipMemcpyDeviceToHost, st));
-    DG_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_leaf_overflow, dim3(1), dim3(64), 0, st, ctr, shard_cap);
+    DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf));
+    DG_HIP(hipEventRecord(ix->ev[3], st));
+    if (packed) {
+      u8* alive = ws[WS_SCR].as<u8>();
+      hipLaunchKernelGGL(k_group_pack, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr,
+                         grp_off, ws[WS_LEAFG].as<PLeaf>());
+      hipLaunchKernelGGL(k_leaf_alive, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
+                         (u32)indel, alive, ctr);
+      hipLaunchKernelGGL(k_leaf_rank, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
+                         (const u8*)alive, ws[WS_SEL].as<Sel>(), nsel, ctr);
+      hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_off, nsel, ws[WS_SEL].as<Sel>(), qhits, ctr);
+    } else {
+      hipLaunchKernelGGL(k_group, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr, grp_off,
+                         ws[WS_LEAFG].as<Leaf>());
+      u32* scr_rank = ws[WS_SCR].as<u32>();
+      u8* scr_keep = (u8*)(scr_rank + leaf_slots + 1);
+      hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, ws[WS_SEL].as<Sel>(),
+                         nsel, qhits, scr_keep, scr_rank, ctr);
+    }
+    DG_HIP(hipEventRecord(ix->ev[4], st));
+    DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
+    DG_HIP(hipEventRecord(ix->ev[5], st));
+    hipLaunchKernelGGL(k_locate, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, ws[WS_SEL].as<Sel>(), grp_off, nsel, ngrp,
+                       hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap);
+    DG_HIP(hipEventRecord(ix->ev[6], st));
+    {
+      VerifyArgs va;
+      va.seeds = ws[WS_SEEDS].as<HitSeed>();
+      va.nhits = hit_off + nq;
+      va.hit_cap = hit_cap;
+      va.cum = ws[WS_CUM].as<u64>();
+      va.nseq = nseq;
+      va.hits = ws[WS_HITS].as<dg_hit>();
+      va.refalign = ws[WS_ALN].as<char>();
+      va.queryalign = ws[WS_ALN].as<char>() + (hit_cap + 1) * (u64)stride;
+      va.stride = stride;
+      const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
+      const u32 VT = 128;
+      const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
+      if (maxlen <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      else if (cells <= 32 * 160) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+    }
+    DG_HIP(hipEventRecord(ix->ev[7], st));
+    DG_HIP(hipMemcpyAsync(&hctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(&nhits, hit_off + nq, 8, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
     DG_HIP(hipGetLastError());
     nleaf = 0;
     u32 worst = 0;
@@ -1023,114 +1171,53 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
       nleaf += hctr.leaf_cnt[k];
       worst = std::max(worst, hctr.leaf_cnt[k]);
     }
-    if (worst <= shard_cap) break;
-    if (attempt > 2) return fail(DG_ENOMEM, "leaf buffer overflow persists (%llu leaves)", (unsigned long long)nleaf);
-    shard_cap = worst + worst / 4 + 64;
+    if (worst > shard_cap) {
+      shard_cap = worst + worst / 4 + 64;
+      continue;
+    }
+    if (nhits > hit_cap) {
+      hit_cap = nhits + nhits / 4 + 1024;
+      continue;
+    }
+    break;
   }
-  // ---- group by (query,strand): host exclusive scan of the group sizes
-  std::vector<u32> hcnt(ngrp);
-  std::vector<u64> hoff(ngrp + 1);
-  DG_HIP(hipMemcpyAsync(hcnt.data(), grp_cnt, ngrp * 4, hipMemcpyDeviceToHost, st));
-  DG_HIP(hipStreamSynchronize(st));
-  hoff[0] = 0;
-  for (u64 g = 0; g < ngrp; ++g) hoff[g + 1] = hoff[g] + hcnt[g];
-  if (hoff[ngrp] != nleaf) return fail(DG_EHIP, "internal: leaf accounting mismatch (%llu vs %llu)", (unsigned long long)hoff[ngrp], (unsigned long long)nleaf);
-  DG_HIP(hipMemcpyAsync(grp_off, hoff.data(), (ngrp + 1) * 8, hipMemcpyHostToDevice, st));
-  const bool packed = maxlen + dmax_eff <= PACK_MAX_LEN;  // every neighbourhood string fits 128 bits
-  DG_TRY(ws[WS_LEAFG].reserve((nleaf + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
-  DG_TRY(ws[WS_SEL].reserve((nleaf + 1) * sizeof(Sel)));
-  DG_HIP(hipEventRecord(ix->ev[3], st));
-  if (packed) {
-    if (nleaf)
-      hipLaunchKernelGGL(k_group_pack, dim3(ceil_div((u64)NSHARD * shard_cap, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(),
-                         shard_cap, ctr, grp_off, ws[WS_LEAFG].as<PLeaf>());
-    hipLaunchKernelGGL(k_select_packed, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<PLeaf>(), grp_off,
-                       ws[WS_SEL].as<Sel>(), nsel, qhits);
-  } else {
-    DG_TRY(ws[WS_SCR].reserve((nleaf + 1) * 5 + 64));
-    if (nleaf)
-      hipLaunchKernelGGL(k_group, dim3(ceil_div((u64)NSHARD * shard_cap, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap,
-                         ctr, grp_off, ws[WS_LEAFG].as<Leaf>());
-    u32* scr_rank = ws[WS_SCR].as<u32>();
-    u8* scr_keep = (u8*)(scr_rank + nleaf + 1);
-    hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, ws[WS_SEL].as<Sel>(),
-                       nsel, qhits, scr_keep, scr_rank);
-  }
-  DG_HIP(hipEventRecord(ix->ev[4], st));
-  std::vector<u32> hq(nq);
-  DG_HIP(hipMemcpyAsync(hq.data(), qhits, nq * 4, hipMemcpyDeviceToHost, st));
-  DG_HIP(hipStreamSynchronize(st));
-  DG_HIP(hipGetLastError());
+  ix->shard_cap_hint = shard_cap;
+  ix->hit_cap_hint = std::max<u64>(ix->hit_cap_hint, nhits + nhits / 4 + 1024);
+
   dg_hunt_result* R = new dg_hunt_result;
   std::memset(R, 0, sizeof *R);
   R->nq = nq;
-  R->hit_off = new uint64_t[nq + 1];
-  R->hit_off[0] = 0;
-  for (size_t q = 0; q < nq; ++q) R->hit_off[q + 1] = R->hit_off[q] + hq[q];
-  const u64 nhits = R->hit_off[nq];
   R->nhits = nhits;
-  *out = R;
-  DG_HIP(hipMemcpyAsync(hit_off, R->hit_off, (nq + 1) * 8, hipMemcpyHostToDevice, st));
-  // ---- locate + verify
-  const u32 stride = ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
   R->aln_stride = stride;
-  DG_TRY(ws[WS_SEEDS].reserve((nhits + 1) * sizeof(HitSeed)));
-  DG_TRY(ws[WS_HITS].reserve((nhits + 1) * sizeof(dg_hit)));
-  DG_TRY(ws[WS_ALN].reserve((nhits + 1) * 2 * (u64)stride));
-  DG_HIP(hipEventRecord(ix->ev[5], st));
-  if (nhits) {
-    hipLaunchKernelGGL(k_locate, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, ws[WS_SEL].as<Sel>(), grp_off, nsel, ngrp,
-                       hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr);
-  }
-  DG_HIP(hipEventRecord(ix->ev[6], st));
-  if (nhits) {
-    VerifyArgs va;
-    va.seeds = ws[WS_SEEDS].as<HitSeed>();
-    va.nhits = nhits;
-    va.cum = ws[WS_CUM].as<u64>();
-    va.nseq = nseq;
-    va.hits = ws[WS_HITS].as<dg_hit>();
-    va.refalign = ws[WS_ALN].as<char>();
-    va.queryalign = ws[WS_ALN].as<char>() + (nhits + 1) * (u64)stride;
-    va.stride = stride;
-    const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
-    const u32 VT = 128;
-    if (maxlen <= 32)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
-    else if (cells <= 32 * 160)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), dim3(ceil_div(nhits, VT)), dim3(VT), 0, st, ix->view, b, va, ctr);
-  }
-  DG_HIP(hipEventRecord(ix->ev[7], st));
-  DG_HIP(hipMemcpyAsync(&hctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
-  // per-query metadata always comes back (small)
-  R->qflags = new uint32_t[nq];
-  R->qdistance = new uint32_t[nq];
-  R->qnondna = new uint32_t[nq];
-  DG_HIP(hipMemcpyAsync(R->qdistance, b.qdist, nq * 4, hipMemcpyDeviceToHost, st));
-  DG_HIP(hipMemcpyAsync(R->qflags, b.qflags, nq * 4, hipMemcpyDeviceToHost, st));
-  DG_HIP(hipMemcpyAsync(R->qnondna, b.qnondna, nq * 4, hipMemcpyDeviceToHost, st));
+  *out = R;
   if (fetch) {
+    R->hit_off = new uint64_t[nq + 1];
+    R->qflags = new uint32_t[nq];
+    R->qdistance = new uint32_t[nq];
+    R->qnondna = new uint32_t[nq];
     R->hits = new dg_hit[nhits ? nhits : 1];
     R->refalign = new char[(nhits ? nhits : 1) * (u64)stride];
     R->queryalign = new char[(nhits ? nhits : 1) * (u64)stride];
     R->qseq = new uint8_t[total ? total : 1];
     R->qoff = new uint64_t[nq + 1];
+    DG_HIP(hipMemcpyAsync(R->hit_off, hit_off, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(R->qdistance, b.qdist, nq * 4, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(R->qflags, b.qflags, nq * 4, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(R->qnondna, b.qnondna, nq * 4, hipMemcpyDeviceToHost, st));
     if (nhits) {
       DG_HIP(hipMemcpyAsync(R->hits, ws[WS_HITS].p, nhits * sizeof(dg_hit), hipMemcpyDeviceToHost, st));
       DG_HIP(hipMemcpyAsync(R->refalign, ws[WS_ALN].p, nhits * (u64)stride, hipMemcpyDeviceToHost, st));
-      DG_HIP(hipMemcpyAsync(R->queryalign, ws[WS_ALN].as<char>() + (nhits + 1) * (u64)stride, nhits * (u64)stride,
+      DG_HIP(hipMemcpyAsync(R->queryalign, ws[WS_ALN].as<char>() + (hit_cap + 1) * (u64)stride, nhits * (u64)stride,
                             hipMemcpyDeviceToHost, st));
     }
     if (total) DG_HIP(hipMemcpyAsync(R->qseq, b.qseq, total, hipMemcpyDeviceToHost, st));
     DG_HIP(hipMemcpyAsync(R->qoff, d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipStreamSynchronize(st));
+    DG_HIP(hipGetLastError());
   }
-  DG_HIP(hipStreamSynchronize(st));
-  DG_HIP(hipGetLastError());
   R->d_hits = ws[WS_HITS].p;
   R->d_refalign = ws[WS_ALN].p;
-  R->d_queryalign = ws[WS_ALN].as<char>() + (nhits + 1) * (u64)stride;
+  R->d_queryalign = ws[WS_ALN].as<char>() + (hit_cap + 1) * (u64)stride;
   R->ctr_leaves = nleaf;
   for (u32 k = 0; k < NSHARD; ++k) {
     R->ctr_ext_steps += hctr.steps[k];
@@ -1185,7 +1272,7 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
   DG_TRY(ix->ws[WS_QOFF].reserve((nq + 1) * 8));
   if (total) DG_HIP(hipMemcpyAsync(ix->ws[WS_QB].p, qbytes, total, hipMemcpyHostToDevice, ix->stream));
   DG_HIP(hipMemcpyAsync(ix->ws[WS_QOFF].p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
-  int rc = run_batch(ix, p, seqlen, nseq, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, minlen, 1, qbytes, out);
+  int rc = run_batch(ix, p, seqlen, nseq, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, 1, out);
   if (rc != DG_OK && *out) {
     dg_hunt_result_free(*out);
     *out = nullptr;
@@ -1212,7 +1299,7 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     maxlen = std::max<u32>(maxlen, (u32)l);
     minlen = std::min<u32>(minlen, (u32)l);
   }
-  int rc = run_batch(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, maxlen, minlen, fetch, nullptr, out);
+  int rc = run_batch(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, maxlen, fetch, out);
   if (rc != DG_OK && *out) {
     dg_hunt_result_free(*out);
     *out = nullptr;

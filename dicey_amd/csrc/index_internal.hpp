@@ -16,5 +16,7 @@ struct dg_index {
   static constexpr int NWS = 16;
   dg::DevBuf ws[NWS];
   hipEvent_t ev[8] = {nullptr};
+  uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
+  uint64_t hit_cap_hint = 0;
   ~dg_index();
 };

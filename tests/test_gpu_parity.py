@@ -161,3 +161,14 @@ def test_gpu_builder_handles_long_repeats(tmp_path):
     dicey_amd.build_index(text, a)
     O.build_fm9(text, b)
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_capacity_retry_path(small_genome, monkeypatch):
+    """Leaf regions and hit buffers start from guesses the kernels check themselves; a batch that overflows them is
+    repeated with larger buffers and must give the same answer."""
+    import dicey_amd
+    monkeypatch.setenv("DICEY_DEBUG_CAPS", "2")
+    orc = O.Index(small_genome["fm9"])
+    with dicey_amd.FmIndex(small_genome["fm9"]) as ix:
+        qs = make_queries(77, small_genome["text"], 400)
+        _compare(ix, orc, small_genome, qs, distance=1)

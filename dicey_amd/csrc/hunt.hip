@@ -974,9 +974,15 @@ static u64 neighbourhood_bound(u32 m, u32 d, bool indel) {
   if (d == 0) return 1;
   if (d == 1) return 7ULL * m + 5;  // 1 + 3m substitutions + m deletions + (3m+4) insertions
   if (d == 2) {
-    u64 ss = binom(m, 2) * 9, dd = binom(m, 2), ii = 1 + 3ULL * (m + 2) + 9 * binom(m + 2, 2);
-    u64 sd = 3ULL * m * (m - 1), si = 3ULL * m * (3ULL * m + 4), di = (u64)m * (3ULL * (m - 1) + 4);
-    return ss + dd + ii + sd + si + di + 7ULL * m + 5;
+    // Distinct strings within two edits, by length class (DESIGN.md "neighbourhood size bound"); M = m-1 is the query
+    // without its last character, which every string of L must still align to (no insertion after the last column).
+    const u64 M = m - 1;
+    u64 len_m2 = binom(m, 2);                                              // two deletions
+    u64 len_m1 = m + 3ULL * m * (m - 1);                                   // D, D+S
+    u64 len_0 = 1 + 3ULL * m + 9 * binom(m, 2) + m * (3ULL * (m - 1) + 4) - (3ULL * m + 1);  // q, S, SS, D+I (q and S counted once)
+    u64 len_p1 = (3 * M + 4) * (1 + 3 * M) - 6 * M - 3 * M + 3 * (3 * M + 4);  // I, I+S; last column M or S
+    u64 len_p2 = 1 + 3 * (m + 1) + 9 * binom(m + 1, 2);                    // supersequences of q[0..m-1) of length m+1, then q[m-1]
+    return len_m2 + len_m1 + len_0 + len_p1 + len_p2;
   }
   return ~0ULL;
 }

@@ -100,7 +100,7 @@ def test_hunt_edge_cases(gpu_small, small_genome):
 def test_unsupported_envelope_fails_loudly(gpu_small, small_genome):
     import dicey_amd
     with pytest.raises(dicey_amd.DgError):
-        gpu_small.hunt(["ACGT" * 5], small_genome["seqlen"], distance=2)  # cap cannot be proven silent -> DG_ELIMIT
+        gpu_small.hunt(["ACGT" * 5 + "A"], small_genome["seqlen"], distance=2)  # 21-mer, d=2: cap not provably silent
     with pytest.raises(dicey_amd.DgError):
         gpu_small.hunt(["ACGTACGTACGT"], small_genome["seqlen"], distance=30)
 
@@ -172,3 +172,12 @@ def test_capacity_retry_path(small_genome, monkeypatch):
     with dicey_amd.FmIndex(small_genome["fm9"]) as ix:
         qs = make_queries(77, small_genome["text"], 400)
         _compare(ix, orc, small_genome, qs, distance=1)
+
+
+def test_hunt_edit_distance_two(gpu_small, small_genome):
+    """BASELINE configs[3] shape (20-mers, edit distance 2) on a handful of queries — the oracle's neighbors() needs
+    seconds per 20-mer at d=2, exactly like the reference."""
+    orc = O.Index(small_genome["fm9"])
+    for n, m in ((10, 12), (6, 15), (4, 20)):
+        qs = [q[:m] for q in make_queries(200 + m, small_genome["text"], 4 * n, (m,)) if len(q) >= m][:n]
+        _compare(gpu_small, orc, small_genome, qs, distance=2)

@@ -278,12 +278,14 @@ def main():
                                  f"frequencies, 5% N runs, seed 1 (no real genome is available offline)",
                        "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
                        "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_search<true,1>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": f"k_search<true,{a.distance}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "ext_steps_per_launch": ext,
                          "bytes_per_ext_step": BYTES_PER_EXT, "table_reads_per_launch": tab,
                          "bytes_per_table_read": BYTES_PER_TAB_READ, "kernel_ms": ms_search,
-                         "index_lines_per_s": (2 * ext + tab) / (ms_search * 1e-3) if ms_search > 0 else 0.0},
+                         "index_lines_per_s": (2 * ext + tab) / (ms_search * 1e-3) if ms_search > 0 else 0.0,
+                         "gather_ceiling_note": "random 64-B lines over >=16 GiB top out at 19 G lines/s = 1.2 TB/s on this chip "
+                                                "(profiles/r01b_gather_bench.jsonl); this kernel is a gather, not a stream"},
             "cpu_baseline": cpu,
             "parity_sample": parity,
             "phases_ms": {k: float(np.mean([r[k] for r in acc])) for k in ("ms_total", "ms_search", "ms_select", "ms_locate", "ms_verify")},

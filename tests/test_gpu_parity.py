@@ -181,3 +181,29 @@ def test_hunt_edit_distance_two(gpu_small, small_genome):
     for n, m in ((10, 12), (6, 15), (4, 20)):
         qs = [q[:m] for q in make_queries(200 + m, small_genome["text"], 4 * n, (m,)) if len(q) >= m][:n]
         _compare(gpu_small, orc, small_genome, qs, distance=2)
+
+
+def test_device_pointer_view_for_the_rccl_gather(gpu_small, small_genome):
+    """bench.py hands the hit records to torch.distributed as views of libdiceygpu's device buffers."""
+    import ctypes as C
+    import torch
+    from dicey_amd import _capi
+    from dicey_amd.shard import device_bytes
+    L = _capi.load()
+    qs = make_queries(5, small_genome["text"], 50)
+    qb = b"".join(q.encode() for q in qs)
+    off = [0]
+    for q in qs:
+        off.append(off[-1] + len(q))
+    d_q = torch.frombuffer(bytearray(qb), dtype=torch.uint8).cuda()
+    d_off = torch.tensor(off, dtype=torch.int64).cuda()
+    sl = (C.c_uint32 * 3)(*small_genome["seqlen"])
+    p = _capi.HuntParams(1, 0, 0, 1000, 10000)
+    rp = C.POINTER(_capi.HuntResult)()
+    _capi.check(L, L.dg_hunt_device(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()),
+                                    len(qs), len(qb), 1, C.byref(rp)))
+    R = rp.contents
+    hb = device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), torch.device("cuda", 0))
+    host = bytes(C.string_at(C.addressof(R.hits.contents), R.nhits * C.sizeof(_capi.Hit)))
+    assert R.nhits > 0 and bytes(hb.cpu().numpy().tobytes()) == host
+    L.dg_hunt_result_free(rp)

@@ -122,18 +122,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fm9", default="", help="reuse an existing index file instead of building the synthetic one")
     ap.add_argument("--keep-index", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.same_device:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -197,7 +205,8 @@ def main():
             hb = device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), dev)
             ra = device_bytes(R.d_refalign, R.nhits * R.aln_stride, dev)
             qa = device_bytes(R.d_queryalign, R.nhits * R.aln_stride, dev)
-            got = gather_bytes(torch.cat([hb, ra, qa]), dst=0)
+            payload = torch.cat([hb, ra, qa])
+            got = gather_bytes(payload if a.backend == "nccl" else payload.cpu(), dst=0)
             if rank == 0:
                 res["gathered_bytes"] = sum(int(g.numel()) for g in got)
         L.dg_hunt_result_free(rp)
@@ -213,7 +222,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -684,8 +684,12 @@ struct HitSeed {
   u32 qs;
   u32 len;  // its length
 };
+struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_big
+  u32 lo, occs, take, g, len;
+  u64 out;  // first hit slot
+};
 __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32* nsel, u64 ngroups, const u64* hit_off,
-                         HitSeed* seeds, Counters* ctr, u64 hit_cap) {
+                         HitSeed* seeds, Counters* ctr, u64 hit_cap, BigJob* jobs, u32 job_cap, u32* job_count) {
   u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // g = 2*query + strand
   if (g >= ngroups || ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
   const Sel* S = sel + grp_off[g];
@@ -708,8 +712,21 @@ __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32
       }
       reads += occs;
       for (u32 i = 0; i < take; ++i) out[i] = HitSeed{v[i], (u32)g, S[r].len};
+    } else if (jobs && take <= 16384) {
+      // repeat-rich string: a whole workgroup selects and sorts (k_locate_big)
+      u32 j = atomicAdd(job_count, 1u);
+      if (j < job_cap) {
+        BigJob bj;
+        bj.lo = lo;
+        bj.occs = occs;
+        bj.take = take;
+        bj.g = (u32)g;
+        bj.len = S[r].len;
+        bj.out = hit_off[g >> 1] + S[r].hbase;
+        jobs[j] = bj;
+      }
     } else {
-      // repeat-rich string: selection by repeated minimum above the previous pick (positions are distinct)
+      // fallback: selection by repeated minimum above the previous pick (positions are distinct)
       u64 prev = 0;
       bool first = true;
       for (u32 i = 0; i < take; ++i) {
@@ -726,6 +743,73 @@ __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32
     }
   }
   if (reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
+}
+
+// One workgroup per repeat-rich string: radix-select the take-th smallest suffix-array value (32 counting passes over
+// the interval, coalesced), collect everything up to it, bitonic-sort the <= 16384 survivors in LDS.
+__global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds,
+                                                    Counters* ctr) {
+  __shared__ u32 buf[16384];
+  __shared__ u32 red[256];
+  __shared__ u32 fill;
+  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+  for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
+    const BigJob J = jobs[jb];
+    const u32* sa = f.sa + J.lo;
+    u32 prefix = 0, k = J.take - 1;  // rank of the largest value we keep
+    for (int bit = 31; bit >= 0; --bit) {
+      u32 c0 = 0;
+      const u32 hi_mask = bit == 31 ? 0u : ~0u << (bit + 1);
+      for (u32 i = threadIdx.x; i < J.occs; i += blockDim.x) {
+        u32 x = sa[i];
+        c0 += ((x & hi_mask) == (prefix & hi_mask)) && !((x >> bit) & 1);
+      }
+      red[threadIdx.x] = c0;
+      __syncthreads();
+      for (u32 s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+      }
+      c0 = red[0];
+      __syncthreads();
+      if (k >= c0) {
+        k -= c0;
+        prefix |= 1u << bit;
+      }
+    }
+    // prefix is now the take-th smallest value; positions are distinct, so exactly `take` values are <= prefix
+    if (threadIdx.x == 0) fill = 0;
+    u32 n2 = 1;
+    while (n2 < J.take) n2 <<= 1;
+    for (u32 i = threadIdx.x; i < n2; i += blockDim.x) buf[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < J.occs; i += blockDim.x) {
+      u32 x = sa[i];
+      if (x <= prefix) {
+        u32 at = atomicAdd(&fill, 1u);
+        if (at < n2) buf[at] = x;
+      }
+    }
+    __syncthreads();
+    for (u32 kk = 2; kk <= n2; kk <<= 1)
+      for (u32 j = kk >> 1; j > 0; j >>= 1) {
+        for (u32 i = threadIdx.x; i < n2; i += blockDim.x) {
+          u32 l = i ^ j;
+          if (l > i) {
+            u32 a = buf[i], b2 = buf[l];
+            bool up = (i & kk) == 0;
+            if ((a > b2) == up) {
+              buf[i] = b2;
+              buf[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len};
+    if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], 33ULL * J.occs);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -946,7 +1030,7 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
 // ------------------------------------------------------------------------------------------------------------
 // Host orchestration
 // ------------------------------------------------------------------------------------------------------------
-enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR };
+enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS };
 
 static double ev_ms(hipEvent_t a, hipEvent_t b) {
   float ms = 0;
@@ -1091,6 +1175,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
     DG_TRY(ws[WS_SEL].reserve((leaf_slots + 1) * sizeof(Sel)));
     DG_TRY(ws[WS_SCR].reserve((leaf_slots + 1) * 5 + 64));
     DG_TRY(ws[WS_SEEDS].reserve((hit_cap + 1) * sizeof(HitSeed)));
+    DG_TRY(ws[WS_JOBS].reserve(std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
     DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
     DG_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
@@ -1145,8 +1230,18 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
     DG_HIP(hipEventRecord(ix->ev[4], st));
     DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
     DG_HIP(hipEventRecord(ix->ev[5], st));
-    hipLaunchKernelGGL(k_locate, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, ws[WS_SEL].as<Sel>(), grp_off, nsel, ngrp,
-                       hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap);
+    {
+      // strings with many occurrences go to a job list served by one workgroup each
+      static const bool no_block = std::getenv("DICEY_NO_BLOCK_LOCATE") != nullptr;  // debugging aid (per-lane path only)
+      const u32 job_cap = (u32)std::min<u64>(leaf_slots, 1u << 20);
+      BigJob* jobs = no_block ? nullptr : ws[WS_JOBS].as<BigJob>();
+      u32* job_count = (u32*)&ctr->pad_[0];
+      hipLaunchKernelGGL(k_locate, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, ws[WS_SEL].as<Sel>(), grp_off, nsel, ngrp,
+                         hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, jobs, job_cap, job_count);
+      if (!no_block)
+        hipLaunchKernelGGL(k_locate_big, dim3(1024), dim3(256), 0, st, ix->view, (const BigJob*)jobs, (const u32*)job_count, job_cap,
+                           ws[WS_SEEDS].as<HitSeed>(), ctr);
+    }
     DG_HIP(hipEventRecord(ix->ev[6], st));
     {
       VerifyArgs va;

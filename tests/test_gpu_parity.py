@@ -207,3 +207,25 @@ def test_device_pointer_view_for_the_rccl_gather(gpu_small, small_genome):
     host = bytes(C.string_at(C.addressof(R.hits.contents), R.nhits * C.sizeof(_capi.Hit)))
     assert R.nhits > 0 and bytes(hb.cpu().numpy().tobytes()) == host
     L.dg_hunt_result_free(rp)
+
+
+def test_repeat_rich_strings_use_the_workgroup_locate(tmp_path):
+    """A 20-mer present thousands of times: locate must return the max_locations SMALLEST positions in ascending order
+    (hunter.h:355-357), through the radix-select kernel and through the per-lane fallback (take > 16384)."""
+    import dicey_amd
+    rng = random.Random(8)
+    unit = "".join(rng.choice("ACGT") for _ in range(20))
+    parts = []
+    for i in range(6000):
+        parts.append(unit)
+        parts.append("".join(rng.choice("ACGT") for _ in range(rng.randint(3, 9))))
+    seqs = ["".join(parts[:8000]), "".join(parts[8000:])]
+    text = genome_text(seqs)
+    path = str(tmp_path / "rep.fm9")
+    O.build_fm9(text, path)
+    g = {"seqlen": [len(s) + 1 for s in seqs], "names": ["r1", "r2"]}
+    orc = O.Index(path)
+    with dicey_amd.FmIndex(path) as ix:
+        for kw in (dict(distance=0, max_locations=1000), dict(distance=1, max_locations=700), dict(distance=0, max_locations=100000),
+                   dict(distance=1, hamming=True, max_locations=5000)):
+            _compare(ix, orc, g, [unit, unit[:19] + ("A" if unit[19] != "A" else "C"), unit[1:] + "G"], **kw)

@@ -1,6 +1,7 @@
 """DEVELOPMENT TOOL: run the kernel bodies under host emulation and compare with the oracle.
 Not a test of the product (the product is the gfx950 build); used to debug logic without a GPU."""
 import os, random, sys, time
+os.environ.setdefault("DICEY_NO_BLOCK_LOCATE", "1")  # the workgroup-cooperative locate needs barriers, which the emulator lacks
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O

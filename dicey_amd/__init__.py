@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 from . import _capi
 from ._capi import DgError, DG_Q_DIST_ADJUSTED, DG_Q_MAX_MATCHES, DG_Q_NBHD_EXCEEDED, DG_Q_TOO_SHORT
 
-__all__ = ["FmIndex", "DnaHit", "QueryResult", "HuntBatch", "build_index", "DgError"]
+__all__ = ["FmIndex", "Thal", "DnaHit", "QueryResult", "HuntBatch", "build_index", "DgError"]
 
 
 @dataclass
@@ -168,6 +168,40 @@ class FmIndex:
             return self._unpack(rp)
         finally:
             self._L.dg_hunt_result_free(rp)
+
+
+class Thal:
+    """primer3 thal() as `dicey search` uses it (src/silica.h:316-329,437,511): END1, temponly, 37 C."""
+
+    def __init__(self, config_dir: str, mv: float = 50.0, dv: float = 1.5, dntp: float = 0.6, dna_conc: float = 50.0,
+                 device: int = 0, _lib=None):
+        self._L = _lib or _capi.load()
+        self._h = C.c_void_p()
+        _capi.check(self._L, self._L.dg_thal_open(config_dir.encode(), mv, dv, dntp, dna_conc, device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.dg_thal_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tm(self, pairs):
+        """pairs: sequence of (oligo1, oligo2) strings -> list of (temp, align_end_1, align_end_2)"""
+        items = []
+        for a, b in pairs:
+            items += [a.encode(), b.encode()]
+        buf, off = _pack(items)
+        n = len(pairs)
+        t = (C.c_double * max(1, n))()
+        e1 = (C.c_int32 * max(1, n))()
+        e2 = (C.c_int32 * max(1, n))()
+        _capi.check(self._L, self._L.dg_thal_batch(self._h, buf, off, n, t, e1, e2))
+        return [(t[i], e1[i], e2[i]) for i in range(n)]
 
 
 def build_index(text: bytes, out_fm9: str, device: int = 0, _lib=None):

@@ -53,7 +53,8 @@ class Locations(C.Structure):
 # every symbol include/dicey_gpu.h declares; tests/test_capi_symbols.py checks the list against the header
 SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_locate", "dg_locations_free",
            "dg_extract", "dg_hunt", "dg_hunt_result_free", "dg_hunt_device", "dg_index_build",
-           "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count"]
+           "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
+           "dg_thal_open", "dg_thal_close", "dg_thal_batch"]
 
 _lib = None
 
@@ -87,6 +88,10 @@ def load(path=None):
     L.dg_hunt_result_free.restype = None
     L.dg_index_build.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p]
     L.dg_index_build_device.argtypes = [vp, C.c_uint64, C.c_int, C.c_char_p]
+    L.dg_thal_open.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(vp)]
+    L.dg_thal_close.argtypes = [vp]
+    L.dg_thal_close.restype = None
+    L.dg_thal_batch.argtypes = [vp, C.c_char_p, u64p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     if path is None:
         _lib = L
     return L

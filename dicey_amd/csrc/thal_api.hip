@@ -1,0 +1,286 @@
+// dg_thal_open / dg_thal_batch: primer3's thermodynamic alignment for `dicey search`, one GPU lane per (oligo, target)
+// pair.  Replaces primer3thal::get_thermodynamic_values (reference src/silica.h:320-323, src/thal.h:2374-2397) and
+// primer3thal::thal() with type = thal_end1, temponly = 1 (src/silica.h:437,511; src/thal.h:2409-2655).
+#include <cmath>
+#include <fstream>
+#include <sstream>
+
+#include "index_internal.hpp"
+#include "thal.hpp"
+
+struct dg_thal {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  dg::thal::Tables host_tables;
+  dg::thal::Tables* d_tables = nullptr;
+  dg::thal::Env env;
+  dg::DevBuf ws[6];
+  ~dg_thal() {
+    if (d_tables) (void)hipFree(d_tables);
+    for (auto& w : ws) w.release();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace dg {
+namespace {
+
+// one value per line, possibly "inf" (thal.h:403-414)
+struct ValueFile {
+  std::ifstream f;
+  bool ok;
+  explicit ValueFile(const std::string& p) : f(p.c_str()), ok(f.good()) {}
+  bool line(std::string& s) { return (bool)std::getline(f, s); }
+  double next() {
+    std::string s;
+    if (!line(s)) {
+      ok = false;
+      return 0;
+    }
+    size_t k = 0;
+    while (k < s.size() && std::isspace((unsigned char)s[k])) ++k;
+    if (s.compare(k, 3, "inf") == 0) return thal::kInf;
+    return std::strtod(s.c_str() + k, nullptr);
+  }
+};
+static double field(const std::string& tok) { return tok == "inf" ? thal::kInf : std::strtod(tok.c_str(), nullptr); }
+
+static int load_tables(const std::string& dir, thal::Tables& t) {
+  using thal::fin;
+  using thal::kInf;
+  auto quad = [&](const char* sname, const char* hname, double S[5][5][5][5], double H[5][5][5][5], bool terminal) -> int {
+    ValueFile fs(dir + sname), fh(dir + hname);
+    if (!fs.ok || !fh.ok) return fail(DG_EIO, "cannot read %s%s / %s", dir.c_str(), sname, hname);
+    for (int i = 0; i < 5; ++i)
+      for (int ii = 0; ii < 5; ++ii)
+        for (int j = 0; j < 5; ++j)
+          for (int jj = 0; jj < 5; ++jj) {
+            if (!terminal) {  // getStack / getStackint2 (thal.h:497-555)
+              if (i == 4 || j == 4 || ii == 4 || jj == 4) {
+                S[i][ii][j][jj] = -1.0;
+                H[i][ii][j][jj] = kInf;
+                continue;
+              }
+            } else {  // getTstack / getTstack2 (thal.h:622-679)
+              if (i == 4 || j == 4) {
+                H[i][ii][j][jj] = kInf;
+                S[i][ii][j][jj] = -1.0;
+                continue;
+              }
+              if (ii == 4 || jj == 4) {
+                S[i][ii][j][jj] = 0.00000000001;
+                H[i][ii][j][jj] = 0.0;
+                continue;
+              }
+            }
+            S[i][ii][j][jj] = fs.next();
+            H[i][ii][j][jj] = fh.next();
+            if (!fin(S[i][ii][j][jj]) || !fin(H[i][ii][j][jj])) {
+              S[i][ii][j][jj] = -1.0;
+              H[i][ii][j][jj] = kInf;
+            }
+          }
+    if (!fs.ok || !fh.ok) return fail(DG_EFORMAT, "%s%s / %s are too short", dir.c_str(), sname, hname);
+    return DG_OK;
+  };
+  DG_TRY(quad("stack.ds", "stack.dh", t.stackS, t.stackH, false));
+  DG_TRY(quad("stackmm.ds", "stackmm.dh", t.stackmmS, t.stackmmH, false));
+  {  // getDangle (thal.h:558-604): 3' block then 5' block in the same files
+    ValueFile fs(dir + "dangle.ds"), fh(dir + "dangle.dh");
+    if (!fs.ok || !fh.ok) return fail(DG_EIO, "cannot read %sdangle.ds/.dh", dir.c_str());
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j)
+        for (int k = 0; k < 5; ++k) {
+          if (i == 4 || j == 4 || k == 4) {
+            t.dangle3S[i][k][j] = -1.0;
+            t.dangle3H[i][k][j] = kInf;
+          } else {
+            t.dangle3S[i][k][j] = fs.next();
+            t.dangle3H[i][k][j] = fh.next();
+            if (!fin(t.dangle3S[i][k][j]) || !fin(t.dangle3H[i][k][j])) {
+              t.dangle3S[i][k][j] = -1.0;
+              t.dangle3H[i][k][j] = kInf;
+            }
+          }
+        }
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j)
+        for (int k = 0; k < 5; ++k) {
+          if (i == 4 || j == 4 || k == 4) {
+            t.dangle5S[i][j][k] = -1.0;
+            t.dangle5H[i][j][k] = kInf;
+          } else {
+            t.dangle5S[i][j][k] = fs.next();
+            t.dangle5H[i][j][k] = fh.next();
+            if (!fin(t.dangle5S[i][j][k]) || !fin(t.dangle5H[i][j][k])) {
+              t.dangle5S[i][j][k] = -1.0;
+              t.dangle5H[i][j][k] = kInf;
+            }
+          }
+        }
+    if (!fs.ok || !fh.ok) return fail(DG_EFORMAT, "%sdangle.ds/.dh are too short", dir.c_str());
+  }
+  {  // getLoop (thal.h:606-620): "<size> <interior> <bulge> <hairpin>" per line, 30 lines
+    ValueFile fs(dir + "loops.ds"), fh(dir + "loops.dh");
+    if (!fs.ok || !fh.ok) return fail(DG_EIO, "cannot read %sloops.ds/.dh", dir.c_str());
+    for (int k = 0; k < 30; ++k) {
+      std::string ls, lh, a, b, c, d;
+      if (!fs.line(ls) || !fh.line(lh)) return fail(DG_EFORMAT, "%sloops.ds/.dh are too short", dir.c_str());
+      std::istringstream ss(ls), sh(lh);
+      ss >> a >> b >> c >> d;
+      t.interiorS[k] = field(b);
+      t.bulgeS[k] = field(c);
+      sh >> a >> b >> c >> d;
+      t.interiorH[k] = field(b);
+      t.bulgeH[k] = field(c);
+    }
+  }
+  DG_TRY(quad("tstack_tm_inf.ds", "tstack.dh", t.tstackS, t.tstackH, true));
+  DG_TRY(quad("tstack2.ds", "tstack2.dh", t.tstack2S, t.tstack2H, true));
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) {  // tableStartATS / tableStartATH (thal.h:767-783), AT_S = 6.9, AT_H = 2200
+      t.atpS[i][j] = 0.00000000001;
+      t.atpH[i][j] = 0.0;
+    }
+  t.atpS[0][3] = t.atpS[3][0] = 6.9;
+  t.atpH[0][3] = t.atpH[3][0] = 2200.0;
+  return DG_OK;
+}
+
+struct PairDesc {
+  u64 a_off, b_off, dp_off;  // framed codes of oligo 1 / reversed oligo 2, DP planes
+  u32 len1, len2;
+  u32 symmetric, pad;
+};
+
+__global__ void k_thal(const thal::Tables* T, thal::Env env, const PairDesc* pd, u64 n, const u8* codes, double* dp, double* temp,
+                       int* end1, int* end2) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const PairDesc d = pd[t];
+  thal::Result r = thal::end1_tm(*T, env, codes + d.a_off, (int)d.len1, codes + d.b_off, (int)d.len2, d.symmetric != 0, dp + d.dp_off,
+                                 dp + d.dp_off + (u64)d.len1 * d.len2);
+  temp[t] = r.temp;
+  end1[t] = r.end1;
+  end2[t] = r.end2;
+}
+
+static u8 code_of(char c) {
+  c = (char)std::toupper((unsigned char)c);
+  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;  // str2int, thal.h:260-275
+}
+// symmetry_thermo (thal.h:1976-2010): even length and self-complementary
+static bool self_complementary(const u8* s, size_t n) {
+  if (n % 2) return false;
+  for (size_t i = 0; i < n / 2; ++i) {
+    char a = (char)std::toupper(s[i]), b = (char)std::toupper(s[n - 1 - i]);
+    if ((a == 'A' && b != 'T') || (a == 'T' && b != 'A') || (b == 'A' && a != 'T') || (b == 'T' && a != 'A')) return false;
+    if ((a == 'C' && b != 'G') || (a == 'G' && b != 'C') || (b == 'C' && a != 'G') || (b == 'G' && a != 'C')) return false;
+  }
+  return true;
+}
+
+}  // namespace
+}  // namespace dg
+
+using namespace dg;
+
+extern "C" {
+
+int dg_thal_open(const char* config_dir, double mv, double dv, double dntp, double dna_conc, int device, dg_thal** out) {
+  if (!config_dir || !out) return fail(DG_EINVAL, "dg_thal_open: null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DG_ENODEV, "no HIP device available");
+  if (device < 0 || device >= ndev) return fail(DG_EINVAL, "device %d out of range (have %d)", device, ndev);
+  std::string dir(config_dir);
+  if (!dir.empty() && dir.back() != '/') dir.push_back('/');
+  dg_thal* th = new dg_thal;
+  th->device = device;
+  int rc = load_tables(dir, th->host_tables);
+  if (rc != DG_OK) {
+    delete th;
+    return rc;
+  }
+  // saltCorrectS (thal.h:354-359) and the two RC values (thal.h:2504-2508)
+  double dn = dntp;
+  if (dv <= 0) dn = dv;
+  th->env.salt_correction = 0.368 * ((log((mv + 120 * (sqrt(fmax(0.0, dv - dn)))) / 1000)));
+  th->env.rc_sym = 1.9872 * log(dna_conc / 1000000000.0);
+  th->env.rc_asym = 1.9872 * log(dna_conc / 4000000000.0);
+  auto body = [&]() -> int {
+    DG_HIP(hipSetDevice(device));
+    DG_HIP(hipStreamCreate(&th->stream));
+    DG_HIP(hipMalloc((void**)&th->d_tables, sizeof(thal::Tables)));
+    DG_HIP(hipMemcpy(th->d_tables, &th->host_tables, sizeof(thal::Tables), hipMemcpyHostToDevice));
+    return DG_OK;
+  };
+  rc = body();
+  if (rc != DG_OK) {
+    delete th;
+    return rc;
+  }
+  *out = th;
+  return DG_OK;
+}
+
+void dg_thal_close(dg_thal* th) {
+  if (!th) return;
+  (void)hipSetDevice(th->device);
+  delete th;
+}
+
+int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t npairs, double* temp, int32_t* end1, int32_t* end2) {
+  if (!th || !seqs || !off || !temp) return fail(DG_EINVAL, "dg_thal_batch: null argument");
+  if (!npairs) return DG_OK;
+  std::vector<PairDesc> pd(npairs);
+  u64 ncode = 0, ndp = 0;
+  for (size_t k = 0; k < npairs; ++k) {
+    u64 l1 = off[2 * k + 1] - off[2 * k], l2 = off[2 * k + 2] - off[2 * k + 1];
+    if (l1 > 10000 || l2 > 10000) return fail(DG_ELIMIT, "pair %zu: sequence longer than THAL_MAX_SEQ", k);
+    pd[k].len1 = (u32)l1;
+    pd[k].len2 = (u32)l2;
+    pd[k].a_off = ncode;
+    ncode += l1 + 2;
+    pd[k].b_off = ncode;
+    ncode += l2 + 2;
+    pd[k].dp_off = ndp;
+    bool both_long = l1 > (u64)thal::kMaxAlign && l2 > (u64)thal::kMaxAlign;
+    ndp += both_long ? 0 : 2 * l1 * l2;
+    pd[k].symmetric = self_complementary(seqs + off[2 * k], l1) && self_complementary(seqs + off[2 * k + 1], l2);
+    pd[k].pad = 0;
+  }
+  std::vector<u8> codes(ncode, 4);
+  for (size_t k = 0; k < npairs; ++k) {
+    const u8* s1 = seqs + off[2 * k];
+    const u8* s2 = seqs + off[2 * k + 1];
+    for (u32 i = 0; i < pd[k].len1; ++i) codes[pd[k].a_off + 1 + i] = code_of((char)s1[i]);
+    for (u32 j = 0; j < pd[k].len2; ++j) codes[pd[k].b_off + 1 + j] = code_of((char)s2[pd[k].len2 - 1 - j]);  // reversed
+  }
+  DG_HIP(hipSetDevice(th->device));
+  hipStream_t st = th->stream;
+  DG_TRY(th->ws[0].reserve(npairs * sizeof(PairDesc)));
+  DG_TRY(th->ws[1].reserve(ncode + 8));
+  DG_TRY(th->ws[2].reserve((ndp + 1) * 8));
+  DG_TRY(th->ws[3].reserve(npairs * 8));
+  DG_TRY(th->ws[4].reserve(npairs * 8));
+  DG_HIP(hipMemcpyAsync(th->ws[0].p, pd.data(), npairs * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+  DG_HIP(hipMemcpyAsync(th->ws[1].p, codes.data(), ncode, hipMemcpyHostToDevice, st));
+  int* e1 = th->ws[4].as<int>();
+  int* e2 = e1 + npairs;
+  hipLaunchKernelGGL(k_thal, dim3(ceil_div(npairs, 64)), dim3(64), 0, st, (const thal::Tables*)th->d_tables, th->env,
+                     th->ws[0].as<PairDesc>(), (u64)npairs, th->ws[1].as<u8>(), th->ws[2].as<double>(), th->ws[3].as<double>(), e1, e2);
+  DG_HIP(hipMemcpyAsync(temp, th->ws[3].p, npairs * 8, hipMemcpyDeviceToHost, st));
+  std::vector<int> h1(npairs), h2(npairs);
+  DG_HIP(hipMemcpyAsync(h1.data(), e1, npairs * 4, hipMemcpyDeviceToHost, st));
+  DG_HIP(hipMemcpyAsync(h2.data(), e2, npairs * 4, hipMemcpyDeviceToHost, st));
+  DG_HIP(hipStreamSynchronize(st));
+  DG_HIP(hipGetLastError());
+  for (size_t k = 0; k < npairs; ++k) {
+    if (end1) end1[k] = h1[k];
+    if (end2) end2[k] = h2[k];
+  }
+  return DG_OK;
+}
+
+}  // extern "C"

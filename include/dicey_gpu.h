@@ -155,6 +155,16 @@ int dg_index_build(const uint8_t* text, uint64_t len, int device, const char* ou
 /* same, text already in HBM (bench: synthetic genome generated on device) */
 int dg_index_build_device(const void* d_text, uint64_t len, int device, const char* out_fm9_path);
 
+/* ---- thermodynamic alignment for `dicey search` (primer3 thal(), type END1, temponly) ----
+ * replaces primer3thal::get_thermodynamic_values + set_thal_default_args (silica.h:316-329) and primer3thal::thal()
+ * (silica.h:437, 511; thal.h:2409-2655).  config_dir holds primer3's stack.ds ... tstack2.dh tables. */
+typedef struct dg_thal dg_thal;
+int dg_thal_open(const char* config_dir, double mv, double dv, double dntp, double dna_conc, int device, dg_thal** out);
+void dg_thal_close(dg_thal* th);
+/* pair k = (oligo1, oligo2) = seqs[off[2k]..off[2k+1]), seqs[off[2k+1]..off[2k+2]); temp[k] = o.temp (-999999 = THAL_ERROR_SCORE
+ * when both sequences exceed 60 nt), end1/end2 = align_end_1/2 (may be NULL) */
+int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t npairs, double* temp, int32_t* end1, int32_t* end2);
+
 const char* dg_last_error(void);
 int dg_abi_version(void);
 int dg_device_count(void);

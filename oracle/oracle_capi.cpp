@@ -9,6 +9,7 @@
 
 #include "fm9.hpp"
 #include "hunt_ref.hpp"
+#include "search_ref.hpp"
 
 using namespace orc;
 
@@ -188,6 +189,57 @@ double orc_hunt_timed(void* h, const uint32_t* seqlen, uint32_t nseq, const orc_
     for (auto v : th) *total_hits += v;
   }
   return dt;
+}
+
+struct orc_search_params {
+  int32_t hamming, pruneprimer;
+  double cutTemp;
+  uint32_t maxProdSize;
+  double cutofPen, penDiff, penMis, penLen;
+  uint32_t kmer, distance, maxNeighborhood, maxPruneCount;
+  uint64_t max_locations;
+};
+
+// silica.h:355-640 + writer :100-187.  thal_fn / dump_fn come from oracle/_ref (the reference's own thal.h / json.hpp).
+char* orc_search(void* h, const uint32_t* seqlen, const char* const* seqname, uint32_t nseq, const char* text, uint64_t textlen,
+                 const orc_search_params* p, const char* genome, const char* outfile, const char* fasta, void* thal_fn, void* dump_fn,
+                 int* rc, uint64_t* json_len) {
+  SearchRun r;
+  r.fm = &((Handle*)h)->csa;
+  r.seqlen.assign(seqlen, seqlen + nseq);
+  for (uint32_t i = 0; i < nseq; ++i) r.seqname.push_back(seqname[i]);
+  std::string T(text, textlen);
+  r.text = &T;
+  r.thal = (ThalFn)thal_fn;
+  r.dump_double = (DumpDoubleFn)dump_fn;
+  r.c.indel = !p->hamming;
+  r.c.pruneprimer = p->pruneprimer != 0;
+  r.c.cutTemp = p->cutTemp;
+  r.c.maxProdSize = p->maxProdSize;
+  r.c.cutofPen = p->cutofPen;
+  r.c.penDiff = p->penDiff;
+  r.c.penMis = p->penMis;
+  r.c.penLen = p->penLen;
+  r.c.kmer = p->kmer;
+  r.c.distance = p->distance;
+  r.c.maxNeighborhood = p->maxNeighborhood;
+  r.c.maxPruneCount = p->maxPruneCount;
+  r.c.max_locations = p->max_locations;
+  r.c.genome = genome ? genome : "";
+  r.c.outfile = outfile ? outfile : "";
+  std::vector<std::string> lines;
+  std::string cur;
+  for (const char* q = fasta; *q; ++q) {
+    if (*q == '\n') {
+      lines.push_back(cur);
+      cur.clear();
+    } else cur.push_back(*q);
+  }
+  if (!cur.empty()) lines.push_back(cur);
+  int code = 0;
+  std::string js = r.run(lines, code);
+  if (rc) *rc = code;
+  return dup_out(js, json_len);
 }
 
 }  // extern "C"

@@ -16,8 +16,35 @@ class HuntParams(C.Structure):
                 ("max_locations", C.c_uint64), ("max_neighborhood", C.c_uint32)]
 
 
+class SearchParams(C.Structure):
+    _fields_ = [("hamming", C.c_int32), ("pruneprimer", C.c_int32), ("cutTemp", C.c_double), ("maxProdSize", C.c_uint32),
+                ("cutofPen", C.c_double), ("penDiff", C.c_double), ("penMis", C.c_double), ("penLen", C.c_double),
+                ("kmer", C.c_uint32), ("distance", C.c_uint32), ("maxNeighborhood", C.c_uint32), ("maxPruneCount", C.c_uint32),
+                ("max_locations", C.c_uint64)]
+
+
+REF_THAL = os.path.join(_ODIR, "_ref", "libthalref.so")
+REF_JSON = os.path.join(_ODIR, "_ref", "libjsonref.so")
+PRIMER3_CONFIG = os.path.join(_ROOT, "tests", "golden", "primer3_config") + "/"
+_ref = {}
+
+
+def ref_libs(temp_c=37.0, mv=50.0, dv=1.5, dna_conc=50.0, dntp=0.6):
+    """oracle/_ref: the reference's own thal.h and nlohmann json.hpp, compiled in place where /root/reference exists
+    (the built .so files travel to the GPU box).  Returns (thal_lib, json_lib) or None."""
+    if not (os.path.exists(REF_THAL) and os.path.exists(REF_JSON)):
+        return None
+    if "t" not in _ref:
+        T = C.CDLL(REF_THAL)
+        T.ref_thal_init.argtypes = [C.c_char_p] + [C.c_double] * 5
+        J = C.CDLL(REF_JSON)
+        _ref["t"], _ref["j"] = T, J
+    assert _ref["t"].ref_thal_init(PRIMER3_CONFIG.encode(), temp_c, mv, dv, dna_conc, dntp) == 0
+    return _ref["t"], _ref["j"]
+
+
 def build():
-    srcs = [os.path.join(_ODIR, f) for f in ("oracle_capi.cpp", "fm9.hpp", "hunt_ref.hpp", "Makefile")]
+    srcs = [os.path.join(_ODIR, f) for f in ("oracle_capi.cpp", "fm9.hpp", "hunt_ref.hpp", "search_ref.hpp", "Makefile")]
     if (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _ODIR, "-s"])
     return _SO
@@ -60,6 +87,10 @@ def lib():
         L.orc_hunt_timed.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(HuntParams), C.POINTER(C.c_char_p),
                                      C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.orc_hunt_timed.restype = C.c_double
+        L.orc_search.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_uint64,
+                                 C.POINTER(SearchParams), C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+        L.orc_search.restype = C.c_void_p
         _lib = L
     return _lib
 
@@ -157,6 +188,27 @@ class Index:
                 f = ln.split("\t")
                 hits.append((int(f[0]), int(f[1]), int(f[2]), int(f[3]), f[4], f[5], f[6]))
         return js, hits
+
+    def search(self, seqlen, seqname, text: bytes, fasta: str, genome="", outfile="", hamming=False, pruneprimer=None,
+               cutTemp=45.0, maxProdSize=15000, cutofPen=-1.0, penDiff=0.6, penMis=0.4, penLen=0.001, kmer=15, distance=1,
+               maxNeighborhood=10000, max_locations=10000):
+        """`dicey search` through the restated silica.h driver + the reference's own thal()/json dump (oracle/_ref).
+        Returns (json_text, exit_code)."""
+        libs = ref_libs()
+        if libs is None:
+            raise RuntimeError("oracle/_ref is not built")
+        T, J = libs
+        nseq = len(seqlen)
+        sl = (C.c_uint32 * nseq)(*seqlen)
+        sn = (C.c_char_p * nseq)(*[s.encode() for s in seqname])
+        p = SearchParams(int(hamming), int(pruneprimer is not None), cutTemp, maxProdSize, cutofPen, penDiff, penMis, penLen, kmer,
+                         distance, maxNeighborhood, pruneprimer or 0, max_locations)
+        rc, jl = C.c_int(), C.c_uint64()
+        tf = C.cast(T.ref_thal, C.c_void_p)
+        jf = C.cast(J.ref_json_dump_double, C.c_void_p)
+        jp = lib().orc_search(self.h, sl, sn, nseq, text, len(text), C.byref(p), genome.encode(), outfile.encode(), fasta.encode(),
+                              tf, jf, C.byref(rc), C.byref(jl))
+        return _take(jp, jl.value).decode(), rc.value
 
     def hunt_timed(self, seqlen, seqs, threads=1, distance=1, hamming=False, forward_only=False,
                    max_locations=1000, max_neighborhood=10000):

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 from . import _capi
 from ._capi import DgError, DG_Q_DIST_ADJUSTED, DG_Q_MAX_MATCHES, DG_Q_NBHD_EXCEEDED, DG_Q_TOO_SHORT
 
-__all__ = ["FmIndex", "Thal", "DnaHit", "QueryResult", "HuntBatch", "build_index", "DgError"]
+__all__ = ["FmIndex", "Thal", "search_sites", "DnaHit", "QueryResult", "HuntBatch", "build_index", "DgError"]
 
 
 @dataclass
@@ -202,6 +202,29 @@ class Thal:
         e2 = (C.c_int32 * max(1, n))()
         _capi.check(self._L, self._L.dg_thal_batch(self._h, buf, off, n, t, e1, e2))
         return [(t[i], e1[i], e2[i]) for i in range(n)]
+
+
+def search_sites(ix: "FmIndex", th: "Thal", primers: Sequence[str], seqlen: Sequence[int], kmer: int = 15, distance: int = 1,
+                 hamming: bool = False, max_locations: int = 10000, max_neighborhood: int = 10000, cut_temp: float = 45.0):
+    """Binding sites of a primer batch (src/silica.h:429-573).  Returns (sites, match_temp, pflags, nhits): sites are dicts
+    in the reference's push order (primer-major, forward-strand hits first)."""
+    L = ix._L
+    buf, off = _pack([p.encode() for p in primers])
+    sl = (C.c_uint32 * len(seqlen))(*seqlen)
+    p = _capi.SearchParams(distance, int(hamming), max_locations, max_neighborhood, kmer, cut_temp)
+    rp = C.POINTER(_capi.SearchResult)()
+    _capi.check(L, L.dg_search_sites(ix.handle, th._h, C.byref(p), sl, len(seqlen), buf, off, len(primers), C.byref(rp)))
+    try:
+        R = rp.contents
+        sites = []
+        for i in range(R.nsites):
+            s = R.sites[i]
+            g = C.string_at(C.addressof(R.genome_pool.contents) + s.genome_off, s.genome_len).decode("latin-1")
+            sites.append({"ref": s.ref, "pos": s.pos, "primer": s.primer, "on_for": bool(s.on_for), "temp": s.temp,
+                          "perf_temp": s.perf_temp, "genome": g})
+        return sites, [R.match_temp[i] for i in range(R.nprimers)], [R.pflags[i] for i in range(R.nprimers)], R.nhits
+    finally:
+        L.dg_search_result_free(rp)
 
 
 def build_index(text: bytes, out_fm9: str, device: int = 0, _lib=None):

@@ -46,6 +46,21 @@ class HuntResult(C.Structure):
                 ("d_hits", C.c_void_p), ("d_refalign", C.c_void_p), ("d_queryalign", C.c_void_p)]
 
 
+class SearchParams(C.Structure):
+    _fields_ = [("distance", C.c_uint32), ("hamming", C.c_int32), ("max_locations", C.c_uint64), ("max_neighborhood", C.c_uint32),
+                ("kmer", C.c_uint32), ("cut_temp", C.c_double)]
+
+
+class Site(C.Structure):
+    _fields_ = [("ref", C.c_uint32), ("pos", C.c_uint32), ("primer", C.c_uint32), ("on_for", C.c_uint8), ("reserved", C.c_uint8 * 3),
+                ("temp", C.c_double), ("perf_temp", C.c_double), ("genome_off", C.c_uint64), ("genome_len", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class SearchResult(C.Structure):
+    _fields_ = [("nprimers", C.c_size_t), ("nsites", C.c_uint64), ("sites", C.POINTER(Site)), ("genome_pool", C.POINTER(C.c_char)),
+                ("pflags", C.POINTER(C.c_uint32)), ("match_temp", C.POINTER(C.c_double)), ("nhits", C.c_uint64), ("ms_device", C.c_double)]
+
+
 class Locations(C.Structure):
     _fields_ = [("npat", C.c_size_t), ("off", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_uint64))]
 
@@ -54,7 +69,7 @@ class Locations(C.Structure):
 SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_locate", "dg_locations_free",
            "dg_extract", "dg_hunt", "dg_hunt_result_free", "dg_hunt_device", "dg_index_build",
            "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
-           "dg_thal_open", "dg_thal_close", "dg_thal_batch"]
+           "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free"]
 
 _lib = None
 
@@ -92,6 +107,10 @@ def load(path=None):
     L.dg_thal_close.argtypes = [vp]
     L.dg_thal_close.restype = None
     L.dg_thal_batch.argtypes = [vp, C.c_char_p, u64p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.dg_search_sites.argtypes = [vp, vp, C.POINTER(SearchParams), u32p, C.c_uint32, C.c_char_p, u64p, C.c_size_t,
+                                  C.POINTER(C.POINTER(SearchResult))]
+    L.dg_search_result_free.argtypes = [C.POINTER(SearchResult)]
+    L.dg_search_result_free.restype = None
     if path is None:
         _lib = L
     return L

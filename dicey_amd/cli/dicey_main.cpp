@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -20,6 +21,7 @@
 #include <vector>
 
 #include "../../include/dicey_gpu.h"
+#include "dtoa.hpp"
 
 namespace {
 
@@ -471,6 +473,371 @@ int hunter(int argc, char** argv) {
   return rc_all;
 }
 
+// ------------------------------------------------------------------------------------------------ search (silica.h:208-651)
+struct SearchConfig {
+  std::string genome, outfile, infile, primer3Config = "./src/primer3_config/";
+  bool has_outfile = false, hamming = false, pruneprimer = false, help = false;
+  double cutTemp = 45.0, cutofPen = -1.0, penDiff = 0.6, penMis = 0.4, penLen = 0.001;
+  double temp = 37.0, mv = 50.0, dv = 1.5, dna_conc = 50.0, dntp = 0.6;
+  uint32_t maxProdSize = 15000, kmer = 15, distance = 1, maxNeighborhood = 10000, maxPruneCount = 0;
+  uint64_t max_locations = 10000;
+};
+struct PrimerBind {  // silica.h:69-82
+  uint32_t refIndex, pos, primerId;
+  bool onFor;
+  double temp, perfTemp;
+  std::string genome;
+  bool operator<(const PrimerBind& b) const { return (temp > b.temp); }
+};
+struct PcrProduct {  // silica.h:84-98
+  uint32_t refIndex, leng, forPos, revPos, forId, revId;
+  double forTemp, revTemp, penalty;
+  bool operator<(const PcrProduct& b) const { return (penalty < b.penalty); }
+};
+
+// silica.h:100-187; amplicon sequences come from the index text (what faidx_fetch_seq + to_upper would return)
+std::string search_json(const SearchConfig& c, dg_index* ix, const std::vector<uint32_t>& seqlen, const std::vector<std::string>& qn,
+                        const std::vector<PrimerBind>& allp, const std::vector<PcrProduct>& pcr, const std::vector<std::string>& pName,
+                        const std::vector<std::string>& pSeq, const std::vector<std::string>& msg) {
+  std::string o = "{\"errors\": [";
+  bool errors = false;
+  for (size_t i = 0; i < msg.size(); ++i) {
+    bool err = msg[i].compare(0, 5, "Error") == 0;
+    errors = errors || err;
+    if (i) o.push_back(',');
+    o += "{\"title\":" + jstr(msg[i]) + ",\"type\":" + (err ? "\"error\"" : "\"warning\"") + "}";
+  }
+  o.push_back(']');
+  if (!errors) {
+    o += ",\"meta\":{\"distance\":" + std::to_string(c.distance) + ",\"genome\":" + jstr(c.genome);
+    o += std::string(",\"hamming\":") + (c.hamming ? "true" : "false") + ",\"maxmatches\":" + std::to_string(c.max_locations);
+    o += ",\"outfile\":" + jstr(c.outfile) + ",\"subcommand\":\"search\",\"version\":\"" + kVersion + "\"},";
+    o += "\"data\":{\"primers\":[";
+    for (size_t i = 0; i < allp.size(); ++i) {
+      const PrimerBind& p = allp[i];
+      if (i) o.push_back(',');
+      o += "{\"Chrom\":" + jstr(qn[p.refIndex]) + ",\"End\":" + std::to_string((uint64_t)p.pos + pSeq[p.primerId].size());
+      o += ",\"Genome\":" + jstr(p.genome) + ",\"Id\":" + std::to_string(i) + ",\"MatchTm\":" + dtoa::dump_double(p.perfTemp);
+      o += ",\"Name\":" + jstr(pName[p.primerId]) + ",\"Ori\":" + (p.onFor ? "\"forward\"" : "\"reverse\"");
+      o += ",\"Pos\":" + std::to_string(p.pos + 1) + ",\"Seq\":" + jstr(pSeq[p.primerId]) + ",\"Tm\":" + dtoa::dump_double(p.temp) + "}";
+    }
+    o += "],\"amplicons\":[";
+    // amplicon sequences in one extract batch
+    std::vector<uint64_t> lo, hi, off;
+    uint64_t tot = 0;
+    std::vector<char> has(pcr.size(), 0);
+    for (size_t i = 0; i < pcr.size(); ++i) {
+      const PcrProduct& a = pcr[i];
+      uint64_t cstart = 0;
+      for (uint32_t r = 0; r < a.refIndex; ++r) cstart += seqlen[r];
+      uint64_t clen = seqlen[a.refIndex] - 1, b0 = a.forPos, e0 = (uint64_t)a.revPos + pSeq[a.revId].size() - 1;
+      if (b0 < clen) {
+        if (e0 >= clen) e0 = clen - 1;
+        if (e0 >= b0) {
+          has[i] = 1;
+          lo.push_back(cstart + b0);
+          hi.push_back(cstart + e0);
+          off.push_back(tot);
+          tot += e0 - b0 + 1;
+        }
+      }
+    }
+    std::string pool(tot, '\0');
+    if (!lo.empty() && dg_extract(ix, lo.data(), hi.data(), lo.size(), (uint8_t*)&pool[0], off.data()) != DG_OK)
+      std::cerr << "dicey: " << dg_last_error() << std::endl;
+    size_t k = 0;
+    for (size_t i = 0; i < pcr.size(); ++i) {
+      const PcrProduct& a = pcr[i];
+      std::string seqstr;
+      if (has[i]) {
+        seqstr = pool.substr(off[k], hi[k] - lo[k] + 1);
+        ++k;
+      }
+      if (i) o.push_back(',');
+      o += "{\"Chrom\":" + jstr(qn[a.refIndex]) + ",\"ForEnd\":" + std::to_string((uint64_t)a.forPos + pSeq[a.forId].size());
+      o += ",\"ForName\":" + jstr(pName[a.forId]) + ",\"ForPos\":" + std::to_string(a.forPos + 1) + ",\"ForSeq\":" + jstr(pSeq[a.forId]);
+      o += ",\"ForTm\":" + dtoa::dump_double(a.forTemp) + ",\"Id\":" + std::to_string(i) + ",\"Length\":" + std::to_string(a.leng);
+      o += ",\"Penalty\":" + dtoa::dump_double(a.penalty) + ",\"RevEnd\":" + std::to_string((uint64_t)a.revPos + pSeq[a.revId].size());
+      o += ",\"RevName\":" + jstr(pName[a.revId]) + ",\"RevPos\":" + std::to_string(a.revPos + 1) + ",\"RevSeq\":" + jstr(pSeq[a.revId]);
+      o += ",\"RevTm\":" + dtoa::dump_double(a.revTemp) + ",\"Seq\":" + jstr(seqstr) + "}";
+    }
+    o += "]}";
+  }
+  o += "}\n";
+  return o;
+}
+
+void emit_search(const SearchConfig& c, const std::string& json) {
+  if (c.has_outfile) {  // silica.h:192-198: one gzip stream, file overwritten
+    std::ofstream trunc(c.outfile.c_str(), std::ios_base::out | std::ios_base::binary | std::ios_base::trunc);
+    trunc.close();
+    append_gzip_member(c.outfile, json);
+  } else {
+    std::fwrite(json.data(), 1, json.size(), stdout);
+    std::fflush(stdout);
+  }
+}
+
+std::string revcomp_upper(std::string s) {  // util.h:110-114
+  for (auto& ch : s) {
+    char u = (char)std::toupper((unsigned char)ch);
+    ch = u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : u == 'U' ? 'A' : u == 'R' ? 'Y' : u == 'Y' ? 'R' : u == 'S' ? 'S'
+         : u == 'W' ? 'W' : u == 'K' ? 'M' : u == 'M' ? 'K' : u == 'B' ? 'V' : u == 'V' ? 'B' : u == 'D' ? 'H' : u == 'H' ? 'D' : 'N';
+  }
+  return std::string(s.rbegin(), s.rend());
+}
+
+int silica(int argc, char** argv) {
+  SearchConfig c;
+  const OptSpec specs[] = {{"help", '?', false}, {"genome", 'g', true}, {"config", 'i', true}, {"outfile", 'o', true}, {"kmer", 'k', true},
+                           {"maxmatches", 'm', true}, {"maxNeighborhood", 'x', true}, {"distance", 'd', true}, {"pruneprimer", 'q', true},
+                           {"hamming", 'n', false}, {"cutTemp", 'c', true}, {"maxProdSize", 'l', true}, {"cutoffPenalty", 0, true},
+                           {"penaltyTmDiff", 0, true}, {"penaltyTmMismatch", 0, true}, {"penaltyLength", 0, true}, {"enttemp", 0, true},
+                           {"monovalent", 0, true}, {"divalent", 0, true}, {"dna", 0, true}, {"dntp", 0, true}, {"input-file", 0, true}};
+  Parsed p = parse_options(argc, argv, specs, sizeof specs / sizeof specs[0]);
+  if (!p.error.empty()) {
+    std::cerr << "terminate called after throwing an instance of 'boost::program_options::error'\n  what():  " << p.error << std::endl;
+    std::abort();
+  }
+  bool have_genome = false, have_input = false;
+  for (auto& kv : p.kv) {
+    const std::string& k = kv.first;
+    const char* v = kv.second.c_str();
+    if (k == "help") c.help = true;
+    else if (k == "genome") { c.genome = v; have_genome = true; }
+    else if (k == "config") c.primer3Config = v;
+    else if (k == "outfile") { c.outfile = v; c.has_outfile = true; }
+    else if (k == "kmer") c.kmer = (uint32_t)std::strtoul(v, nullptr, 10);
+    else if (k == "maxmatches") c.max_locations = std::strtoull(v, nullptr, 10);
+    else if (k == "maxNeighborhood") c.maxNeighborhood = (uint32_t)std::strtoul(v, nullptr, 10);
+    else if (k == "distance") c.distance = (uint32_t)std::strtoul(v, nullptr, 10);
+    else if (k == "pruneprimer") { c.maxPruneCount = (uint32_t)std::strtoul(v, nullptr, 10); c.pruneprimer = true; }
+    else if (k == "hamming") c.hamming = true;
+    else if (k == "cutTemp") c.cutTemp = std::strtod(v, nullptr);
+    else if (k == "maxProdSize") c.maxProdSize = (uint32_t)std::strtoul(v, nullptr, 10);
+    else if (k == "cutoffPenalty") c.cutofPen = std::strtod(v, nullptr);
+    else if (k == "penaltyTmDiff") c.penDiff = std::strtod(v, nullptr);
+    else if (k == "penaltyTmMismatch") c.penMis = std::strtod(v, nullptr);
+    else if (k == "penaltyLength") c.penLen = std::strtod(v, nullptr);
+    else if (k == "enttemp") c.temp = std::strtod(v, nullptr);
+    else if (k == "monovalent") c.mv = std::strtod(v, nullptr);
+    else if (k == "divalent") c.dv = std::strtod(v, nullptr);
+    else if (k == "dna") c.dna_conc = std::strtod(v, nullptr);
+    else if (k == "dntp") c.dntp = std::strtod(v, nullptr);
+    else if (k == "input-file") { c.infile = v; have_input = true; }
+  }
+  if (!p.positional.empty()) {
+    c.infile = p.positional.back();
+    have_input = true;
+  }
+  if (c.help || !have_input || !have_genome) {
+    std::cout << "Usage: dicey " << argv[0] << " [OPTIONS] -g <ref.fa.gz> sequences.fasta" << std::endl;
+    std::cout << "  -g genome  -i primer3 config dir  -o outfile  -k kmer(15)  -m maxmatches(10000)  -x maxNeighborhood(10000)\n"
+                 "  -d distance(1)  -q pruneprimer  -n hamming  -c cutTemp(45)  -l maxProdSize(15000)  --cutoffPenalty(-1)\n"
+                 "  --penaltyTmDiff(0.6)  --penaltyTmMismatch(0.4)  --penaltyLength(0.001)  --enttemp(37)  --monovalent(50)\n"
+                 "  --divalent(1.5)  --dna(50)  --dntp(0.6)\n\n";
+    return -1;
+  }
+  std::vector<PrimerBind> allp;
+  std::vector<PcrProduct> pcrColl;
+  std::vector<std::string> msg, seqname, pName, pSeq;
+  std::vector<uint32_t> seqlen;
+  dg_index* ix = nullptr;
+  auto bail = [&](const char* m) {
+    msg.push_back(m);
+    emit_search(c, search_json(c, ix, seqlen, seqname, allp, pcrColl, pName, pSeq, msg));
+    if (ix) dg_index_close(ix);
+    return 1;
+  };
+  if (!file_nonempty(c.genome)) return bail("Error: Genome does not exist!");
+  {  // silica.h:303-315
+    struct stat st;
+    if (stat(c.primer3Config.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return bail("Error: Cannot find primer3 config directory!");
+    while (c.primer3Config.size() > 1 && c.primer3Config.back() == '/') c.primer3Config.pop_back();
+    c.primer3Config.push_back('/');
+    if (!is_regular(c.primer3Config + "tetraloop.dh")) return bail("Error: Config directory path appears to be incorrect!");
+  }
+  if (!seq_len_name(c.genome, seqlen, seqname)) return bail("Error: Could not retrieve sequence lengths!");
+  const int dev = device_from_env();
+  if (dg_index_open((strip_last_extension(c.genome) + ".fm9").c_str(), dev, DG_OPEN_DEFAULT, &ix) != DG_OK) {
+    std::cerr << "dicey: " << dg_last_error() << std::endl;
+    ix = nullptr;
+    return bail("Error: FM-Index cannot be loaded!");
+  }
+  dg_thal* th = nullptr;
+  if (dg_thal_open(c.primer3Config.c_str(), c.mv, c.dv, c.dntp, c.dna_conc, dev, &th) != DG_OK) {
+    std::cerr << "dicey: " << dg_last_error() << std::endl;
+    return bail("Error: Config directory path appears to be incorrect!");
+  }
+  {  // silica.h:350-353
+    struct stat st;
+    if (stat(c.infile.c_str(), &st) != 0 || S_ISDIR(st.st_mode)) {
+      dg_thal_close(th);
+      return bail("Error: Input fasta file is missing!");
+    }
+  }
+  // ---- primer FASTA (silica.h:355-410), quirks included: a record counts only if longer than k, and the sequence
+  // buffer is cleared only when a record is taken
+  auto count_le = [&](const std::string& s, uint32_t limit) {
+    uint64_t off[2] = {0, s.size()}, cnt = 0;
+    if (dg_count(ix, (const uint8_t*)s.data(), off, 1, &cnt) != DG_OK) std::cerr << "dicey: " << dg_last_error() << std::endl;
+    return cnt <= limit;
+  };
+  bool fatal = false;
+  auto take = [&](const std::string& fan, const std::string& tmpfasta) -> bool {
+    std::string qr = tmpfasta.substr(tmpfasta.size() - c.kmer);
+    if (!c.pruneprimer || count_le(qr, c.maxPruneCount)) {
+      qr = revcomp_upper(qr);
+      if (!c.pruneprimer || count_le(qr, c.maxPruneCount)) {
+        std::string inseq;
+        for (char ch : tmpfasta) {  // util.h:208-219
+          if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') inseq.push_back(ch);
+          else {
+            msg.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
+            inseq.push_back('N');
+          }
+        }
+        if (inseq.size() < 10 || inseq.size() < c.kmer) {
+          msg.push_back("Error: Input sequence is shorter than 10 nucleotides or shorter than the selected k-mer length!");
+          return false;
+        }
+        if (c.distance >= inseq.size()) {
+          c.distance = (uint32_t)inseq.size() - 1;
+          msg.push_back("Warning: Distance was adjusted to sequence length!");
+        }
+        pName.push_back(fan);
+        pSeq.push_back(inseq);
+      }
+    }
+    return true;
+  };
+  {
+    std::ifstream fa(c.infile.c_str());
+    std::string fan, tmpfasta, line;
+    while (!fatal && std::getline(fa, line)) {
+      if (line.empty()) continue;
+      if (line[0] == '>') {
+        if (!fan.empty() && !tmpfasta.empty() && tmpfasta.size() > c.kmer) {
+          if (!take(fan, tmpfasta)) fatal = true;
+          tmpfasta = "";
+        }
+        fan = line.substr(1);
+      } else {
+        for (auto& ch : line) ch = (char)std::toupper((unsigned char)ch);
+        tmpfasta += line;
+      }
+    }
+    if (!fatal && !fan.empty() && !tmpfasta.empty() && tmpfasta.size() > c.kmer)
+      if (!take(fan, tmpfasta)) fatal = true;
+  }
+  auto finish = [&](int rc) {
+    emit_search(c, search_json(c, ix, seqlen, seqname, allp, pcrColl, pName, pSeq, msg));
+    dg_thal_close(th);
+    dg_index_close(ix);
+    return rc;
+  };
+  if (fatal) return finish(1);
+  const uint32_t nseq = (uint32_t)seqlen.size();
+  std::vector<std::vector<PrimerBind>> forBind(nseq), revBind(nseq);
+  if (!pSeq.empty()) {
+    std::string pb;
+    std::vector<uint64_t> poff(1, 0);
+    for (auto& s : pSeq) {
+      pb += s;
+      poff.push_back(pb.size());
+    }
+    dg_search_params sp;
+    sp.distance = c.distance;
+    sp.hamming = c.hamming;
+    sp.max_locations = c.max_locations;
+    sp.max_neighborhood = c.maxNeighborhood;
+    sp.kmer = c.kmer;
+    sp.cut_temp = c.cutTemp;
+    dg_search_result* R = nullptr;
+    if (dg_search_sites(ix, th, &sp, seqlen.data(), nseq, (const uint8_t*)pb.data(), poff.data(), pSeq.size(), &R) != DG_OK) {
+      std::cerr << "dicey: " << dg_last_error() << std::endl;
+      dg_thal_close(th);
+      dg_index_close(ix);
+      return 2;
+    }
+    // per primer in order: a thal failure ends the run with the error JSON (silica.h:438-442, 512-516)
+    uint64_t si = 0;
+    for (size_t q = 0; q < pSeq.size(); ++q) {
+      if (R->pflags[q] & DG_P_THAL_FAILED) {
+        msg.push_back("Error: Thermodynamical calculation failed!");
+        dg_search_result_free(R);
+        return finish(1);
+      }
+      for (; si < R->nsites && R->sites[si].primer == q; ++si) {
+        const dg_site& s = R->sites[si];
+        PrimerBind b;
+        b.refIndex = s.ref;
+        b.pos = s.pos;
+        b.primerId = s.primer;
+        b.onFor = s.on_for != 0;
+        b.temp = s.temp;
+        b.perfTemp = s.perf_temp;
+        b.genome.assign(R->genome_pool + s.genome_off, s.genome_len);
+        (b.onFor ? forBind : revBind)[s.ref].push_back(b);
+      }
+      if (R->pflags[q] & DG_Q_MAX_MATCHES) {
+        std::string x = std::to_string(c.max_locations);
+        msg.push_back("Warning: More than " + x + " matches found. Only first " + x + " matches are reported, results are likely incomplete!");
+      }
+    }
+    dg_search_result_free(R);
+  }
+  for (uint32_t r = 0; r < nseq; ++r) {  // silica.h:581-584
+    allp.insert(allp.end(), forBind[r].begin(), forBind[r].end());
+    allp.insert(allp.end(), revBind[r].begin(), revBind[r].end());
+  }
+  std::sort(allp.begin(), allp.end());  // silica.h:587
+  if (!c.pruneprimer) {
+    for (uint32_t r = 0; r < nseq; ++r) {  // silica.h:592-634
+      std::vector<std::pair<uint32_t, uint32_t>> rvByPos;
+      rvByPos.reserve(revBind[r].size());
+      for (uint32_t k = 0; k < revBind[r].size(); ++k) rvByPos.push_back(std::make_pair(revBind[r][k].pos, k));
+      std::sort(rvByPos.begin(), rvByPos.end());
+      std::vector<uint32_t> rvPos(rvByPos.size());
+      for (uint32_t k = 0; k < rvByPos.size(); ++k) rvPos[k] = rvByPos[k].first;
+      std::vector<uint32_t> cand;
+      for (auto fw = forBind[r].begin(); fw != forBind[r].end(); ++fw) {
+        auto loIt = std::upper_bound(rvPos.begin(), rvPos.end(), fw->pos);
+        auto hiIt = rvPos.end();
+        uint64_t hiBound = (uint64_t)fw->pos + (uint64_t)c.maxProdSize;
+        if (hiBound < ((uint64_t)1 << 32)) hiIt = std::upper_bound(rvPos.begin(), rvPos.end(), (uint32_t)hiBound);
+        cand.clear();
+        for (auto pit = loIt; pit != hiIt; ++pit) cand.push_back(rvByPos[pit - rvPos.begin()].second);
+        std::sort(cand.begin(), cand.end());
+        for (uint32_t ci : cand) {
+          const PrimerBind& rv = revBind[r][ci];
+          if ((rv.pos > fw->pos) && (rv.pos + pSeq[rv.primerId].size() - fw->pos <= c.maxProdSize)) {
+            PcrProduct pp;
+            pp.refIndex = r;
+            pp.forPos = fw->pos;
+            pp.forTemp = fw->temp;
+            pp.forId = fw->primerId;
+            pp.revPos = rv.pos;
+            pp.revTemp = rv.temp;
+            pp.revId = rv.primerId;
+            pp.leng = (uint32_t)((rv.pos + pSeq[pp.revId].size()) - fw->pos);
+            double pen = (fw->perfTemp - fw->temp) * c.penDiff;
+            if (pen < 0) pen = 0;
+            double bpen = (rv.perfTemp - rv.temp) * c.penDiff;
+            if (bpen > 0) pen += bpen;
+            pen += std::abs(fw->temp - rv.temp) * c.penMis;
+            pen += pp.leng * c.penLen;
+            pp.penalty = pen;
+            if ((c.cutofPen < 0) || (pen < c.cutofPen)) pcrColl.push_back(pp);
+          }
+        }
+      }
+    }
+    std::sort(pcrColl.begin(), pcrColl.end());  // silica.h:637
+  }
+  return finish(0);
+}
+
 // ------------------------------------------------------------------------------------------------ index (index.h:34-141)
 int indexer(int argc, char** argv) {
   std::string genome, outfile;
@@ -529,8 +896,9 @@ void display_usage() {  // dicey.cpp:19-33 (only the subcommands this build carr
   std::cout << std::endl;
   std::cout << "    index        index FASTA reference file (GPU builder)" << std::endl;
   std::cout << "    hunt         search DNA sequences (MI355X search path)" << std::endl;
+  std::cout << "    search       in-silico PCR (MI355X search path)" << std::endl;
   std::cout << std::endl;
-  std::cout << "search, padlock, chop and mappability are not part of this build; use the reference binary for them." << std::endl;
+  std::cout << "padlock, chop and mappability are not part of this build; use the reference binary for them." << std::endl;
   std::cout << std::endl;
 }
 
@@ -552,6 +920,7 @@ int main(int argc, char** argv) {
   }
   if (cmd == "hunt") return hunter(argc - 1, argv + 1);
   if (cmd == "index") return indexer(argc - 1, argv + 1);
+  if (cmd == "search") return silica(argc - 1, argv + 1);
   std::cerr << "Unrecognized command " << cmd << std::endl;
   return 1;
 }

@@ -8,19 +8,7 @@
 #include "index_internal.hpp"
 #include "thal.hpp"
 
-struct dg_thal {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  dg::thal::Tables host_tables;
-  dg::thal::Tables* d_tables = nullptr;
-  dg::thal::Env env;
-  dg::DevBuf ws[6];
-  ~dg_thal() {
-    if (d_tables) (void)hipFree(d_tables);
-    for (auto& w : ws) w.release();
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-};
+#include "thal_internal.hpp"
 
 namespace dg {
 namespace {

@@ -165,6 +165,46 @@ void dg_thal_close(dg_thal* th);
  * when both sequences exceed 60 nt), end1/end2 = align_end_1/2 (may be NULL) */
 int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t npairs, double* temp, int32_t* end1, int32_t* end2);
 
+/* ---- `dicey search`: binding sites of a batch of primers (reference src/silica.h:429-573) ----
+ * Per primer: thal(primer, revcomp) (silica.h:437); neighbourhood of its last k nucleotides on both strands through the
+ * FM-index; per located hit the context window with the 5' overhang, thal(primer, window), the Tm cut, the alignment
+ * position that de-duplicates hits, and the trimmed genomic site (silica.h:474-566). */
+typedef struct {
+  uint32_t distance;         /* -d */
+  int32_t hamming;           /* -n */
+  uint64_t max_locations;    /* -m (default 10000) */
+  uint32_t max_neighborhood; /* -x */
+  uint32_t kmer;             /* -k (default 15) */
+  double cut_temp;           /* -c (default 45.0) */
+} dg_search_params;
+#define DG_P_THAL_FAILED 16u /* "Error: Thermodynamical calculation failed!" (silica.h:438-442, 512-516) */
+typedef struct {
+  uint32_t ref;      /* refIndex */
+  uint32_t pos;      /* PrimerBind::pos (0-based) */
+  uint32_t primer;   /* primerId */
+  uint8_t on_for;    /* forward-strand site */
+  uint8_t reserved[3];
+  double temp;       /* Tm of primer vs site */
+  double perf_temp;  /* Tm of primer vs its perfect complement */
+  uint64_t genome_off;
+  uint32_t genome_len;
+  uint32_t pad;
+} dg_site;
+typedef struct {
+  size_t nprimers;
+  uint64_t nsites;
+  dg_site* sites;     /* reference push order: primer-major, forward-strand hits then reverse-strand hits */
+  char* genome_pool;  /* PrimerBind::genome strings */
+  uint32_t* pflags;   /* [nprimers] DG_Q_MAX_MATCHES | DG_P_THAL_FAILED */
+  double* match_temp; /* [nprimers] */
+  uint64_t nhits;     /* located hits, each of which went through thal() */
+  double ms_device;   /* device time of the search + site kernels (HIP events) */
+} dg_search_result;
+/* primers: already upper-cased / N-replaced sequences (silica.h:368), each at least `kmer` long */
+int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const uint32_t* seqlen, uint32_t nseq,
+                    const uint8_t* pbytes, const uint64_t* poff, size_t nprimers, dg_search_result** out);
+void dg_search_result_free(dg_search_result* r);
+
 const char* dg_last_error(void);
 int dg_abi_version(void);
 int dg_device_count(void);

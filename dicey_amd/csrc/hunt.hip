@@ -18,6 +18,7 @@
 // This holds while the maxNeighborhood cap cannot fire; dg_hunt refuses (DG_ELIMIT) inputs where it could.
 #include <algorithm>
 #include <chrono>
+#include <set>
 
 #include "devfm.hpp"
 #include "index_internal.hpp"
@@ -1747,7 +1748,7 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
     u32 fl = qfl[q] & DG_Q_MAX_MATCHES;
     if (R->match_temp[q] == -thal::kInf) fl |= DG_P_THAL_FAILED;
     const u32 plen = (u32)(poff[q + 1] - poff[q]);
-    std::vector<std::pair<u32, u32>> seen[2];
+    std::set<std::pair<u32, u32>> seen[2];  // silica.h:465 TUniquePrimerHits, one per strand
     for (u64 h = hoff[q]; h < hoff[q + 1]; ++h) {
       const SiteRaw& r = raw[h];
       const u32 fr = r.qs & 1;
@@ -1757,8 +1758,7 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
       }
       if (!(r.temp > p->cut_temp)) continue;
       std::pair<u32, u32> key(r.ref, r.alignpos);
-      if (std::find(seen[fr].begin(), seen[fr].end(), key) != seen[fr].end()) continue;
-      seen[fr].push_back(key);
+      if (!seen[fr].insert(key).second) continue;
       const char* g = (const char*)win.data() + h * (u64)sx.win_stride;
       u32 glen = std::min<u32>(r.glen, sx.win_stride);
       u32 chrpos, goff = 0, gl = glen;

@@ -69,7 +69,7 @@ def test_search_json_identical_to_oracle(pcr, extra, kw):
     assert r.stdout == want
     j = json.loads(r.stdout)
     if not kw:
-        assert len(j["data"]["primers"]) >= 40 and len(j["data"]["amplicons"]) >= 10  # the designed pairs are found
+        assert len(j["data"]["primers"]) >= 15 and len(j["data"]["amplicons"]) >= 3  # the designed pairs are found
 
 
 @needs_ref

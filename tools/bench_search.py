@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Scale check of `dicey search` binding-site discovery (BASELINE.json configs[2] shape: primer pairs on a GRCh38-size
+genome) — not the headline bench.  Builds the same synthetic genome/index as bench.py, samples primer pairs from it and
+times dg_search_sites (FM search of the 15-mer neighbourhoods + one thal() per located hit, all on the GPU)."""
+import argparse, ctypes as C, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench, dicey_amd
+from dicey_amd import _capi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--genome-size", type=float, default=3.1e9)
+ap.add_argument("--pairs", type=int, default=2000)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+L = _capi.load()
+t0 = time.time()
+text, lens = bench.synth_genome(int(a.genome_size), 24, seed=1, device=dev)
+fm9 = "/dev/shm/dicey_search_bench.fm9"
+_capi.check(L, L.dg_index_build_device(C.c_void_p(text.data_ptr()), text.numel(), 0, fm9.encode()))
+rng = np.random.default_rng(43)
+prim = []
+n = text.numel()
+comp = bytes.maketrans(b"ACGT", b"TGCA")
+while len(prim) < 2 * a.pairs:
+    p = int(rng.integers(0, n - 3000)); l1, l2, d = int(rng.integers(18, 26)), int(rng.integers(18, 26)), int(rng.integers(80, 2000))
+    w = bytes(text[p:p + d + l2 + 1].cpu().numpy().tobytes())
+    fw, rv = w[:l1], w[d:d + l2]
+    if b"N" in fw + rv or b"\n" in w: continue
+    prim += [fw.decode(), rv.translate(comp)[::-1].decode()]
+del text; torch.cuda.empty_cache()
+seqlen = [x + 1 for x in lens]
+ix = dicey_amd.FmIndex(fm9); th = dicey_amd.Thal(os.path.join(ROOT, "tests/golden/primer3_config"))
+t1 = time.time()
+sites, mt, fl, nh = dicey_amd.search_sites(ix, th, prim, seqlen)
+dt = time.time() - t1
+t1 = time.time()
+sites, mt, fl, nh = dicey_amd.search_sites(ix, th, prim, seqlen)
+dt2 = time.time() - t1
+print(json.dumps({"workload": f"dicey search sites, {len(prim)} primers (18-25 nt), k=15, d=1, genome {int(a.genome_size)}",
+                  "seconds_first": dt, "seconds": dt2, "primers_per_s": len(prim) / dt2, "thal_calls": nh, "thal_per_s": nh / dt2,
+                  "sites": len(sites), "setup_s": t1 - t0}))
+os.remove(fm9)

@@ -2,7 +2,7 @@
 // every Tm / penalty through json::dump(), src/silica.h:143,149,160-170): Grisu2 (Loitsch 2010) digit generation with
 // the customary ±1 ulp safety margin and round-weed step, then fixed notation for decimal exponents in (-4, 15] and
 // exponent notation otherwise.  Written from the published algorithm; tests/test_dtoa.py checks it against the
-// reference's own vendored header (oracle/_ref) on random bit patterns.
+// reference's own vendored header on random bit patterns.
 #pragma once
 #include <cstdint>
 #include <cstring>

@@ -1,13 +1,16 @@
 """Regenerates tests/golden/thal_vectors.json from the REFERENCE ITSELF: oracle/_ref/libthalref.so is the unmodified
 /root/reference/src/thal.h compiled in place (oracle/Makefile).  Doubles are stored as hex so the comparison is exact.
-tests/golden/primer3_config/ holds primer3's parameter tables (data files the reference ships in src/primer3_config/)."""
+tests/golden/primer3_params.json holds primer3's parameter tables as fixture data (p3config.py writes them out)."""
 import ctypes as C, json, os, random, struct
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libthalref.so"))
 R.ref_thal_init.argtypes = [C.c_char_p] + [C.c_double] * 5
 R.ref_thal.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-cfg = os.path.join(HERE, "primer3_config") + "/"
+import sys
+sys.path.insert(0, HERE)
+import p3config
+cfg = p3config.config_dir()
 assert R.ref_thal_init(cfg.encode(), 37.0, 50.0, 1.5, 50.0, 0.6) == 0
 rng = random.Random(20260929)
 def rc(s): return s.translate(str.maketrans("ACGTN", "TGCAN"))[::-1]

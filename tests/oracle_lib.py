@@ -25,7 +25,12 @@ class SearchParams(C.Structure):
 
 REF_THAL = os.path.join(_ODIR, "_ref", "libthalref.so")
 REF_JSON = os.path.join(_ODIR, "_ref", "libjsonref.so")
-PRIMER3_CONFIG = os.path.join(_ROOT, "tests", "golden", "primer3_config") + "/"
+sys_path_added = os.path.join(_ROOT, "tests", "golden")
+import sys as _sys
+if sys_path_added not in _sys.path:
+    _sys.path.insert(0, sys_path_added)
+import p3config as _p3
+PRIMER3_CONFIG = _p3.config_dir()
 _ref = {}
 
 

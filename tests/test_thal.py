@@ -7,6 +7,8 @@ import struct
 
 import pytest
 
+import oracle_lib as O
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libthalref.so")
@@ -30,7 +32,7 @@ def test_reference_build_reproduces_the_golden_vectors():
     R.ref_thal.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     g = _vectors()
     p = g["params"]
-    assert R.ref_thal_init((os.path.join(GOLD, "primer3_config") + "/").encode(), p["temp_c"], p["mv"], p["dv"], p["dna_conc"], p["dntp"]) == 0
+    assert R.ref_thal_init(O.PRIMER3_CONFIG.encode(), p["temp_c"], p["mv"], p["dv"], p["dna_conc"], p["dntp"]) == 0
     t, a, b = C.c_double(), C.c_int(), C.c_int()
     for o1, o2, hx, e1, e2, ok in g["vectors"][:300]:
         assert R.ref_thal(o1.encode(), o2.encode(), C.byref(t), C.byref(a), C.byref(b)) == ok
@@ -42,7 +44,7 @@ def test_thal_kernel_is_bit_identical_to_the_reference():
     import dicey_amd
     g = _vectors()
     p = g["params"]
-    th = dicey_amd.Thal(os.path.join(GOLD, "primer3_config"), mv=p["mv"], dv=p["dv"], dntp=p["dntp"], dna_conc=p["dna_conc"])
+    th = dicey_amd.Thal(O.PRIMER3_CONFIG, mv=p["mv"], dv=p["dv"], dntp=p["dntp"], dna_conc=p["dna_conc"])
     got = th.tm([(v[0], v[1]) for v in g["vectors"]])
     bad = [(v, r) for v, r in zip(g["vectors"], got)
            if struct.pack(">d", r[0]).hex() != v[2] or [r[1], r[2]] != v[3:5]]

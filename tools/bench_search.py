@@ -31,7 +31,9 @@ while len(prim) < 2 * a.pairs:
     prim += [fw.decode(), rv.translate(comp)[::-1].decode()]
 del text; torch.cuda.empty_cache()
 seqlen = [x + 1 for x in lens]
-ix = dicey_amd.FmIndex(fm9); th = dicey_amd.Thal(os.path.join(ROOT, "tests/golden/primer3_config"))
+ix = dicey_amd.FmIndex(fm9); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import p3config
+th = dicey_amd.Thal(p3config.config_dir())
 t1 = time.time()
 sites, mt, fl, nh = dicey_amd.search_sites(ix, th, prim, seqlen)
 dt = time.time() - t1

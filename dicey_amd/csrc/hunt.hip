@@ -59,6 +59,12 @@ struct Batch {  // device pointers of one batch
   u32 distance;
   u32 indel, reverse;
   u64 max_locations;
+  struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
+};
+struct GidInfo {
+  u64 qpk;    // the sequence 2-bit packed, q[i] at bits 2(m-1-i) (only for m <= 32 without N)
+  u32 m;      // length; 0 = this (query, strand) is not searched
+  u32 d_win;  // bits 0-7 effective distance, bit 8: window mode allowed by the query (no N)
 };
 
 DG_DEV u32 ascii_rank(u32 code) { return code == 3 ? 4u : code == 4 ? 3u : code; }  // 'A'<'C'<'G'<'N'<'T'
@@ -89,6 +95,17 @@ __global__ void k_prepare(Batch b) {
   b.qdist[q] = d;
   b.qflags[q] = flags;
   b.qnondna[q] = bad;
+  for (u32 strand = 0; strand < 2; ++strand) {
+    GidInfo gi;
+    gi.qpk = 0;
+    gi.m = ((flags & DG_Q_TOO_SHORT) || (strand && !b.reverse)) ? 0u : m;
+    gi.d_win = d | (bad == 0 ? 256u : 0u);
+    if (bad == 0 && m <= 32) {
+      const u8* sq = (strand ? b.rv : b.fw) + s;
+      for (u32 i = 0; i < m; ++i) gi.qpk |= (u64)sq[i] << (2 * (m - 1 - i));
+    }
+    b.ginfo[2 * q + strand] = gi;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -216,22 +233,25 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   u64 steps = 0, lookups = 0;
   constexpr u32 NOPS = INDEL ? 9u : 4u;  // INDEL: D, S(A,C,G,T), I(A,C,G,T);  Hamming: S(A,C,G,T)
   bool active = gid < ngrp;
-  u64 q = gid >> 1;
-  u32 strand = (u32)(gid & 1);
-  if (active && ((strand && !b.reverse) || (b.qflags[q] & DG_Q_TOO_SHORT))) active = false;
+  const u64 q = gid >> 1;
+  const u32 strand = (u32)(gid & 1);
+  GidInfo gi;
+  gi.qpk = 0;
+  gi.m = 0;
+  gi.d_win = 0;
+  if (active) gi = b.ginfo[gid];
+  if (gi.m == 0) active = false;
   if (active) {
     const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
-    const u32 m = b.qlen[q];
-    u32 d = b.qdist[q];
+    const u32 m = gi.m;
+    u32 d = gi.d_win & 255;
     if (d > (u32)D) d = D;  // cannot happen: the host instantiates D >= the largest effective distance
-    const bool use_win = f.K != 0 && m >= f.K + d && b.qnondna[q] == 0;
+    const bool use_win = f.K != 0 && m >= f.K + d && (gi.d_win & 256);
     const bool rest = item == items - 1;
     // lanes of a split launch: without the table (or without budget) only the rest lane works, as a full search
     if (!rest && (!use_win || d == 0)) active = false;
     if (active) {
-      u64 qpk = 0;
-      if (use_win && m <= 32)
-        for (u32 i = 0; i < m; ++i) qpk |= (u64)seq[i] << (2 * (m - 1 - i));
+      const u64 qpk = gi.qpk;
       FrameStack<D> S;
       OpStack<D> ops;
       u32 L = 0;
@@ -288,7 +308,8 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
           continue;
         }
         const u32 pos = F.pos;
-        const u32 here = seq[pos - 1];
+        // the query character: from the packed copy when there is one (no memory access on the critical path)
+        const u32 here = (m <= 32 && (gi.d_win & 256)) ? (u32)(qpk >> (2 * (m - pos))) & 3u : (u32)seq[pos - 1];
         const u32 op = F.st & 15;
         if (single && L == 0 && op != single_op) break;  // the item's one operation has been explored
         if (budget > 0 && op < NOPS) {
@@ -1184,7 +1205,7 @@ __global__ void __launch_bounds__(64) k_site(FmView f, Batch b, SiteArgs a, Coun
 // ------------------------------------------------------------------------------------------------------------
 // Host orchestration
 // ------------------------------------------------------------------------------------------------------------
-enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM };
+enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO };
 
 static double ev_ms(hipEvent_t a, hipEvent_t b) {
   float ms = 0;
@@ -1289,6 +1310,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   DG_TRY(ws[WS_RV].reserve(total + 8));
   DG_TRY(ws[WS_QSEQ].reserve(total + 8));
   DG_TRY(ws[WS_QMETA].reserve(nq * 16 + 64));
+  DG_TRY(ws[WS_GINFO].reserve(ngrp * sizeof(GidInfo) + 64));
   DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 2 + nq * 4 + scan_tmp * 8 + 256));
   DG_TRY(ws[WS_MISC].reserve(sizeof(Counters)));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
@@ -1308,6 +1330,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   b.indel = indel;
   b.reverse = !p->forward_only;
   b.max_locations = p->max_locations;
+  b.ginfo = ws[WS_GINFO].as<GidInfo>();
   u8* gp = ws[WS_GRP].as<u8>();
   u64* grp_off = (u64*)gp;
   gp += (ngrp + 1) * 8;

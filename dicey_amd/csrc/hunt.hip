@@ -361,11 +361,27 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
 }
 
-__global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap) {
-  if (blockIdx.x || threadIdx.x) return;
-  u32 bad = 0;
-  for (u32 k = 0; k < NSHARD; ++k) bad |= ctr->leaf_cnt[k] > shard_cap;
-  ctr->overflow = bad;
+__global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap) {  // NSHARD lanes
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < NSHARD && ctr->leaf_cnt[k] > shard_cap) atomicOr(&ctr->overflow, 1u);
+}
+// what the host needs at the end of a batch, in 64 bytes instead of the 36 KB of sharded counters
+struct Summary {
+  unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow;
+};
+__global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {  // NSHARD lanes
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= NSHARD) return;
+  atomicAdd(&out->nleaf, (unsigned long long)ctr->leaf_cnt[k]);
+  atomicMax(&out->worst_shard, (unsigned long long)ctr->leaf_cnt[k]);
+  if (ctr->steps[k]) atomicAdd(&out->steps, ctr->steps[k]);
+  if (ctr->lookups[k]) atomicAdd(&out->lookups, ctr->lookups[k]);
+  if (ctr->sa_reads[k]) atomicAdd(&out->sa_reads, ctr->sa_reads[k]);
+  if (ctr->win_bytes[k]) atomicAdd(&out->win_bytes, ctr->win_bytes[k]);
+  if (k == 0) {
+    out->nhits = *nhits;
+    out->overflow = ctr->overflow;
+  }
 }
 // group leaves by (query,strand): dst = grp_off[qs] + slot
 __global__ void k_group(const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, Leaf* out) {
@@ -1312,7 +1328,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   DG_TRY(ws[WS_QMETA].reserve(nq * 16 + 64));
   DG_TRY(ws[WS_GINFO].reserve(ngrp * sizeof(GidInfo) + 64));
   DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 2 + nq * 4 + scan_tmp * 8 + 256));
-  DG_TRY(ws[WS_MISC].reserve(sizeof(Counters)));
+  DG_TRY(ws[WS_MISC].reserve(sizeof(Counters) + sizeof(Summary) + 64));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   Batch b;
   b.qbytes = (const u8*)d_qbytes;
@@ -1344,15 +1360,20 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   gp += ngrp * 4;
   u32* qhits = (u32*)gp;
   Counters* ctr = ws[WS_MISC].as<Counters>();
-  std::vector<Counters> hctr_store(1);
-  Counters& hctr = hctr_store[0];
+  Summary* d_sum = (Summary*)(ws[WS_MISC].as<u8>() + ((sizeof(Counters) + 63) & ~(size_t)63));
+  if (!ix->pinned) DG_HIP(hipHostMalloc((void**)&ix->pinned, 4096, 0));
+  Summary& hsum = *(Summary*)ix->pinned;
   std::vector<u64> cum(nseq);
   u64 run = 0;
   for (u32 r = 0; r < nseq; ++r) {
     cum[r] = run;
     run += seqlen[r];
   }
-  DG_HIP(hipMemcpyAsync(ws[WS_CUM].p, cum.data(), (u64)nseq * 8, hipMemcpyHostToDevice, st));
+  if (cum != ix->cum_cache) {  // sequence lengths rarely change between batches
+    DG_HIP(hipMemcpyAsync(ws[WS_CUM].p, cum.data(), (u64)nseq * 8, hipMemcpyHostToDevice, st));
+    DG_HIP(hipStreamSynchronize(st));
+    ix->cum_cache = cum;
+  }
 
   u32 shard_cap = std::max<u32>(ix->shard_cap_hint, (u32)std::max<u64>(64, (16 * (u64)nq) / NSHARD));
   u64 hit_cap = std::max<u64>(ix->hit_cap_hint, 4 * (u64)nq + 1024);
@@ -1372,7 +1393,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
     DG_TRY(ws[WS_JOBS].reserve(std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
     DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
-    DG_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
+    DG_HIP(hipMemsetAsync(ctr, 0, ((sizeof(Counters) + 63) & ~(size_t)63) + sizeof(Summary), st));
     DG_HIP(hipMemsetAsync(grp_cnt, 0, ngrp * 4 * 2, st));  // grp_cnt and nsel are adjacent
     DG_HIP(hipEventRecord(ix->ev[0], st));
     hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b);
@@ -1401,7 +1422,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
 #undef DG_LAUNCH_SEARCH
     }
     DG_HIP(hipEventRecord(ix->ev[2], st));
-    hipLaunchKernelGGL(k_leaf_overflow, dim3(1), dim3(64), 0, st, ctr, shard_cap);
+    hipLaunchKernelGGL(k_leaf_overflow, dim3(NSHARD / 256), dim3(256), 0, st, ctr, shard_cap);
     DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf));
     DG_HIP(hipEventRecord(ix->ev[3], st));
     if (packed) {
@@ -1495,16 +1516,13 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
     }
     DG_HIP(hipEventRecord(ix->ev[7], st));
-    DG_HIP(hipMemcpyAsync(&hctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
-    DG_HIP(hipMemcpyAsync(&nhits, hit_off + nq, 8, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_summary, dim3(NSHARD / 256), dim3(256), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), d_sum);
+    DG_HIP(hipMemcpyAsync(&hsum, d_sum, sizeof(Summary), hipMemcpyDeviceToHost, st));
     DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
     DG_HIP(hipGetLastError());
-    nleaf = 0;
-    u32 worst = 0;
-    for (u32 k = 0; k < NSHARD; ++k) {
-      nleaf += hctr.leaf_cnt[k];
-      worst = std::max(worst, hctr.leaf_cnt[k]);
-    }
+    nleaf = hsum.nleaf;
+    nhits = hsum.nhits;
+    const u32 worst = (u32)hsum.worst_shard;
     if (worst > shard_cap) {
       shard_cap = worst + worst / 4 + 64;
       continue;
@@ -1553,12 +1571,10 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   R->d_refalign = ws[WS_ALN].p;
   R->d_queryalign = ws[WS_ALN].as<char>() + (hit_cap + 1) * (u64)stride;
   R->ctr_leaves = nleaf;
-  for (u32 k = 0; k < NSHARD; ++k) {
-    R->ctr_ext_steps += hctr.steps[k];
-    R->ctr_tab_reads += hctr.lookups[k];
-    R->ctr_sa_reads += hctr.sa_reads[k];
-    R->ctr_win_bytes += hctr.win_bytes[k];
-  }
+  R->ctr_ext_steps = hsum.steps;
+  R->ctr_tab_reads = hsum.lookups;
+  R->ctr_sa_reads = hsum.sa_reads;
+  R->ctr_win_bytes = hsum.win_bytes;
   R->ms_total = ev_ms(ix->ev[0], ix->ev[7]);
   R->ms_search = ev_ms(ix->ev[1], ix->ev[2]);
   R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);

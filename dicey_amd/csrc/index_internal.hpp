@@ -18,5 +18,7 @@ struct dg_index {
   hipEvent_t ev[8] = {nullptr};
   uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
   uint64_t hit_cap_hint = 0;
+  void* pinned = nullptr;             // 4 KB of pinned host memory for the end-of-batch summary
+  std::vector<uint64_t> cum_cache;    // cumulative sequence starts currently resident in WS_CUM
   ~dg_index();
 };

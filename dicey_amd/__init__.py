@@ -222,6 +222,7 @@ def search_sites(ix: "FmIndex", th: "Thal", primers: Sequence[str], seqlen: Sequ
             g = C.string_at(C.addressof(R.genome_pool.contents) + s.genome_off, s.genome_len).decode("latin-1")
             sites.append({"ref": s.ref, "pos": s.pos, "primer": s.primer, "on_for": bool(s.on_for), "temp": s.temp,
                           "perf_temp": s.perf_temp, "genome": g})
+        search_sites.last_ms_device = R.ms_device
         return sites, [R.match_temp[i] for i in range(R.nprimers)], [R.pflags[i] for i in range(R.nprimers)], R.nhits
     finally:
         L.dg_search_result_free(rp)

@@ -1092,8 +1092,9 @@ struct SiteArgs {
   SiteRaw* out;
   u8* windows;
   u32 win_stride;
-  double* dp;      // per launch lane: 2 * dp_stride doubles
-  u64 dp_stride;
+  double* dp;      // per launch lane: 2 * dp_stride doubles, interleaved per wavefront
+  u64 dp_stride;   // cells per plane = max primer length * dp_row
+  u32 dp_row;      // common row length (largest window of the batch)
 };
 DG_DEV bool codes_self_complementary(const u8* s, u32 n, bool ascii) {  // symmetry_thermo, thal.h:1976-2010
   if (n & 1) return false;
@@ -1105,8 +1106,20 @@ DG_DEV bool codes_self_complementary(const u8* s, u32 n, bool ascii) {  // symme
   }
   return true;
 }
-template <u32 TRACE_WORDS>
-__global__ void __launch_bounds__(64) k_site(FmView f, Batch b, SiteArgs a, Counters* ctr) {
+// LDS_TABLES: the 45 KB of nearest-neighbour tables are staged in LDS once per workgroup (every loop step of thal reads
+// about ten of them).  DP planes are interleaved across the 64 lanes of a wavefront with a common row length, so lanes
+// working on the same (i,j) cell read one contiguous 512-byte run instead of 64 scattered lines.
+template <u32 TRACE_WORDS, bool LDS_TABLES>
+__global__ void __launch_bounds__(256) k_site(FmView f, Batch b, SiteArgs a, Counters* ctr) {
+  __shared__ thal::Tables lds_tables;
+  const thal::Tables* tabs = a.tables;
+  if (LDS_TABLES) {
+    const u64* src = reinterpret_cast<const u64*>(a.tables);
+    u64* dst = reinterpret_cast<u64*>(&lds_tables);
+    for (u32 k = threadIdx.x; k < sizeof(thal::Tables) / 8; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+    tabs = &lds_tables;
+  }
   const u64 lane = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 h = a.first + lane;
   const u64 nh = *a.nhits;
@@ -1155,17 +1168,35 @@ __global__ void __launch_bounds__(64) k_site(FmView f, Batch b, SiteArgs a, Coun
   r.pad = 0;
   r.temp = -thal::kInf;
   if (!(plen > (u32)thal::kMaxAlign && mg > (u32)thal::kMaxAlign) && plen <= 64 && mg <= 320) {
-    u8 fa[66], fb[322];
-    fa[0] = fa[plen + 1] = 4;
-    for (u32 i = 0; i < plen; ++i) fa[i + 1] = prim[i];
-    fb[0] = fb[mg + 1] = 4;
-    for (u32 j = 0; j < mg; ++j) {
-      u32 c = code_of_byte(g[mg - 1 - j]);
-      fb[j + 1] = (u8)(c < 4 ? c : 4);
-    }
     const bool sym = codes_self_complementary(prim, plen, false) && codes_self_complementary(g, mg, true);
-    double* H = a.dp + lane * 2 * a.dp_stride;
-    thal::Result tr = thal::end1_tm(*a.tables, a.env, fa, (int)plen, fb, (int)mg, sym, H, H + a.dp_stride);
+    // wave w of this launch owns 64 * 2 * dp_stride doubles; inside, cell c of lane l sits at c*64 + l
+    double* H = a.dp + (lane >> 6) * (64 * 2 * a.dp_stride) + (lane & 63);
+    thal::Result tr;
+    if (plen <= (u32)thal::kPackedMax && mg <= (u32)thal::kPackedMax) {  // sequences in registers
+      thal::PackedSeq fa, fb;
+      fa.set(0, 4);
+      fa.set((int)plen + 1, 4);
+      for (u32 i = 0; i < plen; ++i) fa.set((int)i + 1, prim[i]);
+      fb.set(0, 4);
+      fb.set((int)mg + 1, 4);
+      for (u32 j = 0; j < mg; ++j) {
+        u32 c = code_of_byte(g[mg - 1 - j]);
+        fb.set((int)j + 1, c < 4 ? c : 4);
+      }
+      tr = thal::end1_tm<thal::PackedSeq>(*tabs, a.env, fa, (int)plen, fb, (int)mg, sym, H, H + 64 * a.dp_stride, (int)a.dp_row, 64);
+    } else {
+      u8 fa[66], fb[322];
+      fa[0] = fa[plen + 1] = 4;
+      for (u32 i = 0; i < plen; ++i) fa[i + 1] = prim[i];
+      fb[0] = fb[mg + 1] = 4;
+      for (u32 j = 0; j < mg; ++j) {
+        u32 c = code_of_byte(g[mg - 1 - j]);
+        fb[j + 1] = (u8)(c < 4 ? c : 4);
+      }
+      const u8* pa = fa;
+      const u8* pb = fb;
+      tr = thal::end1_tm<const u8*>(*tabs, a.env, pa, (int)plen, pb, (int)mg, sym, H, H + 64 * a.dp_stride, (int)a.dp_row, 64);
+    }
     r.temp = tr.temp;
   }
   u32 alignpos = chrpos;
@@ -1465,7 +1496,7 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
       const u64 chunk = std::max<u64>(4096, std::min<u64>(hit_cap, ((u64)6 << 30) / (2 * dp_stride * 8 + 1)));
       DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(SiteRaw)));
       DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * (u64)wstride));
-      DG_TRY(ws[WS_DP].reserve(chunk * 2 * dp_stride * 8 + 64));
+      DG_TRY(ws[WS_DP].reserve(((chunk + 63) & ~(u64)63) * 2 * dp_stride * 8 + 64));
       SiteArgs sa;
       sa.seeds = ws[WS_SEEDS].as<HitSeed>();
       sa.nhits = hit_off + nq;
@@ -1484,13 +1515,20 @@ static int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
       sa.win_stride = wstride;
       sa.dp = ws[WS_DP].as<double>();
       sa.dp_stride = dp_stride;
+      sa.dp_row = wmax;
       const u32 cells = (wmax + 1) * (maxlen + 1);
       for (u64 first = 0; first < hit_cap; first += chunk) {  // launches beyond the real hit count exit at once
         sa.first = first;
         sa.count = std::min<u64>(chunk, hit_cap - first);
-        const dim3 sgrid(ceil_div(sa.count, 64)), sblock(64);
-        if (cells <= 32 * 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<128>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<2600>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+        static const bool no_lds = std::getenv("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
+        const dim3 sgrid(ceil_div(sa.count, 256)), sblock(256);
+        if (cells <= 32 * 128) {
+          if (no_lds) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<128, false>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<128, true>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+        } else {
+          if (no_lds) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<2600, false>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<2600, true>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+        }
       }
       sx->d_sites = sa.out;
       sx->d_windows = sa.windows;

@@ -47,20 +47,46 @@ struct Env {
 DG_HD bool fin(double x) { return x < kInf / 2; }
 DG_HD int pairs(int a, int b) { return a + b == 3 && a < 4 && b < 4; }  // A-T, C-G (BPI, thal.h:133-138)
 
-struct Problem {
+// A framed code sequence (sentinel 4, codes, sentinel 4) held in registers: 3 bits per code, 21 codes per word.
+// Indexing is shifts and selects — no memory access on the DP's critical path (up to 84 codes).
+struct PackedSeq {
+  uint64_t w[4];
+  DG_HD PackedSeq() : w{0, 0, 0, 0} {}
+  DG_HD void set(int i, unsigned c) {
+    const int k = i / 21, sh = 3 * (i % 21);
+    const uint64_t v = (uint64_t)c << sh;
+    if (k == 0) w[0] |= v;
+    else if (k == 1) w[1] |= v;
+    else if (k == 2) w[2] |= v;
+    else w[3] |= v;
+  }
+  DG_HD int operator[](int i) const {
+    const int k = i / 21, sh = 3 * (i % 21);
+    const uint64_t x = k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3];
+    return (int)((x >> sh) & 7);
+  }
+};
+constexpr int kPackedMax = 82;  // longest sequence a PackedSeq can frame
+
+template <class SeqT>
+struct ProblemT {
   const Tables* T;
-  const uint8_t* a;  // numSeq1[0..len1+1], sentinels 4 at both ends
-  const uint8_t* b;  // numSeq2 (second oligo REVERSED), same framing
+  SeqT a;  // numSeq1[0..len1+1], sentinels 4 at both ends
+  SeqT b;  // numSeq2 (second oligo REVERSED), same framing
   int len1, len2;
   double rc;
-  double* H;  // len1*len2 planes, (i,j) 1-based
+  double* H;  // DP planes, (i,j) 1-based; cell (i,j) lives at ((j-1) + (i-1)*row) * cs
   double* S;
-  DG_HD double& h(int i, int j) const { return H[(j - 1) + (i - 1) * len2]; }
-  DG_HD double& s(int i, int j) const { return S[(j - 1) + (i - 1) * len2]; }
+  int row;  // cells per row (>= len2; a common value lets the lanes of a wave touch the same cell index together)
+  int cs;   // distance between consecutive cells in doubles (1, or 64 when planes are interleaved across a wavefront)
+  DG_HD double& h(int i, int j) const { return H[(size_t)((j - 1) + (i - 1) * row) * cs]; }
+  DG_HD double& s(int i, int j) const { return S[(size_t)((j - 1) + (i - 1) * row) * cs]; }
 };
+typedef ProblemT<const uint8_t*> Problem;
 
 // The three dangling-end alternatives of an end compete with the terminal-mismatch stack in the same way.
-DG_HD void end_compete(const Problem& p, double S2, double H2, double& S1, double& H1, double& T1, double G1) {
+template <class PROB>
+DG_HD void end_compete(const PROB& p, double S2, double H2, double& S1, double& H1, double& T1, double G1) {
   double G2 = H2 - kT * S2;
   if (!fin(H2) || G2 > 0) {
     H2 = kInf;
@@ -81,7 +107,8 @@ DG_HD void end_compete(const Problem& p, double S2, double H2, double& S1, doubl
     T1 = T2;
   }
 }
-DG_HD void end_finish(const Problem& p, int x, int y, double S1, double H1, double T1, double& outS, double& outH) {
+template <class PROB>
+DG_HD void end_finish(const PROB& p, int x, int y, double S1, double H1, double T1, double& outS, double& outH) {
   const Tables& t = *p.T;
   double S2 = t.atpS[x][y], H2 = t.atpH[x][y];
   double T2 = (H2 + kInitH) / (S2 + kInitS + p.rc);
@@ -95,7 +122,8 @@ DG_HD void end_finish(const Problem& p, int x, int y, double S1, double H1, doub
 }
 
 // Left end of the duplex at (i,j): thal.h:853-959.  Leaves (outS,outH) untouched when i/j cannot pair.
-DG_HD void left_end(const Problem& p, int i, int j, double& outS, double& outH) {
+template <class PROB>
+DG_HD void left_end(const PROB& p, int i, int j, double& outS, double& outH) {
   const Tables& t = *p.T;
   const int x = p.a[i], y = p.b[j], xm = p.a[i - 1], ym = p.b[j - 1];
   if (!pairs(x, y)) {
@@ -124,7 +152,8 @@ DG_HD void left_end(const Problem& p, int i, int j, double& outS, double& outH) 
   end_finish(p, x, y, S1, H1, T1, outS, outH);
 }
 // Right end at (i,j): thal.h:962-1076
-DG_HD void right_end(const Problem& p, int i, int j, double& outS, double& outH) {
+template <class PROB>
+DG_HD void right_end(const PROB& p, int i, int j, double& outS, double& outH) {
   const Tables& t = *p.T;
   const int x = p.a[i], y = p.b[j], xp = p.a[i + 1], yp = p.b[j + 1];
   if (!pairs(x, y)) {
@@ -154,7 +183,8 @@ DG_HD void right_end(const Problem& p, int i, int j, double& outS, double& outH)
 }
 
 // Extend the duplex ending at (i-1,j-1) by the stacked pair (i,j) if that melts higher: thal.h:1123-1163
-DG_HD void stack_step(const Problem& p, int i, int j) {
+template <class PROB>
+DG_HD void stack_step(const PROB& p, int i, int j) {
   const Tables& t = *p.T;
   double S0 = p.s(i, j), H0 = p.h(i, j), rS, rH;
   right_end(p, i, j, rS, rH);
@@ -187,12 +217,14 @@ DG_HD void stack_step(const Problem& p, int i, int j) {
   }
 }
 
-// Closing pair (ii,jj) after an opening pair (i,j) with unpaired bases in between: thal.h:1200-1333.
-// `force` = the traceback's unconditional evaluation.
-DG_HD void loop_step(const Problem& p, int i, int j, int ii, int jj, bool force, double& outS, double& outH) {
+// Candidate (S,H) for closing pair (ii,jj) after an opening pair (i,j) with unpaired bases in between: the table part of
+// thal.h:1200-1333 (everything up to the G1/G2 comparison).
+template <class PROB>
+DG_HD void loop_candidate(const PROB& p, int i, int j, int ii, int jj, double& S, double& H) {
   const Tables& t = *p.T;
   const int l1 = ii - i - 1, l2 = jj - j - 1, ls = l1 + l2 - 1;
-  double S = -1.0, H = kInf;
+  S = -1.0;
+  H = kInf;
   if ((l1 == 0 && l2 > 0) || (l2 == 0 && l1 > 0)) {
     if (l2 == 1 || l1 == 1) {  // single-base bulge: the flanking pairs still stack
       H = t.bulgeH[ls] + t.stackH[p.a[i]][p.a[ii]][p.b[j]][p.b[jj]];
@@ -251,14 +283,6 @@ DG_HD void loop_step(const Problem& p, int i, int j, int ii, int jj, bool force,
       S = -1.0;
     }
   }
-  double rS, rH;
-  right_end(p, ii, jj, rS, rH);
-  const double G1 = H + rH - kT * (S + rS);
-  const double G2 = p.h(ii, jj) + rH - kT * (p.s(ii, jj) + rS);
-  if (G1 < G2 || force) {
-    outS = S;
-    outH = H;
-  }
 }
 
 // the diagonal walk over opening pairs (ii,jj) whose loop to (i,j) has d-2 unpaired bases: thal.h:1521-1527
@@ -278,8 +302,9 @@ struct Result {
 };
 
 // a/b: framed code arrays (see Problem); oligo2 must already be reversed.  H/S: len1*len2 doubles each.
-DG_HD Result end1_tm(const Tables& T, const Env& env, const uint8_t* a, int len1, const uint8_t* b, int len2, bool both_symmetric,
-                     double* H, double* S) {
+template <class SeqT>
+DG_HD Result end1_tm(const Tables& T, const Env& env, const SeqT& a, int len1, const SeqT& b, int len2, bool both_symmetric,
+                     double* H, double* S, int row = 0, int cs = 1) {
   Result r;
   r.temp = -kInf;  // THAL_ERROR_SCORE
   r.end1 = r.end2 = -1;
@@ -289,7 +314,7 @@ DG_HD Result end1_tm(const Tables& T, const Env& env, const uint8_t* a, int len1
     return r;
   }
   if (len1 > kMaxAlign && len2 > kMaxAlign) return r;
-  Problem p;
+  ProblemT<SeqT> p;
   p.T = &T;
   p.a = a;
   p.b = b;
@@ -298,6 +323,8 @@ DG_HD Result end1_tm(const Tables& T, const Env& env, const uint8_t* a, int len1
   p.rc = both_symmetric ? env.rc_sym : env.rc_asym;
   p.H = H;
   p.S = S;
+  p.row = row > 0 ? row : len2;
+  p.cs = cs;
   r.ok = true;
   // initMatrix (thal.h:820-835) + fillMatrix (thal.h:1503-1551)
   for (int i = 1; i <= len1; ++i)
@@ -321,22 +348,40 @@ DG_HD Result end1_tm(const Tables& T, const Env& env, const uint8_t* a, int len1
       }
       if (i > 1 && j > 1) {
         stack_step(p, i, j);
+        // The reference evaluates RSH(i,j) and re-reads cell (i,j) for every candidate; both only depend on the
+        // sequences / on the value we hold, so they are computed once and the cell stays in registers.
+        double rS, rH;
+        right_end(p, i, j, rS, rH);
+        double curS = p.s(i, j), curH = p.h(i, j);
+        bool changed = false;
         for (int d = 3; d <= kMaxLoop + 2; ++d) {
           int ii, jj;
           loop_start(i, j, d, ii, jj);
           for (; ii > 0 && jj < j; --ii, ++jj) {
             if (!fin(p.h(ii, jj))) continue;
+            double S, H;
+            loop_candidate(p, ii, jj, i, j, S, H);
+            const double G1 = H + rH - kT * (S + rS);
+            const double G2 = curH + rH - kT * (curS + rS);
             double lS = -1.0, lH = kInf;
-            loop_step(p, ii, jj, i, j, false, lS, lH);
+            if (G1 < G2) {
+              lS = S;
+              lH = H;
+            }
             if (lS < kMinEntropyCutoff) {
               lS = kMinEntropy;
               lH = 0.0;
             }
             if (fin(lH)) {
-              p.h(i, j) = lH;
-              p.s(i, j) = lS;
+              curH = lH;
+              curS = lS;
+              changed = true;
             }
           }
+        }
+        if (changed) {
+          p.h(i, j) = curH;
+          p.s(i, j) = curS;
         }
       }
     }
@@ -383,8 +428,8 @@ DG_HD Result end1_tm(const Tables& T, const Env& env, const uint8_t* a, int len1
       int ii, jj;
       loop_start(i, j, d, ii, jj);
       for (; !done && ii > 0 && jj < j; --ii, ++jj) {
-        double lS = -1.0, lH = kInf;
-        loop_step(p, ii, jj, i, j, true, lS, lH);
+        double lS, lH;
+        loop_candidate(p, ii, jj, i, j, lS, lH);
         if (p.s(i, j) == lS && p.h(i, j) == lH) {
           i = ii;
           j = jj;

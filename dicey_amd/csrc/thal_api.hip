@@ -146,8 +146,10 @@ __global__ void k_thal(const thal::Tables* T, thal::Env env, const PairDesc* pd,
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const PairDesc d = pd[t];
-  thal::Result r = thal::end1_tm(*T, env, codes + d.a_off, (int)d.len1, codes + d.b_off, (int)d.len2, d.symmetric != 0, dp + d.dp_off,
-                                 dp + d.dp_off + (u64)d.len1 * d.len2);
+  const u8* pa = codes + d.a_off;
+  const u8* pb = codes + d.b_off;
+  thal::Result r = thal::end1_tm<const u8*>(*T, env, pa, (int)d.len1, pb, (int)d.len2, d.symmetric != 0, dp + d.dp_off,
+                                            dp + d.dp_off + (u64)d.len1 * d.len2);
   temp[t] = r.temp;
   end1[t] = r.end1;
   end2[t] = r.end2;

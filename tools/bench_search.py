@@ -42,5 +42,5 @@ sites, mt, fl, nh = dicey_amd.search_sites(ix, th, prim, seqlen)
 dt2 = time.time() - t1
 print(json.dumps({"workload": f"dicey search sites, {len(prim)} primers (18-25 nt), k=15, d=1, genome {int(a.genome_size)}",
                   "seconds_first": dt, "seconds": dt2, "primers_per_s": len(prim) / dt2, "thal_calls": nh, "thal_per_s": nh / dt2,
-                  "sites": len(sites), "setup_s": t1 - t0}))
+                  "sites": len(sites), "ms_device": dicey_amd.search_sites.last_ms_device, "setup_s": t1 - t0}))
 os.remove(fm9)

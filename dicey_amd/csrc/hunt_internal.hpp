@@ -1,0 +1,91 @@
+// Shared between hunt.hip (the hunt pipeline, run_batch) and search.hip (the `dicey search` stage that replaces verify).
+#pragma once
+#include "devfm.hpp"
+#include "index_internal.hpp"
+#include "thal_internal.hpp"
+
+namespace dg {
+
+static constexpr u32 DMAX = 4;          // largest supported distance
+static constexpr u32 MAX_QLEN = 255;    // longest supported query
+enum : u32 { OP_S = 0, OP_I = 1, OP_D = 2 };
+
+
+struct Batch {  // device pointers of one batch
+  const u8* qbytes;
+  const u64* qoff;
+  u64 nq;
+  u8* fw;    // codes 0..4 (A,C,G,T,N), same offsets as qbytes
+  u8* rv;    // reverse complement
+  u8* qseq;  // normalised ASCII
+  u32* qlen;
+  u32* qdist;
+  u32* qflags;
+  u32* qnondna;
+  u32 distance;
+  u32 indel, reverse;
+  u64 max_locations;
+  struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
+};
+struct GidInfo {
+  u64 qpk;    // the sequence 2-bit packed, q[i] at bits 2(m-1-i) (only for m <= 32 without N)
+  u32 m;      // length; 0 = this (query, strand) is not searched
+  u32 d_win;  // bits 0-7 effective distance, bit 8: window mode allowed by the query (no N)
+};
+
+DG_DEV u32 ascii_rank(u32 code) { return code == 3 ? 4u : code == 4 ? 3u : code; }  // 'A'<'C'<'G'<'N'<'T'
+DG_DEV u8 ascii_of(u32 code) { return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : 'N'; }
+
+
+
+// Counters and the leaf allocator are sharded by workgroup: a single hot word serialises at ~11 ns per atomic, which
+// is milliseconds once hundreds of thousands of wavefronts report.
+static constexpr u32 NSHARD = 1024;
+struct Counters {
+  u32 overflow;          // set by k_leaf_overflow when a shard's region was too small: later kernels do nothing
+  u32 pad_[15];
+  u32 leaf_cnt[NSHARD];  // leaves allocated in each shard's region of the leaf buffer
+  unsigned long long steps[NSHARD], lookups[NSHARD], sa_reads[NSHARD], win_bytes[NSHARD];
+};
+
+struct HitSeed {
+  u32 pos;  // text position of the neighbourhood string
+  u32 qs;
+  u32 len;  // its length
+};
+
+enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO };
+
+// one located hit after the `dicey search` stage
+struct SiteRaw {
+  double temp;   // o.temp of thal(); -999999 when thal() refuses (both sequences > 60 nt)
+  u32 ref, chrpos, alignpos, glen;
+  u32 qs;        // 2*primer + strand
+  u32 pad;
+};
+
+struct SearchExtra {  // set by dg_search_sites: replace the verify stage by k_site
+  const dg_thal* th;
+  const u8* d_pfw;
+  const u8* d_prv;
+  const u64* d_poff;
+  const u32* d_koff;
+  double cut_temp;
+  u32 max_primer_len, max_koff;
+  // results (device buffers of the index workspaces, valid until the next call)
+  const SiteRaw* d_sites = nullptr;
+  const u8* d_windows = nullptr;
+  u32 win_stride = 0;
+  const u64* d_hit_off = nullptr;
+  const u32* d_qflags = nullptr;
+};
+
+
+// hunt.hip
+int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes, const void* d_qoff,
+              size_t nq, u64 total, u32 maxlen, int fetch, dg_hunt_result** out, SearchExtra* sx = nullptr);
+// search.hip: launches k_site over the located hits (capacity hit_cap) and fills sx's result pointers
+int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSeed* seeds, const u64* hit_off, u64 hit_cap,
+                      const u64* cum, u32 nseq, u32 dmax_eff, u32 maxlen, Counters* ctr);
+
+}  // namespace dg

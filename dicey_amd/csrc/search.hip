@@ -1,0 +1,423 @@
+// `dicey search` on the GPU: the per-hit block of reference src/silica.h:474-532 as a kernel (k_site) that replaces the
+// verify stage of the hunt pipeline, and dg_search_sites (silica.h:429-573 for a batch of primers).
+#include <algorithm>
+#include <set>
+
+#include "hunt_internal.hpp"
+
+namespace dg {
+
+// `dicey search` per-hit block (reference src/silica.h:474-532): context window with the primer's 5' overhang
+// (koffset), '\n' trimming, thal(primer, window) -> Tm, and — when Tm passes the cut — the Needleman-Wunsch of the
+// window against the searched k-mer to find the position that de-duplicates hits.  One lane per located hit.
+struct SiteArgs {
+  const HitSeed* seeds;
+  const u64* nhits;
+  u64 hit_cap, first, count;  // this launch handles hits [first, first+count)
+  const u64* cum;
+  u32 nseq;
+  const thal::Tables* tables;
+  thal::Env env;
+  const u8* pfw;   // full primers as codes 0..4, concatenated; prv = reverse complements
+  const u8* prv;
+  const u64* poff;
+  const u32* koff;  // primer length - k
+  double cut_temp;
+  SiteRaw* out;
+  u8* windows;
+  u32 win_stride;
+  double* dp;      // per launch lane: 2 * dp_stride doubles, interleaved per wavefront
+  u64 dp_stride;   // cells per plane = max primer length * dp_row
+  u32 dp_row;      // common row length (largest window of the batch)
+};
+DG_DEV bool codes_self_complementary(const u8* s, u32 n, bool ascii) {  // symmetry_thermo, thal.h:1976-2010
+  if (n & 1) return false;
+  for (u32 i = 0; i < n / 2; ++i) {
+    u32 a = ascii ? code_of_byte(s[i]) : s[i], c = ascii ? code_of_byte(s[n - 1 - i]) : s[n - 1 - i];
+    if (a < 4 || c < 4) {
+      if (a > 3 || c > 3 || a + c != 3) return false;
+    }
+  }
+  return true;
+}
+// LDS_TABLES: the 45 KB of nearest-neighbour tables are staged in LDS once per workgroup (every loop step of thal reads
+// about ten of them).  DP planes are interleaved across the 64 lanes of a wavefront with a common row length, so lanes
+// working on the same (i,j) cell read one contiguous 512-byte run instead of 64 scattered lines.
+template <u32 TRACE_WORDS, bool LDS_TABLES>
+__global__ void __launch_bounds__(256) k_site(FmView f, Batch b, SiteArgs a, Counters* ctr) {
+  __shared__ thal::Tables lds_tables;
+  const thal::Tables* tabs = a.tables;
+  if (LDS_TABLES) {
+    const u64* src = reinterpret_cast<const u64*>(a.tables);
+    u64* dst = reinterpret_cast<u64*>(&lds_tables);
+    for (u32 k = threadIdx.x; k < sizeof(thal::Tables) / 8; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+    tabs = &lds_tables;
+  }
+  const u64 lane = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 h = a.first + lane;
+  const u64 nh = *a.nhits;
+  if (ctr->overflow || nh > a.hit_cap || lane >= a.count || h >= nh) return;
+  const HitSeed sd = a.seeds[h];
+  const u64 q = sd.qs >> 1;
+  const u32 strand = sd.qs & 1;
+  const u64 loc = sd.pos;
+  const u32 mlen = sd.len, koff = a.koff[q];
+  u32 lo_r = 0, hi_r = a.nseq - 1;
+  while (lo_r < hi_r) {
+    u32 mid = (lo_r + hi_r + 1) >> 1;
+    if (a.cum[mid] <= loc) lo_r = mid;
+    else hi_r = mid - 1;
+  }
+  const u32 ref = lo_r;
+  u32 chrpos = (u32)(loc - a.cum[ref]);
+  u64 pre = b.indel ? b.qdist[q] : 0, post = pre;  // silica.h:480-483: the overhang is on the 5' side of the primer
+  if (strand) post += koff;
+  else pre += koff;
+  if (pre > loc) pre = loc;
+  if (loc + mlen + post > f.n) post = f.n - loc - mlen;
+  u32 pre_eff = 0;
+  for (u32 i = 1; i <= pre; ++i) {
+    if (f.text[loc - i] == '\n') break;
+    pre_eff = i;
+  }
+  u32 post_eff = 0;
+  for (u32 i = 0; i < post; ++i) {
+    if (f.text[loc + mlen + i] == '\n') break;
+    post_eff = i + 1;
+  }
+  const u8* g = f.text + (loc - pre_eff);
+  const u32 mg = pre_eff + mlen + post_eff;
+  if (pre_eff <= chrpos) chrpos -= pre_eff;  // silica.h:501 (non-strict)
+  u8* win = a.windows + h * a.win_stride;
+  for (u32 i = 0; i < mg && i < a.win_stride; ++i) win[i] = g[i];
+  // thal(oligo1 = reverse complement of the primer for forward hits / the primer for reverse hits, oligo2 = window)
+  const u64 p0 = a.poff[q];
+  const u32 plen = (u32)(a.poff[q + 1] - p0);
+  const u8* prim = (strand ? a.pfw : a.prv) + p0;
+  SiteRaw r;
+  r.ref = ref;
+  r.glen = mg;
+  r.qs = sd.qs;
+  r.pad = 0;
+  r.temp = -thal::kInf;
+  if (!(plen > (u32)thal::kMaxAlign && mg > (u32)thal::kMaxAlign) && plen <= 64 && mg <= 320) {
+    const bool sym = codes_self_complementary(prim, plen, false) && codes_self_complementary(g, mg, true);
+    // wave w of this launch owns 64 * 2 * dp_stride doubles; inside, cell c of lane l sits at c*64 + l
+    double* H = a.dp + (lane >> 6) * (64 * 2 * a.dp_stride) + (lane & 63);
+    thal::Result tr;
+    if (plen <= (u32)thal::kPackedMax && mg <= (u32)thal::kPackedMax) {  // sequences in registers
+      thal::PackedSeq fa, fb;
+      fa.set(0, 4);
+      fa.set((int)plen + 1, 4);
+      for (u32 i = 0; i < plen; ++i) fa.set((int)i + 1, prim[i]);
+      fb.set(0, 4);
+      fb.set((int)mg + 1, 4);
+      for (u32 j = 0; j < mg; ++j) {
+        u32 c = code_of_byte(g[mg - 1 - j]);
+        fb.set((int)j + 1, c < 4 ? c : 4);
+      }
+      tr = thal::end1_tm<thal::PackedSeq>(*tabs, a.env, fa, (int)plen, fb, (int)mg, sym, H, H + 64 * a.dp_stride, (int)a.dp_row, 64);
+    } else {
+      u8 fa[66], fb[322];
+      fa[0] = fa[plen + 1] = 4;
+      for (u32 i = 0; i < plen; ++i) fa[i + 1] = prim[i];
+      fb[0] = fb[mg + 1] = 4;
+      for (u32 j = 0; j < mg; ++j) {
+        u32 c = code_of_byte(g[mg - 1 - j]);
+        fb[j + 1] = (u8)(c < 4 ? c : 4);
+      }
+      const u8* pa = fa;
+      const u8* pb = fb;
+      tr = thal::end1_tm<const u8*>(*tabs, a.env, pa, (int)plen, pb, (int)mg, sym, H, H + 64 * a.dp_stride, (int)a.dp_row, 64);
+    }
+    r.temp = tr.temp;
+  }
+  u32 alignpos = chrpos;
+  if (r.temp > a.cut_temp) {
+    // silica.h:519-532: needle(window, searched k-mer); leading columns whose k-mer row is a gap shift the position.
+    // Those columns are exactly the vertical moves taken in column 0, so the traceback stops when it gets there.
+    const u8* qseq = (strand ? b.rv : b.fw) + b.qoff[q];
+    const u32 n = b.qlen[q];
+    int s[MAX_QLEN + 1];
+    u64 trace[TRACE_WORDS];
+    const u32 mf = n + 1;
+    for (u32 w = 0; w < TRACE_WORDS; ++w) trace[w] = 0;
+    s[0] = 0;
+    for (u32 col = 1; col <= n; ++col) s[col] = -(int)col;
+    for (u32 row = 1; row <= mg; ++row) {
+      int diag = 0;
+      const u8 gc = g[row - 1];
+      for (u32 col = 1; col <= n; ++col) {
+        int up = s[col];
+        int dsc = diag + (gc == ascii_of(qseq[col - 1]) ? 0 : -1);
+        int vsc = up + (col == n ? 0 : -1);
+        int hsc = s[col - 1] - 1;
+        int best = dsc > vsc ? dsc : vsc;
+        best = best > hsc ? best : hsc;
+        s[col] = best;
+        u32 cell = row * mf + col;
+        if (best == hsc) trace[cell >> 5] |= 1ULL << ((cell & 31) * 2);
+        else if (best == vsc) trace[cell >> 5] |= 2ULL << ((cell & 31) * 2);
+        diag = up;
+      }
+    }
+    u32 row = mg, col = n;
+    while (col > 0) {
+      u32 tr = 1;  // row 0: horizontal
+      if (row > 0) {
+        u32 cell = row * mf + col;
+        tr = (u32)(trace[cell >> 5] >> ((cell & 31) * 2)) & 3;
+      }
+      if (tr == 1) --col;
+      else if (tr == 2) --row;
+      else {
+        --row;
+        --col;
+      }
+    }
+    alignpos = chrpos + row;
+  }
+  r.chrpos = chrpos;
+  r.alignpos = alignpos;
+  a.out[h] = r;
+}
+
+
+int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSeed* seeds, const u64* hit_off, u64 hit_cap,
+                      const u64* cum, u32 nseq, u32 dmax_eff, u32 maxlen, Counters* ctr) {
+  auto& ws = ix->ws;
+  hipStream_t st = ix->stream;
+  const u64 nq = b.nq;
+      const u32 wmax = sx->max_primer_len + 3 * dmax_eff + 2;  // k + overhang + context on both sides + edits
+      const u32 wstride = (wmax + 15) & ~15u;
+      const u64 dp_stride = (u64)sx->max_primer_len * wmax;
+      const u64 chunk = std::max<u64>(4096, std::min<u64>(hit_cap, ((u64)6 << 30) / (2 * dp_stride * 8 + 1)));
+      DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(SiteRaw)));
+      DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * (u64)wstride));
+      DG_TRY(ws[WS_DP].reserve(((chunk + 63) & ~(u64)63) * 2 * dp_stride * 8 + 64));
+      SiteArgs sa;
+      sa.seeds = seeds;
+      sa.nhits = hit_off + nq;
+      sa.hit_cap = hit_cap;
+      sa.cum = cum;
+      sa.nseq = nseq;
+      sa.tables = sx->th->d_tables;
+      sa.env = sx->th->env;
+      sa.pfw = sx->d_pfw;
+      sa.prv = sx->d_prv;
+      sa.poff = sx->d_poff;
+      sa.koff = sx->d_koff;
+      sa.cut_temp = sx->cut_temp;
+      sa.out = ws[WS_HITS].as<SiteRaw>();
+      sa.windows = ws[WS_ALN].as<u8>();
+      sa.win_stride = wstride;
+      sa.dp = ws[WS_DP].as<double>();
+      sa.dp_stride = dp_stride;
+      sa.dp_row = wmax;
+      const u32 cells = (wmax + 1) * (maxlen + 1);
+      for (u64 first = 0; first < hit_cap; first += chunk) {  // launches beyond the real hit count exit at once
+        sa.first = first;
+        sa.count = std::min<u64>(chunk, hit_cap - first);
+        static const bool no_lds = std::getenv("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
+        const dim3 sgrid(ceil_div(sa.count, 256)), sblock(256);
+        if (cells <= 32 * 128) {
+          if (no_lds) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<128, false>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<128, true>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+        } else {
+          if (no_lds) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<2600, false>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<2600, true>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
+        }
+      }
+      sx->d_sites = sa.out;
+      sx->d_windows = sa.windows;
+      sx->win_stride = wstride;
+      sx->d_hit_off = hit_off;
+      sx->d_qflags = b.qflags;
+  return DG_OK;
+}
+
+}  // namespace dg
+
+using namespace dg;
+
+// ------------------------------------------------------------------------------------------------------------
+// dg_search_sites
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+void dg_search_result_free(dg_search_result* r) {
+  if (!r) return;
+  delete[] r->sites;
+  delete[] r->genome_pool;
+  delete[] r->pflags;
+  delete[] r->match_temp;
+  delete r;
+}
+
+int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const uint32_t* seqlen, uint32_t nseq,
+                    const uint8_t* pbytes, const uint64_t* poff, size_t np, dg_search_result** out) {
+  if (!ix || !th || !p || !seqlen || !pbytes || !poff || !out) return fail(DG_EINVAL, "dg_search_sites: null argument");
+  *out = nullptr;
+  if (!np) return fail(DG_EINVAL, "dg_search_sites: no primers");
+  if (th->device != ix->device) return fail(DG_EINVAL, "dg_search_sites: index and thal handles live on different devices");
+  if (p->kmer < 10 || p->kmer > MAX_QLEN) return fail(DG_ELIMIT, "k-mer size %u outside [10,%u]", p->kmer, MAX_QLEN);
+  // k-mer queries (last k nucleotides), primer codes and their reverse complements
+  const u64 ptotal = poff[np];
+  std::vector<u8> kq(np * (u64)p->kmer), pfw(ptotal), prv(ptotal);
+  std::vector<u64> koffs(np + 1);
+  std::vector<u32> koff(np);
+  u32 maxp = 0, maxk = 0;
+  for (size_t i = 0; i < np; ++i) {
+    const u64 b0 = poff[i], len = poff[i + 1] - b0;
+    if (len < p->kmer) return fail(DG_EINVAL, "primer %zu is shorter than k", i);
+    if (len > 64) return fail(DG_ELIMIT, "primer %zu has %llu nt; thal() accepts at most 60 and this build stores 64", i, (unsigned long long)len);
+    maxp = std::max<u32>(maxp, (u32)len);
+    koff[i] = (u32)(len - p->kmer);
+    maxk = std::max(maxk, koff[i]);
+    koffs[i] = (u64)i * p->kmer;
+    for (u64 k = 0; k < len; ++k) {
+      u8 ch = pbytes[b0 + k];
+      if (ch >= 'a' && ch <= 'z') ch -= 32;
+      u8 c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+      pfw[b0 + k] = c;
+      prv[b0 + (len - 1 - k)] = c < 4 ? (u8)(3 - c) : (u8)4;
+    }
+    std::memcpy(kq.data() + koffs[i], pbytes + b0 + koff[i], p->kmer);
+  }
+  koffs[np] = np * (u64)p->kmer;
+  DG_HIP(hipSetDevice(ix->device));
+  hipStream_t st = ix->stream;
+  auto& ws = ix->ws;
+  DG_TRY(ws[WS_QB].reserve(kq.size() + 8));
+  DG_TRY(ws[WS_QOFF].reserve((np + 1) * 8));
+  DG_TRY(ws[WS_PRIM].reserve(2 * ptotal + (np + 1) * 8 + np * 4 + 64));
+  u8* d_pfw = ws[WS_PRIM].as<u8>();
+  u8* d_prv = d_pfw + ptotal;
+  u64* d_poff = (u64*)(d_pfw + ((2 * ptotal + 7) & ~7ULL));
+  u32* d_koff = (u32*)(d_poff + np + 1);
+  DG_HIP(hipMemcpyAsync(ws[WS_QB].p, kq.data(), kq.size(), hipMemcpyHostToDevice, st));
+  DG_HIP(hipMemcpyAsync(ws[WS_QOFF].p, koffs.data(), (np + 1) * 8, hipMemcpyHostToDevice, st));
+  DG_HIP(hipMemcpyAsync(d_pfw, pfw.data(), ptotal, hipMemcpyHostToDevice, st));
+  DG_HIP(hipMemcpyAsync(d_prv, prv.data(), ptotal, hipMemcpyHostToDevice, st));
+  DG_HIP(hipMemcpyAsync(d_poff, poff, (np + 1) * 8, hipMemcpyHostToDevice, st));
+  DG_HIP(hipMemcpyAsync(d_koff, koff.data(), np * 4, hipMemcpyHostToDevice, st));
+  dg_hunt_params hp;
+  hp.distance = p->distance;
+  hp.hamming = p->hamming;
+  hp.forward_only = 0;
+  hp.max_locations = p->max_locations;
+  hp.max_neighborhood = p->max_neighborhood;
+  SearchExtra sx;
+  sx.th = th;
+  sx.d_pfw = d_pfw;
+  sx.d_prv = d_prv;
+  sx.d_poff = d_poff;
+  sx.d_koff = d_koff;
+  sx.cut_temp = p->cut_temp;
+  sx.max_primer_len = maxp;
+  sx.max_koff = maxk;
+  dg_hunt_result* hr = nullptr;
+  int rc = run_batch(ix, &hp, seqlen, nseq, ws[WS_QB].p, ws[WS_QOFF].p, np, kq.size(), p->kmer, 0, &hr, &sx);
+  if (rc != DG_OK) {
+    if (hr) dg_hunt_result_free(hr);
+    return rc;
+  }
+  const u64 nhits = hr->nhits;
+  const double ms_dev = hr->ms_total;
+  dg_hunt_result_free(hr);
+  std::vector<u64> hoff(np + 1);
+  std::vector<u32> qfl(np);
+  std::vector<SiteRaw> raw(nhits ? nhits : 1);
+  std::vector<u8> win((nhits ? nhits : 1) * (u64)sx.win_stride);
+  DG_HIP(hipMemcpyAsync(hoff.data(), sx.d_hit_off, (np + 1) * 8, hipMemcpyDeviceToHost, st));
+  DG_HIP(hipMemcpyAsync(qfl.data(), sx.d_qflags, np * 4, hipMemcpyDeviceToHost, st));
+  if (nhits) {
+    DG_HIP(hipMemcpyAsync(raw.data(), sx.d_sites, nhits * sizeof(SiteRaw), hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(win.data(), sx.d_windows, nhits * (u64)sx.win_stride, hipMemcpyDeviceToHost, st));
+  }
+  DG_HIP(hipStreamSynchronize(st));
+  // Tm of every primer against its perfect complement (silica.h:431-443)
+  std::vector<u8> pairs;
+  std::vector<u64> pairoff(2 * np + 1, 0);
+  for (size_t i = 0; i < np; ++i) {
+    const u64 b0 = poff[i], len = poff[i + 1] - b0;
+    static const char asc[5] = {'A', 'C', 'G', 'T', 'N'};
+    for (u64 k = 0; k < len; ++k) pairs.push_back((u8)asc[pfw[b0 + k]]);
+    pairoff[2 * i + 1] = pairs.size();
+    for (u64 k = 0; k < len; ++k) pairs.push_back((u8)asc[prv[b0 + k]]);
+    pairoff[2 * i + 2] = pairs.size();
+  }
+  dg_search_result* R = new dg_search_result;
+  std::memset(R, 0, sizeof *R);
+  R->nprimers = np;
+  R->nhits = nhits;
+  R->ms_device = ms_dev;
+  R->pflags = new uint32_t[np];
+  R->match_temp = new double[np];
+  *out = R;
+  rc = dg_thal_batch(th, pairs.data(), pairoff.data(), np, R->match_temp, nullptr, nullptr);
+  if (rc != DG_OK) {
+    dg_search_result_free(R);
+    *out = nullptr;
+    return rc;
+  }
+  // silica.h:533-566 on the host: de-duplicate on (refIndex, alignpos) per primer and strand, trim the site
+  std::vector<dg_site> sites;
+  std::string pool;
+  for (size_t q = 0; q < np; ++q) {
+    u32 fl = qfl[q] & DG_Q_MAX_MATCHES;
+    if (R->match_temp[q] == -thal::kInf) fl |= DG_P_THAL_FAILED;
+    const u32 plen = (u32)(poff[q + 1] - poff[q]);
+    std::set<std::pair<u32, u32>> seen[2];  // silica.h:465 TUniquePrimerHits, one per strand
+    for (u64 h = hoff[q]; h < hoff[q + 1]; ++h) {
+      const SiteRaw& r = raw[h];
+      const u32 fr = r.qs & 1;
+      if (r.temp == -thal::kInf) {
+        fl |= DG_P_THAL_FAILED;
+        continue;
+      }
+      if (!(r.temp > p->cut_temp)) continue;
+      std::pair<u32, u32> key(r.ref, r.alignpos);
+      if (!seen[fr].insert(key).second) continue;
+      const char* g = (const char*)win.data() + h * (u64)sx.win_stride;
+      u32 glen = std::min<u32>(r.glen, sx.win_stride);
+      u32 chrpos, goff = 0, gl = glen;
+      u32 alignshift = r.alignpos - r.chrpos;
+      if (fr) {
+        chrpos = r.alignpos;
+        goff = std::min(alignshift, glen);
+        gl = std::min<u32>(plen, glen - goff);
+      } else {
+        chrpos = r.alignpos - koff[q];
+        if (alignshift >= koff[q]) {
+          alignshift -= koff[q];
+          goff = std::min(alignshift, glen);
+          gl = std::min<u32>(plen, glen - goff);
+        }
+      }
+      dg_site sgl;
+      std::memset(&sgl, 0, sizeof sgl);
+      sgl.ref = r.ref;
+      sgl.pos = chrpos;
+      sgl.primer = (u32)q;
+      sgl.on_for = fr ? 0 : 1;
+      sgl.temp = r.temp;
+      sgl.perf_temp = R->match_temp[q];
+      sgl.genome_off = pool.size();
+      sgl.genome_len = gl;
+      pool.append(g + goff, gl);
+      sites.push_back(sgl);
+    }
+    R->pflags[q] = fl;
+  }
+  R->nsites = sites.size();
+  R->sites = new dg_site[sites.size() ? sites.size() : 1];
+  std::copy(sites.begin(), sites.end(), R->sites);
+  R->genome_pool = new char[pool.size() + 1];
+  std::memcpy(R->genome_pool, pool.data(), pool.size());
+  R->genome_pool[pool.size()] = 0;
+  return DG_OK;
+}
+
+}  // extern "C"

@@ -229,3 +229,18 @@ def test_repeat_rich_strings_use_the_workgroup_locate(tmp_path):
         for kw in (dict(distance=0, max_locations=1000), dict(distance=1, max_locations=700), dict(distance=0, max_locations=100000),
                    dict(distance=1, hamming=True, max_locations=5000)):
             _compare(ix, orc, g, [unit, unit[:19] + ("A" if unit[19] != "A" else "C"), unit[1:] + "G"], **kw)
+
+
+@pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13"])
+def test_every_search_mode_gives_the_same_hits(small_genome, monkeypatch, mode):
+    """Interval mode (no table), window mode with a table shorter than every query, and tables long enough that some
+    queries fall back to interval mode (10/11-mers against K=11/13) must all reproduce the oracle."""
+    import dicey_amd
+    if mode != "no_table":
+        monkeypatch.setenv("DICEY_KMER_K", mode[1:])
+    orc = O.Index(small_genome["fm9"])
+    with dicey_amd.FmIndex(small_genome["fm9"], kmer_table=(mode != "no_table")) as ix:
+        qs = make_queries(31, small_genome["text"], 300, (10, 11, 14, 20, 33))
+        _compare(ix, orc, small_genome, qs, distance=1)
+        _compare(ix, orc, small_genome, qs[:120], distance=1, hamming=True)
+        _compare(ix, orc, small_genome, [q[:12] for q in qs[:12]], distance=2)

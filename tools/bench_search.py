@@ -29,6 +29,7 @@ while len(prim) < 2 * a.pairs:
     fw, rv = w[:l1], w[d:d + l2]
     if b"N" in fw + rv or b"\n" in w: continue
     prim += [fw.decode(), rv.translate(comp)[::-1].decode()]
+host_text = text.cpu().numpy().tobytes()  # the oracle's amplicon sequences come from the text
 del text; torch.cuda.empty_cache()
 seqlen = [x + 1 for x in lens]
 ix = dicey_amd.FmIndex(fm9); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -40,7 +41,24 @@ dt = time.time() - t1
 t1 = time.time()
 sites, mt, fl, nh = dicey_amd.search_sites(ix, th, prim, seqlen)
 dt2 = time.time() - t1
-print(json.dumps({"workload": f"dicey search sites, {len(prim)} primers (18-25 nt), k=15, d=1, genome {int(a.genome_size)}",
+# CPU baseline: the oracle's restated silica.h driver on the REFERENCE's own thal() (oracle/_ref), one thread, bounded sample
+cpu = None
+try:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    if O.ref_libs() is not None:
+        orc = O.Index(fm9)
+        ns = 40
+        fa = "".join(">p%d\n%s\n" % (i, s) for i, s in enumerate(prim[:ns]))
+        tc = time.time()
+        js, rc = orc.search(seqlen, ["s%d" % i for i in range(len(seqlen))], host_text, fa)
+        dtc = time.time() - tc
+        nthal = sum(1 for _ in ())  # thal calls are not counted by the oracle; hits per primer are the same as on the GPU
+        cpu = {"value": ns / dtc, "unit": "primers/s", "cores": 1, "kind": "reference",
+               "sample": f"first {ns} primers, restated silica.h:429-573 calling the reference thal.h (oracle/_ref), {dtc:.1f} s"}
+except Exception as e:  # the checker is optional here
+    cpu = {"error": str(e)}
+print(json.dumps({"cpu_baseline": cpu, "workload": f"dicey search sites, {len(prim)} primers (18-25 nt), k=15, d=1, genome {int(a.genome_size)}",
                   "seconds_first": dt, "seconds": dt2, "primers_per_s": len(prim) / dt2, "thal_calls": nh, "thal_per_s": nh / dt2,
                   "sites": len(sites), "ms_device": dicey_amd.search_sites.last_ms_device, "setup_s": t1 - t0}))
 os.remove(fm9)

@@ -921,28 +921,65 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
     for (int c = 0; c <= NC; ++c)
       if ((u32)c == n) fin = s[c];
     out.score = fin;
+    // Traceback into a move stack held in registers (2 bits per column, <= 76 columns), then ONE forward pass that
+    // writes the kept columns: no write-backwards / read-again / compact round trips through global memory.
+    u64 mv0 = 0, mv1 = 0, mv2 = 0;  // stack of moves, most recent push at the bottom of mv0
+    u32 nmv = 0, trail = 0;
+    bool seen_query = false;
     u32 row = mg, col = n;
     while (row > 0 || col > 0) {
       u32 code = col == 0 ? 2u : (row == 0 ? 1u : (u32)(tr[row] >> (2 * (col - 1))) & 3u);
+      if (code == 1) --col;
+      else if (code == 2) --row;
+      else {
+        --row;
+        --col;
+      }
+      if (code == 2 && !seen_query) ++trail;  // trailing columns whose query row is a gap (_trailGap, hunter.h:69-77)
+      else seen_query = true;
+      mv2 = (mv2 << 2) | (mv1 >> 62);
+      mv1 = (mv1 << 2) | (mv0 >> 62);
+      mv0 = (mv0 << 2) | code;
+      ++nmv;
+    }
+    // forward: pop moves; leading query-gap columns only advance chrpos (hunter.h:391-401)
+    u32 r = 0, c = 0, len = 0, lead = 0;
+    bool in_lead = true;
+    const u32 stop = nmv - trail;
+    for (u32 k = 0; k < stop; ++k) {
+      const u32 code = (u32)mv0 & 3u;
+      mv0 = (mv0 >> 2) | (mv1 << 62);
+      mv1 = (mv1 >> 2) | (mv2 << 62);
+      mv2 >>= 2;
       char r0, r1;
       if (code == 1) {
-        --col;
         r0 = '-';
-        r1 = (char)ascii_of(qseq[col]);
+        r1 = (char)ascii_of(qseq[c]);  // (qc[] is indexed with constants only, so that it stays in registers)
+        ++c;
       } else if (code == 2) {
-        --row;
-        r0 = (char)g[row];
+        r0 = (char)g[r];
         r1 = '-';
+        ++r;
       } else {
-        --row;
-        --col;
-        r0 = (char)g[row];
-        r1 = (char)ascii_of(qseq[col]);
+        r0 = (char)g[r];
+        r1 = (char)ascii_of(qseq[c]);
+        ++r;
+        ++c;
       }
-      ++tl;
-      ra[S - tl] = r0;
-      qa[S - tl] = r1;
+      if (r1 != '-') in_lead = false;
+      if (in_lead) {
+        ++lead;
+        continue;
+      }
+      ra[len] = r0;
+      qa[len] = r1;
+      ++len;
     }
+    chrpos += lead;
+    out.start = chrpos + 1;
+    out.aln_len = (u16)len;
+    a.hits[h] = out;
+    return;
   } else {
   int s[MAX_QLEN + 1];
   u64 trace[TRACE_WORDS];  // 2 bits per cell: 1 = horizontal, 2 = vertical

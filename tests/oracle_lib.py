@@ -145,7 +145,10 @@ class Index:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     @property
     def size(self):

@@ -53,6 +53,7 @@ try:
         tc = time.time()
         js, rc = orc.search(seqlen, ["s%d" % i for i in range(len(seqlen))], host_text, fa)
         dtc = time.time() - tc
+        orc.close()
         nthal = sum(1 for _ in ())  # thal calls are not counted by the oracle; hits per primer are the same as on the GPU
         cpu = {"value": ns / dtc, "unit": "primers/s", "cores": 1, "kind": "reference",
                "sample": f"first {ns} primers, restated silica.h:429-573 calling the reference thal.h (oracle/_ref), {dtc:.1f} s"}

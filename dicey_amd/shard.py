@@ -48,3 +48,49 @@ def device_bytes(ptr: int, nbytes: int, device) -> torch.Tensor:
     if nbytes == 0 or not ptr:
         return torch.empty(0, dtype=torch.uint8, device=device)
     return torch.as_tensor(DevicePtrView(ptr, nbytes), device=device)
+
+
+class PipelinedGather:
+    """Gather of per-step hit lists to rank `dst` that overlaps with the next step's kernels.
+
+    Every submit() stages the payload (so the library may reuse its buffers), prefixes its length, and starts an
+    asynchronous gather of fixed-capacity byte tensors on the collective's own stream; at most `depth` gathers are in
+    flight; finish() waits for all of them.  Capacity is agreed once (all_reduce MAX) outside any timed region."""
+
+    def __init__(self, capacity: int, device, dst: int = 0, depth: int = 2, group=None):
+        self.group, self.dst, self.depth = group, dst, depth
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        cap = torch.tensor([int(capacity)], dtype=torch.int64, device=device)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
+        self.cap = int(cap.item())
+        self.send = [torch.zeros(self.cap + 8, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.recv = ([[torch.empty(self.cap + 8, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(depth)]
+                     if self.rank == dst else None)
+        self.work = [None] * depth
+        self.n = 0
+        self.bytes_received = 0
+
+    def _drain(self, slot):
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+            if self.rank == self.dst:  # lengths are read only now: no host synchronisation on the submit path
+                for buf in self.recv[slot]:
+                    self.bytes_received += int(buf[:8].view(torch.int64).item())
+
+    def submit(self, payload: torch.Tensor):
+        if payload.numel() > self.cap:
+            raise RuntimeError(f"payload of {payload.numel()} bytes exceeds the agreed capacity {self.cap}")
+        slot = self.n % self.depth
+        self._drain(slot)
+        buf = self.send[slot]
+        buf[:8] = torch.tensor([payload.numel()], dtype=torch.int64).view(torch.uint8).to(buf.device, non_blocking=True)
+        buf[8:8 + payload.numel()] = payload
+        self.work[slot] = dist.gather(buf, self.recv[slot] if self.rank == self.dst else None, dst=self.dst, group=self.group,
+                                      async_op=True)
+        self.n += 1
+
+    def finish(self) -> int:
+        for slot in range(self.depth):
+            self._drain(slot)
+        return self.bytes_received

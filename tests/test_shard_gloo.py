@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dicey_amd.shard import gather_bytes, shard_range
+from dicey_amd.shard import PipelinedGather, gather_bytes, shard_range
 
 
 def test_shard_range_covers_batch_in_order():
@@ -31,6 +31,19 @@ def _worker(rank, world, port, out):
         torch.save([g.clone() for g in got], out)
     else:
         assert got is None
+    # pipelined variant: 5 steps of rank- and step-dependent payloads, two in flight
+    pg = PipelinedGather(capacity=64 + 10 * rank, device="cpu", depth=2)
+    total = 0
+    for step in range(5):
+        n = 20 + rank * 7 + step
+        pg.submit(torch.full((n,), (rank * 16 + step) % 256, dtype=torch.uint8))
+        total += n
+    got_bytes = pg.finish()
+    t = torch.tensor([total], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        assert got_bytes == int(t.item()), (got_bytes, int(t.item()))
+        assert pg.cap == 74
     dist.barrier()
     dist.destroy_process_group()
 

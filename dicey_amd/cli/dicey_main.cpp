@@ -389,7 +389,15 @@ int hunter(int argc, char** argv) {
   }
   std::string index_file = strip_last_extension(c.genome) + ".fm9";
   dg_index* ix = nullptr;
-  if (dg_index_open(index_file.c_str(), device_from_env(), DG_OPEN_DEFAULT, &ix) != DG_OK) {
+  // the K-mer jump table (up to 137 GB, ~1.5 s to derive) only pays off for large batches: a literal sequence or a
+  // small FASTA is answered from the Occ blocks alone
+  uint32_t open_flags = DG_OPEN_DEFAULT;
+  {
+    struct stat ist;
+    if (!(stat(c.input.c_str(), &ist) == 0 && S_ISREG(ist.st_mode) && ist.st_size > (1 << 20)) && !std::getenv("DICEY_KMER_K"))
+      open_flags |= DG_OPEN_NO_KMER_TABLE;
+  }
+  if (dg_index_open(index_file.c_str(), device_from_env(), open_flags, &ix) != DG_OK) {
     std::cerr << "dicey: " << dg_last_error() << std::endl;
     msg.push_back("Error: FM-Index cannot be loaded!");
     emit(c, hunt_json(c, c.distance, c.input, "", seqname, none, msg));

@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build what is missing (a checkout without the git-ignored artefacts): the gfx950 library, the host binary, the
+    oracle.  hipcc cross-compiles without a GPU, so this works in the build container and on the GPU box alike."""
+    import subprocess
+    need = [(os.path.join(ROOT, "dicey_amd", "libdiceygpu.so"), ["make", "-C", os.path.join(ROOT, "dicey_amd", "csrc"), "-s", "-j4"]),
+            (os.path.join(ROOT, "dicey_amd", "dicey"), ["make", "-C", os.path.join(ROOT, "dicey_amd", "cli"), "-s"]),
+            (os.path.join(ROOT, "oracle", "liboracle.so"), ["make", "-C", os.path.join(ROOT, "oracle"), "-s"])]
+    for artefact, cmd in need:
+        if not os.path.exists(artefact):
+            subprocess.call(cmd)
+
+
 def make_genome(seed, nchr, length, nrate=0.002, repeats=True, iupac=False):
     """Small synthetic multi-chromosome genome with N runs, copied segments and homopolymers."""
     rng = random.Random(seed)

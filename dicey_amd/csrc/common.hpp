@@ -11,6 +11,11 @@
 
 #include "../../include/dicey_gpu.h"
 
+// dynamic LDS of a kernel (size given at launch)
+#ifndef DG_DYNAMIC_LDS
+#define DG_DYNAMIC_LDS(name) extern __shared__ __align__(16) unsigned char name[]
+#endif
+
 namespace dg {
 
 using u8 = uint8_t;

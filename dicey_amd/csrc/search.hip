@@ -4,6 +4,7 @@
 #include <set>
 
 #include "hunt_internal.hpp"
+#include "thal_wave.hpp"
 
 namespace dg {
 
@@ -29,6 +30,9 @@ struct SiteArgs {
   double* dp;      // per launch lane: 2 * dp_stride doubles, interleaved per wavefront
   u64 dp_stride;   // cells per plane = max primer length * dp_row
   u32 dp_row;      // common row length (largest window of the batch)
+  u32 only_flagged;  // k_site: recompute only the hits the wave kernel handed back (SiteRaw.pad == 1)
+  u32 wave_len1, wave_stride, wave_bytes;  // k_site_wave: LDS table shape per wavefront
+  u32 force_redo;    // debugging aid: hand every hit back to k_site
 };
 DG_DEV bool codes_self_complementary(const u8* s, u32 n, bool ascii) {  // symmetry_thermo, thal.h:1976-2010
   if (n & 1) return false;
@@ -40,6 +44,51 @@ DG_DEV bool codes_self_complementary(const u8* s, u32 n, bool ascii) {  // symme
   }
   return true;
 }
+// silica.h:519-532: needle(window, searched k-mer); leading columns whose k-mer row is a gap shift the position.
+// Those columns are exactly the vertical moves taken in column 0, so the traceback stops when it gets there and
+// returns the row it arrives at.
+template <u32 TRACE_WORDS>
+DG_DEV u32 site_lead_rows(const u8* g, u32 mg, const u8* qseq, u32 n) {
+  int s[MAX_QLEN + 1];
+  u64 trace[TRACE_WORDS];
+  const u32 mf = n + 1;
+  for (u32 w = 0; w < TRACE_WORDS; ++w) trace[w] = 0;
+  s[0] = 0;
+  for (u32 col = 1; col <= n; ++col) s[col] = -(int)col;
+  for (u32 row = 1; row <= mg; ++row) {
+    int diag = 0;
+    const u8 gc = g[row - 1];
+    for (u32 col = 1; col <= n; ++col) {
+      int up = s[col];
+      int dsc = diag + (gc == ascii_of(qseq[col - 1]) ? 0 : -1);
+      int vsc = up + (col == n ? 0 : -1);
+      int hsc = s[col - 1] - 1;
+      int best = dsc > vsc ? dsc : vsc;
+      best = best > hsc ? best : hsc;
+      s[col] = best;
+      u32 cell = row * mf + col;
+      if (best == hsc) trace[cell >> 5] |= 1ULL << ((cell & 31) * 2);
+      else if (best == vsc) trace[cell >> 5] |= 2ULL << ((cell & 31) * 2);
+      diag = up;
+    }
+  }
+  u32 row = mg, col = n;
+  while (col > 0) {
+    u32 tr = 1;  // row 0: horizontal
+    if (row > 0) {
+      u32 cell = row * mf + col;
+      tr = (u32)(trace[cell >> 5] >> ((cell & 31) * 2)) & 3;
+    }
+    if (tr == 1) --col;
+    else if (tr == 2) --row;
+    else {
+      --row;
+      --col;
+    }
+  }
+  return row;
+}
+
 // LDS_TABLES: the 45 KB of nearest-neighbour tables are staged in LDS once per workgroup (every loop step of thal reads
 // about ten of them).  DP planes are interleaved across the 64 lanes of a wavefront with a common row length, so lanes
 // working on the same (i,j) cell read one contiguous 512-byte run instead of 64 scattered lines.
@@ -47,6 +96,11 @@ template <u32 TRACE_WORDS, bool LDS_TABLES>
 __global__ void __launch_bounds__(256) k_site(FmView f, Batch b, SiteArgs a, Counters* ctr) {
   __shared__ thal::Tables lds_tables;
   const thal::Tables* tabs = a.tables;
+  if (LDS_TABLES && a.only_flagged) {  // nothing handed back to this workgroup: skip staging the tables
+    const u64 hh = a.first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool want = !ctr->overflow && *a.nhits <= a.hit_cap && hh < a.first + a.count && hh < *a.nhits && a.out[hh].pad == 1;
+    if (!__syncthreads_or(want)) return;
+  }
   if (LDS_TABLES) {
     const u64* src = reinterpret_cast<const u64*>(a.tables);
     u64* dst = reinterpret_cast<u64*>(&lds_tables);
@@ -58,6 +112,7 @@ __global__ void __launch_bounds__(256) k_site(FmView f, Batch b, SiteArgs a, Cou
   const u64 h = a.first + lane;
   const u64 nh = *a.nhits;
   if (ctr->overflow || nh > a.hit_cap || lane >= a.count || h >= nh) return;
+  if (a.only_flagged && a.out[h].pad != 1) return;
   const HitSeed sd = a.seeds[h];
   const u64 q = sd.qs >> 1;
   const u32 strand = sd.qs & 1;
@@ -103,8 +158,8 @@ __global__ void __launch_bounds__(256) k_site(FmView f, Batch b, SiteArgs a, Cou
   r.temp = -thal::kInf;
   if (!(plen > (u32)thal::kMaxAlign && mg > (u32)thal::kMaxAlign) && plen <= 64 && mg <= 320) {
     const bool sym = codes_self_complementary(prim, plen, false) && codes_self_complementary(g, mg, true);
-    // wave w of this launch owns 64 * 2 * dp_stride doubles; inside, cell c of lane l sits at c*64 + l
-    double* H = a.dp + (lane >> 6) * (64 * 2 * a.dp_stride) + (lane & 63);
+    // wave w of this launch owns 64 * dp_stride cells; inside, cell c of lane l sits at c*64 + l
+    thal::Cell* cells = reinterpret_cast<thal::Cell*>(a.dp) + (lane >> 6) * (64 * a.dp_stride) + (lane & 63);
     thal::Result tr;
     if (plen <= (u32)thal::kPackedMax && mg <= (u32)thal::kPackedMax) {  // sequences in registers
       thal::PackedSeq fa, fb;
@@ -117,7 +172,7 @@ __global__ void __launch_bounds__(256) k_site(FmView f, Batch b, SiteArgs a, Cou
         u32 c = code_of_byte(g[mg - 1 - j]);
         fb.set((int)j + 1, c < 4 ? c : 4);
       }
-      tr = thal::end1_tm<thal::PackedSeq>(*tabs, a.env, fa, (int)plen, fb, (int)mg, sym, H, H + 64 * a.dp_stride, (int)a.dp_row, 64);
+      tr = thal::end1_tm<thal::PackedSeq>(*tabs, a.env, fa, (int)plen, fb, (int)mg, sym, cells, (int)a.dp_row, 64);
     } else {
       u8 fa[66], fb[322];
       fa[0] = fa[plen + 1] = 4;
@@ -129,60 +184,174 @@ __global__ void __launch_bounds__(256) k_site(FmView f, Batch b, SiteArgs a, Cou
       }
       const u8* pa = fa;
       const u8* pb = fb;
-      tr = thal::end1_tm<const u8*>(*tabs, a.env, pa, (int)plen, pb, (int)mg, sym, H, H + 64 * a.dp_stride, (int)a.dp_row, 64);
+      tr = thal::end1_tm<const u8*>(*tabs, a.env, pa, (int)plen, pb, (int)mg, sym, cells, (int)a.dp_row, 64);
     }
     r.temp = tr.temp;
   }
   u32 alignpos = chrpos;
   if (r.temp > a.cut_temp) {
-    // silica.h:519-532: needle(window, searched k-mer); leading columns whose k-mer row is a gap shift the position.
-    // Those columns are exactly the vertical moves taken in column 0, so the traceback stops when it gets there.
     const u8* qseq = (strand ? b.rv : b.fw) + b.qoff[q];
-    const u32 n = b.qlen[q];
-    int s[MAX_QLEN + 1];
-    u64 trace[TRACE_WORDS];
-    const u32 mf = n + 1;
-    for (u32 w = 0; w < TRACE_WORDS; ++w) trace[w] = 0;
-    s[0] = 0;
-    for (u32 col = 1; col <= n; ++col) s[col] = -(int)col;
-    for (u32 row = 1; row <= mg; ++row) {
-      int diag = 0;
-      const u8 gc = g[row - 1];
-      for (u32 col = 1; col <= n; ++col) {
-        int up = s[col];
-        int dsc = diag + (gc == ascii_of(qseq[col - 1]) ? 0 : -1);
-        int vsc = up + (col == n ? 0 : -1);
-        int hsc = s[col - 1] - 1;
-        int best = dsc > vsc ? dsc : vsc;
-        best = best > hsc ? best : hsc;
-        s[col] = best;
-        u32 cell = row * mf + col;
-        if (best == hsc) trace[cell >> 5] |= 1ULL << ((cell & 31) * 2);
-        else if (best == vsc) trace[cell >> 5] |= 2ULL << ((cell & 31) * 2);
-        diag = up;
-      }
-    }
-    u32 row = mg, col = n;
-    while (col > 0) {
-      u32 tr = 1;  // row 0: horizontal
-      if (row > 0) {
-        u32 cell = row * mf + col;
-        tr = (u32)(trace[cell >> 5] >> ((cell & 31) * 2)) & 3;
-      }
-      if (tr == 1) --col;
-      else if (tr == 2) --row;
-      else {
-        --row;
-        --col;
-      }
-    }
-    alignpos = chrpos + row;
+    alignpos = chrpos + site_lead_rows<TRACE_WORDS>(g, mg, qseq, b.qlen[q]);
   }
   r.chrpos = chrpos;
   r.alignpos = alignpos;
   a.out[h] = r;
 }
 
+// The same alignment by one wavefront: lane c owns column c of the score row.  The horizontal-gap dependency along a
+// row, best[c] = max(cand[c], best[c-1] - 1), is a prefix maximum of cand[c] + c; every lane keeps the 2-bit moves of its
+// own column (row r at bits 2(r-1)), and the traceback reads them back lane by lane.  n <= 63, mg <= 64.
+DG_DEV u32 wave_lead_rows(u32 mybyte, u32 g0, u32 mg, const u8* qseq, u32 n) {
+  const u32 lane = threadIdx.x & 63;
+  const u32 qc = (lane >= 1 && lane <= n) ? (u32)ascii_of(qseq[lane - 1]) : 0u;
+  int sc = -(int)lane;  // row 0
+  u64 tr0 = 0, tr1 = 0;
+  for (u32 row = 1; row <= mg; ++row) {
+    const u32 gc = (u32)__shfl((int)mybyte, (int)(g0 + row - 1));
+    const int up = sc, diagv = __shfl_up(sc, 1);
+    const int dsc = diagv + (gc == qc ? 0 : -1);
+    const int vsc = up + (lane == n ? 0 : -1);
+    const int cand = lane == 0 ? 0 : (dsc > vsc ? dsc : vsc);
+    int t = cand + (int)lane;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(t, off);
+      if ((int)lane >= off && o > t) t = o;
+    }
+    const int best = t - (int)lane;
+    const int hsc = __shfl_up(best, 1) - 1;
+    u64 mv = 0;
+    if (lane >= 1) {
+      if (best == hsc) mv = 1;
+      else if (best == vsc) mv = 2;
+    }
+    if (row <= 32) tr0 |= mv << (2 * (row - 1));
+    else tr1 |= mv << (2 * (row - 33));
+    sc = lane == 0 ? 0 : best;
+  }
+  u32 row = mg, col = n;
+  while (col > 0) {
+    u32 tr = 1;  // row 0: horizontal
+    if (row > 0) {
+      const u64 w = row <= 32 ? tr0 : tr1;
+      const u32 lo = (u32)__shfl((int)(u32)w, (int)col), hi = (u32)__shfl((int)(u32)(w >> 32), (int)col);
+      const u64 wc = ((u64)hi << 32) | lo;
+      tr = (u32)(wc >> (2 * ((row - 1) & 31))) & 3;
+    }
+    if (tr == 1) --col;
+    else if (tr == 2) --row;
+    else {
+      --row;
+      --col;
+    }
+  }
+  return row;
+}
+
+// One WAVEFRONT per located hit: context window and thal() with the DP table in LDS (thal_wave.hpp).  Workgroups are
+// persistent (the tables are staged once), wave w of the grid takes hits w, w + #waves, ...  Everything that depends
+// only on the hit is wave-uniform; hits whose Tm passes the cut are aligned by the same wavefront (silica.h:519-532).  Pairs the wave formulation cannot take (an oligo longer than the LDS table) or
+// hands back as ambiguous are marked pad = 1 and recomputed by k_site.
+__global__ void __launch_bounds__(512) k_site_wave(FmView f, Batch b, SiteArgs a, Counters* ctr) {
+  DG_DYNAMIC_LDS(lds_raw);
+  thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
+  {
+    const u64* src = reinterpret_cast<const u64*>(a.tables);
+    u64* dst = reinterpret_cast<u64*>(lds_raw);
+    for (u32 k = threadIdx.x; k < sizeof(thal::Tables) / 8; k += blockDim.x) dst[k] = src[k];
+  }
+  __syncthreads();
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const u32 lane = threadIdx.x & 63;
+  const thal::WaveMem wm =
+      thal::wave_mem_at(lds_raw + ((sizeof(thal::Tables) + 15) & ~(size_t)15) + (size_t)wave * a.wave_bytes, a.wave_len1, a.wave_stride);
+  const u64 nh = *a.nhits;
+  if (ctr->overflow || nh > a.hit_cap) return;
+  for (u64 h = (u64)blockIdx.x * wpb + wave; h < nh; h += (u64)gridDim.x * wpb) {
+    const HitSeed sd = a.seeds[h];
+    const u64 q = sd.qs >> 1;
+    const u32 strand = sd.qs & 1;
+    const u64 loc = sd.pos;
+    const u32 mlen = sd.len, koff = a.koff[q];
+    u32 lo_r = 0, hi_r = a.nseq - 1;
+    while (lo_r < hi_r) {
+      u32 mid = (lo_r + hi_r + 1) >> 1;
+      if (a.cum[mid] <= loc) lo_r = mid;
+      else hi_r = mid - 1;
+    }
+    const u32 ref = lo_r;
+    u32 chrpos = (u32)(loc - a.cum[ref]);
+    u64 pre = b.indel ? b.qdist[q] : 0, post = pre;  // silica.h:480-483
+    if (strand) post += koff;
+    else pre += koff;
+    if (pre > loc) pre = loc;
+    if (loc + mlen + post > f.n) post = f.n - loc - mlen;
+    // the window stops at a '\n' on either side: lanes look at one byte each
+    const u64 wlo = loc - pre, wlen = pre + mlen + post;
+    const u8 mybyte = lane < wlen ? f.text[wlo + lane] : 0;
+    const u64 nlmask = __ballot(lane < wlen && mybyte == '\n');
+    const u64 before = nlmask & thal::low_bits((int)pre);             // newlines in the left context
+    const u64 after = wlen <= 64 ? nlmask >> ((pre + mlen) & 63) : 0;  // newlines in the right context
+    const u32 pre_eff = before ? (u32)pre - (64 - (u32)__builtin_clzll(before)) : (u32)pre;
+    const u32 post_eff = after ? (u32)__builtin_ctzll(after) : (u32)post;
+    const u32 mg = pre_eff + mlen + post_eff;
+    const u32 g0 = (u32)pre - pre_eff;  // window start inside the 64 bytes the lanes hold
+    if (pre_eff <= chrpos) chrpos -= pre_eff;  // silica.h:501 (non-strict)
+    u8* win = a.windows + h * a.win_stride;
+    if (lane >= g0 && lane < g0 + mg && lane - g0 < a.win_stride) win[lane - g0] = mybyte;
+    const u64 p0 = a.poff[q];
+    const u32 plen = (u32)(a.poff[q + 1] - p0);
+    const u8* prim = (strand ? a.pfw : a.prv) + p0;
+    SiteRaw r;
+    r.ref = ref;
+    r.glen = mg;
+    r.qs = sd.qs;
+    r.pad = 0;
+    r.temp = -thal::kInf;
+    r.chrpos = chrpos;
+    r.alignpos = chrpos;
+    if (wlen > 64 || plen > a.wave_len1 || mg > a.wave_stride || plen == 0 || mg == 0 || pre + mlen >= 64) {
+      r.pad = 1;
+    } else {
+      // framed code sequences: lane L holds position L; words are OR-reduced over the wave
+      const u32 mycode = code_of_byte(mybyte);
+      const u32 gcode = mycode < 4 ? mycode : 4;
+      // position L of oligo 2 (the reversed window) is window byte mg-L, held by lane g0+mg-L
+      const int srcl = (int)(g0 + mg) - (int)lane;
+      const u32 got = (u32)__shfl((int)gcode, srcl >= 0 && srcl < 64 ? srcl : 0);
+      const u32 cb = (lane >= 1 && lane <= mg) ? got : 4u;
+      const u32 ca = (lane >= 1 && lane <= plen) ? (u32)prim[lane - 1] : 4u;
+      const bool ina = lane <= plen + 1, inb = lane <= mg + 1;
+      thal::PlaneSeq fa, fb;
+      fa.b0 = __ballot(ina && (ca & 1));
+      fa.b1 = __ballot(ina && (ca & 2));
+      fa.b2 = __ballot(ina && (ca & 4));
+      fb.b0 = __ballot(inb && (cb & 1));
+      fb.b1 = __ballot(inb && (cb & 2));
+      fb.b2 = __ballot(inb && (cb & 4));
+      // symmetry_thermo (thal.h:1976-2010) on both oligos
+      bool sym = !(plen & 1) && !(mg & 1);
+      if (sym) {
+        bool bad = false;
+        if (lane < plen / 2) {
+          const u32 x = prim[lane], y = prim[plen - 1 - lane];
+          if ((x < 4 || y < 4) && (x > 3 || y > 3 || x + y != 3)) bad = true;
+        }
+        if (lane < mg / 2) {
+          const u32 x = (u32)fb[(int)mg - (int)lane], y = (u32)fb[(int)lane + 1];  // window[lane], window[mg-1-lane]
+          if ((x < 4 || y < 4) && (x > 3 || y > 3 || x + y != 3)) bad = true;
+        }
+        sym = __ballot(bad) == 0;
+      }
+      bool amb = false;
+      const thal::Result tr = thal::wave_end1_tm(*tabs, a.env, fa, (int)plen, fb, (int)mg, sym, wm, (int)a.wave_stride, amb);
+      r.temp = tr.temp;
+      if (amb || a.force_redo) r.pad = 1;
+      else if (r.temp > a.cut_temp)  // silica.h:519-532
+        r.alignpos = chrpos + wave_lead_rows(mybyte, g0, mg, (strand ? b.rv : b.fw) + b.qoff[q], b.qlen[q]);
+    }
+    if (lane == 0) a.out[h] = r;
+  }
+}
 
 int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSeed* seeds, const u64* hit_off, u64 hit_cap,
                       const u64* cum, u32 nseq, u32 dmax_eff, u32 maxlen, Counters* ctr) {
@@ -215,11 +384,38 @@ int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSe
       sa.dp = ws[WS_DP].as<double>();
       sa.dp_stride = dp_stride;
       sa.dp_row = wmax;
+      sa.only_flagged = 0;
+      sa.wave_len1 = sa.wave_stride = sa.wave_bytes = 0;
+      static const bool force_redo = std::getenv("DICEY_DEBUG_THAL_REDO") != nullptr;
+      sa.force_redo = force_redo ? 1 : 0;
       const u32 cells = (wmax + 1) * (maxlen + 1);
+      static const bool no_lds = std::getenv("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
+      static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential thal only
+      // wave-per-hit path: LDS holds the tables once per workgroup and one DP table per wavefront
+      const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
+      const u32 per_wave = thal::wave_mem_bytes(sx->max_primer_len, wmax);
+      const u32 lds_cap = 160 * 1024;
+      u32 wpb = std::min<u32>(8, (lds_cap - tab_bytes) / per_wave);
+      const bool wave_path = !no_wave && !no_lds && sx->max_primer_len <= (u32)thal::kWaveMaxLen && wmax <= (u32)thal::kWaveMaxLen && wpb >= 2 && maxlen <= 63;
+      if (wave_path) {
+        const u32 lds_total = tab_bytes + wpb * per_wave;
+        static int cus = 0;
+        if (!cus) DG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device));
+        DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_site_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+        sa.first = 0;
+        sa.count = hit_cap;
+        sa.wave_len1 = sx->max_primer_len;
+        sa.wave_stride = wmax;
+        sa.wave_bytes = per_wave;
+        const u32 blocks_per_cu = std::max<u32>(1, lds_cap / lds_total);
+        const u64 want_blocks = ceil_div(hit_cap, wpb);
+        const dim3 wgrid((u32)std::min<u64>(want_blocks, (u64)cus * blocks_per_cu)), wblock(wpb * 64);
+        hipLaunchKernelGGL(k_site_wave, wgrid, wblock, lds_total, st, ix->view, b, sa, ctr);
+        sa.only_flagged = 1;  // whatever the wave kernel handed back goes through the sequential kernel below
+      }
       for (u64 first = 0; first < hit_cap; first += chunk) {  // launches beyond the real hit count exit at once
         sa.first = first;
         sa.count = std::min<u64>(chunk, hit_cap - first);
-        static const bool no_lds = std::getenv("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
         const dim3 sgrid(ceil_div(sa.count, 256)), sblock(256);
         if (cells <= 32 * 128) {
           if (no_lds) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_site<128, false>), sgrid, sblock, 0, st, ix->view, b, sa, ctr);
@@ -337,6 +533,15 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
     DG_HIP(hipMemcpyAsync(win.data(), sx.d_windows, nhits * (u64)sx.win_stride, hipMemcpyDeviceToHost, st));
   }
   DG_HIP(hipStreamSynchronize(st));
+  if (const char* dump = std::getenv("DICEY_DEBUG_DUMP_RAW")) {  // TEMP debugging aid
+    FILE* fp = fopen(dump, "wb");
+    fwrite(raw.data(), sizeof(SiteRaw), nhits, fp);
+    fclose(fp);
+    std::string wp = std::string(dump) + ".win";
+    fp = fopen(wp.c_str(), "wb");
+    fwrite(win.data(), sx.win_stride, nhits, fp);
+    fclose(fp);
+  }
   // Tm of every primer against its perfect complement (silica.h:431-443)
   std::vector<u8> pairs;
   std::vector<u64> pairoff(2 * np + 1, 0);

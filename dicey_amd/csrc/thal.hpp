@@ -68,6 +68,17 @@ struct PackedSeq {
 };
 constexpr int kPackedMax = 82;  // longest sequence a PackedSeq can frame
 
+// The same as three bit planes, position i <-> bit i: what a wavefront gets from three ballots when lane i holds code i.
+struct PlaneSeq {
+  uint64_t b0, b1, b2;
+  DG_HD int operator[](int i) const { return (int)(((b0 >> i) & 1) | (((b1 >> i) & 1) << 1) | (((b2 >> i) & 1) << 2)); }
+};
+constexpr int kPlaneMax = 62;  // positions 0..len+1 must fit 64 bits
+
+struct alignas(16) Cell {  // enthalpy and entropy of the best structure ending with pair (i,j): one 16-byte access
+  double h, s;
+};
+
 template <class SeqT>
 struct ProblemT {
   const Tables* T;
@@ -75,12 +86,12 @@ struct ProblemT {
   SeqT b;  // numSeq2 (second oligo REVERSED), same framing
   int len1, len2;
   double rc;
-  double* H;  // DP planes, (i,j) 1-based; cell (i,j) lives at ((j-1) + (i-1)*row) * cs
-  double* S;
+  Cell* C;  // DP table, (i,j) 1-based; cell (i,j) lives at ((j-1) + (i-1)*row) * cs
   int row;  // cells per row (>= len2; a common value lets the lanes of a wave touch the same cell index together)
-  int cs;   // distance between consecutive cells in doubles (1, or 64 when planes are interleaved across a wavefront)
-  DG_HD double& h(int i, int j) const { return H[(size_t)((j - 1) + (i - 1) * row) * cs]; }
-  DG_HD double& s(int i, int j) const { return S[(size_t)((j - 1) + (i - 1) * row) * cs]; }
+  int cs;   // distance between consecutive cells (1, or 64 when tables are interleaved across a wavefront)
+  DG_HD Cell& cell(int i, int j) const { return C[(size_t)((j - 1) + (i - 1) * row) * cs]; }
+  DG_HD double& h(int i, int j) const { return cell(i, j).h; }
+  DG_HD double& s(int i, int j) const { return cell(i, j).s; }
 };
 typedef ProblemT<const uint8_t*> Problem;
 
@@ -182,18 +193,21 @@ DG_HD void right_end(const PROB& p, int i, int j, double& outS, double& outH) {
   end_finish(p, x, y, S1, H1, T1, outS, outH);
 }
 
-// Extend the duplex ending at (i-1,j-1) by the stacked pair (i,j) if that melts higher: thal.h:1123-1163
+// Extend the duplex ending at (i-1,j-1) by the stacked pair (i,j) if that melts higher: thal.h:1123-1163, on values.
+// (S0,H0) is what cell (i,j) holds, `diag` is cell (i-1,j-1), (rS,rH) the right end at (i,j).  When neither comparison
+// holds (a NaN) the reference leaves the cell as it was, before the cutoff normalisation.
 template <class PROB>
-DG_HD void stack_step(const PROB& p, int i, int j) {
+DG_HD void stack_pick(const PROB& p, int i, int j, double S0, double H0, const Cell& diag, double rS, double rH, double& outS,
+                      double& outH) {
   const Tables& t = *p.T;
-  double S0 = p.s(i, j), H0 = p.h(i, j), rS, rH;
-  right_end(p, i, j, rS, rH);
+  outS = S0;
+  outH = H0;
   const double T0 = (H0 + kInitH + rH) / (S0 + kInitS + rS + p.rc);
   const double stH = t.stackH[p.a[i - 1]][p.a[i]][p.b[j - 1]][p.b[j]];
   double S1, H1, T1;
-  if (fin(p.h(i - 1, j - 1)) && fin(stH)) {
-    S1 = p.s(i - 1, j - 1) + t.stackS[p.a[i - 1]][p.a[i]][p.b[j - 1]][p.b[j]];
-    H1 = p.h(i - 1, j - 1) + stH;
+  if (fin(diag.h) && fin(stH)) {
+    S1 = diag.s + t.stackS[p.a[i - 1]][p.a[i]][p.b[j - 1]][p.b[j]];
+    H1 = diag.h + stH;
     T1 = (H1 + kInitH + rH) / (S1 + kInitS + rS + p.rc);
   } else {
     S1 = -1.0;
@@ -209,18 +223,18 @@ DG_HD void stack_step(const PROB& p, int i, int j) {
     H0 = 0.0;
   }
   if (T1 > T0) {
-    p.s(i, j) = S1;
-    p.h(i, j) = H1;
+    outS = S1;
+    outH = H1;
   } else if (T0 >= T1) {
-    p.s(i, j) = S0;
-    p.h(i, j) = H0;
+    outS = S0;
+    outH = H0;
   }
 }
 
 // Candidate (S,H) for closing pair (ii,jj) after an opening pair (i,j) with unpaired bases in between: the table part of
 // thal.h:1200-1333 (everything up to the G1/G2 comparison).
 template <class PROB>
-DG_HD void loop_candidate(const PROB& p, int i, int j, int ii, int jj, double& S, double& H) {
+DG_HD void loop_candidate(const PROB& p, const Cell& open, int i, int j, int ii, int jj, double& S, double& H) {
   const Tables& t = *p.T;
   const int l1 = ii - i - 1, l2 = jj - j - 1, ls = l1 + l2 - 1;
   S = -1.0;
@@ -233,17 +247,17 @@ DG_HD void loop_candidate(const PROB& p, int i, int j, int ii, int jj, double& S
         H = kInf;
         S = -1.0;
       }
-      H += p.h(i, j);
-      S += p.s(i, j);
+      H += open.h;
+      S += open.s;
       if (!fin(H)) {
         H = kInf;
         S = -1.0;
       }
     } else {
       H = t.bulgeH[ls] + t.atpH[p.a[i]][p.b[j]] + t.atpH[p.a[ii]][p.b[jj]];
-      H += p.h(i, j);
+      H += open.h;
       S = t.bulgeS[ls] + t.atpS[p.a[i]][p.b[j]] + t.atpS[p.a[ii]][p.b[jj]];
-      S += p.s(i, j);
+      S += open.s;
       if (!fin(H)) {
         H = kInf;
         S = -1.0;
@@ -255,9 +269,9 @@ DG_HD void loop_candidate(const PROB& p, int i, int j, int ii, int jj, double& S
     }
   } else if (l1 == 1 && l2 == 1) {
     S = t.stackmmS[p.a[i]][p.a[i + 1]][p.b[j]][p.b[j + 1]] + t.stackmmS[p.b[jj]][p.b[jj - 1]][p.a[ii]][p.a[ii - 1]];
-    S += p.s(i, j);
+    S += open.s;
     H = t.stackmmH[p.a[i]][p.a[i + 1]][p.b[j]][p.b[j + 1]] + t.stackmmH[p.b[jj]][p.b[jj - 1]][p.a[ii]][p.a[ii - 1]];
-    H += p.h(i, j);
+    H += open.h;
     if (!fin(H)) {
       H = kInf;
       S = -1.0;
@@ -270,10 +284,10 @@ DG_HD void loop_candidate(const PROB& p, int i, int j, int ii, int jj, double& S
     const int asym = l1 > l2 ? l1 - l2 : l2 - l1;
     H = t.interiorH[ls] + t.tstackH[p.a[i]][p.a[i + 1]][p.b[j]][p.b[j + 1]] + t.tstackH[p.b[jj]][p.b[jj - 1]][p.a[ii]][p.a[ii - 1]] +
         (kILAH * asym);
-    H += p.h(i, j);
+    H += open.h;
     S = t.interiorS[ls] + t.tstackS[p.a[i]][p.a[i + 1]][p.b[j]][p.b[j + 1]] + t.tstackS[p.b[jj]][p.b[jj - 1]][p.a[ii]][p.a[ii - 1]] +
         (kILAS * asym);
-    S += p.s(i, j);
+    S += open.s;
     if (!fin(H)) {
       H = kInf;
       S = -1.0;
@@ -301,10 +315,10 @@ struct Result {
   bool ok;
 };
 
-// a/b: framed code arrays (see Problem); oligo2 must already be reversed.  H/S: len1*len2 doubles each.
+// a/b: framed code sequences (see ProblemT); oligo2 must already be reversed.  cells: len1*row Cells (stride cs).
 template <class SeqT>
 DG_HD Result end1_tm(const Tables& T, const Env& env, const SeqT& a, int len1, const SeqT& b, int len2, bool both_symmetric,
-                     double* H, double* S, int row = 0, int cs = 1) {
+                     Cell* cells, int row = 0, int cs = 1) {
   Result r;
   r.temp = -kInf;  // THAL_ERROR_SCORE
   r.end1 = r.end2 = -1;
@@ -321,8 +335,7 @@ DG_HD Result end1_tm(const Tables& T, const Env& env, const SeqT& a, int len1, c
   p.len1 = len1;
   p.len2 = len2;
   p.rc = both_symmetric ? env.rc_sym : env.rc_asym;
-  p.H = H;
-  p.S = S;
+  p.C = cells;
   p.row = row > 0 ? row : len2;
   p.cs = cs;
   r.ok = true;
@@ -347,20 +360,22 @@ DG_HD Result end1_tm(const Tables& T, const Env& env, const SeqT& a, int len1, c
         p.h(i, j) = eH;
       }
       if (i > 1 && j > 1) {
-        stack_step(p, i, j);
         // The reference evaluates RSH(i,j) and re-reads cell (i,j) for every candidate; both only depend on the
         // sequences / on the value we hold, so they are computed once and the cell stays in registers.
         double rS, rH;
         right_end(p, i, j, rS, rH);
-        double curS = p.s(i, j), curH = p.h(i, j);
-        bool changed = false;
+        const Cell here = p.cell(i, j), diag = p.cell(i - 1, j - 1);
+        double curS, curH;
+        stack_pick(p, i, j, here.s, here.h, diag, rS, rH, curS, curH);
+        bool changed = curS != here.s || curH != here.h;
         for (int d = 3; d <= kMaxLoop + 2; ++d) {
           int ii, jj;
           loop_start(i, j, d, ii, jj);
           for (; ii > 0 && jj < j; --ii, ++jj) {
-            if (!fin(p.h(ii, jj))) continue;
+            const Cell open = p.cell(ii, jj);
+            if (!fin(open.h)) continue;
             double S, H;
-            loop_candidate(p, ii, jj, i, j, S, H);
+            loop_candidate(p, open, ii, jj, i, j, S, H);
             const double G1 = H + rH - kT * (S + rS);
             const double G2 = curH + rH - kT * (curS + rS);
             double lS = -1.0, lH = kInf;
@@ -429,7 +444,8 @@ DG_HD Result end1_tm(const Tables& T, const Env& env, const SeqT& a, int len1, c
       loop_start(i, j, d, ii, jj);
       for (; !done && ii > 0 && jj < j; --ii, ++jj) {
         double lS, lH;
-        loop_candidate(p, ii, jj, i, j, lS, lH);
+        const Cell open = p.cell(ii, jj);
+        loop_candidate(p, open, ii, jj, i, j, lS, lH);
         if (p.s(i, j) == lS && p.h(i, j) == lH) {
           i = ii;
           j = jj;

@@ -9,6 +9,7 @@
 #include "thal.hpp"
 
 #include "thal_internal.hpp"
+#include "thal_wave.hpp"
 
 namespace dg {
 namespace {
@@ -141,18 +142,59 @@ struct PairDesc {
   u32 symmetric, pad;
 };
 
+// One lane per pair, DP table in global memory: pairs too long for the wave kernel, or handed back by it (redo[t]).
 __global__ void k_thal(const thal::Tables* T, thal::Env env, const PairDesc* pd, u64 n, const u8* codes, double* dp, double* temp,
-                       int* end1, int* end2) {
+                       int* end1, int* end2, const u8* redo) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const PairDesc d = pd[t];
+  if (d.pad && !redo[t]) return;
   const u8* pa = codes + d.a_off;
   const u8* pb = codes + d.b_off;
-  thal::Result r = thal::end1_tm<const u8*>(*T, env, pa, (int)d.len1, pb, (int)d.len2, d.symmetric != 0, dp + d.dp_off,
-                                            dp + d.dp_off + (u64)d.len1 * d.len2);
+  thal::Result r = thal::end1_tm<const u8*>(*T, env, pa, (int)d.len1, pb, (int)d.len2, d.symmetric != 0,
+                                            reinterpret_cast<thal::Cell*>(dp + d.dp_off));
   temp[t] = r.temp;
   end1[t] = r.end1;
   end2[t] = r.end2;
+}
+
+// One wavefront per pair (thal_wave.hpp), persistent workgroups; pairs with pad == 1 only.
+__global__ void __launch_bounds__(512) k_thal_wave(const thal::Tables* T, thal::Env env, const PairDesc* pd, u64 n, const u8* codes,
+                                                   double* temp, int* end1, int* end2, u8* redo, u32 len1cap, u32 stride, u32 wave_bytes,
+                                                   u32 force_redo) {
+  DG_DYNAMIC_LDS(lds_raw);
+  thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
+  {
+    const u64* src = reinterpret_cast<const u64*>(T);
+    u64* dst = reinterpret_cast<u64*>(lds_raw);
+    for (u32 k = threadIdx.x; k < sizeof(thal::Tables) / 8; k += blockDim.x) dst[k] = src[k];
+  }
+  __syncthreads();
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const u32 lane = threadIdx.x & 63;
+  const thal::WaveMem wm =
+      thal::wave_mem_at(lds_raw + ((sizeof(thal::Tables) + 15) & ~(size_t)15) + (size_t)wave * wave_bytes, len1cap, stride);
+  for (u64 t = (u64)blockIdx.x * wpb + wave; t < n; t += (u64)gridDim.x * wpb) {
+    const PairDesc d = pd[t];
+    if (!d.pad) continue;
+    const u32 ca = lane <= d.len1 + 1 ? codes[d.a_off + lane] : 0u;  // framed: sentinel 4 at both ends
+    const u32 cb = lane <= d.len2 + 1 ? codes[d.b_off + lane] : 0u;
+    thal::PlaneSeq fa, fb;
+    fa.b0 = __ballot(ca & 1);
+    fa.b1 = __ballot(ca & 2);
+    fa.b2 = __ballot(ca & 4);
+    fb.b0 = __ballot(cb & 1);
+    fb.b1 = __ballot(cb & 2);
+    fb.b2 = __ballot(cb & 4);
+    bool amb = false;
+    const thal::Result r = thal::wave_end1_tm(*tabs, env, fa, (int)d.len1, fb, (int)d.len2, d.symmetric != 0, wm, (int)stride, amb);
+    if (lane == 0) {
+      temp[t] = r.temp;
+      end1[t] = r.end1;
+      end2[t] = r.end2;
+      redo[t] = (amb || force_redo) ? 1 : 0;
+    }
+  }
 }
 
 static u8 code_of(char c) {
@@ -225,6 +267,11 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
   if (!npairs) return DG_OK;
   std::vector<PairDesc> pd(npairs);
   u64 ncode = 0, ndp = 0;
+  static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;       // debugging aids: sequential kernel only /
+  static const bool force_redo = std::getenv("DICEY_DEBUG_THAL_REDO") != nullptr;  // recompute every pair sequentially too
+  const u64 kWaveLenCap = 48;  // two 48 x 48 tables still fit a workgroup's LDS next to the parameter tables
+  u32 wl1 = 0, wl2 = 0;
+  u64 nwave = 0;
   for (size_t k = 0; k < npairs; ++k) {
     u64 l1 = off[2 * k + 1] - off[2 * k], l2 = off[2 * k + 2] - off[2 * k + 1];
     if (l1 > 10000 || l2 > 10000) return fail(DG_ELIMIT, "pair %zu: sequence longer than THAL_MAX_SEQ", k);
@@ -238,7 +285,12 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
     bool both_long = l1 > (u64)thal::kMaxAlign && l2 > (u64)thal::kMaxAlign;
     ndp += both_long ? 0 : 2 * l1 * l2;
     pd[k].symmetric = self_complementary(seqs + off[2 * k], l1) && self_complementary(seqs + off[2 * k + 1], l2);
-    pd[k].pad = 0;
+    pd[k].pad = (!no_wave && l1 >= 1 && l2 >= 1 && l1 <= kWaveLenCap && l2 <= kWaveLenCap) ? 1 : 0;  // wave kernel takes it
+    if (pd[k].pad) {
+      wl1 = std::max<u32>(wl1, (u32)l1);
+      wl2 = std::max<u32>(wl2, (u32)l2);
+      ++nwave;
+    }
   }
   std::vector<u8> codes(ncode, 4);
   for (size_t k = 0; k < npairs; ++k) {
@@ -258,8 +310,25 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
   DG_HIP(hipMemcpyAsync(th->ws[1].p, codes.data(), ncode, hipMemcpyHostToDevice, st));
   int* e1 = th->ws[4].as<int>();
   int* e2 = e1 + npairs;
+  DG_TRY(th->ws[5].reserve(npairs + 8));
+  DG_HIP(hipMemsetAsync(th->ws[5].p, 0, npairs, st));
+  if (nwave) {
+    const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
+    const u32 per_wave = thal::wave_mem_bytes(wl1, wl2);
+    const u32 lds_cap = 160 * 1024;
+    const u32 wpb = std::max<u32>(1, std::min<u32>(8, (lds_cap - tab_bytes) / per_wave));
+    const u32 lds_total = tab_bytes + wpb * per_wave;
+    int cus = 0;
+    DG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, th->device));
+    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_thal_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+    const u64 blocks = std::min<u64>(ceil_div(npairs, wpb), (u64)cus * std::max<u32>(1, lds_cap / lds_total));
+    hipLaunchKernelGGL(k_thal_wave, dim3((u32)blocks), dim3(wpb * 64), lds_total, st, (const thal::Tables*)th->d_tables, th->env,
+                       th->ws[0].as<PairDesc>(), (u64)npairs, th->ws[1].as<u8>(), th->ws[3].as<double>(), e1, e2, th->ws[5].as<u8>(), wl1,
+                       wl2, per_wave, force_redo ? 1u : 0u);
+  }
   hipLaunchKernelGGL(k_thal, dim3(ceil_div(npairs, 64)), dim3(64), 0, st, (const thal::Tables*)th->d_tables, th->env,
-                     th->ws[0].as<PairDesc>(), (u64)npairs, th->ws[1].as<u8>(), th->ws[2].as<double>(), th->ws[3].as<double>(), e1, e2);
+                     th->ws[0].as<PairDesc>(), (u64)npairs, th->ws[1].as<u8>(), th->ws[2].as<double>(), th->ws[3].as<double>(), e1, e2,
+                     (const u8*)th->ws[5].as<u8>());
   DG_HIP(hipMemcpyAsync(temp, th->ws[3].p, npairs * 8, hipMemcpyDeviceToHost, st));
   std::vector<int> h1(npairs), h2(npairs);
   DG_HIP(hipMemcpyAsync(h1.data(), e1, npairs * 4, hipMemcpyDeviceToHost, st));

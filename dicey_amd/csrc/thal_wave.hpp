@@ -1,0 +1,279 @@
+// thal() END1 melting temperature with ONE WAVEFRONT per oligo pair, DP table in LDS (device only).
+//
+// thal.hpp states the reference's table fill (src/thal.h:1503-1551) one cell after the other.  The recurrence only
+// looks at cells (ii,jj) with ii < i AND jj < j, so the cells of one row are independent of each other: the 64 lanes
+// first settle the sequence-only terms of a row (left/right ends, stack extension: one lane per column), then share
+// out all (target column, opening row) pairs of that row and scan the pairing opening cells of "their" row with a
+// bit mask.  The reference walks the openings in a fixed order (loop size d ascending, ii descending) and replaces
+// the running value on strict improvement of the free energy, i.e. it keeps the FIRST minimum in visiting order;
+// lanes therefore carry (G, visiting key) and the group reduces lexicographically — the same cell value, bit for bit.
+//
+// The one place where the walk is not a plain minimum is its entropy cutoff (thal.h:1322-1330: a candidate with
+// S < -2500 that "wins" resets the value to (H=0, S=-3224)).  Such candidates only ever arise from openings that hold
+// that same placeholder, their free energy is ~1e6 and a real structure's is below 3e5, so they can never displace a
+// real value and re-writing the placeholder over itself changes nothing.  The kernel CHECKS this separation for every
+// value it touches (g < 8e5 for real ones, g > 9e5 for cutoff ones, placeholder exactly (0,-3224)) and reports
+// `ambiguous` otherwise; the caller then recomputes that pair with the sequential code of thal.hpp.
+//
+// The traceback (thal.h:2133-2179) needs no second search: every cell records which of the reference's three tests
+// (left end, stacked pair, first matching opening) identifies its value, in the reference's order of testing.
+#pragma once
+#include "thal.hpp"
+
+namespace dg {
+namespace thal {
+
+constexpr int kWaveMaxLen = kPlaneMax;  // longest oligo the wave kernel takes (lane = position, 64-bit column masks)
+
+struct RowInfo {   // per column of the row being filled
+  double rS, rH;   // right end at (i,j)
+  double G2;       // free energy of the value the cell holds before the openings are tried
+  double eS, eH;   // left end at (i,j): the traceback's first test (thal.h:2143)
+  double kS, kH;   // stacked continuation of (i-1,j-1): its second test (thal.h:2150)
+  double pad;
+};
+struct WaveMem {  // LDS owned by one wavefront
+  RowInfo* row;          // [stride]
+  Cell* cells;           // len1 x stride
+  unsigned short* from;  // same indexing: kFromLeft / kFromStack / visiting key of the opening / kFromNone
+  unsigned char* tlist;  // [stride] columns of the current row that take openings
+};
+constexpr unsigned short kFromNone = 0, kFromLeft = 1, kFromStack = 2;  // opening keys are >= 3*64
+
+DG_HD constexpr unsigned wave_mem_bytes(unsigned len1, unsigned stride) {
+  return (stride * (unsigned)sizeof(RowInfo) + len1 * stride * ((unsigned)sizeof(Cell) + 2u) + stride + 15u) & ~15u;
+}
+__device__ inline WaveMem wave_mem_at(unsigned char* base, unsigned len1, unsigned stride) {
+  WaveMem m;
+  m.row = reinterpret_cast<RowInfo*>(base);
+  m.cells = reinterpret_cast<Cell*>(base + stride * sizeof(RowInfo));
+  m.from = reinterpret_cast<unsigned short*>(m.cells + (size_t)len1 * stride);
+  m.tlist = reinterpret_cast<unsigned char*>(m.from + (size_t)len1 * stride);
+  return m;
+}
+
+__device__ inline void wave_sync() {  // lanes of a wave run in lockstep; this only pins the order of LDS traffic
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ inline uint64_t wave_uniform(uint64_t x) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ inline uint64_t low_bits(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
+
+// a, b: framed code sequences (wave-uniform), oligo2 reversed; 1 <= len1, len2 <= kWaveMaxLen; m.cells has
+// len1*stride cells, stride >= len2.  Every lane returns the same Result.
+template <class SeqT>
+__device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const SeqT& a, int len1, const SeqT& b, int len2,
+                                      bool both_symmetric, const WaveMem& m, int stride, bool& ambiguous) {
+  const int lane = (int)(threadIdx.x & 63);
+  Result r;
+  r.temp = -kInf;
+  r.end1 = r.end2 = -1;
+  r.ok = true;
+  ProblemT<SeqT> p;
+  p.T = &T;
+  p.a = a;
+  p.b = b;
+  p.len1 = len1;
+  p.len2 = len2;
+  p.rc = both_symmetric ? env.rc_sym : env.rc_asym;
+  p.C = m.cells;
+  p.row = stride;
+  p.cs = 1;
+  bool amb = false;
+  // pm[c]: columns jj (bit jj-1) whose base pairs with code c
+  const int myb = lane < len2 ? b[lane + 1] : 4;
+  uint64_t pm[4];
+  for (int c = 0; c < 4; ++c) pm[c] = __ballot(myb == 3 - c);
+  const int j = lane + 1;  // the column this lane owns in the per-row pass
+  for (int i = 1; i <= len1; ++i) {
+    const int ai = a[i];
+    const bool mine = lane < len2 && pairs(ai, myb);
+    bool takes = false;
+    // ---- per-row pass: left end, stack extension, right end (thal.h:1507-1519) ----
+    if (lane < len2) {
+      double curS = -1.0, curH = kInf;
+      unsigned short fr = kFromNone;
+      if (mine) {
+        curS = kMinEntropy;
+        curH = 0.0;
+        double eS = -1.0, eH = kInf;
+        left_end(p, i, j, eS, eH);
+        if (fin(eH)) {
+          curS = eS;
+          curH = eH;
+        }
+        double kS = 0, kH = 0;
+        if (i > 1 && j > 1) {
+          double rS, rH;
+          right_end(p, i, j, rS, rH);
+          const Cell diag = p.cell(i - 1, j - 1);
+          double nS, nH;
+          stack_pick(p, i, j, curS, curH, diag, rS, rH, nS, nH);
+          curS = nS;
+          curH = nH;
+          kS = T.stackS[p.a[i - 1]][ai][p.b[j - 1]][myb] + diag.s;  // what the traceback compares (thal.h:2150)
+          kH = T.stackH[p.a[i - 1]][ai][p.b[j - 1]][myb] + diag.h;
+          RowInfo ri;
+          ri.rS = rS;
+          ri.rH = rH;
+          ri.G2 = curH + rH - kT * (curS + rS);
+          ri.eS = eS;
+          ri.eH = eH;
+          ri.kS = kS;
+          ri.kH = kH;
+          ri.pad = 0;
+          m.row[lane] = ri;
+          takes = true;
+          const double g = curH - kT * curS;  // real value, or exactly the placeholder
+          if (curS < kMinEntropyCutoff ? !(curS == kMinEntropy && curH == 0.0) : !(g < 800000.0)) amb = true;
+        }
+        if (curS == eS && curH == eH) fr = kFromLeft;
+        else if (i > 1 && j > 1 && curS == kS && curH == kH) fr = kFromStack;
+      }
+      Cell c;
+      c.h = curH;
+      c.s = curS;
+      p.cell(i, j) = c;
+      m.from[(j - 1) + (i - 1) * stride] = fr;
+    }
+    const uint64_t tm = __ballot(takes);
+    if (takes) m.tlist[__popcll(tm & low_bits(lane))] = (unsigned char)j;
+    wave_sync();
+    const int P = __popcll(tm);
+    if (P == 0) continue;
+    // ---- openings: groups of R lanes (one per opening row ii) serve one target column each ----
+    const int n1 = i - 1 < kMaxLoop + 1 ? i - 1 : kMaxLoop + 1;  // l1 = i-ii-1 <= 30
+    int lg = 0;
+    while ((1 << lg) < n1) ++lg;
+    const int R = 1 << lg, G = 64 >> lg;
+    const int rr = lane & (R - 1), ii = i - 1 - rr;
+    const int ca = rr < n1 ? a[ii] : 4;
+    const uint64_t rowmask = ca == 0 ? pm[0] : ca == 1 ? pm[1] : ca == 2 ? pm[2] : ca == 3 ? pm[3] : 0;
+    const int l1 = rr;
+    for (int t0 = 0; t0 < P; t0 += G) {
+      const int t = t0 + (lane >> lg);
+      double bestG = 1e300, bestS = 0, bestH = 0, G2 = 0;
+      unsigned bestKey = ~0u;
+      int tj = 0;
+      if (t < P && rr < n1) {
+        tj = m.tlist[t];
+        const RowInfo ri = m.row[tj - 1];
+        G2 = ri.G2;
+        // jj < tj, l2 = tj-jj-1 <= 30-l1, and not the stacked pair itself
+        uint64_t mask = rowmask & low_bits(tj - 1);
+        const int lo = tj - 2 - (kMaxLoop - l1);
+        if (lo > 0) mask &= ~low_bits(lo);
+        if (l1 == 0) mask &= ~(1ULL << (tj - 2));
+        while (mask) {
+          const int jj = __builtin_ctzll(mask) + 1;
+          mask &= mask - 1;
+          const Cell open = p.cell(ii, jj);
+          if (!fin(open.h)) continue;
+          double S, H;
+          loop_candidate(p, open, ii, jj, i, tj, S, H);
+          if (!fin(H)) continue;  // (-1, inf): its free energy is above the placeholder's, never taken
+          const double g = H - kT * S;
+          if (S < kMinEntropyCutoff) {
+            if (!(g > 900000.0)) amb = true;
+            continue;
+          }
+          if (!(g < 800000.0)) amb = true;
+          const double G1 = H + ri.rH - kT * (S + ri.rS);
+          const unsigned key = (unsigned)((l1 + (tj - jj - 1) + 2) * 64 + (i - ii));
+          if (G1 < bestG || (G1 == bestG && key < bestKey)) {
+            bestG = G1;
+            bestKey = key;
+            bestS = S;
+            bestH = H;
+          }
+        }
+      }
+      double grpG = bestG;
+      unsigned grpKey = bestKey;
+      for (int off = R >> 1; off > 0; off >>= 1) {
+        const double oG = __shfl_xor(grpG, off);
+        const unsigned oK = (unsigned)__shfl_xor((int)grpKey, off);
+        if (oG < grpG || (oG == grpG && oK < grpKey)) {
+          grpG = oG;
+          grpKey = oK;
+        }
+      }
+      if (bestKey != ~0u && bestKey == grpKey && grpG < G2) {  // the walk's final value for (i,tj)
+        const int at = (tj - 1) + (i - 1) * stride;
+        const RowInfo ri = m.row[tj - 1];
+        unsigned short fr = (unsigned short)bestKey;  // the traceback's tests, in its order, applied to the new value
+        if (bestS == ri.eS && bestH == ri.eH) fr = kFromLeft;
+        else if (bestS == ri.kS && bestH == ri.kH) fr = kFromStack;
+        Cell c;
+        c.h = bestH;
+        c.s = bestS;
+        m.cells[at] = c;
+        m.from[at] = fr;
+      }
+    }
+    wave_sync();
+  }
+  wave_sync();
+  ambiguous = __ballot(amb) != 0;
+  // ---- END1: the first oligo's last base takes part (thal.h:2608-2626), first minimum over j ----
+  double myG = kInf;
+  if (lane < len2) {
+    double rS, rH;
+    right_end(p, len1, j, rS, rH);
+    rS = rS + 0.000001;
+    rH = rH + 0.000001;
+    const Cell c = p.cell(len1, j);
+    myG = (c.h + rH + kInitH) - kT * (c.s + rS + kInitS);
+  }
+  double bestG = myG;
+  int bestJ = myG < kInf ? j : 0x7fffffff;
+  if (!(myG < kInf)) bestG = kInf;
+  for (int off = 32; off > 0; off >>= 1) {
+    const double oG = __shfl_xor(bestG, off);
+    const int oJ = __shfl_xor(bestJ, off);
+    if (oG < bestG || (oG == bestG && oJ < bestJ)) {
+      bestG = oG;
+      bestJ = oJ;
+    }
+  }
+  int bestI = len1;
+  if (bestJ == 0x7fffffff) bestJ = 0;
+  if (!fin(bestG)) bestI = bestJ = 1;
+  double rS, rH;
+  right_end(p, bestI, bestJ, rS, rH);
+  const Cell top = p.cell(bestI, bestJ);
+  const double dH = top.h + rH + kInitH;
+  const double dS = top.s + rS + kInitS;
+  if (!fin(top.h)) {
+    r.temp = 0.0;
+    return r;
+  }
+  // traceback: follow the recorded tests, counting base pairs
+  int ti = bestI, tj = bestJ, npairs = 1;
+  for (;;) {
+    const unsigned fr = m.from[(tj - 1) + (ti - 1) * stride];
+    if (fr == kFromLeft || fr == kFromNone) break;
+    if (fr == kFromStack) {
+      --ti;
+      --tj;
+    } else {
+      const int d = (int)(fr >> 6), di = (int)(fr & 63);
+      const int l1 = di - 1, l2 = d - 2 - l1;
+      ti -= di;
+      tj = tj - 1 - l2;
+    }
+    ++npairs;
+  }
+  const int N = npairs - 1;
+  r.temp = (dH / (dS + (N * env.salt_correction) + p.rc)) - kZeroC;
+  r.end1 = bestI;
+  r.end2 = bestJ;
+  return r;
+}
+
+}  // namespace thal
+}  // namespace dg

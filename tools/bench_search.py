@@ -12,6 +12,8 @@ from dicey_amd import _capi
 ap = argparse.ArgumentParser()
 ap.add_argument("--genome-size", type=float, default=3.1e9)
 ap.add_argument("--pairs", type=int, default=2000)
+ap.add_argument("--dump", default="", help="write the site list (JSON lines) here, to diff two runs")
+ap.add_argument("--no-cpu", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 L = _capi.load()
@@ -43,7 +45,13 @@ sites, mt, fl, nh = dicey_amd.search_sites(ix, th, prim, seqlen)
 dt2 = time.time() - t1
 # CPU baseline: the oracle's restated silica.h driver on the REFERENCE's own thal() (oracle/_ref), one thread, bounded sample
 cpu = None
+if a.dump:
+    with open(a.dump, "w") as f:
+        for s_ in sites:
+            s_ = dict(s_); s_["temp"] = float(s_["temp"]).hex(); s_["perf_temp"] = float(s_["perf_temp"]).hex(); s_["pseq"] = prim[s_["primer"]]
+            f.write(json.dumps(s_, sort_keys=True) + "\n")
 try:
+    if a.no_cpu: raise RuntimeError("skipped")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     if O.ref_libs() is not None:

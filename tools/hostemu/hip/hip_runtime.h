@@ -41,6 +41,21 @@ inline void __syncthreads() {
   std::abort();
 }
 
+// Wave collectives are not emulated (lanes run one after the other): kernels that use them compile, and abort if a
+// launch reaches them.  emu_globals.cpp sets DICEY_NO_WAVE_THAL so the library takes its lane-per-item kernels.
+[[noreturn]] inline void emu_no_collectives(const char* what) {
+  std::fprintf(stderr, "hostemu: %s is not emulated\n", what);
+  std::abort();
+}
+inline unsigned long long __ballot(int) { emu_no_collectives("__ballot"); }
+template <class T> inline T __shfl(T, int) { emu_no_collectives("__shfl"); }
+template <class T> inline T __shfl_xor(T, int) { emu_no_collectives("__shfl_xor"); }
+template <class T> inline T __shfl_up(T, int) { emu_no_collectives("__shfl_up"); }
+inline int __syncthreads_or(int) { emu_no_collectives("__syncthreads_or"); }
+inline unsigned __builtin_amdgcn_readfirstlane(unsigned x) { return x; }
+inline void __builtin_amdgcn_wave_barrier() {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost, hipMemcpyDefault };
@@ -50,6 +65,11 @@ typedef hipEventEmu* hipEvent_t;
 
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "hostemu error"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+enum { hipDeviceAttributeMultiprocessorCount = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+// kernels with launch-sized LDS only exist in wave-collective form; give them a dummy buffer so they compile
+#define DG_DYNAMIC_LDS(name) static thread_local unsigned char name[16]
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

@@ -267,6 +267,9 @@ __global__ void __launch_bounds__(512) k_site_wave(FmView f, Batch b, SiteArgs a
   const u64 nh = *a.nhits;
   if (ctr->overflow || nh > a.hit_cap) return;
   for (u64 h = (u64)blockIdx.x * wpb + wave; h < nh; h += (u64)gridDim.x * wpb) {
+#ifdef DG_WAVE_PROFILE
+    DG_PROF_T(tH0);
+#endif
     const HitSeed sd = a.seeds[h];
     const u64 q = sd.qs >> 1;
     const u32 strand = sd.qs & 1;
@@ -350,6 +353,10 @@ __global__ void __launch_bounds__(512) k_site_wave(FmView f, Batch b, SiteArgs a
         r.alignpos = chrpos + wave_lead_rows(mybyte, g0, mg, (strand ? b.rv : b.fw) + b.qoff[q], b.qlen[q]);
     }
     if (lane == 0) a.out[h] = r;
+#ifdef DG_WAVE_PROFILE
+    DG_PROF_T(tH1);
+    if (lane == 0) atomicAdd(&::dg::thal::g_wave_prof[6], tH1 - tH0);
+#endif
   }
 }
 
@@ -440,6 +447,14 @@ using namespace dg;
 // ------------------------------------------------------------------------------------------------------------
 // dg_search_sites
 // ------------------------------------------------------------------------------------------------------------
+#ifdef DG_WAVE_PROFILE
+extern "C" void dg_debug_wave_profile(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dg::thal::g_wave_prof), 64);
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(dg::thal::g_wave_prof), z, 64);
+}
+#endif
+
 extern "C" {
 
 void dg_search_result_free(dg_search_result* r) {

@@ -18,6 +18,8 @@
 // The traceback (thal.h:2133-2179) needs no second search: every cell records which of the reference's three tests
 // (left end, stacked pair, first matching opening) identifies its value, in the reference's order of testing.
 #pragma once
+#include <cstddef>
+
 #include "thal.hpp"
 
 namespace dg {
@@ -52,6 +54,31 @@ __device__ inline WaveMem wave_mem_at(unsigned char* base, unsigned len1, unsign
   return m;
 }
 
+// The parameter tables as one array of doubles: entry e of an ...S table sits at offS + e, of its ...H twin at offH + e.
+// kOff* name a table PAIR by the position of its S member, kTwin* the distance to the H twin.
+#define DG_TOFF(member) ((int)(offsetof(Tables, member) / sizeof(double)))
+constexpr int kOffStack = DG_TOFF(stackS), kOffStackmm = DG_TOFF(stackmmS), kOffTstack = DG_TOFF(tstackS);
+constexpr int kOffInterior = DG_TOFF(interiorS), kOffBulge = DG_TOFF(bulgeS), kOffAtp = DG_TOFF(atpS);
+static_assert(DG_TOFF(stackH) - DG_TOFF(stackS) == 625 && DG_TOFF(stackmmH) - DG_TOFF(stackmmS) == 625 &&
+                  DG_TOFF(tstackH) - DG_TOFF(tstackS) == 625,
+              "four-index tables: H follows S");
+static_assert(DG_TOFF(interiorH) - DG_TOFF(interiorS) == 30 && DG_TOFF(bulgeH) - DG_TOFF(bulgeS) == 30, "loop tables: H follows S");
+static_assert(DG_TOFF(atpH) - DG_TOFF(atpS) == 25, "atp: H follows S");
+constexpr int kTwin4 = 625, kTwinLoop = 30, kTwinAtp = 25;
+
+#ifdef DG_WAVE_PROFILE
+__device__ unsigned long long g_wave_prof[8];
+#define DG_PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define DG_PROF_ADD(slot, t0, t1) prof_acc[slot] += (t1) - (t0)
+#define DG_PROF_DECL unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DG_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; ++k_) if (prof_acc[k_]) atomicAdd(&::dg::thal::g_wave_prof[k_], prof_acc[k_]); } while (0)
+#else
+#define DG_PROF_T(var)
+#define DG_PROF_ADD(slot, t0, t1)
+#define DG_PROF_DECL
+#define DG_PROF_FLUSH
+#endif
+
 __device__ inline void wave_sync() {  // lanes of a wave run in lockstep; this only pins the order of LDS traffic
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -84,12 +111,15 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
   p.row = stride;
   p.cs = 1;
   bool amb = false;
+  DG_PROF_DECL;
+  const double* TD = reinterpret_cast<const double*>(&T);
   // pm[c]: columns jj (bit jj-1) whose base pairs with code c
   const int myb = lane < len2 ? b[lane + 1] : 4;
   uint64_t pm[4];
   for (int c = 0; c < 4; ++c) pm[c] = __ballot(myb == 3 - c);
   const int j = lane + 1;  // the column this lane owns in the per-row pass
   for (int i = 1; i <= len1; ++i) {
+    DG_PROF_T(tA0);
     const int ai = a[i];
     const bool mine = lane < len2 && pairs(ai, myb);
     bool takes = false;
@@ -143,6 +173,8 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
     const uint64_t tm = __ballot(takes);
     if (takes) m.tlist[__popcll(tm & low_bits(lane))] = (unsigned char)j;
     wave_sync();
+    DG_PROF_T(tA1);
+    DG_PROF_ADD(0, tA0, tA1);
     const int P = __popcll(tm);
     if (P == 0) continue;
     // ---- openings: groups of R lanes (one per opening row ii) serve one target column each ----
@@ -155,6 +187,7 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
     const uint64_t rowmask = ca == 0 ? pm[0] : ca == 1 ? pm[1] : ca == 2 ? pm[2] : ca == 3 ? pm[3] : 0;
     const int l1 = rr;
     for (int t0 = 0; t0 < P; t0 += G) {
+      DG_PROF_T(tB0);
       const int t = t0 + (lane >> lg);
       double bestG = 1e300, bestS = 0, bestH = 0, G2 = 0;
       unsigned bestKey = ~0u;
@@ -168,23 +201,64 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
         const int lo = tj - 2 - (kMaxLoop - l1);
         if (lo > 0) mask &= ~low_bits(lo);
         if (l1 == 0) mask &= ~(1ULL << (tj - 2));
+        // thal.h:1200-1333 without branches: the four loop shapes differ in which tables feed the sum
+        //   single bulge   bulge[ls] + stack[ao][ac][bo][bc]                    (sign test BEFORE the opening is added)
+        //   longer bulge   bulge[ls] + atp[ao][bo] + atp[ac][bc]
+        //   1x1 loop       stackmm[ao][ao'][bo][bo'] + stackmm[bc][bc'][ac][ac']
+        //   interior loop  interior[ls] + tstack[ao][ao'][bo][bo'] + tstack[bc][bc'][ac][ac'] + ILA*|l1-l2|
+        // (o = opening pair (ii,jj), c = closing pair (i,tj), ' = the neighbour inside the loop); operand order as there.
+        const int ao = ca, ao1 = a[ii + 1], ac = ai, ac1 = a[i - 1], bc = b[tj], bc1 = b[tj - 1];
+        const int q2 = ((bc * 5 + bc1) * 5 + ac) * 5 + ac1, q1hi = (ao * 5 + ao1) * 25, sthi = (ao * 5 + ac) * 25, atpc = ac * 5 + bc;
         while (mask) {
           const int jj = __builtin_ctzll(mask) + 1;
           mask &= mask - 1;
           const Cell open = p.cell(ii, jj);
-          if (!fin(open.h)) continue;
-          double S, H;
-          loop_candidate(p, open, ii, jj, i, tj, S, H);
-          if (!fin(H)) continue;  // (-1, inf): its free energy is above the placeholder's, never taken
-          const double g = H - kT * S;
-          if (S < kMinEntropyCutoff) {
-            if (!(g > 900000.0)) amb = true;
-            continue;
+          const int bo = b[jj], bo1 = b[jj + 1];
+          const int l2 = tj - jj - 1, ls = l1 + l2 - 1;
+          const bool bulge = (l1 == 0) != (l2 == 0);
+          const bool single = bulge && l1 + l2 == 1, longb = bulge && !single, one = l1 == 1 && l2 == 1;
+          const bool inter = !bulge && !one;
+          const int q1 = q1hi + bo * 5 + bo1;
+          const int e0 = one ? kOffStackmm + q1 : (inter ? kOffInterior : kOffBulge) + ls;
+          const int e1 = single ? kOffStack + sthi + bo * 5 + bc : longb ? kOffAtp + ao * 5 + bo : one ? kOffStackmm + q2 : kOffTstack + q1;
+          const int e2 = longb ? kOffAtp + atpc : kOffTstack + q2;
+          const bool three = longb || inter;
+          const int h0 = one ? kTwin4 : kTwinLoop, h12 = longb ? kTwinAtp : kTwin4;  // distance to the H twin
+          double S = TD[e0] + TD[e1];
+          double H = TD[e0 + h0] + TD[e1 + h12];
+          const double S3 = S + TD[e2], H3 = H + TD[e2 + h12];
+          if (three) {
+            S = S3;
+            H = H3;
           }
-          if (!(g < 800000.0)) amb = true;
+          const int asym = l1 > l2 ? l1 - l2 : l2 - l1;
+          const double S4 = S + (kILAS * asym), H4 = H + (kILAH * asym);
+          if (inter) {
+            S = S4;
+            H = H4;
+          }
+          if (single && (H > 0 || S > 0)) {
+            H = kInf;
+            S = -1.0;
+          }
+          H += open.h;
+          S += open.s;
+          if (!fin(H)) {
+            H = kInf;
+            S = -1.0;
+          }
+          if (!single && H > 0 && S > 0) {
+            H = kInf;
+            S = -1.0;
+          }
+          // (-1, inf): its free energy is above the placeholder's, never taken
+          const bool valid = fin(open.h) && fin(H);
+          const bool cut = S < kMinEntropyCutoff;
+          const double g = H - kT * S;
+          if (valid && (cut ? !(g > 900000.0) : !(g < 800000.0))) amb = true;
           const double G1 = H + ri.rH - kT * (S + ri.rS);
-          const unsigned key = (unsigned)((l1 + (tj - jj - 1) + 2) * 64 + (i - ii));
-          if (G1 < bestG || (G1 == bestG && key < bestKey)) {
+          const unsigned key = (unsigned)((l1 + l2 + 2) * 64 + (i - ii));
+          if (valid && !cut && (G1 < bestG || (G1 == bestG && key < bestKey))) {
             bestG = G1;
             bestKey = key;
             bestS = S;
@@ -192,6 +266,9 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
           }
         }
       }
+      DG_PROF_T(tB1);
+      DG_PROF_ADD(1, tB0, tB1);
+      DG_PROF_ADD(4, 0ULL, 1ULL);
       double grpG = bestG;
       unsigned grpKey = bestKey;
       for (int off = R >> 1; off > 0; off >>= 1) {
@@ -214,10 +291,13 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
         m.cells[at] = c;
         m.from[at] = fr;
       }
+      DG_PROF_T(tB2);
+      DG_PROF_ADD(2, tB1, tB2);
     }
     wave_sync();
   }
   wave_sync();
+  DG_PROF_T(tE0);
   ambiguous = __ballot(amb) != 0;
   // ---- END1: the first oligo's last base takes part (thal.h:2608-2626), first minimum over j ----
   double myG = kInf;
@@ -268,6 +348,10 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
     }
     ++npairs;
   }
+  DG_PROF_T(tE1);
+  DG_PROF_ADD(3, tE0, tE1);
+  DG_PROF_ADD(5, 0ULL, 1ULL);
+  DG_PROF_FLUSH;
   const int N = npairs - 1;
   r.temp = (dH / (dS + (N * env.salt_correction) + p.rc)) - kZeroC;
   r.end1 = bestI;

@@ -14,13 +14,15 @@ ap.add_argument("--genome-size", type=float, default=3.1e9)
 ap.add_argument("--pairs", type=int, default=2000)
 ap.add_argument("--dump", default="", help="write the site list (JSON lines) here, to diff two runs")
 ap.add_argument("--no-cpu", action="store_true")
+ap.add_argument("--fm9", default="", help="reuse an index of the same synthetic genome (bench.py --keep-index)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 L = _capi.load()
 t0 = time.time()
 text, lens = bench.synth_genome(int(a.genome_size), 24, seed=1, device=dev)
-fm9 = "/dev/shm/dicey_search_bench.fm9"
-_capi.check(L, L.dg_index_build_device(C.c_void_p(text.data_ptr()), text.numel(), 0, fm9.encode()))
+fm9 = a.fm9 or "/dev/shm/dicey_search_bench.fm9"
+if not a.fm9:
+    _capi.check(L, L.dg_index_build_device(C.c_void_p(text.data_ptr()), text.numel(), 0, fm9.encode()))
 rng = np.random.default_rng(43)
 prim = []
 n = text.numel()
@@ -67,7 +69,12 @@ try:
                "sample": f"first {ns} primers, restated silica.h:429-573 calling the reference thal.h (oracle/_ref), {dtc:.1f} s"}
 except Exception as e:  # the checker is optional here
     cpu = {"error": str(e)}
+if hasattr(L, "dg_debug_wave_profile"):
+    buf = (C.c_ulonglong * 8)(); L.dg_debug_wave_profile(buf)
+    v = list(buf); np_ = max(1, v[5])
+    print("PROFILE per pair (cycles): rowpass %.0f openings %.0f reduce+write %.0f end+trace %.0f | rounds/pair %.1f | whole hit %.0f | pairs %d" % (v[0]/np_, v[1]/np_, v[2]/np_, v[3]/np_, v[4]/np_, v[6]/np_, v[5]), file=sys.stderr)
 print(json.dumps({"cpu_baseline": cpu, "workload": f"dicey search sites, {len(prim)} primers (18-25 nt), k=15, d=1, genome {int(a.genome_size)}",
                   "seconds_first": dt, "seconds": dt2, "primers_per_s": len(prim) / dt2, "thal_calls": nh, "thal_per_s": nh / dt2,
                   "sites": len(sites), "ms_device": dicey_amd.search_sites.last_ms_device, "setup_s": t1 - t0}))
-os.remove(fm9)
+if not a.fm9:
+    os.remove(fm9)

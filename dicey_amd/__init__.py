@@ -113,6 +113,16 @@ class FmIndex:
         _capi.check(self._L, self._L.dg_count(self._h, buf, off, len(patterns), out))
         return list(out[:len(patterns)])
 
+    def neighborhood_count(self, seqs: Sequence[bytes], distance: int = 1, hamming: bool = False,
+                           max_neighborhood: int = 10000) -> List[tuple]:
+        """(forward, reverse-complement) occurrence totals over the neighbourhood of every sequence (src/padlock.h:392-421)."""
+        buf, off = _pack(seqs)
+        n = len(seqs)
+        fw = (C.c_uint64 * max(1, n))()
+        rv = (C.c_uint64 * max(1, n))()
+        _capi.check(self._L, self._L.dg_neighborhood_count(self._h, distance, 1 if hamming else 0, max_neighborhood, buf, off, n, fw, rv))
+        return [(fw[i], rv[i]) for i in range(n)]
+
     def locate(self, patterns: Sequence[bytes]) -> List[List[int]]:
         buf, off = _pack(patterns)
         lp = C.POINTER(_capi.Locations)()

@@ -70,7 +70,8 @@ class Locations(C.Structure):
 SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_locate", "dg_locations_free",
            "dg_extract", "dg_hunt", "dg_hunt_result_free", "dg_hunt_device", "dg_index_build",
            "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
-           "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free"]
+           "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
+           "dg_neighborhood_count"]
 
 _lib = None
 
@@ -96,6 +97,7 @@ def load(path=None):
     L.dg_locations_free.argtypes = [C.POINTER(Locations)]
     L.dg_locations_free.restype = None
     L.dg_extract.argtypes = [vp, u64p, u64p, C.c_size_t, C.c_char_p, u64p]
+    L.dg_neighborhood_count.argtypes = [vp, C.c_uint32, C.c_int, C.c_uint32, C.c_char_p, u64p, C.c_size_t, u64p, u64p]
     L.dg_hunt.argtypes = [vp, C.POINTER(HuntParams), u32p, C.c_uint32, C.c_char_p, u64p, C.c_size_t,
                           C.POINTER(C.POINTER(HuntResult))]
     L.dg_hunt_device.argtypes = [vp, C.POINTER(HuntParams), u32p, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int,

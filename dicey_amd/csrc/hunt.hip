@@ -555,6 +555,19 @@ __global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u
   if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
 }
 
+// count mode: occurrences of all kept strings of a (query, strand) group
+__global__ void k_group_count(const u64* grp_off, const u32* nsel, const Sel* sel, u64 ngrp, u64* out, const Counters* ctr) {
+  u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngrp) return;
+  u64 sum = 0;
+  if (!ctr->overflow) {
+    const Sel* S = sel + grp_off[g];
+    const u32 ns = nsel[g];
+    for (u32 r = 0; r < ns; ++r) sum += (u64)S[r].hi - S[r].lo;
+  }
+  out[g] = sum;
+}
+
 // Exclusive prefix sum of n 32-bit counts into 64-bit offsets (out[n] = total), lane-independent three-level scheme so
 // that no host round trip is needed between the kernels of a batch.
 static constexpr u32 SCAN_CHUNK = 64;
@@ -1117,8 +1130,11 @@ static int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/,
 // One batch through the five kernels.  All sizes that are only known on the device (number of leaves, number of hits)
 // are handled with capacity guesses that the kernels check themselves; the host synchronises ONCE at the end, and
 // repeats the batch with larger buffers in the rare case a capacity was exceeded.
+// group_counts != nullptr: count mode (`dicey padlock`, padlock.h:396-421) — stop after the select stage and return, per
+// (query, strand), the occurrences summed over the kept neighbourhood strings; no locate, no verify.
 int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
-                     const void* d_qoff, size_t nq, u64 total, u32 maxlen, int fetch, dg_hunt_result** out, SearchExtra* sx) {
+                     const void* d_qoff, size_t nq, u64 total, u32 maxlen, int fetch, dg_hunt_result** out, SearchExtra* sx,
+                     uint64_t* group_counts) {
   if (!p->max_locations) return fail(DG_EINVAL, "max_locations must be positive");
   if (nseq == 0) return fail(DG_EINVAL, "no reference sequences");
   const bool indel = !p->hamming;
@@ -1265,6 +1281,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
                          nsel, qhits, scr_keep, scr_rank, ctr);
     }
     DG_HIP(hipEventRecord(ix->ev[4], st));
+    if (group_counts) {
+      DG_TRY(ws[WS_HITS].reserve(ngrp * 8 + 64));
+      hipLaunchKernelGGL(k_group_count, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, grp_off, nsel, ws[WS_SEL].as<Sel>(), ngrp,
+                         ws[WS_HITS].as<u64>(), ctr);
+      DG_HIP(hipMemsetAsync(hit_off + nq, 0, 8, st));  // no hits in this mode
+      for (int e = 5; e <= 7; ++e) DG_HIP(hipEventRecord(ix->ev[e], st));
+    } else {
     DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
     DG_HIP(hipEventRecord(ix->ev[5], st));
     {
@@ -1301,6 +1324,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
     }
     DG_HIP(hipEventRecord(ix->ev[7], st));
+    }
     hipLaunchKernelGGL(k_summary, dim3(NSHARD / 256), dim3(256), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), d_sum);
     DG_HIP(hipMemcpyAsync(&hsum, d_sum, sizeof(Summary), hipMemcpyDeviceToHost, st));
     DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
@@ -1320,6 +1344,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   ix->shard_cap_hint = shard_cap;
   ix->hit_cap_hint = std::max<u64>(ix->hit_cap_hint, nhits + nhits / 4 + 1024);
+  if (group_counts) {
+    DG_HIP(hipMemcpyAsync(group_counts, ws[WS_HITS].p, ngrp * 8, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipStreamSynchronize(st));
+  }
 
   dg_hunt_result* R = new dg_hunt_result;
   std::memset(R, 0, sizeof *R);
@@ -1413,6 +1441,49 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
     *out = nullptr;
   }
   return rc;
+}
+
+int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t max_neighborhood, const uint8_t* qbytes,
+                           const uint64_t* qoff, size_t nq, uint64_t* fw_count, uint64_t* rv_count) {
+  if (!ix || !qoff || !fw_count || !rv_count || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_neighborhood_count: null argument");
+  if (!nq) return DG_OK;
+  const u64 total = qoff[nq];
+  u32 maxlen = 0;
+  for (size_t i = 0; i < nq; ++i) {
+    if (qoff[i + 1] < qoff[i]) return fail(DG_EINVAL, "dg_neighborhood_count: qoff must be non-decreasing");
+    const u64 l = qoff[i + 1] - qoff[i];
+    // hunt skips queries under 10 nt and clamps the distance to the length (hunter.h:299-315); padlock.h does neither
+    if (l < 10 || l <= distance) return fail(DG_ELIMIT, "sequence %zu has %llu nt; this entry point takes >= 10 nt and more than `distance`", i, (unsigned long long)l);
+    if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "sequence %zu is too long", i);
+    for (u64 k = qoff[i]; k < qoff[i + 1]; ++k) {
+      const u8 ch = qbytes[k];
+      if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
+        return fail(DG_ELIMIT, "sequence %zu holds '%c'; only upper-case A/C/G/T sequences are counted (the reference searches the raw string, which matches nothing)", i, ch);
+    }
+    maxlen = std::max<u32>(maxlen, (u32)l);
+  }
+  DG_HIP(hipSetDevice(ix->device));
+  DG_TRY(ix->ws[WS_QB].reserve(total + 8));
+  DG_TRY(ix->ws[WS_QOFF].reserve((nq + 1) * 8));
+  DG_HIP(hipMemcpyAsync(ix->ws[WS_QB].p, qbytes, total, hipMemcpyHostToDevice, ix->stream));
+  DG_HIP(hipMemcpyAsync(ix->ws[WS_QOFF].p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+  dg_hunt_params hp;
+  hp.distance = distance;
+  hp.hamming = hamming;
+  hp.forward_only = 0;
+  hp.max_locations = 1;
+  hp.max_neighborhood = max_neighborhood;
+  const uint32_t one_seq = 1;  // chromosome lookup is not used in count mode
+  std::vector<u64> counts(2 * nq);
+  dg_hunt_result* hr = nullptr;
+  int rc = run_batch(ix, &hp, &one_seq, 1, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, 0, &hr, nullptr, counts.data());
+  if (hr) dg_hunt_result_free(hr);
+  if (rc != DG_OK) return rc;
+  for (size_t i = 0; i < nq; ++i) {
+    fw_count[i] = counts[2 * i];
+    rv_count[i] = counts[2 * i + 1];
+  }
+  return DG_OK;
 }
 
 int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,

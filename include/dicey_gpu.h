@@ -149,6 +149,16 @@ void dg_hunt_result_free(dg_hunt_result* r);
 int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
                    const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out);
 
+/* ---- `dicey padlock`: how often the neighbourhood of a probe arm occurs (reference src/padlock.h:392-421) ----
+ * For sequence i (upper-case A/C/G/T, >= 10 nt): fw_count[i] = sum over s in neighbors(seq_i, distance, indel, maxsize) of
+ * sdsl::count(fm_index, s) and rv_count[i] the same for its reverse complement — the totals the reference accumulates in
+ * hits[0] / hits[1] (its loops only stop early once the running total already exceeds the threshold it is compared with,
+ * so every comparison it makes has the same outcome on the full totals).  The original sequence is part of its own
+ * neighbourhood.  max_neighborhood is neighbors()' cap (10000 in padlock.h:396); refused with DG_ELIMIT when the cap
+ * could fire. */
+int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t max_neighborhood, const uint8_t* qbytes,
+                           const uint64_t* qoff, size_t nq, uint64_t* fw_count, uint64_t* rv_count);
+
 /* ---- index construction on the GPU (what `dicey index` does with sdsl::construct, index.h:97-123) ---- */
 /* text = SEQ1 '\n' SEQ2 '\n' ... SEQk '\n' (upper-cased), no NUL inside.  Writes sdsl csa_wt<> layout. */
 int dg_index_build(const uint8_t* text, uint64_t len, int device, const char* out_fm9_path);

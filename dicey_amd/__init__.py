@@ -238,6 +238,29 @@ def search_sites(ix: "FmIndex", th: "Thal", primers: Sequence[str], seqlen: Sequ
         L.dg_search_result_free(rp)
 
 
+def padlock_scan(ix: "FmIndex", th: "Thal", exons: Sequence[bytes], armlen: int = 20, distance: int = 1, hamming: bool = False,
+                 tmdiff: int = 2, gc_min: float = 0.4, gc_max: float = 0.6):
+    """Per-position values of a batch of exons (src/padlock.h:321-428; see dg_padlock_scan in include/dicey_gpu.h).
+    Returns a dict of numpy arrays (pos_off, arm_gc, arm_tm, probe_gc, probe_tm, arm_count, arm_nbcount) + work counters."""
+    import numpy as np
+    L = ix._L
+    buf, off = _pack(exons)
+    p = _capi.PadlockParams(armlen, distance, 1 if hamming else 0, tmdiff, gc_min, gc_max)
+    rp = C.POINTER(_capi.PadlockResult)()
+    _capi.check(L, L.dg_padlock_scan(ix.handle, th._h, C.byref(p), buf, off, len(exons), C.byref(rp)))
+    try:
+        R = rp.contents
+        n = R.npos
+        take = lambda ptr, cnt, dt: np.ctypeslib.as_array(ptr, shape=(max(1, cnt),))[:cnt].astype(dt, copy=True)
+        return {"pos_off": take(R.pos_off, R.nexons + 1, np.uint64), "arm_gc": take(R.arm_gc, n, np.float64),
+                "arm_tm": take(R.arm_tm, n, np.float64), "probe_gc": take(R.probe_gc, n, np.float64),
+                "probe_tm": take(R.probe_tm, n, np.float64), "arm_count": take(R.arm_count, n, np.int64),
+                "arm_nbcount": take(R.arm_nbcount, n, np.int64), "n_arm_thal": R.n_arm_thal, "n_probe_thal": R.n_probe_thal,
+                "n_arms_counted": R.n_arms_counted}
+    finally:
+        L.dg_padlock_result_free(rp)
+
+
 def build_index(text: bytes, out_fm9: str, device: int = 0, _lib=None):
     """GPU counterpart of `dicey index` (src/index.h:97-123): text = SEQ1\\nSEQ2\\n...SEQk\\n, upper-case."""
     L = _lib or _capi.load()

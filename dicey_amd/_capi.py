@@ -67,11 +67,23 @@ class Locations(C.Structure):
 
 
 # every symbol include/dicey_gpu.h declares; tests/test_capi_symbols.py checks the list against the header
+class PadlockParams(C.Structure):
+    _fields_ = [("armlen", C.c_uint32), ("distance", C.c_uint32), ("hamming", C.c_int32), ("tmdiff", C.c_uint32),
+                ("gc_min", C.c_double), ("gc_max", C.c_double)]
+
+
+class PadlockResult(C.Structure):
+    _fields_ = [("nexons", C.c_uint64), ("npos", C.c_uint64), ("pos_off", C.POINTER(C.c_uint64)),
+                ("arm_gc", C.POINTER(C.c_double)), ("arm_tm", C.POINTER(C.c_double)), ("probe_gc", C.POINTER(C.c_double)),
+                ("probe_tm", C.POINTER(C.c_double)), ("arm_count", C.POINTER(C.c_int64)), ("arm_nbcount", C.POINTER(C.c_int64)),
+                ("n_arm_thal", C.c_uint64), ("n_probe_thal", C.c_uint64), ("n_arms_counted", C.c_uint64)]
+
+
 SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_locate", "dg_locations_free",
            "dg_extract", "dg_hunt", "dg_hunt_result_free", "dg_hunt_device", "dg_index_build",
            "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
            "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
-           "dg_neighborhood_count"]
+           "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free"]
 
 _lib = None
 
@@ -97,6 +109,9 @@ def load(path=None):
     L.dg_locations_free.argtypes = [C.POINTER(Locations)]
     L.dg_locations_free.restype = None
     L.dg_extract.argtypes = [vp, u64p, u64p, C.c_size_t, C.c_char_p, u64p]
+    L.dg_padlock_scan.argtypes = [vp, vp, C.POINTER(PadlockParams), C.c_char_p, u64p, C.c_size_t, C.POINTER(C.POINTER(PadlockResult))]
+    L.dg_padlock_result_free.argtypes = [C.POINTER(PadlockResult)]
+    L.dg_padlock_result_free.restype = None
     L.dg_neighborhood_count.argtypes = [vp, C.c_uint32, C.c_int, C.c_uint32, C.c_char_p, u64p, C.c_size_t, u64p, u64p]
     L.dg_hunt.argtypes = [vp, C.POINTER(HuntParams), u32p, C.c_uint32, C.c_char_p, u64p, C.c_size_t,
                           C.POINTER(C.POINTER(HuntResult))]

@@ -175,6 +175,39 @@ void dg_thal_close(dg_thal* th);
  * when both sequences exceed 60 nt), end1/end2 = align_end_1/2 (may be NULL) */
 int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t npairs, double* temp, int32_t* end1, int32_t* end2);
 
+/* ---- `dicey padlock`: the per-position values of a batch of exons (reference src/padlock.h:321-428) ----
+ * exons: strand-corrected, upper-case exon sequences (exonseq of padlock.h:313-315), concatenated; exon e =
+ * exons[exon_off[e] .. exon_off[e+1]).  Exons shorter than 2*armlen carry no positions.  For exon e, arm window q
+ * (0 <= q <= len-armlen) has slot pos_off[e] + q:
+ *   arm_gc      gccontent(arm)                          (padlock.h:324, 342; -1 when the window holds an N)
+ *   arm_tm      thal(arm, reverse complement).temp      (:331-336; DG_PADLOCK_NOT_COMPUTED when arm_gc fails the filter)
+ *   probe_gc / probe_tm  the same for the 2*armlen probe starting at q (:356-371; q <= len-2*armlen; probe_tm is computed
+ *                only when both arms pass GC, the Tm ceiling 93 + GC - 675/armlen and the Tm difference)
+ *   arm_count   sdsl::count(arm) + sdsl::count(reverse complement)   (:381-385)
+ *   arm_nbcount occurrences summed over neighbors(arm) and neighbors(reverse complement) (:396-405; see
+ *                dg_neighborhood_count); both -1 unless the arm belongs to a probe inside the Tm window (:372-374)
+ * The caller replays the reference's decisions (including `k += targetlen - 1` after an accepted probe) on these arrays;
+ * a decision that would need a value not computed here cannot be reached.  thal refusing a pair (both oligos > 60 nt)
+ * shows as -999999, the reference's error path (:337-340). */
+#define DG_PADLOCK_NOT_COMPUTED (-1e300)
+typedef struct {
+  uint32_t armlen;    /* -m */
+  uint32_t distance;  /* -d */
+  int32_t hamming;    /* -n */
+  uint32_t tmdiff;    /* -z */
+  double gc_min, gc_max; /* --gcmin / --gcmax */
+} dg_padlock_params;
+typedef struct {
+  uint64_t nexons, npos;
+  uint64_t* pos_off; /* nexons+1 */
+  double *arm_gc, *arm_tm, *probe_gc, *probe_tm;
+  int64_t *arm_count, *arm_nbcount;
+  uint64_t n_arm_thal, n_probe_thal, n_arms_counted; /* work done, for measurements */
+} dg_padlock_result;
+int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const uint8_t* exons, const uint64_t* exon_off, size_t nexons,
+                    dg_padlock_result** out);
+void dg_padlock_result_free(dg_padlock_result* r);
+
 /* ---- `dicey search`: binding sites of a batch of primers (reference src/silica.h:429-573) ----
  * Per primer: thal(primer, revcomp) (silica.h:437); neighbourhood of its last k nucleotides on both strands through the
  * FM-index; per located hit the context window with the 5' overhang, thal(primer, window), the Tm cut, the alignment

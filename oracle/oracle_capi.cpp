@@ -10,6 +10,7 @@
 #include "fm9.hpp"
 #include "hunt_ref.hpp"
 #include "search_ref.hpp"
+#include "padlock_ref.hpp"
 
 using namespace orc;
 
@@ -240,6 +241,71 @@ char* orc_search(void* h, const uint32_t* seqlen, const char* const* seqname, ui
   std::string js = r.run(lines, code);
   if (rc) *rc = code;
   return dup_out(js, json_len);
+}
+
+struct orc_padlock_params {
+  int32_t json, hamming, probe_mode, overlapping, compute_all, input_fasta, absent;
+  uint32_t distance, armlen, tmdiff;
+  double gcmin, gcmax;
+};
+
+static std::vector<std::string> split_lines(const char* text) {  // std::getline over the decompressed file
+  std::vector<std::string> lines;
+  std::string cur;
+  for (const char* q = text; *q; ++q) {
+    if (*q == '\n') {
+      lines.push_back(cur);
+      cur.clear();
+    } else cur.push_back(*q);
+  }
+  if (!cur.empty()) lines.push_back(cur);
+  return lines;
+}
+
+// padlock.h:147-531 (+ gtf.h).  strs = {ucscDB, anchor, spacerleft, spacerright, feature, idname, genome, infile, outfile,
+// barcodes, gtf, jsonfile}; thal_fn = oracle/_ref's ref_thal, initialised by the caller.  Returns the TSV; *json_out the
+// (uncompressed) JSON, *err_out what the reference writes to std::cerr.
+char* orc_padlock(void* h, const orc_padlock_params* p, const char* const* strs, const char* const* genes, uint32_t ngenes,
+                  const char* const* chrname, const char* const* chrseq, uint32_t nchr, const char* gtf_text, const char* bar_text,
+                  void* thal_fn, int* rc, char** json_out, char** err_out) {
+  PadlockRun r;
+  r.fm = &((Handle*)h)->csa;
+  r.thal = (ThalFn)thal_fn;
+  r.c.json = p->json != 0;
+  r.c.indel = !p->hamming;
+  r.c.armMode = !p->probe_mode;
+  r.c.overlapping = p->overlapping != 0;
+  r.c.computeAll = p->compute_all != 0;
+  r.c.inputFasta = p->input_fasta != 0;
+  r.c.absent = p->absent != 0;
+  r.c.distance = p->distance;
+  r.c.armlen = p->armlen;
+  r.c.tmdiff = p->tmdiff;
+  r.c.mingcth = p->gcmin;
+  r.c.maxgcth = p->gcmax;
+  r.c.ucscDB = strs[0];
+  r.c.anchor = strs[1];
+  r.c.spacerleft = strs[2];
+  r.c.spacerright = strs[3];
+  r.c.feature = strs[4];
+  r.c.idname = strs[5];
+  r.c.genome = strs[6];
+  r.c.infile = strs[7];
+  r.c.outfile = strs[8];
+  r.c.barcodes = strs[9];
+  r.c.gtf = strs[10];
+  r.c.jsonfile = strs[11];
+  for (uint32_t i = 0; i < ngenes; ++i) r.c.geneset.insert(genes[i]);
+  for (uint32_t i = 0; i < nchr; ++i) {
+    r.chrname.push_back(chrname[i]);
+    r.chrseq.push_back(chrseq[i]);
+  }
+  std::string tsv, json;
+  int code = r.run(split_lines(gtf_text), split_lines(bar_text), tsv, json);
+  if (rc) *rc = code;
+  if (json_out) *json_out = dup_out(json, nullptr);
+  if (err_out) *err_out = dup_out(r.err, nullptr);
+  return dup_out(tsv, nullptr);
 }
 
 }  // extern "C"

@@ -49,7 +49,7 @@ def ref_libs(temp_c=37.0, mv=50.0, dv=1.5, dna_conc=50.0, dntp=0.6):
 
 
 def build():
-    srcs = [os.path.join(_ODIR, f) for f in ("oracle_capi.cpp", "fm9.hpp", "hunt_ref.hpp", "search_ref.hpp", "Makefile")]
+    srcs = [os.path.join(_ODIR, f) for f in ("oracle_capi.cpp", "fm9.hpp", "hunt_ref.hpp", "search_ref.hpp", "padlock_ref.hpp", "Makefile")]
     if (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _ODIR, "-s"])
     return _SO
@@ -217,6 +217,41 @@ class Index:
         jp = lib().orc_search(self.h, sl, sn, nseq, text, len(text), C.byref(p), genome.encode(), outfile.encode(), fasta.encode(),
                               tf, jf, C.byref(rc), C.byref(jl))
         return _take(jp, jl.value).decode(), rc.value
+
+    def padlock(self, chrname, chrseq, gtf_text: str, barcodes_text: str, genes=(), compute_all=False, input_fasta=False, absent=False,
+                json=False, hamming=False, probe_mode=False, overlapping=False, distance=1, armlen=20, tmdiff=2, gcmin=0.4, gcmax=0.6,
+                ucsc="Unknown", anchor="TGCGTCTATTTAGTGGAGCC", spacerleft="TCCTC", spacerright="TCTTT", feature="exon", idname="gene_id",
+                genome="", infile="", outfile="out.tsv", barcodes="", gtf="", jsonfile="", mv=50.0, dv=1.5, dna_conc=50.0, dntp=0.6):
+        """`dicey padlock` through the restated padlock.h/gtf.h driver + the reference's own thal() (oracle/_ref).
+        chrseq: the FASTA sequences as stored.  Returns (tsv, json_text, stderr_text, exit_code)."""
+        libs = ref_libs(37.0, mv, dv, dna_conc, dntp)
+        if libs is None:
+            raise RuntimeError("oracle/_ref is not built")
+        T, _ = libs
+
+        class P(C.Structure):
+            _fields_ = [(n, C.c_int32) for n in ("json", "hamming", "probe_mode", "overlapping", "compute_all", "input_fasta", "absent")] + \
+                       [(n, C.c_uint32) for n in ("distance", "armlen", "tmdiff")] + [("gcmin", C.c_double), ("gcmax", C.c_double)]
+        p = P(int(json), int(hamming), int(probe_mode), int(overlapping), int(compute_all), int(input_fasta), int(absent), distance, armlen,
+              tmdiff, gcmin, gcmax)
+        strs = [ucsc, anchor, spacerleft, spacerright, feature, idname, genome, infile, outfile, barcodes, gtf, jsonfile]
+        sa = (C.c_char_p * len(strs))(*[x.encode() for x in strs])
+        ga = (C.c_char_p * max(1, len(genes)))(*[g.encode() for g in genes])
+        n = len(chrname)
+        cn = (C.c_char_p * n)(*[x.encode() for x in chrname])
+        cs = (C.c_char_p * n)(*[x.encode() if isinstance(x, str) else x for x in chrseq])
+        rc, jo, eo = C.c_int(), C.c_void_p(), C.c_void_p()
+        L = lib()
+        L.orc_padlock.restype = C.c_void_p
+        L.orc_padlock.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p,
+                                  C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        tp = L.orc_padlock(self.h, C.byref(p), sa, ga, len(genes), cn, cs, n, gtf_text.encode(), barcodes_text.encode(),
+                           C.cast(T.ref_thal, C.c_void_p), C.byref(rc), C.byref(jo), C.byref(eo))
+        out = []
+        for ptr in (tp, jo.value, eo.value):
+            out.append(C.string_at(ptr).decode())
+            L.orc_free(C.c_void_p(ptr))
+        return out[0], out[1], out[2], rc.value
 
     def hunt_timed(self, seqlen, seqs, threads=1, distance=1, hamming=False, forward_only=False,
                    max_locations=1000, max_neighborhood=10000):

@@ -4,12 +4,15 @@
 // stages — thal of every arm window that passes the GC filter, thal of every probe whose two arms pass, exact and
 // neighbourhood occurrence counts of the arms of probes inside the Tm window — and the caller replays the reference's
 // decision sequence on the returned arrays (the values do not depend on which positions the reference skips).
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "common.hpp"
+#include "thal_internal.hpp"
 
 using namespace dg;
 
@@ -21,17 +24,6 @@ char complement_iupac(char n) {  // util.h:54-91
   const char* p = n ? std::strchr(from, n) : nullptr;
   return p ? to[p - from] : 'N';
 }
-double gccontent(const uint8_t* s, size_t n) {  // util.h:99-107
-  if (!n) return -1;
-  uint32_t gc = 0;
-  for (size_t i = 0; i < n; ++i) {
-    const char ch = (char)s[i];
-    if (ch == 'N' || ch == 'n') return -1;
-    else if (ch == 'C' || ch == 'G' || ch == 'c' || ch == 'g') ++gc;
-  }
-  return (double)gc / (double)n;
-}
-
 }  // namespace
 
 extern "C" {
@@ -81,6 +73,14 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     R->probe_gc[i] = 0;
     R->arm_count[i] = R->arm_nbcount[i] = -1;
   }
+  static const bool timing = std::getenv("DICEY_DEBUG_TIMING") != nullptr;  // debugging aid: host-side phase times on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "dg_padlock_scan: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   auto fail_with = [&](int rc) {
     dg_padlock_result_free(R);
     return rc;
@@ -90,9 +90,19 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
   auto revcomp_into = [&](std::string& buf, const uint8_t* s, uint64_t n) {
     for (uint64_t i = 0; i < n; ++i) buf.push_back(complement_iupac((char)s[n - 1 - i]));
   };
+  const uint64_t nbytes = nexons ? exon_off[nexons] : 0;
   auto thal_pairs = [&](const std::vector<std::pair<uint64_t, uint64_t>>& win /* (byte offset, length) */, std::vector<double>& temps) -> int {
     temps.assign(win.size(), 0.0);
     if (win.empty()) return DG_OK;
+    if (win[0].second <= kSelfWindowMax) {  // pairs formed on the device from the exon bytes
+      std::vector<uint64_t> wo(win.size());
+      std::vector<uint32_t> wl(win.size());
+      for (size_t i = 0; i < win.size(); ++i) {
+        wo[i] = win[i].first;
+        wl[i] = (uint32_t)win[i].second;
+      }
+      return thal_self_windows(th, exons, nbytes, wo.data(), wl.data(), win.size(), temps.data());
+    }
     std::string buf;
     std::vector<uint64_t> off(1, 0);
     for (auto& w : win) {
@@ -103,6 +113,17 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     }
     return dg_thal_batch(th, (const uint8_t*)buf.data(), off.data(), win.size(), temps.data(), nullptr, nullptr);
   };
+  // gccontent() of any window from running counts: G/C so far, and N/n so far (a window with an N scores -1)
+  std::vector<uint32_t> gcs(nbytes + 1, 0), nns(nbytes + 1, 0);
+  for (uint64_t i = 0; i < nbytes; ++i) {
+    const char ch = (char)exons[i];
+    gcs[i + 1] = gcs[i] + (ch == 'C' || ch == 'G' || ch == 'c' || ch == 'g');
+    nns[i + 1] = nns[i] + (ch == 'N' || ch == 'n');
+  }
+  auto gc_of = [&](uint64_t at, uint64_t n) -> double {
+    if (nns[at + n] != nns[at]) return -1;
+    return (double)(gcs[at + n] - gcs[at]) / (double)n;
+  };
   // stage 1: GC of every arm window; thal(arm, reverse complement) where the GC filter lets it through (padlock.h:323-345)
   std::vector<std::pair<uint64_t, uint64_t>> win;
   std::vector<uint64_t> where;
@@ -111,14 +132,16 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     if (len < T) continue;
     for (uint64_t q = 0; q + L <= len; ++q) {
       const uint64_t at = R->pos_off[e] + q;
-      R->arm_gc[at] = gccontent(exons + b0 + q, L);
+      R->arm_gc[at] = gc_of(b0 + q, L);
       if (R->arm_gc[at] < minGC || R->arm_gc[at] > maxGC) continue;
       win.emplace_back(b0 + q, L);
       where.push_back(at);
     }
   }
+  lap("arm GC + window list");
   std::vector<double> temps;
   int rc = thal_pairs(win, temps);
+  lap("arm thal (pack + GPU)");
   if (rc != DG_OK) return fail_with(rc);
   for (size_t i = 0; i < where.size(); ++i) R->arm_tm[where[i]] = temps[i];
   // stage 2: probes whose two arms pass GC, Tm ceiling and Tm difference (padlock.h:327-362)
@@ -134,7 +157,7 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     if (len < T) continue;
     for (uint64_t k = 0; k + T <= len; ++k) {
       const uint64_t at = R->pos_off[e] + k;
-      R->probe_gc[at] = gccontent(exons + b0 + k, T);
+      R->probe_gc[at] = gc_of(b0 + k, T);
       if (!arm_ok(at) || !arm_ok(at + L)) continue;
       if (std::abs(R->arm_tm[at] - R->arm_tm[at + L]) > (double)p->tmdiff) continue;
       if (R->probe_gc[at] < minGC || R->probe_gc[at] > maxGC) continue;
@@ -142,9 +165,11 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
       where.push_back(at);
     }
   }
+  lap("probe GC + window list");
   rc = thal_pairs(win, temps);
   if (rc != DG_OK) return fail_with(rc);
   for (size_t i = 0; i < where.size(); ++i) R->probe_tm[where[i]] = temps[i];
+  lap("probe thal (pack + GPU)");
   // stage 3: arms of probes inside the Tm window: exact occurrences on both strands and the neighbourhood totals
   std::vector<std::pair<uint64_t, uint64_t>> arms;  // (byte offset, result slot)
   for (size_t i = 0; i < where.size(); ++i) {
@@ -170,6 +195,7 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     rc = dg_count(ix, (const uint8_t*)buf.data(), off.data(), 2 * arms.size(), cnt.data());
     if (rc != DG_OK) return fail_with(rc);
     for (size_t i = 0; i < arms.size(); ++i) R->arm_count[arms[i].second] = (int64_t)(cnt[2 * i] + cnt[2 * i + 1]);
+    lap("exact counts");
     if (p->distance > 0) {
       std::string fbuf;
       std::vector<uint64_t> foff(1, 0);
@@ -181,6 +207,7 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
       rc = dg_neighborhood_count(ix, p->distance, p->hamming, 10000, (const uint8_t*)fbuf.data(), foff.data(), arms.size(), fw.data(), rv.data());
       if (rc != DG_OK) return fail_with(rc);
       for (size_t i = 0; i < arms.size(); ++i) R->arm_nbcount[arms[i].second] = (int64_t)(fw[i] + rv[i]);
+      lap("neighbourhood counts");
     }
   }
   R->n_arm_thal = 0;

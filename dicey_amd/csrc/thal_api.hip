@@ -1,6 +1,7 @@
 // dg_thal_open / dg_thal_batch: primer3's thermodynamic alignment for `dicey search`, one GPU lane per (oligo, target)
 // pair.  Replaces primer3thal::get_thermodynamic_values (reference src/silica.h:320-323, src/thal.h:2374-2397) and
 // primer3thal::thal() with type = thal_end1, temponly = 1 (src/silica.h:437,511; src/thal.h:2409-2655).
+#include <chrono>
 #include <cmath>
 #include <fstream>
 #include <sstream>
@@ -144,11 +145,11 @@ struct PairDesc {
 
 // One lane per pair, DP table in global memory: pairs too long for the wave kernel, or handed back by it (redo[t]).
 __global__ void k_thal(const thal::Tables* T, thal::Env env, const PairDesc* pd, u64 n, const u8* codes, double* dp, double* temp,
-                       int* end1, int* end2, const u8* redo) {
+                       int* end1, int* end2, const u8* redo, u32 only_redo) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const PairDesc d = pd[t];
-  if (d.pad && !redo[t]) return;
+  if (only_redo ? !redo[t] : d.pad != 0) return;  // first pass: pairs the wave kernel does not take; second: its hand-backs
   const u8* pa = codes + d.a_off;
   const u8* pb = codes + d.b_off;
   thal::Result r = thal::end1_tm<const u8*>(*T, env, pa, (int)d.len1, pb, (int)d.len2, d.symmetric != 0,
@@ -197,6 +198,71 @@ __global__ void __launch_bounds__(512) k_thal_wave(const thal::Tables* T, thal::
   }
 }
 
+// thal(window, reverse complement of the window) for windows of one byte buffer (`dicey padlock`: arms and probes against
+// their perfect complements, padlock.h:327-371).  Oligo 2 reversed is the complement in window order, so both code
+// sequences come from the same bytes: A/C/G/T -> (c, 3-c); 'U' is code 4 on the oligo and complements to 'A'
+// (util.h:64); anything else is 4 on both.
+struct WinDesc {
+  u64 off;
+  u32 len, pad;
+};
+__global__ void __launch_bounds__(512) k_thal_self_wave(const thal::Tables* T, thal::Env env, const WinDesc* wd, u64 n, const u8* bytes,
+                                                        double* temp, u8* redo, u32 lencap, u32 wave_bytes, u32 force_redo) {
+  DG_DYNAMIC_LDS(lds_raw);
+  thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
+  {
+    const u64* src = reinterpret_cast<const u64*>(T);
+    u64* dst = reinterpret_cast<u64*>(lds_raw);
+    for (u32 k = threadIdx.x; k < sizeof(thal::Tables) / 8; k += blockDim.x) dst[k] = src[k];
+  }
+  __syncthreads();
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const u32 lane = threadIdx.x & 63;
+  const thal::WaveMem wm =
+      thal::wave_mem_at(lds_raw + ((sizeof(thal::Tables) + 15) & ~(size_t)15) + (size_t)wave * wave_bytes, lencap, lencap);
+  for (u64 t = (u64)blockIdx.x * wpb + wave; t < n; t += (u64)gridDim.x * wpb) {
+    const WinDesc d = wd[t];
+    const u32 len = d.len;
+    u32 ca = 4, cb = 4;  // frame sentinels at positions 0 and len+1
+    if (lane >= 1 && lane <= len) {
+      const u8 ch = bytes[d.off + lane - 1];
+      ca = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+      cb = ca < 4 ? 3u - ca : (ch == 'U' ? 0u : 4u);
+    }
+    const bool in = lane <= len + 1;
+    thal::PlaneSeq fa, fb;
+    fa.b0 = __ballot(in && (ca & 1));
+    fa.b1 = __ballot(in && (ca & 2));
+    fa.b2 = __ballot(in && (ca & 4));
+    fb.b0 = __ballot(in && (cb & 1));
+    fb.b1 = __ballot(in && (cb & 2));
+    fb.b2 = __ballot(in && (cb & 4));
+    // symmetry_thermo (thal.h:1976-2010) of both oligos: the check is invariant under reversal, so cb stands for oligo 2
+    bool sym = !(len & 1);
+    if (sym) {
+      bool bad = false;
+      if (lane >= 1 && lane <= len / 2) {
+        const u32 x = ca, y = (u32)fa[(int)(len + 1 - lane)], u = cb, v = (u32)fb[(int)(len + 1 - lane)];
+        if ((x < 4 || y < 4) && (x > 3 || y > 3 || x + y != 3)) bad = true;
+        if ((u < 4 || v < 4) && (u > 3 || v > 3 || u + v != 3)) bad = true;
+      }
+      sym = __ballot(bad) == 0;
+    }
+    bool amb = false;
+    const thal::Result r = thal::wave_end1_tm(*tabs, env, fa, (int)len, fb, (int)len, sym, wm, (int)lencap, amb);
+    if (lane == 0) {
+      temp[t] = r.temp;
+      redo[t] = (amb || force_redo) ? 1 : 0;
+    }
+  }
+}
+
+static char complement_iupac_upper(char n) {  // util.h:54-91 on upper-case input
+  static const char* from = "ACGTURYSWKMBVDHN";
+  static const char* to = "TGCAAYRSWMKVBHDN";
+  const char* p = n ? std::strchr(from, n) : nullptr;
+  return p ? to[p - from] : 'N';
+}
 static u8 code_of(char c) {
   c = (char)std::toupper((unsigned char)c);
   return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;  // str2int, thal.h:260-275
@@ -265,6 +331,8 @@ void dg_thal_close(dg_thal* th) {
 int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t npairs, double* temp, int32_t* end1, int32_t* end2) {
   if (!th || !seqs || !off || !temp) return fail(DG_EINVAL, "dg_thal_batch: null argument");
   if (!npairs) return DG_OK;
+  static const bool timing = std::getenv("DICEY_DEBUG_TIMING") != nullptr;
+  auto t_start = std::chrono::steady_clock::now();
   std::vector<PairDesc> pd(npairs);
   u64 ncode = 0, ndp = 0;
   static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;       // debugging aids: sequential kernel only /
@@ -272,6 +340,12 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
   const u64 kWaveLenCap = 48;  // two 48 x 48 tables still fit a workgroup's LDS next to the parameter tables
   u32 wl1 = 0, wl2 = 0;
   u64 nwave = 0;
+  static u8 lut[256];
+  static bool lut_ready = false;
+  if (!lut_ready) {
+    for (int c = 0; c < 256; ++c) lut[c] = code_of((char)c);
+    lut_ready = true;
+  }
   for (size_t k = 0; k < npairs; ++k) {
     u64 l1 = off[2 * k + 1] - off[2 * k], l2 = off[2 * k + 2] - off[2 * k + 1];
     if (l1 > 10000 || l2 > 10000) return fail(DG_ELIMIT, "pair %zu: sequence longer than THAL_MAX_SEQ", k);
@@ -281,24 +355,29 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
     ncode += l1 + 2;
     pd[k].b_off = ncode;
     ncode += l2 + 2;
-    pd[k].dp_off = ndp;
-    bool both_long = l1 > (u64)thal::kMaxAlign && l2 > (u64)thal::kMaxAlign;
-    ndp += both_long ? 0 : 2 * l1 * l2;
     pd[k].symmetric = self_complementary(seqs + off[2 * k], l1) && self_complementary(seqs + off[2 * k + 1], l2);
     pd[k].pad = (!no_wave && l1 >= 1 && l2 >= 1 && l1 <= kWaveLenCap && l2 <= kWaveLenCap) ? 1 : 0;  // wave kernel takes it
+    pd[k].dp_off = ndp;  // the sequential kernel's table; hand-backs of the wave kernel get theirs in the second pass
+    const bool both_long = l1 > (u64)thal::kMaxAlign && l2 > (u64)thal::kMaxAlign;
+    if (!pd[k].pad) ndp += both_long ? 0 : 2 * l1 * l2;
     if (pd[k].pad) {
       wl1 = std::max<u32>(wl1, (u32)l1);
       wl2 = std::max<u32>(wl2, (u32)l2);
       ++nwave;
     }
   }
-  std::vector<u8> codes(ncode, 4);
+  std::vector<u8> codes(ncode);
   for (size_t k = 0; k < npairs; ++k) {
     const u8* s1 = seqs + off[2 * k];
     const u8* s2 = seqs + off[2 * k + 1];
-    for (u32 i = 0; i < pd[k].len1; ++i) codes[pd[k].a_off + 1 + i] = code_of((char)s1[i]);
-    for (u32 j = 0; j < pd[k].len2; ++j) codes[pd[k].b_off + 1 + j] = code_of((char)s2[pd[k].len2 - 1 - j]);  // reversed
+    u8* ca = codes.data() + pd[k].a_off;
+    u8* cb = codes.data() + pd[k].b_off;
+    const u32 l1 = pd[k].len1, l2 = pd[k].len2;
+    ca[0] = ca[l1 + 1] = cb[0] = cb[l2 + 1] = 4;
+    for (u32 i = 0; i < l1; ++i) ca[1 + i] = lut[s1[i]];
+    for (u32 j = 0; j < l2; ++j) cb[1 + j] = lut[s2[l2 - 1 - j]];  // reversed
   }
+  if (timing) std::fprintf(stderr, "dg_thal_batch: host prep %.1f ms for %zu pairs\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), npairs);
   DG_HIP(hipSetDevice(th->device));
   hipStream_t st = th->stream;
   DG_TRY(th->ws[0].reserve(npairs * sizeof(PairDesc)));
@@ -326,9 +405,29 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
                        th->ws[0].as<PairDesc>(), (u64)npairs, th->ws[1].as<u8>(), th->ws[3].as<double>(), e1, e2, th->ws[5].as<u8>(), wl1,
                        wl2, per_wave, force_redo ? 1u : 0u);
   }
-  hipLaunchKernelGGL(k_thal, dim3(ceil_div(npairs, 64)), dim3(64), 0, st, (const thal::Tables*)th->d_tables, th->env,
-                     th->ws[0].as<PairDesc>(), (u64)npairs, th->ws[1].as<u8>(), th->ws[2].as<double>(), th->ws[3].as<double>(), e1, e2,
-                     (const u8*)th->ws[5].as<u8>());
+  if (nwave < npairs)
+    hipLaunchKernelGGL(k_thal, dim3(ceil_div(npairs, 64)), dim3(64), 0, st, (const thal::Tables*)th->d_tables, th->env,
+                       th->ws[0].as<PairDesc>(), (u64)npairs, th->ws[1].as<u8>(), th->ws[2].as<double>(), th->ws[3].as<double>(), e1, e2,
+                       (const u8*)th->ws[5].as<u8>(), 0u);
+  std::vector<u8> redo(npairs, 0);
+  if (nwave) {  // pairs the wave kernel handed back go through the sequential kernel, with tables allocated only now
+    DG_HIP(hipMemcpyAsync(redo.data(), th->ws[5].p, npairs, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipStreamSynchronize(st));
+    u64 ndp2 = 0, nredo = 0;
+    for (size_t k = 0; k < npairs; ++k)
+      if (redo[k]) {
+        pd[k].dp_off = ndp2;
+        ndp2 += 2 * (u64)pd[k].len1 * pd[k].len2;
+        ++nredo;
+      }
+    if (nredo) {
+      DG_TRY(th->ws[2].reserve((ndp2 + 1) * 8));
+      DG_HIP(hipMemcpyAsync(th->ws[0].p, pd.data(), npairs * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_thal, dim3(ceil_div(npairs, 64)), dim3(64), 0, st, (const thal::Tables*)th->d_tables, th->env,
+                         th->ws[0].as<PairDesc>(), (u64)npairs, th->ws[1].as<u8>(), th->ws[2].as<double>(), th->ws[3].as<double>(), e1, e2,
+                         (const u8*)th->ws[5].as<u8>(), 1u);
+    }
+  }
   DG_HIP(hipMemcpyAsync(temp, th->ws[3].p, npairs * 8, hipMemcpyDeviceToHost, st));
   std::vector<int> h1(npairs), h2(npairs);
   DG_HIP(hipMemcpyAsync(h1.data(), e1, npairs * 4, hipMemcpyDeviceToHost, st));
@@ -343,3 +442,68 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
 }
 
 }  // extern "C"
+
+// thal(window, its reverse complement) for n windows of `bytes` (host), every window at most kSelfWindowMax nt: the pairs
+// are formed on the device (k_thal_self_wave).  Hand-backs of the wave kernel are recomputed through dg_thal_batch.
+int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, const uint64_t* win_off, const uint32_t* win_len, size_t n,
+                          double* temp) {
+  if (!n) return DG_OK;
+  static const bool force_redo = std::getenv("DICEY_DEBUG_THAL_REDO") != nullptr;
+  u32 maxlen = 0;
+  std::vector<WinDesc> wd(n);
+  for (size_t k = 0; k < n; ++k) {
+    if (win_len[k] == 0 || win_len[k] > kSelfWindowMax || win_off[k] + win_len[k] > nbytes) return fail(DG_EINVAL, "thal_self_windows: window %zu out of range", k);
+    wd[k].off = win_off[k];
+    wd[k].len = win_len[k];
+    wd[k].pad = 0;
+    maxlen = std::max(maxlen, win_len[k]);
+  }
+  static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential kernel only
+  std::vector<u8> redo(n, 1);
+  if (!no_wave) {
+    DG_HIP(hipSetDevice(th->device));
+    hipStream_t st = th->stream;
+    DG_TRY(th->ws[0].reserve(n * sizeof(WinDesc)));
+    DG_TRY(th->ws[1].reserve(nbytes + 8));
+    DG_TRY(th->ws[3].reserve(n * 8));
+    DG_TRY(th->ws[5].reserve(n + 8));
+    DG_HIP(hipMemcpyAsync(th->ws[0].p, wd.data(), n * sizeof(WinDesc), hipMemcpyHostToDevice, st));
+    DG_HIP(hipMemcpyAsync(th->ws[1].p, bytes, nbytes, hipMemcpyHostToDevice, st));
+    const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
+    const u32 per_wave = thal::wave_mem_bytes(maxlen, maxlen);
+    const u32 lds_cap = 160 * 1024;
+    const u32 wpb = std::max<u32>(1, std::min<u32>(8, (lds_cap - tab_bytes) / per_wave));
+    const u32 lds_total = tab_bytes + wpb * per_wave;
+    int cus = 0;
+    DG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, th->device));
+    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_thal_self_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+    const u64 blocks = std::min<u64>(ceil_div(n, wpb), (u64)cus * std::max<u32>(1, lds_cap / lds_total));
+    hipLaunchKernelGGL(k_thal_self_wave, dim3((u32)blocks), dim3(wpb * 64), lds_total, st, (const thal::Tables*)th->d_tables, th->env,
+                       th->ws[0].as<WinDesc>(), (u64)n, th->ws[1].as<u8>(), th->ws[3].as<double>(), th->ws[5].as<u8>(), maxlen, per_wave,
+                       force_redo ? 1u : 0u);
+    DG_HIP(hipMemcpyAsync(temp, th->ws[3].p, n * 8, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(redo.data(), th->ws[5].p, n, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipStreamSynchronize(st));
+    DG_HIP(hipGetLastError());
+  }
+  std::vector<size_t> again;
+  for (size_t k = 0; k < n; ++k)
+    if (redo[k]) again.push_back(k);
+  if (!again.empty()) {  // explicit pairs through the general entry point (whose wave kernel hands them to the sequential one)
+    std::string buf;
+    std::vector<uint64_t> off(1, 0);
+    for (size_t k : again) {
+      const uint8_t* w = bytes + win_off[k];
+      const uint32_t len = win_len[k];
+      buf.append((const char*)w, len);
+      off.push_back(buf.size());
+      for (uint32_t i = 0; i < len; ++i) buf.push_back(complement_iupac_upper((char)w[len - 1 - i]));
+      off.push_back(buf.size());
+    }
+    std::vector<double> t2(again.size());
+    int rc = dg_thal_batch(th, (const uint8_t*)buf.data(), off.data(), again.size(), t2.data(), nullptr, nullptr);
+    if (rc != DG_OK) return rc;
+    for (size_t i = 0; i < again.size(); ++i) temp[again[i]] = t2[i];
+  }
+  return DG_OK;
+}

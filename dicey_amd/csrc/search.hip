@@ -251,7 +251,7 @@ DG_DEV u32 wave_lead_rows(u32 mybyte, u32 g0, u32 mg, const u8* qseq, u32 n) {
 // persistent (the tables are staged once), wave w of the grid takes hits w, w + #waves, ...  Everything that depends
 // only on the hit is wave-uniform; hits whose Tm passes the cut are aligned by the same wavefront (silica.h:519-532).  Pairs the wave formulation cannot take (an oligo longer than the LDS table) or
 // hands back as ambiguous are marked pad = 1 and recomputed by k_site.
-__global__ void __launch_bounds__(512) k_site_wave(FmView f, Batch b, SiteArgs a, Counters* ctr) {
+__global__ void __launch_bounds__(1024) k_site_wave(FmView f, Batch b, SiteArgs a, Counters* ctr) {
   DG_DYNAMIC_LDS(lds_raw);
   thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
   {
@@ -402,7 +402,7 @@ int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSe
       const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
       const u32 per_wave = thal::wave_mem_bytes(sx->max_primer_len, wmax);
       const u32 lds_cap = 160 * 1024;
-      u32 wpb = std::min<u32>(8, (lds_cap - tab_bytes) / per_wave);
+      u32 wpb = std::min<u32>(16, (lds_cap - tab_bytes) / per_wave);
       const bool wave_path = !no_wave && !no_lds && sx->max_primer_len <= (u32)thal::kWaveMaxLen && wmax <= (u32)thal::kWaveMaxLen && wpb >= 2 && maxlen <= 63;
       if (wave_path) {
         const u32 lds_total = tab_bytes + wpb * per_wave;

@@ -160,7 +160,7 @@ __global__ void k_thal(const thal::Tables* T, thal::Env env, const PairDesc* pd,
 }
 
 // One wavefront per pair (thal_wave.hpp), persistent workgroups; pairs with pad == 1 only.
-__global__ void __launch_bounds__(512) k_thal_wave(const thal::Tables* T, thal::Env env, const PairDesc* pd, u64 n, const u8* codes,
+__global__ void __launch_bounds__(1024) k_thal_wave(const thal::Tables* T, thal::Env env, const PairDesc* pd, u64 n, const u8* codes,
                                                    double* temp, int* end1, int* end2, u8* redo, u32 len1cap, u32 stride, u32 wave_bytes,
                                                    u32 force_redo) {
   DG_DYNAMIC_LDS(lds_raw);
@@ -206,7 +206,7 @@ struct WinDesc {
   u64 off;
   u32 len, pad;
 };
-__global__ void __launch_bounds__(512) k_thal_self_wave(const thal::Tables* T, thal::Env env, const WinDesc* wd, u64 n, const u8* bytes,
+__global__ void __launch_bounds__(1024) k_thal_self_wave(const thal::Tables* T, thal::Env env, const WinDesc* wd, u64 n, const u8* bytes,
                                                         double* temp, u8* redo, u32 lencap, u32 wave_bytes, u32 force_redo) {
   DG_DYNAMIC_LDS(lds_raw);
   thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
@@ -395,7 +395,7 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
     const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
     const u32 per_wave = thal::wave_mem_bytes(wl1, wl2);
     const u32 lds_cap = 160 * 1024;
-    const u32 wpb = std::max<u32>(1, std::min<u32>(8, (lds_cap - tab_bytes) / per_wave));
+    const u32 wpb = std::max<u32>(1, std::min<u32>(16, (lds_cap - tab_bytes) / per_wave));
     const u32 lds_total = tab_bytes + wpb * per_wave;
     int cus = 0;
     DG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, th->device));
@@ -472,7 +472,7 @@ int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, co
     const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
     const u32 per_wave = thal::wave_mem_bytes(maxlen, maxlen);
     const u32 lds_cap = 160 * 1024;
-    const u32 wpb = std::max<u32>(1, std::min<u32>(8, (lds_cap - tab_bytes) / per_wave));
+    const u32 wpb = std::max<u32>(1, std::min<u32>(16, (lds_cap - tab_bytes) / per_wave));
     const u32 lds_total = tab_bytes + wpb * per_wave;
     int cus = 0;
     DG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, th->device));

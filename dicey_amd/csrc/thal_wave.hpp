@@ -15,6 +15,11 @@
 // value it touches (g < 8e5 for real ones, g > 9e5 for cutoff ones, placeholder exactly (0,-3224)) and reports
 // `ambiguous` otherwise; the caller then recomputes that pair with the sequential code of thal.hpp.
 //
+// Only cells whose two bases pair ever hold a value (every other cell is the constant (H=inf, S=-1) of initMatrix), and
+// pairing is a property of the sequences alone: the table in LDS stores just those cells, row after row; cell (i,j) sits
+// at rowstart[i] + (number of pairing columns of row i left of j), one popcount on the row's column mask.  That is about
+// a quarter of len1*len2 for mixed sequences; a pair with more pairing cells than the table holds is handed back.
+//
 // The traceback (thal.h:2133-2179) needs no second search: every cell records which of the reference's three tests
 // (left end, stacked pair, first matching opening) identifies its value, in the reference's order of testing.
 #pragma once
@@ -35,22 +40,28 @@ struct RowInfo {   // per column of the row being filled
   double pad;
 };
 struct WaveMem {  // LDS owned by one wavefront
-  RowInfo* row;          // [stride]
-  Cell* cells;           // len1 x stride
-  unsigned short* from;  // same indexing: kFromLeft / kFromStack / visiting key of the opening / kFromNone
-  unsigned char* tlist;  // [stride] columns of the current row that take openings
+  RowInfo* row;              // [stride]
+  Cell* cells;               // [cap] pairing cells, row after row
+  unsigned short* from;      // same indexing: kFromLeft / kFromStack / visiting key of the opening / kFromNone
+  unsigned short* rowstart;  // [len1 + 2] first slot of each row
+  unsigned char* tlist;      // [stride] columns of the current row that take openings
+  unsigned cap;
 };
 constexpr unsigned short kFromNone = 0, kFromLeft = 1, kFromStack = 2;  // opening keys are >= 3*64
 
+// slots for pairing cells: 7/16 of the full table (mixed sequences need about 1/4) plus one row
+DG_HD constexpr unsigned wave_cell_cap(unsigned len1, unsigned stride) { return (len1 * stride * 7u) / 16u + stride + 16u; }
 DG_HD constexpr unsigned wave_mem_bytes(unsigned len1, unsigned stride) {
-  return (stride * (unsigned)sizeof(RowInfo) + len1 * stride * ((unsigned)sizeof(Cell) + 2u) + stride + 15u) & ~15u;
+  return (stride * (unsigned)sizeof(RowInfo) + wave_cell_cap(len1, stride) * ((unsigned)sizeof(Cell) + 2u) + (len1 + 2u) * 2u + stride + 15u) & ~15u;
 }
 __device__ inline WaveMem wave_mem_at(unsigned char* base, unsigned len1, unsigned stride) {
   WaveMem m;
+  m.cap = wave_cell_cap(len1, stride);
   m.row = reinterpret_cast<RowInfo*>(base);
   m.cells = reinterpret_cast<Cell*>(base + stride * sizeof(RowInfo));
-  m.from = reinterpret_cast<unsigned short*>(m.cells + (size_t)len1 * stride);
-  m.tlist = reinterpret_cast<unsigned char*>(m.from + (size_t)len1 * stride);
+  m.from = reinterpret_cast<unsigned short*>(m.cells + m.cap);
+  m.rowstart = m.from + m.cap;
+  m.tlist = reinterpret_cast<unsigned char*>(m.rowstart + len1 + 2);
   return m;
 }
 
@@ -90,8 +101,8 @@ __device__ inline uint64_t wave_uniform(uint64_t x) {
 }
 __device__ inline uint64_t low_bits(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
 
-// a, b: framed code sequences (wave-uniform), oligo2 reversed; 1 <= len1, len2 <= kWaveMaxLen; m.cells has
-// len1*stride cells, stride >= len2.  Every lane returns the same Result.
+// a, b: framed code sequences (wave-uniform), oligo2 reversed; 1 <= len1, len2 <= kWaveMaxLen; m from
+// wave_mem_at(.., >= len1, stride >= len2).  Every lane returns the same Result.
 template <class SeqT>
 __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const SeqT& a, int len1, const SeqT& b, int len2,
                                       bool both_symmetric, const WaveMem& m, int stride, bool& ambiguous) {
@@ -107,7 +118,7 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
   p.len1 = len1;
   p.len2 = len2;
   p.rc = both_symmetric ? env.rc_sym : env.rc_asym;
-  p.C = m.cells;
+  p.C = nullptr;  // cells are addressed through slot() below
   p.row = stride;
   p.cs = 1;
   bool amb = false;
@@ -118,9 +129,21 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
   uint64_t pm[4];
   for (int c = 0; c < 4; ++c) pm[c] = __ballot(myb == 3 - c);
   const int j = lane + 1;  // the column this lane owns in the per-row pass
+  const Cell kNoPair = {kInf, -1.0};  // what initMatrix leaves in a cell whose bases do not pair (thal.h:820-835)
+  auto row_mask = [&](int code) -> uint64_t { return code == 0 ? pm[0] : code == 1 ? pm[1] : code == 2 ? pm[2] : code == 3 ? pm[3] : 0; };
+  unsigned rowbase = 0, prevbase = 0;  // first slot of row i / of row i-1
+  uint64_t prevmask = 0;
   for (int i = 1; i <= len1; ++i) {
     DG_PROF_T(tA0);
     const int ai = a[i];
+    const uint64_t imask = row_mask(ai);
+    if (rowbase + (unsigned)__popcll(imask) > m.cap) {  // more pairing cells than the table holds: not for this kernel
+      ambiguous = true;
+      r.temp = 0.0;
+      return r;
+    }
+    if (lane == 0) m.rowstart[i] = (unsigned short)rowbase;
+    const unsigned myslot = rowbase + (unsigned)__popcll(imask & low_bits(lane));  // slot of (i, j) when it pairs
     const bool mine = lane < len2 && pairs(ai, myb);
     bool takes = false;
     // ---- per-row pass: left end, stack extension, right end (thal.h:1507-1519) ----
@@ -140,7 +163,8 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
         if (i > 1 && j > 1) {
           double rS, rH;
           right_end(p, i, j, rS, rH);
-          const Cell diag = p.cell(i - 1, j - 1);
+          const bool dpair = (prevmask >> (j - 2)) & 1;
+          const Cell diag = dpair ? m.cells[prevbase + (unsigned)__popcll(prevmask & low_bits(j - 2))] : kNoPair;
           double nS, nH;
           stack_pick(p, i, j, curS, curH, diag, rS, rH, nS, nH);
           curS = nS;
@@ -164,11 +188,13 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
         if (curS == eS && curH == eH) fr = kFromLeft;
         else if (i > 1 && j > 1 && curS == kS && curH == kH) fr = kFromStack;
       }
-      Cell c;
-      c.h = curH;
-      c.s = curS;
-      p.cell(i, j) = c;
-      m.from[(j - 1) + (i - 1) * stride] = fr;
+      if (mine) {
+        Cell c;
+        c.h = curH;
+        c.s = curS;
+        m.cells[myslot] = c;
+        m.from[myslot] = fr;
+      }
     }
     const uint64_t tm = __ballot(takes);
     if (takes) m.tlist[__popcll(tm & low_bits(lane))] = (unsigned char)j;
@@ -176,6 +202,10 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
     DG_PROF_T(tA1);
     DG_PROF_ADD(0, tA0, tA1);
     const int P = __popcll(tm);
+    const unsigned thisbase = rowbase;
+    prevbase = rowbase;
+    prevmask = imask;
+    rowbase += (unsigned)__popcll(imask);
     if (P == 0) continue;
     // ---- openings: groups of R lanes (one per opening row ii) serve one target column each ----
     const int n1 = i - 1 < kMaxLoop + 1 ? i - 1 : kMaxLoop + 1;  // l1 = i-ii-1 <= 30
@@ -184,7 +214,8 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
     const int R = 1 << lg, G = 64 >> lg;
     const int rr = lane & (R - 1), ii = i - 1 - rr;
     const int ca = rr < n1 ? a[ii] : 4;
-    const uint64_t rowmask = ca == 0 ? pm[0] : ca == 1 ? pm[1] : ca == 2 ? pm[2] : ca == 3 ? pm[3] : 0;
+    const uint64_t rowmask = row_mask(ca);
+    const unsigned obase = rr < n1 ? m.rowstart[ii] : 0;  // first slot of the opening row this lane serves
     const int l1 = rr;
     for (int t0 = 0; t0 < P; t0 += G) {
       DG_PROF_T(tB0);
@@ -212,7 +243,7 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
         while (mask) {
           const int jj = __builtin_ctzll(mask) + 1;
           mask &= mask - 1;
-          const Cell open = p.cell(ii, jj);
+          const Cell open = m.cells[obase + (unsigned)__popcll(rowmask & low_bits(jj - 1))];
           const int bo = b[jj], bo1 = b[jj + 1];
           const int l2 = tj - jj - 1, ls = l1 + l2 - 1;
           const bool bulge = (l1 == 0) != (l2 == 0);
@@ -280,7 +311,7 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
         }
       }
       if (bestKey != ~0u && bestKey == grpKey && grpG < G2) {  // the walk's final value for (i,tj)
-        const int at = (tj - 1) + (i - 1) * stride;
+        const unsigned at = thisbase + (unsigned)__popcll(imask & low_bits(tj - 1));
         const RowInfo ri = m.row[tj - 1];
         unsigned short fr = (unsigned short)bestKey;  // the traceback's tests, in its order, applied to the new value
         if (bestS == ri.eS && bestH == ri.eH) fr = kFromLeft;
@@ -306,7 +337,7 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
     right_end(p, len1, j, rS, rH);
     rS = rS + 0.000001;
     rH = rH + 0.000001;
-    const Cell c = p.cell(len1, j);
+    const Cell c = ((prevmask >> lane) & 1) ? m.cells[prevbase + (unsigned)__popcll(prevmask & low_bits(lane))] : kNoPair;  // row len1
     myG = (c.h + rH + kInitH) - kT * (c.s + rS + kInitS);
   }
   double bestG = myG;
@@ -325,7 +356,14 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
   if (!fin(bestG)) bestI = bestJ = 1;
   double rS, rH;
   right_end(p, bestI, bestJ, rS, rH);
-  const Cell top = p.cell(bestI, bestJ);
+  auto slot = [&](int ci, int cj, bool& there) -> unsigned {  // wave-uniform lookup of an arbitrary cell
+    const uint64_t mk = row_mask(a[ci]);
+    there = (mk >> (cj - 1)) & 1;
+    return (unsigned)m.rowstart[ci] + (unsigned)__popcll(mk & low_bits(cj - 1));
+  };
+  bool top_there;
+  const unsigned top_at = slot(bestI, bestJ, top_there);
+  const Cell top = top_there ? m.cells[top_at] : kNoPair;
   const double dH = top.h + rH + kInitH;
   const double dS = top.s + rS + kInitS;
   if (!fin(top.h)) {
@@ -335,7 +373,9 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
   // traceback: follow the recorded tests, counting base pairs
   int ti = bestI, tj = bestJ, npairs = 1;
   for (;;) {
-    const unsigned fr = m.from[(tj - 1) + (ti - 1) * stride];
+    bool there;
+    const unsigned at = slot(ti, tj, there);
+    const unsigned fr = there ? m.from[at] : kFromNone;
     if (fr == kFromLeft || fr == kFromNone) break;
     if (fr == kFromStack) {
       --ti;

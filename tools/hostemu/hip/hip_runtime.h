@@ -51,8 +51,11 @@ inline unsigned long long __ballot(int) { emu_no_collectives("__ballot"); }
 template <class T> inline T __shfl(T, int) { emu_no_collectives("__shfl"); }
 template <class T> inline T __shfl_xor(T, int) { emu_no_collectives("__shfl_xor"); }
 template <class T> inline T __shfl_up(T, int) { emu_no_collectives("__shfl_up"); }
+template <class T> inline T __shfl_down(T, int) { emu_no_collectives("__shfl_down"); }
 inline int __syncthreads_or(int) { emu_no_collectives("__syncthreads_or"); }
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned x) { return x; }
+inline int __builtin_amdgcn_readlane(int x, int) { return x; }
+inline int __builtin_amdgcn_mov_dpp(int, int, int, int, bool) { emu_no_collectives("mov_dpp"); }
 inline void __builtin_amdgcn_wave_barrier() {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 

@@ -548,14 +548,16 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
     DG_HIP(hipMemcpyAsync(win.data(), sx.d_windows, nhits * (u64)sx.win_stride, hipMemcpyDeviceToHost, st));
   }
   DG_HIP(hipStreamSynchronize(st));
-  if (const char* dump = std::getenv("DICEY_DEBUG_DUMP_RAW")) {  // TEMP debugging aid
-    FILE* fp = fopen(dump, "wb");
-    fwrite(raw.data(), sizeof(SiteRaw), nhits, fp);
-    fclose(fp);
-    std::string wp = std::string(dump) + ".win";
-    fp = fopen(wp.c_str(), "wb");
-    fwrite(win.data(), sx.win_stride, nhits, fp);
-    fclose(fp);
+  if (const char* dump = std::getenv("DICEY_DEBUG_DUMP_RAW")) {  // debugging aid: per-hit records for tools/diff_raw.py
+    if (FILE* fp = std::fopen(dump, "wb")) {
+      std::fwrite(raw.data(), sizeof(SiteRaw), nhits, fp);
+      std::fclose(fp);
+    }
+    const std::string wp = std::string(dump) + ".win";
+    if (FILE* fp = std::fopen(wp.c_str(), "wb")) {
+      std::fwrite(win.data(), sx.win_stride, nhits, fp);
+      std::fclose(fp);
+    }
   }
   // Tm of every primer against its perfect complement (silica.h:431-443)
   std::vector<u8> pairs;

@@ -1114,7 +1114,62 @@ static u64 neighbourhood_bound(u32 m, u32 d, bool indel) {
   return ~0ULL;
 }
 
+// Two-launch scan for the production path: tiles of 1024 entries (256 lanes x 4); k_scan_tile_sums writes one sum per
+// tile, k_scan_tiles adds up the sums of the tiles before its own (a few hundred values) and scans its tile in place.
+constexpr u32 SCAN_TILE = 1024;
+DG_DEV u64 block_sum_256(u64 v, u64* lds4) {  // sum over a 256-lane workgroup, result in every lane
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const u64 r = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return r;
+}
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const u32* in, u64 n, u64* sums) {
+  __shared__ u64 lds4[4];
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  u64 s = 0;
+  for (u32 k = 0; k < 4; ++k)
+    if (base + k < n) s += in[base + k];
+  s = block_sum_256(s, lds4);
+  if (threadIdx.x == 0) sums[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_scan_tiles(const u32* in, u64 n, const u64* sums, u64* out /*[n+1]*/) {
+  __shared__ u64 lds4[4];
+  u64 before = 0;  // entries of all earlier tiles
+  for (u32 k = threadIdx.x; k < blockIdx.x; k += 256) before += sums[k];
+  before = block_sum_256(before, lds4);
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  u32 v[4];
+  u64 mine = 0;
+  for (u32 k = 0; k < 4; ++k) {
+    v[k] = base + k < n ? in[base + k] : 0u;
+    mine += v[k];
+  }
+  u64 incl = mine;  // inclusive scan of the lane totals: inside the wavefront by shuffles, across the four through LDS
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const u64 o = __shfl_up(incl, off);
+    if ((int)lane >= off) incl += o;
+  }
+  if (lane == 63) lds4[wave] = incl;
+  __syncthreads();
+  u64 run = before + incl - mine;
+  for (u32 w = 0; w < wave; ++w) run += lds4[w];
+  for (u32 k = 0; k < 4; ++k) {
+    if (base + k <= n) out[base + k] = run;  // index n receives the total
+    run += v[k];
+  }
+}
+
 static int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* tmp) {
+  static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
+  if (!lane_only && n <= ((u64)1 << 24)) {
+    const u32 tiles = (u32)((n + SCAN_TILE) / SCAN_TILE);  // covers index n as well
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(256), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, in, n, (const u64*)tmp, out);
+    return DG_OK;
+  }
   const u64 n1 = (n + SCAN_CHUNK - 1) / SCAN_CHUNK, n2 = (n1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
   u64* p1 = tmp;
   u64* p2 = tmp + n1;

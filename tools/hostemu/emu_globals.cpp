@@ -7,6 +7,9 @@ thread_local dim3 blockDim, gridDim;
 // Wave-cooperative kernels cannot run with serial lanes: make the library choose its lane-per-item kernels.
 namespace {
 struct EmuEnv {
-  EmuEnv() { setenv("DICEY_NO_WAVE_THAL", "1", 0); }
+  EmuEnv() {
+    setenv("DICEY_NO_WAVE_THAL", "1", 0);
+    setenv("DICEY_NO_BLOCK_SCAN", "1", 0);
+  }
 } emu_env;
 }  // namespace

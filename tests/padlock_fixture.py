@@ -24,6 +24,10 @@ CASES = [
     ("transcript", ["-u", "transcript_id"], "ENSG02T1", dict(genes=["ENSG02T1"], idname="transcript_id")),
     ("fasta_input", [], "@custom.fa", dict(input_fasta=True)),
     ("fasta_input_absent", ["-e"], "@custom.fa", dict(input_fasta=True, absent=True)),
+    ("arm26_general_thal_path", ["-m", "26", "-d", "1", "-n", "-z", "6", "--gcmin", "0.3", "--gcmax", "0.7"], "ENSG03",
+     dict(genes=["ENSG03"], armlen=26, hamming=True, tmdiff=6, gcmin=0.3, gcmax=0.7)),
+    ("arm31_thal_refuses", ["-m", "31", "-n", "--gcmin", "0.2", "--gcmax", "0.8", "-z", "20"], "ENSG03",
+     dict(genes=["ENSG03"], armlen=31, hamming=True, gcmin=0.2, gcmax=0.8, tmdiff=20)),
     ("salt", ["--monovalent", "40", "--divalent", "2.5", "--dna", "100", "--dntp", "0.8"], "ENSG01",
      dict(genes=["ENSG01"], mv=40.0, dv=2.5, dna_conc=100.0, dntp=0.8)),
 ]

@@ -36,7 +36,7 @@ def test_golden_rows_respect_the_filters():
     comp = str.maketrans("ACGT", "TGCA")
     for label, g in GOLD.items():
         if g["rc"]:
-            assert g["rows"] == 0 and "rows" not in g["json"]
+            assert g["rows"] == 0 and not g["json"].rstrip().endswith("]}}")   # nothing, or a header cut short by the error exit
             continue
         lines = g["tsv"].rstrip("\n").split("\n")
         assert lines[0].startswith("Gene\tSymbol\tCode\tPosition")

@@ -368,7 +368,18 @@ int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSe
       const u32 wmax = sx->max_primer_len + 3 * dmax_eff + 2;  // k + overhang + context on both sides + edits
       const u32 wstride = (wmax + 15) & ~15u;
       const u64 dp_stride = (u64)sx->max_primer_len * wmax;
-      const u64 chunk = std::max<u64>(4096, std::min<u64>(hit_cap, ((u64)6 << 30) / (2 * dp_stride * 8 + 1)));
+      static const bool no_lds = std::getenv("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
+      static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential thal only
+      // wave-per-hit path: LDS holds the tables once per workgroup and one DP table per wavefront
+      const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
+      const u32 per_wave = thal::wave_mem_bytes(sx->max_primer_len, wmax);
+      const u32 lds_cap = 160 * 1024;
+      u32 wpb = std::min<u32>(16, (lds_cap - tab_bytes) / per_wave);
+      const bool wave_path = !no_wave && !no_lds && sx->max_primer_len <= (u32)thal::kWaveMaxLen && wmax <= (u32)thal::kWaveMaxLen && wpb >= 2 && maxlen <= 63;
+      // DP tables of the sequential kernel live in HBM, one launch per chunk of hits: 6 GB when it does all the work,
+      // 1 GB when it only sees what the wave kernel hands back
+      const u64 dp_budget = wave_path ? ((u64)1 << 30) : ((u64)6 << 30);
+      const u64 chunk = std::max<u64>(4096, std::min<u64>(hit_cap, dp_budget / (2 * dp_stride * 8 + 1)));
       DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(SiteRaw)));
       DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * (u64)wstride));
       DG_TRY(ws[WS_DP].reserve(((chunk + 63) & ~(u64)63) * 2 * dp_stride * 8 + 64));
@@ -396,14 +407,6 @@ int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSe
       static const bool force_redo = std::getenv("DICEY_DEBUG_THAL_REDO") != nullptr;
       sa.force_redo = force_redo ? 1 : 0;
       const u32 cells = (wmax + 1) * (maxlen + 1);
-      static const bool no_lds = std::getenv("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
-      static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential thal only
-      // wave-per-hit path: LDS holds the tables once per workgroup and one DP table per wavefront
-      const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
-      const u32 per_wave = thal::wave_mem_bytes(sx->max_primer_len, wmax);
-      const u32 lds_cap = 160 * 1024;
-      u32 wpb = std::min<u32>(16, (lds_cap - tab_bytes) / per_wave);
-      const bool wave_path = !no_wave && !no_lds && sx->max_primer_len <= (u32)thal::kWaveMaxLen && wmax <= (u32)thal::kWaveMaxLen && wpb >= 2 && maxlen <= 63;
       if (wave_path) {
         const u32 lds_total = tab_bytes + wpb * per_wave;
         static int cus = 0;

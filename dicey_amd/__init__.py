@@ -76,6 +76,15 @@ class FmIndex:
         flags = (0 if selfcheck else _capi.DG_OPEN_NO_SELFCHECK) | (0 if kmer_table else _capi.DG_OPEN_NO_KMER_TABLE)
         _capi.check(self._L, self._L.dg_index_open(fm9_path.encode(), device, flags, C.byref(self._h)))
 
+    def share(self) -> "FmIndex":
+        """A second handle on the same resident index (own stream and workspaces) for a concurrent host thread; close it
+        before this one."""
+        other = FmIndex.__new__(FmIndex)
+        other._L = self._L
+        other._h = C.c_void_p()
+        _capi.check(self._L, self._L.dg_index_share(self._h, C.byref(other._h)))
+        return other
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._L.dg_index_close(self._h)

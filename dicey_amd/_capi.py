@@ -83,7 +83,7 @@ SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_
            "dg_extract", "dg_hunt", "dg_hunt_result_free", "dg_hunt_device", "dg_index_build",
            "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
            "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
-           "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free"]
+           "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free", "dg_index_share"]
 
 _lib = None
 
@@ -97,10 +97,17 @@ def load(path=None):
     if not os.path.exists(p):
         raise ImportError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). dicey_amd has no CPU fallback.")
+    import sys
+    if "torch" in sys.modules:  # torch ships its own HIP runtime, which only finds the GPU if it initialises first
+        try:
+            sys.modules["torch"].cuda.is_available()
+        except Exception:
+            pass
     L = C.CDLL(p)
     vp, u64p, u8p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
     L.dg_last_error.restype = C.c_char_p
     L.dg_index_open.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(vp)]
+    L.dg_index_share.argtypes = [vp, C.POINTER(vp)]
     L.dg_index_close.argtypes = [vp]
     L.dg_index_close.restype = None
     L.dg_index_stats.argtypes = [vp, C.POINTER(IndexStats)]

@@ -391,6 +391,27 @@ int dg_index_open(const char* fm9_path, int device, uint32_t flags, dg_index** o
   return DG_OK;
 }
 
+int dg_index_share(dg_index* src, dg_index** out) {
+  if (!src || !out) return fail(DG_EINVAL, "dg_index_share: null argument");
+  *out = nullptr;
+  DG_HIP(hipSetDevice(src->device));
+  dg_index* ix = new dg_index;
+  ix->device = src->device;
+  ix->view = src->view;  // the index arrays stay owned by `src`
+  ix->sigma = src->sigma;
+  std::memcpy(ix->code_len, src->code_len, sizeof ix->code_len);
+  ix->file_bytes = src->file_bytes;
+  ix->hbm_bytes = 0;
+  ix->shard_cap_hint = src->shard_cap_hint;
+  ix->hit_cap_hint = src->hit_cap_hint;
+  if (hipStreamCreate(&ix->stream) != hipSuccess) {
+    delete ix;
+    return fail(DG_EHIP, "dg_index_share: cannot create a stream");
+  }
+  *out = ix;
+  return DG_OK;
+}
+
 void dg_index_close(dg_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);

@@ -55,6 +55,10 @@ typedef struct dg_index dg_index;
  * HBM on `device`, and derives the search layouts there (Occ blocks, full suffix array, text copy). */
 int dg_index_open(const char* fm9_path, int device, uint32_t flags, dg_index** out);
 void dg_index_close(dg_index* ix);
+/* A second handle on the SAME device-resident index with its own HIP stream and batch workspaces, so that another host
+ * thread can run batches concurrently (the small tail kernels of one batch overlap with the search kernel of the other).
+ * No index data is copied.  Close every shared handle before the handle it was taken from. */
+int dg_index_share(dg_index* src, dg_index** out);
 
 typedef struct {
   uint64_t n;              /* fm_index.size(): text length + 1 (sentinel) */

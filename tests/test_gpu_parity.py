@@ -5,6 +5,12 @@ import zlib
 
 import pytest
 
+try:  # torch bundles its own HIP runtime: it only finds the GPU if it initialises before libdiceygpu's (system) runtime does
+    import torch
+    torch.cuda.is_available()
+except Exception:  # pragma: no cover
+    torch = None
+
 import oracle_lib as O
 from conftest import genome_text, make_genome, make_queries
 
@@ -244,3 +250,27 @@ def test_every_search_mode_gives_the_same_hits(small_genome, monkeypatch, mode):
         _compare(ix, orc, small_genome, qs, distance=1)
         _compare(ix, orc, small_genome, qs[:120], distance=1, hamming=True)
         _compare(ix, orc, small_genome, [q[:12] for q in qs[:12]], distance=2)
+
+
+def test_shared_handles_run_concurrently_and_agree(small_genome):
+    """dg_index_share: two host threads, each with its own handle (stream + workspaces) on one resident index."""
+    import threading
+    import dicey_amd
+    sc = small_genome
+    qs = make_queries(9, sc["text"], 400, (20,))
+    with dicey_amd.FmIndex(sc["fm9"]) as ix:
+        want = ix.hunt(qs, sc["seqlen"])
+        other = ix.share()
+        got = [None, None]
+
+        def run(k, h):
+            for _ in range(5):
+                got[k] = h.hunt(qs, sc["seqlen"])
+        ths = [threading.Thread(target=run, args=(0, ix)), threading.Thread(target=run, args=(1, other))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        key = lambda R: [[(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in q.hits] for q in R.queries]
+        assert key(got[0]) == key(want) and key(got[1]) == key(want)
+        other.close()

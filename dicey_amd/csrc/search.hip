@@ -254,16 +254,12 @@ DG_DEV u32 wave_lead_rows(u32 mybyte, u32 g0, u32 mg, const u8* qseq, u32 n) {
 __global__ void __launch_bounds__(1024) k_site_wave(FmView f, Batch b, SiteArgs a, Counters* ctr) {
   DG_DYNAMIC_LDS(lds_raw);
   thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
-  {
-    const u64* src = reinterpret_cast<const u64*>(a.tables);
-    u64* dst = reinterpret_cast<u64*>(lds_raw);
-    for (u32 k = threadIdx.x; k < sizeof(thal::Tables) / 8; k += blockDim.x) dst[k] = src[k];
-  }
-  __syncthreads();
+  thal::wave_header_init(lds_raw, a.tables, a.env);
+  const thal::EndTables& ends = *thal::wave_end_tables(lds_raw);
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const u32 lane = threadIdx.x & 63;
   const thal::WaveMem wm =
-      thal::wave_mem_at(lds_raw + ((sizeof(thal::Tables) + 15) & ~(size_t)15) + (size_t)wave * a.wave_bytes, a.wave_len1, a.wave_stride);
+      thal::wave_mem_at(lds_raw + thal::wave_header_bytes() + (size_t)wave * a.wave_bytes, a.wave_len1, a.wave_stride);
   const u64 nh = *a.nhits;
   if (ctr->overflow || nh > a.hit_cap) return;
   for (u64 h = (u64)blockIdx.x * wpb + wave; h < nh; h += (u64)gridDim.x * wpb) {
@@ -346,7 +342,7 @@ __global__ void __launch_bounds__(1024) k_site_wave(FmView f, Batch b, SiteArgs 
         sym = __ballot(bad) == 0;
       }
       bool amb = false;
-      const thal::Result tr = thal::wave_end1_tm(*tabs, a.env, fa, (int)plen, fb, (int)mg, sym, wm, (int)a.wave_stride, amb);
+      const thal::Result tr = thal::wave_end1_tm(*tabs, ends, a.env, fa, (int)plen, fb, (int)mg, sym, wm, (int)a.wave_stride, amb);
       r.temp = tr.temp;
       if (amb || a.force_redo) r.pad = 1;
       else if (r.temp > a.cut_temp)  // silica.h:519-532
@@ -371,7 +367,7 @@ int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSe
       static const bool no_lds = std::getenv("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
       static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential thal only
       // wave-per-hit path: LDS holds the tables once per workgroup and one DP table per wavefront
-      const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
+      const u32 tab_bytes = thal::wave_header_bytes();
       const u32 per_wave = thal::wave_mem_bytes(sx->max_primer_len, wmax);
       const u32 lds_cap = 160 * 1024;
       u32 wpb = std::min<u32>(16, (lds_cap - tab_bytes) / per_wave);

@@ -165,16 +165,12 @@ __global__ void __launch_bounds__(1024) k_thal_wave(const thal::Tables* T, thal:
                                                    u32 force_redo) {
   DG_DYNAMIC_LDS(lds_raw);
   thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
-  {
-    const u64* src = reinterpret_cast<const u64*>(T);
-    u64* dst = reinterpret_cast<u64*>(lds_raw);
-    for (u32 k = threadIdx.x; k < sizeof(thal::Tables) / 8; k += blockDim.x) dst[k] = src[k];
-  }
-  __syncthreads();
+  thal::wave_header_init(lds_raw, T, env);
+  const thal::EndTables& ends = *thal::wave_end_tables(lds_raw);
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const u32 lane = threadIdx.x & 63;
   const thal::WaveMem wm =
-      thal::wave_mem_at(lds_raw + ((sizeof(thal::Tables) + 15) & ~(size_t)15) + (size_t)wave * wave_bytes, len1cap, stride);
+      thal::wave_mem_at(lds_raw + thal::wave_header_bytes() + (size_t)wave * wave_bytes, len1cap, stride);
   for (u64 t = (u64)blockIdx.x * wpb + wave; t < n; t += (u64)gridDim.x * wpb) {
     const PairDesc d = pd[t];
     if (!d.pad) continue;
@@ -188,7 +184,7 @@ __global__ void __launch_bounds__(1024) k_thal_wave(const thal::Tables* T, thal:
     fb.b1 = __ballot(cb & 2);
     fb.b2 = __ballot(cb & 4);
     bool amb = false;
-    const thal::Result r = thal::wave_end1_tm(*tabs, env, fa, (int)d.len1, fb, (int)d.len2, d.symmetric != 0, wm, (int)stride, amb);
+    const thal::Result r = thal::wave_end1_tm(*tabs, ends, env, fa, (int)d.len1, fb, (int)d.len2, d.symmetric != 0, wm, (int)stride, amb);
     if (lane == 0) {
       temp[t] = r.temp;
       end1[t] = r.end1;
@@ -210,16 +206,12 @@ __global__ void __launch_bounds__(1024) k_thal_self_wave(const thal::Tables* T, 
                                                         double* temp, u8* redo, u32 lencap, u32 wave_bytes, u32 force_redo) {
   DG_DYNAMIC_LDS(lds_raw);
   thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
-  {
-    const u64* src = reinterpret_cast<const u64*>(T);
-    u64* dst = reinterpret_cast<u64*>(lds_raw);
-    for (u32 k = threadIdx.x; k < sizeof(thal::Tables) / 8; k += blockDim.x) dst[k] = src[k];
-  }
-  __syncthreads();
+  thal::wave_header_init(lds_raw, T, env);
+  const thal::EndTables& ends = *thal::wave_end_tables(lds_raw);
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const u32 lane = threadIdx.x & 63;
   const thal::WaveMem wm =
-      thal::wave_mem_at(lds_raw + ((sizeof(thal::Tables) + 15) & ~(size_t)15) + (size_t)wave * wave_bytes, lencap, lencap);
+      thal::wave_mem_at(lds_raw + thal::wave_header_bytes() + (size_t)wave * wave_bytes, lencap, lencap);
   for (u64 t = (u64)blockIdx.x * wpb + wave; t < n; t += (u64)gridDim.x * wpb) {
     const WinDesc d = wd[t];
     const u32 len = d.len;
@@ -249,7 +241,7 @@ __global__ void __launch_bounds__(1024) k_thal_self_wave(const thal::Tables* T, 
       sym = __ballot(bad) == 0;
     }
     bool amb = false;
-    const thal::Result r = thal::wave_end1_tm(*tabs, env, fa, (int)len, fb, (int)len, sym, wm, (int)lencap, amb);
+    const thal::Result r = thal::wave_end1_tm(*tabs, ends, env, fa, (int)len, fb, (int)len, sym, wm, (int)lencap, amb);
     if (lane == 0) {
       temp[t] = r.temp;
       redo[t] = (amb || force_redo) ? 1 : 0;
@@ -392,7 +384,7 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
   DG_TRY(th->ws[5].reserve(npairs + 8));
   DG_HIP(hipMemsetAsync(th->ws[5].p, 0, npairs, st));
   if (nwave) {
-    const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
+    const u32 tab_bytes = thal::wave_header_bytes();
     const u32 per_wave = thal::wave_mem_bytes(wl1, wl2);
     const u32 lds_cap = 160 * 1024;
     const u32 wpb = std::max<u32>(1, std::min<u32>(16, (lds_cap - tab_bytes) / per_wave));
@@ -469,7 +461,7 @@ int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, co
     DG_TRY(th->ws[5].reserve(n + 8));
     DG_HIP(hipMemcpyAsync(th->ws[0].p, wd.data(), n * sizeof(WinDesc), hipMemcpyHostToDevice, st));
     DG_HIP(hipMemcpyAsync(th->ws[1].p, bytes, nbytes, hipMemcpyHostToDevice, st));
-    const u32 tab_bytes = (u32)((sizeof(thal::Tables) + 15) & ~(size_t)15);
+    const u32 tab_bytes = thal::wave_header_bytes();
     const u32 per_wave = thal::wave_mem_bytes(maxlen, maxlen);
     const u32 lds_cap = 160 * 1024;
     const u32 wpb = std::max<u32>(1, std::min<u32>(16, (lds_cap - tab_bytes) / per_wave));

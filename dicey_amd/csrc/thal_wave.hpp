@@ -77,6 +77,65 @@ static_assert(DG_TOFF(interiorH) - DG_TOFF(interiorS) == 30 && DG_TOFF(bulgeH) -
 static_assert(DG_TOFF(atpH) - DG_TOFF(atpS) == 25, "atp: H follows S");
 constexpr int kTwin4 = 625, kTwinLoop = 30, kTwinAtp = 25;
 
+// Left and right duplex ends (thal.h:853-1076) only look at the closing pair and its two outer neighbours: with x pairing
+// y = 3-x that is 4 x 5 x 5 cases per end and per RC value (both oligos self-complementary or not).  A workgroup works
+// them out once with the functions of thal.hpp — same arithmetic, same bits — and the row pass reads them back.
+struct EndTables {
+  Cell L[2][4][5][5];  // [symmetric][x][a[i-1]][b[j-1]]  -> (eS, eH) of left_end
+  Cell R[2][4][5][5];  // [symmetric][x][a[i+1]][b[j+1]]  -> (rS, rH) of right_end
+};
+DG_HD constexpr unsigned wave_header_bytes() {  // parameter tables + end tables at the start of a workgroup's LDS
+  return (((unsigned)sizeof(Tables) + 15u) & ~15u) + (((unsigned)sizeof(EndTables) + 15u) & ~15u);
+}
+__device__ inline const EndTables* wave_end_tables(const unsigned char* lds) {
+  return reinterpret_cast<const EndTables*>(lds + (((unsigned)sizeof(Tables) + 15u) & ~15u));
+}
+// every thread of the workgroup calls this once; ends with a barrier
+__device__ inline void wave_header_init(unsigned char* lds, const Tables* global_tables, const Env& env) {
+  {
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(global_tables);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(lds);
+    for (unsigned k = threadIdx.x; k < sizeof(Tables) / 8; k += blockDim.x) dst[k] = src[k];
+  }
+  __syncthreads();
+  const Tables& T = *reinterpret_cast<const Tables*>(lds);
+  EndTables* E = reinterpret_cast<EndTables*>(lds + (((unsigned)sizeof(Tables) + 15u) & ~15u));
+  for (unsigned k = threadIdx.x; k < 400; k += blockDim.x) {
+    const unsigned right = k / 200, sym = (k / 100) & 1, x = (k / 25) & 3, n1 = (k / 5) % 5, n2 = k % 5;
+    uint8_t aa[2], bb[2];
+    ProblemT<const uint8_t*> p;
+    p.T = &T;
+    p.len1 = p.len2 = 1;
+    p.rc = sym ? env.rc_sym : env.rc_asym;
+    p.C = nullptr;
+    p.row = 1;
+    p.cs = 1;
+    double S = -1.0, H = kInf;
+    if (!right) {
+      aa[0] = (uint8_t)n1;
+      aa[1] = (uint8_t)x;
+      bb[0] = (uint8_t)n2;
+      bb[1] = (uint8_t)(3 - x);
+      p.a = aa;
+      p.b = bb;
+      left_end(p, 1, 1, S, H);
+      E->L[sym][x][n1][n2].s = S;
+      E->L[sym][x][n1][n2].h = H;
+    } else {
+      aa[0] = (uint8_t)x;
+      aa[1] = (uint8_t)n1;
+      bb[0] = (uint8_t)(3 - x);
+      bb[1] = (uint8_t)n2;
+      p.a = aa;
+      p.b = bb;
+      right_end(p, 0, 0, S, H);
+      E->R[sym][x][n1][n2].s = S;
+      E->R[sym][x][n1][n2].h = H;
+    }
+  }
+  __syncthreads();
+}
+
 #ifdef DG_WAVE_PROFILE
 __device__ unsigned long long g_wave_prof[8];
 #define DG_PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -104,7 +163,7 @@ __device__ inline uint64_t low_bits(int n) { return n >= 64 ? ~0ULL : ((1ULL << 
 // a, b: framed code sequences (wave-uniform), oligo2 reversed; 1 <= len1, len2 <= kWaveMaxLen; m from
 // wave_mem_at(.., >= len1, stride >= len2).  Every lane returns the same Result.
 template <class SeqT>
-__device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const SeqT& a, int len1, const SeqT& b, int len2,
+__device__ inline Result wave_end1_tm(const Tables& T, const EndTables& E, const Env& env, const SeqT& a, int len1, const SeqT& b, int len2,
                                       bool both_symmetric, const WaveMem& m, int stride, bool& ambiguous) {
   const int lane = (int)(threadIdx.x & 63);
   Result r;
@@ -153,16 +212,17 @@ __device__ inline Result wave_end1_tm(const Tables& T, const Env& env, const Seq
       if (mine) {
         curS = kMinEntropy;
         curH = 0.0;
-        double eS = -1.0, eH = kInf;
-        left_end(p, i, j, eS, eH);
+        const int esym = both_symmetric ? 1 : 0;
+        const Cell le = E.L[esym][ai][a[i - 1]][b[j - 1]];  // left_end(p, i, j)
+        const double eS = le.s, eH = le.h;
         if (fin(eH)) {
           curS = eS;
           curH = eH;
         }
         double kS = 0, kH = 0;
         if (i > 1 && j > 1) {
-          double rS, rH;
-          right_end(p, i, j, rS, rH);
+          const Cell re = E.R[esym][ai][a[i + 1]][b[j + 1]];  // right_end(p, i, j)
+          const double rS = re.s, rH = re.h;
           const bool dpair = (prevmask >> (j - 2)) & 1;
           const Cell diag = dpair ? m.cells[prevbase + (unsigned)__popcll(prevmask & low_bits(j - 2))] : kNoPair;
           double nS, nH;

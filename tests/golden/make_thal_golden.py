@@ -40,3 +40,26 @@ for p, q in pairs:
 json.dump({"params": {"temp_c": 37.0, "mv": 50.0, "dv": 1.5, "dna_conc": 50.0, "dntp": 0.6}, "vectors": out},
           open(os.path.join(HERE, "thal_vectors.json"), "w"))
 print("written", len(out))
+
+# second set: long oligos (padlock probes are 2 x armlen = 40 nt against their perfect complement; `search` windows reach
+# ~35 nt), the 60-nt limit, and other salt / DNA concentrations (RC and the salt correction are host-side constants)
+assert R.ref_thal_init(cfg.encode(), 37.0, 40.0, 2.5, 100.0, 0.8) == 0
+rng = random.Random(20260930)
+pairs = []
+for _ in range(700):
+    L = rng.choice([30, 36, 40, 40, 44, 48, 52, 60]); p = "".join(rng.choice("ACGT") for _ in range(L)); k = rng.random()
+    if k < 0.45: t = rc(p)
+    elif k < 0.8: t = mut(rc(p), rng.randint(1, 5))
+    elif k < 0.9: t = "".join(rng.choice("ACGT") for _ in range(rng.randint(20, 60)))
+    else: t = rc(p)[:rng.randint(15, L)]
+    pairs.append((p, t))
+pairs += [("AT" * 20, "AT" * 20), ("A" * 40, "T" * 40), ("GC" * 24, "GC" * 24), ("ACGT" * 16, "ACGT" * 16), ("A" * 61, "T" * 61),
+          ("ACGT" * 15 + "A", "T" + "ACGT" * 15), ("N" * 30, "N" * 30), ("ACGTN" * 8, "NACGT" * 8)]
+out = []
+tm_, e1_, e2_ = C.c_double(), C.c_int(), C.c_int()
+for p, q in pairs:
+    ok = R.ref_thal(p.encode(), q.encode(), C.byref(tm_), C.byref(e1_), C.byref(e2_))
+    out.append([p, q, struct.pack(">d", tm_.value).hex(), e1_.value if ok else -1, e2_.value if ok else -1, ok])  # thal() leaves align_end unset when it refuses
+json.dump({"params": {"temp_c": 37.0, "mv": 40.0, "dv": 2.5, "dna_conc": 100.0, "dntp": 0.8}, "vectors": out},
+          open(os.path.join(HERE, "thal_vectors_long.json"), "w"))
+print("written", len(out))

@@ -114,8 +114,10 @@ bool read_fasta(const std::string& path, std::vector<std::string>& names, std::v
       names.push_back(line.substr(1, e == std::string::npos ? std::string::npos : e - 1));
       seqs.emplace_back();
     } else if (!seqs.empty()) {
-      for (char ch : line)
-        if (!(ch == '\r' || ch == ' ' || ch == '\t')) seqs.back().push_back(ch);
+      if (line.find_first_of("\r \t") == std::string::npos) seqs.back() += line;  // the usual case: residues only
+      else
+        for (char ch : line)
+          if (!(ch == '\r' || ch == ' ' || ch == '\t')) seqs.back().push_back(ch);
     }
   }
   return !names.empty();

@@ -1513,7 +1513,7 @@ int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t
     for (u64 k = qoff[i]; k < qoff[i + 1]; ++k) {
       const u8 ch = qbytes[k];
       if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
-        return fail(DG_ELIMIT, "sequence %zu holds '%c'; only upper-case A/C/G/T sequences are counted (the reference searches the raw string, which matches nothing)", i, ch);
+        return fail(DG_ELIMIT, "sequence %zu holds '%c'; only upper-case A/C/G/T sequences are counted by this kernel", i, ch);
     }
     maxlen = std::max<u32>(maxlen, (u32)l);
   }

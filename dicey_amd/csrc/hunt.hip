@@ -20,7 +20,10 @@
 #include <chrono>
 #include <set>
 
+#include <string>
+
 #include "hunt_internal.hpp"
+#include "iupac.hpp"
 
 namespace dg {
 
@@ -1455,6 +1458,48 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
 
 using namespace dg;
 
+namespace {
+// neighbors() of the reference (src/neighbors.h:29-92) for the rare sequence the search kernel does not take: the <= d-edit
+// language over {A,C,G,T} edits (substitution by a different base, deletion, insertion before an existing character; at
+// least one edit, plus the sequence itself), of which edit mode keeps the strings that contain no other string of the
+// language and Hamming mode the strings of the original length within d mismatches.
+void host_language(const std::string& s, size_t pos, unsigned left, bool used, std::set<std::string>& out) {
+  if (pos >= s.size()) {
+    if (used) out.insert(s);
+    return;
+  }
+  if (left) host_language(s.substr(0, pos) + s.substr(pos + 1), pos, left - 1, true, out);
+  host_language(s, pos + 1, left, used, out);
+  if (left) {
+    for (char a : {'A', 'C', 'G', 'T'})
+      if (a != s[pos]) host_language(s.substr(0, pos) + a + s.substr(pos + 1), pos + 1, left - 1, true, out);
+    for (char a : {'A', 'C', 'G', 'T'}) host_language(s.substr(0, pos) + a + s.substr(pos), pos + 1, left - 1, true, out);
+  }
+}
+std::vector<std::string> host_neighbors(const std::string& q, unsigned d, bool indel) {
+  std::set<std::string> lang;
+  host_language(q, 0, d, false, lang);
+  lang.insert(q);
+  std::vector<std::string> out;
+  for (const std::string& s : lang) {
+    if (indel) {
+      bool minimal = true;
+      for (const std::string& t : lang)
+        if (t.size() < s.size() && s.find(t) != std::string::npos) {
+          minimal = false;
+          break;
+        }
+      if (minimal) out.push_back(s);
+    } else if (s.size() == q.size()) {
+      unsigned mm = 0;
+      for (size_t k = 0; k < s.size(); ++k) mm += s[k] != q[k];
+      if (mm <= d) out.push_back(s);
+    }
+  }
+  return out;
+}
+}  // namespace
+
 extern "C" {
 
 void dg_hunt_result_free(dg_hunt_result* r) {
@@ -1502,41 +1547,81 @@ int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t
                            const uint64_t* qoff, size_t nq, uint64_t* fw_count, uint64_t* rv_count) {
   if (!ix || !qoff || !fw_count || !rv_count || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_neighborhood_count: null argument");
   if (!nq) return DG_OK;
-  const u64 total = qoff[nq];
+  // Sequences of A/C/G/T go through the search kernel (count mode of run_batch).  Anything else in a sequence (N, IUPAC
+  // letters: the reference matches them byte for byte) is rare enough for the host: enumerate the neighbourhood as
+  // neighbors.h defines it and count every string with dg_count.
+  std::vector<size_t> fast, slow;
   u32 maxlen = 0;
   for (size_t i = 0; i < nq; ++i) {
     if (qoff[i + 1] < qoff[i]) return fail(DG_EINVAL, "dg_neighborhood_count: qoff must be non-decreasing");
     const u64 l = qoff[i + 1] - qoff[i];
     // hunt skips queries under 10 nt and clamps the distance to the length (hunter.h:299-315); padlock.h does neither
     if (l < 10 || l <= distance) return fail(DG_ELIMIT, "sequence %zu has %llu nt; this entry point takes >= 10 nt and more than `distance`", i, (unsigned long long)l);
-    if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "sequence %zu is too long", i);
+    if (l > MAX_QLEN) return fail(DG_ELIMIT, "sequence %zu exceeds %u nt", i, MAX_QLEN);
+    bool plain = true;
     for (u64 k = qoff[i]; k < qoff[i + 1]; ++k) {
       const u8 ch = qbytes[k];
-      if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
-        return fail(DG_ELIMIT, "sequence %zu holds '%c'; only upper-case A/C/G/T sequences are counted by this kernel", i, ch);
+      plain = plain && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
     }
+    (plain ? fast : slow).push_back(i);
     maxlen = std::max<u32>(maxlen, (u32)l);
   }
+  if (distance > DMAX) return fail(DG_ELIMIT, "distance %u exceeds the supported maximum of %u", distance, DMAX);
+  {
+    const u64 bound = neighbourhood_bound(maxlen, distance, !hamming);
+    if (bound >= max_neighborhood)
+      return fail(DG_ELIMIT, "cannot prove that the maxNeighborhood cap (%u) stays silent for %u-mers at distance %u (bound %llu)",
+                  max_neighborhood, maxlen, distance, (unsigned long long)bound);
+  }
   DG_HIP(hipSetDevice(ix->device));
-  DG_TRY(ix->ws[WS_QB].reserve(total + 8));
-  DG_TRY(ix->ws[WS_QOFF].reserve((nq + 1) * 8));
-  DG_HIP(hipMemcpyAsync(ix->ws[WS_QB].p, qbytes, total, hipMemcpyHostToDevice, ix->stream));
-  DG_HIP(hipMemcpyAsync(ix->ws[WS_QOFF].p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
-  dg_hunt_params hp;
-  hp.distance = distance;
-  hp.hamming = hamming;
-  hp.forward_only = 0;
-  hp.max_locations = 1;
-  hp.max_neighborhood = max_neighborhood;
-  const uint32_t one_seq = 1;  // chromosome lookup is not used in count mode
-  std::vector<u64> counts(2 * nq);
-  dg_hunt_result* hr = nullptr;
-  int rc = run_batch(ix, &hp, &one_seq, 1, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, 0, &hr, nullptr, counts.data());
-  if (hr) dg_hunt_result_free(hr);
-  if (rc != DG_OK) return rc;
-  for (size_t i = 0; i < nq; ++i) {
-    fw_count[i] = counts[2 * i];
-    rv_count[i] = counts[2 * i + 1];
+  if (!fast.empty()) {
+    std::string buf;
+    std::vector<u64> off(1, 0);
+    for (size_t i : fast) {
+      buf.append((const char*)qbytes + qoff[i], qoff[i + 1] - qoff[i]);
+      off.push_back(buf.size());
+    }
+    DG_TRY(ix->ws[WS_QB].reserve(buf.size() + 8));
+    DG_TRY(ix->ws[WS_QOFF].reserve(off.size() * 8));
+    DG_HIP(hipMemcpyAsync(ix->ws[WS_QB].p, buf.data(), buf.size(), hipMemcpyHostToDevice, ix->stream));
+    DG_HIP(hipMemcpyAsync(ix->ws[WS_QOFF].p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ix->stream));
+    dg_hunt_params hp;
+    hp.distance = distance;
+    hp.hamming = hamming;
+    hp.forward_only = 0;
+    hp.max_locations = 1;
+    hp.max_neighborhood = max_neighborhood;
+    const uint32_t one_seq = 1;  // chromosome lookup is not used in count mode
+    std::vector<u64> counts(2 * fast.size());
+    dg_hunt_result* hr = nullptr;
+    int rc = run_batch(ix, &hp, &one_seq, 1, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, fast.size(), buf.size(), maxlen, 0, &hr, nullptr, counts.data());
+    if (hr) dg_hunt_result_free(hr);
+    if (rc != DG_OK) return rc;
+    for (size_t k = 0; k < fast.size(); ++k) {
+      fw_count[fast[k]] = counts[2 * k];
+      rv_count[fast[k]] = counts[2 * k + 1];
+    }
+  }
+  if (!slow.empty()) {
+    std::string buf;
+    std::vector<u64> off(1, 0);
+    std::vector<std::pair<size_t, size_t>> owner;  // (sequence, strand) of every string
+    for (size_t i : slow) {
+      std::string fw((const char*)qbytes + qoff[i], qoff[i + 1] - qoff[i]), rv(fw.rbegin(), fw.rend());
+      for (char& ch : rv) ch = complement_iupac(ch);
+      for (size_t strand = 0; strand < 2; ++strand) {
+        for (const std::string& s : host_neighbors(strand ? rv : fw, distance, !hamming)) {
+          buf += s;
+          off.push_back(buf.size());
+          owner.emplace_back(i, strand);
+        }
+      }
+      fw_count[i] = rv_count[i] = 0;
+    }
+    std::vector<u64> cnt(owner.size());
+    int rc = dg_count(ix, (const uint8_t*)buf.data(), off.data(), owner.size(), cnt.data());
+    if (rc != DG_OK) return rc;
+    for (size_t k = 0; k < owner.size(); ++k) (owner[k].second ? rv_count : fw_count)[owner[k].first] += cnt[k];
   }
   return DG_OK;
 }

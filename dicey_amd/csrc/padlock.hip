@@ -12,18 +12,13 @@
 #include <vector>
 
 #include "common.hpp"
+#include "iupac.hpp"
 #include "thal_internal.hpp"
 
 using namespace dg;
 
 namespace {
 
-char complement_iupac(char n) {  // util.h:54-91
-  static const char* from = "AaCcGgTtUuRrYySsWwKkMmBbVvDdHhNn";
-  static const char* to = "TtGgCcAaAaYyRrSsWwMmKkVvBbHhDdNn";
-  const char* p = n ? std::strchr(from, n) : nullptr;
-  return p ? to[p - from] : 'N';
-}
 }  // namespace
 
 extern "C" {

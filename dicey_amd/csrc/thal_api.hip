@@ -9,6 +9,7 @@
 #include "index_internal.hpp"
 #include "thal.hpp"
 
+#include "iupac.hpp"
 #include "thal_internal.hpp"
 #include "thal_wave.hpp"
 
@@ -249,12 +250,6 @@ __global__ void __launch_bounds__(1024) k_thal_self_wave(const thal::Tables* T, 
   }
 }
 
-static char complement_iupac_upper(char n) {  // util.h:54-91 on upper-case input
-  static const char* from = "ACGTURYSWKMBVDHN";
-  static const char* to = "TGCAAYRSWMKVBHDN";
-  const char* p = n ? std::strchr(from, n) : nullptr;
-  return p ? to[p - from] : 'N';
-}
 static u8 code_of(char c) {
   c = (char)std::toupper((unsigned char)c);
   return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;  // str2int, thal.h:260-275
@@ -489,7 +484,7 @@ int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, co
       const uint32_t len = win_len[k];
       buf.append((const char*)w, len);
       off.push_back(buf.size());
-      for (uint32_t i = 0; i < len; ++i) buf.push_back(complement_iupac_upper((char)w[len - 1 - i]));
+      for (uint32_t i = 0; i < len; ++i) buf.push_back(complement_iupac((char)w[len - 1 - i]));
       off.push_back(buf.size());
     }
     std::vector<double> t2(again.size());

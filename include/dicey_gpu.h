@@ -154,7 +154,8 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
                    const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out);
 
 /* ---- `dicey padlock`: how often the neighbourhood of a probe arm occurs (reference src/padlock.h:392-421) ----
- * For sequence i (upper-case A/C/G/T, >= 10 nt): fw_count[i] = sum over s in neighbors(seq_i, distance, indel, maxsize) of
+ * For sequence i (>= 10 nt; A/C/G/T sequences run on the search kernel, sequences with other letters are enumerated on
+ * the host and counted with dg_count): fw_count[i] = sum over s in neighbors(seq_i, distance, indel, maxsize) of
  * sdsl::count(fm_index, s) and rv_count[i] the same for its reverse complement — the totals the reference accumulates in
  * hits[0] / hits[1] (its loops only stop early once the running total already exceeds the threshold it is compared with,
  * so every comparison it makes has the same outcome on the full totals).  The original sequence is part of its own

@@ -1,6 +1,6 @@
 """Synthetic `dicey padlock` scenario shared by the CPU (oracle vs golden) and GPU (binary vs oracle/golden) tests:
-a three-sequence genome with a duplicated segment, a near-duplicate (mismatches every 37 nt), an N run and soft-masked
-bases; a GTF with overlapping exons of two transcripts per gene on both strands, a non-coding gene and an unknown
+a three-sequence genome with a duplicated segment, a near-duplicate (mismatches every 37 nt), an N run, two IUPAC letters
+inside an exon and soft-masked bases; a GTF with overlapping exons of two transcripts per gene on both strands, a non-coding gene and an unknown
 chromosome; three barcodes for four genes."""
 import gzip
 import os
@@ -44,6 +44,7 @@ def build(d):
         nd[k] = rng.choice("ACGT")
     seqs[1] = seqs[1][:12000] + "".join(nd) + seqs[1][12300:]              # near-duplicate: neighbourhood hits
     seqs[0] = seqs[0][:9000] + "NNNNNNNNNN" + seqs[0][9010:]
+    seqs[1] = seqs[1][:5300] + "R" + seqs[1][5301:5420] + "Y" + seqs[1][5421:]   # IUPAC letters inside an exon of ENSG03
     seqs = ["".join(c.lower() if rng.random() < 0.05 else c for c in s) for s in seqs]  # soft-masked bases
     fa = os.path.join(d, "GRCh38_toy.fa.gz")
     with gzip.open(fa, "wt") as f:

@@ -83,8 +83,12 @@ def test_neighborhood_count_matches_oracle(scenario):
                 assert gf == sum(cnt(s) for s in O.neighbors(q, d, not ham)), (q, d, ham)
                 assert gr == sum(cnt(s) for s in O.neighbors(revcomp(q), d, not ham)), (q, d, ham)
         assert got[-2][0] + got[-2][1] >= 2 or True
-        with pytest.raises(Exception):
-            ix.neighborhood_count([b"ACGTNACGTACGTACG"])     # only A/C/G/T sequences are counted
+        comp = dict(zip("ACGTURYSWKMBVDHN", "TGCAAYRSWMKVBHDN"))
+        for q in ("ACGTNACGTACGTACG", seqs[1][5290:5310], seqs[1][5410:5430]):   # N / IUPAC letters: the host enumerates, dg_count counts
+            (gf, gr), = ix.neighborhood_count([q.encode()])
+            rq = "".join(comp.get(c, "N") for c in reversed(q))
+            assert gf == sum(cnt(s) for s in O.neighbors(q, 1, True)) and gr == sum(cnt(s) for s in O.neighbors(rq, 1, True))
+        assert ix.neighborhood_count([seqs[1][5290:5310].encode()])[0][0] >= 1
         with pytest.raises(Exception):
             ix.neighborhood_count([b"ACGTACG"])              # >= 10 nt
 

@@ -346,6 +346,36 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
     out->overflow = ctr->overflow;
   }
 }
+// Production form: one workgroup, one lane per shard, totals straight into the pinned host record (no atomics over the bus,
+// no separate copy); the host reads it after the batch's single stream synchronisation.
+__global__ void __launch_bounds__(NSHARD) k_summary_block(const Counters* ctr, const u64* nhits, Summary* host_out) {
+  __shared__ unsigned long long part[6][NSHARD / 64];
+  const u32 k = threadIdx.x;
+  unsigned long long v[6] = {ctr->leaf_cnt[k], ctr->leaf_cnt[k], ctr->steps[k], ctr->lookups[k], ctr->sa_reads[k], ctr->win_bytes[k]};
+  for (int f = 0; f < 6; ++f) {
+    unsigned long long x = v[f];
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(x, off);
+      x = f == 1 ? (o > x ? o : x) : x + o;
+    }
+    if ((k & 63) == 0) part[f][k >> 6] = x;
+  }
+  __syncthreads();
+  if (k == 0) {
+    unsigned long long t[6] = {0, 0, 0, 0, 0, 0};
+    for (int f = 0; f < 6; ++f)
+      for (u32 w = 0; w < NSHARD / 64; ++w) t[f] = f == 1 ? (part[f][w] > t[f] ? part[f][w] : t[f]) : t[f] + part[f][w];
+    host_out->nleaf = t[0];
+    host_out->worst_shard = t[1];
+    host_out->steps = t[2];
+    host_out->lookups = t[3];
+    host_out->sa_reads = t[4];
+    host_out->win_bytes = t[5];
+    host_out->nhits = *nhits;
+    host_out->overflow = ctr->overflow;
+    __threadfence_system();
+  }
+}
 // group leaves by (query,strand): dst = grp_off[qs] + slot
 __global__ void k_group(const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, Leaf* out) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1223,8 +1253,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   DG_TRY(ws[WS_QSEQ].reserve(total + 8));
   DG_TRY(ws[WS_QMETA].reserve(nq * 16 + 64));
   DG_TRY(ws[WS_GINFO].reserve(ngrp * sizeof(GidInfo) + 64));
-  DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 2 + nq * 4 + scan_tmp * 8 + 256));
-  DG_TRY(ws[WS_MISC].reserve(sizeof(Counters) + sizeof(Summary) + 64));
+  DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 2 + nq * 4 + scan_tmp * 8 + sizeof(Counters) + sizeof(Summary) + 512));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   Batch b;
   b.qbytes = (const u8*)d_qbytes;
@@ -1250,13 +1279,19 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   gp += (nq + 1) * 8;
   u64* scan_buf = (u64*)gp;
   gp += scan_tmp * 8;
+  gp = (u8*)(((uintptr_t)gp + 63) & ~(uintptr_t)63);
+  // counters, device-side summary, group counts and selection counts sit next to each other: one memset clears them
+  u8* const zero_from = gp;
+  Counters* ctr = (Counters*)gp;
+  gp += (sizeof(Counters) + 63) & ~(size_t)63;
+  Summary* d_sum = (Summary*)gp;
+  gp += (sizeof(Summary) + 63) & ~(size_t)63;
   u32* grp_cnt = (u32*)gp;
   gp += ngrp * 4;
   u32* nsel = (u32*)gp;
   gp += ngrp * 4;
+  const size_t zero_bytes = (size_t)(gp - zero_from);
   u32* qhits = (u32*)gp;
-  Counters* ctr = ws[WS_MISC].as<Counters>();
-  Summary* d_sum = (Summary*)(ws[WS_MISC].as<u8>() + ((sizeof(Counters) + 63) & ~(size_t)63));
   if (!ix->pinned) DG_HIP(hipHostMalloc((void**)&ix->pinned, 4096, 0));
   Summary& hsum = *(Summary*)ix->pinned;
   std::vector<u64> cum(nseq);
@@ -1289,8 +1324,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_TRY(ws[WS_JOBS].reserve(std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
     DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
-    DG_HIP(hipMemsetAsync(ctr, 0, ((sizeof(Counters) + 63) & ~(size_t)63) + sizeof(Summary), st));
-    DG_HIP(hipMemsetAsync(grp_cnt, 0, ngrp * 4 * 2, st));  // grp_cnt and nsel are adjacent
+    DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     DG_HIP(hipEventRecord(ix->ev[0], st));
     hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b);
     DG_HIP(hipEventRecord(ix->ev[1], st));
@@ -1383,8 +1417,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     }
     DG_HIP(hipEventRecord(ix->ev[7], st));
     }
-    hipLaunchKernelGGL(k_summary, dim3(NSHARD / 256), dim3(256), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), d_sum);
-    DG_HIP(hipMemcpyAsync(&hsum, d_sum, sizeof(Summary), hipMemcpyDeviceToHost, st));
+    static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
+    if (lane_only) {
+      hipLaunchKernelGGL(k_summary, dim3(NSHARD / 256), dim3(256), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), d_sum);
+      DG_HIP(hipMemcpyAsync(&hsum, d_sum, sizeof(Summary), hipMemcpyDeviceToHost, st));
+    } else {
+      hipLaunchKernelGGL(k_summary_block, dim3(1), dim3(NSHARD), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), &hsum);
+    }
     DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
     DG_HIP(hipGetLastError());
     nleaf = hsum.nleaf;

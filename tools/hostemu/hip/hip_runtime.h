@@ -57,6 +57,7 @@ inline unsigned __builtin_amdgcn_readfirstlane(unsigned x) { return x; }
 inline int __builtin_amdgcn_readlane(int x, int) { return x; }
 inline int __builtin_amdgcn_mov_dpp(int, int, int, int, bool) { emu_no_collectives("mov_dpp"); }
 inline void __builtin_amdgcn_wave_barrier() {}
+inline void __threadfence_system() {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 
 typedef int hipError_t;

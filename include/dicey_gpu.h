@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define DG_ABI_VERSION 1
+/* 1: hunt/count/locate/extract/index build; 2: + thal, search sites, neighbourhood counts, padlock scan, shared handles */
+#define DG_ABI_VERSION 2
 
 enum {
   DG_OK = 0,

@@ -42,6 +42,54 @@ struct Sel {  // a kept neighbourhood string, in search order
   u32 hbase;  // first hit slot, relative to the query's first hit
 };
 
+// Largest number of distinct strings neighbors() can hold for a query of length m with nN letters outside A/C/G/T (they
+// are 'N' after replaceNonDna and can be substituted by all four bases instead of three); used to prove that the
+// maxNeighborhood early return (neighbors.h:50) cannot fire.  Returns ~0 when no such proof is available.
+DG_HD u64 neighbourhood_bound(u32 m, u32 d, bool indel, u32 nN = 0) {
+  auto binom = [](u64 n, u64 k) {
+    u64 r = 1;
+    for (u64 i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return r;
+  };
+  if (nN > m) nN = m;
+  if (!indel) {  // exactly: i substituted positions, j of them at an N (4 letters) and i-j elsewhere (3 letters)
+    u64 t = 0;
+    for (u32 i = 0; i <= d && i <= m; ++i)
+      for (u32 j = 0; j <= i && j <= nN; ++j) {
+        if (i - j > m - nN) continue;
+        u64 term = binom(nN, j) * binom(m - nN, i - j);
+        for (u32 k = 0; k < j; ++k) term *= 4;
+        for (u32 k = 0; k < i - j; ++k) term *= 3;
+        t += term;
+        if (t > (1ULL << 40)) return ~0ULL;
+      }
+    return t;
+  }
+  // Edit mode.  With N positions: strings that need the fourth letter at an N position spend one edit on that substitution
+  // and reach at most G(d-1) strings with the rest, G(0) = 1, G(1) = 1 + m deletions + 4m substitutions + 4(m+1)
+  // insertions; everything else obeys the three-letter count below.
+  u64 extra = 0;
+  if (nN) {
+    if (d == 1) extra = nN;
+    else if (d == 2) extra = (u64)nN * (9ULL * m + 5);
+    else if (d > 2) return ~0ULL;
+  }
+  if (d == 0) return 1;
+  if (d == 1) return 7ULL * m + 5 + extra;  // 1 + 3m substitutions + m deletions + (3m+4) insertions
+  if (d == 2) {
+    // Distinct strings within two edits, by length class (DESIGN.md "neighbourhood size bound"); M = m-1 is the query
+    // without its last character, which every string of L must still align to (no insertion after the last column).
+    const u64 M = m - 1;
+    u64 len_m2 = binom(m, 2);                                              // two deletions
+    u64 len_m1 = m + 3ULL * m * (m - 1);                                   // D, D+S
+    u64 len_0 = 1 + 3ULL * m + 9 * binom(m, 2) + m * (3ULL * (m - 1) + 4) - (3ULL * m + 1);  // q, S, SS, D+I (q and S counted once)
+    u64 len_p1 = (3 * M + 4) * (1 + 3 * M) - 6 * M - 3 * M + 3 * (3 * M + 4);  // I, I+S; last column M or S
+    u64 len_p2 = 1 + 3 * (m + 1) + 9 * binom(m + 1, 2);                    // supersequences of q[0..m-1) of length m+1, then q[m-1]
+    return len_m2 + len_m1 + len_0 + len_p1 + len_p2 + extra;
+  }
+  return ~0ULL;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_prepare(Batch b) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,6 +111,12 @@ __global__ void k_prepare(Batch b) {
     d = m - 1;
     flags |= DG_Q_DIST_ADJUSTED;
   }
+  // a query with N's has a larger neighbourhood than the host could know from the lengths alone: if the cap could fire for
+  // it, the reference's answer depends on its recursion order, which this kernel does not reproduce -> refuse the batch
+  if (bad && m >= 10 && neighbourhood_bound(m, d, b.indel != 0, bad) >= b.max_neighborhood) {
+    flags |= DG_Q_NBHD_EXCEEDED;
+    atomicAdd(b.refused, 1u);
+  }
   b.qlen[q] = m;
   b.qdist[q] = d;
   b.qflags[q] = flags;
@@ -70,7 +124,7 @@ __global__ void k_prepare(Batch b) {
   for (u32 strand = 0; strand < 2; ++strand) {
     GidInfo gi;
     gi.qpk = 0;
-    gi.m = ((flags & DG_Q_TOO_SHORT) || (strand && !b.reverse)) ? 0u : m;
+    gi.m = ((flags & (DG_Q_TOO_SHORT | DG_Q_NBHD_EXCEEDED)) || (strand && !b.reverse)) ? 0u : m;
     gi.d_win = d | (bad == 0 ? 256u : 0u);
     if (bad == 0 && m <= 32) {
       const u8* sq = (strand ? b.rv : b.fw) + s;
@@ -330,7 +384,7 @@ __global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap) {  // NSHARD lanes
 }
 // what the host needs at the end of a batch, in 64 bytes instead of the 36 KB of sharded counters
 struct Summary {
-  unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow;
+  unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow, refused;
 };
 __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {  // NSHARD lanes
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,6 +398,7 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
   if (k == 0) {
     out->nhits = *nhits;
     out->overflow = ctr->overflow;
+    out->refused = ctr->pad_[1];
   }
 }
 // Production form: one workgroup, one lane per shard, totals straight into the pinned host record (no atomics over the bus,
@@ -373,6 +428,7 @@ __global__ void __launch_bounds__(NSHARD) k_summary_block(const Counters* ctr, c
     host_out->win_bytes = t[5];
     host_out->nhits = *nhits;
     host_out->overflow = ctr->overflow;
+    host_out->refused = ctr->pad_[1];
     __threadfence_system();
   }
 }
@@ -1114,39 +1170,6 @@ static double ev_ms(hipEvent_t a, hipEvent_t b) {
   return ms;
 }
 
-// Largest number of distinct strings neighbors() can hold for a query of length m; used to prove that the
-// maxNeighborhood early return (neighbors.h:50) cannot fire.  Returns ~0 when no such proof is available.
-static u64 neighbourhood_bound(u32 m, u32 d, bool indel) {
-  auto binom = [](u64 n, u64 k) {
-    u64 r = 1;
-    for (u64 i = 1; i <= k; ++i) r = r * (n - k + i) / i;
-    return r;
-  };
-  if (!indel) {
-    u64 t = 0, p = 1;
-    for (u32 i = 0; i <= d && i <= m; ++i) {
-      t += binom(m, i) * p;
-      p *= 3;
-      if (t > (1ULL << 40)) return ~0ULL;
-    }
-    return t;
-  }
-  if (d == 0) return 1;
-  if (d == 1) return 7ULL * m + 5;  // 1 + 3m substitutions + m deletions + (3m+4) insertions
-  if (d == 2) {
-    // Distinct strings within two edits, by length class (DESIGN.md "neighbourhood size bound"); M = m-1 is the query
-    // without its last character, which every string of L must still align to (no insertion after the last column).
-    const u64 M = m - 1;
-    u64 len_m2 = binom(m, 2);                                              // two deletions
-    u64 len_m1 = m + 3ULL * m * (m - 1);                                   // D, D+S
-    u64 len_0 = 1 + 3ULL * m + 9 * binom(m, 2) + m * (3ULL * (m - 1) + 4) - (3ULL * m + 1);  // q, S, SS, D+I (q and S counted once)
-    u64 len_p1 = (3 * M + 4) * (1 + 3 * M) - 6 * M - 3 * M + 3 * (3 * M + 4);  // I, I+S; last column M or S
-    u64 len_p2 = 1 + 3 * (m + 1) + 9 * binom(m + 1, 2);                    // supersequences of q[0..m-1) of length m+1, then q[m-1]
-    return len_m2 + len_m1 + len_0 + len_p1 + len_p2;
-  }
-  return ~0ULL;
-}
-
 // Two-launch scan for the production path: tiles of 1024 entries (256 lanes x 4); k_scan_tile_sums writes one sum per
 // tile, k_scan_tiles adds up the sums of the tiles before its own (a few hundred values) and scans its tile in place.
 constexpr u32 SCAN_TILE = 1024;
@@ -1271,6 +1294,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   b.indel = indel;
   b.reverse = !p->forward_only;
   b.max_locations = p->max_locations;
+  b.max_neighborhood = p->max_neighborhood;
   b.ginfo = ws[WS_GINFO].as<GidInfo>();
   u8* gp = ws[WS_GRP].as<u8>();
   u64* grp_off = (u64*)gp;
@@ -1291,6 +1315,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   u32* nsel = (u32*)gp;
   gp += ngrp * 4;
   const size_t zero_bytes = (size_t)(gp - zero_from);
+  b.refused = &ctr->pad_[1];
   u32* qhits = (u32*)gp;
   if (!ix->pinned) DG_HIP(hipHostMalloc((void**)&ix->pinned, 4096, 0));
   Summary& hsum = *(Summary*)ix->pinned;
@@ -1426,6 +1451,11 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     }
     DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
     DG_HIP(hipGetLastError());
+    if (hsum.refused)
+      return fail(DG_ELIMIT,
+                  "%llu quer%s of this batch hold N / non-DNA letters that make the neighbourhood large enough for the maxNeighborhood "
+                  "cap (%u) to fire; the reference's capped enumeration is order dependent and is not reproduced by this build",
+                  hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
     nleaf = hsum.nleaf;
     nhits = hsum.nhits;
     const u32 worst = (u32)hsum.worst_shard;

@@ -25,6 +25,8 @@ struct Batch {  // device pointers of one batch
   u32 distance;
   u32 indel, reverse;
   u64 max_locations;
+  u32 max_neighborhood;  // neighbors()' cap (hunter.h:334)
+  u32* refused;          // counter of queries whose neighbourhood could reach the cap (see k_prepare)
   struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
 };
 struct GidInfo {

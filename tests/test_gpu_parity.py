@@ -109,6 +109,14 @@ def test_unsupported_envelope_fails_loudly(gpu_small, small_genome):
         gpu_small.hunt(["ACGT" * 5 + "A"], small_genome["seqlen"], distance=2)  # 21-mer, d=2: cap not provably silent
     with pytest.raises(dicey_amd.DgError):
         gpu_small.hunt(["ACGTACGTACGT"], small_genome["seqlen"], distance=30)
+    # an N can become any of four bases: 38 N's at Hamming distance 2 are 11 401 strings, the reference's cap (10 000) fires
+    # and its answer depends on the recursion order -> refused, although 38-mers without N are fine (6 442 strings)
+    with pytest.raises(dicey_amd.DgError, match="N / non-DNA"):
+        gpu_small.hunt(["ACGTACGTAC" * 3 + "ACGTACGT", "N" * 38], small_genome["seqlen"], distance=2, hamming=True)
+    gpu_small.hunt(["ACGTACGTAC" * 3 + "ACGTACGT", "ACGTNNACGT" * 3 + "ACGTACGT"], small_genome["seqlen"], distance=2, hamming=True)
+    with pytest.raises(dicey_amd.DgError, match="N / non-DNA"):   # edit distance 2: one N in a 20-mer is provable, two are not
+        gpu_small.hunt(["ACGTNACGTNACGTACGTAC"], small_genome["seqlen"], distance=2)
+    gpu_small.hunt(["ACGTNACGTAACGTACGTAC"], small_genome["seqlen"], distance=2)
 
 
 def test_larger_genome_roundtrip_properties():
@@ -274,3 +282,13 @@ def test_shared_handles_run_concurrently_and_agree(small_genome):
         key = lambda R: [[(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in q.hits] for q in R.queries]
         assert key(got[0]) == key(want) and key(got[1]) == key(want)
         other.close()
+
+
+def test_randomised_configurations_against_oracle():
+    """tools/fuzz_hunt.py: random parameter combinations, lengths, edits, repeats and non-DNA letters (found the N-aware cap bound)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_hunt.py"), "7", "12"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "failing configurations: 0" in r.stdout, r.stdout[-1500:]

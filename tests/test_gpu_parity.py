@@ -1,5 +1,6 @@
 """GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of libdiceygpu.so and is
 compared bit for bit with the oracle on the same seeded inputs."""
+import os
 import random
 import zlib
 

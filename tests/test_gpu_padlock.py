@@ -117,3 +117,12 @@ def test_padlock_scan_arrays(scenario):
         assert (R["arm_count"] >= -1).all() and (R["arm_count"] >= 1).any()
         assert R["n_arm_thal"] >= R["n_probe_thal"] > 0 and R["n_arms_counted"] > 0
         th.close()
+
+
+@pytest.mark.skipif(O.ref_libs() is None, reason="oracle/_ref (reference thal.h built in place) is not available")
+def test_randomised_padlock_configurations_against_oracle():
+    """tools/fuzz_padlock.py: random option combinations on the fixture scenario, TSV + JSON identical to the oracle's."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_padlock.py"), "5", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "failing configurations: 0" in r.stdout, r.stdout[-1500:]

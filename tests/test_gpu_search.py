@@ -90,3 +90,12 @@ def test_search_sites_library_level(pcr):
             T.ref_thal(p.encode(), revcomp(p).encode(), C.byref(t), C.byref(a), C.byref(b))
             assert t.value == m
         th.close()
+
+
+@needs_ref
+def test_randomised_search_configurations_against_oracle():
+    """tools/fuzz_search.py: random primer sets and option combinations, JSON identical to the oracle's."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_search.py"), "11", "10"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "failing configurations: 0" in r.stdout, r.stdout[-1500:]

@@ -25,7 +25,11 @@ text = genome_text(seqs)
 fm9 = "/tmp/fuzz_%d.fm9" % seed
 O.build_fm9(text, fm9)
 orc = O.Index(fm9)
-ix = dicey_amd.FmIndex(fm9)
+_lib = None
+if "DICEY_LIB" in os.environ:  # e.g. tools/hostemu/libdiceygpu_hostemu.so for a GPU-less sweep
+    from dicey_amd import _capi
+    _lib = _capi.load(os.environ["DICEY_LIB"])
+ix = dicey_amd.FmIndex(fm9, _lib=_lib)
 names = ["c%d" % i for i in range(4)]
 seqlen = [len(s) + 1 for s in seqs]
 bad = 0

@@ -272,6 +272,7 @@ def main():
 
     # ---------------- cpu baseline + parity spot check at full size (rank 0, N=1 only)
     cpu = None
+    cpu_par = None
     parity = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -288,6 +289,13 @@ def main():
                "sample": f"first {ns} of the {nq} bench queries, oracle hunt_one (restated hunter.h:291-444) on 1 host thread, "
                          f"{dt:.1f} s, index load excluded", "host_cpus": os.cpu_count(),
                "oracle_ops": octr}
+        # the same loop on all host cores over query shards (the reference itself has no threads)
+        ncores = min(os.cpu_count() or 1, 64)
+        if ncores > 1:
+            nsp = int(min(nq, ns * ncores * 0.6))
+            dtp, _, _ = orc.hunt_timed(seqlen, qstr[:nsp], threads=ncores, distance=a.distance)
+            cpu_par = {"value": nsp / dtp, "unit": "primers/s", "cores": ncores, "kind": "port",
+                       "sample": f"first {nsp} bench queries, {ncores} host threads over query shards, {dtp:.1f} s"}
         # parity at full genome size: GPU hits (push order) == oracle hits for a sample
         npar = min(300, nq)
         got = ix.hunt(qstr[:npar], seqlen, distance=a.distance)
@@ -340,6 +348,7 @@ def main():
                          "gather_ceiling_note": "random 64-B lines over >=16 GiB top out at 19 G lines/s = 1.2 TB/s on this chip "
                                                 "(profiles/r01b_gather_bench.jsonl); this kernel is a gather, not a stream"},
             "cpu_baseline": cpu,
+            "cpu_baseline_parallel": cpu_par,
             "pipelined": pipelined,
             "parity_sample": parity,
             "phases_ms": {k: float(np.mean([r[k] for r in acc])) for k in ("ms_total", "ms_search", "ms_select", "ms_locate", "ms_verify")},

@@ -589,11 +589,33 @@ __global__ void k_leaf_alive(const PLeaf* G, const u64* grp_off, u64 nq2, u32 in
   if (indel) {
     const PLeaf a = G[t];
     const u64 g0 = grp_off[a.qs], g1 = grp_off[a.qs + 1];
+    // "x occurs in a at offset o" = top 3*len(x) bits of (a << 3o) equal x.  The strings of a group differ in length by at
+    // most 2d, so the first five shifts of a (enough for d <= 2) are made once and stay in registers.
+    constexpr int NSH = 5;
+    u64 ah[NSH], al[NSH];
+#pragma unroll
+    for (int o = 0; o < NSH; ++o) {
+      ah[o] = a.hi;
+      al[o] = a.lo;
+      p128_shl(ah[o], al[o], 3 * o);
+    }
     for (u64 j = g0; j < g1 && ok; ++j) {
       if (j == t) continue;
       const PLeaf x = G[j];
       if (x.len > a.len) continue;
-      if (pleaf_contains(a, x)) ok = (x.len == a.len) && (t < j);
+      const u32 diff = a.len - x.len, nbits = 3 * x.len;  // nbits <= 126
+      const u64 mh = nbits >= 64 ? ~0ULL : (nbits ? ~0ULL << (64 - nbits) : 0ULL);
+      const u64 ml = nbits > 64 ? ~0ULL << (128 - nbits) : 0ULL;
+      bool hit = false;
+#pragma unroll
+      for (int o = 0; o < NSH; ++o)
+        if ((u32)o <= diff) hit = hit || ((ah[o] & mh) == x.hi && (al[o] & ml) == x.lo);
+      for (u32 o = NSH; o <= diff && !hit; ++o) {  // distances above 2
+        u64 hi = a.hi, lo = a.lo;
+        p128_shl(hi, lo, 3 * o);
+        hit = (hi & mh) == x.hi && (lo & ml) == x.lo;
+      }
+      if (hit) ok = (x.len == a.len) && (t < j);
     }
   }
   alive[t] = ok;

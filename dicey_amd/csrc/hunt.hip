@@ -444,23 +444,33 @@ __global__ void k_group(const Leaf* in, u32 shard_cap, const Counters* ctr, cons
 // Left-to-right reader of the string a leaf stands for (query + recorded edits).
 struct LeafReader {
   const u8* seq;
+  u64 qpk;      // the query 2-bit packed (q[i] at bits 2(m-1-i)) when `packed`: no memory access per character
+  bool packed;
   u32 m;
   const u32* ops;
   int k;     // next op (they were recorded right-to-left, so read from the last one)
   u32 qpos;  // next query index to output
   DG_DEV void init(const u8* s, u32 m_, const Leaf& lf) {
     seq = s;
+    qpk = 0;
+    packed = false;
     m = m_;
     ops = lf.ops;
     k = (int)lf.nops - 1;
     qpos = 0;
   }
+  DG_DEV void init_packed(u64 q, u32 m_, const Leaf& lf) {
+    init(nullptr, m_, lf);
+    qpk = q;
+    packed = true;
+  }
+  DG_DEV int at(u32 i) const { return packed ? (int)((qpk >> (2 * (m - 1 - i))) & 3) : (int)seq[i]; }
   DG_DEV int next() {  // code 0..4, or -1 at the end
     for (;;) {
-      if (k < 0) return qpos < m ? (int)seq[qpos++] : -1;
+      if (k < 0) return qpos < m ? at(qpos++) : -1;
       u32 op = ops[k], p = op >> 4, kind = (op >> 2) & 3, c = op & 3;
       u32 upto = kind == OP_I ? p : p - 1;
-      if (qpos < upto) return (int)seq[qpos++];
+      if (qpos < upto) return at(qpos++);
       --k;
       qpos = p;
       if (kind != OP_D) return (int)c;
@@ -541,10 +551,11 @@ __global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Count
   if (ctr->overflow || t >= (u64)NSHARD * shard_cap || (u32)(t % shard_cap) >= ctr->leaf_cnt[t / shard_cap]) return;
   Leaf lf = in[t];
   const u64 q = lf.qs >> 1;
-  const u8* seq = ((lf.qs & 1) ? b.rv : b.fw) + b.qoff[q];
-  const u32 m = b.qlen[q];
+  const GidInfo gi = b.ginfo[lf.qs];  // one 16-byte record: length, and the packed query when it has no N and <= 32 nt
+  const u32 m = gi.m;
   LeafReader r;
-  r.init(seq, m, lf);
+  if ((gi.d_win & 256) && m <= 32) r.init_packed(gi.qpk, m, lf);
+  else r.init(((lf.qs & 1) ? b.rv : b.fw) + b.qoff[q], m, lf);
   u64 hi = 0, lo = 0;
   u32 len = 0;
   for (int c = r.next(); c >= 0; c = r.next()) {

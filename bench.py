@@ -122,9 +122,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fm9", default="", help="reuse an existing index file instead of building the synthetic one")
     ap.add_argument("--keep-index", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=2,
-                    help="extra measurement after the timed region (N=1 only): the same steps with this many batches in flight, "
-                         "one host thread + one handle on the shared index each (dg_index_share); 1 = skip")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="optional extra measurement after the timed region (N=1 only): the same steps with this many batches in "
+                         "flight, one host thread + one handle on the shared index each (dg_index_share).  Off by default so that "
+                         "a kernel trace of the default run only holds launches that had the GPU to themselves")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--same-device", action="store_true",
                     help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")

@@ -957,7 +957,8 @@ struct VerifyArgs {
 
 // SMALL = true (all queries of the batch <= 32 nt): the DP row lives in registers (columns fully unrolled) and each
 // row's trace is one 64-bit word (2 bits per column 1..32; column 0 is implied: vertical below the origin).
-template <u32 TRACE_WORDS, bool SMALL>
+// SMALL: queries of at most NCOLS (24 or 32) characters: score row, query and window live in registers.
+template <u32 TRACE_WORDS, bool SMALL, int NCOLS = 32>
 __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a, Counters* ctr) {
   u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 nh = *a.nhits;
@@ -1022,16 +1023,49 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
   u32 tl = 0;
   const u32 S = a.stride;
   if (SMALL) {
-    constexpr int NC = 32;
+    constexpr int NC = NCOLS;
     int s[NC + 1];
     u8 qc[NC];
     u64 tr[NC + 3 * DMAX + 2];
 #pragma unroll
     for (int c = 0; c < NC; ++c) qc[c] = (u32)c < n ? ascii_of(qseq[c]) : 0;
+    // The window (<= NC + 3*DMAX bytes) and the query are packed into registers once, eight characters per word: the DP
+    // rows and the row-writing pass below then take their characters with shifts instead of one dependent load each.
+    constexpr int GW = (NC + 3 * DMAX + 7) / 8;
+    u64 gw[GW], qw[NC / 8];
+#pragma unroll
+    for (int w = 0; w < GW; ++w) {
+      u64 v = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((u32)(8 * w + k) < mg) v |= (u64)g[8 * w + k] << (8 * k);
+      gw[w] = v;
+    }
+#pragma unroll
+    for (int w = 0; w < NC / 8; ++w) {
+      u64 v = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v |= (u64)qc[8 * w + k] << (8 * k);
+      qw[w] = v;
+    }
+    auto g_at = [&](u32 i) -> u32 {
+      u64 w = gw[0];
+#pragma unroll
+      for (int k = 1; k < GW; ++k)
+        if ((i >> 3) == (u32)k) w = gw[k];
+      return (u32)(w >> (8 * (i & 7))) & 255u;
+    };
+    auto q_at = [&](u32 i) -> u32 {
+      u64 w = qw[0];
+#pragma unroll
+      for (int k = 1; k < NC / 8; ++k)
+        if ((i >> 3) == (u32)k) w = qw[k];
+      return (u32)(w >> (8 * (i & 7))) & 255u;
+    };
 #pragma unroll
     for (int c = 0; c <= NC; ++c) s[c] = -c;
     for (u32 row = 1; row <= mg; ++row) {
-      const u8 gc = g[row - 1];
+      const u8 gc = (u8)g_at(row - 1);
       int diag = 0;  // cell (row-1, 0); s[0] stays 0: vertical gaps are free in column 0
       u64 bits = 0;
 #pragma unroll
@@ -1089,15 +1123,15 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
       char r0, r1;
       if (code == 1) {
         r0 = '-';
-        r1 = (char)ascii_of(qseq[c]);  // (qc[] is indexed with constants only, so that it stays in registers)
+        r1 = (char)q_at(c);
         ++c;
       } else if (code == 2) {
-        r0 = (char)g[r];
+        r0 = (char)g_at(r);
         r1 = '-';
         ++r;
       } else {
-        r0 = (char)g[r];
-        r1 = (char)ascii_of(qseq[c]);
+        r0 = (char)g_at(r);
+        r1 = (char)q_at(c);
         ++r;
         ++c;
       }
@@ -1469,7 +1503,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
-      if (maxlen <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      if (maxlen <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 24>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      else if (maxlen <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 32>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else if (cells <= 32 * 160) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
     }

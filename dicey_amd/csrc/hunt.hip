@@ -1032,7 +1032,8 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
     // The window (<= NC + 3*DMAX bytes) and the query are packed into registers once, eight characters per word: the DP
     // rows and the row-writing pass below then take their characters with shifts instead of one dependent load each.
     constexpr int GW = (NC + 3 * DMAX + 7) / 8;
-    u64 gw[GW], qw[NC / 8];
+    constexpr int QW = (NC + 7) / 8;
+    u64 gw[GW], qw[QW];
 #pragma unroll
     for (int w = 0; w < GW; ++w) {
       u64 v = 0;
@@ -1042,10 +1043,11 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
       gw[w] = v;
     }
 #pragma unroll
-    for (int w = 0; w < NC / 8; ++w) {
+    for (int w = 0; w < QW; ++w) {
       u64 v = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v |= (u64)qc[8 * w + k] << (8 * k);
+      for (int k = 0; k < 8; ++k)
+        if (8 * w + k < NC) v |= (u64)qc[8 * w + k] << (8 * k);
       qw[w] = v;
     }
     auto g_at = [&](u32 i) -> u32 {
@@ -1058,7 +1060,7 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
     auto q_at = [&](u32 i) -> u32 {
       u64 w = qw[0];
 #pragma unroll
-      for (int k = 1; k < NC / 8; ++k)
+      for (int k = 1; k < QW; ++k)
         if ((i >> 3) == (u32)k) w = qw[k];
       return (u32)(w >> (8 * (i & 7))) & 255u;
     };

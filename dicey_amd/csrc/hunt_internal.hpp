@@ -27,6 +27,8 @@ struct Batch {  // device pointers of one batch
   u64 max_locations;
   u32 max_neighborhood;  // neighbors()' cap (hunter.h:334)
   u32* refused;          // counter of queries whose neighbourhood could reach the cap (see k_prepare)
+  u32 maxlen_bound;      // the host sized the batch for queries up to this length ...
+  u32* too_long;         // ... k_prepare counts the ones that are longer (only possible when the host trusted a cached bound)
   struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
 };
 struct GidInfo {

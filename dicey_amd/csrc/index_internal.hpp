@@ -18,6 +18,11 @@ struct dg_index {
   hipEvent_t ev[8] = {nullptr};
   uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
   uint64_t hit_cap_hint = 0;
+  // dg_hunt_device: the (offsets pointer, count, bytes) of the previous call and the longest query it held; a repeated
+  // call skips reading the offsets back, and k_prepare reports any query longer than this bound (hunt.hip)
+  const void* last_qoff = nullptr;
+  uint64_t last_nq = 0, last_total = 0;
+  uint32_t last_maxlen = 0;
   void* pinned = nullptr;             // 4 KB of pinned host memory for the end-of-batch summary
   std::vector<uint64_t> cum_cache;    // cumulative sequence starts currently resident in WS_CUM
   ~dg_index();

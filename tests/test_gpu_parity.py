@@ -293,3 +293,38 @@ def test_randomised_configurations_against_oracle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_hunt.py"), "7", "12"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-1500:]
     assert "failing configurations: 0" in r.stdout, r.stdout[-1500:]
+
+
+def test_device_entry_point_rechecks_a_cached_length_bound(gpu_small, small_genome):
+    """dg_hunt_device skips reading the offsets back when buffer, count and byte total repeat; offsets rewritten in place
+    with a longer query are caught on the device and the batch is redone."""
+    import ctypes as C
+    from dicey_amd import _capi
+    L = _capi.load()
+    s = small_genome["seqs"]
+    qa = [s[0][100:120], s[1][200:220], s[2][300:320]]          # 20 + 20 + 20
+    qb = [s[0][100:112], s[1][200:236], s[2][300:312]]          # 12 + 36 + 12: same count, same byte total
+    sl = (C.c_uint32 * 3)(*small_genome["seqlen"])
+    p = _capi.HuntParams(1, 0, 0, 1000, 10000)
+    d_q = torch.zeros(60, dtype=torch.uint8, device="cuda")
+    d_off = torch.zeros(4, dtype=torch.int64, device="cuda")
+
+    def run(qs):
+        d_q.copy_(torch.frombuffer(bytearray("".join(qs).encode()), dtype=torch.uint8))
+        off = [0]
+        for q in qs:
+            off.append(off[-1] + len(q))
+        d_off.copy_(torch.tensor(off, dtype=torch.int64))
+        torch.cuda.synchronize()
+        rp = C.POINTER(_capi.HuntResult)()
+        _capi.check(L, L.dg_hunt_device(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()),
+                                        3, 60, 1, C.byref(rp)))
+        R = rp.contents
+        out = [(R.hits[i].query, R.hits[i].chr, R.hits[i].start, R.hits[i].score) for i in range(R.nhits)]
+        L.dg_hunt_result_free(rp)
+        return out
+
+    first = run(qa)
+    assert run(qa) == first and len(first) >= 3          # second call: cached bound, same answer
+    want = [(i, h.chr, h.start, h.score) for i, q in enumerate(gpu_small.hunt(qb, small_genome["seqlen"]).queries) for h in q.hits]
+    assert run(qb) == want and any(h[0] == 1 for h in want)   # the 36-mer exceeds the cached 20: detected, redone

@@ -150,7 +150,9 @@ void dg_hunt_result_free(dg_hunt_result* r);
 
 /* Device-resident entry point used by bench.py: d_qbytes / d_qoff are HIP device pointers on the index's device.
  * The result stays in HBM; only the counters/timings and nhits are copied back.  `fetch` != 0 additionally
- * copies hits to host like dg_hunt. */
+ * copies hits to host like dg_hunt.  The offsets are read back once to size the batch; a repeated call with the same
+ * d_qoff, nq and total_qbytes reuses that bound, and the kernels report any query that exceeds it (the call then reads
+ * the offsets again by itself), so the buffers may be refilled in place between calls. */
 int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
                    const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out);
 

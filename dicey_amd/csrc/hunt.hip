@@ -1290,7 +1290,7 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const u32* in, u64 n, const 
   }
 }
 
-static int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* tmp) {
+int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* tmp) {
   static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
   if (!lane_only && n <= ((u64)1 << 24)) {
     const u32 tiles = (u32)((n + SCAN_TILE) / SCAN_TILE);  // covers index n as well

@@ -89,6 +89,8 @@ struct SearchExtra {  // set by dg_search_sites: replace the verify stage by k_s
 int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes, const void* d_qoff,
               size_t nq, u64 total, u32 maxlen, int fetch, dg_hunt_result** out, SearchExtra* sx = nullptr,
               uint64_t* group_counts = nullptr);
+// hunt.hip: exclusive prefix sums of n 32-bit counts into 64-bit offsets (out[n] = total); tmp: n/64 + 64 words
+int device_scan(hipStream_t st, const u32* in, u64 n, u64* out, u64* tmp);
 // search.hip: launches k_site over the located hits (capacity hit_cap) and fills sx's result pointers
 int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSeed* seeds, const u64* hit_off, u64 hit_cap,
                       const u64* cum, u32 nseq, u32 dmax_eff, u32 maxlen, Counters* ctr);

@@ -356,6 +356,25 @@ __global__ void __launch_bounds__(1024) k_site_wave(FmView f, Batch b, SiteArgs 
   }
 }
 
+// Only hits whose Tm passes the cut (or whose thal() was refused: the reference's error flag) matter to the host: keep flag,
+// prefix sum, stable compaction of record + window, so that thousands instead of millions of records cross the bus.
+__global__ void k_site_keep(const SiteRaw* raw, u64 n, double cut, u32* keep) {
+  const u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n) return;
+  const double t = raw[h].temp;
+  keep[h] = (t > cut || t == -thal::kInf) ? 1u : 0u;
+}
+__global__ void k_site_compact(const SiteRaw* raw, const u8* win, u32 stride, const u32* keep, const u64* pos, u64 n, SiteRaw* oraw,
+                               u8* owin) {
+  const u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n || !keep[h]) return;
+  const u64 at = pos[h];
+  oraw[at] = raw[h];
+  const uint4* src = reinterpret_cast<const uint4*>(win + h * stride);  // stride is a multiple of 16
+  uint4* dst = reinterpret_cast<uint4*>(owin + at * stride);
+  for (u32 k = 0; k < stride / 16; ++k) dst[k] = src[k];
+}
+
 int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSeed* seeds, const u64* hit_off, u64 hit_cap,
                       const u64* cum, u32 nseq, u32 dmax_eff, u32 maxlen, Counters* ctr) {
   auto& ws = ix->ws;
@@ -536,25 +555,45 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   const u64 nhits = hr->nhits;
   const double ms_dev = hr->ms_total;
   dg_hunt_result_free(hr);
-  std::vector<u64> hoff(np + 1);
   std::vector<u32> qfl(np);
-  std::vector<SiteRaw> raw(nhits ? nhits : 1);
-  std::vector<u8> win((nhits ? nhits : 1) * (u64)sx.win_stride);
-  DG_HIP(hipMemcpyAsync(hoff.data(), sx.d_hit_off, (np + 1) * 8, hipMemcpyDeviceToHost, st));
   DG_HIP(hipMemcpyAsync(qfl.data(), sx.d_qflags, np * 4, hipMemcpyDeviceToHost, st));
+  // stable compaction on the device (debugging aid DICEY_DEBUG_DUMP_RAW keeps every record)
+  const char* dump = std::getenv("DICEY_DEBUG_DUMP_RAW");
+  u64 nkeep = 0;
+  std::vector<SiteRaw> raw;
+  std::vector<u8> win;
   if (nhits) {
-    DG_HIP(hipMemcpyAsync(raw.data(), sx.d_sites, nhits * sizeof(SiteRaw), hipMemcpyDeviceToHost, st));
-    DG_HIP(hipMemcpyAsync(win.data(), sx.d_windows, nhits * (u64)sx.win_stride, hipMemcpyDeviceToHost, st));
+    const u64 scan_words = nhits / 64 + nhits / 4096 + 64;
+    DG_TRY(ws[WS_LEAF].reserve(nhits * 4 + (nhits + 1 + scan_words) * 8 + 64));
+    DG_TRY(ws[WS_LEAFG].reserve(nhits * sizeof(SiteRaw)));
+    DG_TRY(ws[WS_SEL].reserve(nhits * (u64)sx.win_stride));
+    u64* pos = ws[WS_LEAF].as<u64>();
+    u64* tmp = pos + nhits + 1;
+    u32* keep = (u32*)(tmp + scan_words);
+    const dim3 g1(ceil_div(nhits, 256)), b1(256);
+    hipLaunchKernelGGL(k_site_keep, g1, b1, 0, st, (const SiteRaw*)sx.d_sites, nhits, dump ? -1e300 : p->cut_temp, keep);
+    DG_TRY(device_scan(st, keep, nhits, pos, tmp));
+    hipLaunchKernelGGL(k_site_compact, g1, b1, 0, st, (const SiteRaw*)sx.d_sites, (const u8*)sx.d_windows, sx.win_stride, (const u32*)keep,
+                       (const u64*)pos, nhits, ws[WS_LEAFG].as<SiteRaw>(), ws[WS_SEL].as<u8>());
+    DG_HIP(hipMemcpyAsync(&nkeep, pos + nhits, 8, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipStreamSynchronize(st));
+    raw.resize(nkeep);
+    win.resize(nkeep * (u64)sx.win_stride);
+    if (nkeep) {
+      DG_HIP(hipMemcpyAsync(raw.data(), ws[WS_LEAFG].p, nkeep * sizeof(SiteRaw), hipMemcpyDeviceToHost, st));
+      DG_HIP(hipMemcpyAsync(win.data(), ws[WS_SEL].p, nkeep * (u64)sx.win_stride, hipMemcpyDeviceToHost, st));
+    }
   }
   DG_HIP(hipStreamSynchronize(st));
-  if (const char* dump = std::getenv("DICEY_DEBUG_DUMP_RAW")) {  // debugging aid: per-hit records for tools/diff_raw.py
+  DG_HIP(hipGetLastError());
+  if (dump) {  // per-hit records for tools/diff_raw.py
     if (FILE* fp = std::fopen(dump, "wb")) {
-      std::fwrite(raw.data(), sizeof(SiteRaw), nhits, fp);
+      std::fwrite(raw.data(), sizeof(SiteRaw), raw.size(), fp);
       std::fclose(fp);
     }
     const std::string wp = std::string(dump) + ".win";
     if (FILE* fp = std::fopen(wp.c_str(), "wb")) {
-      std::fwrite(win.data(), sx.win_stride, nhits, fp);
+      std::fwrite(win.data(), sx.win_stride, raw.size(), fp);
       std::fclose(fp);
     }
   }
@@ -589,48 +628,55 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   for (size_t q = 0; q < np; ++q) {
     u32 fl = qfl[q] & DG_Q_MAX_MATCHES;
     if (R->match_temp[q] == -thal::kInf) fl |= DG_P_THAL_FAILED;
+    R->pflags[q] = fl;
+  }
+  std::set<std::pair<u32, u32>> seen[2];  // silica.h:465 TUniquePrimerHits, one per strand, per primer
+  size_t cur = (size_t)-1;
+  for (u64 h = 0; h < raw.size(); ++h) {  // records arrive primer by primer, in hit order
+    const SiteRaw& r = raw[h];
+    const size_t q = r.qs >> 1;
+    if (q != cur) {
+      seen[0].clear();
+      seen[1].clear();
+      cur = q;
+    }
     const u32 plen = (u32)(poff[q + 1] - poff[q]);
-    std::set<std::pair<u32, u32>> seen[2];  // silica.h:465 TUniquePrimerHits, one per strand
-    for (u64 h = hoff[q]; h < hoff[q + 1]; ++h) {
-      const SiteRaw& r = raw[h];
-      const u32 fr = r.qs & 1;
-      if (r.temp == -thal::kInf) {
-        fl |= DG_P_THAL_FAILED;
-        continue;
-      }
-      if (!(r.temp > p->cut_temp)) continue;
-      std::pair<u32, u32> key(r.ref, r.alignpos);
-      if (!seen[fr].insert(key).second) continue;
-      const char* g = (const char*)win.data() + h * (u64)sx.win_stride;
-      u32 glen = std::min<u32>(r.glen, sx.win_stride);
-      u32 chrpos, goff = 0, gl = glen;
-      u32 alignshift = r.alignpos - r.chrpos;
-      if (fr) {
-        chrpos = r.alignpos;
+    const u32 fr = r.qs & 1;
+    if (r.temp == -thal::kInf) {
+      R->pflags[q] |= DG_P_THAL_FAILED;
+      continue;
+    }
+    if (!(r.temp > p->cut_temp)) continue;
+    std::pair<u32, u32> key(r.ref, r.alignpos);
+    if (!seen[fr].insert(key).second) continue;
+    const char* g = (const char*)win.data() + h * (u64)sx.win_stride;
+    u32 glen = std::min<u32>(r.glen, sx.win_stride);
+    u32 chrpos, goff = 0, gl = glen;
+    u32 alignshift = r.alignpos - r.chrpos;
+    if (fr) {
+      chrpos = r.alignpos;
+      goff = std::min(alignshift, glen);
+      gl = std::min<u32>(plen, glen - goff);
+    } else {
+      chrpos = r.alignpos - koff[q];
+      if (alignshift >= koff[q]) {
+        alignshift -= koff[q];
         goff = std::min(alignshift, glen);
         gl = std::min<u32>(plen, glen - goff);
-      } else {
-        chrpos = r.alignpos - koff[q];
-        if (alignshift >= koff[q]) {
-          alignshift -= koff[q];
-          goff = std::min(alignshift, glen);
-          gl = std::min<u32>(plen, glen - goff);
-        }
       }
-      dg_site sgl;
-      std::memset(&sgl, 0, sizeof sgl);
-      sgl.ref = r.ref;
-      sgl.pos = chrpos;
-      sgl.primer = (u32)q;
-      sgl.on_for = fr ? 0 : 1;
-      sgl.temp = r.temp;
-      sgl.perf_temp = R->match_temp[q];
-      sgl.genome_off = pool.size();
-      sgl.genome_len = gl;
-      pool.append(g + goff, gl);
-      sites.push_back(sgl);
     }
-    R->pflags[q] = fl;
+    dg_site sgl;
+    std::memset(&sgl, 0, sizeof sgl);
+    sgl.ref = r.ref;
+    sgl.pos = chrpos;
+    sgl.primer = (u32)q;
+    sgl.on_for = fr ? 0 : 1;
+    sgl.temp = r.temp;
+    sgl.perf_temp = R->match_temp[q];
+    sgl.genome_off = pool.size();
+    sgl.genome_len = gl;
+    pool.append(g + goff, gl);
+    sites.push_back(sgl);
   }
   R->nsites = sites.size();
   R->sites = new dg_site[sites.size() ? sites.size() : 1];

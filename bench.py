@@ -211,13 +211,12 @@ def main():
             hb = device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), dev)
             ra = device_bytes(R.d_refalign, R.nhits * R.aln_stride, dev)
             qa = device_bytes(R.d_queryalign, R.nhits * R.aln_stride, dev)
-            payload = torch.cat([hb, ra, qa])  # staged copy: the library reuses its buffers in the next step
-            torch.cuda.current_stream().synchronize()  # ...which runs on the library's own stream: the copy must be done first
-            if a.backend != "nccl":
-                payload = payload.cpu()
+            parts = [hb, ra, qa]  # views of the library's buffers, copied straight into the gather's staging buffer
             if pipe["g"] is None:  # first (warm-up) step: agree on a capacity once
-                pipe["g"] = PipelinedGather(int(payload.numel() * 1.25) + 4096, payload.device)
-            pipe["g"].submit(payload)
+                nbytes = sum(int(t.numel()) for t in parts)
+                pipe["g"] = PipelinedGather(int(nbytes * 1.25) + 4096, dev if a.backend == "nccl" else torch.device("cpu"))
+            pipe["g"].submit(parts)
+            torch.cuda.current_stream().synchronize()  # the library reuses its buffers in the next step, on its own stream
         L.dg_hunt_result_free(rp)
         return res
 

@@ -78,14 +78,20 @@ class PipelinedGather:
                 for buf in self.recv[slot]:
                     self.bytes_received += int(buf[:8].view(torch.int64).item())
 
-    def submit(self, payload: torch.Tensor):
-        if payload.numel() > self.cap:
-            raise RuntimeError(f"payload of {payload.numel()} bytes exceeds the agreed capacity {self.cap}")
+    def submit(self, payload):
+        """payload: a uint8 tensor, or a sequence of them (copied one after the other: no concatenated temporary)."""
+        parts = [payload] if isinstance(payload, torch.Tensor) else list(payload)
+        total = sum(int(t.numel()) for t in parts)
+        if total > self.cap:
+            raise RuntimeError(f"payload of {total} bytes exceeds the agreed capacity {self.cap}")
         slot = self.n % self.depth
         self._drain(slot)
         buf = self.send[slot]
-        buf[:8] = torch.tensor([payload.numel()], dtype=torch.int64).view(torch.uint8).to(buf.device, non_blocking=True)
-        buf[8:8 + payload.numel()] = payload
+        buf[:8] = torch.tensor([total], dtype=torch.int64).view(torch.uint8).to(buf.device, non_blocking=True)
+        at = 8
+        for t in parts:
+            buf[at:at + t.numel()] = t.to(buf.device, non_blocking=True) if t.device != buf.device else t
+            at += int(t.numel())
         self.work[slot] = dist.gather(buf, self.recv[slot] if self.rank == self.dst else None, dst=self.dst, group=self.group,
                                       async_op=True)
         self.n += 1

@@ -83,7 +83,8 @@ SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_
            "dg_extract", "dg_hunt", "dg_hunt_result_free", "dg_hunt_device", "dg_index_build",
            "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
            "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
-           "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free", "dg_index_share"]
+           "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free", "dg_index_share",
+           "dg_neighbors", "dg_buffer_free"]
 
 _lib = None
 
@@ -136,6 +137,9 @@ def load(path=None):
                                   C.POINTER(C.POINTER(SearchResult))]
     L.dg_search_result_free.argtypes = [C.POINTER(SearchResult)]
     L.dg_search_result_free.restype = None
+    L.dg_neighbors.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(vp), u64p, C.POINTER(C.c_int)]
+    L.dg_buffer_free.argtypes = [vp]
+    L.dg_buffer_free.restype = None
     if path is None:
         _lib = L
     return L

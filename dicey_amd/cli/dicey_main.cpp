@@ -558,6 +558,10 @@ int silica(int argc, char** argv) {
         dg_search_result_free(R);
         return finish(1);
       }
+      if (R->pflags[q] & DG_Q_NBHD_EXCEEDED) {  // silica.h:457-460
+        std::string x = std::to_string(c.maxNeighborhood);
+        msg.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x + " neighbors are searched, results are likely incomplete!");
+      }
       for (; si < R->nsites && R->sites[si].primer == q; ++si) {
         const dg_site& s = R->sites[si];
         PrimerBind b;

@@ -15,15 +15,19 @@
 // language L.  A non-minimal string that occurs implies its minimal substring occurs too, hence
 // M ∩ Occ = minimal elements of (L ∩ Occ); and every string reachable with fewer than d edits is dominated by the
 // same string minus its first character, so only cost-exactly-d leaves can be minimal (DESIGN.md §"neighbourhood").
-// This holds while the maxNeighborhood cap cannot fire; dg_hunt refuses (DG_ELIMIT) inputs where it could.
+// This holds while the maxNeighborhood cap cannot fire.  Queries for which it could are enumerated on the host in the
+// reference's own generation order (nbhd_host.hpp); when the cap stays silent the kernel's set is the reference's, and
+// when it fires the capped set enters the pipeline as explicit patterns (k_explicit) next to k_search's leaves.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <set>
-
 #include <string>
+#include <thread>
 
 #include "hunt_internal.hpp"
 #include "iupac.hpp"
+#include "nbhd_host.hpp"
 
 namespace dg {
 
@@ -112,12 +116,13 @@ __global__ void k_prepare(Batch b) {
     d = m - 1;
     flags |= DG_Q_DIST_ADJUSTED;
   }
-  // a query with N's has a larger neighbourhood than the host could know from the lengths alone: if the cap could fire for
-  // it, the reference's answer depends on its recursion order, which this kernel does not reproduce -> refuse the batch
-  if (bad && m >= 10 && neighbourhood_bound(m, d, b.indel != 0, bad) >= b.max_neighborhood) {
-    flags |= DG_Q_NBHD_EXCEEDED;
-    atomicAdd(b.refused, 1u);
-  }
+  // If the cap could fire for a query, the reference's answer depends on its generation order, which k_search does not
+  // reproduce: the host has enumerated such queries beforehand (qmode).  A query that could reach the cap without the host
+  // having looked at it is a bookkeeping error of this library and stops the batch.
+  const u32 mode = b.qmode ? b.qmode[q] : (u32)QM_KERNEL;
+  const bool explicit_set = (mode & 15u) == QM_EXPLICIT;
+  if ((mode & 15u) == QM_KERNEL && m >= 10 && neighbourhood_bound(m, d, b.indel != 0, bad) >= b.max_neighborhood) atomicAdd(b.refused, 1u);
+  if ((mode & QM_FIRED) && m >= 10) flags |= DG_Q_NBHD_EXCEEDED;  // hunter.h:342-345
   b.qlen[q] = m;
   b.qdist[q] = d;
   b.qflags[q] = flags;
@@ -125,7 +130,7 @@ __global__ void k_prepare(Batch b) {
   for (u32 strand = 0; strand < 2; ++strand) {
     GidInfo gi;
     gi.qpk = 0;
-    gi.m = ((flags & (DG_Q_TOO_SHORT | DG_Q_NBHD_EXCEEDED)) || (strand && !b.reverse) || m > b.maxlen_bound) ? 0u : m;
+    gi.m = ((flags & DG_Q_TOO_SHORT) || explicit_set || (strand && !b.reverse) || m > b.maxlen_bound) ? 0u : m;
     gi.d_win = d | (bad == 0 ? 256u : 0u);
     if (bad == 0 && m <= 32) {
       const u8* sq = (strand ? b.rv : b.fw) + s;
@@ -379,6 +384,40 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
 }
 
+// Explicit patterns (the host-enumerated capped neighbourhoods): one lane per string, plain backward search right to
+// left (sdsl::count, hunter.h:353); occurring strings become leaves of their (query, strand) group like k_search's.
+__global__ void __launch_bounds__(256) k_explicit(FmView f, Batch b, SearchOut o) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 steps = 0;
+  if (i < b.nxs) {
+    const u64 s = b.xs_off[i], e = b.xs_off[i + 1];
+    u32 lo = 0, hi = (u32)f.n;
+    for (u64 k = e; k > s && lo < hi; --k) {
+      const u32 code = b.xs_bytes[k - 1];
+      bs_extend_sym(f, lo, hi, 'N', code);
+      ++steps;
+    }
+    if (lo < hi) {
+      const u32 gid = b.xs_gid[i];
+      const u32 shard = blockIdx.x & (NSHARD - 1);
+      const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+      const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+      if (at < o.shard_cap) {
+        Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+        lf->qs = gid;
+        lf->slot = slot;
+        lf->lo = lo;
+        lf->hi = hi;
+        lf->nops = LEAF_EXPLICIT;
+        lf->ops[0] = (u32)i;
+#pragma unroll
+        for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+      }
+    }
+  }
+  wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
+}
+
 __global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap) {  // NSHARD lanes
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < NSHARD && ctr->leaf_cnt[k] > shard_cap) atomicOr(&ctr->overflow, 1u);
@@ -462,6 +501,14 @@ struct LeafReader {
     k = (int)lf.nops - 1;
     qpos = 0;
   }
+  // any leaf of the batch: an explicit pattern reads its own bytes, everything else the query + recorded edits
+  DG_DEV void init_any(const Batch& b, const u8* s, u32 m_, const Leaf& lf) {
+    if (lf.nops == LEAF_EXPLICIT) {
+      const u64 x0 = b.xs_off[lf.ops[0]];
+      init(b.xs_bytes + x0, (u32)(b.xs_off[lf.ops[0] + 1] - x0), lf);
+      k = -1;
+    } else init(s, m_, lf);
+  }
   DG_DEV void init_packed(u64 q, u32 m_, const Leaf& lf) {
     init(nullptr, m_, lf);
     qpk = q;
@@ -480,7 +527,8 @@ struct LeafReader {
     }
   }
 };
-DG_DEV u32 leaf_len(u32 m, const Leaf& lf) {
+DG_DEV u32 leaf_len(const Batch& b, u32 m, const Leaf& lf) {
+  if (lf.nops == LEAF_EXPLICIT) return (u32)(b.xs_off[lf.ops[0] + 1] - b.xs_off[lf.ops[0]]);
   u32 len = m;
   for (u32 k = 0; k < lf.nops; ++k) {
     u32 kind = (lf.ops[k] >> 2) & 3;
@@ -490,12 +538,12 @@ DG_DEV u32 leaf_len(u32 m, const Leaf& lf) {
   return len;
 }
 // is string(b) found inside string(a)?  (std::string::find, neighbors.h:37,39)
-DG_DEV bool leaf_contains(const u8* seq, u32 m, const Leaf& a, u32 la, const Leaf& b, u32 lb) {
+DG_DEV bool leaf_contains(const Batch& bt, const u8* seq, u32 m, const Leaf& a, u32 la, const Leaf& b, u32 lb) {
   if (lb > la) return false;
   for (u32 o = 0; o + lb <= la; ++o) {
     LeafReader ra, rb;
-    ra.init(seq, m, a);
-    rb.init(seq, m, b);
+    ra.init_any(bt, seq, m, a);
+    rb.init_any(bt, seq, m, b);
     for (u32 i = 0; i < o; ++i) (void)ra.next();
     bool same = true;
     for (u32 i = 0; i < lb; ++i)
@@ -508,10 +556,10 @@ DG_DEV bool leaf_contains(const u8* seq, u32 m, const Leaf& a, u32 la, const Lea
   return false;
 }
 // std::string operator< on the ASCII strings
-DG_DEV bool leaf_less(const u8* seq, u32 m, const Leaf& a, const Leaf& b) {
+DG_DEV bool leaf_less(const Batch& bt, const u8* seq, u32 m, const Leaf& a, const Leaf& b) {
   LeafReader ra, rb;
-  ra.init(seq, m, a);
-  rb.init(seq, m, b);
+  ra.init_any(bt, seq, m, a);
+  rb.init_any(bt, seq, m, b);
   for (;;) {
     int x = ra.next(), y = rb.next();
     if (x < 0 || y < 0) return x < 0 && y >= 0;
@@ -557,7 +605,8 @@ __global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Count
   const GidInfo gi = b.ginfo[lf.qs];  // one 16-byte record: length, and the packed query when it has no N and <= 32 nt
   const u32 m = gi.m;
   LeafReader r;
-  if ((gi.d_win & 256) && m <= 32) r.init_packed(gi.qpk, m, lf);
+  if (lf.nops == LEAF_EXPLICIT) r.init_any(b, nullptr, 0, lf);
+  else if ((gi.d_win & 256) && m <= 32) r.init_packed(gi.qpk, m, lf);
   else r.init(((lf.qs & 1) ? b.rv : b.fw) + b.qoff[q], m, lf);
   u64 hi = 0, lo = 0;
   u32 len = 0;
@@ -766,14 +815,14 @@ __global__ void k_select(Batch b, const Leaf* grouped, const u64* grp_off, Sel* 
     u32* rank = scratch_rank + g0;
     // keep[i] <=> no other occurring string is a proper substring of it, and it is the first copy of itself
     for (u32 i = 0; i < k; ++i) {
-      u32 li = leaf_len(m, G[i]);
+      u32 li = leaf_len(b, m, G[i]);
       bool alive = true;
       if (b.indel) {
         for (u32 j = 0; j < k && alive; ++j) {
           if (j == i) continue;
-          u32 lj = leaf_len(m, G[j]);
+          u32 lj = leaf_len(b, m, G[j]);
           if (lj > li) continue;
-          if (leaf_contains(seq, m, G[i], li, G[j], lj)) alive = (lj == li) && (i < j);  // equal strings: lowest slot stays
+          if (leaf_contains(b, seq, m, G[i], li, G[j], lj)) alive = (lj == li) && (i < j);  // equal strings: lowest slot stays
         }
       }
       keep[i] = alive;
@@ -784,7 +833,7 @@ __global__ void k_select(Batch b, const Leaf* grouped, const u64* grp_off, Sel* 
       if (!keep[i]) continue;
       u32 r = 0;
       for (u32 j = 0; j < k; ++j)
-        if (j != i && keep[j] && leaf_less(seq, m, G[j], G[i])) ++r;
+        if (j != i && keep[j] && leaf_less(b, seq, m, G[j], G[i])) ++r;
       rank[i] = r;
       ++ns;
     }
@@ -794,7 +843,7 @@ __global__ void k_select(Batch b, const Leaf* grouped, const u64* grp_off, Sel* 
         Sel s;
         s.lo = G[i].lo;
         s.hi = G[i].hi;
-        s.len = leaf_len(m, G[i]);
+        s.len = leaf_len(b, m, G[i]);
         s.take = 0;
         s.hbase = 0;
         S[rank[i]] = s;
@@ -1310,29 +1359,110 @@ int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* t
   return DG_OK;
 }
 
+// Host pass over the queries whose neighbourhood could reach the cap (neighbors.h:50): the reference's enumeration is
+// run for both strands (nbhd_host.hpp).  mode[q] and the explicit patterns of the queries where the cap fired come back.
+struct CapScan {
+  std::vector<u8> mode;      // per query, QM_*; empty = no query needed a look
+  std::vector<u8> xs_bytes;  // codes 0..4
+  std::vector<u64> xs_off;
+  std::vector<u32> xs_gid;
+  u64 looked_at = 0, fired = 0;
+};
+static void cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_params* p, bool count_mode, CapScan& cs) {
+  const bool indel = !p->hamming;
+  struct Job {
+    size_t q;
+    std::string fw, rv;
+    u32 d;
+    std::vector<std::string> set[2];
+    bool fired[2] = {false, false};
+  };
+  std::vector<Job> jobs;
+  for (size_t q = 0; q < nq; ++q) {
+    const u64 s = qoff[q], m = qoff[q + 1] - s;
+    if (m < 10 && !count_mode) continue;  // hunter.h:299: not searched at all
+    u32 d = p->distance, bad = 0;
+    if (d >= m) d = (u32)m - 1;  // hunter.h:312-315
+    for (u64 i = 0; i < m; ++i) {
+      u8 ch = qbytes[s + i];
+      if (ch >= 'a' && ch <= 'z') ch -= 32;
+      bad += !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+    }
+    if (neighbourhood_bound((u32)m, d, indel, bad) < p->max_neighborhood) continue;
+    Job j;
+    j.q = q;
+    j.d = d;
+    j.fw.resize(m);
+    j.rv.resize(m);
+    for (u64 i = 0; i < m; ++i) {  // boost::to_upper_copy + replaceNonDna + reverseComplement (hunter.h:306-309)
+      u8 ch = qbytes[s + i];
+      if (ch >= 'a' && ch <= 'z') ch -= 32;
+      const bool dna = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+      j.fw[i] = dna ? (char)ch : 'N';
+      j.rv[m - 1 - i] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : 'N';
+    }
+    jobs.push_back(std::move(j));
+  }
+  if (jobs.empty()) return;
+  const bool reverse = !p->forward_only;
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= jobs.size() * 2) return;
+      Job& j = jobs[k >> 1];
+      const int strand = (int)(k & 1);
+      if (strand && !reverse) continue;
+      bool fired = false;
+      j.set[strand] = CappedNeighborhood::enumerate(strand ? j.rv : j.fw, j.d, indel, p->max_neighborhood, fired);
+      j.fired[strand] = fired;
+    }
+  };
+  unsigned nthreads = std::thread::hardware_concurrency();
+  if (nthreads == 0) nthreads = 1;
+  nthreads = (unsigned)std::min<size_t>(std::min<unsigned>(nthreads, 64u), jobs.size() * 2);
+  if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthreads = (unsigned)std::max(1, std::atoi(e));
+  if (nthreads <= 1) work();
+  else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(work);
+    for (auto& t : pool) t.join();
+  }
+  cs.mode.assign(nq, (u8)QM_KERNEL);
+  cs.xs_off.assign(1, 0);
+  cs.looked_at = jobs.size();
+  for (Job& j : jobs) {
+    if (!j.fired[0] && !j.fired[1]) {
+      cs.mode[j.q] = QM_SILENT;
+      continue;
+    }
+    ++cs.fired;
+    cs.mode[j.q] = QM_EXPLICIT | QM_FIRED;
+    for (int strand = 0; strand < 2; ++strand)
+      for (const std::string& str : j.set[strand]) {
+        for (char ch : str) cs.xs_bytes.push_back(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4);
+        cs.xs_off.push_back(cs.xs_bytes.size());
+        cs.xs_gid.push_back((u32)(2 * j.q + strand));
+      }
+  }
+}
+
 // One batch through the five kernels.  All sizes that are only known on the device (number of leaves, number of hits)
 // are handled with capacity guesses that the kernels check themselves; the host synchronises ONCE at the end, and
 // repeats the batch with larger buffers in the rare case a capacity was exceeded.
 // group_counts != nullptr: count mode (`dicey padlock`, padlock.h:396-421) — stop after the select stage and return, per
 // (query, strand), the occurrences summed over the kept neighbourhood strings; no locate, no verify.
+// h_qbytes / h_qoff: the host copy of the queries when the caller has one (needed only when a neighbourhood could reach
+// the cap; read back from the device otherwise).
 int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
                      const void* d_qoff, size_t nq, u64 total, u32 maxlen, int fetch, dg_hunt_result** out, SearchExtra* sx,
-                     uint64_t* group_counts) {
-  if (!p->max_locations) return fail(DG_EINVAL, "max_locations must be positive");
+                     uint64_t* group_counts, const uint8_t* h_qbytes, const uint64_t* h_qoff) {
   if (nseq == 0) return fail(DG_EINVAL, "no reference sequences");
   const bool indel = !p->hamming;
   if (maxlen > MAX_QLEN) return fail(DG_ELIMIT, "query of %u nt exceeds the supported maximum of %u", maxlen, MAX_QLEN);
   u32 dmax_eff = p->distance;
   if (maxlen >= 1 && dmax_eff >= maxlen) dmax_eff = maxlen - 1;
   if (dmax_eff > DMAX) return fail(DG_ELIMIT, "distance %u exceeds the supported maximum of %u", p->distance, DMAX);
-  if (maxlen >= 10) {
-    u64 bound = neighbourhood_bound(maxlen, dmax_eff, indel);
-    if (bound >= p->max_neighborhood)
-      return fail(DG_ELIMIT,
-                  "cannot prove that the maxNeighborhood cap (%u) stays silent for %u-mers at distance %u (bound %llu); "
-                  "the reference's capped enumeration is order dependent and is not reproduced by this build",
-                  p->max_neighborhood, maxlen, dmax_eff, (unsigned long long)bound);
-  }
   DG_HIP(hipSetDevice(ix->device));
   hipStream_t st = ix->stream;
   for (int i = 0; i < 8; ++i)
@@ -1350,7 +1480,51 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   DG_TRY(ws[WS_GINFO].reserve(ngrp * sizeof(GidInfo) + 64));
   DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 2 + nq * 4 + scan_tmp * 8 + sizeof(Counters) + sizeof(Summary) + 512));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
+  // Could any query of this batch reach the cap?  (the bound grows with the length and with the number of N's)
+  CapScan cs;
+  if (maxlen >= 1 && neighbourhood_bound(maxlen, dmax_eff, indel, maxlen) >= p->max_neighborhood) {
+    std::vector<u8> hb;
+    std::vector<u64> ho;
+    if (!h_qbytes || !h_qoff) {
+      hb.resize(total + 1);
+      ho.resize(nq + 1);
+      if (total) DG_HIP(hipMemcpyAsync(hb.data(), d_qbytes, total, hipMemcpyDeviceToHost, st));
+      DG_HIP(hipMemcpyAsync(ho.data(), d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
+      DG_HIP(hipStreamSynchronize(st));
+      h_qbytes = hb.data();
+      h_qoff = ho.data();
+    }
+    cap_scan(h_qbytes, h_qoff, nq, p, group_counts != nullptr, cs);
+  }
+  const u64 nxs = cs.xs_gid.size();
+  if (nxs >= 0xFFFFFFFFull || cs.xs_bytes.size() > (48ull << 30))
+    return fail(DG_ELIMIT, "%llu explicit neighbourhood strings in one batch; pass fewer sequences per call", (unsigned long long)nxs);
+  u8* d_qmode = nullptr;
+  u8* d_xs_bytes = nullptr;
+  u64* d_xs_off = nullptr;
+  u32* d_xs_gid = nullptr;
+  if (!cs.mode.empty()) {
+    const u64 a0 = (nq + 63) & ~63ull, a1 = a0 + ((cs.xs_bytes.size() + 63) & ~63ull), a2 = a1 + (nxs + 1) * 8, a3 = a2 + nxs * 4;
+    DG_TRY(ws[WS_XS].reserve(a3 + 64));
+    u8* base = ws[WS_XS].as<u8>();
+    d_qmode = base;
+    d_xs_bytes = base + a0;
+    d_xs_off = (u64*)(base + a1);
+    d_xs_gid = (u32*)(base + a2);
+    DG_HIP(hipMemcpyAsync(d_qmode, cs.mode.data(), nq, hipMemcpyHostToDevice, st));
+    if (nxs) {
+      DG_HIP(hipMemcpyAsync(d_xs_bytes, cs.xs_bytes.data(), cs.xs_bytes.size(), hipMemcpyHostToDevice, st));
+      DG_HIP(hipMemcpyAsync(d_xs_gid, cs.xs_gid.data(), nxs * 4, hipMemcpyHostToDevice, st));
+    }
+    DG_HIP(hipMemcpyAsync(d_xs_off, cs.xs_off.data(), (nxs + 1) * 8, hipMemcpyHostToDevice, st));
+    DG_HIP(hipStreamSynchronize(st));  // the host vectors go out of use only after the copies
+  }
   Batch b;
+  b.qmode = d_qmode;
+  b.xs_bytes = d_xs_bytes;
+  b.xs_off = d_xs_off;
+  b.xs_gid = d_xs_gid;
+  b.nxs = nxs;
   b.qbytes = (const u8*)d_qbytes;
   b.qoff = (const u64*)d_qoff;
   b.nq = nq;
@@ -1405,7 +1579,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     ix->cum_cache = cum;
   }
 
-  u32 shard_cap = std::max<u32>(ix->shard_cap_hint, (u32)std::max<u64>(64, (16 * (u64)nq) / NSHARD));
+  u32 shard_cap = std::max<u32>(ix->shard_cap_hint, (u32)std::max<u64>(64, (16 * (u64)nq + nxs / 8) / NSHARD));
   u64 hit_cap = std::max<u64>(ix->hit_cap_hint, 4 * (u64)nq + 1024);
   if (const char* e = std::getenv("DICEY_DEBUG_CAPS")) {  // tests: start from tiny capacities to exercise the retry path
     shard_cap = (u32)std::max(1, std::atoi(e));
@@ -1449,6 +1623,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         else DG_LAUNCH_SEARCH(false, 4);
       }
 #undef DG_LAUNCH_SEARCH
+      if (nxs) hipLaunchKernelGGL(k_explicit, dim3(ceil_div(nxs, TB)), dim3(TB), 0, st, ix->view, b, so);
     }
     DG_HIP(hipEventRecord(ix->ev[2], st));
     hipLaunchKernelGGL(k_leaf_overflow, dim3(NSHARD / 256), dim3(256), 0, st, ctr, shard_cap);
@@ -1528,9 +1703,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipGetLastError());
     if (hsum.too_long) return fail(DG_EINVAL, "%llu queries are longer than the %u nt this batch was sized for", hsum.too_long, maxlen);
     if (hsum.refused)
-      return fail(DG_ELIMIT,
-                  "%llu quer%s of this batch hold N / non-DNA letters that make the neighbourhood large enough for the maxNeighborhood "
-                  "cap (%u) to fire; the reference's capped enumeration is order dependent and is not reproduced by this build",
+      return fail(DG_EINVAL, "internal error: %llu quer%s could reach the maxNeighborhood cap (%u) without having been enumerated on the host",
                   hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
     nleaf = hsum.nleaf;
     nhits = hsum.nhits;
@@ -1603,48 +1776,6 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
 
 using namespace dg;
 
-namespace {
-// neighbors() of the reference (src/neighbors.h:29-92) for the rare sequence the search kernel does not take: the <= d-edit
-// language over {A,C,G,T} edits (substitution by a different base, deletion, insertion before an existing character; at
-// least one edit, plus the sequence itself), of which edit mode keeps the strings that contain no other string of the
-// language and Hamming mode the strings of the original length within d mismatches.
-void host_language(const std::string& s, size_t pos, unsigned left, bool used, std::set<std::string>& out) {
-  if (pos >= s.size()) {
-    if (used) out.insert(s);
-    return;
-  }
-  if (left) host_language(s.substr(0, pos) + s.substr(pos + 1), pos, left - 1, true, out);
-  host_language(s, pos + 1, left, used, out);
-  if (left) {
-    for (char a : {'A', 'C', 'G', 'T'})
-      if (a != s[pos]) host_language(s.substr(0, pos) + a + s.substr(pos + 1), pos + 1, left - 1, true, out);
-    for (char a : {'A', 'C', 'G', 'T'}) host_language(s.substr(0, pos) + a + s.substr(pos), pos + 1, left - 1, true, out);
-  }
-}
-std::vector<std::string> host_neighbors(const std::string& q, unsigned d, bool indel) {
-  std::set<std::string> lang;
-  host_language(q, 0, d, false, lang);
-  lang.insert(q);
-  std::vector<std::string> out;
-  for (const std::string& s : lang) {
-    if (indel) {
-      bool minimal = true;
-      for (const std::string& t : lang)
-        if (t.size() < s.size() && s.find(t) != std::string::npos) {
-          minimal = false;
-          break;
-        }
-      if (minimal) out.push_back(s);
-    } else if (s.size() == q.size()) {
-      unsigned mm = 0;
-      for (size_t k = 0; k < s.size(); ++k) mm += s[k] != q[k];
-      if (mm <= d) out.push_back(s);
-    }
-  }
-  return out;
-}
-}  // namespace
-
 extern "C" {
 
 void dg_hunt_result_free(dg_hunt_result* r) {
@@ -1680,7 +1811,7 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
   DG_TRY(ix->ws[WS_QOFF].reserve((nq + 1) * 8));
   if (total) DG_HIP(hipMemcpyAsync(ix->ws[WS_QB].p, qbytes, total, hipMemcpyHostToDevice, ix->stream));
   DG_HIP(hipMemcpyAsync(ix->ws[WS_QOFF].p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
-  int rc = run_batch(ix, p, seqlen, nseq, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, 1, out);
+  int rc = run_batch(ix, p, seqlen, nseq, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, 1, out, nullptr, nullptr, qbytes, qoff);
   if (rc != DG_OK && *out) {
     dg_hunt_result_free(*out);
     *out = nullptr;
@@ -1712,12 +1843,6 @@ int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t
     maxlen = std::max<u32>(maxlen, (u32)l);
   }
   if (distance > DMAX) return fail(DG_ELIMIT, "distance %u exceeds the supported maximum of %u", distance, DMAX);
-  {
-    const u64 bound = neighbourhood_bound(maxlen, distance, !hamming);
-    if (bound >= max_neighborhood)
-      return fail(DG_ELIMIT, "cannot prove that the maxNeighborhood cap (%u) stays silent for %u-mers at distance %u (bound %llu)",
-                  max_neighborhood, maxlen, distance, (unsigned long long)bound);
-  }
   DG_HIP(hipSetDevice(ix->device));
   if (!fast.empty()) {
     std::string buf;
@@ -1739,7 +1864,8 @@ int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t
     const uint32_t one_seq = 1;  // chromosome lookup is not used in count mode
     std::vector<u64> counts(2 * fast.size());
     dg_hunt_result* hr = nullptr;
-    int rc = run_batch(ix, &hp, &one_seq, 1, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, fast.size(), buf.size(), maxlen, 0, &hr, nullptr, counts.data());
+    int rc = run_batch(ix, &hp, &one_seq, 1, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, fast.size(), buf.size(), maxlen, 0, &hr, nullptr, counts.data(),
+                       (const uint8_t*)buf.data(), off.data());
     if (hr) dg_hunt_result_free(hr);
     if (rc != DG_OK) return rc;
     for (size_t k = 0; k < fast.size(); ++k) {
@@ -1755,7 +1881,8 @@ int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t
       std::string fw((const char*)qbytes + qoff[i], qoff[i + 1] - qoff[i]), rv(fw.rbegin(), fw.rend());
       for (char& ch : rv) ch = complement_iupac(ch);
       for (size_t strand = 0; strand < 2; ++strand) {
-        for (const std::string& s : host_neighbors(strand ? rv : fw, distance, !hamming)) {
+        bool fired = false;  // the sums are taken over whatever the (possibly capped) reference set holds
+        for (const std::string& s : CappedNeighborhood::enumerate(strand ? rv : fw, distance, !hamming, max_neighborhood, fired)) {
           buf += s;
           off.push_back(buf.size());
           owner.emplace_back(i, strand);
@@ -1770,6 +1897,31 @@ int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t
   }
   return DG_OK;
 }
+
+int dg_neighbors(const uint8_t* seq, uint32_t len, uint32_t distance, int hamming, uint32_t max_neighborhood, char** out,
+                 uint64_t* count, int* cap_fired) {
+  if (!seq || !out) return fail(DG_EINVAL, "dg_neighbors: null argument");
+  *out = nullptr;
+  if (len == 0 || len > 0xFFFFFFu) return fail(DG_EINVAL, "dg_neighbors: sequence length %u", len);
+  bool fired = false;
+  const std::vector<std::string> set = CappedNeighborhood::enumerate(std::string((const char*)seq, len), distance, !hamming, max_neighborhood, fired);
+  size_t bytes = 1;
+  for (const std::string& s : set) bytes += s.size() + 1;
+  char* buf = (char*)std::malloc(bytes);
+  if (!buf) return fail(DG_ENOMEM, "dg_neighbors: out of memory");
+  char* w = buf;
+  for (const std::string& s : set) {
+    std::memcpy(w, s.data(), s.size());
+    w += s.size();
+    *w++ = '\n';
+  }
+  *w = 0;
+  *out = buf;
+  if (count) *count = set.size();
+  if (cap_fired) *cap_fired = fired;
+  return DG_OK;
+}
+void dg_buffer_free(void* p) { std::free(p); }
 
 int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
                    const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out) {

@@ -30,7 +30,19 @@ struct Batch {  // device pointers of one batch
   u32 maxlen_bound;      // the host sized the batch for queries up to this length ...
   u32* too_long;         // ... k_prepare counts the ones that are longer (only possible when the host trusted a cached bound)
   struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
+  // Queries whose neighbourhood could reach the cap are enumerated on the host (nbhd_host.hpp) before the batch starts:
+  // qmode[q] (nullptr = no such query in this batch): QM_KERNEL = not looked at (k_prepare's own bound must hold),
+  // QM_EXPLICIT = the strings of both strands arrive as explicit patterns (xs_*) and k_search skips the query,
+  // QM_SILENT = the host ran the reference's enumeration and the cap stayed silent on both strands, so k_search's set is
+  // the reference's; | QM_FIRED = a strand reached the cap (hunter.h:342-345 warning).
+  const u8* qmode;
+  const u8* xs_bytes;  // explicit patterns: codes 0..4, pattern i = xs_bytes[xs_off[i] .. xs_off[i+1])
+  const u64* xs_off;
+  const u32* xs_gid;   // 2*query + strand of pattern i; patterns of a group are in std::set order
+  u64 nxs;
 };
+enum : u8 { QM_KERNEL = 0, QM_EXPLICIT = 1, QM_SILENT = 2, QM_FIRED = 16 };
+static constexpr u32 LEAF_EXPLICIT = 0x80000000u;  // Leaf::nops marker: ops[0] is an index into Batch::xs_*
 struct GidInfo {
   u64 qpk;    // the sequence 2-bit packed, q[i] at bits 2(m-1-i) (only for m <= 32 without N)
   u32 m;      // length; 0 = this (query, strand) is not searched
@@ -58,7 +70,7 @@ struct HitSeed {
   u32 len;  // its length
 };
 
-enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO };
+enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO, WS_XS };
 
 // one located hit after the `dicey search` stage
 struct SiteRaw {
@@ -88,7 +100,7 @@ struct SearchExtra {  // set by dg_search_sites: replace the verify stage by k_s
 // hunt.hip
 int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes, const void* d_qoff,
               size_t nq, u64 total, u32 maxlen, int fetch, dg_hunt_result** out, SearchExtra* sx = nullptr,
-              uint64_t* group_counts = nullptr);
+              uint64_t* group_counts = nullptr, const uint8_t* h_qbytes = nullptr, const uint64_t* h_qoff = nullptr);
 // hunt.hip: exclusive prefix sums of n 32-bit counts into 64-bit offsets (out[n] = total); tmp: n/64 + 64 words
 int device_scan(hipStream_t st, const u32* in, u64 n, u64* out, u64* tmp);
 // search.hip: launches k_site over the located hits (capacity hit_cap) and fills sx's result pointers

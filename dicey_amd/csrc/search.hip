@@ -547,7 +547,7 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   sx.max_primer_len = maxp;
   sx.max_koff = maxk;
   dg_hunt_result* hr = nullptr;
-  int rc = run_batch(ix, &hp, seqlen, nseq, ws[WS_QB].p, ws[WS_QOFF].p, np, kq.size(), p->kmer, 0, &hr, &sx);
+  int rc = run_batch(ix, &hp, seqlen, nseq, ws[WS_QB].p, ws[WS_QOFF].p, np, kq.size(), p->kmer, 0, &hr, &sx, nullptr, kq.data(), koffs.data());
   if (rc != DG_OK) {
     if (hr) dg_hunt_result_free(hr);
     return rc;
@@ -626,7 +626,7 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   std::vector<dg_site> sites;
   std::string pool;
   for (size_t q = 0; q < np; ++q) {
-    u32 fl = qfl[q] & DG_Q_MAX_MATCHES;
+    u32 fl = qfl[q] & (DG_Q_MAX_MATCHES | DG_Q_NBHD_EXCEEDED);
     if (R->match_temp[q] == -thal::kInf) fl |= DG_P_THAL_FAILED;
     R->pflags[q] = fl;
   }

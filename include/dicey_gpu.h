@@ -13,6 +13,7 @@
  *   neighbors() -> count -> locate -> extract -> needle()/needleScore -> DnaHit push
  *                                            hunter.h:291-437 (whole per-query loop)  dg_hunt
  *   sdsl::construct + store_to_checked_file  index.h:121-122                      dg_index_build
+ *   neighbors(q, alphabet, d, indel, maxsize, set)  neighbors.h:86-92 (hunter.h:334,339)  dg_neighbors
  *
  * Conventions: plain C types only; every function returns 0 on success or a negative DG_E* code and
  * leaves a message retrievable with dg_last_error() (thread-local); objects returned through `out`
@@ -31,8 +32,9 @@
 extern "C" {
 #endif
 
-/* 1: hunt/count/locate/extract/index build; 2: + thal, search sites, neighbourhood counts, padlock scan, shared handles */
-#define DG_ABI_VERSION 2
+/* 1: hunt/count/locate/extract/index build; 2: + thal, search sites, neighbourhood counts, padlock scan, shared handles;
+ * 3: + dg_neighbors, capped neighbourhoods answered instead of refused, max_locations 0 */
+#define DG_ABI_VERSION 3
 
 enum {
   DG_OK = 0,
@@ -99,7 +101,8 @@ typedef struct {
 #define DG_Q_TOO_SHORT 1u     /* < 10 nt: "Error: Input sequence is shorter than 10 nucleotides!" (hunter.h:299-303) */
 #define DG_Q_DIST_ADJUSTED 2u /* hunter.h:312-315 */
 #define DG_Q_MAX_MATCHES 4u   /* hits >= max_locations (hunter.h:434-437) */
-#define DG_Q_NBHD_EXCEEDED 8u /* hunter.h:342-345; never set inside the supported envelope */
+#define DG_Q_NBHD_EXCEEDED 8u /* hunter.h:342-345: a strand's neighbourhood reached max_neighborhood; the strings searched are
+                               * the ones the reference's capped enumeration holds (see dg_neighbors) */
 
 typedef struct {
   int32_t score;     /* DnaHit::score (0, -1, ...) */
@@ -166,6 +169,18 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
  * could fire. */
 int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t max_neighborhood, const uint8_t* qbytes,
                            const uint64_t* qoff, size_t nq, uint64_t* fw_count, uint64_t* rv_count);
+
+/* ---- neighbors() with its size cap (reference src/neighbors.h:29-92), host side ----
+ * The strings `dicey hunt` / `search` / `padlock` search for one sequence and one strand: seq is the normalised sequence
+ * (A,C,G,T,N), alphabet {A,C,G,T}.  Edit mode keeps the substring-minimal strings; when the working set reaches
+ * max_neighborhood the reference stops generating (neighbors.h:50) and what it holds then depends on its generation order,
+ * which this function follows.  *out = the strings in std::set order, '\n'-terminated each, NUL at the end (release with
+ * dg_buffer_free); *count their number; *cap_fired != 0 <=> count >= max_neighborhood (hunter.h:342-345 warns).
+ * dg_hunt, dg_search_sites and dg_neighborhood_count call this for the sequences whose neighbourhood could reach the cap
+ * and search exactly these strings; all other sequences are enumerated inside the search kernel.  Needs no device. */
+int dg_neighbors(const uint8_t* seq, uint32_t len, uint32_t distance, int hamming, uint32_t max_neighborhood, char** out,
+                 uint64_t* count, int* cap_fired);
+void dg_buffer_free(void* p);
 
 /* ---- index construction on the GPU (what `dicey index` does with sdsl::construct, index.h:97-123) ---- */
 /* text = SEQ1 '\n' SEQ2 '\n' ... SEQk '\n' (upper-cased), no NUL inside.  Writes sdsl csa_wt<> layout. */
@@ -246,7 +261,7 @@ typedef struct {
   uint64_t nsites;
   dg_site* sites;     /* reference push order: primer-major, forward-strand hits then reverse-strand hits */
   char* genome_pool;  /* PrimerBind::genome strings */
-  uint32_t* pflags;   /* [nprimers] DG_Q_MAX_MATCHES | DG_P_THAL_FAILED */
+  uint32_t* pflags;   /* [nprimers] DG_Q_MAX_MATCHES | DG_Q_NBHD_EXCEEDED | DG_P_THAL_FAILED */
   double* match_temp; /* [nprimers] */
   uint64_t nhits;     /* located hits, each of which went through thal() */
   double ms_device;   /* device time of the search + site kernels (HIP events) */

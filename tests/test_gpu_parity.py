@@ -107,17 +107,18 @@ def test_hunt_edge_cases(gpu_small, small_genome):
 def test_unsupported_envelope_fails_loudly(gpu_small, small_genome):
     import dicey_amd
     with pytest.raises(dicey_amd.DgError):
-        gpu_small.hunt(["ACGT" * 5 + "A"], small_genome["seqlen"], distance=2)  # 21-mer, d=2: cap not provably silent
+        gpu_small.hunt(["ACGT" * 64], small_genome["seqlen"], distance=1)  # 256 nt: above the 255 nt this build verifies
     with pytest.raises(dicey_amd.DgError):
         gpu_small.hunt(["ACGTACGTACGT"], small_genome["seqlen"], distance=30)
-    # an N can become any of four bases: 38 N's at Hamming distance 2 are 11 401 strings, the reference's cap (10 000) fires
-    # and its answer depends on the recursion order -> refused, although 38-mers without N are fine (6 442 strings)
-    with pytest.raises(dicey_amd.DgError, match="N / non-DNA"):
-        gpu_small.hunt(["ACGTACGTAC" * 3 + "ACGTACGT", "N" * 38], small_genome["seqlen"], distance=2, hamming=True)
-    gpu_small.hunt(["ACGTACGTAC" * 3 + "ACGTACGT", "ACGTNNACGT" * 3 + "ACGTACGT"], small_genome["seqlen"], distance=2, hamming=True)
-    with pytest.raises(dicey_amd.DgError, match="N / non-DNA"):   # edit distance 2: one N in a 20-mer is provable, two are not
-        gpu_small.hunt(["ACGTNACGTNACGTACGTAC"], small_genome["seqlen"], distance=2)
-    gpu_small.hunt(["ACGTNACGTAACGTACGTAC"], small_genome["seqlen"], distance=2)
+
+
+def test_former_envelope_is_answered(gpu_small, small_genome):
+    """inputs round 1 refused because the maxNeighborhood cap could fire: now answered like the reference (the capped
+    enumeration is reproduced on the host, tests/test_gpu_capped.py has the broad coverage)"""
+    orc = O.Index(small_genome["fm9"])
+    # an N can become any of four bases: 38 N's at Hamming distance 2 are 11 401 strings, the cap (10 000) fires
+    _compare(gpu_small, orc, small_genome, ["ACGTACGTAC" * 3 + "ACGTACGT", "N" * 38, "ACGTNNACGT" * 3 + "ACGTACGT"], distance=2, hamming=True)
+    _compare(gpu_small, orc, small_genome, ["ACGTNACGTNACGTACGTAC", "ACGTNACGTAACGTACGTAC", "ACGT" * 5 + "A"], distance=2)
 
 
 def test_larger_genome_roundtrip_properties():

@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 OCC_LINE_BYTES = 64    # one Occ block
 BYTES_PER_EXT = 2 * OCC_LINE_BYTES  # an interval extension reads the block of each interval end
 BYTES_PER_TAB_READ = 8  # one K-mer jump-table entry (lo, hi)
+BYTES_PER_FILTER_PROBE = 4  # one word of the K-mer presence filter
 GRCH38_FREQ = (0.295, 0.205, 0.205, 0.295)  # A C G T
 
 
@@ -204,7 +205,7 @@ def main():
         _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(p), sl, len(seqlen), C.c_void_p(d_q.data_ptr()),
                                         C.c_void_p(d_off.data_ptr()), nq, len(qbytes), fetch, C.byref(rp)))
         R = rp.contents
-        res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes, "tab": R.ctr_tab_reads,
+        res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes, "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes,
                "ms_total": R.ms_total, "ms_search": R.ms_search, "ms_select": R.ms_select, "ms_locate": R.ms_locate,
                "ms_verify": R.ms_verify}
         if world > 1:  # hit lists to rank 0 over RCCL/xGMI, overlapped with the next step (dicey_amd/shard.py)
@@ -315,7 +316,13 @@ def main():
         ext = float(np.mean([r["ext"] for r in acc]))
         ms_search = float(np.mean([r["ms_search"] for r in acc]))
         tab = float(np.mean([r["tab"] for r in acc]))
-        alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ
+        probe = float(np.mean([r["probe"] for r in acc]))
+        alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
+        # the same launch in SURVEY.md §8(d) units: a backward step on c = 2 L(c) rank ops of 24 B on the sdsl layout
+        # (L = Huffman code length in the loaded wavelet tree), small reads by their payload
+        cl = st["code_len"]
+        avg_l = sum(f * cl.get(ord(ch), 0) for f, ch in zip(GRCH38_FREQ, "ACGT"))
+        survey_bytes = ext * 2 * avg_l * 24 + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
         achieved = alg_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_k_search.json")
@@ -343,8 +350,14 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "ext_steps_per_launch": ext,
                          "bytes_per_ext_step": BYTES_PER_EXT, "table_reads_per_launch": tab,
-                         "bytes_per_table_read": BYTES_PER_TAB_READ, "kernel_ms": ms_search,
-                         "index_lines_per_s": (2 * ext + tab) / (ms_search * 1e-3) if ms_search > 0 else 0.0,
+                         "bytes_per_table_read": BYTES_PER_TAB_READ, "filter_probes_per_launch": probe,
+                         "bytes_per_filter_probe": BYTES_PER_FILTER_PROBE, "kernel_ms": ms_search,
+                         "survey_units": {"bytes_per_launch": survey_bytes, "avg_code_len": avg_l,
+                                          "achieved": survey_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0,
+                                          "frac": survey_bytes / (ms_search * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_search > 0 else 0.0,
+                                          "note": "24 B per rank op, 2 L(c) rank ops per backward step (SURVEY.md 8(d))"},
+                         "index_accesses_per_query": (2 * ext + tab + probe) / nq,
+                         "index_lines_per_s": (2 * ext + tab + probe) / (ms_search * 1e-3) if ms_search > 0 else 0.0,
                          "gather_ceiling_note": "random 64-B lines over >=16 GiB top out at 19 G lines/s = 1.2 TB/s on this chip "
                                                 "(profiles/r01b_gather_bench.jsonl); this kernel is a gather, not a stream"},
             "cpu_baseline": cpu,

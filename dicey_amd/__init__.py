@@ -170,7 +170,7 @@ class FmIndex:
                 q.hits.append(DnaHit(H.score, H.chr, H.start, chr(H.strand), ra, qa))
             qs.append(q)
         ctr = {"ext_steps": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa_reads": R.ctr_sa_reads,
-               "win_bytes": R.ctr_win_bytes, "tab_reads": R.ctr_tab_reads, "nhits": R.nhits}
+               "win_bytes": R.ctr_win_bytes, "tab_reads": R.ctr_tab_reads, "filter_probes": R.ctr_filter_probes, "nhits": R.nhits}
         tm = {"total": R.ms_total, "search": R.ms_search, "select": R.ms_select, "locate": R.ms_locate,
               "verify": R.ms_verify}
         return HuntBatch(qs, ctr, tm)

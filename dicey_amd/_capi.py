@@ -44,7 +44,8 @@ class HuntResult(C.Structure):
                 ("ctr_ext_steps", C.c_uint64), ("ctr_leaves", C.c_uint64), ("ctr_sa_reads", C.c_uint64),
                 ("ctr_win_bytes", C.c_uint64), ("ctr_tab_reads", C.c_uint64), ("ms_total", C.c_double), ("ms_search", C.c_double),
                 ("ms_select", C.c_double), ("ms_locate", C.c_double), ("ms_verify", C.c_double),
-                ("d_hits", C.c_void_p), ("d_refalign", C.c_void_p), ("d_queryalign", C.c_void_p)]
+                ("d_hits", C.c_void_p), ("d_refalign", C.c_void_p), ("d_queryalign", C.c_void_p),
+                ("ctr_filter_probes", C.c_uint64)]
 
 
 class SearchParams(C.Structure):

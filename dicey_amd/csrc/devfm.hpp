@@ -66,7 +66,35 @@ struct FmView {
   // backward search meets the characters.
   const uint2* ktab;
   u32 K;  // 0 = no table
+  // Presence filter in front of the table (derived at load from the table): bit = "this K-mer occurs", kept in up to four
+  // differently permuted copies.  Copy r stores the 512 codes that differ only in code bits [kf_s[r], kf_s[r]+9) in ONE
+  // 64-byte line (line index = the remaining 2K-9 bits), so all K-mers that differ from each other only inside one block of
+  // four window positions sit in the same line of the copy whose block that is.  The neighbourhood of a query probes ~150
+  // K-mers per strand that all differ from the query's window by one edit: lanes pick the copy by the position of their
+  // edit and the ~150 probes fall into about a dozen lines instead of ~150 table lines; only K-mers that occur (about one
+  // in six on a 3.1 Gb genome at K = 17) go on to read their table entry.  Any copy answers any code: the choice is
+  // locality only.
+  const u32* kf[4];
+  u32 kf_s[4];
+  u32 kf_nr;  // 0 = no filter
 };
+
+// is the K-mer `code` present?  t = window position (0 = right-most character) of the most recent edit
+DG_DEV bool kf_present(const FmView& f, u64 code, u32 t) {
+  u32 r = t >> 2;
+  if (r >= f.kf_nr) r = f.kf_nr - 1;
+  const u32* base = f.kf[0];
+  u32 s = f.kf_s[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (r == (u32)k) {
+      base = f.kf[k];
+      s = f.kf_s[k];
+    }
+  const u32 inl = (u32)(code >> s) & 511u;
+  const u64 line = (code & ((1ULL << s) - 1)) | ((code >> (s + 9)) << s);
+  return (base[line * 16 + (inl >> 5)] >> (inl & 31)) & 1u;
+}
 
 DG_DEV u64 packed_get(const u64* w, u32 width, u64 i) {
   u64 b = i * width, q = b >> 6, o = b & 63;

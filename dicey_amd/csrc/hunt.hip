@@ -132,6 +132,7 @@ __global__ void k_prepare(Batch b) {
     gi.qpk = 0;
     gi.m = ((flags & DG_Q_TOO_SHORT) || explicit_set || (strand && !b.reverse) || m > b.maxlen_bound) ? 0u : m;
     gi.d_win = d | (bad == 0 ? 256u : 0u);
+    if (b.fastK && gi.m && bad == 0 && d == 1 && m <= 31 && m >= b.fastK + 1) gi.d_win |= 512u;
     if (bad == 0 && m <= 32) {
       const u8* sq = (strand ? b.rv : b.fw) + s;
       for (u32 i = 0; i < m; ++i) gi.qpk |= (u64)sq[i] << (2 * (m - 1 - i));
@@ -191,7 +192,16 @@ struct SearchOut {
 };
 
 // emit one character (code 0..3) in front of what the frame stands for; returns false when the branch is dead
-DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& lookups) {
+// K-mer code -> SA interval: the presence filter first (one bit, FmView::kf), the table entry only for K-mers that occur
+DG_DEV uint2 kmer_interval(const FmView& f, u64 code, u32 edit_at, u64& lookups, u64& probes) {
+  if (f.kf_nr) {
+    ++probes;
+    if (!kf_present(f, code, edit_at)) return make_uint2(0u, 0u);
+  }
+  ++lookups;
+  return f.ktab[code];
+}
+DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& lookups, u64& probes) {
   if (fr.st & ST_WIN) {
     u32 e = (fr.st >> 4) & 31;
     u64 code = ((u64)fr.hi << 32 | fr.lo) | ((u64)c << (2 * e));
@@ -199,8 +209,7 @@ DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& looku
     fr.hi = (u32)(code >> 32);
     ++e;
     if (e == f.K) {
-      uint2 iv = f.ktab[code];
-      ++lookups;
+      uint2 iv = kmer_interval(f, code, e - 1, lookups, probes);
       fr.lo = iv.x;
       fr.hi = iv.y;
       fr.st &= ~(ST_WIN | (31u << 4));
@@ -214,7 +223,7 @@ DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& looku
   return fr.lo < fr.hi;
 }
 // window mode with no budget left: the remaining K-e characters are the query's own; one table read
-DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m, u64 qpk, u64& lookups) {
+DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m, u64 qpk, u64& lookups, u64& probes) {
   const u32 e = (fr.st >> 4) & 31, need = f.K - e;
   u64 code = (u64)fr.hi << 32 | fr.lo;
   if (m <= 32) {  // qpk holds q[i] at bits 2(m-1-i): the next character to emit is at the bottom after the shift
@@ -225,8 +234,7 @@ DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m
     for (u32 t = 0; t < need; ++t) code |= (u64)seq[fr.pos - 1 - t] << (2 * (e + t));
   }
   fr.pos -= need;
-  uint2 iv = f.ktab[code];
-  ++lookups;
+  uint2 iv = kmer_interval(f, code, e ? e - 1 : 0u, lookups, probes);  // the last edit sits just right of the copied characters
   fr.lo = iv.x;
   fr.hi = iv.y;
   fr.st &= ~(ST_WIN | (31u << 4));
@@ -238,6 +246,153 @@ DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m
 // every first edit to the left of it.  An item lane jumps straight to its node (the j characters right of the edit are
 // the query's own), applies its single operation and explores that subtree only.  ~K*NOPS+1 times more lanes, each with
 // a handful of dependent index reads instead of hundreds: the kernel becomes throughput- instead of latency-bound.
+// ------------------------------------------------------------------------------------------------------------
+// Distance 1, the common case, without the state machine.  Profiling the general kernel (SQ counters, r02) showed it is
+// bound by instruction issue, not by memory: ~1400 instructions per wavefront at 45 % lane utilisation, because every lane
+// sits in a different state of the walker.  With one edit the work is flat, so it is laid out flat:
+//   phase A, one lane per (query, strand, position, operation): build the edited string in a 64-bit register (2 bits per
+//            character), take its last K characters as the table code and test the presence filter (or the table itself
+//            when there is no filter) — a dozen instructions and one memory access; about four lanes in five stop here;
+//   phase B: the survivors of the workgroup are packed through LDS into its first lanes, which read the table entry and
+//            extend the interval over the characters left of the window (two Occ lines per step).
+// Every lane of phase B has the same few steps ahead of it, so wavefronts stay full and short.  Strings and leaves are
+// exactly those of k_search<INDEL,1>: deletions, substitutions by another base and insertions between two characters
+// (neighbors.h:51-78; a leading insertion is dominated by the string without it, a trailing one is not generated), and in
+// Hamming mode the sequence itself.  Queries with an N, longer than 31 nt or shorter than K+1 stay with k_search.
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o, u32 ipg) {
+  __shared__ unsigned long long q_code[256], q_rest[256];
+  __shared__ u32 q_gid[256], q_op[256];
+  __shared__ u32 q_n;
+  constexpr u32 NOPS = INDEL ? 9u : 4u;
+  if (threadIdx.x == 0) q_n = 0;
+  __syncthreads();
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 gid = t / ipg;
+  const u32 item = (u32)(t % ipg);
+  u64 steps = 0, lookups = 0, probes = 0;
+  const u32 K = f.K;
+  const u64 kmask = (1ULL << (2 * K)) - 1;
+  bool cand = false;
+  u64 code = 0, rest = 0;
+  u32 opword = 0;  // bits 0-27 Leaf::ops[0], bit 28: one op recorded; bits 29.. unused
+  u32 nrest = 0, hint = 0;
+  if (gid < 2 * b.nq) {
+    const GidInfo gi = b.ginfo[gid];
+    if (gi.m && (gi.d_win & 512u)) {
+      const u32 m = gi.m;
+      const u64 qpk = gi.qpk;
+      u64 s_pk = 0;
+      u32 mlen = 0;
+      if (!INDEL && item == ipg - 1) {  // Hamming: the sequence itself belongs to the set
+        s_pk = qpk;
+        mlen = m;
+        cand = true;
+      } else {
+        const u32 pos = item / NOPS + 1, op = item % NOPS;  // the operation sits right of q[0..pos)
+        if (pos <= m && item < m * NOPS) {
+          const u32 R = m - pos;  // unchanged characters right of it
+          const u64 low = qpk & ((1ULL << (2 * R)) - 1);
+          const u32 old = (u32)(qpk >> (2 * R)) & 3u;
+          u32 kind, c;
+          if (INDEL) {
+            kind = op == 0 ? OP_D : (op <= 4 ? OP_S : OP_I);
+            c = op == 0 ? 0u : (op - 1) & 3u;
+          } else {
+            kind = OP_S;
+            c = op;
+          }
+          if (kind == OP_D) {
+            s_pk = low | ((qpk >> (2 * R + 2)) << (2 * R));
+            mlen = m - 1;
+            cand = true;
+          } else if (kind == OP_S) {
+            s_pk = qpk ^ ((u64)(old ^ c) << (2 * R));
+            mlen = m;
+            cand = c != old;  // neighbors.h:63
+          } else {
+            s_pk = low | ((u64)c << (2 * R)) | ((qpk >> (2 * R)) << (2 * R + 2));
+            mlen = m + 1;
+            cand = pos < m;  // neighbors.h:51: nothing after the last character
+          }
+          opword = ((pos << 4) | (kind << 2) | c) | (1u << 28);
+          hint = R < K ? R : K - 1;
+        }
+      }
+      if (cand) {
+        code = s_pk & kmask;
+        rest = s_pk >> (2 * K);
+        nrest = mlen - K;
+        if (f.kf_nr) {
+          ++probes;
+          cand = kf_present(f, code, hint);
+        } else {
+          ++lookups;
+          const uint2 iv = f.ktab[code];
+          cand = iv.x < iv.y;
+          code = (u64)iv.y << 32 | iv.x;
+        }
+      }
+    }
+  }
+  // pack the survivors of the workgroup into its first lanes
+  const unsigned long long mask = __ballot(cand);
+  const u32 lane = threadIdx.x & 63;
+  u32 base = 0;
+  if (lane == 0 && mask) base = atomicAdd(&q_n, (u32)__popcll(mask));
+  base = __shfl(base, 0);
+  if (cand) {
+    const u32 at = base + (u32)__popcll(mask & ((1ULL << lane) - 1));
+    q_code[at] = code;
+    q_rest[at] = rest | ((u64)nrest << 56);
+    q_gid[at] = (u32)gid;
+    q_op[at] = opword;
+  }
+  __syncthreads();
+  if (threadIdx.x < q_n) {
+    const u64 cd = q_code[threadIdx.x];
+    u64 rs = q_rest[threadIdx.x];
+    const u32 g = q_gid[threadIdx.x], ow = q_op[threadIdx.x];
+    u32 n = (u32)(rs >> 56);
+    rs &= (1ULL << 56) - 1;
+    u32 lo, hi;
+    if (f.kf_nr) {
+      ++lookups;
+      const uint2 iv = f.ktab[cd];
+      lo = iv.x;
+      hi = iv.y;
+    } else {
+      lo = (u32)cd;
+      hi = (u32)(cd >> 32);
+    }
+    while (n && lo < hi) {
+      bs_extend_code(f, lo, hi, (u32)rs & 3u);
+      rs >>= 2;
+      --n;
+      ++steps;
+    }
+    if (lo < hi) {
+      const u32 shard = blockIdx.x & (NSHARD - 1);
+      const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+      const u32 slot = atomicAdd(o.grp_cnt + g, 1u);
+      if (at < o.shard_cap) {
+        Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+        lf->qs = g;
+        lf->slot = slot;
+        lf->lo = lo;
+        lf->hi = hi;
+        lf->nops = ow >> 28;
+        lf->ops[0] = ow & 0x0FFFFFFFu;
+#pragma unroll
+        for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+      }
+    }
+  }
+  wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
+  wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
+  wave_add(&o.ctr->probes[blockIdx.x & (NSHARD - 1)], probes);
+}
+
 template <bool INDEL, int D>
 __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, u32 items) {
   // lane layout: the long-running "rest" lanes come first, packed densely (a rest lane among 63 short item lanes
@@ -253,7 +408,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
     gid = (t - ngrp) / (items - 1);
     item = (u32)((t - ngrp) % (items - 1));
   }
-  u64 steps = 0, lookups = 0;
+  u64 steps = 0, lookups = 0, probes = 0;
   constexpr u32 NOPS = INDEL ? 9u : 4u;  // INDEL: D, S(A,C,G,T), I(A,C,G,T);  Hamming: S(A,C,G,T)
   bool active = gid < ngrp;
   const u64 q = gid >> 1;
@@ -263,7 +418,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   gi.m = 0;
   gi.d_win = 0;
   if (active) gi = b.ginfo[gid];
-  if (gi.m == 0) active = false;
+  if (gi.m == 0 || (gi.d_win & 512u)) active = false;
   if (active) {
     const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
     const u32 m = gi.m;
@@ -289,7 +444,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
         if (use_win && items > 1) {
           if (rest) {
             // the unedited window in one table read; first edits left of the window follow in interval mode
-            if (!frame_finish_window(f, r, seq, m, qpk, lookups)) active = false;
+            if (!frame_finish_window(f, r, seq, m, qpk, lookups, probes)) active = false;
           } else {
             const u32 j = item / NOPS;  // characters right of the edit
             single_op = item % NOPS;
@@ -350,9 +505,9 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
           if (kind == OP_I && L == 0 && pos == m) continue;   // nothing may be inserted after the last character (neighbors.h:51)
           Frame ch = F;
           ch.st &= ~15u;
-          if (kind != OP_D && !frame_emit(f, ch, c, steps, lookups)) continue;
+          if (kind != OP_D && !frame_emit(f, ch, c, steps, lookups, probes)) continue;
           ch.pos = kind == OP_I ? pos : pos - 1;
-          if (budget == 1 && (ch.st & ST_WIN) && !frame_finish_window(f, ch, seq, m, qpk, lookups)) continue;
+          if (budget == 1 && (ch.st & ST_WIN) && !frame_finish_window(f, ch, seq, m, qpk, lookups, probes)) continue;
           ops.set(L, (pos << 4) | (kind << 2) | c);
           ++L;
           S.set(L, ch);
@@ -360,10 +515,10 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
         }
         // keep the query character(s)
         bool alive;
-        if (budget == 0 && (F.st & ST_WIN)) alive = frame_finish_window(f, F, seq, m, qpk, lookups);  // only a d = 0 root
+        if (budget == 0 && (F.st & ST_WIN)) alive = frame_finish_window(f, F, seq, m, qpk, lookups, probes);  // only a d = 0 root
         else {
           F.st &= ~15u;
-          if (here < 4) alive = frame_emit(f, F, here, steps, lookups);
+          if (here < 4) alive = frame_emit(f, F, here, steps, lookups, probes);
           else {  // an N in the query (never in window mode): through the wavelet tree like sdsl
             bs_extend_sym(f, F.lo, F.hi, 'N', here);
             ++steps;
@@ -382,6 +537,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   }
   wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
   wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
+  wave_add(&o.ctr->probes[blockIdx.x & (NSHARD - 1)], probes);
 }
 
 // Explicit patterns (the host-enumerated capped neighbourhoods): one lane per string, plain backward search right to
@@ -424,7 +580,7 @@ __global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap) {  // NSHARD lanes
 }
 // what the host needs at the end of a batch, in 64 bytes instead of the 36 KB of sharded counters
 struct Summary {
-  unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow, refused, too_long;
+  unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow, refused, too_long, probes;
 };
 __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {  // NSHARD lanes
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -435,6 +591,7 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
   if (ctr->lookups[k]) atomicAdd(&out->lookups, ctr->lookups[k]);
   if (ctr->sa_reads[k]) atomicAdd(&out->sa_reads, ctr->sa_reads[k]);
   if (ctr->win_bytes[k]) atomicAdd(&out->win_bytes, ctr->win_bytes[k]);
+  if (ctr->probes[k]) atomicAdd(&out->probes, ctr->probes[k]);
   if (k == 0) {
     out->nhits = *nhits;
     out->overflow = ctr->overflow;
@@ -445,10 +602,11 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
 // Production form: one workgroup, one lane per shard, totals straight into the pinned host record (no atomics over the bus,
 // no separate copy); the host reads it after the batch's single stream synchronisation.
 __global__ void __launch_bounds__(NSHARD) k_summary_block(const Counters* ctr, const u64* nhits, Summary* host_out) {
-  __shared__ unsigned long long part[6][NSHARD / 64];
+  constexpr int NF = 7;
+  __shared__ unsigned long long part[NF][NSHARD / 64];
   const u32 k = threadIdx.x;
-  unsigned long long v[6] = {ctr->leaf_cnt[k], ctr->leaf_cnt[k], ctr->steps[k], ctr->lookups[k], ctr->sa_reads[k], ctr->win_bytes[k]};
-  for (int f = 0; f < 6; ++f) {
+  unsigned long long v[NF] = {ctr->leaf_cnt[k], ctr->leaf_cnt[k], ctr->steps[k], ctr->lookups[k], ctr->sa_reads[k], ctr->win_bytes[k], ctr->probes[k]};
+  for (int f = 0; f < NF; ++f) {
     unsigned long long x = v[f];
     for (int off = 32; off > 0; off >>= 1) {
       const unsigned long long o = __shfl_xor(x, off);
@@ -458,8 +616,8 @@ __global__ void __launch_bounds__(NSHARD) k_summary_block(const Counters* ctr, c
   }
   __syncthreads();
   if (k == 0) {
-    unsigned long long t[6] = {0, 0, 0, 0, 0, 0};
-    for (int f = 0; f < 6; ++f)
+    unsigned long long t[NF] = {0, 0, 0, 0, 0, 0, 0};
+    for (int f = 0; f < NF; ++f)
       for (u32 w = 0; w < NSHARD / 64; ++w) t[f] = f == 1 ? (part[f][w] > t[f] ? part[f][w] : t[f]) : t[f] + part[f][w];
     host_out->nleaf = t[0];
     host_out->worst_shard = t[1];
@@ -467,6 +625,7 @@ __global__ void __launch_bounds__(NSHARD) k_summary_block(const Counters* ctr, c
     host_out->lookups = t[3];
     host_out->sa_reads = t[4];
     host_out->win_bytes = t[5];
+    host_out->probes = t[6];
     host_out->nhits = *nhits;
     host_out->overflow = ctr->overflow;
     host_out->refused = ctr->pad_[1];
@@ -1519,7 +1678,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipMemcpyAsync(d_xs_off, cs.xs_off.data(), (nxs + 1) * 8, hipMemcpyHostToDevice, st));
     DG_HIP(hipStreamSynchronize(st));  // the host vectors go out of use only after the copies
   }
+  static const bool no_fast1 = std::getenv("DICEY_NO_FAST1") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
   Batch b;
+  b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen <= 31 && maxlen > ix->view.K) ? ix->view.K : 0u;
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
   b.xs_off = d_xs_off;
@@ -1607,8 +1768,14 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       so.shard_cap = shard_cap;
       so.ctr = ctr;
       so.grp_cnt = grp_cnt;
+      if (b.fastK) {  // distance 1: the flat kernel takes every query that qualifies, k_search (one lane per strand) the rest
+        const u32 ipg = indel ? maxlen * 9u : maxlen * 4u + 1u;
+        const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
+        if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);
+      }
       // root-level work split (see k_search): only with the table and with at least one edit to place
-      const u32 items = (ix->view.K && dmax_eff >= 1) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
+      const u32 items = (ix->view.K && dmax_eff >= 1 && !b.fastK) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
       const dim3 grid(ceil_div(ngrp * items, TB)), block(TB);
 #define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so, items)
       if (indel) {
@@ -1762,6 +1929,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->ctr_leaves = nleaf;
   R->ctr_ext_steps = hsum.steps;
   R->ctr_tab_reads = hsum.lookups;
+  R->ctr_filter_probes = hsum.probes;
   R->ctr_sa_reads = hsum.sa_reads;
   R->ctr_win_bytes = hsum.win_bytes;
   R->ms_total = ev_ms(ix->ev[0], ix->ev[7]);

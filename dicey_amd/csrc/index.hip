@@ -190,6 +190,113 @@ __global__ void k_kmer_table(FmView f, uint2* tab, u32 K) {
   if (next != me) tab[me].y = (u32)(i + 1);
 }
 
+// ---- presence filter (FmView::kf) ----
+// copy 0 (in-line bits = the low 9 code bits = address order of the table): one coalesced pass over the table
+__global__ void __launch_bounds__(256) k_kf_from_table(const uint2* tab, u64 entries, u32* out) {  // entries: multiple of 64
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += stride) {  // a launch holds < 2^32 threads
+    const uint2 e = tab[i];
+    const unsigned long long m = __ballot(e.x < e.y);
+    if ((threadIdx.x & 63) == 0) *reinterpret_cast<unsigned long long*>(out + (i >> 5)) = m;
+  }
+}
+// any copy, one lane per output word, straight from the table: small tables, and the lane-independent debugging build
+__global__ void k_kf_generic(const uint2* tab, u32 bits, u32 s, u32* out, u64 nwords) {
+  const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 line = w >> 4;
+  u32 v = 0;
+  for (u32 i = 0; i < 32; ++i) {
+    const u64 inl = ((w & 15) << 5) | i;
+    const u64 code = (line & ((1ULL << s) - 1)) | (inl << s) | ((line >> s) << (s + 9));
+    if (code >> bits) continue;
+    const uint2 e = tab[code];
+    v |= (u32)(e.x < e.y) << i;
+  }
+  out[w] = v;
+}
+// copy with in-line bits [s, s+9), s >= 8, from copy 0: a workgroup owns the 2^17 codes that share everything but those
+// nine bits and the low eight; lane M reads the 256 bits of its in-line value (32 contiguous bytes of copy 0), the
+// 512 x 256 bit matrix is turned by ballots and leaves as 256 consecutive lines of the new copy.
+__global__ void __launch_bounds__(512) k_kf_transpose(const u32* r0, u32* out, u32 s) {
+  __shared__ unsigned long long tile[256][8];  // [line][wavefront]: 64 in-line bits each
+  const u64 T = blockIdx.x;
+  const u64 lowpart = (T & ((1ULL << (s - 8)) - 1)) << 8, high = T >> (s - 8);
+  const u32 M = threadIdx.x, wave = M >> 6, lane = M & 63;
+  const u64 src_bit = lowpart | ((u64)M << s) | (high << (s + 9));
+  const uint4* src = reinterpret_cast<const uint4*>(r0 + (src_bit >> 5));
+  const uint4 a = src[0], b = src[1];
+  const u32 word[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned long long keep[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int wi = 0; wi < 8; ++wi)
+#pragma unroll
+    for (int bit = 0; bit < 32; ++bit) {
+      const unsigned long long m = __ballot((word[wi] >> bit) & 1u);
+      const int l = wi * 32 + bit;
+      if ((int)lane == (l & 63)) keep[l >> 6] = m;
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tile[64 * k + lane][wave] = keep[k];
+  __syncthreads();
+  const u64 line0 = lowpart | (high << s);
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(out + line0 * 16);
+  const unsigned long long* flat = &tile[0][0];
+  for (u32 k = threadIdx.x; k < 256 * 8; k += 512) dst[k] = flat[k];
+}
+
+__global__ void k_kf_compare(const u32* a, const u32* b, u64 n, u32* bad) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && a[i] != b[i]) atomicAdd(bad, 1u);
+}
+
+static int build_filter(dg_index* ix, const uint2* tab, u32 K) {
+  FmView& f = ix->view;
+  const u32 bits = 2 * K;
+  if (bits < 17 || std::getenv("DICEY_NO_KMER_FILTER")) return DG_OK;  // a table this small is cache resident anyway
+  const u64 entries = 1ULL << bits, nwords = entries >> 5;
+  u32 nr = (bits - 9 + 7) / 8 + 1;
+  if (nr > 4) nr = 4;
+  static const bool generic = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
+  const u32 TB = 256;
+  for (u32 r = 0; r < nr; ++r) {
+    const u32 s = r + 1 < nr ? 8 * r : bits - 9;
+    u32* bm = nullptr;
+    DG_HIP(hipMalloc((void**)&bm, nwords * 4 + 64));
+    ix->owned.push_back(bm);
+    ix->hbm_bytes += nwords * 4 + 64;
+    if (generic || (r > 0 && s < 8)) {
+      hipLaunchKernelGGL(k_kf_generic, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, tab, bits, s, bm, nwords);
+    } else if (r == 0) {
+      hipLaunchKernelGGL(k_kf_from_table, dim3((u32)std::min<u64>(entries / TB, 1u << 20)), dim3(TB), 0, ix->stream, tab, entries, bm);
+    } else {
+      hipLaunchKernelGGL(k_kf_transpose, dim3((u32)(entries >> 17)), dim3(512), 0, ix->stream, f.kf[0], bm, s);
+    }
+    f.kf[r] = bm;
+    f.kf_s[r] = s;
+    if (std::getenv("DICEY_KF_VERIFY")) {  // debugging aid: the fast builders against the one-lane-per-word builder
+      u32* ref = nullptr;
+      u32* bad = nullptr;
+      DG_HIP(hipMalloc((void**)&ref, nwords * 4 + 64));
+      DG_HIP(hipMalloc((void**)&bad, 4));
+      DG_HIP(hipMemsetAsync(bad, 0, 4, ix->stream));
+      hipLaunchKernelGGL(k_kf_generic, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, tab, bits, s, ref, nwords);
+      hipLaunchKernelGGL(k_kf_compare, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, (const u32*)bm, (const u32*)ref, nwords, bad);
+      u32 hbad = 0;
+      DG_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ix->stream));
+      DG_HIP(hipStreamSynchronize(ix->stream));
+      DG_HIP(hipFree(ref));
+      DG_HIP(hipFree(bad));
+      std::fprintf(stderr, "DICEY_KF_VERIFY: copy %u (s=%u): %u of %llu words differ\n", r, s, hbad, (unsigned long long)nwords);
+      if (hbad) return fail(DG_EHIP, "presence filter copy %u differs from its definition in %u words", r, hbad);
+    }
+  }
+  DG_HIP(hipStreamSynchronize(ix->stream));
+  DG_HIP(hipGetLastError());
+  f.kf_nr = nr;
+  return DG_OK;
+}
+
 static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
   FmView& f = ix->view;
   const u64 n = f.n;
@@ -272,6 +379,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
     f.ktab = tab;
     f.K = K;
     ix->hbm_bytes += entries * sizeof(uint2);
+    DG_TRY(build_filter(ix, tab, K));
   }
   if (!(flags & DG_OPEN_NO_SELFCHECK)) {
     DG_HIP(hipMalloc((void**)&bad, 4));

@@ -143,6 +143,8 @@ typedef struct {
   const void* d_hits;       /* dg_hit[nhits] */
   const void* d_refalign;   /* nhits * aln_stride bytes */
   const void* d_queryalign; /* nhits * aln_stride bytes */
+  uint64_t ctr_filter_probes; /* K-mer presence-filter bits tested (one 4-byte word each); ctr_tab_reads counts the table
+                               * entries actually read, i.e. the probes that found their K-mer present */
 } dg_hunt_result;
 
 /* Host-buffer entry point: queries are raw bytes as read from the FASTA/argv (any case), concatenated.

@@ -200,6 +200,28 @@ DG_DEV void bs_extend_code(const FmView& f, u32& lo, u32& hi, u32 code) {  // co
   lo = c4 + occ_in_line(A, lo & 127, code);
   hi = c4 + occ_in_line(B, hi & 127, code);
 }
+// the same step when both interval ends usually fall into one Occ block (narrow intervals, i.e. after the K-mer table):
+// one line read and one pair of plane masks instead of two
+DG_DEV void bs_extend_code_narrow(const FmView& f, u32& lo, u32& hi, u32 code) {
+  const u32 c4 = sel4(code, f.C4[0], f.C4[1], f.C4[2], f.C4[3]);
+  const OccLine A = occ_load(f.occ, lo >> 7);
+  if ((lo >> 7) == (hi >> 7)) {
+    const u32 a = lo & 127, b = hi & 127;  // a <= b
+    const u64 x0 = (code & 1) ? A.p0[0] : ~A.p0[0], x1 = (code & 1) ? A.p0[1] : ~A.p0[1];
+    const u64 y0 = (code & 2) ? A.p1[0] : ~A.p1[0], y1 = (code & 2) ? A.p1[1] : ~A.p1[1];
+    const u64 w0 = x0 & y0 & ~A.p2[0], w1 = x1 & y1 & ~A.p2[1];  // positions of the block that hold `code`
+    const u64 ma0 = a >= 64 ? ~0ULL : ((1ULL << a) - 1), ma1 = a > 64 ? ((1ULL << (a - 64)) - 1) : 0ULL;
+    const u64 mb0 = b >= 64 ? ~0ULL : ((1ULL << b) - 1), mb1 = b > 64 ? ((1ULL << (b - 64)) - 1) : 0ULL;
+    const u32 below = (u32)__popcll(w0 & ma0) + (u32)__popcll(w1 & ma1);
+    const u32 inside = (u32)__popcll(w0 & mb0 & ~ma0) + (u32)__popcll(w1 & mb1 & ~ma1);
+    lo = c4 + sel4(code, A.cnt[0], A.cnt[1], A.cnt[2], A.cnt[3]) + below;
+    hi = lo + inside;
+    return;
+  }
+  const OccLine B = occ_load(f.occ, hi >> 7);
+  lo = c4 + occ_in_line(A, lo & 127, code);
+  hi = c4 + occ_in_line(B, hi & 127, code);
+}
 DG_DEV void bs_extend_sym(const FmView& f, u32& lo, u32& hi, u32 sym, u32 code) {
   if (code < 4) {
     bs_extend_code(f, lo, hi, code);

@@ -263,71 +263,74 @@ template <bool INDEL>
 __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o, u32 ipg) {
   __shared__ unsigned long long q_code[256], q_rest[256];
   __shared__ u32 q_gid[256], q_op[256];
-  __shared__ u32 q_n;
-  constexpr u32 NOPS = INDEL ? 9u : 4u;
-  if (threadIdx.x == 0) q_n = 0;
+  __shared__ u32 q_n, c_probe, c_look;
+  // operations of one position: INDEL 0 = delete, 1-3 = substitute by (old + op) & 3, 4-7 = insert base op-4;
+  // Hamming 0 = the sequence itself (position 1 only), 1-3 = substitute
+  constexpr u32 NOPS = INDEL ? 8u : 4u;
+  if (threadIdx.x == 0) {
+    q_n = 0;
+    c_probe = 0;
+    c_look = 0;
+  }
   __syncthreads();
-  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u64 gid = t / ipg;
-  const u32 item = (u32)(t % ipg);
-  u64 steps = 0, lookups = 0, probes = 0;
+  // lane -> (group, item): one division per workgroup on the scalar unit, a short subtract loop per lane (the host keeps
+  // the launch below 2^32 lanes)
+  const u32 first = blockIdx.x * 256u;
+  u32 gid = first / ipg, item = first % ipg + threadIdx.x;
+  while (item >= ipg) {
+    item -= ipg;
+    ++gid;
+  }
   const u32 K = f.K;
   const u64 kmask = (1ULL << (2 * K)) - 1;
-  bool cand = false;
+  bool cand = false, probed = false, looked = false;
   u64 code = 0, rest = 0;
-  u32 opword = 0;  // bits 0-27 Leaf::ops[0], bit 28: one op recorded; bits 29.. unused
-  u32 nrest = 0, hint = 0;
+  u32 opword = 0;  // bits 0-27 Leaf::ops[0], bit 28: one op recorded
+  u32 nrest = 0;
   if (gid < 2 * b.nq) {
-    const GidInfo gi = b.ginfo[gid];
-    if (gi.m && (gi.d_win & 512u)) {
-      const u32 m = gi.m;
-      const u64 qpk = gi.qpk;
-      u64 s_pk = 0;
-      u32 mlen = 0;
-      if (!INDEL && item == ipg - 1) {  // Hamming: the sequence itself belongs to the set
-        s_pk = qpk;
+    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);  // the whole record in one load
+    const u64 qpk = (u64)raw.y << 32 | raw.x;
+    const u32 m = raw.z, d_win = raw.w;
+    const u32 pos = item / NOPS + 1, op = item % NOPS;  // the operation sits right of q[0..pos)
+    if (m && (d_win & 512u) && pos <= m) {
+      const u32 R = m - pos;  // unchanged characters right of it
+      const u64 low = qpk & ((1ULL << (2 * R)) - 1);
+      const u32 old = (u32)(qpk >> (2 * R)) & 3u;
+      u64 s_pk;
+      u32 mlen, kind = OP_S, c = (old + op) & 3u;
+      if (op == 0) {
+        if (INDEL) {
+          kind = OP_D;
+          c = 0;
+          s_pk = low | ((qpk >> (2 * R + 2)) << (2 * R));
+          mlen = m - 1;
+          cand = true;
+        } else {  // the sequence itself belongs to the Hamming set
+          s_pk = qpk;
+          mlen = m;
+          cand = pos == 1;
+        }
+      } else if (op < 4) {
+        s_pk = qpk ^ ((u64)(old ^ c) << (2 * R));  // neighbors.h:63: a different base
         mlen = m;
         cand = true;
       } else {
-        const u32 pos = item / NOPS + 1, op = item % NOPS;  // the operation sits right of q[0..pos)
-        if (pos <= m && item < m * NOPS) {
-          const u32 R = m - pos;  // unchanged characters right of it
-          const u64 low = qpk & ((1ULL << (2 * R)) - 1);
-          const u32 old = (u32)(qpk >> (2 * R)) & 3u;
-          u32 kind, c;
-          if (INDEL) {
-            kind = op == 0 ? OP_D : (op <= 4 ? OP_S : OP_I);
-            c = op == 0 ? 0u : (op - 1) & 3u;
-          } else {
-            kind = OP_S;
-            c = op;
-          }
-          if (kind == OP_D) {
-            s_pk = low | ((qpk >> (2 * R + 2)) << (2 * R));
-            mlen = m - 1;
-            cand = true;
-          } else if (kind == OP_S) {
-            s_pk = qpk ^ ((u64)(old ^ c) << (2 * R));
-            mlen = m;
-            cand = c != old;  // neighbors.h:63
-          } else {
-            s_pk = low | ((u64)c << (2 * R)) | ((qpk >> (2 * R)) << (2 * R + 2));
-            mlen = m + 1;
-            cand = pos < m;  // neighbors.h:51: nothing after the last character
-          }
-          opword = ((pos << 4) | (kind << 2) | c) | (1u << 28);
-          hint = R < K ? R : K - 1;
-        }
+        kind = OP_I;
+        c = op - 4;
+        s_pk = low | ((u64)c << (2 * R)) | ((qpk >> (2 * R)) << (2 * R + 2));
+        mlen = m + 1;
+        cand = pos < m;  // neighbors.h:51: nothing after the last character
       }
+      if (INDEL || op) opword = ((pos << 4) | (kind << 2) | c) | (1u << 28);
       if (cand) {
         code = s_pk & kmask;
         rest = s_pk >> (2 * K);
         nrest = mlen - K;
         if (f.kf_nr) {
-          ++probes;
-          cand = kf_present(f, code, hint);
+          probed = true;
+          cand = kf_present(f, code, R < K ? R : K - 1);
         } else {
-          ++lookups;
+          looked = true;
           const uint2 iv = f.ktab[code];
           cand = iv.x < iv.y;
           code = (u64)iv.y << 32 | iv.x;
@@ -338,18 +341,32 @@ __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o,
   // pack the survivors of the workgroup into its first lanes
   const unsigned long long mask = __ballot(cand);
   const u32 lane = threadIdx.x & 63;
+  const u32 np = (u32)__popcll(__ballot(probed)), nl = (u32)__popcll(__ballot(looked));
   u32 base = 0;
-  if (lane == 0 && mask) base = atomicAdd(&q_n, (u32)__popcll(mask));
+  if (lane == 0) {
+    if (mask) base = atomicAdd(&q_n, (u32)__popcll(mask));
+    if (np) atomicAdd(&c_probe, np);
+    if (nl) atomicAdd(&c_look, nl);
+  }
   base = __shfl(base, 0);
   if (cand) {
     const u32 at = base + (u32)__popcll(mask & ((1ULL << lane) - 1));
     q_code[at] = code;
     q_rest[at] = rest | ((u64)nrest << 56);
-    q_gid[at] = (u32)gid;
+    q_gid[at] = gid;
     q_op[at] = opword;
   }
   __syncthreads();
-  if (threadIdx.x < q_n) {
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  if (threadIdx.x == 0) {
+    if (c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
+    if (c_look) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)c_look);
+  }
+  const u32 qn = q_n;
+  if ((threadIdx.x & ~63u) >= qn) return;  // this wavefront has no survivor to work on
+  u32 steps = 0;
+  const bool work = threadIdx.x < qn;
+  if (work) {
     const u64 cd = q_code[threadIdx.x];
     u64 rs = q_rest[threadIdx.x];
     const u32 g = q_gid[threadIdx.x], ow = q_op[threadIdx.x];
@@ -357,7 +374,6 @@ __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o,
     rs &= (1ULL << 56) - 1;
     u32 lo, hi;
     if (f.kf_nr) {
-      ++lookups;
       const uint2 iv = f.ktab[cd];
       lo = iv.x;
       hi = iv.y;
@@ -366,13 +382,12 @@ __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o,
       hi = (u32)(cd >> 32);
     }
     while (n && lo < hi) {
-      bs_extend_code(f, lo, hi, (u32)rs & 3u);
+      bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
       rs >>= 2;
       --n;
       ++steps;
     }
     if (lo < hi) {
-      const u32 shard = blockIdx.x & (NSHARD - 1);
       const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
       const u32 slot = atomicAdd(o.grp_cnt + g, 1u);
       if (at < o.shard_cap) {
@@ -388,9 +403,12 @@ __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o,
       }
     }
   }
-  wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
-  wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
-  wave_add(&o.ctr->probes[blockIdx.x & (NSHARD - 1)], probes);
+  for (int off = 32; off > 0; off >>= 1) steps += __shfl_xor(steps, off);
+  const u32 nwork = (u32)__popcll(__ballot(work));
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (f.kf_nr) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nwork);
+  }
 }
 
 template <bool INDEL, int D>
@@ -1680,7 +1698,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   static const bool no_fast1 = std::getenv("DICEY_NO_FAST1") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
   Batch b;
-  b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen <= 31 && maxlen > ix->view.K) ? ix->view.K : 0u;
+  b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen <= 31 && maxlen > ix->view.K && ngrp * (u64)maxlen * 9 < 0xFFFFFF00ull) ? ix->view.K : 0u;
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
   b.xs_off = d_xs_off;
@@ -1769,7 +1787,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       so.ctr = ctr;
       so.grp_cnt = grp_cnt;
       if (b.fastK) {  // distance 1: the flat kernel takes every query that qualifies, k_search (one lane per strand) the rest
-        const u32 ipg = indel ? maxlen * 9u : maxlen * 4u + 1u;
+        const u32 ipg = indel ? maxlen * 8u : maxlen * 4u;
         const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
         if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);

@@ -130,9 +130,27 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--same-device", action="store_true",
                     help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--dump-gather", default="",
+                    help="directory: every rank writes the hit-list bytes of its last step (local_<rank>.bin) and rank 0 what the "
+                         "gather delivered for every rank (gathered_<rank>.bin); used by the tests")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand: launch the ranks ourselves, exactly as the driver would (one process per GPU)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; using the launcher's world size", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.same_device:
@@ -218,6 +236,8 @@ def main():
                 pipe["g"] = PipelinedGather(int(nbytes * 1.25) + 4096, dev if a.backend == "nccl" else torch.device("cpu"))
             pipe["g"].submit(parts)
             torch.cuda.current_stream().synchronize()  # the library reuses its buffers in the next step, on its own stream
+            if a.dump_gather:
+                pipe["last_local"] = torch.cat([t.reshape(-1) for t in parts]).cpu().numpy().tobytes()
         L.dg_hunt_result_free(rp)
         return res
 
@@ -234,6 +254,12 @@ def main():
     gathered = pipe["g"].finish() if pipe["g"] is not None else 0  # every gather completes inside the timed region
     barrier()
     elapsed = time.perf_counter() - t_start
+    if a.dump_gather and pipe["g"] is not None:
+        os.makedirs(a.dump_gather, exist_ok=True)
+        open(os.path.join(a.dump_gather, f"local_{rank}.bin"), "wb").write(pipe.get("last_local", b""))
+        if rank == 0:
+            for r, payload in enumerate(pipe["g"].last_received()):
+                open(os.path.join(a.dump_gather, f"gathered_{r}.bin"), "wb").write(payload)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -17,6 +17,8 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <functional>
 #include <sys/stat.h>
 #include <vector>
 
@@ -122,6 +124,22 @@ int device_from_env() {
   const char* e = std::getenv("DICEY_DEVICE");
   return e ? std::atoi(e) : 0;
 }
+// DICEY_DEVICES=0,1,2,...: the GPUs a batch is sharded over (a device may be listed more than once: one replica each)
+std::vector<int> devices_from_env() {
+  std::vector<int> out;
+  if (const char* e = std::getenv("DICEY_DEVICES")) {
+    std::string tok;
+    for (const char* q = e;; ++q) {
+      if (*q == ',' || *q == 0) {
+        if (!tok.empty()) out.push_back(std::atoi(tok.c_str()));
+        tok.clear();
+        if (!*q) break;
+      } else tok.push_back(*q);
+    }
+  }
+  if (out.empty()) out.push_back(device_from_env());
+  return out;
+}
 
 // ------------------------------------------------------------------------------------------------ hunt (hunter.h:177-447)
 int hunter(int argc, char** argv) {
@@ -170,7 +188,27 @@ int hunter(int argc, char** argv) {
     return 1;
   }
   std::string index_file = strip_last_extension(c.genome) + ".fm9";
-  dg_index* ix = nullptr;
+  // hunter.h:262-287: a FASTA file of queries, or the literal sequence (read before the index is opened: the shard plan
+  // needs the count; a malformed input is still reported after a failing index, as in the reference)
+  std::vector<std::pair<std::string, std::string>> queries;
+  bool bad_fasta = false;
+  if (is_regular(c.input)) {
+    if (!is_fasta(c.input)) bad_fasta = true;
+    else {
+      std::ifstream fa(c.input.c_str());
+      std::string line, fan, faseq;
+      while (std::getline(fa, line)) {
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+          if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
+          faseq.clear();
+          fan = line.substr(1);
+        } else faseq += line;
+      }
+      if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
+    }
+  } else queries.emplace_back(std::string(), c.input);
+
   // the K-mer jump table (up to 137 GB, ~1.5 s to derive) only pays off for large batches: a literal sequence or a
   // small FASTA is answered from the Occ blocks alone
   uint32_t open_flags = DG_OPEN_DEFAULT;
@@ -179,33 +217,40 @@ int hunter(int argc, char** argv) {
     if (!(stat(c.input.c_str(), &ist) == 0 && S_ISREG(ist.st_mode) && ist.st_size > (1 << 20)) && !std::getenv("DICEY_KMER_K"))
       open_flags |= DG_OPEN_NO_KMER_TABLE;
   }
-  if (dg_index_open(index_file.c_str(), device_from_env(), open_flags, &ix) != DG_OK) {
-    std::cerr << "dicey: " << dg_last_error() << std::endl;
-    msg.push_back("Error: FM-Index cannot be loaded!");
-    emit(c, hunt_json(c, c.distance, c.input, "", seqname, none, msg));
-    return 1;
+  // Queries are independent (hunter.h:291), so a batch shards over the GPUs of the node by contiguous ranges
+  // (ceil(nq/G) each): DICEY_DEVICES=0,1,... gives one host thread and one full index replica per listed
+  // device; results are written in query order.  One device (DICEY_DEVICE, default 0): results stream out chunk by chunk.
+  std::vector<int> devices = devices_from_env();
+  if (devices.size() > queries.size()) devices.resize(std::max<size_t>(1, queries.size()));
+  const size_t G = devices.size();
+  std::vector<dg_index*> handles(G, nullptr);
+  std::vector<std::string> open_err(G);
+  {
+    std::vector<std::thread> pool;
+    for (size_t g = 0; g < G; ++g)
+      pool.emplace_back([&, g]() {
+        if (dg_index_open(index_file.c_str(), devices[g], open_flags, &handles[g]) != DG_OK) open_err[g] = dg_last_error();
+      });
+    for (auto& t : pool) t.join();
   }
-  // hunter.h:262-287: a FASTA file of queries, or the literal sequence
-  std::vector<std::pair<std::string, std::string>> queries;
-  if (is_regular(c.input)) {
-    if (!is_fasta(c.input)) {
-      msg.push_back("Error: Input file is not in FASTA format!");
+  auto close_all = [&]() {
+    for (dg_index* h : handles)
+      if (h) dg_index_close(h);
+  };
+  for (size_t g = 0; g < G; ++g)
+    if (!handles[g]) {
+      std::cerr << "dicey: " << open_err[g] << std::endl;
+      msg.push_back("Error: FM-Index cannot be loaded!");
       emit(c, hunt_json(c, c.distance, c.input, "", seqname, none, msg));
-      dg_index_close(ix);
+      close_all();
       return 1;
     }
-    std::ifstream fa(c.input.c_str());
-    std::string line, fan, faseq;
-    while (std::getline(fa, line)) {
-      if (line.empty()) continue;
-      if (line[0] == '>') {
-        if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
-        faseq.clear();
-        fan = line.substr(1);
-      } else faseq += line;
-    }
-    if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
-  } else queries.emplace_back(std::string(), c.input);
+  if (bad_fasta) {
+    msg.push_back("Error: Input file is not in FASTA format!");
+    emit(c, hunt_json(c, c.distance, c.input, "", seqname, none, msg));
+    close_all();
+    return 1;
+  }
 
   dg_hunt_params hp;
   hp.distance = c.distance;
@@ -213,53 +258,83 @@ int hunter(int argc, char** argv) {
   hp.forward_only = c.forward;
   hp.max_locations = c.max_locations;
   hp.max_neighborhood = c.max_neighborhood;
-  const size_t CHUNK = 1u << 20;
+  // queries [q0, q1) on one handle, chunk by chunk; sink(i, json line of query i) is called in query order
+  auto run_slice = [&](dg_index* ix, size_t s0, size_t s1, const std::function<void(size_t, std::string&&)>& sink, std::string& err) -> bool {
+    const size_t CHUNK = 1u << 20;
+    for (size_t q0 = s0; q0 < s1; q0 += CHUNK) {
+      size_t q1 = std::min(s1, q0 + CHUNK), nq = q1 - q0;
+      std::string qb;
+      std::vector<uint64_t> off(nq + 1, 0);
+      for (size_t i = 0; i < nq; ++i) {
+        qb += queries[q0 + i].second;
+        off[i + 1] = qb.size();
+      }
+      dg_hunt_result* R = nullptr;
+      if (dg_hunt(ix, &hp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), nq, &R) != DG_OK) {
+        err = dg_last_error();  // outside the supported envelope: say so, never guess
+        return false;
+      }
+      for (size_t i = 0; i < nq; ++i) {
+        std::vector<std::string> m;
+        std::vector<DnaHit> ht;
+        const std::string& qname = queries[q0 + i].first;
+        if (R->qflags[i] & DG_Q_TOO_SHORT) {
+          m.push_back("Error: Input sequence is shorter than 10 nucleotides!");
+          sink(q0 + i, hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m));
+          continue;
+        }
+        for (uint32_t k = 0; k < R->qnondna[i]; ++k) m.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
+        if (R->qflags[i] & DG_Q_DIST_ADJUSTED) m.push_back("Warning: Distance was adjusted to sequence length!");
+        if (R->qflags[i] & DG_Q_NBHD_EXCEEDED) {
+          std::string x = std::to_string(c.max_neighborhood);
+          m.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x + " neighbors are searched, results are likely incomplete!");
+        }
+        for (uint64_t h = R->hit_off[i]; h < R->hit_off[i + 1]; ++h) {
+          const dg_hit& H = R->hits[h];
+          ht.push_back(DnaHit{H.score, H.chr, H.start, (char)H.strand, std::string(R->refalign + h * R->aln_stride, H.aln_len),
+                              std::string(R->queryalign + h * R->aln_stride, H.aln_len)});
+        }
+        if (R->qflags[i] & DG_Q_MAX_MATCHES) {
+          std::string x = std::to_string(c.max_locations);
+          m.push_back("Warning: More than " + x + " matches found. Only first " + x + " matches are reported, results are likely incomplete!");
+        }
+        std::sort(ht.begin(), ht.end());  // hunter.h:440 — same comparator, same libstdc++ algorithm, same input order
+        std::string seq((const char*)R->qseq + R->qoff[i], R->qoff[i + 1] - R->qoff[i]);
+        sink(q0 + i, hunt_json(c, R->qdistance[i], seq, qname, seqname, ht, m));
+      }
+      dg_hunt_result_free(R);
+    }
+    return true;
+  };
   int rc_all = 0;
-  for (size_t q0 = 0; q0 < queries.size(); q0 += CHUNK) {
-    size_t q1 = std::min(queries.size(), q0 + CHUNK), nq = q1 - q0;
-    std::string qb;
-    std::vector<uint64_t> off(nq + 1, 0);
-    for (size_t i = 0; i < nq; ++i) {
-      qb += queries[q0 + i].second;
-      off[i + 1] = qb.size();
-    }
-    dg_hunt_result* R = nullptr;
-    if (dg_hunt(ix, &hp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), nq, &R) != DG_OK) {
-      std::cerr << "dicey: " << dg_last_error() << std::endl;  // outside the supported envelope: say so, never guess
+  if (G == 1) {
+    std::string err;
+    if (!run_slice(handles[0], 0, queries.size(), [&](size_t, std::string&& js) { emit(c, js); }, err)) {
+      std::cerr << "dicey: " << err << std::endl;
       rc_all = 2;
-      break;
     }
-    for (size_t i = 0; i < nq; ++i) {
-      std::vector<std::string> m;
-      std::vector<DnaHit> ht;
-      const std::string& qname = queries[q0 + i].first;
-      if (R->qflags[i] & DG_Q_TOO_SHORT) {
-        m.push_back("Error: Input sequence is shorter than 10 nucleotides!");
-        emit(c, hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m));
-        continue;
+  } else {
+    const size_t nq = queries.size(), per = (nq + G - 1) / G;
+    std::vector<std::string> lines(nq);
+    std::vector<std::string> errs(G);
+    std::vector<char> ok(G, 1);
+    std::vector<std::thread> pool;
+    for (size_t g = 0; g < G; ++g)
+      pool.emplace_back([&, g]() {
+        const size_t s0 = std::min(nq, g * per), s1 = std::min(nq, s0 + per);
+        ok[g] = run_slice(handles[g], s0, s1, [&](size_t i, std::string&& js) { lines[i] = std::move(js); }, errs[g]);
+      });
+    for (auto& t : pool) t.join();
+    for (size_t g = 0; g < G && !rc_all; ++g) {  // query order; stop at the first shard that failed
+      const size_t s0 = std::min(nq, g * per), s1 = std::min(nq, s0 + per);
+      for (size_t i = s0; i < s1 && !lines[i].empty(); ++i) emit(c, lines[i]);
+      if (!ok[g]) {
+        std::cerr << "dicey: " << errs[g] << std::endl;
+        rc_all = 2;
       }
-      for (uint32_t k = 0; k < R->qnondna[i]; ++k) m.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
-      if (R->qflags[i] & DG_Q_DIST_ADJUSTED) m.push_back("Warning: Distance was adjusted to sequence length!");
-      if (R->qflags[i] & DG_Q_NBHD_EXCEEDED) {
-        std::string x = std::to_string(c.max_neighborhood);
-        m.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x + " neighbors are searched, results are likely incomplete!");
-      }
-      for (uint64_t h = R->hit_off[i]; h < R->hit_off[i + 1]; ++h) {
-        const dg_hit& H = R->hits[h];
-        ht.push_back(DnaHit{H.score, H.chr, H.start, (char)H.strand, std::string(R->refalign + h * R->aln_stride, H.aln_len),
-                            std::string(R->queryalign + h * R->aln_stride, H.aln_len)});
-      }
-      if (R->qflags[i] & DG_Q_MAX_MATCHES) {
-        std::string x = std::to_string(c.max_locations);
-        m.push_back("Warning: More than " + x + " matches found. Only first " + x + " matches are reported, results are likely incomplete!");
-      }
-      std::sort(ht.begin(), ht.end());  // hunter.h:440 — same comparator, same libstdc++ algorithm, same input order
-      std::string seq((const char*)R->qseq + R->qoff[i], R->qoff[i + 1] - R->qoff[i]);
-      emit(c, hunt_json(c, R->qdistance[i], seq, qname, seqname, ht, m));
     }
-    dg_hunt_result_free(R);
   }
-  dg_index_close(ix);
+  close_all();
   return rc_all;
 }
 

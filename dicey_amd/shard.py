@@ -69,6 +69,7 @@ class PipelinedGather:
         self.work = [None] * depth
         self.n = 0
         self.bytes_received = 0
+        self.last_slot = None  # receive buffers of the most recently completed gather (rank dst)
 
     def _drain(self, slot):
         if self.work[slot] is not None:
@@ -77,6 +78,16 @@ class PipelinedGather:
             if self.rank == self.dst:  # lengths are read only now: no host synchronisation on the submit path
                 for buf in self.recv[slot]:
                     self.bytes_received += int(buf[:8].view(torch.int64).item())
+
+    def last_received(self) -> List[bytes]:
+        """Rank dst, after finish(): the payload every rank sent in the last completed gather, in rank order."""
+        if self.rank != self.dst or self.last_slot is None:
+            return []
+        out = []
+        for buf in self.recv[self.last_slot]:
+            n = int(buf[:8].view(torch.int64).item())
+            out.append(buf[8:8 + n].cpu().numpy().tobytes())
+        return out
 
     def submit(self, payload):
         """payload: a uint8 tensor, or a sequence of them (copied one after the other: no concatenated temporary)."""
@@ -87,16 +98,20 @@ class PipelinedGather:
         slot = self.n % self.depth
         self._drain(slot)
         buf = self.send[slot]
-        buf[:8] = torch.tensor([total], dtype=torch.int64).view(torch.uint8).to(buf.device, non_blocking=True)
+        buf[:8] = torch.tensor([total], dtype=torch.int64).view(torch.uint8).to(buf.device)
         at = 8
         for t in parts:
-            buf[at:at + t.numel()] = t.to(buf.device, non_blocking=True) if t.device != buf.device else t
+            # staging buffer on another device (the gloo/CPU path): a blocking copy, so the bytes are there before the gather
+            # reads them; same device: an ordinary stream-ordered copy
+            buf[at:at + t.numel()] = t.to(buf.device) if t.device != buf.device else t
             at += int(t.numel())
         self.work[slot] = dist.gather(buf, self.recv[slot] if self.rank == self.dst else None, dst=self.dst, group=self.group,
                                       async_op=True)
         self.n += 1
 
     def finish(self) -> int:
-        for slot in range(self.depth):
-            self._drain(slot)
+        for k in range(self.depth):  # oldest first
+            self._drain((self.n + k) % self.depth)
+        if self.n and self.rank == self.dst:
+            self.last_slot = (self.n - 1) % self.depth
         return self.bytes_received

@@ -1,0 +1,72 @@
+"""The N>1 entry points, run for real on whatever the box has: `bench.py --gpus 2` launches its own ranks (as the driver's
+torch.distributed.run command would) and the C++ host shards a batch over DICEY_DEVICES.  On a 1-GPU box both ranks /
+both device slots use GPU 0 (--same-device, gloo; DICEY_DEVICES=0,0): the control flow, the sharding and the gather are
+the multi-GPU ones, only the wires differ."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_gpus2_spawns_ranks_and_gathers_hit_lists(tmp_path):
+    dump = str(tmp_path / "gather")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--genome-size", "2e6",
+           "--queries", "2000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--dump-gather", dump]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["gathered_bytes_per_step"] > 0
+    assert out["value"] > 0 and out["steps"] == 3
+    total = 0
+    for r in range(2):
+        local = open(os.path.join(dump, f"local_{r}.bin"), "rb").read()
+        got = open(os.path.join(dump, f"gathered_{r}.bin"), "rb").read()
+        assert local and got == local, (r, len(local), len(got))
+        total += len(local)
+    assert abs(out["gathered_bytes_per_step"] - total) < 1e-6 * total + 1  # the same queries every step
+
+
+def test_cli_shards_a_batch_over_dicey_devices(tmp_path):
+    """`dicey hunt` with DICEY_DEVICES=0,0,0: three host threads, three index replicas, contiguous query shards
+    (SURVEY.md 8(e)); stdout and the gz outfile must be byte-identical to the single-device run, capped queries included"""
+    import gzip
+    import random
+    from conftest import genome_text, make_genome, make_queries
+    dicey = os.path.join(ROOT, "dicey_amd", "dicey")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dicey_amd", "cli"), "-s"])
+    seqs = make_genome(77, 3, 15000)
+    fa = tmp_path / "g.fa.gz"
+    with gzip.open(fa, "wt") as f:
+        for i, s in enumerate(seqs):
+            f.write(">c%d\n%s\n" % (i, s))
+    assert subprocess.run([dicey, "index", str(fa)], capture_output=True).returncode == 0
+    qs = make_queries(3, genome_text(seqs), 101, lens=(12, 20, 26)) + ["ACGTAC", "N" * 15]
+    random.Random(1).shuffle(qs)
+    qf = tmp_path / "q.fa"
+    qf.write_text("".join(">q%d\n%s\n" % (i, q) for i, q in enumerate(qs)))
+    for extra in ([], ["-d", "2", "-m", "5"]):
+        one = subprocess.run([dicey, "hunt", *extra, "-g", str(fa), str(qf)], capture_output=True, text=True)
+        assert one.returncode == 0, one.stderr
+        env = dict(os.environ, DICEY_DEVICES="0,0,0")
+        many = subprocess.run([dicey, "hunt", *extra, "-g", str(fa), str(qf)], capture_output=True, text=True, env=env)
+        assert many.returncode == 0, many.stderr
+        assert many.stdout == one.stdout and many.stdout.count("\n") == len(qs)
+    out = tmp_path / "o.json.gz"
+    r = subprocess.run([dicey, "hunt", "-o", str(out), "-g", str(fa), str(qf)], capture_output=True, text=True,
+                       env=dict(os.environ, DICEY_DEVICES="0,0"))
+    assert r.returncode == 0 and r.stdout == ""
+    one = subprocess.run([dicey, "hunt", "-g", str(fa), str(qf)], capture_output=True, text=True)
+    assert gzip.open(out, "rt").read().replace(str(out), "") == one.stdout  # only the outfile field differs

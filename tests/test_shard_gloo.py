@@ -44,6 +44,16 @@ def _worker(rank, world, port, out):
     if rank == 0:
         assert got_bytes == int(t.item()), (got_bytes, int(t.item()))
         assert pg.cap == 74
+        # the contents of the last gather, rank by rank (step 4)
+        assert pg.last_received() == [bytes([(r * 16 + 4) % 256]) * (20 + r * 7 + 4) for r in range(world)]
+    else:
+        assert pg.last_received() == []
+    # multi-part payloads are laid out one after the other
+    pg2 = PipelinedGather(capacity=40, device="cpu", depth=2)
+    pg2.submit([torch.full((3,), rank, dtype=torch.uint8), torch.empty(0, dtype=torch.uint8), torch.full((5,), 100 + rank, dtype=torch.uint8)])
+    pg2.finish()
+    if rank == 0:
+        assert pg2.last_received() == [bytes([r] * 3 + [100 + r] * 5) for r in range(world)]
     dist.barrier()
     dist.destroy_process_group()
 

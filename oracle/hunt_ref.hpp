@@ -8,6 +8,7 @@
 //
 // Each function names the reference lines it follows.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <set>
@@ -222,6 +223,86 @@ inline std::string json_str(const std::string& s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The reference serialises every JSON object with nlohmann::json::dump() (hunter.h:112-116,122-152, silica.h:113-181).
+// When oracle/_ref/libjsonref.so (that very header, compiled in place) has been loaded with orc_use_ref_json, the writers
+// below build their objects THROUGH it — member by member, in the reference's assignment order and with its member types
+// — and only the fixed punctuation between objects is written here.  Without it they fall back to json_str / std::to_string
+// (same output on everything tests/test_oracle.py::test_own_json_writer_equals_reference_nlohmann tries).
+struct RefJsonApi {
+  void* (*nw)() = nullptr;
+  void (*del)(void*) = nullptr;
+  void (*set_str)(void*, const char*, const char*, uint64_t) = nullptr;
+  void (*set_u64)(void*, const char*, uint64_t) = nullptr;
+  void (*set_i64)(void*, const char*, int64_t) = nullptr;
+  void (*set_bool)(void*, const char*, int) = nullptr;
+  void (*set_f64)(void*, const char*, double) = nullptr;
+  char* (*dump)(void*, uint64_t*) = nullptr;
+  void (*release)(char*) = nullptr;
+  bool ok() const { return nw && del && set_str && set_u64 && set_i64 && set_bool && set_f64 && dump && release; }
+};
+inline RefJsonApi& ref_json_api() {
+  static RefJsonApi api;
+  return api;
+}
+inline bool& ref_json_enabled() {
+  static bool on = false;
+  return on;
+}
+// one JSON object; members in any order (nlohmann keeps a std::map, the fallback sorts the same way)
+class JsonObject {
+ public:
+  JsonObject() {
+    if (ref_json_enabled()) h_ = ref_json_api().nw();
+  }
+  ~JsonObject() {
+    if (h_) ref_json_api().del(h_);
+  }
+  JsonObject(const JsonObject&) = delete;
+  void str(const char* k, const std::string& v) {
+    if (h_) ref_json_api().set_str(h_, k, v.data(), v.size());
+    else own_.emplace_back(k, json_str(v));
+  }
+  void u64(const char* k, uint64_t v) {
+    if (h_) ref_json_api().set_u64(h_, k, v);
+    else own_.emplace_back(k, std::to_string(v));
+  }
+  void i64(const char* k, int64_t v) {
+    if (h_) ref_json_api().set_i64(h_, k, v);
+    else own_.emplace_back(k, std::to_string(v));
+  }
+  void boolean(const char* k, bool v) {
+    if (h_) ref_json_api().set_bool(h_, k, v);
+    else own_.emplace_back(k, v ? "true" : "false");
+  }
+  // doubles: `formatted` is what the caller's number printer gives (the fallback has no Grisu2 of its own)
+  void f64(const char* k, double v, const std::string& formatted) {
+    if (h_) ref_json_api().set_f64(h_, k, v);
+    else own_.emplace_back(k, formatted);
+  }
+  std::string dump() {
+    if (h_) {
+      uint64_t n = 0;
+      char* p = ref_json_api().dump(h_, &n);
+      if (!p) return "<nlohmann::json::dump() threw: the reference would terminate here>";
+      std::string s(p, n);
+      ref_json_api().release(p);
+      return s;
+    }
+    std::sort(own_.begin(), own_.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    std::string o = "{";
+    for (size_t i = 0; i < own_.size(); ++i) {
+      if (i) o.push_back(',');
+      o += json_str(own_[i].first) + ":" + own_[i].second;
+    }
+    return o + "}";
+  }
+
+ private:
+  void* h_ = nullptr;
+  std::vector<std::pair<std::string, std::string>> own_;
+};
+
+// ---------------------------------------------------------------------------------------------
 // hunter.h:53-66 DnaHit, :99-160 writer, :289-444 per-query loop
 // ---------------------------------------------------------------------------------------------
 struct DnaHit {
@@ -250,38 +331,50 @@ inline std::string hunt_json(const HuntParams& p, uint32_t distance, const std::
                              const std::vector<std::string>& msg) {
   std::string o = "{\"errors\": [";
   bool errors = false;
-  for (size_t i = 0; i < msg.size(); ++i) {
+  for (size_t i = 0; i < msg.size(); ++i) {  // hunter.h:105-118
     bool err = msg[i].compare(0, 5, "Error") == 0;
     errors |= err;
+    JsonObject e;
+    e.str("type", err ? "error" : "warning");
+    e.str("title", msg[i]);
     if (i) o.push_back(',');
-    o += "{\"title\":" + json_str(msg[i]) + ",\"type\":" + json_str(err ? "error" : "warning") + "}";
+    o += e.dump();
   }
   o.push_back(']');
   if (!errors) {
-    o += ",\"meta\":{\"distance\":" + std::to_string(distance);
-    o += std::string(",\"forwardonly\":") + (p.reverse ? "false" : "true");
-    o += ",\"genome\":" + json_str(p.genome);
-    o += std::string(",\"hamming\":") + (p.indel ? "false" : "true");
-    o += ",\"maxmatches\":" + std::to_string(p.max_locations);
-    if (!qname.empty()) o += ",\"name\":" + json_str(qname);
-    o += ",\"outfile\":" + json_str(p.outfile);
-    o += ",\"sequence\":" + json_str(sequence);
-    o += ",\"subcommand\":\"hunt\",\"version\":\"0.5.1\"},\"data\":[";
+    o += ",\"meta\":";
+    {  // hunter.h:122-134
+      JsonObject meta;
+      meta.str("version", "0.5.1");
+      meta.str("subcommand", "hunt");
+      meta.u64("distance", distance);
+      meta.str("sequence", sequence);
+      if (!qname.empty()) meta.str("name", qname);
+      meta.str("genome", p.genome);
+      meta.str("outfile", p.outfile);
+      meta.u64("maxmatches", p.max_locations);
+      meta.boolean("hamming", !p.indel);
+      meta.boolean("forwardonly", !p.reverse);
+      o += meta.dump() + ",";
+    }
+    o += "\"data\":[";
     uint32_t oldchr = 999999, oldstart = 0;
     bool first = true;
-    for (const auto& h : ht) {
+    for (const auto& h : ht) {  // hunter.h:140-155
       if (oldchr != h.chr || oldstart != h.start) {
         if (!first) o.push_back(',');
         first = false;
         uint32_t nuc = 0;
         for (char ch : h.refalign) nuc += (ch != '-');
-        o += "{\"chr\":" + json_str(seqname[h.chr]);
-        o += ",\"distance\":" + std::to_string(std::abs(h.score));
-        o += ",\"end\":" + std::to_string(h.start + nuc - 1);
-        o += ",\"queryalign\":" + json_str(h.queryalign);
-        o += ",\"refalign\":" + json_str(h.refalign);
-        o += ",\"start\":" + std::to_string(h.start);
-        o += ",\"strand\":" + json_str(std::string(1, h.strand)) + "}";
+        JsonObject j;
+        j.i64("distance", std::abs(h.score));
+        j.str("chr", seqname[h.chr]);
+        j.u64("start", h.start);
+        j.u64("end", h.start + nuc - 1);
+        j.str("strand", std::string(1, h.strand));
+        j.str("refalign", h.refalign);
+        j.str("queryalign", h.queryalign);
+        o += j.dump();
       }
       oldchr = h.chr;
       oldstart = h.start;

@@ -1,5 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (ctypes entry points for tests/, smoke() and bench.py's
 // cpu_baseline leg).  Nothing under dicey_amd/ may include, link or call this.
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -85,6 +87,36 @@ uint64_t orc_bf_locate(const char* text, uint64_t n, const char* pat, uint64_t m
     }
   return k;
 }
+
+// Route every JSON object of the hunt / search writers through the reference's own nlohmann::json (oracle/_ref/libjsonref.so,
+// built in place from /root/reference/src/jlib by oracle/Makefile).  path == NULL switches back to the restated writer.
+// Returns 1 when the reference library is in use.
+int orc_use_ref_json(const char* path) {
+  ref_json_enabled() = false;
+  if (!path) return 0;
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) {
+    g_err = dlerror();
+    return 0;
+  }
+  RefJsonApi& a = ref_json_api();
+  a.nw = (void* (*)())dlsym(h, "ref_json_new");
+  a.del = (void (*)(void*))dlsym(h, "ref_json_free");
+  a.set_str = (void (*)(void*, const char*, const char*, uint64_t))dlsym(h, "ref_json_set_str");
+  a.set_u64 = (void (*)(void*, const char*, uint64_t))dlsym(h, "ref_json_set_u64");
+  a.set_i64 = (void (*)(void*, const char*, int64_t))dlsym(h, "ref_json_set_i64");
+  a.set_bool = (void (*)(void*, const char*, int))dlsym(h, "ref_json_set_bool");
+  a.set_f64 = (void (*)(void*, const char*, double))dlsym(h, "ref_json_set_f64");
+  a.dump = (char* (*)(void*, uint64_t*))dlsym(h, "ref_json_dump");
+  a.release = (void (*)(char*))dlsym(h, "ref_json_release");
+  if (!a.ok()) {
+    g_err = "libjsonref.so lacks the object builder";
+    return 0;
+  }
+  ref_json_enabled() = true;
+  return 1;
+}
+int orc_ref_json_in_use() { return ref_json_enabled() ? 1 : 0; }
 
 // neighbors.h:86 — newline-joined, std::set order
 char* orc_neighbors(const char* query, int dist, int indel, uint32_t maxsize, uint64_t* count) {

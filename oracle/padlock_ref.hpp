@@ -245,11 +245,22 @@ struct PadlockRun {
     std::ostringstream rc, of;
     bool firstRec = true;
     if (c.json) {  // padlock.h:273-299; nlohmann dump(): keys in alphabetical order
-      rc << "{\"errors\": [],\"meta\":{";
-      rc << "\"armlength\":" << c.armlen << ",\"barcodes\":" << json_str(c.barcodes) << ",\"distance\":" << c.distance;
-      rc << ",\"genome\":" << json_str(c.genome) << ",\"gtf\":" << json_str(c.gtf) << ",\"hamming\":" << (c.indel ? "false" : "true");
-      rc << ",\"infile\":" << json_str(c.infile) << ",\"jsonfile\":" << json_str(c.jsonfile) << ",\"outfile\":" << json_str(c.outfile);
-      rc << ",\"subcommand\":\"padlock\",\"version\":\"0.5.1\"},";
+      rc << "{\"errors\": [],\"meta\":";
+      {  // padlock.h:282-295, through the reference's nlohmann when oracle/_ref is loaded (hunt_ref.hpp JsonObject)
+        JsonObject meta;
+        meta.str("version", "0.5.1");
+        meta.str("subcommand", "padlock");
+        meta.u64("armlength", c.armlen);
+        meta.u64("distance", c.distance);
+        meta.str("genome", c.genome);
+        meta.str("infile", c.infile);
+        meta.str("outfile", c.outfile);
+        meta.str("barcodes", c.barcodes);
+        meta.str("gtf", c.gtf);
+        meta.str("jsonfile", c.jsonfile);
+        meta.boolean("hamming", !c.indel);
+        rc << meta.dump() << ",";
+      }
       rc << "\"data\":{\"columns\": [";
       rc << "\"Gene\", \"Symbol\", \"Code\", \"Position\", \"UCSC\", \"Strand\", \"FeatureCoordinates\", \"ProbeSeq\", \"SpacerLeft\", "
             "\"AnchorSeq\", \"BarcodeSeq\", \"SpacerRight\", \"PadlockSeq\", \"Arm1TM\", \"Arm2TM\", \"BarcodeTM\", \"ProbeTM\", \"Arm1GC\", "

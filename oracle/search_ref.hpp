@@ -64,28 +64,48 @@ struct SearchRun {
                    const std::vector<std::string>& pSeq, const std::vector<std::string>& msg, uint32_t distance) const {
     std::string o = "{\"errors\": [";
     bool errors = false;
-    for (size_t i = 0; i < msg.size(); ++i) {
+    for (size_t i = 0; i < msg.size(); ++i) {  // silica.h:106-119
       bool err = msg[i].compare(0, 5, "Error") == 0;
       errors |= err;
+      JsonObject e;
+      e.str("type", err ? "error" : "warning");
+      e.str("title", msg[i]);
       if (i) o.push_back(',');
-      o += "{\"title\":" + json_str(msg[i]) + ",\"type\":" + json_str(err ? "error" : "warning") + "}";
+      o += e.dump();
     }
     o.push_back(']');
     if (!errors) {
-      o += ",\"meta\":{\"distance\":" + std::to_string(distance) + ",\"genome\":" + json_str(c.genome);
-      o += std::string(",\"hamming\":") + (c.indel ? "false" : "true") + ",\"maxmatches\":" + std::to_string(c.max_locations);
-      o += ",\"outfile\":" + json_str(c.outfile) + ",\"subcommand\":\"search\",\"version\":\"0.5.1\"},";
+      o += ",\"meta\":";
+      {  // silica.h:126-134
+        JsonObject meta;
+        meta.str("version", "0.5.1");
+        meta.str("subcommand", "search");
+        meta.u64("distance", distance);
+        meta.str("genome", c.genome);
+        meta.str("outfile", c.outfile);
+        meta.u64("maxmatches", c.max_locations);
+        meta.boolean("hamming", !c.indel);
+        o += meta.dump() + ",";
+      }
       o += "\"data\":{\"primers\":[";
-      for (size_t i = 0; i < allp.size(); ++i) {
+      for (size_t i = 0; i < allp.size(); ++i) {  // silica.h:138-153
         const PrimerBind& p = allp[i];
         if (i) o.push_back(',');
-        o += "{\"Chrom\":" + json_str(seqname[p.refIndex]) + ",\"End\":" + std::to_string(p.pos + pSeq[p.primerId].size());
-        o += ",\"Genome\":" + json_str(p.genome) + ",\"Id\":" + std::to_string(i) + ",\"MatchTm\":" + num(p.perfTemp);
-        o += ",\"Name\":" + json_str(pName[p.primerId]) + ",\"Ori\":" + json_str(p.onFor ? "forward" : "reverse");
-        o += ",\"Pos\":" + std::to_string(p.pos + 1) + ",\"Seq\":" + json_str(pSeq[p.primerId]) + ",\"Tm\":" + num(p.temp) + "}";
+        JsonObject j;
+        j.str("Chrom", seqname[p.refIndex]);
+        j.u64("Id", i);
+        j.f64("Tm", p.temp, num(p.temp));
+        j.u64("Pos", p.pos + 1);
+        j.u64("End", p.pos + pSeq[p.primerId].size());
+        j.str("Ori", p.onFor ? "forward" : "reverse");
+        j.str("Name", pName[p.primerId]);
+        j.f64("MatchTm", p.perfTemp, num(p.perfTemp));
+        j.str("Seq", pSeq[p.primerId]);
+        j.str("Genome", p.genome);
+        o += j.dump();
       }
       o += "],\"amplicons\":[";
-      for (size_t i = 0; i < pcr.size(); ++i) {
+      for (size_t i = 0; i < pcr.size(); ++i) {  // silica.h:156-181
         const PcrProduct& a = pcr[i];
         if (i) o.push_back(',');
         // faidx_fetch_seq(chr, forPos, revPos + len - 1): inclusive, clipped to the sequence
@@ -98,12 +118,23 @@ struct SearchRun {
           if (e0 >= clen) e0 = clen - 1;
           if (e0 >= b0) seqstr = text->substr(cstart + b0, e0 - b0 + 1);
         }
-        o += "{\"Chrom\":" + json_str(seqname[a.refIndex]) + ",\"ForEnd\":" + std::to_string(a.forPos + pSeq[a.forId].size());
-        o += ",\"ForName\":" + json_str(pName[a.forId]) + ",\"ForPos\":" + std::to_string(a.forPos + 1) + ",\"ForSeq\":" + json_str(pSeq[a.forId]);
-        o += ",\"ForTm\":" + num(a.forTemp) + ",\"Id\":" + std::to_string(i) + ",\"Length\":" + std::to_string(a.leng);
-        o += ",\"Penalty\":" + num(a.penalty) + ",\"RevEnd\":" + std::to_string(a.revPos + pSeq[a.revId].size());
-        o += ",\"RevName\":" + json_str(pName[a.revId]) + ",\"RevPos\":" + std::to_string(a.revPos + 1) + ",\"RevSeq\":" + json_str(pSeq[a.revId]);
-        o += ",\"RevTm\":" + num(a.revTemp) + ",\"Seq\":" + json_str(seqstr) + "}";
+        JsonObject j;
+        j.str("Chrom", seqname[a.refIndex]);
+        j.u64("Id", i);
+        j.u64("Length", a.leng);
+        j.f64("Penalty", a.penalty, num(a.penalty));
+        j.u64("ForPos", a.forPos + 1);
+        j.u64("ForEnd", a.forPos + pSeq[a.forId].size());
+        j.f64("ForTm", a.forTemp, num(a.forTemp));
+        j.str("ForName", pName[a.forId]);
+        j.str("ForSeq", pSeq[a.forId]);
+        j.u64("RevPos", a.revPos + 1);
+        j.u64("RevEnd", a.revPos + pSeq[a.revId].size());
+        j.f64("RevTm", a.revTemp, num(a.revTemp));
+        j.str("RevName", pName[a.revId]);
+        j.str("RevSeq", pSeq[a.revId]);
+        j.str("Seq", seqstr);
+        o += j.dump();
       }
       o += "]}";
     }

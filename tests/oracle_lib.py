@@ -96,8 +96,21 @@ def lib():
                                  C.POINTER(SearchParams), C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
         L.orc_search.restype = C.c_void_p
+        L.orc_use_ref_json.argtypes = [C.c_char_p]
         _lib = L
+        # every JSON object of the writers through the reference's own nlohmann::json when oracle/_ref has it
+        if os.path.exists(REF_JSON) and os.environ.get("ORC_JSON", "ref") != "own":
+            L.orc_use_ref_json(REF_JSON.encode())
     return _lib
+
+
+def use_ref_json(on: bool) -> bool:
+    """Switch the oracle's JSON writers between the reference's nlohmann (oracle/_ref/libjsonref.so) and the restated one."""
+    return bool(lib().orc_use_ref_json(REF_JSON.encode() if on else None))
+
+
+def ref_json_in_use() -> bool:
+    return bool(lib().orc_ref_json_in_use())
 
 
 def _take(ptr, n=None):

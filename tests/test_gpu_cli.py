@@ -89,3 +89,30 @@ def test_error_paths_match_reference_messages(cli_genome):
     notfa.write_text("hello\n")
     r = subprocess.run([DICEY, "hunt", "-g", g["fa"], str(notfa)], capture_output=True, text=True)
     assert r.returncode == 1 and "Error: Input file is not in FASTA format!" in r.stdout
+
+
+def test_json_strings_with_special_characters(tmp_path):
+    """chromosome and query names with quotes, backslashes, control characters and UTF-8: the binary's writer against the
+    oracle, whose objects are dumped by the reference's own nlohmann::json (oracle/_ref/libjsonref.so) when present"""
+    seqs = make_genome(91, 3, 8000)
+    names = ['chr"1"', "back\\slash|x", "ünï©ødé_漢字😀"]
+    fa = tmp_path / 'g "x".fa.gz'
+    with gzip.open(fa, "wt") as f:
+        for n, s in zip(names, seqs):
+            f.write(">" + n + " description\n" + s + "\n")
+    assert subprocess.run([DICEY, "index", str(fa)], capture_output=True).returncode == 0
+    fm9 = str(fa)[:-3][:-3] + ".fm9" if False else str(tmp_path / 'g "x".fa.fm9')
+    assert os.path.exists(fm9)
+    qs = [seqs[0][100:120], seqs[1][300:322], seqs[2][50:62], "ACGTAC"]
+    qn = ['q "one"\twith tab', "two\\three \x01\x1f ctl", "ünï 漢字 😀", "short\x7f"]
+    qf = tmp_path / "q.fa"
+    with open(qf, "w") as f:
+        for n, s in zip(qn, qs):
+            f.write(">%s\n%s\n" % (n, s))
+    g = {"fm9": fm9, "fa": str(fa), "seqlen": [len(s) + 1 for s in seqs], "names": names}
+    for extra, kw in [([], dict(distance=1)), (["-d", "2", "-x", "40"], dict(distance=2, max_neighborhood=40))]:
+        r = subprocess.run([DICEY, "hunt", *extra, "-g", str(fa), str(qf)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.decode() == _oracle_json(g, qs, qn, **kw)
+    if os.path.exists(O.REF_JSON):
+        assert O.ref_json_in_use()

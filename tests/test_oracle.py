@@ -112,3 +112,41 @@ def test_oracle_reproduces_golden_vectors():
             js, _ = ix.hunt([len(s) + 1 for s in seqs], g["names"], case["queries"], qnames=case["qnames"],
                             genome="genome.fa.gz", **case["params"])
             assert js == case["json"]
+
+
+NASTY = ['chr1', 'chr "quoted"', 'back\\slash', 'tab\there', 'nl\nin', 'ctl\x01\x1f', 'del\x7f', 'ünï©ødé', '漢字', '😀 emoji', '',
+         'a/b', "single'quote", 'cr\rlf', '\x08\x0c', 'percent% &amp; <tag>']
+
+
+def test_own_json_writer_equals_reference_nlohmann(small_genome):
+    """Every JSON object `dicey hunt` writes goes through nlohmann::json::dump() in the reference (hunter.h:112-116,
+    122-152).  oracle/_ref/libjsonref.so is that library, compiled in place; the oracle's writers use it when it is loaded.
+    Here the restated writer (escaping, key order, integers) is held against it on names and sequences chosen to hurt."""
+    import pytest
+    if not os.path.exists(O.REF_JSON):
+        pytest.skip("oracle/_ref/libjsonref.so not built (no /root/reference on this box)")
+    g = small_genome
+    orc = O.Index(g["fm9"])
+    rng = random.Random(4)
+    seqs = g["seqs"]
+    qs, qn = [], []
+    for i, nm in enumerate(NASTY * 2):
+        s = seqs[i % 3]
+        p = rng.randrange(len(s) - 30)
+        qs.append(s[p:p + rng.choice([12, 20, 25])])
+        qn.append(nm)
+    qs += ["ACGTAC", "acgtnnacgtacgtacgtac"]
+    qn += ["short \"one\"", "lower\tcase"]
+    names = [NASTY[1], NASTY[7], NASTY[3]]
+    out = {}
+    try:
+        for mode in (True, False):
+            assert O.use_ref_json(mode) == mode
+            out[mode] = [orc.hunt(g["seqlen"], names, qs, qnames=qn, genome='/data/"genomes"/g\tx.fa.gz', outfile="o\\ut.json.gz", **kw)[0]
+                         for kw in (dict(distance=1), dict(distance=0, hamming=True, forward_only=True, max_locations=1),
+                                    dict(distance=2, max_neighborhood=50))]
+    finally:
+        O.use_ref_json(True)
+    assert out[True] == out[False]
+    assert O.ref_json_in_use()
+    assert '"chr":"chr \\"quoted\\""' in out[True][0] and "\\u0001\\u001f" in out[True][0] and "漢字" in out[True][0]

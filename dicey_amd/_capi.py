@@ -45,7 +45,7 @@ class HuntResult(C.Structure):
                 ("ctr_win_bytes", C.c_uint64), ("ctr_tab_reads", C.c_uint64), ("ms_total", C.c_double), ("ms_search", C.c_double),
                 ("ms_select", C.c_double), ("ms_locate", C.c_double), ("ms_verify", C.c_double),
                 ("d_hits", C.c_void_p), ("d_refalign", C.c_void_p), ("d_queryalign", C.c_void_p),
-                ("ctr_filter_probes", C.c_uint64)]
+                ("ctr_filter_probes", C.c_uint64), ("ms_search_flat", C.c_double)]
 
 
 class SearchParams(C.Structure):
@@ -60,7 +60,9 @@ class Site(C.Structure):
 
 class SearchResult(C.Structure):
     _fields_ = [("nprimers", C.c_size_t), ("nsites", C.c_uint64), ("sites", C.POINTER(Site)), ("genome_pool", C.POINTER(C.c_char)),
-                ("pflags", C.POINTER(C.c_uint32)), ("match_temp", C.POINTER(C.c_double)), ("nhits", C.c_uint64), ("ms_device", C.c_double)]
+                ("pflags", C.POINTER(C.c_uint32)), ("match_temp", C.POINTER(C.c_double)), ("nhits", C.c_uint64), ("ms_device", C.c_double),
+                ("ms_fm_search", C.c_double), ("ms_site_stage", C.c_double), ("ctr_ext_steps", C.c_uint64), ("ctr_tab_reads", C.c_uint64),
+                ("ctr_filter_probes", C.c_uint64), ("ctr_sa_reads", C.c_uint64)]
 
 
 class Locations(C.Structure):

@@ -662,43 +662,54 @@ int silica(int argc, char** argv) {
   }
   std::sort(allp.begin(), allp.end());  // silica.h:587
   if (!c.pruneprimer) {
-    for (uint32_t r = 0; r < nseq; ++r) {  // silica.h:592-634
-      std::vector<std::pair<uint32_t, uint32_t>> rvByPos;
-      rvByPos.reserve(revBind[r].size());
-      for (uint32_t k = 0; k < revBind[r].size(); ++k) rvByPos.push_back(std::make_pair(revBind[r][k].pos, k));
-      std::sort(rvByPos.begin(), rvByPos.end());
-      std::vector<uint32_t> rvPos(rvByPos.size());
-      for (uint32_t k = 0; k < rvByPos.size(); ++k) rvPos[k] = rvByPos[k].first;
-      std::vector<uint32_t> cand;
-      for (auto fw = forBind[r].begin(); fw != forBind[r].end(); ++fw) {
-        auto loIt = std::upper_bound(rvPos.begin(), rvPos.end(), fw->pos);
-        auto hiIt = rvPos.end();
-        uint64_t hiBound = (uint64_t)fw->pos + (uint64_t)c.maxProdSize;
-        if (hiBound < ((uint64_t)1 << 32)) hiIt = std::upper_bound(rvPos.begin(), rvPos.end(), (uint32_t)hiBound);
-        cand.clear();
-        for (auto pit = loIt; pit != hiIt; ++pit) cand.push_back(rvByPos[pit - rvPos.begin()].second);
-        std::sort(cand.begin(), cand.end());
-        for (uint32_t ci : cand) {
-          const PrimerBind& rv = revBind[r][ci];
-          if ((rv.pos > fw->pos) && (rv.pos + pSeq[rv.primerId].size() - fw->pos <= c.maxProdSize)) {
-            PcrProduct pp;
-            pp.refIndex = r;
-            pp.forPos = fw->pos;
-            pp.forTemp = fw->temp;
-            pp.forId = fw->primerId;
-            pp.revPos = rv.pos;
-            pp.revTemp = rv.temp;
-            pp.revId = rv.primerId;
-            pp.leng = (uint32_t)((rv.pos + pSeq[pp.revId].size()) - fw->pos);
-            double pen = (fw->perfTemp - fw->temp) * c.penDiff;
-            if (pen < 0) pen = 0;
-            double bpen = (rv.perfTemp - rv.temp) * c.penDiff;
-            if (bpen > 0) pen += bpen;
-            pen += std::abs(fw->temp - rv.temp) * c.penMis;
-            pen += pp.leng * c.penLen;
-            pp.penalty = pen;
-            if ((c.cutofPen < 0) || (pen < c.cutofPen)) pcrColl.push_back(pp);
-          }
+    // Amplicons (what silica.h:590-634 produces): per chromosome, every forward site in the order it was found, paired with
+    // the reverse sites — taken in the order THEY were found — that start right of it and end within maxProdSize of it.
+    // The reverse sites are looked up through a position-ordered view so that only the ones inside the window are touched;
+    // the window's members are then put back into discovery order, which is the order the products must have before the
+    // final (unstable) sort by penalty.
+    struct Placed {
+      uint32_t pos, found;  // position, discovery index within the chromosome's reverse sites
+    };
+    // the penalty of one primer pair: both Tm shortfalls against the perfect match, the Tm difference, the product length
+    // (operands and order as in silica.h:623-629: the doubles are printed with 17 significant digits)
+    auto pair_penalty = [&c](const PrimerBind& f, const PrimerBind& v, uint32_t span) {
+      const double short_f = (f.perfTemp - f.temp) * c.penDiff, short_v = (v.perfTemp - v.temp) * c.penDiff;
+      double total = short_f < 0 ? 0 : short_f;
+      if (short_v > 0) total += short_v;
+      total += std::abs(f.temp - v.temp) * c.penMis;
+      total += span * c.penLen;
+      return total;
+    };
+    std::vector<Placed> view;
+    std::vector<uint32_t> window;
+    for (uint32_t chrom = 0; chrom < nseq; ++chrom) {
+      const std::vector<PrimerBind>& fwd = forBind[chrom];
+      const std::vector<PrimerBind>& rev = revBind[chrom];
+      view.resize(rev.size());
+      for (uint32_t k = 0; k < rev.size(); ++k) view[k] = Placed{rev[k].pos, k};
+      std::sort(view.begin(), view.end(), [](const Placed& x, const Placed& y) { return x.pos != y.pos ? x.pos < y.pos : x.found < y.found; });
+      for (const PrimerBind& f : fwd) {
+        const uint64_t reach = (uint64_t)f.pos + c.maxProdSize;  // a reverse site further right cannot end inside the limit
+        const auto from = std::partition_point(view.begin(), view.end(), [&](const Placed& x) { return x.pos <= f.pos; });
+        const auto upto = std::partition_point(from, view.end(), [&](const Placed& x) { return (uint64_t)x.pos <= reach; });
+        window.clear();
+        for (auto it = from; it != upto; ++it) window.push_back(it->found);
+        std::sort(window.begin(), window.end());
+        for (uint32_t k : window) {
+          const PrimerBind& v = rev[k];
+          const uint64_t span = (uint64_t)v.pos + pSeq[v.primerId].size() - f.pos;
+          if (span > c.maxProdSize) continue;
+          PcrProduct amp;
+          amp.refIndex = chrom;
+          amp.leng = (uint32_t)span;
+          amp.forPos = f.pos;
+          amp.revPos = v.pos;
+          amp.forId = f.primerId;
+          amp.revId = v.primerId;
+          amp.forTemp = f.temp;
+          amp.revTemp = v.temp;
+          amp.penalty = pair_penalty(f, v, amp.leng);
+          if (c.cutofPen < 0 || amp.penalty < c.cutofPen) pcrColl.push_back(amp);
         }
       }
     }

@@ -1642,7 +1642,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   if (dmax_eff > DMAX) return fail(DG_ELIMIT, "distance %u exceeds the supported maximum of %u", p->distance, DMAX);
   DG_HIP(hipSetDevice(ix->device));
   hipStream_t st = ix->stream;
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 9; ++i)
     if (!ix->ev[i]) DG_HIP(hipEventCreate(&ix->ev[i]));
   auto& ws = ix->ws;
   const u64 ngrp = 2 * (u64)nq;
@@ -1791,6 +1791,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
         if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);
+        DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       // root-level work split (see k_search): only with the table and with at least one edit to place
       const u32 items = (ix->view.K && dmax_eff >= 1 && !b.fastK) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
@@ -1952,6 +1953,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->ctr_win_bytes = hsum.win_bytes;
   R->ms_total = ev_ms(ix->ev[0], ix->ev[7]);
   R->ms_search = ev_ms(ix->ev[1], ix->ev[2]);
+  R->ms_search_flat = b.fastK ? ev_ms(ix->ev[1], ix->ev[8]) : 0.0;
   R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);
   R->ms_locate = ev_ms(ix->ev[5], ix->ev[6]);
   R->ms_verify = ev_ms(ix->ev[6], ix->ev[7]);

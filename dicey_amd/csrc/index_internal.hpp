@@ -15,7 +15,7 @@ struct dg_index {
   // grow-only batch workspaces (see hunt.hip / seam.hip for the slot meaning)
   static constexpr int NWS = 21;
   dg::DevBuf ws[NWS];
-  hipEvent_t ev[8] = {nullptr};
+  hipEvent_t ev[9] = {nullptr};  // [8]: end of the flat distance-1 kernel
   uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
   uint64_t hit_cap_hint = 0;
   // dg_hunt_device: the (offsets pointer, count, bytes) of the previous call and the longest query it held; a repeated

@@ -554,6 +554,7 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   }
   const u64 nhits = hr->nhits;
   const double ms_dev = hr->ms_total;
+  const dg_hunt_result hcopy = *hr;  // counters and phase timings (the pointers inside are not used)
   dg_hunt_result_free(hr);
   std::vector<u32> qfl(np);
   DG_HIP(hipMemcpyAsync(qfl.data(), sx.d_qflags, np * 4, hipMemcpyDeviceToHost, st));
@@ -613,6 +614,12 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   R->nprimers = np;
   R->nhits = nhits;
   R->ms_device = ms_dev;
+  R->ms_fm_search = hcopy.ms_search;
+  R->ms_site_stage = hcopy.ms_verify;
+  R->ctr_ext_steps = hcopy.ctr_ext_steps;
+  R->ctr_tab_reads = hcopy.ctr_tab_reads;
+  R->ctr_filter_probes = hcopy.ctr_filter_probes;
+  R->ctr_sa_reads = hcopy.ctr_sa_reads;
   R->pflags = new uint32_t[np];
   R->match_temp = new double[np];
   *out = R;

@@ -145,6 +145,7 @@ typedef struct {
   const void* d_queryalign; /* nhits * aln_stride bytes */
   uint64_t ctr_filter_probes; /* K-mer presence-filter bits tested (one 4-byte word each); ctr_tab_reads counts the table
                                * entries actually read, i.e. the probes that found their K-mer present */
+  double ms_search_flat;      /* part of ms_search spent in the flat distance-1 kernel (k_search1); 0 when it did not run */
 } dg_hunt_result;
 
 /* Host-buffer entry point: queries are raw bytes as read from the FASTA/argv (any case), concatenated.
@@ -267,6 +268,9 @@ typedef struct {
   double* match_temp; /* [nprimers] */
   uint64_t nhits;     /* located hits, each of which went through thal() */
   double ms_device;   /* device time of the search + site kernels (HIP events) */
+  /* measurement, as in dg_hunt_result: the FM-index part and the per-hit thal()/alignment part of ms_device */
+  double ms_fm_search, ms_site_stage;
+  uint64_t ctr_ext_steps, ctr_tab_reads, ctr_filter_probes, ctr_sa_reads;
 } dg_search_result;
 /* primers: already upper-cased / N-replaced sequences (silica.h:368), each at least `kmer` long */
 int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const uint32_t* seqlen, uint32_t nseq,

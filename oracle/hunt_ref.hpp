@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <set>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "fm9.hpp"
@@ -116,6 +117,74 @@ inline std::set<std::string> neighbors(const std::string& query, const std::stri
   nb.put(q);
   nb.walk(q, dist, 0);
   return nb.S;
+}
+
+// The same set without the reference's quadratic _insert scan, for parity runs over many distance-2 queries (the literal
+// form above needs ~1.3 s per 20-mer).  Only used where the result provably does not depend on the generation order: the
+// whole <= d-edit language is enumerated into a hash set and, if it stays below maxsize (so neighbors.h:50 can never fire:
+// the working set is a subset of the strings generated so far), the answer is its substring-minimal subset (edit mode) /
+// the set itself (Hamming mode).  Otherwise the literal restatement runs.  tests/test_oracle.py holds the two against
+// each other.
+inline void language_walk(std::string& q, const std::string& alphabet, int input_dist, int dist, bool indel, int pos,
+                          std::unordered_set<std::string>& out) {
+  if (pos >= (int)q.size()) {
+    if (dist < input_dist) out.insert(q);
+    return;
+  }
+  if (dist > 0 && indel) {
+    std::string del = q.substr(0, pos) + q.substr(pos + 1);
+    language_walk(del, alphabet, input_dist, dist - 1, indel, pos, out);
+  }
+  language_walk(q, alphabet, input_dist, dist, indel, pos + 1, out);
+  if (dist > 0) {
+    const char orig = q[pos];
+    for (char a : alphabet)
+      if (a != orig) {
+        q[pos] = a;
+        language_walk(q, alphabet, input_dist, dist - 1, indel, pos + 1, out);
+      }
+    q[pos] = orig;
+    if (indel)
+      for (char a : alphabet) {
+        std::string ins = q.substr(0, pos) + std::string(1, a) + q.substr(pos);
+        language_walk(ins, alphabet, input_dist, dist - 1, indel, pos + 1, out);
+      }
+  }
+}
+inline std::set<std::string> neighbors_fast(const std::string& query, const std::string& alphabet, int dist, bool indel,
+                                            uint32_t maxsize) {
+  std::set<char> a(alphabet.begin(), alphabet.end());
+  std::string alpha(a.begin(), a.end());
+  std::unordered_set<std::string> lang;
+  lang.insert(query);
+  std::string q(query);
+  language_walk(q, alpha, dist, dist, indel, 0, lang);
+  if (lang.size() >= maxsize) return neighbors(query, alphabet, dist, indel, maxsize);
+  std::set<std::string> out;
+  if (!indel) {
+    out.insert(lang.begin(), lang.end());
+    return out;
+  }
+  const size_t minlen = query.size() > (size_t)dist ? query.size() - dist : 1;
+  for (const std::string& s : lang) {
+    bool minimal = true;
+    for (size_t len = minlen; len < s.size() && minimal; ++len)
+      for (size_t at = 0; at + len <= s.size(); ++at)
+        if (lang.count(s.substr(at, len))) {
+          minimal = false;
+          break;
+        }
+    if (minimal) out.insert(s);
+  }
+  return out;
+}
+inline bool& fast_neighbors_enabled() {
+  static bool on = false;
+  return on;
+}
+inline std::set<std::string> neighbors_for_driver(const std::string& query, const std::string& alphabet, int dist, bool indel,
+                                                   uint32_t maxsize) {
+  return fast_neighbors_enabled() ? neighbors_fast(query, alphabet, dist, indel, maxsize) : neighbors(query, alphabet, dist, indel, maxsize);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,8 +477,8 @@ inline std::string hunt_one(const Csa& fm, const std::vector<uint32_t>& seqlen, 
   }
   size_t pre_context = p.indel ? distance : 0, post_context = pre_context;
   std::vector<std::set<std::string>> fwrv(2);
-  fwrv[0] = neighbors(sequence, "ACGT", (int)distance, p.indel, p.max_neighborhood);
-  if (p.reverse) fwrv[1] = neighbors(rev, "ACGT", (int)distance, p.indel, p.max_neighborhood);
+  fwrv[0] = neighbors_for_driver(sequence, "ACGT", (int)distance, p.indel, p.max_neighborhood);
+  if (p.reverse) fwrv[1] = neighbors_for_driver(rev, "ACGT", (int)distance, p.indel, p.max_neighborhood);
   if (fwrv[0].size() >= p.max_neighborhood || fwrv[1].size() >= p.max_neighborhood) {
     std::string x = std::to_string(p.max_neighborhood);
     msg.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x +

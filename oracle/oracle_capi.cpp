@@ -118,7 +118,20 @@ int orc_use_ref_json(const char* path) {
 }
 int orc_ref_json_in_use() { return ref_json_enabled() ? 1 : 0; }
 
-// neighbors.h:86 — newline-joined, std::set order
+// hunt_one's neighbourhoods through neighbors_fast (hash-set minimality, tested equal to the literal restatement)
+void orc_fast_neighbors(int on) { fast_neighbors_enabled() = on != 0; }
+
+// neighbors.h:86 — newline-joined, std::set order; fast != 0: the hash-set form
+char* orc_neighbors2(const char* query, int dist, int indel, uint32_t maxsize, int fast, uint64_t* count) {
+  std::set<std::string> s = fast ? neighbors_fast(query, "ACGT", dist, indel != 0, maxsize) : neighbors(query, "ACGT", dist, indel != 0, maxsize);
+  std::string o;
+  for (const auto& x : s) {
+    o += x;
+    o.push_back('\n');
+  }
+  if (count) *count = s.size();
+  return dup_out(o, nullptr);
+}
 char* orc_neighbors(const char* query, int dist, int indel, uint32_t maxsize, uint64_t* count) {
   std::set<std::string> s = neighbors(query, "ACGT", dist, indel != 0, maxsize);
   std::string o;

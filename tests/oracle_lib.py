@@ -133,6 +133,23 @@ def neighbors(query: str, dist: int, indel: bool, maxsize: int = 10000):
     return out
 
 
+def neighbors_fast(query: str, dist: int, indel: bool, maxsize: int = 10000):
+    """the hash-set form used for large distance-2 parity runs (oracle/hunt_ref.hpp neighbors_fast)"""
+    cnt = C.c_uint64()
+    L = lib()
+    L.orc_neighbors2.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]
+    L.orc_neighbors2.restype = C.c_void_p
+    s = _take(L.orc_neighbors2(query.encode(), dist, int(indel), maxsize, 1, C.byref(cnt))).decode()
+    out = s.split("\n")[:-1] if s else []
+    assert len(out) == cnt.value
+    return out
+
+
+def fast_neighbors(on: bool):
+    """hunt_one / hunt_timed enumerate neighbourhoods with neighbors_fast (only for order-independent cases)"""
+    lib().orc_fast_neighbors(int(on))
+
+
 def needle(a1: str, a2: str):
     r0, r1, tg = C.c_void_p(), C.c_void_p(), C.c_uint32()
     sc = lib().orc_needle(a1.encode(), a2.encode(), C.byref(r0), C.byref(r1), C.byref(tg))

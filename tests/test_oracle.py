@@ -150,3 +150,13 @@ def test_own_json_writer_equals_reference_nlohmann(small_genome):
     assert out[True] == out[False]
     assert O.ref_json_in_use()
     assert '"chr":"chr \\"quoted\\""' in out[True][0] and "\\u0001\\u001f" in out[True][0] and "漢字" in out[True][0]
+
+
+def test_fast_neighbors_equal_the_literal_restatement():
+    """bench.py's distance-2 parity sample enumerates neighbourhoods with the hash-set form; it must be the same set"""
+    rng = random.Random(6)
+    cases = [("".join(rng.choice("ACGT") for _ in range(m)), d, indel, cap)
+             for m in (10, 13, 20) for d in (0, 1, 2) for indel in (True, False) for cap in (10000, 60)]
+    cases += [("A" * 14, 2, True, 10000), ("ACGTNNACGTACGT", 2, True, 10000), ("ACACACACACACAC", 2, True, 10000)]
+    for q, d, indel, cap in cases:
+        assert O.neighbors_fast(q, d, indel, cap) == list(O.neighbors(q, d, indel, cap)), (q, d, indel, cap)

@@ -15,6 +15,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <chrono>
 
@@ -495,6 +496,29 @@ static int build_impl(const u8* d_text, u64 len, const char* out_path) {
 }
 
 }  // namespace
+
+// Used by dg_index_open (index.hip): the suffix array as the inverse of the inverse suffix array.  isa[p] = rank of the
+// suffix at p; sorting the pairs (isa[p], p) by their key leaves the positions in rank order, i.e. SA.  Four 8-bit radix
+// passes stream the 3.1 G pairs at memory speed, where writing sa[isa[p]] = p directly is 3.1 G random 4-byte stores
+// (measured: ~2.6 G stores/s, 1.3 s).  `isa` is clobbered.
+int derive_sa_by_sort(hipStream_t st, u32* isa, u64 n, u32* sa) {
+  u32* keys_out = nullptr;
+  DG_HIP(big_alloc((void**)&keys_out, n * 4 + 64, st));
+  Scratch tmp;
+  u32 bits = 1;
+  while (bits < 32 && (1ULL << bits) < n) ++bits;
+  size_t bytes = 0;
+  rocprim::counting_iterator<u32> pos(0);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, isa, keys_out, pos, sa, (size_t)n, 0u, bits, st);
+  int rc = DG_OK;
+  if (e == hipSuccess) rc = tmp.need(bytes);
+  if (e == hipSuccess && rc == DG_OK) e = rocprim::radix_sort_pairs(tmp.p, bytes, isa, keys_out, pos, sa, (size_t)n, 0u, bits, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  big_free(keys_out, st);
+  if (rc != DG_OK) return rc;
+  if (e != hipSuccess) return fail(DG_EHIP, "suffix array by sort: %s", hipGetErrorString(e));
+  return DG_OK;
+}
 }  // namespace dg
 
 using namespace dg;

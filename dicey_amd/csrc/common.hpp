@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -71,5 +72,26 @@ struct DevBuf {
 };
 
 static inline u32 ceil_div(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// Large device allocations go through the stream-ordered pool: hipMalloc costs ~40 ms per GiB on this stack (5.8 s for the
+// 137 GB K-mer table, tools/microbench/malloc_bench.hip), hipMallocAsync 0.1-0.3 s for the same block.  Memory obtained
+// here is released with big_free on the same stream; the caller synchronises the stream before other streams use it.
+static inline hipError_t big_alloc(void** p, size_t bytes, hipStream_t st) {
+  static const bool plain = std::getenv("DICEY_PLAIN_MALLOC") != nullptr;
+  if (!plain && bytes >= ((size_t)64 << 20)) {
+    const hipError_t e = hipMallocAsync(p, bytes, st);
+    if (e == hipSuccess) return hipSuccess;
+    if (std::getenv("DICEY_TIMING")) std::fprintf(stderr, "dicey timing: hipMallocAsync(%zu) failed: %s\n", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+  }
+  return hipMalloc(p, bytes);
+}
+static inline void big_free(void* p, hipStream_t st) {
+  if (!p) return;
+  if (hipFreeAsync(p, st) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+  }
+}
 
 }  // namespace dg

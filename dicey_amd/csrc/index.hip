@@ -120,6 +120,36 @@ __global__ void k_derive_text(FmView f, u8* text) {
   }
 }
 
+// The same walk also knows the rank of every suffix it passes: after the LF step that produced T[p], i is the rank of
+// suffix p.  isa[p] = i is written next to text[p] (consecutive p per lane), and the suffix array is obtained from it by
+// a sort (derive_sa_by_sort) instead of a second walk with scattered stores.
+__global__ void k_derive_text_isa(FmView f, u8* text, u32* isa) {
+  u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= f.n_isa_samp) return;
+  u64 i = packed_get(f.isa_samp, f.samp_width, k);
+  u64 hi, lo;  // writes [lo, hi)
+  if (k == 0) {
+    hi = f.n;
+    lo = (f.n_isa_samp - 1) * 64;
+  } else {
+    hi = k * 64;
+    lo = hi - 64;
+  }
+  for (u64 p = hi; p > lo;) {
+    u32 sym;
+    i = lf_step(f, i, sym);
+    --p;
+    text[p] = (u8)sym;
+    isa[p] = (u32)i;
+  }
+}
+// the file's own SA samples must agree with the suffix array derived from its ISA samples
+__global__ void k_check_sa_samples(FmView f, const u32* sa, u32* bad) {
+  u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= f.n_sa_samp) return;
+  if (packed_get(f.sa_samp, f.samp_width, j) != sa[j * 32]) atomicAdd(bad, 1u);
+}
+
 // Full SA from SA samples: SA[LF(i)] = SA[i] - 1.  Thread j owns the LF chain that leaves index 32j and stops at
 // the next index that is itself sampled; LF is a permutation, so every unsampled index is written exactly once.
 __global__ void k_derive_sa(FmView f, u32* sa) {
@@ -262,7 +292,7 @@ static int build_filter(dg_index* ix, const uint2* tab, u32 K) {
   for (u32 r = 0; r < nr; ++r) {
     const u32 s = r + 1 < nr ? 8 * r : bits - 9;
     u32* bm = nullptr;
-    DG_HIP(hipMalloc((void**)&bm, nwords * 4 + 64));
+    DG_HIP(big_alloc((void**)&bm, nwords * 4 + 64, ix->stream));
     ix->owned.push_back(bm);
     ix->hbm_bytes += nwords * 4 + 64;
     if (generic || (r > 0 && s < 8)) {
@@ -297,18 +327,47 @@ static int build_filter(dg_index* ix, const uint2* tab, u32 K) {
   return DG_OK;
 }
 
+// The same table with one text gather per lane instead of three: the K-mers of the neighbouring suffixes come from the
+// neighbouring lanes (the first / last lane of a wavefront read theirs).
+__global__ void __launch_bounds__(256) k_kmer_table_wave(FmView f, uint2* tab, u32 K) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 none = 1ULL << 63;
+  const u64 me = i < f.n ? kmer_code_at(f, f.sa[i], K) : none;
+  const u32 lane = threadIdx.x & 63;
+  u32 plo = __shfl_up((u32)me, 1), phi = __shfl_up((u32)(me >> 32), 1);
+  u32 nlo = __shfl_down((u32)me, 1), nhi = __shfl_down((u32)(me >> 32), 1);
+  u64 prev = (u64)phi << 32 | plo, next = (u64)nhi << 32 | nlo;
+  if (i >= f.n || (me >> 63)) return;
+  if (lane == 0) prev = i ? kmer_code_at(f, f.sa[i - 1], K) : none;
+  if (lane == 63) next = i + 1 < f.n ? kmer_code_at(f, f.sa[i + 1], K) : none;
+  if (prev != me) tab[me].x = (u32)i;
+  if (next != me) tab[me].y = (u32)(i + 1);
+}
+
+struct PhaseClock {  // DICEY_TIMING=1: host wall clock of the load phases on stderr
+  bool on = std::getenv("DICEY_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    if (!on) return;
+    auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "dicey timing: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
   FmView& f = ix->view;
+  PhaseClock pc;
   const u64 n = f.n;
   const u64 nblk = (n >> 7) + 1, nhalf = nblk * 2;
   const u64 nchunk = (nhalf + HALF_PER_CHUNK - 1) / HALF_PER_CHUNK;
   OccBlock* occ = nullptr;
   u32 *half_cnt = nullptr, *chunk = nullptr, *sa = nullptr, *bad = nullptr;
   u8* text = nullptr;
-  DG_HIP(hipMalloc((void**)&occ, nblk * sizeof(OccBlock)));
+  DG_HIP(big_alloc((void**)&occ, nblk * sizeof(OccBlock), ix->stream));
   ix->owned.push_back(occ);
   DG_HIP(hipMemsetAsync(occ, 0, nblk * sizeof(OccBlock), ix->stream));
-  DG_HIP(hipMalloc((void**)&half_cnt, nhalf * 4));
+  DG_HIP(big_alloc((void**)&half_cnt, nhalf * 4, ix->stream));
   DG_HIP(hipMalloc((void**)&chunk, nchunk * 16));
   const u32 TB = 256;
   hipLaunchKernelGGL(k_decode_bwt, dim3(ceil_div(nhalf, TB)), dim3(TB), 0, ix->stream, f, occ, half_cnt, nhalf);
@@ -338,19 +397,45 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
                      nblk);
   f.occ = occ;
   DG_HIP(hipStreamSynchronize(ix->stream));
-  DG_HIP(hipFree(half_cnt));
+  big_free(half_cnt, ix->stream);
   DG_HIP(hipFree(chunk));
+  pc.lap("occ blocks");
 
-  DG_HIP(hipMalloc((void**)&text, n + 64));
+  DG_HIP(big_alloc((void**)&text, n + 64, ix->stream));
   ix->owned.push_back(text);
-  DG_HIP(hipMalloc((void**)&sa, n * 4 + 64));
+  DG_HIP(big_alloc((void**)&sa, n * 4 + 64, ix->stream));
   ix->owned.push_back(sa);
-  hipLaunchKernelGGL(k_derive_text, dim3(ceil_div(f.n_isa_samp, TB)), dim3(TB), 0, ix->stream, f, text);
-  hipLaunchKernelGGL(k_derive_sa, dim3(ceil_div(f.n_sa_samp, TB)), dim3(TB), 0, ix->stream, f, sa);
+  bool sorted_sa = false;
+  if (!std::getenv("DICEY_NO_BLOCK_SCAN") && !std::getenv("DICEY_SA_BY_WALK") && n > (1u << 16)) {
+    // text and inverse suffix array in one walk, suffix array by sorting (isa[p], p)
+    u32* isa = nullptr;
+    if (big_alloc((void**)&isa, n * 4 + 64, ix->stream) == hipSuccess) {
+      hipLaunchKernelGGL(k_derive_text_isa, dim3(ceil_div(f.n_isa_samp, TB)), dim3(TB), 0, ix->stream, f, text, isa);
+      const int rc = derive_sa_by_sort(ix->stream, isa, n, sa);
+      big_free(isa, ix->stream);
+      if (rc == DG_OK) {
+        u32* badp = nullptr;
+        u32 hbad = 0;
+        DG_HIP(hipMalloc((void**)&badp, 4));
+        DG_HIP(hipMemsetAsync(badp, 0, 4, ix->stream));
+        hipLaunchKernelGGL(k_check_sa_samples, dim3(ceil_div(f.n_sa_samp, TB)), dim3(TB), 0, ix->stream, f, (const u32*)sa, badp);
+        DG_HIP(hipMemcpyAsync(&hbad, badp, 4, hipMemcpyDeviceToHost, ix->stream));
+        DG_HIP(hipStreamSynchronize(ix->stream));
+        DG_HIP(hipFree(badp));
+        if (hbad) return fail(DG_EFORMAT, "index self-check: %u suffix-array samples of the file disagree with its inverse samples", hbad);
+        sorted_sa = true;
+      } else if (rc != DG_ENODEV && rc != DG_ENOMEM) return rc;
+    } else (void)hipGetLastError();
+  }
+  if (!sorted_sa) {  // the two independent walks (small indexes, low memory, debugging builds)
+    hipLaunchKernelGGL(k_derive_text, dim3(ceil_div(f.n_isa_samp, TB)), dim3(TB), 0, ix->stream, f, text);
+    hipLaunchKernelGGL(k_derive_sa, dim3(ceil_div(f.n_sa_samp, TB)), dim3(TB), 0, ix->stream, f, sa);
+  }
   f.text = text;
   f.sa = sa;
   DG_HIP(hipStreamSynchronize(ix->stream));
   DG_HIP(hipGetLastError());
+  pc.lap("text + suffix array");
   if (!(flags & DG_OPEN_NO_KMER_TABLE)) {
     // K = ceil(log4 n) clamped to [8,16]: about one expected occurrence per K-mer; 16 -> 34 GB, which is what the
     // 288 GB of HBM are for
@@ -368,18 +453,24 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
       int v = std::atoi(ek);
       if (v >= 8 && v <= 17) K = (u32)v;
     }
+    pc.lap("table order (hipMemGetInfo)");
     uint2* tab = nullptr;
     u64 entries = 1ULL << (2 * K);
-    DG_HIP(hipMalloc((void**)&tab, entries * sizeof(uint2)));
+    DG_HIP(big_alloc((void**)&tab, entries * sizeof(uint2), ix->stream));
     ix->owned.push_back(tab);
+    pc.lap("table hipMalloc");
     DG_HIP(hipMemsetAsync(tab, 0, entries * sizeof(uint2), ix->stream));
-    hipLaunchKernelGGL(k_kmer_table, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K);
+    static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (no wave collectives)
+    if (lane_only) hipLaunchKernelGGL(k_kmer_table, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K);
+    else hipLaunchKernelGGL(k_kmer_table_wave, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K);
     DG_HIP(hipStreamSynchronize(ix->stream));
     DG_HIP(hipGetLastError());
     f.ktab = tab;
     f.K = K;
     ix->hbm_bytes += entries * sizeof(uint2);
+    pc.lap("table fill");
     DG_TRY(build_filter(ix, tab, K));
+    pc.lap("presence filter");
   }
   if (!(flags & DG_OPEN_NO_SELFCHECK)) {
     DG_HIP(hipMalloc((void**)&bad, 4));
@@ -391,6 +482,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
     DG_HIP(hipStreamSynchronize(ix->stream));
     DG_HIP(hipFree(bad));
     if (hbad) return fail(DG_EFORMAT, "index self-check failed on %u of %llu sampled suffixes", hbad, (unsigned long long)ns);
+    pc.lap("self-check");
   }
   ix->hbm_bytes += nblk * sizeof(OccBlock) + n + 64 + n * 4 + 64;
   return DG_OK;
@@ -399,7 +491,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
 template <class T>
 static int upload(dg_index* ix, const void* src, size_t bytes, const T** dst) {
   void* d = nullptr;
-  DG_HIP(hipMalloc(&d, bytes + 64));  // +64: packed_get may touch one word past the last element
+  DG_HIP(big_alloc(&d, bytes + 64, ix->stream));  // +64: packed_get may touch one word past the last element
   ix->owned.push_back(d);
   DG_HIP(hipMemsetAsync((char*)d + bytes, 0, 64, ix->stream));
   DG_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ix->stream));
@@ -416,8 +508,10 @@ static int open_impl(const char* path, int device, u32 flags, dg_index* ix) {
   DG_HIP(hipSetDevice(device));
   ix->device = device;
   DG_HIP(hipStreamCreate(&ix->stream));
+  PhaseClock pc;
   SdslCsa c;
   DG_TRY(sdsl_open(path, c));
+  pc.lap("file map + parse");
   if (c.n > 0xFFFFFFFFULL) return fail(DG_ELIMIT, "index has %llu symbols; this build keeps 32-bit suffix-array entries", (unsigned long long)c.n);
   ix->file_bytes = c.len;
   FmView& f = ix->view;
@@ -453,6 +547,7 @@ static int open_impl(const char* path, int device, u32 flags, dg_index* ix) {
   }
   DG_HIP(hipStreamSynchronize(ix->stream));
   delete t;
+  pc.lap("upload of the sdsl sections");
   static const u8 soc[8] = {'A', 'C', 'G', 'T', 'N', '\n', 0, 0};
   std::memcpy(f.sym_of_code, soc, 8);
   auto t1 = std::chrono::steady_clock::now();
@@ -468,7 +563,8 @@ static int open_impl(const char* path, int device, u32 flags, dg_index* ix) {
 using namespace dg;
 
 dg_index::~dg_index() {
-  for (void* p : owned) (void)hipFree(p);
+  for (void* p : owned) dg::big_free(p, stream);
+  if (stream) (void)hipStreamSynchronize(stream);
   for (auto& w : ws) w.release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);

@@ -27,3 +27,8 @@ struct dg_index {
   std::vector<uint64_t> cum_cache;    // cumulative sequence starts currently resident in WS_CUM
   ~dg_index();
 };
+
+namespace dg {
+// build.hip: sa = inverse permutation of isa by a radix sort of (isa[p], p); isa is clobbered
+int derive_sa_by_sort(hipStream_t st, u32* isa, u64 n, u32* sa);
+}

@@ -83,6 +83,8 @@ inline hipError_t hipMalloc(void** p, size_t n) {
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
+inline hipError_t hipFreeAsync(void* p, hipStream_t) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }

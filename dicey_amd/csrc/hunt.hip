@@ -1103,51 +1103,81 @@ __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32
   if (reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
 }
 
-// One workgroup per repeat-rich string: radix-select the take-th smallest suffix-array value (32 counting passes over
-// the interval, coalesced), collect everything up to it, bitonic-sort the <= 16384 survivors in LDS.
+// One workgroup per repeat-rich string: the `take` smallest suffix-array values of its interval, ascending.
+// Radix select, one byte per pass from the top: a 256-bin histogram (LDS atomics) of the values that still match the
+// prefix found so far tells which bin holds the take-th smallest value; the passes stop as soon as everything up to the end
+// of that bin fits the LDS buffer (on a genome-wide repeat family that is after the first pass: positions spread over the
+// whole text, so one top-byte bin holds occs/185 values).  One more pass collects those values, a bitonic sort orders
+// them.  2-3 coalesced passes over the interval instead of 33 (r02: 33 ms -> see DESIGN.md on the repeat-rich genome).
 __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds,
                                                     Counters* ctr) {
-  __shared__ u32 buf[16384];
-  __shared__ u32 red[256];
-  __shared__ u32 fill;
+  constexpr u32 CAP = 16384;
+  __shared__ u32 buf[CAP];
+  __shared__ u32 hist[256];
+  __shared__ u32 fill, s_prefix, s_mask, s_k, s_below, s_done;
   const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
   for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
     const BigJob J = jobs[jb];
     const u32* sa = f.sa + J.lo;
-    u32 prefix = 0, k = J.take - 1;  // rank of the largest value we keep
-    for (int bit = 31; bit >= 0; --bit) {
-      u32 c0 = 0;
-      const u32 hi_mask = bit == 31 ? 0u : ~0u << (bit + 1);
-      for (u32 i = threadIdx.x; i < J.occs; i += blockDim.x) {
-        u32 x = sa[i];
-        c0 += ((x & hi_mask) == (prefix & hi_mask)) && !((x >> bit) & 1);
-      }
-      red[threadIdx.x] = c0;
-      __syncthreads();
-      for (u32 s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    // refine until at most `limit` values are left to sort: sorting costs n log^2 n, another pass over the interval does not
+    const u32 limit = 2 * J.take > CAP ? CAP : (2 * J.take < 1024 ? 1024u : 2 * J.take);
+    if (threadIdx.x == 0) {
+      s_prefix = 0;
+      s_mask = 0;
+      s_k = J.take - 1;  // rank (among the values matching the prefix) of the largest value we keep
+      s_below = 0;       // values smaller than every value matching the prefix
+      s_done = J.occs <= limit ? 1u : 0u;  // a short interval is sorted whole
+    }
+    __syncthreads();
+    u32 passes = 0;
+    u32 upper = 0xFFFFFFFFu;  // everything <= upper is collected
+    if (!s_done) {
+      for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;
         __syncthreads();
-      }
-      c0 = red[0];
-      __syncthreads();
-      if (k >= c0) {
-        k -= c0;
-        prefix |= 1u << bit;
+        const u32 prefix = s_prefix, mask = s_mask;
+        for (u32 i = threadIdx.x; i < J.occs; i += blockDim.x) {
+          const u32 x = sa[i];
+          if ((x & mask) == prefix) atomicAdd(&hist[(x >> shift) & 255u], 1u);
+        }
+        ++passes;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          u32 k = s_k, cum = 0, bin = 0;
+          for (; bin < 256; ++bin) {
+            if (k < cum + hist[bin]) break;
+            cum += hist[bin];
+          }
+          s_k = k - cum;
+          s_below += cum;
+          s_prefix = prefix | (bin << shift);
+          s_mask = mask | (255u << shift);
+          if (s_below + hist[bin] <= limit || shift == 0) s_done = (u32)shift + 1;  // remember where we stopped
+        }
+        __syncthreads();
+        if (s_done) {
+          const u32 sh = s_done - 1;
+          upper = s_prefix | (sh ? ((1u << sh) - 1) : 0u);
+          break;
+        }
       }
     }
-    // prefix is now the take-th smallest value; positions are distinct, so exactly `take` values are <= prefix
+    __syncthreads();
     if (threadIdx.x == 0) fill = 0;
-    u32 n2 = 1;
-    while (n2 < J.take) n2 <<= 1;
-    for (u32 i = threadIdx.x; i < n2; i += blockDim.x) buf[i] = 0xFFFFFFFFu;
     __syncthreads();
     for (u32 i = threadIdx.x; i < J.occs; i += blockDim.x) {
-      u32 x = sa[i];
-      if (x <= prefix) {
-        u32 at = atomicAdd(&fill, 1u);
-        if (at < n2) buf[at] = x;
+      const u32 x = sa[i];
+      if (x <= upper) {
+        const u32 at = atomicAdd(&fill, 1u);
+        if (at < CAP) buf[at] = x;
       }
     }
+    ++passes;
+    __syncthreads();
+    const u32 have = fill < CAP ? fill : CAP;  // >= take by construction
+    u32 n2 = 1;
+    while (n2 < have) n2 <<= 1;
+    for (u32 i = have + threadIdx.x; i < n2; i += blockDim.x) buf[i] = 0xFFFFFFFFu;
     __syncthreads();
     for (u32 kk = 2; kk <= n2; kk <<= 1)
       for (u32 j = kk >> 1; j > 0; j >>= 1) {
@@ -1165,7 +1195,7 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs
         __syncthreads();
       }
     for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len};
-    if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], 33ULL * J.occs);
+    if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)passes * J.occs);
     __syncthreads();
   }
 }

@@ -45,6 +45,14 @@ struct WtTables {  // small, read with scalar loads
   u32 sigma;
 };
 
+struct KFilter {
+  const u32* cp[4];
+  u32 s[4];
+  u32 nr;    // 0 = no filter
+  u32 k;     // order: codes have 2k bits
+  u64 pick;  // 2 bits per window position t (0 = right-most character): the copy whose in-line bits cover code bits 2t, 2t+1
+};
+
 struct FmView {
   u64 n;  // text length + 1
   // sdsl sections
@@ -66,30 +74,29 @@ struct FmView {
   // backward search meets the characters.
   const uint2* ktab;
   u32 K;  // 0 = no table
-  // Presence filter in front of the table (derived at load from the table): bit = "this K-mer occurs", kept in up to four
-  // differently permuted copies.  Copy r stores the 512 codes that differ only in code bits [kf_s[r], kf_s[r]+9) in ONE
-  // 64-byte line (line index = the remaining 2K-9 bits), so all K-mers that differ from each other only inside one block of
-  // four window positions sit in the same line of the copy whose block that is.  The neighbourhood of a query probes ~150
-  // K-mers per strand that all differ from the query's window by one edit: lanes pick the copy by the position of their
-  // edit and the ~150 probes fall into about a dozen lines instead of ~150 table lines; only K-mers that occur (about one
-  // in six on a 3.1 Gb genome at K = 17) go on to read their table entry.  Any copy answers any code: the choice is
-  // locality only.
-  const u32* kf[4];
-  u32 kf_s[4];
-  u32 kf_nr;  // 0 = no filter
+  // Presence filters (derived at load): bit = "this k-mer occurs", kept in up to four differently permuted copies.  Copy r
+  // stores the 512 codes that differ only in code bits [s[r], s[r]+9) in ONE 64-byte line (line index = the remaining
+  // 2k-9 bits), so all k-mers that differ from each other only inside one block of four window positions sit in the same
+  // line of the copy whose block that is.  The neighbourhood of a query probes k-mers that all differ from the query's
+  // window by an edit or two: lanes pick the copy by the position of their edit, and probes of neighbouring edits fall into
+  // the same line.  Any copy answers any code: the choice is locality only.
+  //   kf   order K (the table's): in front of the table, about one random 17-mer in six passes on a 3.1 Gb genome;
+  //   kf2  order K2 > K (DESIGN.md "long filter"): strings of at least K2 characters are tested here first — a random
+  //        19-mer passes with p = 0.011, so nearly every table read and interval extension that remains belongs to a
+  //        string that really occurs.  This is what the HBM the table does not need is spent on.
+  KFilter kf, kf2;
 };
 
-// is the K-mer `code` present?  t = window position (0 = right-most character) of the most recent edit
-DG_DEV bool kf_present(const FmView& f, u64 code, u32 t) {
-  u32 r = t >> 2;
-  if (r >= f.kf_nr) r = f.kf_nr - 1;
-  const u32* base = f.kf[0];
-  u32 s = f.kf_s[0];
+// is the k-mer `code` present?  t = window position (0 = right-most character) of the edit the neighbouring lanes vary
+DG_DEV bool kf_present(const KFilter& kf, u64 code, u32 t) {
+  const u32 r = (u32)(kf.pick >> (2 * (t < 31 ? t : 31))) & 3u;
+  const u32* base = kf.cp[0];
+  u32 s = kf.s[0];
 #pragma unroll
   for (int k = 1; k < 4; ++k)
     if (r == (u32)k) {
-      base = f.kf[k];
-      s = f.kf_s[k];
+      base = kf.cp[k];
+      s = kf.s[k];
     }
   const u32 inl = (u32)(code >> s) & 511u;
   const u64 line = (code & ((1ULL << s) - 1)) | ((code >> (s + 9)) << s);

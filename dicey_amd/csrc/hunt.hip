@@ -133,6 +133,7 @@ __global__ void k_prepare(Batch b) {
     gi.m = ((flags & DG_Q_TOO_SHORT) || explicit_set || (strand && !b.reverse) || m > b.maxlen_bound) ? 0u : m;
     gi.d_win = d | (bad == 0 ? 256u : 0u);
     if (b.fastK && gi.m && bad == 0 && d == 1 && m <= 31 && m >= b.fastK + 1) gi.d_win |= 512u;
+    if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
     if (bad == 0 && m <= 32) {
       const u8* sq = (strand ? b.rv : b.fw) + s;
       for (u32 i = 0; i < m; ++i) gi.qpk |= (u64)sq[i] << (2 * (m - 1 - i));
@@ -194,9 +195,9 @@ struct SearchOut {
 // emit one character (code 0..3) in front of what the frame stands for; returns false when the branch is dead
 // K-mer code -> SA interval: the presence filter first (one bit, FmView::kf), the table entry only for K-mers that occur
 DG_DEV uint2 kmer_interval(const FmView& f, u64 code, u32 edit_at, u64& lookups, u64& probes) {
-  if (f.kf_nr) {
+  if (f.kf.nr) {
     ++probes;
-    if (!kf_present(f, code, edit_at)) return make_uint2(0u, 0u);
+    if (!kf_present(f.kf, code, edit_at)) return make_uint2(0u, 0u);
   }
   ++lookups;
   return f.ktab[code];
@@ -326,14 +327,19 @@ __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o,
         code = s_pk & kmask;
         rest = s_pk >> (2 * K);
         nrest = mlen - K;
-        if (f.kf_nr) {
+        const u32 K2 = f.kf2.k;
+        if (f.kf2.nr && mlen >= K2) {  // the long filter first: nearly nothing that does not occur gets past it
           probed = true;
-          cand = kf_present(f, code, R < K ? R : K - 1);
+          cand = kf_present(f.kf2, s_pk & ((1ULL << (2 * K2)) - 1), R < K2 ? R : K2 - 1);
+        } else if (f.kf.nr) {
+          probed = true;
+          cand = kf_present(f.kf, code, R < K ? R : K - 1);
         } else {
           looked = true;
           const uint2 iv = f.ktab[code];
           cand = iv.x < iv.y;
           code = (u64)iv.y << 32 | iv.x;
+          rest |= 1ULL << 55;  // `code` already holds the interval
         }
       }
     }
@@ -364,19 +370,21 @@ __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o,
   }
   const u32 qn = q_n;
   if ((threadIdx.x & ~63u) >= qn) return;  // this wavefront has no survivor to work on
-  u32 steps = 0;
+  u32 steps = 0, nlook = 0;
   const bool work = threadIdx.x < qn;
   if (work) {
     const u64 cd = q_code[threadIdx.x];
     u64 rs = q_rest[threadIdx.x];
     const u32 g = q_gid[threadIdx.x], ow = q_op[threadIdx.x];
     u32 n = (u32)(rs >> 56);
-    rs &= (1ULL << 56) - 1;
+    const bool have_iv = (rs >> 55) & 1;
+    rs &= (1ULL << 55) - 1;
     u32 lo, hi;
-    if (f.kf_nr) {
+    if (!have_iv) {
       const uint2 iv = f.ktab[cd];
       lo = iv.x;
       hi = iv.y;
+      ++nlook;
     } else {
       lo = (u32)cd;
       hi = (u32)(cd >> 32);
@@ -404,10 +412,205 @@ __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o,
     }
   }
   for (int off = 32; off > 0; off >>= 1) steps += __shfl_xor(steps, off);
-  const u32 nwork = (u32)__popcll(__ballot(work));
+  const u32 nwork = (u32)__popcll(__ballot(nlook != 0));
   if (lane == 0) {
     if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
-    if (f.kf_nr) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nwork);
+    if (nwork) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nwork);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Distance 2 (edit mode) laid out flat as well.  r02 profile of the state machine at d = 2: 124 ms per 100 000 20-mers,
+// 1.7 G filter probes + 0.36 G table reads + 0.59 G interval extensions — issue bound like its d = 1 form was, and most of
+// its memory accesses belong to strings that do not occur.  Here:
+//   * one WORKGROUP per (query, strand); its four wavefronts walk the pairs of edit positions (p2 <= p1, counted as "the
+//     operation sits right of q[0..p)"), one wavefront per pair, one LANE per pair of operations (8 x 8: delete, substitute
+//     by the three other bases, insert A/C/G/T) — every two-operation path of the trie k_search<true,2> walks
+//     (neighbors.h:47-83), so the same strings, duplicates included, reach the select stage;
+//   * a lane applies its two operations to the 2-bit packed query with shifts and masks and asks the LONG presence filter
+//     (order K2, FmView::kf2) about the last K2 characters; strings shorter than K2 ask the table's filter.  U pairs per
+//     wavefront are in flight at once (the probes are independent loads).  Neighbouring pairs differ in p1 only, lanes pick
+//     the filter copy by p1's window position, so the probes of a workgroup keep hitting the lines it already has in L1/L2;
+//   * survivors (about 1 % of the candidates behind a 19-mer filter on a 3.1 Gb genome) are pushed on an LDS stack; whenever
+//     it holds 256 of them the workgroup pops 256 and runs them densely: table entry, interval extension over the
+//     characters left of the table window, leaf record.  Leaf slots of the group come from an LDS counter, leaf space from
+//     one atomic per wavefront.
+// Taken: queries of 2-edit budget without N, up to 30 nt (the edited string fits 64 bits) and at least K + 2 long.
+DG_DEV void apply_edit(u64 pk, u32 len, u32 pos, u32 op, u64& out, u32& olen, u32& word) {
+  const u32 R = len - pos;  // characters right of the operation
+  const u64 low = pk & ((1ULL << (2 * R)) - 1);
+  const u32 old = (u32)(pk >> (2 * R)) & 3u;
+  if (op == 0) {
+    out = low | ((pk >> (2 * R + 2)) << (2 * R));
+    olen = len - 1;
+    word = (pos << 4) | (OP_D << 2);
+  } else if (op < 4) {
+    const u32 c = (old + op) & 3u;  // neighbors.h:63: a different base
+    out = pk ^ ((u64)(old ^ c) << (2 * R));
+    olen = len;
+    word = (pos << 4) | (OP_S << 2) | c;
+  } else {
+    const u32 c = op - 4;
+    out = low | ((u64)c << (2 * R)) | ((pk >> (2 * R)) << (2 * R + 2));
+    olen = len + 1;
+    word = (pos << 4) | (OP_I << 2) | c;
+  }
+}
+
+template <int U>
+__global__ void __launch_bounds__(256) k_search2(FmView f, Batch b, SearchOut o) {
+  constexpr u32 QCAP = 256 * U + 256;
+  __shared__ unsigned long long q_pk[QCAP];
+  __shared__ u32 q_meta[QCAP];  // bits 0-5 string length, 6-14 first operation (pos:5, kind:2, c:2), 15-23 second operation
+  __shared__ u32 q_n, g_slots, c_probe;
+  const u32 gid = blockIdx.x;
+  const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+  const u32 m = raw.z, d_win = raw.w;
+  if (!m || !(d_win & 1024u)) return;  // uniform for the workgroup
+  const u64 qpk = (u64)raw.y << 32 | raw.x;
+  if (threadIdx.x == 0) {
+    q_n = 0;
+    g_slots = 0;
+    c_probe = 0;
+  }
+  __syncthreads();
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1;
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32 op1 = lane & 7u, op2 = lane >> 3;
+  const u32 npairs = m * (m + 1) / 2 - 1;  // p2 = 1..m-1, p1 = p2..m
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  u32 steps = 0, nlook = 0;
+  for (u32 base = 0; base < npairs; base += 4 * U) {
+    bool cand[U];
+    u64 pk[U];
+    u32 meta[U];
+    u32 nprobe = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32 w = base + (u32)u * 4 + wave;
+      cand[u] = false;
+      pk[u] = 0;
+      meta[u] = 0;
+      if (w < npairs) {
+        // w -> (p2, p1): rows p2 = 1, 2, ... hold m, m-1, ... pairs; row a = p2-1 starts at a(2m+1-a)/2
+        const float tm = (float)(2 * m + 1);
+        int a = (int)((tm - sqrtf(tm * tm - 8.0f * (float)w)) * 0.5f);
+        if (a < 0) a = 0;
+        if (a > (int)m - 2) a = (int)m - 2;
+        while (a > 0 && (u32)a * (2 * m + 1 - (u32)a) / 2 > w) --a;
+        while ((u32)(a + 1) * (2 * m - (u32)a) / 2 <= w) ++a;
+        const u32 p2 = (u32)a + 1, p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
+        const bool ins1 = op1 >= 4;
+        // the first operation must leave p2 characters to its left, and nothing is inserted after the last character
+        const bool ok = (p1 > p2 || ins1) && !(p1 == m && ins1);
+        if (ok) {
+          u64 s1, s2;
+          u32 l1, l2, w1, w2;
+          apply_edit(qpk, m, p1, op1, s1, l1, w1);
+          apply_edit(s1, l1, p2, op2, s2, l2, w2);
+          const u32 R1 = m - p1;
+          bool pass = true;
+          if (K2 && l2 >= K2) {
+            pass = kf_present(f.kf2, s2 & ((1ULL << (2 * K2)) - 1), R1 < K2 ? R1 : K2 - 1);
+            ++nprobe;
+          } else if (f.kf.nr) {
+            pass = kf_present(f.kf, s2 & kmask, R1 < K ? R1 : K - 1);
+            ++nprobe;
+          }
+          cand[u] = pass;
+          pk[u] = s2;
+          meta[u] = l2 | ((w1 & 511u) << 6) | ((w2 & 511u) << 15);
+        }
+      }
+    }
+    // push the survivors: one LDS atomic per wavefront
+    unsigned long long mk[U];
+    u32 tot = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mk[u] = __ballot(cand[u]);
+      tot += (u32)__popcll(mk[u]);
+    }
+    for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+    u32 at = 0;
+    if (lane == 0) {
+      if (tot) at = atomicAdd(&q_n, tot);
+      if (nprobe) atomicAdd(&c_probe, nprobe);
+    }
+    at = __shfl(at, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (cand[u]) {
+        const u32 k = at + (u32)__popcll(mk[u] & ((1ULL << lane) - 1));
+        q_pk[k] = pk[u];
+        q_meta[k] = meta[u];
+      }
+      at += (u32)__popcll(mk[u]);
+    }
+    __syncthreads();  // the pushes are in place
+    u32 n = q_n;
+    __syncthreads();  // everybody has read the count before lane 0 rewrites it
+    const bool last = base + 4 * U >= npairs;
+    // pop 256 at a time while the stack holds that many (everything at the end); nothing is pushed meanwhile, so the rounds
+    // need no barrier between them and every lane follows the count on its own
+    while (n && (n >= 256 || last)) {
+      const u32 cnt = n < 256 ? n : 256u, start = n - cnt;
+      bool leaf = false;
+      u32 lo = 0, hi = 0, mt = 0;
+      if (threadIdx.x < cnt) {
+        const u64 sp = q_pk[start + threadIdx.x];
+        mt = q_meta[start + threadIdx.x];
+        const uint2 iv = f.ktab[sp & kmask];
+        ++nlook;
+        lo = iv.x;
+        hi = iv.y;
+        u64 rs = sp >> (2 * K);
+        u32 nr = (mt & 63u) - K;
+        while (nr && lo < hi) {
+          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+          rs >>= 2;
+          --nr;
+          ++steps;
+        }
+        leaf = lo < hi;
+      }
+      const unsigned long long lm = __ballot(leaf);
+      u32 lbase = 0;
+      if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
+      lbase = __shfl(lbase, 0);
+      if (leaf) {
+        const u32 slot = atomicAdd(&g_slots, 1u);
+        const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
+        if (la < o.shard_cap) {
+          Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
+          lf->qs = gid;
+          lf->slot = slot;
+          lf->lo = lo;
+          lf->hi = hi;
+          lf->nops = 2;
+          lf->ops[0] = (mt >> 6) & 511u;
+          lf->ops[1] = (mt >> 15) & 511u;
+#pragma unroll
+          for (int k = 2; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+        }
+      }
+      n = start;
+    }
+    if (threadIdx.x == 0) q_n = n;
+    __syncthreads();  // the popped part of the stack may be overwritten from here on
+  }
+  if (threadIdx.x == 0) {
+    if (g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
+    if (c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    nlook += __shfl_xor(nlook, off);
+  }
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
   }
 }
 
@@ -436,7 +639,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   gi.m = 0;
   gi.d_win = 0;
   if (active) gi = b.ginfo[gid];
-  if (gi.m == 0 || (gi.d_win & 512u)) active = false;
+  if (gi.m == 0 || (gi.d_win & (512u | 1024u))) active = false;  // not searched, or taken by a flat kernel
   if (active) {
     const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
     const u32 m = gi.m;
@@ -1729,6 +1932,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   static const bool no_fast1 = std::getenv("DICEY_NO_FAST1") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
   Batch b;
   b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen <= 31 && maxlen > ix->view.K && ngrp * (u64)maxlen * 9 < 0xFFFFFF00ull) ? ix->view.K : 0u;
+  b.fast2K = (!no_fast1 && indel && dmax_eff == 2 && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
   b.xs_off = d_xs_off;
@@ -1821,6 +2025,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
         if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);
+        DG_HIP(hipEventRecord(ix->ev[8], st));
+      }
+      if (b.fast2K) {  // edit distance 2: one workgroup per (query, strand) for every query that qualifies
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2<4>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       // root-level work split (see k_search): only with the table and with at least one edit to place
@@ -1983,7 +2191,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->ctr_win_bytes = hsum.win_bytes;
   R->ms_total = ev_ms(ix->ev[0], ix->ev[7]);
   R->ms_search = ev_ms(ix->ev[1], ix->ev[2]);
-  R->ms_search_flat = b.fastK ? ev_ms(ix->ev[1], ix->ev[8]) : 0.0;
+  R->ms_search_flat = (b.fastK || b.fast2K) ? ev_ms(ix->ev[1], ix->ev[8]) : 0.0;
   R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);
   R->ms_locate = ev_ms(ix->ev[5], ix->ev[6]);
   R->ms_verify = ev_ms(ix->ev[6], ix->ev[7]);

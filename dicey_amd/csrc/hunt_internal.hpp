@@ -31,6 +31,7 @@ struct Batch {  // device pointers of one batch
   u32* too_long;         // ... k_prepare counts the ones that are longer (only possible when the host trusted a cached bound)
   struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
   u32 fastK;              // != 0: the batch runs k_search1 (distance 1, table order fastK) for the queries that qualify
+  u32 fast2K;             // != 0: the batch runs k_search2 (edit distance 2) for the queries that qualify
   // Queries whose neighbourhood could reach the cap are enumerated on the host (nbhd_host.hpp) before the batch starts:
   // qmode[q] (nullptr = no such query in this batch): QM_KERNEL = not looked at (k_prepare's own bound must hold),
   // QM_EXPLICIT = the strings of both strands arrive as explicit patterns (xs_*) and k_search skips the query,
@@ -47,7 +48,7 @@ static constexpr u32 LEAF_EXPLICIT = 0x80000000u;  // Leaf::nops marker: ops[0] 
 struct GidInfo {
   u64 qpk;    // the sequence 2-bit packed, q[i] at bits 2(m-1-i) (only for m <= 32 without N)
   u32 m;      // length; 0 = this (query, strand) is not searched
-  u32 d_win;  // bits 0-7 effective distance, bit 8: window mode allowed by the query (no N), bit 9: taken by k_search1
+  u32 d_win;  // bits 0-7 effective distance, bit 8: window mode allowed by the query (no N), bit 9: taken by k_search1, bit 10: taken by k_search2
 };
 
 DG_DEV u32 ascii_rank(u32 code) { return code == 3 ? 4u : code == 4 ? 3u : code; }  // 'A'<'C'<'G'<'N'<'T'

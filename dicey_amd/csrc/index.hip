@@ -199,25 +199,33 @@ __global__ void k_selfcheck(FmView f, u64 nsample, u32* bad) {
 
 // K-mer table: thread i looks at the K-mer that starts suffix SA[i]; the first / last suffix of each run of equal K-mers
 // writes the interval bounds.  K-mers that run into a separator, an N or the end of the text have no entry.
-DG_DEV u64 kmer_code_at(const FmView& f, u64 p, u32 K) {  // bit 63 set = not an A/C/G/T K-mer
-  if (p + K > f.n - 1) return 1ULL << 63;
-  u64 code = 0;
-  for (u32 t = 0; t < K; ++t) {
-    u32 c = code_of_byte(f.text[p + K - 1 - t]);
-    if (c > 3) return 1ULL << 63;
-    code |= (u64)c << (2 * t);
+// the K-mer and the K2-mer (K2 > K, or 0) that start at text position p, from one left-to-right read
+DG_DEV void kmer_codes_at(const FmView& f, u64 p, u32 K, u32 K2, u64& code, u64& code2) {
+  const u64 none = 1ULL << 63;
+  const u32 want = K2 > K ? K2 : K;
+  u64 acc = 0;
+  u32 got = 0;
+  for (; got < want && p + got < f.n - 1; ++got) {
+    const u32 c = code_of_byte(f.text[p + got]);
+    if (c > 3) break;
+    acc = acc << 2 | c;
   }
-  return code;
+  code = got >= K ? acc >> (2 * (got - K)) : none;
+  code2 = (K2 && got >= K2) ? acc : none;
 }
-__global__ void k_kmer_table(FmView f, uint2* tab, u32 K) {
+// kf2: copy 0 of the long presence filter (bit address = K2-mer code), zeroed by the caller; nullptr = none
+__global__ void k_kmer_table(FmView f, uint2* tab, u32 K, u32 K2, u32* kf2) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= f.n) return;
-  u64 me = kmer_code_at(f, f.sa[i], K);
+  u64 me, me2, prev, next, x2;
+  kmer_codes_at(f, f.sa[i], K, kf2 ? K2 : 0u, me, me2);
   if (me >> 63) return;
-  u64 prev = i ? kmer_code_at(f, f.sa[i - 1], K) : (1ULL << 63);
-  u64 next = i + 1 < f.n ? kmer_code_at(f, f.sa[i + 1], K) : (1ULL << 63);
+  prev = next = 1ULL << 63;
+  if (i) kmer_codes_at(f, f.sa[i - 1], K, 0u, prev, x2);
+  if (i + 1 < f.n) kmer_codes_at(f, f.sa[i + 1], K, 0u, next, x2);
   if (prev != me) tab[me].x = (u32)i;
   if (next != me) tab[me].y = (u32)(i + 1);
+  if (kf2 && !(me2 >> 63)) atomicOr(&kf2[me2 >> 5], 1u << (me2 & 31));
 }
 
 // ---- presence filter (FmView::kf) ----
@@ -275,73 +283,132 @@ __global__ void __launch_bounds__(512) k_kf_transpose(const u32* r0, u32* out, u
   for (u32 k = threadIdx.x; k < 256 * 8; k += 512) dst[k] = flat[k];
 }
 
+// any copy, one lane per output word, from copy 0 (in-line bits = the low nine code bits, i.e. bit address = code): the long
+// filter has no table to read
+__global__ void k_kf_generic0(const u32* r0, u32 bits, u32 s, u32* out, u64 nwords) {
+  const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 line = w >> 4;
+  u32 v = 0;
+  for (u32 i = 0; i < 32; ++i) {
+    const u64 inl = ((w & 15) << 5) | i;
+    const u64 code = (line & ((1ULL << s) - 1)) | (inl << s) | ((line >> s) << (s + 9));
+    if (code >> bits) continue;
+    v |= ((r0[code >> 5] >> (code & 31)) & 1u) << i;
+  }
+  out[w] = v;
+}
+
 __global__ void k_kf_compare(const u32* a, const u32* b, u64 n, u32* bad) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && a[i] != b[i]) atomicAdd(bad, 1u);
 }
 
-static int build_filter(dg_index* ix, const uint2* tab, u32 K) {
-  FmView& f = ix->view;
-  const u32 bits = 2 * K;
+// Number of copies, their in-line bit fields (spread evenly over the code) and, per window position, the copy to ask.
+static void kf_layout(KFilter& kf, u32 k) {
+  const u32 bits = 2 * k;
+  u32 nr = bits <= 9 ? 1u : (bits - 9 + 7) / 8 + 1;
+  if (nr > 4) nr = 4;
+  kf.k = k;
+  for (u32 r = 0; r < 4; ++r) kf.s[r] = (nr > 1 && r < nr) ? (r * (bits - 9) + (nr - 1) / 2) / (nr - 1) : 0u;
+  kf.pick = 0;
+  for (u32 t = 0; t < 32; ++t) {
+    u32 best = 0;
+    int best_score = -1000;
+    for (u32 r = 0; r < nr; ++r) {
+      const int lo = (int)kf.s[r], hi = lo + 9, b0 = 2 * (int)t;
+      const int covered = (b0 >= lo && b0 < hi) + (b0 + 1 >= lo && b0 + 1 < hi);
+      const int off = 2 * b0 + 1 - (2 * lo + 8);  // twice the distance of the character from the field's centre
+      const int score = covered * 100 - (off < 0 ? -off : off);
+      if (score > best_score) {
+        best_score = score;
+        best = r;
+      }
+    }
+    kf.pick |= (u64)best << (2 * t);
+  }
+}
+
+// Copies of a presence filter.  Copy 0 comes from the table (tab != nullptr: one ballot pass) or is already in place
+// (copy0: the long filter, whose bits the table-fill kernel sets); the others are bit-matrix transposes of copy 0.
+static int build_filter(dg_index* ix, KFilter& kf, u32 k, const uint2* tab, u32* copy0) {
+  const u32 bits = 2 * k;
   if (bits < 17 || std::getenv("DICEY_NO_KMER_FILTER")) return DG_OK;  // a table this small is cache resident anyway
   const u64 entries = 1ULL << bits, nwords = entries >> 5;
+  kf_layout(kf, k);
   u32 nr = (bits - 9 + 7) / 8 + 1;
   if (nr > 4) nr = 4;
   static const bool generic = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
   const u32 TB = 256;
   for (u32 r = 0; r < nr; ++r) {
-    const u32 s = r + 1 < nr ? 8 * r : bits - 9;
+    const u32 s = kf.s[r];
     u32* bm = nullptr;
-    DG_HIP(big_alloc((void**)&bm, nwords * 4 + 64, ix->stream));
-    ix->owned.push_back(bm);
-    ix->hbm_bytes += nwords * 4 + 64;
-    if (generic || (r > 0 && s < 8)) {
-      hipLaunchKernelGGL(k_kf_generic, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, tab, bits, s, bm, nwords);
-    } else if (r == 0) {
-      hipLaunchKernelGGL(k_kf_from_table, dim3((u32)std::min<u64>(entries / TB, 1u << 20)), dim3(TB), 0, ix->stream, tab, entries, bm);
-    } else {
-      hipLaunchKernelGGL(k_kf_transpose, dim3((u32)(entries >> 17)), dim3(512), 0, ix->stream, f.kf[0], bm, s);
+    if (r == 0 && copy0) bm = copy0;
+    else {
+      DG_HIP(big_alloc((void**)&bm, nwords * 4 + 64, ix->stream));
+      ix->owned.push_back(bm);
+      ix->hbm_bytes += nwords * 4 + 64;
     }
-    f.kf[r] = bm;
-    f.kf_s[r] = s;
-    if (std::getenv("DICEY_KF_VERIFY")) {  // debugging aid: the fast builders against the one-lane-per-word builder
+    if (r == 0 && copy0) {
+      // filled by the caller
+    } else if (r == 0 && !generic) {
+      hipLaunchKernelGGL(k_kf_from_table, dim3((u32)std::min<u64>(entries / TB, 1u << 20)), dim3(TB), 0, ix->stream, tab, entries, bm);
+    } else if (generic || s < 8) {
+      if (tab) hipLaunchKernelGGL(k_kf_generic, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, tab, bits, s, bm, nwords);
+      else hipLaunchKernelGGL(k_kf_generic0, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, (const u32*)kf.cp[0], bits, s, bm, nwords);
+    } else {
+      hipLaunchKernelGGL(k_kf_transpose, dim3((u32)(entries >> 17)), dim3(512), 0, ix->stream, kf.cp[0], bm, s);
+    }
+    kf.cp[r] = bm;
+    if (std::getenv("DICEY_KF_VERIFY") && !(r == 0 && copy0)) {  // debugging aid: the fast builders against the one-lane-per-word builder
       u32* ref = nullptr;
       u32* bad = nullptr;
       DG_HIP(hipMalloc((void**)&ref, nwords * 4 + 64));
       DG_HIP(hipMalloc((void**)&bad, 4));
       DG_HIP(hipMemsetAsync(bad, 0, 4, ix->stream));
-      hipLaunchKernelGGL(k_kf_generic, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, tab, bits, s, ref, nwords);
+      if (tab) hipLaunchKernelGGL(k_kf_generic, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, tab, bits, s, ref, nwords);
+      else hipLaunchKernelGGL(k_kf_generic0, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, (const u32*)kf.cp[0], bits, s, ref, nwords);
       hipLaunchKernelGGL(k_kf_compare, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, (const u32*)bm, (const u32*)ref, nwords, bad);
       u32 hbad = 0;
       DG_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ix->stream));
       DG_HIP(hipStreamSynchronize(ix->stream));
       DG_HIP(hipFree(ref));
       DG_HIP(hipFree(bad));
-      std::fprintf(stderr, "DICEY_KF_VERIFY: copy %u (s=%u): %u of %llu words differ\n", r, s, hbad, (unsigned long long)nwords);
-      if (hbad) return fail(DG_EHIP, "presence filter copy %u differs from its definition in %u words", r, hbad);
+      std::fprintf(stderr, "DICEY_KF_VERIFY: order %u copy %u (s=%u): %u of %llu words differ\n", k, r, s, hbad, (unsigned long long)nwords);
+      if (hbad) return fail(DG_EHIP, "presence filter (order %u) copy %u differs from its definition in %u words", k, r, hbad);
     }
   }
   DG_HIP(hipStreamSynchronize(ix->stream));
   DG_HIP(hipGetLastError());
-  f.kf_nr = nr;
+  kf.nr = nr;
   return DG_OK;
 }
 
 // The same table with one text gather per lane instead of three: the K-mers of the neighbouring suffixes come from the
 // neighbouring lanes (the first / last lane of a wavefront read theirs).
-__global__ void __launch_bounds__(256) k_kmer_table_wave(FmView f, uint2* tab, u32 K) {
+__global__ void __launch_bounds__(256) k_kmer_table_wave(FmView f, uint2* tab, u32 K, u32 K2, u32* kf2) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 none = 1ULL << 63;
-  const u64 me = i < f.n ? kmer_code_at(f, f.sa[i], K) : none;
+  u64 me = none, me2 = none, x2;
+  if (i < f.n) kmer_codes_at(f, f.sa[i], K, kf2 ? K2 : 0u, me, me2);
   const u32 lane = threadIdx.x & 63;
   u32 plo = __shfl_up((u32)me, 1), phi = __shfl_up((u32)(me >> 32), 1);
   u32 nlo = __shfl_down((u32)me, 1), nhi = __shfl_down((u32)(me >> 32), 1);
   u64 prev = (u64)phi << 32 | plo, next = (u64)nhi << 32 | nlo;
+  const u64 prev2 = (u64)__shfl_up((u32)(me2 >> 32), 1) << 32 | __shfl_up((u32)me2, 1);
   if (i >= f.n || (me >> 63)) return;
-  if (lane == 0) prev = i ? kmer_code_at(f, f.sa[i - 1], K) : none;
-  if (lane == 63) next = i + 1 < f.n ? kmer_code_at(f, f.sa[i + 1], K) : none;
+  if (lane == 0) {
+    prev = none;
+    if (i) kmer_codes_at(f, f.sa[i - 1], K, 0u, prev, x2);
+  }
+  if (lane == 63) {
+    next = none;
+    if (i + 1 < f.n) kmer_codes_at(f, f.sa[i + 1], K, 0u, next, x2);
+  }
   if (prev != me) tab[me].x = (u32)i;
   if (next != me) tab[me].y = (u32)(i + 1);
+  // suffixes are sorted, so equal K2-mers are neighbours: the first lane of a run sets the bit
+  if (kf2 && !(me2 >> 63) && (lane == 0 || prev2 != me2)) atomicOr(&kf2[me2 >> 5], 1u << (me2 & 31));
 }
 
 struct PhaseClock {  // DICEY_TIMING=1: host wall clock of the load phases on stderr
@@ -441,18 +508,30 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
     // 288 GB of HBM are for
     u32 K = 8;
     while (K < 16 && (1ULL << (2 * K)) < n) ++K;
-    // one character more (4x the table, 137 GB at K = 17) when the device has room to spare: a random 17-mer of a
-    // 3.1 Gb genome occurs with p = 0.17 instead of 0.51, so far fewer branches survive the table read
+    // What the rest of the HBM is spent on (DESIGN.md "long filter"): a presence filter of order K2 = K + 3 in four
+    // permuted copies (4 x 34 GB at K2 = 19) in front of everything — a random 19-mer of a 3.1 Gb genome occurs with
+    // p = 0.011, a 16-mer with 0.51, a 17-mer with 0.17.  When the device has no room for it, one character more for the
+    // table instead (4x the table, 137 GB at K = 17) if that fits.
+    u32 K2 = 0;
     {
       size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (1ULL << (2 * K)) < n * 2 &&
-          free_b > ((8ULL << (2 * (K + 1))) + (48ULL << 30)))
-        ++K;
+      const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+      const u64 tab_b = 8ULL << (2 * K), f2_b = 4 * ((1ULL << (2 * (K + 3))) >> 3), slack = (u64)std::min<u64>(48ULL << 30, n * 16 + (64u << 20));
+      if (have && free_b > tab_b + f2_b + slack) K2 = K + 3;
+      else if (have && (1ULL << (2 * K)) < n * 2 && free_b > ((8ULL << (2 * (K + 1))) + slack)) ++K;
     }
-    if (const char* ek = std::getenv("DICEY_KMER_K")) {  // tuning knob: force the table order (8..17)
+    if (const char* ek = std::getenv("DICEY_KMER_K")) {  // tuning knobs: force the table order (8..17) / the long filter's (0 = none)
       int v = std::atoi(ek);
-      if (v >= 8 && v <= 17) K = (u32)v;
+      if (v >= 8 && v <= 17) {
+        K = (u32)v;
+        if (K2) K2 = K + 3;
+      }
     }
+    if (const char* ek = std::getenv("DICEY_KMER_K2")) {
+      int v = std::atoi(ek);
+      K2 = (v > (int)K && v <= 20) ? (u32)v : 0u;
+    }
+    if (std::getenv("DICEY_NO_KMER_FILTER") || 2 * K2 < 17) K2 = 0;
     pc.lap("table order (hipMemGetInfo)");
     uint2* tab = nullptr;
     u64 entries = 1ULL << (2 * K);
@@ -460,17 +539,29 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
     ix->owned.push_back(tab);
     pc.lap("table hipMalloc");
     DG_HIP(hipMemsetAsync(tab, 0, entries * sizeof(uint2), ix->stream));
+    u32* f2 = nullptr;  // copy 0 of the long filter: its bits are set by the pass that fills the table
+    if (K2) {
+      const u64 f2_bytes = ((1ULL << (2 * K2)) >> 3) + 64;
+      DG_HIP(big_alloc((void**)&f2, f2_bytes, ix->stream));
+      ix->owned.push_back(f2);
+      ix->hbm_bytes += f2_bytes;
+      DG_HIP(hipMemsetAsync(f2, 0, f2_bytes, ix->stream));
+    }
     static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (no wave collectives)
-    if (lane_only) hipLaunchKernelGGL(k_kmer_table, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K);
-    else hipLaunchKernelGGL(k_kmer_table_wave, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K);
+    if (lane_only) hipLaunchKernelGGL(k_kmer_table, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K, K2, f2);
+    else hipLaunchKernelGGL(k_kmer_table_wave, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K, K2, f2);
     DG_HIP(hipStreamSynchronize(ix->stream));
     DG_HIP(hipGetLastError());
     f.ktab = tab;
     f.K = K;
     ix->hbm_bytes += entries * sizeof(uint2);
     pc.lap("table fill");
-    DG_TRY(build_filter(ix, tab, K));
+    DG_TRY(build_filter(ix, f.kf, K, tab, nullptr));
     pc.lap("presence filter");
+    if (K2) {
+      DG_TRY(build_filter(ix, f.kf2, K2, nullptr, f2));
+      pc.lap("long presence filter");
+    }
   }
   if (!(flags & DG_OPEN_NO_SELFCHECK)) {
     DG_HIP(hipMalloc((void**)&bad, 4));

@@ -127,9 +127,9 @@ inline int sdsl_parse(SdslCsa& c, size_t start_off) {
   if (!cur.ok || c.n < 2 || c.wt_sigma == 0 || c.wt_sigma > 256) return DG_EFORMAT;
   if (!cur.int_vector_fixed(c.bv, 1)) return DG_EFORMAT;
   if (!cur.int_vector_fixed(c.rank, 64)) return DG_EFORMAT;
-  // rank_support_v holds two words per 512-bit superblock: ((cap>>9)+1)*2
-  u64 cap = ((c.bv.bits + 63) >> 6) << 6;
-  if (c.rank.nwords != (((cap >> 9) + 1) << 1)) return DG_EFORMAT;
+  // rank_support_v holds two words per 512-bit superblock, ((capacity>>9)+1)*2 of them.  How sdsl rounds the capacity
+  // differs between releases, so only what rank() will index is demanded: the superblock of the last bit.
+  if (c.rank.nwords < (((c.bv.bits >> 9) + 1) << 1)) return DG_EFORMAT;
   if (!cur.skip_select() || !cur.skip_select()) return DG_EFORMAT;
   u64 nn = cur.u64v();
   if (!cur.ok || nn == 0 || nn > 511 || nn != 2 * c.wt_sigma - 1) return DG_EFORMAT;
@@ -160,7 +160,9 @@ inline int sdsl_parse(SdslCsa& c, size_t start_off) {
   for (u32 i = 0; i < c.sigma; ++i)
     if (c.C[i] > c.C[i + 1]) return DG_EFORMAT;
   u8 want_w = (u8)(64 - __builtin_clzll(c.n));
-  if (c.sa_samples.width != want_w || c.isa_samples.width != want_w) return DG_EFORMAT;
+  // sdsl stores the samples with bits::hi(n)+1 bits; a wider (e.g. byte-aligned) vector holds the same values
+  if (c.sa_samples.width < want_w || c.sa_samples.width > 64 || c.isa_samples.width != c.sa_samples.width) return DG_EFORMAT;
+  want_w = c.sa_samples.width;
   if (c.sa_samples.bits / want_w != (c.n + 31) / 32) return DG_EFORMAT;
   if (c.isa_samples.bits / want_w != (c.n - 1) / 64 + 1) return DG_EFORMAT;
   for (const auto& nd : c.nodes) {

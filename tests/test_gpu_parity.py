@@ -247,6 +247,22 @@ def test_repeat_rich_strings_use_the_workgroup_locate(tmp_path):
             _compare(ix, orc, g, [unit, unit[:19] + ("A" if unit[19] != "A" else "C"), unit[1:] + "G"], **kw)
 
 
+def test_flat_distance_two_kernel(gpu_small, small_genome, monkeypatch):
+    """k_search2 (one workgroup per strand, lane per pair of operations, long presence filter): lengths around the table
+    order and the filter order, up to the 30 nt it takes, mixed with queries it leaves to k_search (N, > 30 nt); the checker
+    enumerates with its hash-set neighbours (tested equal to the literal ones in tests/test_oracle.py)."""
+    orc = O.Index(small_genome["fm9"])
+    O.fast_neighbors(True)
+    try:
+        qs = make_queries(411, small_genome["text"], 72, (10, 11, 12, 13, 14, 18, 19, 20, 20))
+        qs += make_queries(412, small_genome["text"], 4, (21, 22, 24, 30))  # the checker needs seconds for each of these
+        qs += ["ACGTNACGTAACGTACGTAC", small_genome["seqs"][0][700:733], "A" * 20, "AC" * 10, small_genome["seqs"][1][40:60].lower()]
+        _compare(gpu_small, orc, small_genome, qs, distance=2)
+        _compare(gpu_small, orc, small_genome, qs[:40], distance=2, max_locations=5, forward_only=True)
+    finally:
+        O.fast_neighbors(False)
+
+
 @pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13"])
 def test_every_search_mode_gives_the_same_hits(small_genome, monkeypatch, mode):
     """Interval mode (no table), window mode with a table shorter than every query, and tables long enough that some

@@ -103,6 +103,30 @@ DG_DEV bool kf_present(const KFilter& kf, u64 code, u32 t) {
   return (base[line * 16 + (inl >> 5)] >> (inl & 31)) & 1u;
 }
 
+// the same test in two steps for lanes that ask about several codes with the same edit position: pick the copy once
+struct KfCopy {
+  const u32* base;
+  u32 s;
+};
+DG_DEV KfCopy kf_copy(const KFilter& kf, u32 t) {
+  const u32 r = (u32)(kf.pick >> (2 * (t < 31 ? t : 31))) & 3u;
+  KfCopy c;
+  c.base = kf.cp[0];
+  c.s = kf.s[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (r == (u32)k) {
+      c.base = kf.cp[k];
+      c.s = kf.s[k];
+    }
+  return c;
+}
+DG_DEV bool kf_test(const KfCopy& c, u64 code) {
+  const u32 inl = (u32)(code >> c.s) & 511u;
+  const u64 line = (code & ((1ULL << c.s) - 1)) | ((code >> (c.s + 9)) << c.s);
+  return (c.base[line * 16 + (inl >> 5)] >> (inl & 31)) & 1u;
+}
+
 DG_DEV u64 packed_get(const u64* w, u32 width, u64 i) {
   u64 b = i * width, q = b >> 6, o = b & 63;
   u64 v = w[q] >> o;

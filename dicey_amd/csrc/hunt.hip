@@ -419,6 +419,157 @@ __global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o,
   }
 }
 
+// The same search with one lane per (query, strand, POSITION): the lane builds all eight strings of its position from the
+// shared pieces (the characters right of the position, the query shifted by none / one character) in a fully unrolled loop —
+// the operation is a compile-time constant in every iteration, so nothing diverges — and issues its eight filter probes
+// back to back.  The lane-per-operation form above spends ~200 vector instructions per candidate (every lane runs the code
+// of all three operation kinds, the (group, item) decode and the record load for one string) and was bound by instruction
+// issue once the long filter had removed most of its memory accesses (r02: 0.39 ms whatever the filter / table orders);
+// this form needs ~25 per candidate.  Survivors are queued in LDS as (lane, operation) and rebuilt by the dense phase.
+template <bool INDEL>
+DG_DEV bool cand1(u64 qpk, u32 m, u32 pos, u32 op, u64& s_pk, u32& mlen, u32& opword) {
+  const u32 R = m - pos;  // unchanged characters right of the operation
+  const u64 low = qpk & ((1ULL << (2 * R)) - 1);
+  const u32 old = (u32)(qpk >> (2 * R)) & 3u;
+  if (op == 0) {
+    if (INDEL) {
+      s_pk = low | ((qpk >> (2 * R + 2)) << (2 * R));
+      mlen = m - 1;
+      opword = ((pos << 4) | (OP_D << 2)) | (1u << 28);
+      // deleting either of two equal neighbours gives the same string: the right-most character of a run does it
+      return !(R >= 1 && ((u32)(qpk >> (2 * R - 2)) & 3u) == old);
+    }
+    s_pk = qpk;  // the sequence itself belongs to the Hamming set
+    mlen = m;
+    opword = 0;
+    return pos == 1;
+  }
+  if (op < 4) {
+    const u32 c = (old + op) & 3u;  // neighbors.h:63: a different base
+    s_pk = qpk ^ ((u64)(old ^ c) << (2 * R));
+    mlen = m;
+    opword = ((pos << 4) | (OP_S << 2) | c) | (1u << 28);
+    return true;
+  }
+  const u32 c = op - 4;
+  s_pk = low | ((u64)c << (2 * R)) | ((qpk >> (2 * R)) << (2 * R + 2));
+  mlen = m + 1;
+  opword = ((pos << 4) | (OP_I << 2) | c) | (1u << 28);
+  // neighbors.h:51: nothing after the last character; and a base inserted right of an equal one is the string of the
+  // insertion one position further left (which exists from the second position on)
+  return pos < m && !(pos >= 2 && c == old);
+}
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o, u32 ipg, u32 magic) {
+  __shared__ u16 q_ent[2048];  // lane | operation << 8
+  __shared__ u32 q_n, c_probe;
+  constexpr u32 NOPS = INDEL ? 8u : 4u;
+  if (threadIdx.x == 0) {
+    q_n = 0;
+    c_probe = 0;
+  }
+  __syncthreads();
+  // lane -> (group, position): one division per workgroup, a multiplication per lane (exact for the < 512 values it sees)
+  const u32 first = blockIdx.x * 256u;
+  const u32 g_first = first / ipg, r_first = first - g_first * ipg;
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1;
+  const u32 lane = threadIdx.x & 63;
+  const u32 ngrp2 = (u32)(2 * b.nq);
+  u32 mask8 = 0, nprobe = 0;
+  {
+    const u32 t = r_first + threadIdx.x, qd = (t * magic) >> 16;
+    const u32 gid = g_first + qd, pos = t - qd * ipg + 1;
+    if (gid < ngrp2) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+      const u64 qpk = (u64)raw.y << 32 | raw.x;
+      const u32 m = raw.z, d_win = raw.w;
+      if (m && (d_win & 512u) && pos <= m) {
+        const u32 R = m - pos;
+        const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
+        const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
+        const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          u64 s_pk;
+          u32 mlen, ow;
+          if (cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow)) {
+            bool pass = true;
+            if (K2 && mlen >= K2) {
+              pass = kf_test(c2, s_pk & mask2);
+              ++nprobe;
+            } else if (f.kf.nr) {
+              pass = kf_test(c1, s_pk & kmask);
+              ++nprobe;
+            }
+            mask8 |= (u32)pass << op;
+          }
+        }
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+  if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
+  while (mask8) {
+    const u32 op = (u32)__ffs((int)mask8) - 1u;
+    mask8 &= mask8 - 1;
+    const u32 at = atomicAdd(&q_n, 1u);
+    q_ent[at] = (u16)(threadIdx.x | (op << 8));  // at < 2048: eight operations of 256 lanes
+  }
+  __syncthreads();
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  if (threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
+  const u32 qn = q_n;
+  u32 steps = 0, nlook = 0;
+  for (u32 e0 = 0; e0 < qn; e0 += 256) {
+    if (e0 + (threadIdx.x & ~63u) >= qn) break;  // this wavefront has no survivor to work on
+    const u32 e = e0 + threadIdx.x;
+    if (e < qn) {
+      const u32 ent = q_ent[e], sl = ent & 255u, op = ent >> 8;
+      const u32 t = r_first + sl, qd = (t * magic) >> 16;
+      const u32 gid = g_first + qd, pos = t - qd * ipg + 1;
+      const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+      u64 s_pk;
+      u32 mlen, ow;
+      (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
+      const uint2 iv = f.ktab[s_pk & kmask];
+      ++nlook;
+      u32 lo = iv.x, hi = iv.y;
+      u64 rs = s_pk >> (2 * K);
+      u32 n = mlen - K;
+      while (n && lo < hi) {
+        bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+        rs >>= 2;
+        --n;
+        ++steps;
+      }
+      if (lo < hi) {
+        const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+        const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+        if (at < o.shard_cap) {
+          Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+          lf->qs = gid;
+          lf->slot = slot;
+          lf->lo = lo;
+          lf->hi = hi;
+          lf->nops = ow >> 28;
+          lf->ops[0] = ow & 0x0FFFFFFFu;
+#pragma unroll
+          for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+        }
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    nlook += __shfl_xor(nlook, off);
+  }
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Distance 2 (edit mode) laid out flat as well.  r02 profile of the state machine at d = 2: 124 ms per 100 000 20-mers,
 // 1.7 G filter probes + 0.36 G table reads + 0.59 G interval extensions — issue bound like its d = 1 form was, and most of
@@ -612,6 +763,162 @@ __global__ void __launch_bounds__(256) k_search2(FmView f, Batch b, SearchOut o)
     if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
   }
+}
+
+// k_search2 with one lane per PAIR OF POSITIONS: the lane walks the 8 x 8 operations in two fully unrolled loops (every
+// operation is a compile-time constant where it is applied, the eight probes of an inner loop are independent loads), skips
+// the operations that only repeat another lane's string — deleting the left one of two equal neighbours, inserting a base
+// right of an equal one; checked against the reference's minimal set on random and low-complexity queries — and queues
+// survivors as (pair, operation, operation) for the dense phase, which rebuilds them.  ~30 vector instructions per candidate
+// instead of ~150, and a fifth fewer candidates (12 160 -> ~9 700 for a 20-mer).
+DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... hold m, m-1, ... pairs; row a = p2-1 starts at a(2m+1-a)/2
+  const float tm = (float)(2 * m + 1);
+  int a = (int)((tm - sqrtf(tm * tm - 8.0f * (float)w)) * 0.5f);
+  if (a < 0) a = 0;
+  if (a > (int)m - 2) a = (int)m - 2;
+  while (a > 0 && (u32)a * (2 * m + 1 - (u32)a) / 2 > w) --a;
+  while ((u32)(a + 1) * (2 * m - (u32)a) / 2 <= w) ++a;
+  p2 = (u32)a + 1;
+  p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
+}
+__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o) {
+  constexpr u32 QCAP = 256 * 64;  // every candidate of one pass could survive
+  __shared__ u16 q_ent[QCAP];     // bits 0-8 pair, 9-11 first operation, 12-14 second operation
+  __shared__ u32 q_n, g_slots;
+  const u32 gid = blockIdx.x;
+  const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+  const u32 m = raw.z, d_win = raw.w;
+  if (!m || !(d_win & 1024u)) return;  // uniform for the workgroup
+  const u64 qpk = (u64)raw.y << 32 | raw.x;
+  if (threadIdx.x == 0) {
+    q_n = 0;
+    g_slots = 0;
+  }
+  __syncthreads();
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1, mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+  const u32 lane = threadIdx.x & 63;
+  const u32 npairs = m * (m + 1) / 2 - 1;  // p2 = 1..m-1, p1 = p2..m
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  u32 steps = 0, nlook = 0, nprobe = 0;
+  for (u32 w0 = 0; w0 < npairs; w0 += 256) {
+    const u32 w = w0 + threadIdx.x;
+    if (w < npairs) {
+      u32 p1, p2;
+      pair_of(w, m, p2, p1);
+      const u32 R1 = m - p1;
+      const KfCopy c2 = kf_copy(f.kf2, R1 < K2 ? R1 : (K2 ? K2 - 1 : 0u));
+      const KfCopy c1 = kf_copy(f.kf, R1 < K ? R1 : K - 1);
+      const u32 qa = (u32)(qpk >> (2 * R1)) & 3u;                       // q[p1-1]
+      const u32 qb = R1 ? (u32)(qpk >> (2 * R1 - 2)) & 3u : 4u;         // q[p1], 4 = none
+      const u32 q2a = (u32)(qpk >> (2 * (m - p2))) & 3u;                // q[p2-1]
+      const u32 q2b = (u32)(qpk >> (2 * (m - p2) - 2)) & 3u;            // q[p2] (p2 < m)
+#pragma unroll
+      for (u32 op1 = 0; op1 < 8; ++op1) {
+        const bool ins1 = op1 >= 4;
+        // the first operation leaves p2 characters to its left; nothing is inserted after the last character
+        bool v1 = (p1 > p2 || ins1) && !(p1 == m && ins1);
+        if (op1 == 0) v1 = v1 && qb != qa;
+        if (ins1) v1 = v1 && !(p1 >= 2 && qa == op1 - 4 && p2 + 2 <= p1);
+        if (v1) {
+          u64 s1;
+          u32 l1, w1;
+          apply_edit(qpk, m, p1, op1, s1, l1, w1);
+          const u32 posp = ins1 ? p1 : p1 - 1;  // characters left of the first operation
+          u32 mask8 = 0;
+#pragma unroll
+          for (u32 op2 = 0; op2 < 8; ++op2) {
+            bool v2 = true;
+            if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
+            if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
+            if (v2) {
+              u64 s2;
+              u32 l2, w2;
+              apply_edit(s1, l1, p2, op2, s2, l2, w2);
+              bool pass = true;
+              if (K2 && l2 >= K2) {
+                pass = kf_test(c2, s2 & mask2);
+                ++nprobe;
+              } else if (f.kf.nr) {
+                pass = kf_test(c1, s2 & kmask);
+                ++nprobe;
+              }
+              mask8 |= (u32)pass << op2;
+            }
+          }
+          while (mask8) {
+            const u32 op2 = (u32)__ffs((int)mask8) - 1u;
+            mask8 &= mask8 - 1;
+            const u32 at = atomicAdd(&q_n, 1u);
+            q_ent[at] = (u16)(threadIdx.x | (op1 << 9) | (op2 << 12));  // the pair is w0 + lane number
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const u32 qn = q_n;
+    for (u32 e0 = 0; e0 < qn; e0 += 256) {
+      if (e0 + (threadIdx.x & ~63u) >= qn) break;  // wavefront without work
+      const u32 e = e0 + threadIdx.x;
+      bool leaf = false;
+      u32 lo = 0, hi = 0, w1 = 0, w2 = 0;
+      if (e < qn) {
+        const u32 ent = q_ent[e];
+        u32 p1, p2, l1, l2;
+        u64 s1, s2;
+        pair_of(w0 + (ent & 511u), m, p2, p1);
+        apply_edit(qpk, m, p1, (ent >> 9) & 7u, s1, l1, w1);
+        apply_edit(s1, l1, p2, (ent >> 12) & 7u, s2, l2, w2);
+        const uint2 iv = f.ktab[s2 & kmask];
+        ++nlook;
+        lo = iv.x;
+        hi = iv.y;
+        u64 rs = s2 >> (2 * K);
+        u32 nr = l2 - K;
+        while (nr && lo < hi) {
+          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+          rs >>= 2;
+          --nr;
+          ++steps;
+        }
+        leaf = lo < hi;
+      }
+      const unsigned long long lm = __ballot(leaf);
+      u32 lbase = 0;
+      if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
+      lbase = __shfl(lbase, 0);
+      if (leaf) {
+        const u32 slot = atomicAdd(&g_slots, 1u);
+        const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
+        if (la < o.shard_cap) {
+          Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
+          lf->qs = gid;
+          lf->slot = slot;
+          lf->lo = lo;
+          lf->hi = hi;
+          lf->nops = 2;
+          lf->ops[0] = w1;
+          lf->ops[1] = w2;
+#pragma unroll
+          for (int k = 2; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    nlook += __shfl_xor(nlook, off);
+    nprobe += __shfl_xor(nprobe, off);
+  }
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+    if (nprobe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nprobe);
+  }
+  if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
 }
 
 template <bool INDEL, int D>
@@ -1025,13 +1332,19 @@ DG_DEV bool pleaf_less(const PLeaf& a, const PLeaf& x) { return a.hi < x.hi || (
 //   k_leaf_alive  leaf survives unless another string of its group is a proper substring, or an equal one has a lower slot
 //   k_leaf_rank   rank among the survivors in std::set order -> Sel written at its sorted position
 //   k_take        per query: hunter.h:350,357 gating over forward then reverse strings
-__global__ void k_leaf_alive(const PLeaf* G, const u64* grp_off, u64 nq2, u32 indel, u8* alive, const Counters* ctr) {
+// above: groups of more than `above` leaves only (the others were served by k_group_select)
+__global__ void k_leaf_alive(const PLeaf* G, const u64* grp_off, u64 nq2, u32 indel, u8* alive, const Counters* ctr, u32 above) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || t >= grp_off[nq2]) return;
   bool ok = true;
-  if (indel) {
+  if (indel || above) {
     const PLeaf a = G[t];
     const u64 g0 = grp_off[a.qs], g1 = grp_off[a.qs + 1];
+    if (g1 - g0 <= above) return;
+    if (!indel) {
+      alive[t] = true;
+      return;
+    }
     // "x occurs in a at offset o" = top 3*len(x) bits of (a << 3o) equal x.  The strings of a group differ in length by at
     // most 2d, so the first five shifts of a (enough for d <= 2) are made once and stay in registers.
     constexpr int NSH = 5;
@@ -1064,11 +1377,12 @@ __global__ void k_leaf_alive(const PLeaf* G, const u64* grp_off, u64 nq2, u32 in
   alive[t] = ok;
 }
 __global__ void k_leaf_rank(const PLeaf* G, const u64* grp_off, u64 nq2, const u8* alive, Sel* sel, u32* nsel,
-                            const Counters* ctr) {
+                            const Counters* ctr, u32 above) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || t >= grp_off[nq2]) return;
   const PLeaf a = G[t];
   const u64 g0 = grp_off[a.qs], g1 = grp_off[a.qs + 1];
+  if (g1 - g0 <= above) return;
   u32 r = 0, ns = 0;
   for (u64 j = g0; j < g1; ++j) {
     if (!alive[j]) continue;
@@ -1084,6 +1398,127 @@ __global__ void k_leaf_rank(const PLeaf* G, const u64* grp_off, u64 nq2, const u
   s.take = 0;
   s.hbase = 0;
   sel[g0 + r] = s;
+}
+// The same selection with one WORKGROUP per (query, strand) group, for batches whose groups are not tiny (distance >= 2:
+// ~70 occurring strings per strand of a 20-mer on a 3.1 Gb genome, where the pair loop of k_leaf_alive and the counting loop
+// of k_leaf_rank cost group-size^2).  The packed strings are sorted in LDS (bitonic, 128-bit keys: unsigned order ==
+// std::string order, i.e. the std::set order the reference walks, hunter.h:349); duplicates are then neighbours, and "some
+// other string of the group is a proper substring of this one" (neighbors.h:29-45) becomes one binary search per (length,
+// offset) window of the string — at most 14 windows at distance 2.  Survivors leave in sorted order, so the rank comes for
+// free.  Groups above SELCAP leaves stay with the lane-per-leaf kernels.
+static constexpr u32 SELCAP = 1024;
+__global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64* grp_off, u32 indel, Sel* sel, u32* nsel, const Counters* ctr) {
+  __shared__ unsigned long long kh[SELCAP], kl[SELCAP];
+  __shared__ u16 ix[SELCAP];  // bits 0-9 position in the group, bits 10-15 string length
+  __shared__ u32 s_minlen, s_w[2];
+  const u64 g = blockIdx.x;
+  if (ctr->overflow) return;
+  const u64 g0 = grp_off[g];
+  const u32 k = (u32)(grp_off[g + 1] - g0);
+  if (k == 0 || k > SELCAP) return;  // empty: nsel stays 0;  huge: k_leaf_alive / k_leaf_rank
+  if (k == 1) {
+    if (threadIdx.x == 0) {
+      const PLeaf a = G[g0];
+      Sel o;
+      o.lo = a.sa_lo;
+      o.hi = a.sa_hi;
+      o.len = a.len;
+      o.take = 0;
+      o.hbase = 0;
+      sel[g0] = o;
+      nsel[g] = 1;
+    }
+    return;
+  }
+  u32 n2 = 2;
+  while (n2 < k) n2 <<= 1;
+  if (threadIdx.x == 0) s_minlen = 0xFFFFFFFFu;
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < n2; i += blockDim.x) {
+    if (i < k) {
+      const PLeaf a = G[g0 + i];
+      kh[i] = a.hi;
+      kl[i] = a.lo;
+      ix[i] = (u16)(i | (a.len << 10));
+      atomicMin(&s_minlen, a.len);
+    } else {
+      kh[i] = ~0ULL;
+      kl[i] = ~0ULL;
+      ix[i] = 0xFFFFu;
+    }
+  }
+  __syncthreads();
+  for (u32 kk = 2; kk <= n2; kk <<= 1)
+    for (u32 j = kk >> 1; j > 0; j >>= 1) {
+      for (u32 i = threadIdx.x; i < n2; i += blockDim.x) {
+        const u32 l = i ^ j;
+        if (l > i) {
+          const u64 ah = kh[i], al = kl[i], bh = kh[l], bl = kl[l];
+          const bool gt = ah > bh || (ah == bh && al > bl);
+          if (gt == ((i & kk) == 0)) {
+            kh[i] = bh;
+            kl[i] = bl;
+            kh[l] = ah;
+            kl[l] = al;
+            const u16 t = ix[i];
+            ix[i] = ix[l];
+            ix[l] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  const u32 minlen = s_minlen;
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 base = 0;
+  for (u32 c0 = 0; c0 < k; c0 += blockDim.x) {
+    const u32 i = c0 + threadIdx.x;
+    bool ok = false;
+    u32 len = 0;
+    if (i < k) {
+      const u64 ah = kh[i], al = kl[i];
+      len = ix[i] >> 10;
+      ok = !(i > 0 && kh[i - 1] == ah && kl[i - 1] == al);  // equal strings: the first one stays
+      if (ok && indel) {
+        for (u32 sl = minlen; sl < len && ok; ++sl) {
+          const u32 nbits = 3 * sl;  // <= 126
+          const u64 mh = nbits >= 64 ? ~0ULL : (nbits ? ~0ULL << (64 - nbits) : 0ULL);
+          const u64 ml = nbits > 64 ? ~0ULL << (128 - nbits) : 0ULL;
+          for (u32 o = 0; o + sl <= len && ok; ++o) {
+            u64 h = ah, l = al;
+            p128_shl(h, l, 3 * o);
+            h &= mh;
+            l &= ml;
+            u32 lo = 0, hi = k;
+            while (lo < hi) {
+              const u32 mid = (lo + hi) >> 1;
+              const u64 xh = kh[mid], xl = kl[mid];
+              if (xh < h || (xh == h && xl < l)) lo = mid + 1;
+              else hi = mid;
+            }
+            if (lo < k && kh[lo] == h && kl[lo] == l) ok = false;  // a shorter string of the group occurs in this one
+          }
+        }
+      }
+    }
+    const unsigned long long mk = __ballot(ok);
+    if (lane == 0) s_w[wave] = (u32)__popcll(mk);
+    __syncthreads();
+    if (ok) {
+      const u32 r = base + (wave ? s_w[0] : 0u) + (u32)__popcll(mk & ((1ULL << lane) - 1));
+      const PLeaf a = G[g0 + (ix[i] & 1023u)];
+      Sel o;
+      o.lo = a.sa_lo;
+      o.hi = a.sa_hi;
+      o.len = a.len;
+      o.take = 0;
+      o.hbase = 0;
+      sel[g0 + r] = o;
+    }
+    base += s_w[0] + s_w[1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) nsel[g] = base;
 }
 __global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u32* qhits, const Counters* ctr) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2021,14 +2456,24 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       so.ctr = ctr;
       so.grp_cnt = grp_cnt;
       if (b.fastK) {  // distance 1: the flat kernel takes every query that qualifies, k_search (one lane per strand) the rest
-        const u32 ipg = indel ? maxlen * 8u : maxlen * 4u;
-        const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
-        if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);
+        static const bool per_op = std::getenv("DICEY_FLAT1_PER_OP") != nullptr;  // the lane-per-operation form (A/B runs)
+        if (per_op) {
+          const u32 ipg = indel ? maxlen * 8u : maxlen * 4u;
+          const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
+          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);
+        } else {
+          const u32 ipg = maxlen, magic = (65536u + ipg - 1) / ipg;
+          const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
+          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<false>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
+        }
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       if (b.fast2K) {  // edit distance 2: one workgroup per (query, strand) for every query that qualifies
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2<4>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
+        static const bool per_op = std::getenv("DICEY_FLAT2_PER_OP") != nullptr;  // the lane-per-operation-pair form (A/B runs)
+        if (per_op) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2<4>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
+        else hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       // root-level work split (see k_search): only with the table and with at least one edit to place
@@ -2057,10 +2502,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       u8* alive = ws[WS_SCR].as<u8>();
       hipLaunchKernelGGL(k_group_pack, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr,
                          grp_off, ws[WS_LEAFG].as<PLeaf>());
+      // distance >= 2: groups of up to SELCAP strings are sorted by a workgroup each, the lane-per-leaf kernels keep the rest
+      static const bool no_gsel = std::getenv("DICEY_NO_GROUP_SELECT") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
+      const u32 above = (dmax_eff >= 2 && !no_gsel && ngrp < 0x7FFFFFFFull) ? SELCAP : 0u;
+      if (above)
+        hipLaunchKernelGGL(k_group_select, dim3((u32)ngrp), dim3(128), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, (u32)indel,
+                           ws[WS_SEL].as<Sel>(), nsel, ctr);
       hipLaunchKernelGGL(k_leaf_alive, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
-                         (u32)indel, alive, ctr);
+                         (u32)indel, alive, ctr, above);
       hipLaunchKernelGGL(k_leaf_rank, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
-                         (const u8*)alive, ws[WS_SEL].as<Sel>(), nsel, ctr);
+                         (const u8*)alive, ws[WS_SEL].as<Sel>(), nsel, ctr, above);
       hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_off, nsel, ws[WS_SEL].as<Sel>(), qhits, ctr);
     } else {
       hipLaunchKernelGGL(k_group, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr, grp_off,

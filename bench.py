@@ -347,6 +347,8 @@ def main():
         meta = {"lens": lens}
         if cfg in ("hunt_d1", "hunt_d2"):
             meta["queries"] = [[q.decode() for q in synth_queries(text, units, a.qlen, seed=qseed + r)] for r in range(world)]
+            if os.environ.get("DICEY_BENCH_SORT"):  # experiment: queries in the order of their forward filter window (page locality)
+                meta["queries"] = [sorted(qs, key=lambda q: q[1:]) for qs in meta["queries"]]
         elif cfg == "search":
             meta["primers"] = [synth_primer_pairs(text, units // 2, seed=qseed + 100 * r) for r in range(world)]
         else:
@@ -528,7 +530,7 @@ def main():
             mean = lambda k: float(np.mean([r[k] for r in acc]))  # noqa: E731
             ext, tab, probe = mean("ext"), mean("tab"), mean("probe")
             flat = mean("ms_search_flat")
-            kernel = ("k_search1<true>" if distance == 1 else "k_search2<4>") if flat > 0 else f"k_search<true,{distance}>"
+            kernel = ("k_probe1<true> + k_finish1<true>" if distance == 1 else "k_search2p") if flat > 0 else f"k_search<true,{distance}>"
             kernel_ms = flat if flat > 0 else mean("ms_search")
             alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
             # the same launch in SURVEY.md §8(d) units: a backward step on c = 2 L(c) rank ops of 24 B on the sdsl layout

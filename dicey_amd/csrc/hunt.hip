@@ -570,6 +570,133 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
   }
 }
 
+// k_search1p cut in two kernels.  Its profile (r02): 5.0 M fabric reads and 47 M vector instructions in 0.28 ms — neither
+// the line rate nor the issue rate, but the chain "record, probe, barrier, record, table entry, 3-5 extensions" that every
+// workgroup walks once with a handful of survivors.  k_probe1 is the first half without barrier or LDS: survivors leave
+// as 32-bit (group, position, operation) entries in a sharded queue in HBM (one atomic per wavefront); k_finish1 is the second
+// half, one lane per queued survivor, so the whole batch's chains are in flight together.
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_probe1(FmView f, Batch b, Counters* ctr, u32* squeue, u32 scap_log2, u32 ipg, u32 magic, u32 dbg) {
+  constexpr u32 NOPS = INDEL ? 8u : 4u;
+  const u32 first = blockIdx.x * 256u;
+  const u32 g_first = first / ipg, r_first = first - g_first * ipg;
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1;
+  const u32 lane = threadIdx.x & 63;
+  const u32 ngrp2 = (u32)(2 * b.nq);
+  u32 mask8 = 0, nprobe = 0;
+  const u32 t = r_first + threadIdx.x, qd = (t * magic) >> 16;
+  const u32 gid = g_first + qd, pos = t - qd * ipg + 1;
+  if (gid < ngrp2) {
+    // dbg: timing experiments only (DICEY_DBG_PROBE): 1 = no filter loads, 2 = no queue writes, 4 = no record load
+    uint4 raw;
+    if (dbg & 4u) raw = make_uint4(gid * 2654435761u, gid * 40503u, ipg, 512u | 256u | 1u);
+    else raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+    const u64 qpk = ((u64)raw.y << 32 | raw.x) & ((1ULL << (2 * raw.z)) - 1);
+    const u32 m = raw.z, d_win = raw.w;
+    if (m && (d_win & 512u) && pos <= m) {
+      const u32 R = m - pos;
+      const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
+      const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
+      const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+#pragma unroll
+      for (u32 op = 0; op < NOPS; ++op) {
+        u64 s_pk;
+        u32 mlen, ow;
+        if (cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow)) {
+          bool pass = true;
+          if (dbg & 1u) {
+            pass = ((u32)(s_pk * 0x9E3779B97F4A7C15ULL >> 58)) == 0u;  // one in 64, no load
+          } else if (K2 && mlen >= K2) {
+            pass = kf_test(c2, s_pk & mask2);
+            ++nprobe;
+          } else if (f.kf.nr) {
+            pass = kf_test(c1, s_pk & kmask);
+            ++nprobe;
+          }
+          mask8 |= (u32)pass << op;
+        }
+      }
+    }
+  }
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  // queue space for the wavefront's survivors with one atomic: inclusive scan of the lanes' counts
+  const u32 mine = (u32)__popc(mask8);
+  u32 incl = mine;
+  for (int off = 1; off < 64; off <<= 1) {
+    const u32 v = __shfl_up(incl, off);
+    if ((int)lane >= off) incl += v;
+  }
+  const u32 total = __shfl(incl, 63);
+  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+  u32 base = 0;
+  if (dbg & 2u) return;
+  if (lane == 63) {
+    if (total) base = atomicAdd(&ctr->surv_cnt[shard], total);
+    if (nprobe) atomicAdd(&ctr->probes[shard], (unsigned long long)nprobe);
+  }
+  base = __shfl(base, 63);
+  u32 at = base + incl - mine;
+  const u32 cap = 1u << scap_log2;
+  while (mask8) {
+    const u32 op = (u32)__ffs((int)mask8) - 1u;
+    mask8 &= mask8 - 1;
+    if (at < cap) squeue[((u64)shard << scap_log2) + at] = (gid << 8) | (pos << 3) | op;
+    ++at;
+  }
+}
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_finish1(FmView f, Batch b, SearchOut o, const u32* squeue, u32 scap_log2) {
+  const u64 t = (u64)blockIdx.x * 256u + threadIdx.x;
+  const u32 qshard = (u32)(t >> scap_log2), off = (u32)t & ((1u << scap_log2) - 1);
+  const u32 have = o.ctr->surv_cnt[qshard];
+  u32 steps = 0, nlook = 0;
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  if (have <= (1u << scap_log2) && off < have) {  // an overflowing queue repeats the batch (k_leaf_overflow)
+    const u32 ent = squeue[t], gid = ent >> 8, pos = (ent >> 3) & 31u, op = ent & 7u;
+    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+    u64 s_pk;
+    u32 mlen, ow;
+    (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
+    const u32 K = f.K;
+    const uint2 iv = f.ktab[s_pk & ((1ULL << (2 * K)) - 1)];
+    ++nlook;
+    u32 lo = iv.x, hi = iv.y;
+    u64 rs = s_pk >> (2 * K);
+    u32 n = mlen - K;
+    while (n && lo < hi) {
+      bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+      rs >>= 2;
+      --n;
+      ++steps;
+    }
+    if (lo < hi) {
+      const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+      const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+      if (at < o.shard_cap) {
+        Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+        lf->qs = gid;
+        lf->slot = slot;
+        lf->lo = lo;
+        lf->hi = hi;
+        lf->nops = ow >> 28;
+        lf->ops[0] = ow & 0x0FFFFFFFu;
+#pragma unroll
+        for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+      }
+    }
+  }
+  if (__ballot(nlook != 0) == 0) return;
+  for (int off2 = 32; off2 > 0; off2 >>= 1) {
+    steps += __shfl_xor(steps, off2);
+    nlook += __shfl_xor(nlook, off2);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Distance 2 (edit mode) laid out flat as well.  r02 profile of the state machine at d = 2: 124 ms per 100 000 20-mers,
 // 1.7 G filter probes + 0.36 G table reads + 0.59 G interval extensions — issue bound like its d = 1 form was, and most of
@@ -1102,13 +1229,13 @@ __global__ void __launch_bounds__(256) k_explicit(FmView f, Batch b, SearchOut o
   wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
 }
 
-__global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap) {  // NSHARD lanes
+__global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap, u32 surv_cap) {  // NSHARD lanes
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < NSHARD && ctr->leaf_cnt[k] > shard_cap) atomicOr(&ctr->overflow, 1u);
+  if (k < NSHARD && (ctr->leaf_cnt[k] > shard_cap || ctr->surv_cnt[k] > surv_cap)) atomicOr(&ctr->overflow, 1u);
 }
 // what the host needs at the end of a batch, in 64 bytes instead of the 36 KB of sharded counters
 struct Summary {
-  unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow, refused, too_long, probes;
+  unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow, refused, too_long, probes, worst_surv;
 };
 __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {  // NSHARD lanes
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1120,6 +1247,7 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
   if (ctr->sa_reads[k]) atomicAdd(&out->sa_reads, ctr->sa_reads[k]);
   if (ctr->win_bytes[k]) atomicAdd(&out->win_bytes, ctr->win_bytes[k]);
   if (ctr->probes[k]) atomicAdd(&out->probes, ctr->probes[k]);
+  atomicMax(&out->worst_surv, (unsigned long long)ctr->surv_cnt[k]);
   if (k == 0) {
     out->nhits = *nhits;
     out->overflow = ctr->overflow;
@@ -1130,23 +1258,25 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
 // Production form: one workgroup, one lane per shard, totals straight into the pinned host record (no atomics over the bus,
 // no separate copy); the host reads it after the batch's single stream synchronisation.
 __global__ void __launch_bounds__(NSHARD) k_summary_block(const Counters* ctr, const u64* nhits, Summary* host_out) {
-  constexpr int NF = 7;
+  constexpr int NF = 8;  // fields 1 and 7 are maxima, the others sums
   __shared__ unsigned long long part[NF][NSHARD / 64];
   const u32 k = threadIdx.x;
-  unsigned long long v[NF] = {ctr->leaf_cnt[k], ctr->leaf_cnt[k], ctr->steps[k], ctr->lookups[k], ctr->sa_reads[k], ctr->win_bytes[k], ctr->probes[k]};
+  unsigned long long v[NF] = {ctr->leaf_cnt[k], ctr->leaf_cnt[k], ctr->steps[k], ctr->lookups[k], ctr->sa_reads[k], ctr->win_bytes[k], ctr->probes[k],
+                              ctr->surv_cnt[k]};
   for (int f = 0; f < NF; ++f) {
     unsigned long long x = v[f];
     for (int off = 32; off > 0; off >>= 1) {
       const unsigned long long o = __shfl_xor(x, off);
-      x = f == 1 ? (o > x ? o : x) : x + o;
+      x = (f == 1 || f == 7) ? (o > x ? o : x) : x + o;
     }
     if ((k & 63) == 0) part[f][k >> 6] = x;
   }
   __syncthreads();
   if (k == 0) {
-    unsigned long long t[NF] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t[NF] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int f = 0; f < NF; ++f)
-      for (u32 w = 0; w < NSHARD / 64; ++w) t[f] = f == 1 ? (part[f][w] > t[f] ? part[f][w] : t[f]) : t[f] + part[f][w];
+      for (u32 w = 0; w < NSHARD / 64; ++w) t[f] = (f == 1 || f == 7) ? (part[f][w] > t[f] ? part[f][w] : t[f]) : t[f] + part[f][w];
+    host_out->worst_surv = t[7];
     host_out->nleaf = t[0];
     host_out->worst_shard = t[1];
     host_out->steps = t[2];
@@ -1432,7 +1562,10 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
   }
   u32 n2 = 2;
   while (n2 < k) n2 <<= 1;
-  if (threadIdx.x == 0) s_minlen = 0xFFFFFFFFu;
+  if (threadIdx.x == 0) {
+    s_minlen = 0xFFFFFFFFu;
+    s_w[1] = 0;  // stays 0 when the workgroup is a single wavefront
+  }
   __syncthreads();
   for (u32 i = threadIdx.x; i < n2; i += blockDim.x) {
     if (i < k) {
@@ -2127,6 +2260,256 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Verify for short queries (<= 32 nt) at distance <= 2 with a BANDED matrix.  The hit stems from a neighbourhood string within
+// d operations of the query that occurs at `loc`, so the window (<= d context characters, the string, <= d context characters)
+// aligns to the query with score >= -d: leading rows are free in column 0, the string costs at most d, trailing rows are free
+// in column n.  On a path of score >= -d the diagonal r - c of an interior cell lies in [-d, (mg - n) + 2d]: the free leading
+// rows v0 satisfy v0 + v_end = mg - n + (horizontal - vertical interior moves) <= mg - n + d, and the interior moves shift
+// the diagonal by at most d either way.  Every cell of every optimal path is inside that band, its value inside the band is
+// the full matrix's value (a better predecessor outside would put that predecessor on an optimal path), and a predecessor
+// that ties at such a cell is itself on an optimal path — so the scores AND the reference's tie order (horizontal, then
+// vertical, then diagonal; needle.h:105-131) along the traceback are those of the full matrix, with 7 (d <= 1) or 13 (d = 2)
+// cells per row instead of the query length.  Storage is by diagonal: k = c - r + dm, dm = mg - n + 2d; diagonal move: same k,
+// vertical: k + 1 of the previous row, horizontal: k - 1 of the same row, so one array is updated in place left to right.
+// The query slides through a byte window (one character enters per row).  Window and query come in as aligned 64-bit words,
+// the alignment rows leave as 64-bit words.
+template <int WB>
+__global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyArgs a, Counters* ctr) {
+  constexpr int MAXROW = 32 + 3 * 2 + 2;
+  __shared__ u32 tr_lds[MAXROW * 128];  // [row][lane]: 2 bits per diagonal
+  u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 nh = *a.nhits;
+  if (ctr->overflow || nh > a.hit_cap || h >= nh) return;
+  const HitSeed sd = a.seeds[h];
+  const u64 q = sd.qs >> 1;
+  const u32 strand = sd.qs & 1;
+  const u64 qstart = b.qoff[q];
+  const u8* qseq = (strand ? b.rv : b.fw) + qstart;
+  const u32 n = b.qlen[q];
+  const u64 loc = sd.pos;
+  const u32 mlen = sd.len;
+  const u32 d = b.indel ? b.qdist[q] : 0u;
+  // the whole possible window [loc - pre, loc + mlen + post) as aligned words, before its '\n' trimming is known
+  u64 pre = d, post = d;
+  if (pre > loc) pre = loc;
+  if (loc + mlen + post > f.n) post = f.n - loc - mlen;
+  constexpr int GW = (32 + 3 * 2 + 7) / 8 + 1;  // 38 bytes at any byte offset
+  constexpr int QW = 32 / 8 + 1;
+  u64 gw[GW], qw[QW];
+  {
+    const u64 g0 = loc - pre, a0 = g0 & ~7ULL;
+    const u32 sh = (u32)(g0 & 7) * 8;
+    const u64* src = reinterpret_cast<const u64*>(f.text + a0);
+    u64 w[GW + 1];
+#pragma unroll
+    for (int i = 0; i <= GW; ++i) w[i] = (u32)(8 * i) < (u32)(g0 & 7) + (u32)(pre + mlen + post) ? src[i] : 0ULL;
+#pragma unroll
+    for (int i = 0; i < GW; ++i) gw[i] = sh ? (w[i] >> sh) | (w[i + 1] << (64 - sh)) : w[i];
+    const u64 b0 = (u64)(uintptr_t)qseq, qa0 = b0 & ~7ULL;
+    const u32 qsh = (u32)(b0 & 7) * 8;
+    const u64* qsrc = reinterpret_cast<const u64*>((uintptr_t)qa0);
+    u64 v[QW + 1];
+#pragma unroll
+    for (int i = 0; i <= QW; ++i) v[i] = (u32)(8 * i) < (u32)(b0 & 7) + n ? qsrc[i] : 0ULL;
+#pragma unroll
+    for (int i = 0; i < QW; ++i) qw[i] = qsh ? (v[i] >> qsh) | (v[i + 1] << (64 - qsh)) : v[i];
+  }
+  auto gw_at = [&](u32 i) -> u32 {  // byte i of the maximal window
+    u64 w = gw[0];
+#pragma unroll
+    for (int k = 1; k < GW; ++k)
+      if ((i >> 3) == (u32)k) w = gw[k];
+    return (u32)(w >> (8 * (i & 7))) & 255u;
+  };
+  auto q_at = [&](u32 i) -> u32 {  // ASCII of query character i (i < n)
+    u64 w = qw[0];
+#pragma unroll
+    for (int k = 1; k < QW; ++k)
+      if ((i >> 3) == (u32)k) w = qw[k];
+    return ascii_of((u32)(w >> (8 * (i & 7))) & 255u);
+  };
+  // hunter.h:358-362: text position -> (refIndex, chrpos)
+  u32 lo_r = 0, hi_r = a.nseq - 1;
+  while (lo_r < hi_r) {
+    u32 mid = (lo_r + hi_r + 1) >> 1;
+    if (a.cum[mid] <= loc) lo_r = mid;
+    else hi_r = mid - 1;
+  }
+  const u32 ref = lo_r;
+  u32 chrpos = (u32)(loc - a.cum[ref]);
+  // hunter.h:363-378: the context stops at sequence separators
+  u32 pre_eff = 0;
+  for (u32 i = 1; i <= pre; ++i) {
+    if (gw_at((u32)pre - i) == '\n') break;
+    pre_eff = i;
+  }
+  u32 post_eff = 0;
+  for (u32 i = 0; i < post; ++i) {
+    if (gw_at((u32)pre + mlen + i) == '\n') break;
+    post_eff = i + 1;
+  }
+  const u32 skip = (u32)pre - pre_eff;         // genomicseq starts at byte `skip` of the maximal window
+  const u32 mg = pre_eff + mlen + post_eff;    // rows
+  if (pre_eff < chrpos) chrpos -= pre_eff;     // hunter.h:382 (strict <)
+  char* ra = a.refalign + h * a.stride;
+  char* qa = a.queryalign + h * a.stride;
+  dg_hit out;
+  out.chr = ref;
+  out.query = (u32)q;
+  out.strand = strand ? '-' : '+';
+  out.reserved = 0;
+  atomicAdd(&ctr->win_bytes[blockIdx.x & (NSHARD - 1)], (unsigned long long)(pre + mlen + post));
+  u64* ra8 = reinterpret_cast<u64*>(ra);
+  u64* qa8 = reinterpret_cast<u64*>(qa);
+  if (!b.indel) {
+    // hunter.h:79-88,404-405: score = -(mismatches), alignment rows are the raw strings (mg == mlen == n here)
+    int sc = 0;
+    const u32 k = mg < n ? mg : n;
+    for (u32 i = 0; i < k; ++i) sc -= (gw_at(skip + i) != q_at(i));
+    u64 wr = 0, wq = 0;
+    const u32 top = mg > n ? mg : n;
+    for (u32 i = 0; i < top; ++i) {
+      if (i < mg) wr |= (u64)gw_at(skip + i) << (8 * (i & 7));
+      if (i < n) wq |= (u64)q_at(i) << (8 * (i & 7));
+      if ((i & 7) == 7 || i + 1 == top) {
+        ra8[i >> 3] = wr;
+        qa8[i >> 3] = wq;
+        wr = wq = 0;
+      }
+    }
+    out.score = sc;
+    out.start = chrpos + 1;
+    out.aln_len = (u16)top;
+    a.hits[h] = out;
+    return;
+  }
+  constexpr int NEG = -1000;
+  const int dm = (int)mg - (int)n + 2 * (int)d;  // largest diagonal r - c kept; k = c - r + dm
+  int s[WB];
+#pragma unroll
+  for (int k = 0; k < WB; ++k) {
+    const int c = k - dm;
+    s[k] = (c < 0 || c > (int)n) ? NEG : -c;
+  }
+  // query window of row r: byte k = q[c - 1] for c = r - dm + k (0 outside the query)
+  auto qbyte = [&](int i) -> u64 { return (i >= 0 && i < (int)n) ? (u64)q_at((u32)i) : 0ULL; };
+  u64 qlo = 0, qhi = 0;  // bytes 0-7 and 8-15 of the window
+#pragma unroll
+  for (int k = 0; k < WB; ++k) {  // row 1: c - 1 = k - dm
+    const u64 v = qbyte(k - dm);
+    if (k < 8) qlo |= v << (8 * k);
+    else qhi |= v << (8 * (k - 8));
+  }
+  u32* tr = tr_lds + threadIdx.x;
+  for (u32 row = 1; row <= mg; ++row) {
+    const u32 gc = gw_at(skip + row - 1);
+    const int c0 = (int)row - dm;
+    u32 bits = 0;
+    int left = NEG;
+#pragma unroll
+    for (int k = 0; k < WB; ++k) {
+      const int c = c0 + k;
+      const u32 qc = (u32)((k < 8 ? qlo >> (8 * k) : qhi >> (8 * (k - 8))) & 255u);
+      const int up = k + 1 < WB ? s[k + 1] : NEG;
+      const int dsc = s[k] + (gc == qc ? 0 : -1);
+      const int vsc = up + (c == (int)n ? 0 : -1);
+      const int hsc = left - 1;
+      int best = dsc > vsc ? dsc : vsc;
+      best = best > hsc ? best : hsc;
+      const u32 code = best == hsc ? 1u : (best == vsc ? 2u : 0u);
+      const int val = c < 0 ? NEG : (c == 0 ? 0 : (c > (int)n ? NEG : best));
+      s[k] = val;
+      left = val;
+      bits |= code << (2 * k);
+    }
+    tr[row * 128] = bits;
+    // slide the query window: drop byte 0, the character of column c0 + WB (next row's last diagonal) enters at the top
+    const u64 nb = qbyte(c0 + WB - 1);
+    qlo = (qlo >> 8) | (qhi << 56);
+    qhi >>= 8;
+    if (WB <= 8) qlo |= nb << (8 * (WB - 1));
+    else qhi |= nb << (8 * (WB - 9));
+  }
+  int fin = NEG;
+#pragma unroll
+  for (int k = 0; k < WB; ++k)
+    if (k == 2 * (int)d) fin = s[k];  // cell (mg, n)
+  out.score = fin;
+  // traceback into a move stack held in registers, then one forward pass that writes the kept columns
+  u64 mv0 = 0, mv1 = 0, mv2 = 0;
+  u32 nmv = 0, trail = 0;
+  bool seen_query = false;
+  u32 row = mg, col = n;
+  while (row > 0 || col > 0) {
+    u32 code;
+    if (col == 0) code = 2u;
+    else if (row == 0) code = 1u;
+    else {
+      const int k = (int)col - (int)row + dm;  // inside the band on every optimal path
+      code = (k >= 0 && k < WB) ? (tr[row * 128] >> (2 * k)) & 3u : 1u;
+    }
+    if (code == 1) --col;
+    else if (code == 2) --row;
+    else {
+      --row;
+      --col;
+    }
+    if (code == 2 && !seen_query) ++trail;  // trailing columns whose query row is a gap (_trailGap, hunter.h:69-77)
+    else seen_query = true;
+    mv2 = (mv2 << 2) | (mv1 >> 62);
+    mv1 = (mv1 << 2) | (mv0 >> 62);
+    mv0 = (mv0 << 2) | code;
+    ++nmv;
+  }
+  u32 r = 0, c = 0, len = 0, lead = 0;
+  bool in_lead = true;
+  const u32 stop = nmv - trail;
+  u64 wr = 0, wq = 0;
+  for (u32 k = 0; k < stop; ++k) {
+    const u32 code = (u32)mv0 & 3u;
+    mv0 = (mv0 >> 2) | (mv1 << 62);
+    mv1 = (mv1 >> 2) | (mv2 << 62);
+    mv2 >>= 2;
+    u32 r0, r1;
+    if (code == 1) {
+      r0 = '-';
+      r1 = q_at(c);
+      ++c;
+    } else if (code == 2) {
+      r0 = gw_at(skip + r);
+      r1 = '-';
+      ++r;
+    } else {
+      r0 = gw_at(skip + r);
+      r1 = q_at(c);
+      ++r;
+      ++c;
+    }
+    if (r1 != '-') in_lead = false;
+    if (in_lead) {  // leading query-gap columns only advance chrpos (hunter.h:391-401)
+      ++lead;
+      continue;
+    }
+    wr |= (u64)r0 << (8 * (len & 7));
+    wq |= (u64)r1 << (8 * (len & 7));
+    if ((len & 7) == 7) {
+      ra8[len >> 3] = wr;
+      qa8[len >> 3] = wq;
+      wr = wq = 0;
+    }
+    ++len;
+  }
+  if (len & 7) {
+    ra8[len >> 3] = wr;
+    qa8[len >> 3] = wq;
+  }
+  chrpos += lead;
+  out.start = chrpos + 1;
+  out.aln_len = (u16)len;
+  a.hits[h] = out;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Host orchestration
 // ------------------------------------------------------------------------------------------------------------
 
@@ -2366,7 +2749,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   static const bool no_fast1 = std::getenv("DICEY_NO_FAST1") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
   Batch b;
-  b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen <= 31 && maxlen > ix->view.K && ngrp * (u64)maxlen * 9 < 0xFFFFFF00ull) ? ix->view.K : 0u;
+  b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen <= 31 && maxlen > ix->view.K && ngrp * (u64)maxlen * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
   b.fast2K = (!no_fast1 && indel && dmax_eff == 2 && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
@@ -2433,6 +2816,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     shard_cap = (u32)std::max(1, std::atoi(e));
     hit_cap = (u64)std::max(1, std::atoi(e));
   }
+  // survivor queue of the distance-1 kernels: per shard, a power of two; ~6 survivors per strand on a 3.1 Gb genome
+  u32 surv_cap_log2 = ix->surv_cap_log2_hint;
+  if (!surv_cap_log2) {
+    surv_cap_log2 = 6;
+    while (surv_cap_log2 < 24 && ((u64)NSHARD << surv_cap_log2) < 12 * ngrp) ++surv_cap_log2;
+  }
+  if (std::getenv("DICEY_DEBUG_CAPS")) surv_cap_log2 = 1;
   u64 nleaf = 0, nhits = 0;
   for (int attempt = 0;; ++attempt) {
     if (attempt > 4) return fail(DG_ENOMEM, "buffer overflow persists (%llu leaves, %llu hits)", (unsigned long long)nleaf, (unsigned long long)nhits);
@@ -2442,6 +2832,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_TRY(ws[WS_SEL].reserve((leaf_slots + 1) * sizeof(Sel)));
     DG_TRY(ws[WS_SCR].reserve((leaf_slots + 1) * 5 + 64));
     DG_TRY(ws[WS_SEEDS].reserve((hit_cap + 1) * sizeof(HitSeed)));
+    if (b.fastK && std::getenv("DICEY_FLAT1_SPLIT")) DG_TRY(ws[WS_MISC].reserve(((u64)NSHARD << surv_cap_log2) * 4 + 64));
+    u32 surv_cap = 0xFFFFFFFFu;  // set where the survivor queue is used
     DG_TRY(ws[WS_JOBS].reserve(std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
     DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
@@ -2463,10 +2855,27 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
           else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);
         } else {
+          // probe + finish in one kernel unless DICEY_FLAT1_SPLIT asks for the two-kernel form (r02 A/B: 0.25 ms fused, 0.21 +
+          // 0.19 ms split — both halves run at the memory system's random-access rate, cutting the chain gained nothing)
+          static const bool fused = std::getenv("DICEY_FLAT1_SPLIT") == nullptr;
           const u32 ipg = maxlen, magic = (65536u + ipg - 1) / ipg;
           const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
-          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<false>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
+          if (fused) {
+            if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<false>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
+          } else {
+            u32* sq = ws[WS_MISC].as<u32>();
+            static const u32 dbg_probe = std::getenv("DICEY_DBG_PROBE") ? (u32)std::atoi(std::getenv("DICEY_DBG_PROBE")) : 0u;
+            const dim3 g2((u32)(((u64)NSHARD << surv_cap_log2) / TB));
+            surv_cap = 1u << surv_cap_log2;
+            if (indel) {
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe1<true>), g1, b1, 0, st, ix->view, b, ctr, sq, surv_cap_log2, ipg, magic, dbg_probe);
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_finish1<true>), g2, b1, 0, st, ix->view, b, so, (const u32*)sq, surv_cap_log2);
+            } else {
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe1<false>), g1, b1, 0, st, ix->view, b, ctr, sq, surv_cap_log2, ipg, magic, dbg_probe);
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_finish1<false>), g2, b1, 0, st, ix->view, b, so, (const u32*)sq, surv_cap_log2);
+            }
+          }
         }
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
@@ -2495,7 +2904,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (nxs) hipLaunchKernelGGL(k_explicit, dim3(ceil_div(nxs, TB)), dim3(TB), 0, st, ix->view, b, so);
     }
     DG_HIP(hipEventRecord(ix->ev[2], st));
-    hipLaunchKernelGGL(k_leaf_overflow, dim3(NSHARD / 256), dim3(256), 0, st, ctr, shard_cap);
+    hipLaunchKernelGGL(k_leaf_overflow, dim3(NSHARD / 256), dim3(256), 0, st, ctr, shard_cap, surv_cap);
     DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf));
     DG_HIP(hipEventRecord(ix->ev[3], st));
     if (packed) {
@@ -2506,6 +2915,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       static const bool no_gsel = std::getenv("DICEY_NO_GROUP_SELECT") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
       const u32 above = (dmax_eff >= 2 && !no_gsel && ngrp < 0x7FFFFFFFull) ? SELCAP : 0u;
       if (above)
+        // (one wavefront per group was tried: 1.95 -> 2.5 ms, the second wavefront's share of the window searches is worth more than the barriers)
         hipLaunchKernelGGL(k_group_select, dim3((u32)ngrp), dim3(128), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, (u32)indel,
                            ws[WS_SEL].as<Sel>(), nsel, ctr);
       hipLaunchKernelGGL(k_leaf_alive, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
@@ -2560,7 +2970,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
-      if (maxlen <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 24>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      static const bool no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;
+      if (!no_band && maxlen <= 32 && dmax_eff <= 1 && (stride & 7) == 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_band<7>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      else if (!no_band && maxlen <= 32 && dmax_eff == 2 && (stride & 7) == 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_band<13>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      else if (maxlen <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 24>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else if (maxlen <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 32>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else if (cells <= 32 * 160) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
@@ -2582,6 +2997,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
                   hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
     nleaf = hsum.nleaf;
     nhits = hsum.nhits;
+    if (surv_cap != 0xFFFFFFFFu && hsum.worst_surv > surv_cap) {
+      while (surv_cap_log2 < 30 && (1ull << surv_cap_log2) < hsum.worst_surv + hsum.worst_surv / 4) ++surv_cap_log2;
+      continue;
+    }
     const u32 worst = (u32)hsum.worst_shard;
     if (worst > shard_cap) {
       shard_cap = worst + worst / 4 + 64;
@@ -2594,6 +3013,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     break;
   }
   ix->shard_cap_hint = shard_cap;
+  if (b.fastK) ix->surv_cap_log2_hint = surv_cap_log2;
   ix->hit_cap_hint = std::max<u64>(ix->hit_cap_hint, nhits + nhits / 4 + 1024);
   if (group_counts) {
     DG_HIP(hipMemcpyAsync(group_counts, ws[WS_HITS].p, ngrp * 8, hipMemcpyDeviceToHost, st));

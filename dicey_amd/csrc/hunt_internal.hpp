@@ -64,6 +64,7 @@ struct Counters {
   u32 pad_[15];
   u32 leaf_cnt[NSHARD];  // leaves allocated in each shard's region of the leaf buffer
   unsigned long long steps[NSHARD], lookups[NSHARD], sa_reads[NSHARD], win_bytes[NSHARD], probes[NSHARD];
+  u32 surv_cnt[NSHARD];  // filter survivors queued in each shard's region of the survivor buffer (k_probe1 -> k_finish1)
 };
 
 struct HitSeed {

@@ -309,7 +309,9 @@ static void kf_layout(KFilter& kf, u32 k) {
   const u32 bits = 2 * k;
   u32 nr = bits <= 9 ? 1u : (bits - 9 + 7) / 8 + 1;
   if (nr > 4) nr = 4;
+  if (const char* e = std::getenv("DICEY_KF_COPIES")) nr = (u32)std::min(4, std::max(1, std::atoi(e)));  // experiments
   kf.k = k;
+  kf.nr = nr;
   for (u32 r = 0; r < 4; ++r) kf.s[r] = (nr > 1 && r < nr) ? (r * (bits - 9) + (nr - 1) / 2) / (nr - 1) : 0u;
   kf.pick = 0;
   for (u32 t = 0; t < 32; ++t) {
@@ -336,8 +338,8 @@ static int build_filter(dg_index* ix, KFilter& kf, u32 k, const uint2* tab, u32*
   if (bits < 17 || std::getenv("DICEY_NO_KMER_FILTER")) return DG_OK;  // a table this small is cache resident anyway
   const u64 entries = 1ULL << bits, nwords = entries >> 5;
   kf_layout(kf, k);
-  u32 nr = (bits - 9 + 7) / 8 + 1;
-  if (nr > 4) nr = 4;
+  const u32 nr = kf.nr;
+  kf.nr = 0;  // until the copies exist
   static const bool generic = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
   const u32 TB = 256;
   for (u32 r = 0; r < nr; ++r) {

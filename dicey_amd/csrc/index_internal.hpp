@@ -18,6 +18,7 @@ struct dg_index {
   hipEvent_t ev[9] = {nullptr};  // [8]: end of the flat distance-1 kernel
   uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
   uint64_t hit_cap_hint = 0;
+  uint32_t surv_cap_log2_hint = 0;  // survivor-queue capacity per shard (log2) that was enough for the previous batch
   // dg_hunt_device: the (offsets pointer, count, bytes) of the previous call and the longest query it held; a repeated
   // call skips reading the offsets back, and k_prepare reports any query longer than this bound (hunt.hip)
   const void* last_qoff = nullptr;

@@ -1421,6 +1421,42 @@ __global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Count
   const u64 q = lf.qs >> 1;
   const GidInfo gi = b.ginfo[lf.qs];  // one 16-byte record: length, and the packed query when it has no N and <= 32 nt
   const u32 m = gi.m;
+  if (lf.nops != LEAF_EXPLICIT && lf.nops <= DMAX && (gi.d_win & 256) && m + lf.nops <= 32) {
+    // the usual leaf: the 2-bit packed query with its recorded operations applied right to left (positions refer to the
+    // unchanged part left of the previous operation), then 2 -> 3 bits per character
+    u64 x = gi.qpk;
+    u32 len = m;
+    for (u32 k = 0; k < lf.nops; ++k) {
+      const u32 w = lf.ops[k], pos = w >> 4, kind = (w >> 2) & 3u, c = w & 3u;
+      const u32 R = len - pos;
+      const u64 low = x & ((1ULL << (2 * R)) - 1);
+      if (kind == OP_D) {
+        x = low | ((x >> (2 * R + 2)) << (2 * R));
+        --len;
+      } else if (kind == OP_S) {
+        x = (x & ~(3ULL << (2 * R))) | ((u64)c << (2 * R));
+      } else {
+        x = low | ((u64)c << (2 * R)) | ((x >> (2 * R)) << (2 * R + 2));
+        ++len;
+      }
+    }
+    u64 hi = 0, lo = 0;
+    for (u32 i = 0; i < len; ++i) {
+      const u32 c2 = (u32)(x >> (2 * (len - 1 - i))) & 3u;
+      hi = (hi << 3) | (lo >> 61);
+      lo = (lo << 3) | (u64)(c2 + 1 + (c2 == 3));  // ASCII rank + 1: A1 C2 G3 T5
+    }
+    p128_shl(hi, lo, 128 - 3 * len);
+    PLeaf p;
+    p.hi = hi;
+    p.lo = lo;
+    p.len = len;
+    p.sa_lo = lf.lo;
+    p.sa_hi = lf.hi;
+    p.qs = lf.qs;
+    out[grp_off[lf.qs] + lf.slot] = p;
+    return;
+  }
   LeafReader r;
   if (lf.nops == LEAF_EXPLICIT) r.init_any(b, nullptr, 0, lf);
   else if ((gi.d_win & 256) && m <= 32) r.init_packed(gi.qpk, m, lf);
@@ -2332,7 +2368,7 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
   u32 lo_r = 0, hi_r = a.nseq - 1;
   while (lo_r < hi_r) {
     u32 mid = (lo_r + hi_r + 1) >> 1;
-    if (a.cum[mid] <= loc) lo_r = mid;
+    if (a.cum[mid] <= loc) lo_r = mid;  // (staging the starts in LDS behind a barrier was slower: 91 -> 105 us)
     else hi_r = mid - 1;
   }
   const u32 ref = lo_r;
@@ -2504,6 +2540,159 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     qa8[len >> 3] = wq;
   }
   chrpos += lead;
+  out.start = chrpos + 1;
+  out.aln_len = (u16)len;
+  a.hits[h] = out;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Verify for queries of any length (the ones above MAX_QLEN, whose full matrix no lane could hold): the same banded matrix
+// as k_verify_band (its argument does not depend on the length), 6d + 1 <= 25 diagonals in registers, the trace — one
+// 64-bit word per row — in a workspace in HBM, query and window read where they lie.  One lane per hit; this is the rare
+// path (a primer is 18-30 nt), built for correctness.
+template <int WB>
+__global__ void __launch_bounds__(64) k_verify_long(FmView f, Batch b, VerifyArgs a, Counters* ctr, u64* trace, u32 rows_cap) {
+  u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 nh = *a.nhits;
+  if (ctr->overflow || nh > a.hit_cap || h >= nh) return;
+  const HitSeed sd = a.seeds[h];
+  const u64 q = sd.qs >> 1;
+  const u32 strand = sd.qs & 1;
+  const u8* qseq = (strand ? b.rv : b.fw) + b.qoff[q];
+  const u32 n = b.qlen[q];
+  const u64 loc = sd.pos;
+  const u32 mlen = sd.len;
+  u32 lo_r = 0, hi_r = a.nseq - 1;
+  while (lo_r < hi_r) {
+    u32 mid = (lo_r + hi_r + 1) >> 1;
+    if (a.cum[mid] <= loc) lo_r = mid;
+    else hi_r = mid - 1;
+  }
+  const u32 ref = lo_r;
+  u32 chrpos = (u32)(loc - a.cum[ref]);
+  const u32 d = b.indel ? b.qdist[q] : 0u;
+  u64 pre = d, post = d;
+  if (pre > loc) pre = loc;
+  if (loc + mlen + post > f.n) post = f.n - loc - mlen;
+  u32 pre_eff = 0;
+  for (u32 i = 1; i <= pre; ++i) {
+    if (f.text[loc - i] == '\n') break;
+    pre_eff = i;
+  }
+  u32 post_eff = 0;
+  for (u32 i = 0; i < post; ++i) {
+    if (f.text[loc + mlen + i] == '\n') break;
+    post_eff = i + 1;
+  }
+  const u8* g = f.text + (loc - pre_eff);
+  const u32 mg = pre_eff + mlen + post_eff;
+  if (pre_eff < chrpos) chrpos -= pre_eff;  // hunter.h:382 (strict <)
+  char* ra = a.refalign + h * a.stride;
+  char* qa = a.queryalign + h * a.stride;
+  dg_hit out;
+  out.chr = ref;
+  out.query = (u32)q;
+  out.strand = strand ? '-' : '+';
+  out.reserved = 0;
+  atomicAdd(&ctr->win_bytes[blockIdx.x & (NSHARD - 1)], (unsigned long long)(pre + mlen + post));
+  if (!b.indel) {  // hunter.h:79-88,404-405
+    int sc = 0;
+    u32 k = mg < n ? mg : n;
+    for (u32 i = 0; i < k; ++i) sc -= (g[i] != ascii_of(qseq[i]));
+    for (u32 i = 0; i < mg; ++i) ra[i] = (char)g[i];
+    for (u32 i = 0; i < n; ++i) qa[i] = (char)ascii_of(qseq[i]);
+    out.score = sc;
+    out.start = chrpos + 1;
+    out.aln_len = (u16)(mg > n ? mg : n);
+    a.hits[h] = out;
+    return;
+  }
+  constexpr int NEG = -100000;
+  const int dm = (int)mg - (int)n + 2 * (int)d;  // k = c - r + dm, see k_verify_band
+  int s[WB];
+#pragma unroll
+  for (int k = 0; k < WB; ++k) {
+    const int c = k - dm;
+    s[k] = (c < 0 || c > (int)n) ? NEG : -c;
+  }
+  u64* tr = trace + h * (u64)rows_cap;
+  for (u32 row = 1; row <= mg; ++row) {
+    const u32 gc = g[row - 1];
+    const int c0 = (int)row - dm;
+    u64 bits = 0;
+    int left = NEG;
+#pragma unroll
+    for (int k = 0; k < WB; ++k) {
+      const int c = c0 + k;
+      const u32 qc = (c >= 1 && c <= (int)n) ? (u32)ascii_of(qseq[c - 1]) : 0u;
+      const int up = k + 1 < WB ? s[k + 1] : NEG;
+      const int dsc = s[k] + (gc == qc ? 0 : -1);
+      const int vsc = up + (c == (int)n ? 0 : -1);
+      const int hsc = left - 1;
+      int best = dsc > vsc ? dsc : vsc;
+      best = best > hsc ? best : hsc;
+      const u64 code = best == hsc ? 1ULL : (best == vsc ? 2ULL : 0ULL);
+      const int val = c < 0 ? NEG : (c == 0 ? 0 : (c > (int)n ? NEG : best));
+      s[k] = val;
+      left = val;
+      bits |= code << (2 * k);
+    }
+    if (row < rows_cap) tr[row] = bits;
+  }
+  int fin = NEG;
+#pragma unroll
+  for (int k = 0; k < WB; ++k)
+    if (k == 2 * (int)d) fin = s[k];
+  out.score = fin;
+  // traceback, columns produced last-to-first and written from the end of the row buffers
+  const u32 S = a.stride;
+  u32 tl = 0;
+  u32 row = mg, col = n;
+  while (row > 0 || col > 0) {
+    u32 code;
+    if (col == 0) code = 2u;
+    else if (row == 0) code = 1u;
+    else {
+      const int k = (int)col - (int)row + dm;
+      code = (k >= 0 && k < WB && row < rows_cap) ? (u32)(tr[row] >> (2 * k)) & 3u : 1u;
+    }
+    char r0, r1;
+    if (code == 1) {
+      --col;
+      r0 = '-';
+      r1 = (char)ascii_of(qseq[col]);
+    } else if (code == 2) {
+      --row;
+      r0 = (char)g[row];
+      r1 = '-';
+    } else {
+      --row;
+      --col;
+      r0 = (char)g[row];
+      r1 = (char)ascii_of(qseq[col]);
+    }
+    ++tl;
+    ra[S - tl] = r0;
+    qa[S - tl] = r1;
+  }
+  // hunter.h:391-401 + _trailGap :69-77: drop leading columns whose query row is a gap (each advances chrpos) and the
+  // trailing run of such columns
+  const u32 base = S - tl;
+  u32 lead = 0;
+  while (lead < tl && qa[base + lead] == '-') ++lead;
+  u32 last = tl - 1;
+  for (u32 j = 0; j < tl; ++j)
+    if (qa[base + j] != '-') last = j;
+  const u32 stop = last + 1;
+  u32 len = 0;
+  for (u32 j = 0; j < stop; ++j) {
+    if (j < lead) continue;
+    char x = ra[base + j], y = qa[base + j];
+    ra[len] = x;
+    qa[len] = y;
+    ++len;
+  }
+  chrpos += lead < stop ? lead : stop;
   out.start = chrpos + 1;
   out.aln_len = (u16)len;
   a.hits[h] = out;
@@ -2687,7 +2876,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
                      uint64_t* group_counts, const uint8_t* h_qbytes, const uint64_t* h_qoff) {
   if (nseq == 0) return fail(DG_EINVAL, "no reference sequences");
   const bool indel = !p->hamming;
-  if (maxlen > MAX_QLEN) return fail(DG_ELIMIT, "query of %u nt exceeds the supported maximum of %u", maxlen, MAX_QLEN);
+  // queries above MAX_QLEN take the banded long-query verify (k_verify_long); alignment lengths are 16-bit in dg_hit
+  static constexpr u32 LONG_QLEN_MAX = 30000;
+  if (maxlen > LONG_QLEN_MAX) return fail(DG_ELIMIT, "query of %u nt exceeds the supported maximum of %u", maxlen, LONG_QLEN_MAX);
   u32 dmax_eff = p->distance;
   if (maxlen >= 1 && dmax_eff >= maxlen) dmax_eff = maxlen - 1;
   if (dmax_eff > DMAX) return fail(DG_ELIMIT, "distance %u exceeds the supported maximum of %u", p->distance, DMAX);
@@ -2749,7 +2940,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   static const bool no_fast1 = std::getenv("DICEY_NO_FAST1") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
   Batch b;
-  b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen <= 31 && maxlen > ix->view.K && ngrp * (u64)maxlen * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
+  b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen > ix->view.K && ngrp * (u64)std::min(maxlen, 31u) * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
   b.fast2K = (!no_fast1 && indel && dmax_eff == 2 && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
@@ -2850,7 +3041,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (b.fastK) {  // distance 1: the flat kernel takes every query that qualifies, k_search (one lane per strand) the rest
         static const bool per_op = std::getenv("DICEY_FLAT1_PER_OP") != nullptr;  // the lane-per-operation form (A/B runs)
         if (per_op) {
-          const u32 ipg = indel ? maxlen * 8u : maxlen * 4u;
+          const u32 ipg = std::min(maxlen, 31u) * (indel ? 8u : 4u);  // longer queries stay with k_search
           const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
           if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
           else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);
@@ -2858,7 +3049,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           // probe + finish in one kernel unless DICEY_FLAT1_SPLIT asks for the two-kernel form (r02 A/B: 0.25 ms fused, 0.21 +
           // 0.19 ms split — both halves run at the memory system's random-access rate, cutting the chain gained nothing)
           static const bool fused = std::getenv("DICEY_FLAT1_SPLIT") == nullptr;
-          const u32 ipg = maxlen, magic = (65536u + ipg - 1) / ipg;
+          const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg;  // longer queries stay with k_search
           const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
           if (fused) {
             if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
@@ -2975,7 +3166,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_band<7>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else if (!no_band && maxlen <= 32 && dmax_eff == 2 && (stride & 7) == 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_band<13>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
-      else if (maxlen <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 24>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      else if (maxlen > MAX_QLEN) {
+        const u32 rows_cap = maxlen + 3 * dmax_eff + 2;
+        const u64 tbytes = (hit_cap + 1) * (u64)rows_cap * 8;
+        if (tbytes > (64ull << 30))
+          return fail(DG_ELIMIT, "a batch with a %u nt query and room for %llu hits needs %llu GB of trace; pass long queries in smaller batches",
+                      maxlen, (unsigned long long)hit_cap, (unsigned long long)(tbytes >> 30));
+        DG_TRY(ws[WS_DP].reserve(tbytes + 64));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_long<6 * DMAX + 1>), dim3(ceil_div(hit_cap, 64)), dim3(64), 0, st, ix->view, b, va, ctr,
+                           ws[WS_DP].as<u64>(), rows_cap);
+      } else if (maxlen <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 24>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else if (maxlen <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 32>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else if (cells <= 32 * 160) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);

@@ -107,9 +107,27 @@ def test_hunt_edge_cases(gpu_small, small_genome):
 def test_unsupported_envelope_fails_loudly(gpu_small, small_genome):
     import dicey_amd
     with pytest.raises(dicey_amd.DgError):
-        gpu_small.hunt(["ACGT" * 64], small_genome["seqlen"], distance=1)  # 256 nt: above the 255 nt this build verifies
+        gpu_small.hunt(["ACGT" * 8000], small_genome["seqlen"], distance=1)  # 32 000 nt: alignment lengths are 16-bit
     with pytest.raises(dicey_amd.DgError):
         gpu_small.hunt(["ACGTACGTACGT"], small_genome["seqlen"], distance=30)
+
+
+def test_long_queries_are_answered_next_to_short_ones(gpu_small, small_genome):
+    """queries above 255 nt (round 1 failed their whole batch): banded verify with the trace in HBM; the short queries of
+    the same batch keep their answers"""
+    g = small_genome
+    orc = O.Index(g["fm9"])
+    s = g["seqs"]
+    long1 = s[0][1000:1256]                                   # 256 nt, exact
+    long2 = s[1][200:500] + "A" + s[1][500:1100]              # 901 nt with an insertion
+    long3 = s[2][3000:3300][:150] + s[2][3000:3300][151:]     # 299 nt with a deletion
+    long4 = s[0][7000:7600]
+    long4 = long4[:300] + ("C" if long4[300] != "C" else "G") + long4[301:]  # 600 nt with a substitution
+    qs = [s[0][40:60], long1, s[1][900:925], long2, long3, "ACGTACGTACGTACGTACGT", long4, s[2][10:40]]
+    _compare(gpu_small, orc, g, qs, distance=1)
+    _compare(gpu_small, orc, g, qs, distance=1, hamming=True)
+    _compare(gpu_small, orc, g, qs, distance=0)
+    _compare(gpu_small, orc, g, [long1, s[0][40:60]], distance=2, hamming=True)  # the cap fires for the long one: host enumeration
 
 
 def test_former_envelope_is_answered(gpu_small, small_genome):

@@ -459,6 +459,16 @@ DG_DEV bool cand1(u64 qpk, u32 m, u32 pos, u32 op, u64& s_pk, u32& mlen, u32& op
   // insertion one position further left (which exists from the second position on)
   return pos < m && !(pos >= 2 && c == old);
 }
+// Second look at a survivor that is longer than the long filter's order: its FIRST K2 characters must occur as well.  The two
+// windows overlap in all but (length - K2) characters, yet on a 3.1 Gb genome three of four random survivors end here — for one
+// line instead of the table entry and 3-5 Occ lines.  R = characters right of the (last) edit, for the choice of the copy.
+DG_DEV bool head_window_occurs(const FmView& f, u64 s_pk, u32 mlen, u32 R) {
+  const u32 K2 = f.kf2.k;
+  if (!f.kf2.nr || mlen <= K2) return true;
+  const u32 cut = mlen - K2;
+  const u32 t = R > cut ? R - cut : 0u;
+  return kf_present(f.kf2, (s_pk >> (2 * cut)) & ((1ULL << (2 * K2)) - 1), t < K2 ? t : K2 - 1);
+}
 template <bool INDEL>
 __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o, u32 ipg, u32 magic) {
   __shared__ u16 q_ent[2048];  // lane | operation << 8
@@ -520,7 +530,7 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
   const u32 shard = blockIdx.x & (NSHARD - 1);
   if (threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
   const u32 qn = q_n;
-  u32 steps = 0, nlook = 0;
+  u32 steps = 0, nlook = 0, nhead = 0;
   for (u32 e0 = 0; e0 < qn; e0 += 256) {
     if (e0 + (threadIdx.x & ~63u) >= qn) break;  // this wavefront has no survivor to work on
     const u32 e = e0 + threadIdx.x;
@@ -532,9 +542,14 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
       u64 s_pk;
       u32 mlen, ow;
       (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
-      const uint2 iv = f.ktab[s_pk & kmask];
-      ++nlook;
-      u32 lo = iv.x, hi = iv.y;
+      u32 lo = 0, hi = 0;
+      nhead += (K2 && mlen > K2);
+      if (head_window_occurs(f, s_pk, mlen, raw.z - pos)) {
+        const uint2 iv = f.ktab[s_pk & kmask];
+        ++nlook;
+        lo = iv.x;
+        hi = iv.y;
+      }
       u64 rs = s_pk >> (2 * K);
       u32 n = mlen - K;
       while (n && lo < hi) {
@@ -563,10 +578,12 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
   for (int off = 32; off > 0; off >>= 1) {
     steps += __shfl_xor(steps, off);
     nlook += __shfl_xor(nlook, off);
+    nhead += __shfl_xor(nhead, off);
   }
   if (lane == 0) {
     if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+    if (nhead) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nhead);
   }
 }
 
@@ -996,10 +1013,13 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
         pair_of(w0 + (ent & 511u), m, p2, p1);
         apply_edit(qpk, m, p1, (ent >> 9) & 7u, s1, l1, w1);
         apply_edit(s1, l1, p2, (ent >> 12) & 7u, s2, l2, w2);
-        const uint2 iv = f.ktab[s2 & kmask];
-        ++nlook;
-        lo = iv.x;
-        hi = iv.y;
+        nprobe += (K2 && l2 > K2);
+        if (head_window_occurs(f, s2, l2, l1 - p2)) {
+          const uint2 iv = f.ktab[s2 & kmask];
+          ++nlook;
+          lo = iv.x;
+          hi = iv.y;
+        }
         u64 rs = s2 >> (2 * K);
         u32 nr = l2 - K;
         while (nr && lo < hi) {
@@ -1577,6 +1597,7 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
   __shared__ unsigned long long kh[SELCAP], kl[SELCAP];
   __shared__ u16 ix[SELCAP];  // bits 0-9 position in the group, bits 10-15 string length
   __shared__ u32 s_minlen, s_w[2];
+  __shared__ u32 bm[128];  // 4096-bit membership sketch of the group's keys: most windows are turned away without a search
   const u64 g = blockIdx.x;
   if (ctr->overflow) return;
   const u64 g0 = grp_off[g];
@@ -1602,7 +1623,9 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
     s_minlen = 0xFFFFFFFFu;
     s_w[1] = 0;  // stays 0 when the workgroup is a single wavefront
   }
+  for (u32 i = threadIdx.x; i < 128; i += blockDim.x) bm[i] = 0;
   __syncthreads();
+  auto sketch = [](u64 h, u64 l) -> u32 { return (((u32)h ^ (u32)(h >> 32) ^ (u32)l ^ (u32)(l >> 32)) * 0x9E3779B1u) >> 20; };
   for (u32 i = threadIdx.x; i < n2; i += blockDim.x) {
     if (i < k) {
       const PLeaf a = G[g0 + i];
@@ -1610,6 +1633,8 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
       kl[i] = a.lo;
       ix[i] = (u16)(i | (a.len << 10));
       atomicMin(&s_minlen, a.len);
+      const u32 hb = sketch(a.hi, a.lo);
+      atomicOr(&bm[hb >> 5], 1u << (hb & 31));
     } else {
       kh[i] = ~0ULL;
       kl[i] = ~0ULL;
@@ -1658,6 +1683,8 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
             p128_shl(h, l, 3 * o);
             h &= mh;
             l &= ml;
+            const u32 hb = sketch(h, l);
+            if (!((bm[hb >> 5] >> (hb & 31)) & 1u)) continue;
             u32 lo = 0, hi = k;
             while (lo < hi) {
               const u32 mid = (lo + hi) >> 1;

@@ -145,7 +145,7 @@ typedef struct {
   const void* d_queryalign; /* nhits * aln_stride bytes */
   uint64_t ctr_filter_probes; /* K-mer presence-filter bits tested (one 4-byte word each); ctr_tab_reads counts the table
                                * entries actually read, i.e. the probes that found their K-mer present */
-  double ms_search_flat;      /* part of ms_search spent in the flat distance-1 kernel (k_search1); 0 when it did not run */
+  double ms_search_flat;      /* part of ms_search spent in the flat kernel (k_search1p at distance 1, k_search2p at edit distance 2); 0 when none ran */
 } dg_hunt_result;
 
 /* Host-buffer entry point: queries are raw bytes as read from the FASTA/argv (any case), concatenated.

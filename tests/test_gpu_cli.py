@@ -116,3 +116,33 @@ def test_json_strings_with_special_characters(tmp_path):
         assert r.stdout.decode() == _oracle_json(g, qs, qn, **kw)
     if os.path.exists(O.REF_JSON):
         assert O.ref_json_in_use()
+
+
+def test_baseline_config0_single_18mer_hamming0_on_a_4_6_mb_genome(tmp_path):
+    """BASELINE.json configs[0] / SURVEY.md §8(d) C1: `dicey hunt -n -d 0 -g <genome> <18-mer>` on one 4.64 Mb sequence (the
+    E. coli K-12 size class; no real genome is available offline, so i.i.d. ACGT with a planted 5 kb duplication),
+    18-mer = T[1000000..1000018).  Index by `dicey index`, JSON byte-identical to the oracle, coordinates checked directly."""
+    import json
+    import random
+    rng = random.Random(4641652)
+    n = 4641652
+    seq = bytearray(rng.choices(b"ACGT", k=n))
+    seq[3000000:3005000] = seq[999000:1004000]  # the 18-mer occurs twice
+    seq = seq.decode()
+    fa = tmp_path / "ecoli_like.fa.gz"
+    with gzip.open(fa, "wt", compresslevel=1) as f:
+        f.write(">U00096.3 synthetic\n")
+        for i in range(0, n, 80):
+            f.write(seq[i:i + 80])
+            f.write("\n")
+    r = subprocess.run([DICEY, "index", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    q = seq[1000000:1000018]
+    r = subprocess.run([DICEY, "hunt", "-n", "-d", "0", "-g", str(fa), q], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    g = {"fa": str(fa), "fm9": str(tmp_path / "ecoli_like.fa.fm9"), "seqlen": [n + 1], "names": ["U00096.3"]}
+    assert r.stdout == _oracle_json(g, [q], [""], distance=0, hamming=True)
+    doc = json.loads(r.stdout)
+    starts = sorted((h["chr"], h["start"], h["strand"]) for h in doc["data"])
+    want = [("U00096.3", 1000001, "+"), ("U00096.3", 3001001, "+")]
+    assert [s for s in starts if s[2] == "+"] == want, starts

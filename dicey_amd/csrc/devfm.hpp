@@ -121,6 +121,15 @@ DG_DEV KfCopy kf_copy(const KFilter& kf, u32 t) {
     }
   return c;
 }
+// address of the word that holds a code's bit (and the bit's number): lanes that ask about several codes compute all the
+// addresses first and load them back to back — a test per code with its own branch serialises the loads (r02: every probe of
+// the flat kernels waited for the previous one, `s_waitcnt vmcnt(0)` after each)
+DG_DEV const u32* kf_word(const KfCopy& c, u64 code, u32& bit) {
+  const u32 inl = (u32)(code >> c.s) & 511u;
+  const u64 line = (code & ((1ULL << c.s) - 1)) | ((code >> (c.s + 9)) << c.s);
+  bit = inl & 31u;
+  return c.base + line * 16 + (inl >> 5);
+}
 DG_DEV bool kf_test(const KfCopy& c, u64 code) {
   const u32 inl = (u32)(code >> c.s) & 511u;
   const u64 line = (code & ((1ULL << c.s) - 1)) | ((code >> (c.s + 9)) << c.s);

@@ -499,22 +499,33 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
         const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
         const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
         const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+        // all addresses first, then the eight loads back to back, then the bits
+        const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
+        const u32* addr[NOPS];
+        u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
 #pragma unroll
         for (u32 op = 0; op < NOPS; ++op) {
           u64 s_pk;
           u32 mlen, ow;
-          if (cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow)) {
-            bool pass = true;
-            if (K2 && mlen >= K2) {
-              pass = kf_test(c2, s_pk & mask2);
-              ++nprobe;
-            } else if (f.kf.nr) {
-              pass = kf_test(c1, s_pk & kmask);
-              ++nprobe;
-            }
-            mask8 |= (u32)pass << op;
-          }
+          const bool ok = cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow);
+          const bool use2 = K2 && mlen >= K2;
+          const bool pr = ok && (use2 || f.kf.nr);
+          KfCopy c;
+          c.base = use2 ? c2.base : c1.base;
+          c.s = use2 ? c2.s : c1.s;
+          const u32* a = kf_word(c, use2 ? s_pk & mask2 : s_pk & kmask, bit[op]);
+          addr[op] = pr ? a : idle;
+          valid |= (u32)ok << op;
+          probe |= (u32)pr << op;
         }
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
+          mask8 |= (((valid >> op) & 1u) & present) << op;
+        }
+        nprobe = (u32)__popc(probe);
       }
     }
   }
@@ -970,26 +981,36 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
           apply_edit(qpk, m, p1, op1, s1, l1, w1);
           const u32 posp = ins1 ? p1 : p1 - 1;  // characters left of the first operation
           u32 mask8 = 0;
+          // all addresses first, then the eight loads back to back, then the bits
+          const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
+          const u32* addr[8];
+          u32 bit[8], word[8], valid = 0, probe = 0;
 #pragma unroll
           for (u32 op2 = 0; op2 < 8; ++op2) {
             bool v2 = true;
             if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
             if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
-            if (v2) {
-              u64 s2;
-              u32 l2, w2;
-              apply_edit(s1, l1, p2, op2, s2, l2, w2);
-              bool pass = true;
-              if (K2 && l2 >= K2) {
-                pass = kf_test(c2, s2 & mask2);
-                ++nprobe;
-              } else if (f.kf.nr) {
-                pass = kf_test(c1, s2 & kmask);
-                ++nprobe;
-              }
-              mask8 |= (u32)pass << op2;
-            }
+            u64 s2;
+            u32 l2, w2;
+            apply_edit(s1, l1, p2, op2, s2, l2, w2);
+            const bool use2 = K2 && l2 >= K2;
+            const bool pr = v2 && (use2 || f.kf.nr);
+            KfCopy c;
+            c.base = use2 ? c2.base : c1.base;
+            c.s = use2 ? c2.s : c1.s;
+            const u32* a = kf_word(c, use2 ? s2 & mask2 : s2 & kmask, bit[op2]);
+            addr[op2] = pr ? a : idle;
+            valid |= (u32)v2 << op2;
+            probe |= (u32)pr << op2;
           }
+#pragma unroll
+          for (u32 op2 = 0; op2 < 8; ++op2) word[op2] = *addr[op2];
+#pragma unroll
+          for (u32 op2 = 0; op2 < 8; ++op2) {
+            const u32 present = ((probe >> op2) & 1u) ? (word[op2] >> bit[op2]) & 1u : 1u;
+            mask8 |= (((valid >> op2) & 1u) & present) << op2;
+          }
+          nprobe += (u32)__popc(probe);
           while (mask8) {
             const u32 op2 = (u32)__ffs((int)mask8) - 1u;
             mask8 &= mask8 - 1;

@@ -510,23 +510,29 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
     // 288 GB of HBM are for
     u32 K = 8;
     while (K < 16 && (1ULL << (2 * K)) < n) ++K;
-    // What the rest of the HBM is spent on (DESIGN.md "long filter"): a presence filter of order K2 = K + 3 in four
-    // permuted copies (4 x 34 GB at K2 = 19) in front of everything — a random 19-mer of a 3.1 Gb genome occurs with
-    // p = 0.011, a 16-mer with 0.51, a 17-mer with 0.17.  When the device has no room for it, one character more for the
-    // table instead (4x the table, 137 GB at K = 17) if that fits.
+    // What the rest of the HBM is spent on (DESIGN.md "long filter"): one character more for the table when the device has
+    // room (K = 17, 137 GB, on a 3.1 Gb genome: one interval extension fewer per surviving string), and a presence filter of
+    // order K2 = ceil(log4 n) + 2 in four permuted copies (4 x 8.6 GB at K2 = 18) in front of everything — a random 18-mer of
+    // a 3.1 Gb genome occurs with p = 0.04, a 16-mer with 0.51, a 17-mer with 0.17.  r02 measured K / K2 = 16/19, 16/18 and
+    // 17/18 on the bench workloads; 17/18 is the fastest at both distances.
     u32 K2 = 0;
     {
       size_t free_b = 0, total_b = 0;
       const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-      const u64 tab_b = 8ULL << (2 * K), f2_b = 4 * ((1ULL << (2 * (K + 3))) >> 3), slack = (u64)std::min<u64>(48ULL << 30, n * 16 + (64u << 20));
-      if (have && free_b > tab_b + f2_b + slack) K2 = K + 3;
-      else if (have && (1ULL << (2 * K)) < n * 2 && free_b > ((8ULL << (2 * (K + 1))) + slack)) ++K;
+      const u64 slack = (u64)std::min<u64>(48ULL << 30, n * 16 + (64u << 20));
+      const u64 f2_b = 4 * ((1ULL << (2 * (K + 2))) >> 3);
+      u64 need = (8ULL << (2 * K)) + slack;
+      if (have && free_b > need + f2_b) {
+        K2 = K + 2;
+        need += f2_b;
+      }
+      if (have && (1ULL << (2 * K)) < n * 2 && free_b > need - (8ULL << (2 * K)) + (8ULL << (2 * (K + 1)))) ++K;
     }
     if (const char* ek = std::getenv("DICEY_KMER_K")) {  // tuning knobs: force the table order (8..17) / the long filter's (0 = none)
       int v = std::atoi(ek);
       if (v >= 8 && v <= 17) {
         K = (u32)v;
-        if (K2) K2 = K + 3;
+        if (K2 && K2 <= K) K2 = K + 1;
       }
     }
     if (const char* ek = std::getenv("DICEY_KMER_K2")) {

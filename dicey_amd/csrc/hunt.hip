@@ -480,7 +480,8 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
   }
   __syncthreads();
   // lane -> (group, position): one division per workgroup, a multiplication per lane (exact for the < 512 values it sees)
-  const u32 first = blockIdx.x * 256u;
+  const u32 TBX = blockDim.x;  // 64, 128 or 256
+  const u32 first = blockIdx.x * TBX;
   const u32 g_first = first / ipg, r_first = first - g_first * ipg;
   const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
   const u64 kmask = (1ULL << (2 * K)) - 1;
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
   if (threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
   const u32 qn = q_n;
   u32 steps = 0, nlook = 0, nhead = 0;
-  for (u32 e0 = 0; e0 < qn; e0 += 256) {
+  for (u32 e0 = 0; e0 < qn; e0 += TBX) {
     if (e0 + (threadIdx.x & ~63u) >= qn) break;  // this wavefront has no survivor to work on
     const u32 e = e0 + threadIdx.x;
     if (e < qn) {
@@ -3098,7 +3099,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           // 0.19 ms split — both halves run at the memory system's random-access rate, cutting the chain gained nothing)
           static const bool fused = std::getenv("DICEY_FLAT1_SPLIT") == nullptr;
           const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg;  // longer queries stay with k_search
-          const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
+          static const u32 tb1 = std::getenv("DICEY_FLAT1_TB") ? (u32)std::atoi(std::getenv("DICEY_FLAT1_TB")) : 256u;
+          const u32 TB1 = fused && (tb1 == 64 || tb1 == 128) ? tb1 : TB;
+          const dim3 g1(ceil_div(ngrp * ipg, TB1)), b1(TB1);
           if (fused) {
             if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<false>), g1, b1, 0, st, ix->view, b, so, ipg, magic);

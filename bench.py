@@ -540,14 +540,16 @@ def main():
             survey_bytes = ext * 2 * avg_l * 24 + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_k_search.json")
-            if os.path.exists(tpath):
+            # HBM bytes per launch of this kernel on this workload from the committed PMC passes (tools/summarize_profile.py,
+            # tools/prof_cfg.sh): FETCH_SIZE corrected by the calibration factor + WRITE_SIZE
+            import glob
+            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_k_search*.json"))):
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("workload") == f"{units}x{a.qlen}mer_d{distance}_n{int(a.genome_size)}_{a.genome}" and tj.get("kernel") == kernel:
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
-                    traffic = None
+                    pass
             out = dict(base_out)
             out.update({
                 "value": world * nq * a.steps / elapsed, "ms_per_step": elapsed / a.steps * 1e3, "dtype": "u32",

@@ -24,6 +24,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <type_traits>
 
 #include "hunt_internal.hpp"
 #include "iupac.hpp"
@@ -2361,7 +2362,11 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
 template <int WB>
 __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyArgs a, Counters* ctr) {
   constexpr int MAXROW = 32 + 3 * 2 + 2;
-  __shared__ u32 tr_lds[MAXROW * 128];  // [row][lane]: 2 bits per diagonal
+  using TR = typename std::conditional<(WB <= 8), u16, u32>::type;
+  __shared__ TR tr_lds[MAXROW * 128];  // [row][lane]: 2 bits per diagonal
+  // window bytes [0,40) and query codes [40,72) of every lane: the traceback and the row-writing pass index them with
+  // per-lane positions (a select chain over packed registers cost 15 instructions per character)
+  __shared__ __align__(8) u8 gq_lds[128 * 72];
   u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 nh = *a.nhits;
   if (ctr->overflow || nh > a.hit_cap || h >= nh) return;
@@ -2436,6 +2441,25 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
   const u32 skip = (u32)pre - pre_eff;         // genomicseq starts at byte `skip` of the maximal window
   const u32 mg = pre_eff + mlen + post_eff;    // rows
   if (pre_eff < chrpos) chrpos -= pre_eff;     // hunter.h:382 (strict <)
+  // genomicseq from byte 0 (gsh), the query codes with 7 = "outside" behind the last character (qwm); both also in LDS
+  u64 gsh[5], qwm[QW];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) gsh[i] = skip ? (gw[i] >> (8 * skip)) | (gw[i + 1] << (64 - 8 * skip)) : gw[i];
+#pragma unroll
+  for (int i = 0; i < QW; ++i) {
+    const int keep = (int)n - 8 * i;  // characters of the query in this word
+    const u64 km = keep >= 8 ? ~0ULL : (keep <= 0 ? 0ULL : (1ULL << (8 * keep)) - 1);
+    qwm[i] = (qw[i] & km) | (0x0707070707070707ULL & ~km);
+  }
+  u8* const lds_g = gq_lds + threadIdx.x * 72;
+  u8* const lds_q = lds_g + 40;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) reinterpret_cast<u64*>(lds_g)[i] = gsh[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) reinterpret_cast<u64*>(lds_q)[i] = qwm[i];
+  constexpr u64 ASCII_LUT = 0x4E54474341ULL;  // code 0..4 -> 'A','C','G','T','N'; codes 5..7 -> 0
+  auto g_ch = [&](u32 i) -> u32 { return lds_g[i]; };                                     // genomicseq[i]
+  auto q_ch = [&](u32 i) -> u32 { return (u32)(ASCII_LUT >> (8 * lds_q[i])) & 255u; };    // ASCII of query character i < n
   char* ra = a.refalign + h * a.stride;
   char* qa = a.queryalign + h * a.stride;
   dg_hit out;
@@ -2450,12 +2474,12 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     // hunter.h:79-88,404-405: score = -(mismatches), alignment rows are the raw strings (mg == mlen == n here)
     int sc = 0;
     const u32 k = mg < n ? mg : n;
-    for (u32 i = 0; i < k; ++i) sc -= (gw_at(skip + i) != q_at(i));
+    for (u32 i = 0; i < k; ++i) sc -= (g_ch(i) != q_ch(i));
     u64 wr = 0, wq = 0;
     const u32 top = mg > n ? mg : n;
     for (u32 i = 0; i < top; ++i) {
-      if (i < mg) wr |= (u64)gw_at(skip + i) << (8 * (i & 7));
-      if (i < n) wq |= (u64)q_at(i) << (8 * (i & 7));
+      if (i < mg) wr |= (u64)g_ch(i) << (8 * (i & 7));
+      if (i < n) wq |= (u64)q_ch(i) << (8 * (i & 7));
       if ((i & 7) == 7 || i + 1 == top) {
         ra8[i >> 3] = wr;
         qa8[i >> 3] = wq;
@@ -2485,35 +2509,56 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     if (k < 8) qlo |= v << (8 * k);
     else qhi |= v << (8 * (k - 8));
   }
-  u32* tr = tr_lds + threadIdx.x;
-  for (u32 row = 1; row <= mg; ++row) {
-    const u32 gc = gw_at(skip + row - 1);
-    const int c0 = (int)row - dm;
-    u32 bits = 0;
-    int left = NEG;
+  // the character that enters the window after row r is q[r + WB - 1 - dm]: the query codes shifted left by WB - dm bytes
+  // put it at byte (r - 1), so rows take both their characters from the bottom of two shift registers, a word per 8 rows
+  u64 qs[5];
+  {
+    const u32 off = (u32)((int)WB - dm), ws = off >> 3, bs = (off & 7) * 8;  // 2..11 bytes
+    constexpr u64 PAD = 0x0707070707070707ULL;
 #pragma unroll
-    for (int k = 0; k < WB; ++k) {
-      const int c = c0 + k;
-      const u32 qc = (u32)((k < 8 ? qlo >> (8 * k) : qhi >> (8 * (k - 8))) & 255u);
-      const int up = k + 1 < WB ? s[k + 1] : NEG;
-      const int dsc = s[k] + (gc == qc ? 0 : -1);
-      const int vsc = up + (c == (int)n ? 0 : -1);
-      const int hsc = left - 1;
-      int best = dsc > vsc ? dsc : vsc;
-      best = best > hsc ? best : hsc;
-      const u32 code = best == hsc ? 1u : (best == vsc ? 2u : 0u);
-      const int val = c < 0 ? NEG : (c == 0 ? 0 : (c > (int)n ? NEG : best));
-      s[k] = val;
-      left = val;
-      bits |= code << (2 * k);
+    for (int w = 0; w < 5; ++w) {
+      const u64 x0 = w < QW ? qwm[w < QW ? w : 0] : PAD, x1 = w + 1 < QW ? qwm[w + 1 < QW ? w + 1 : 0] : PAD,
+                x2 = w + 2 < QW ? qwm[w + 2 < QW ? w + 2 : 0] : PAD;
+      const u64 lo = ws ? x1 : x0, hi = ws ? x2 : x1;
+      qs[w] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
     }
-    tr[row * 128] = bits;
-    // slide the query window: drop byte 0, the character of column c0 + WB (next row's last diagonal) enters at the top
-    const u64 nb = qbyte(c0 + WB - 1);
-    qlo = (qlo >> 8) | (qhi << 56);
-    qhi >>= 8;
-    if (WB <= 8) qlo |= nb << (8 * (WB - 1));
-    else qhi |= nb << (8 * (WB - 9));
+  }
+  TR* tr = tr_lds + threadIdx.x;
+#pragma unroll
+  for (int w = 0; w < 5; ++w) {
+    u64 gcur = gsh[w], qcur = qs[w];
+    const u32 rend = mg < 8u * w + 8u ? mg : 8u * w + 8u;
+    for (u32 row = 8u * w + 1; row <= rend; ++row) {
+      const u32 gc = (u32)gcur & 255u;
+      gcur >>= 8;
+      const int c0 = (int)row - dm;
+      u32 bits = 0;
+      int left = NEG;
+#pragma unroll
+      for (int k = 0; k < WB; ++k) {
+        const int c = c0 + k;
+        const u32 qc = (u32)((k < 8 ? qlo >> (8 * k) : qhi >> (8 * (k - 8))) & 255u);
+        const int up = k + 1 < WB ? s[k + 1] : NEG;
+        const int dsc = s[k] + (gc == qc ? 0 : -1);
+        const int vsc = up + (c == (int)n ? 0 : -1);
+        const int hsc = left - 1;
+        int best = dsc > vsc ? dsc : vsc;
+        best = best > hsc ? best : hsc;
+        const u32 code = best == hsc ? 1u : (best == vsc ? 2u : 0u);
+        const int val = c < 0 ? NEG : (c == 0 ? 0 : (c > (int)n ? NEG : best));
+        s[k] = val;
+        left = val;
+        bits |= code << (2 * k);
+      }
+      tr[row * 128] = (TR)bits;
+      // slide the query window: drop byte 0, the character of column c0 + WB (next row's last diagonal) enters at the top
+      const u64 nb = (ASCII_LUT >> (8 * ((u32)qcur & 255u))) & 255u;
+      qcur >>= 8;
+      qlo = (qlo >> 8) | (qhi << 56);
+      qhi >>= 8;
+      if (WB <= 8) qlo |= nb << (8 * (WB - 1));
+      else qhi |= nb << (8 * (WB - 9));
+    }
   }
   int fin = NEG;
 #pragma unroll
@@ -2531,7 +2576,7 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     else if (row == 0) code = 1u;
     else {
       const int k = (int)col - (int)row + dm;  // inside the band on every optimal path
-      code = (k >= 0 && k < WB) ? (tr[row * 128] >> (2 * k)) & 3u : 1u;
+      code = (k >= 0 && k < WB) ? ((u32)tr[row * 128] >> (2 * k)) & 3u : 1u;
     }
     if (code == 1) --col;
     else if (code == 2) --row;
@@ -2558,15 +2603,15 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     u32 r0, r1;
     if (code == 1) {
       r0 = '-';
-      r1 = q_at(c);
+      r1 = q_ch(c);
       ++c;
     } else if (code == 2) {
-      r0 = gw_at(skip + r);
+      r0 = g_ch(r);
       r1 = '-';
       ++r;
     } else {
-      r0 = gw_at(skip + r);
-      r1 = q_at(c);
+      r0 = g_ch(r);
+      r1 = q_ch(c);
       ++r;
       ++c;
     }

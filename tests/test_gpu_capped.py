@@ -145,3 +145,18 @@ def test_neighborhood_count_capped(ix, small_genome):
         for strand, got in ((a, fw[i]), (revcomp(a), rv[i])):
             want = sum(orc.count(s.encode()) for s in O.neighbors(strand, 2, True, 10000))
             assert got == want, (a, got, want)
+
+
+def test_edit2_long_primers_on_the_kernel_path_with_a_wide_cap(ix, small_genome):
+    """-x 200000: the cap cannot fire for 25…30-mers at d=2, so they run on k_search2p itself (two passes over the pairs of edit
+    positions above 22 nt, strings up to 32 characters in one 64-bit register) instead of the host enumeration; the checker's
+    hash-set neighbours take the same cap."""
+    rng = random.Random(2930)
+    qs = [sample(small_genome, rng, L, edits=rng.randrange(3)) for L in (23, 25, 26, 28, 29, 30, 30, 27)]
+    qs += ["A" * 30, "ACGT" * 7 + "AC", "AAAAACCCCCGGGGGTTTTTAAAAACCCCC"]  # runs: the duplicate-string rules at work
+    O.fast_neighbors(True)
+    try:
+        compare(ix, small_genome, qs, distance=2, max_neighborhood=200000)
+        compare(ix, small_genome, qs[:6], distance=2, max_neighborhood=200000, max_locations=4, forward_only=True)
+    finally:
+        O.fast_neighbors(False)

@@ -25,6 +25,8 @@ text = genome_text(seqs)
 fm9 = "/tmp/fuzz_%d.fm9" % seed
 O.build_fm9(text, fm9)
 orc = O.Index(fm9)
+if os.environ.get("FUZZ_FAST_NEIGHBORS"):  # the checker's hash-set neighbourhoods (tested equal to the literal ones): d=2 configurations in seconds
+    O.fast_neighbors(True)
 _lib = None
 if "DICEY_LIB" in os.environ:  # e.g. tools/hostemu/libdiceygpu_hostemu.so for a GPU-less sweep
     from dicey_amd import _capi
@@ -36,7 +38,7 @@ bad = 0
 for c in range(nconf):
     ham = rng.random() < 0.4
     d = rng.choice([0, 1, 1, 1, 2])
-    maxlen = 20 if (d == 2 and not ham) else rng.choice([12, 20, 31, 40, 47])
+    maxlen = (rng.choice([14, 20, 20, 22]) if os.environ.get("FUZZ_FAST_NEIGHBORS") else 20) if (d == 2 and not ham) else rng.choice([12, 20, 31, 40, 47])
     if d == 2 and ham: maxlen = min(maxlen, 47)
     kw = dict(distance=d, hamming=ham, forward_only=rng.random() < 0.3, max_locations=rng.choice([1, 2, 5, 1000, 1000]))
     qs = []

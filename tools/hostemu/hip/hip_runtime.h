@@ -20,6 +20,9 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static thread_local
+#ifndef __align__
+#define __align__(n) alignas(n)
+#endif
 #define __launch_bounds__(...)
 #define __restrict__
 

@@ -940,18 +940,20 @@ DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... ho
   p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
 }
 __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o) {
-  constexpr u32 QCAP = 256 * 64;  // every candidate of one pass could survive
-  __shared__ u16 q_ent[QCAP];     // bits 0-8 pair, 9-11 first operation, 12-14 second operation
-  __shared__ u32 q_n, g_slots;
+  // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
+  // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
+  // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
+  // over the lanes and finds its e-th one by a binary search over the prefix plus a select inside the lane's mask.
+  __shared__ unsigned long long q_mask[256];
+  __shared__ u32 q_ex[256 + 1];  // exclusive prefix of the lanes' survivor counts, [256] = total
+  __shared__ u32 q_wave[4];
+  __shared__ u32 g_slots;
   const u32 gid = blockIdx.x;
   const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
   const u32 m = raw.z, d_win = raw.w;
   if (!m || !(d_win & 1024u)) return;  // uniform for the workgroup
   const u64 qpk = (u64)raw.y << 32 | raw.x;
-  if (threadIdx.x == 0) {
-    q_n = 0;
-    g_slots = 0;
-  }
+  if (threadIdx.x == 0) g_slots = 0;
   __syncthreads();
   const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
   const u64 kmask = (1ULL << (2 * K)) - 1, mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
@@ -961,6 +963,7 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
   u32 steps = 0, nlook = 0, nprobe = 0;
   for (u32 w0 = 0; w0 < npairs; w0 += 256) {
     const u32 w = w0 + threadIdx.x;
+    u64 surv = 0;
     if (w < npairs) {
       u32 p1, p2;
       pair_of(w, m, p2, p1);
@@ -1014,29 +1017,44 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
             mask8 |= (((valid >> op2) & 1u) & present) << op2;
           }
           nprobe += (u32)__popc(probe);
-          while (mask8) {
-            const u32 op2 = (u32)__ffs((int)mask8) - 1u;
-            mask8 &= mask8 - 1;
-            const u32 at = atomicAdd(&q_n, 1u);
-            q_ent[at] = (u16)(threadIdx.x | (op1 << 9) | (op2 << 12));  // the pair is w0 + lane number
-          }
+          surv |= (u64)mask8 << (8 * op1);
         }
       }
     }
+    // number the survivors: inclusive scan of the lanes' counts inside the wavefront, wavefront totals through LDS
+    const u32 mine = (u32)__popcll(surv);
+    u32 incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 v = __shfl_up(incl, off);
+      if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) q_wave[threadIdx.x >> 6] = incl;
+    q_mask[threadIdx.x] = surv;
     __syncthreads();
-    const u32 qn = q_n;
+    u32 before = 0;
+    for (u32 k = 0; k < (threadIdx.x >> 6); ++k) before += q_wave[k];
+    q_ex[threadIdx.x] = before + incl - mine;
+    const u32 qn = q_wave[0] + q_wave[1] + q_wave[2] + q_wave[3];
+    __syncthreads();
     for (u32 e0 = 0; e0 < qn; e0 += 256) {
       if (e0 + (threadIdx.x & ~63u) >= qn) break;  // wavefront without work
       const u32 e = e0 + threadIdx.x;
       bool leaf = false;
       u32 lo = 0, hi = 0, w1 = 0, w2 = 0;
       if (e < qn) {
-        const u32 ent = q_ent[e];
+        // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
+        u32 L = 0;
+#pragma unroll
+        for (u32 step = 128; step > 0; step >>= 1)
+          if (q_ex[L + step] <= e) L += step;
+        unsigned long long mk = q_mask[L];
+        for (u32 r = e - q_ex[L]; r > 0; --r) mk &= mk - 1;
+        const u32 bitno = (u32)__ffsll((long long)mk) - 1u;
         u32 p1, p2, l1, l2;
         u64 s1, s2;
-        pair_of(w0 + (ent & 511u), m, p2, p1);
-        apply_edit(qpk, m, p1, (ent >> 9) & 7u, s1, l1, w1);
-        apply_edit(s1, l1, p2, (ent >> 12) & 7u, s2, l2, w2);
+        pair_of(w0 + L, m, p2, p1);
+        apply_edit(qpk, m, p1, bitno >> 3, s1, l1, w1);
+        apply_edit(s1, l1, p2, bitno & 7u, s2, l2, w2);
         nprobe += (K2 && l2 > K2);
         if (head_window_occurs(f, s2, l2, l1 - p2)) {
           const uint2 iv = f.ktab[s2 & kmask];
@@ -1075,9 +1093,7 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
         }
       }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) q_n = 0;
-    __syncthreads();
+    __syncthreads();  // the masks and prefixes of this pass are not needed any more
   }
   for (int off = 32; off > 0; off >>= 1) {
     steps += __shfl_xor(steps, off);

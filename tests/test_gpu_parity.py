@@ -206,6 +206,12 @@ def test_capacity_retry_path(small_genome, monkeypatch):
     with dicey_amd.FmIndex(small_genome["fm9"]) as ix:
         qs = make_queries(77, small_genome["text"], 400)
         _compare(ix, orc, small_genome, qs, distance=1)
+        # distance 2 under the same tiny capacities (leaf regions overflow several times before they fit)
+        O.fast_neighbors(True)
+        try:
+            _compare(ix, orc, small_genome, [q[:m] for q, m in zip(qs[:40], [12, 14, 20, 18] * 10) if len(q) >= m], distance=2)
+        finally:
+            O.fast_neighbors(False)
 
 
 def test_hunt_edit_distance_two(gpu_small, small_genome):

@@ -2640,13 +2640,15 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     wr |= (u64)r0 << (8 * (len & 7));
     wq |= (u64)r1 << (8 * (len & 7));
     if ((len & 7) == 7) {
-      ra8[len >> 3] = wr;
-      qa8[len >> 3] = wq;
+      if (len < a.stride) {  // always (see the stride's derivation in run_batch); never write past the row
+        ra8[len >> 3] = wr;
+        qa8[len >> 3] = wq;
+      }
       wr = wq = 0;
     }
     ++len;
   }
-  if (len & 7) {
+  if ((len & 7) && len < a.stride) {
     ra8[len >> 3] = wr;
     qa8[len >> 3] = wq;
   }
@@ -3001,7 +3003,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   const u64 ngrp = 2 * (u64)nq;
   const u32 TB = 256;
   const bool packed = maxlen + dmax_eff <= PACK_MAX_LEN;  // every neighbourhood string fits 128 bits
-  const u32 stride = ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
+  // Alignment rows.  The banded verify writes a row front to back, and a row it keeps has the query's characters plus at most d
+  // gap columns inside the query (leading and trailing query-gap columns are stripped, hunter.h:391-401, and an optimal path has
+  // score >= -d): maxlen + d bytes, rounded up to the 64-bit words it stores.  The other verify kernels build the row from the
+  // end of a buffer twice as long.  (r02: 56 -> 24 bytes per row for 20-mers — what travels to the host and over xGMI.)
+  static const bool no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;
+  const bool band_verify = !no_band && !sx && !group_counts && maxlen <= 32 && dmax_eff <= 2;
+  const u32 stride = band_verify ? (maxlen + 2 * dmax_eff + 7) & ~7u : ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
   const u64 scan_tmp = ngrp / SCAN_CHUNK + ngrp / (SCAN_CHUNK * SCAN_CHUNK) + 64;
   DG_TRY(ws[WS_FW].reserve(total + 8));
   DG_TRY(ws[WS_RV].reserve(total + 8));
@@ -3274,10 +3282,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
-      static const bool no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;
-      if (!no_band && maxlen <= 32 && dmax_eff <= 1 && (stride & 7) == 0)
+      if (band_verify && dmax_eff <= 1)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_band<7>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
-      else if (!no_band && maxlen <= 32 && dmax_eff == 2 && (stride & 7) == 0)
+      else if (band_verify)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_band<13>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
       else if (maxlen > MAX_QLEN) {
         const u32 rows_cap = maxlen + 3 * dmax_eff + 2;

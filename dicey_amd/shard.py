@@ -66,6 +66,11 @@ class PipelinedGather:
         self.send = [torch.zeros(self.cap + 8, dtype=torch.uint8, device=device) for _ in range(depth)]
         self.recv = ([[torch.empty(self.cap + 8, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(depth)]
                      if self.rank == dst else None)
+        # length prefixes come from pinned host memory with a stream-ordered copy: a pageable source would block the host for
+        # a tiny transfer once per step
+        self.is_cuda = torch.device(device).type == "cuda"
+        self.prefix = [torch.zeros(1, dtype=torch.int64).pin_memory() if self.is_cuda else torch.zeros(1, dtype=torch.int64)
+                       for _ in range(depth)]
         self.work = [None] * depth
         self.n = 0
         self.bytes_received = 0
@@ -98,7 +103,8 @@ class PipelinedGather:
         slot = self.n % self.depth
         self._drain(slot)
         buf = self.send[slot]
-        buf[:8] = torch.tensor([total], dtype=torch.int64).view(torch.uint8).to(buf.device)
+        self.prefix[slot][0] = total  # slot's previous gather has been drained, so its prefix copy is long done
+        buf[:8].copy_(self.prefix[slot].view(torch.uint8), non_blocking=self.is_cuda)
         at = 8
         for t in parts:
             # staging buffer on another device (the gloo/CPU path): a blocking copy, so the bytes are there before the gather

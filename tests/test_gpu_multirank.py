@@ -70,3 +70,38 @@ def test_cli_shards_a_batch_over_dicey_devices(tmp_path):
     assert r.returncode == 0 and r.stdout == ""
     one = subprocess.run([dicey, "hunt", "-g", str(fa), str(qf)], capture_output=True, text=True)
     assert gzip.open(out, "rt").read().replace(str(out), "") == one.stdout  # only the outfile field differs
+
+
+def test_pipelined_gather_on_the_device_backend_single_rank():
+    """The RCCL form of PipelinedGather (staging buffer in HBM, length prefix from pinned host memory with a stream-ordered
+    copy) — the multi-rank tests above run on gloo, which takes the CPU branch.  One rank, backend nccl, on the test box's GPU:
+    payloads of changing length over more steps than the pipeline is deep; what rank 0 holds after finish() is the last payload
+    and the byte count is the sum."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from dicey_amd.shard import PipelinedGather
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+dev = torch.device("cuda:0")
+g = PipelinedGather(5000, dev, depth=2)
+tot = 0
+for step in range(7):
+    n = 100 + 613 * step
+    a = (torch.arange(n, device=dev) %% 251).to(torch.uint8)
+    b = torch.full((step + 1,), step, dtype=torch.uint8, device=dev)
+    g.submit([a, b]); tot += n + step + 1
+    torch.cuda.current_stream().synchronize()
+got = g.finish()
+last = g.last_received()
+want = bytes((i %% 251) for i in range(100 + 613 * 6)) + bytes([6] * 7)
+assert got == tot, (got, tot)
+assert len(last) == 1 and last[0] == want, (len(last[0]), len(want))
+dist.destroy_process_group()
+print("ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -168,8 +168,9 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
  * sdsl::count(fm_index, s) and rv_count[i] the same for its reverse complement — the totals the reference accumulates in
  * hits[0] / hits[1] (its loops only stop early once the running total already exceeds the threshold it is compared with,
  * so every comparison it makes has the same outcome on the full totals).  The original sequence is part of its own
- * neighbourhood.  max_neighborhood is neighbors()' cap (10000 in padlock.h:396); refused with DG_ELIMIT when the cap
- * could fire. */
+ * neighbourhood.  max_neighborhood is neighbors()' cap (10000 in padlock.h:396); when it can fire the reference's capped
+ * enumeration is reproduced on the host and its strings are counted (DESIGN.md "the cap").  Sequences above 255 nt are
+ * refused here with DG_ELIMIT (dg_hunt takes them). */
 int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t max_neighborhood, const uint8_t* qbytes,
                            const uint64_t* qoff, size_t nq, uint64_t* fw_count, uint64_t* rv_count);
 

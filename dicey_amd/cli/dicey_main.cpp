@@ -274,14 +274,15 @@ int hunter(int argc, char** argv) {
         err = dg_last_error();  // outside the supported envelope: say so, never guess
         return false;
       }
-      for (size_t i = 0; i < nq; ++i) {
+      // one JSON line per query: independent of each other, so a large chunk formats them on several host threads
+      // (100 000 lines are 0.4 s on one) and hands them to the sink in query order
+      auto line_of = [&](size_t i) -> std::string {
         std::vector<std::string> m;
         std::vector<DnaHit> ht;
         const std::string& qname = queries[q0 + i].first;
         if (R->qflags[i] & DG_Q_TOO_SHORT) {
           m.push_back("Error: Input sequence is shorter than 10 nucleotides!");
-          sink(q0 + i, hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m));
-          continue;
+          return hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m);
         }
         for (uint32_t k = 0; k < R->qnondna[i]; ++k) m.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
         if (R->qflags[i] & DG_Q_DIST_ADJUSTED) m.push_back("Warning: Distance was adjusted to sequence length!");
@@ -300,7 +301,23 @@ int hunter(int argc, char** argv) {
         }
         std::sort(ht.begin(), ht.end());  // hunter.h:440 — same comparator, same libstdc++ algorithm, same input order
         std::string seq((const char*)R->qseq + R->qoff[i], R->qoff[i + 1] - R->qoff[i]);
-        sink(q0 + i, hunt_json(c, R->qdistance[i], seq, qname, seqname, ht, m));
+        return hunt_json(c, R->qdistance[i], seq, qname, seqname, ht, m);
+      };
+      unsigned nthr = std::thread::hardware_concurrency();
+      if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthr = (unsigned)std::max(1, std::atoi(e));
+      nthr = (unsigned)std::min<size_t>(std::min<unsigned>(nthr ? nthr : 1u, 32u), nq / 32);
+      if (nthr > 1) {
+        std::vector<std::string> lines(nq);
+        std::vector<std::thread> fmt;
+        const size_t per_thr = (nq + nthr - 1) / nthr;
+        for (unsigned t = 0; t < nthr; ++t)
+          fmt.emplace_back([&, t]() {
+            for (size_t i = t * per_thr, e = std::min(nq, i + per_thr); i < e; ++i) lines[i] = line_of(i);
+          });
+        for (auto& th : fmt) th.join();
+        for (size_t i = 0; i < nq; ++i) sink(q0 + i, std::move(lines[i]));
+      } else {
+        for (size_t i = 0; i < nq; ++i) sink(q0 + i, line_of(i));
       }
       dg_hunt_result_free(R);
     }

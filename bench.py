@@ -413,6 +413,7 @@ def main():
 
     out = None
     gathered = 0
+    cli_job = None
     # =====================================================================================================================
     if cfg in ("hunt_d1", "hunt_d2"):
         queries = [q.encode() for q in meta["queries"][rank if rank < len(meta["queries"]) else 0]]
@@ -455,7 +456,7 @@ def main():
                                         "note": "same steps with fetch=1: hit records, alignment rows, flags and normalised queries copied to "
                                                 "host memory after every batch (pageable host buffers, blocking copies)",
                                         "hit_record_bytes_per_step": int(acc[-1]["nhits"]) * C.sizeof(_capi.Hit)}
-            extras["cli_end_to_end"] = cli_end_to_end(fm9, meta, queries, distance)
+            cli_job = (queries, distance)  # measured in the common tail, after this process has released its own index
         if world == 1 and a.pipeline > 1:
             import threading
             shared = [ix] + [ix.share() for _ in range(a.pipeline - 1)]
@@ -722,12 +723,18 @@ def main():
         out["setup_s"] = info
         if world > 1:
             out["gathered_bytes_per_step"] = gathered / max(1, a.steps)
-        print(json.dumps(out), flush=True)
     for h in shared[1:]:
         h.close()
     if th is not None:
         th.close()
     ix.close()
+    if rank == 0 and out is not None:
+        if cli_job is not None:  # the process seam on a GPU this process no longer occupies (r02f and earlier measured it while
+            # the bench still held its 199 GB index, which left the CLI a smaller table and no long filter)
+            out["cli_end_to_end_after_release"] = cli_end_to_end(fm9, meta, cli_job[0], cli_job[1])  # right after 199 GB were freed
+            time.sleep(8)  # the driver wipes released VRAM at ~32 GiB/s; allocations of the next process wait for it
+            out["cli_end_to_end"] = cli_end_to_end(fm9, meta, cli_job[0], cli_job[1])
+        print(json.dumps(out), flush=True)
     barrier()
     if rank == 0 and not a.fm9 and not a.keep_index:
         for f in (fm9, meta_path):
@@ -769,11 +776,21 @@ def cli_end_to_end(fm9, meta, queries, distance):
         made.append(outp)
         t = time.time()
         with open(outp, "wb") as o:
-            r = subprocess.run([binary, "hunt", "-d", str(distance), "-g", base + ".gz", qf], stdout=o, stderr=subprocess.PIPE, timeout=900)
+            r = subprocess.run([binary, "hunt", "-d", str(distance), "-g", base + ".gz", qf], stdout=o, stderr=subprocess.PIPE, timeout=900,
+                               env=dict(os.environ, DICEY_TIMING="1"))
         dt = time.time() - t
         lines = sum(1 for _ in open(outp, "rb"))
+        phases = {}
+        for ln in r.stderr.decode(errors="replace").splitlines():  # "dicey timing: <phase>   <ms> ms" from the library's open
+            if ln.startswith("dicey timing:") and ln.rstrip().endswith("ms"):
+                name, _, val = ln[len("dicey timing:"):].rstrip()[:-2].rstrip().rpartition(" ")
+                try:
+                    phases[name.strip()] = float(val)
+                except ValueError:
+                    pass
         return {"value": len(queries) / dt, "unit": "primers/s", "seconds": dt, "exit_code": r.returncode, "json_lines": lines,
-                "note": "one process: index open + derivation of the HBM layouts, the whole batch, one JSON line per query on stdout"}
+                "index_open_phases_ms": phases,
+                "note": "one process on a free GPU: index open + derivation of the HBM layouts, the whole batch, one JSON line per query on stdout"}
     except Exception as e:  # an extra, never fatal for the bench line
         return {"error": str(e)[:200]}
     finally:

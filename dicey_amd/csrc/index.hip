@@ -199,19 +199,49 @@ __global__ void k_selfcheck(FmView f, u64 nsample, u32* bad) {
 
 // K-mer table: thread i looks at the K-mer that starts suffix SA[i]; the first / last suffix of each run of equal K-mers
 // writes the interval bounds.  K-mers that run into a separator, an N or the end of the text have no entry.
-// the K-mer and the K2-mer (K2 > K, or 0) that start at text position p, from one left-to-right read
+// the K-mer and the K2-mer (K2 > K, or 0) that start at text position p (K, K2 <= 24).  The text arrives as four aligned
+// 64-bit words (24 characters at any byte offset; the buffer is padded) in one round trip — a byte loop that may stop at the
+// first other letter cannot have its loads hoisted, so it waited for memory once per character (r02: 0.45-0.70 s of table
+// fill).  Which bytes are A/C/G/T is an exact zero-byte test against the four letters; ((b >> 1) ^ (b >> 2)) & 3 maps
+// A,C,G,T to 0..3; the 2-bit fields of a byte-swapped word are squeezed together so that the first character ends up on top.
+DG_DEV u64 acgt_flags(u64 w) {  // 0x80 in every byte that is one of A, C, G, T
+  u64 f = 0;
+  const u64 lo7 = 0x7F7F7F7F7F7F7F7FULL;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u64 v = w ^ ((u64)(k == 0 ? 'A' : k == 1 ? 'C' : k == 2 ? 'G' : 'T') * 0x0101010101010101ULL);
+    f |= ~(((v & lo7) + lo7) | v | lo7);
+  }
+  return f;
+}
+DG_DEV u32 pack8(u64 w) {  // 8 characters (first one in the lowest byte) -> 16 bits, first character in bits 15-14
+  w = __builtin_bswap64(w);
+  u64 x = ((w >> 1) ^ (w >> 2)) & 0x0303030303030303ULL;
+  x = (x | (x >> 6)) & 0x000F000F000F000FULL;
+  x = (x | (x >> 12)) & 0x000000FF000000FFULL;
+  x = (x | (x >> 24)) & 0xFFFFULL;
+  return (u32)x;
+}
 DG_DEV void kmer_codes_at(const FmView& f, u64 p, u32 K, u32 K2, u64& code, u64& code2) {
   const u64 none = 1ULL << 63;
-  const u32 want = K2 > K ? K2 : K;
-  u64 acc = 0;
-  u32 got = 0;
-  for (; got < want && p + got < f.n - 1; ++got) {
-    const u32 c = code_of_byte(f.text[p + got]);
-    if (c > 3) break;
-    acc = acc << 2 | c;
-  }
-  code = got >= K ? acc >> (2 * (got - K)) : none;
-  code2 = (K2 && got >= K2) ? acc : none;
+  const u64* src = reinterpret_cast<const u64*>(f.text + (p & ~7ULL));
+  const u32 sh = (u32)(p & 7) * 8;
+  const u64 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+  const u64 b0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+  const u64 b1 = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
+  const u64 b2 = sh ? (w2 >> sh) | (w3 << (64 - sh)) : w2;
+  // bit i of `valid` <=> character i is A/C/G/T
+  const u64 gather = 0x0102040810204080ULL, ones = 0x0101010101010101ULL;
+  const u32 v0 = (u32)((((acgt_flags(b0) >> 7) & ones) * gather) >> 56), v1 = (u32)((((acgt_flags(b1) >> 7) & ones) * gather) >> 56),
+            v2 = (u32)((((acgt_flags(b2) >> 7) & ones) * gather) >> 56);
+  const u32 valid = v0 | (v1 << 8) | (v2 << 16);
+  u32 got = (u32)__builtin_ctz(~valid | (1u << 24));  // characters before the first other letter, at most 24
+  const u64 room = f.n - 1 - p;                        // characters before the sentinel (p < n - 1 for every suffix but the last)
+  if (p >= f.n - 1) got = 0;
+  else if (got > room) got = (u32)room;
+  const u64 acc = (u64)pack8(b0) << 32 | (u64)pack8(b1) << 16 | (u64)pack8(b2);  // 24 characters, the first on top (bits 47-46)
+  code = got >= K ? acc >> (2 * (24 - K)) : none;
+  code2 = (K2 && got >= K2) ? acc >> (2 * (24 - K2)) : none;
 }
 // kf2: copy 0 of the long presence filter (bit address = K2-mer code), zeroed by the caller; nullptr = none
 __global__ void k_kmer_table(FmView f, uint2* tab, u32 K, u32 K2, u32* kf2) {

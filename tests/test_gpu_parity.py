@@ -287,19 +287,29 @@ def test_flat_distance_two_kernel(gpu_small, small_genome, monkeypatch):
         O.fast_neighbors(False)
 
 
-@pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13"])
+@pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13", "K9_nolong", "K9_long10", "K10_long14"])
 def test_every_search_mode_gives_the_same_hits(small_genome, monkeypatch, mode):
     """Interval mode (no table), window mode with a table shorter than every query, and tables long enough that some
     queries fall back to interval mode (10/11-mers against K=11/13) must all reproduce the oracle."""
     import dicey_amd
     if mode != "no_table":
-        monkeypatch.setenv("DICEY_KMER_K", mode[1:])
+        monkeypatch.setenv("DICEY_KMER_K", mode[1:].split("_")[0])
+    if mode.endswith("_nolong"):  # what a device short of HBM gets: the table and its own filter only
+        monkeypatch.setenv("DICEY_KMER_K2", "0")
+    elif "_long" in mode:         # long filter right above the table order / well above it
+        monkeypatch.setenv("DICEY_KMER_K2", mode.split("_long")[1])
     orc = O.Index(small_genome["fm9"])
     with dicey_amd.FmIndex(small_genome["fm9"], kmer_table=(mode != "no_table")) as ix:
         qs = make_queries(31, small_genome["text"], 300, (10, 11, 14, 20, 33))
         _compare(ix, orc, small_genome, qs, distance=1)
         _compare(ix, orc, small_genome, qs[:120], distance=1, hamming=True)
         _compare(ix, orc, small_genome, [q[:12] for q in qs[:12]], distance=2)
+        if "_" in mode:  # the flat distance-2 kernel around the long filter's order (strings of 12..18 characters)
+            O.fast_neighbors(True)
+            try:
+                _compare(ix, orc, small_genome, [q[:m] for q, m in zip(qs[200:232], [14, 15, 16, 12] * 8) if len(q) >= m], distance=2)
+            finally:
+                O.fast_neighbors(False)
 
 
 def test_shared_handles_run_concurrently_and_agree(small_genome):

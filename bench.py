@@ -541,6 +541,7 @@ def main():
             survey_bytes = ext * 2 * avg_l * 24 + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             traffic = None
+            fabric_reads = traffic_round = None
             # HBM bytes per launch of this kernel on this workload from the committed PMC passes (tools/summarize_profile.py,
             # tools/prof_cfg.sh): FETCH_SIZE corrected by the calibration factor + WRITE_SIZE
             import glob
@@ -549,6 +550,8 @@ def main():
                     tj = json.load(open(tpath))
                     if tj.get("workload") == f"{units}x{a.qlen}mer_d{distance}_n{int(a.genome_size)}_{a.genome}" and tj.get("kernel") == kernel:
                         traffic = tj.get("hbm_bytes_per_launch")
+                        fabric_reads = (tj.get("tcc") or {}).get("ea_rdreq")
+                        traffic_round = tj.get("round")
                 except Exception:
                     pass
             out = dict(base_out)
@@ -569,6 +572,11 @@ def main():
                                               "achieved": survey_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
                                               "frac": survey_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
                                               "note": "24 B per rank op, 2 L(c) rank ops per backward step (SURVEY.md 8(d))"},
+                             # the kernel is a gather of 64-byte lines: what the memory system delivered (TCC_EA0_RDREQ of the
+                             # committed PMC pass for this workload) against this launch's duration
+                             "fabric_reads_per_launch": fabric_reads, "traffic_from_profile_round": traffic_round,
+                             "fabric_reads_per_s": (fabric_reads / (kernel_ms * 1e-3)) if (fabric_reads and kernel_ms > 0) else None,
+                             "lines_per_strand": (fabric_reads / (2 * nq)) if fabric_reads else None,
                              "index_accesses_per_query": (2 * ext + tab + probe) / nq,
                              "index_accesses_per_s": (2 * ext + tab + probe) / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
                              "gather_ceiling_note": "random 64-B lines top out at 26 G lines/s inside 4 GiB and 19 G lines/s (1.2 TB/s) above "

@@ -85,6 +85,13 @@ struct FmView {
   //        19-mer passes with p = 0.011, so nearly every table read and interval extension that remains belongs to a
   //        string that really occurs.  This is what the HBM the table does not need is spent on.
   KFilter kf, kf2;
+  // Block minima over the suffix array (derived at load, r03): samin[0] = sa itself, samin[j][b] = min of
+  // SA[b * 8^j, min(n, (b+1) * 8^j)), j = 1..nlev-1; every level is padded with 0xFFFFFFFF to a multiple of eight entries
+  // (+8), so the eight children of a block are two 16-byte loads.  k_locate_topk walks it to take the smallest positions of a
+  // repeat-rich interval without reading the interval (hunter.h:355-357 keeps the first max_locations of the sorted list).
+  static constexpr u32 MAXLEV = 10;
+  const u32* samin[MAXLEV];
+  u32 nlev;  // levels present, including level 0; 0 = no hierarchy
 };
 
 // is the k-mer `code` present?  t = window position (0 = right-most character) of the edit the neighbouring lanes vary

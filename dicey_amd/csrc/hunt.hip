@@ -1916,65 +1916,114 @@ __global__ void k_select(Batch b, const Leaf* grouped, const u64* grp_off, Sel* 
 
 // ------------------------------------------------------------------------------------------------------------
 // Locate: the `take` smallest SA values of [lo,hi), ascending (locate + std::sort + first min(occs,max) entries).
-struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_big
+static constexpr u32 TOPK_KMAX = 1024;  // largest `take` k_locate_topk serves (its LDS holds 8 * 1 152 candidate minima)
+struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_topk / k_locate_big
   u32 lo, occs, take, g, len;
   u64 out;  // first hit slot
 };
-__global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32* nsel, u64 ngroups, const u64* hit_off,
-                         HitSeed* seeds, Counters* ctr, u64 hit_cap, BigJob* jobs, u32 job_cap, u32* job_count) {
-  u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // g = 2*query + strand
-  if (g >= ngroups || ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
-  const Sel* S = sel + grp_off[g];
+// One lane per kept string (r03; r02 walked the strings of a (query, strand) group in one lane — 170 hits per query on the
+// repeat-bearing genome made that a chain of several hundred dependent reads).  The lane finds its group through the packed /
+// grouped leaf of the same slot (slot_qs: address of that record's `qs` field, slot_stride: record size), serves strings of up to
+// 24 occurrences itself and queues the others: up to 256 occurrences for one wavefront (k_locate_small), more for one
+// workgroup (k_locate_topk / k_locate_big).
+struct LocJobs {
+  BigJob* small;
+  BigJob* big;
+  u32 cap;  // of each list
+  u32* n_small;
+  u32* n_big;
+};
+static constexpr u32 LOC_SMALL_MAX = 256;
+__global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const u8* slot_qs, u32 slot_stride, const u64* grp_off, const u32* nsel,
+                                                u64 ngroups, const u64* hit_off, HitSeed* seeds, Counters* ctr, u64 hit_cap, LocJobs jobs) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
   u64 reads = 0;
-  const u32 ns = nsel[g];
-  for (u32 r = 0; r < ns; ++r) {
-    const u32 take = S[r].take;
-    if (!take) continue;
-    const u32 lo = S[r].lo, occs = S[r].hi - S[r].lo;
-    HitSeed* out = seeds + hit_off[g >> 1] + S[r].hbase;
-    if (occs <= 24) {
-      u32 v[24];
-      for (u32 i = 0; i < occs; ++i) {  // insertion sort of a handful of values
-        u32 x = f.sa[lo + i], j = i;
-        while (j > 0 && v[j - 1] > x) {
-          v[j] = v[j - 1];
-          --j;
+  if (t < grp_off[ngroups]) {
+    const u32 g = *reinterpret_cast<const u32*>(slot_qs + t * slot_stride);  // g = 2*query + strand
+    const Sel S = sel[t];
+    const u32 take = (t - grp_off[g]) < nsel[g] ? S.take : 0u;  // slots behind the group's kept strings hold nothing
+    if (take) {
+      const u32 lo = S.lo, occs = S.hi - S.lo;
+      const u64 out0 = hit_off[g >> 1] + S.hbase;
+      HitSeed* out = seeds + out0;
+      if (occs <= 24) {
+        u32 v[24];
+        for (u32 i = 0; i < occs; ++i) {  // insertion sort of a handful of values
+          u32 x = f.sa[lo + i], j = i;
+          while (j > 0 && v[j - 1] > x) {
+            v[j] = v[j - 1];
+            --j;
+          }
+          v[j] = x;
         }
-        v[j] = x;
-      }
-      reads += occs;
-      for (u32 i = 0; i < take; ++i) out[i] = HitSeed{v[i], (u32)g, S[r].len};
-    } else if (jobs && take <= 16384) {
-      // repeat-rich string: a whole workgroup selects and sorts (k_locate_big)
-      u32 j = atomicAdd(job_count, 1u);
-      if (j < job_cap) {
+        reads += occs;
+        for (u32 i = 0; i < take; ++i) out[i] = HitSeed{v[i], g, S.len};
+      } else if (jobs.big && take <= 16384) {
         BigJob bj;
         bj.lo = lo;
         bj.occs = occs;
         bj.take = take;
-        bj.g = (u32)g;
-        bj.len = S[r].len;
-        bj.out = hit_off[g >> 1] + S[r].hbase;
-        jobs[j] = bj;
-      }
-    } else {
-      // fallback: selection by repeated minimum above the previous pick (positions are distinct)
-      u64 prev = 0;
-      bool first = true;
-      for (u32 i = 0; i < take; ++i) {
-        u32 best = 0xFFFFFFFFu;
-        for (u32 j = 0; j < occs; ++j) {
-          u32 x = f.sa[lo + j];
-          if ((first || x > prev) && x < best) best = x;
+        bj.g = g;
+        bj.len = S.len;
+        bj.out = out0;
+        const bool small = occs <= LOC_SMALL_MAX;
+        const u32 j = atomicAdd(small ? jobs.n_small : jobs.n_big, 1u);
+        if (j < jobs.cap) (small ? jobs.small : jobs.big)[j] = bj;
+      } else {
+        // fallback: selection by repeated minimum above the previous pick (positions are distinct)
+        u64 prev = 0;
+        bool first = true;
+        for (u32 i = 0; i < take; ++i) {
+          u32 best = 0xFFFFFFFFu;
+          for (u32 j = 0; j < occs; ++j) {
+            u32 x = f.sa[lo + j];
+            if ((first || x > prev) && x < best) best = x;
+          }
+          reads += occs;
+          out[i] = HitSeed{best, g, S.len};
+          prev = best;
+          first = false;
         }
-        reads += occs;
-        out[i] = HitSeed{best, (u32)g, S[r].len};
-        prev = best;
-        first = false;
       }
     }
   }
-  if (reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
+  wave_add(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], reads);
+}
+
+// One WAVEFRONT per string of 25..256 occurrences (most of the queued strings on a repeat-bearing genome: 54 k of 72 k per
+// 100 000 queries): the interval is read once, sorted in LDS by the wavefront alone (bitonic, no workgroup barrier to wait
+// for), the first `take` values are written.  Jobs are taken in grid order: they all cost about the same.
+__global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, Counters* ctr) {
+  __shared__ u32 buf[LOC_SMALL_MAX];
+  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+  u64 reads = 0;
+  for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
+    const BigJob J = jobs[jb];
+    u32 n2 = 32;
+    while (n2 < J.occs) n2 <<= 1;
+    const u32* sa = f.sa + J.lo;
+    for (u32 i = threadIdx.x; i < n2; i += 64) buf[i] = i < J.occs ? sa[i] : 0xFFFFFFFFu;
+    reads += J.occs;
+    __syncthreads();
+    for (u32 kk = 2; kk <= n2; kk <<= 1)
+      for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+        for (u32 i = threadIdx.x; i < n2; i += 64) {
+          const u32 l = i ^ jj;
+          if (l > i) {
+            const u32 a = buf[i], b2 = buf[l];
+            if ((a > b2) == ((i & kk) == 0)) {
+              buf[i] = b2;
+              buf[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    for (u32 i = threadIdx.x; i < J.take; i += 64) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len};
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
 }
 
 // One workgroup per repeat-rich string: the `take` smallest suffix-array values of its interval, ascending.
@@ -1984,7 +2033,7 @@ __global__ void k_locate(FmView f, const Sel* sel, const u64* grp_off, const u32
 // whole text, so one top-byte bin holds occs/185 values).  One more pass collects those values, a bitonic sort orders
 // them.  2-3 coalesced passes over the interval instead of 33 (r02: 33 ms -> see DESIGN.md on the repeat-rich genome).
 __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds,
-                                                    Counters* ctr) {
+                                                    Counters* ctr, u32 topk_kmax) {
   constexpr u32 CAP = 16384;
   __shared__ u32 buf[CAP];
   __shared__ u32 hist[256];
@@ -1992,6 +2041,7 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs
   const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
   for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
     const BigJob J = jobs[jb];
+    if (f.nlev > 1 && J.take <= topk_kmax) continue;  // k_locate_topk's
     const u32* sa = f.sa + J.lo;
     // refine until at most `limit` values are left to sort: sorting costs n log^2 n, another pass over the interval does not
     const u32 limit = 2 * J.take > CAP ? CAP : (2 * J.take < 1024 ? 1024u : 2 * J.take);
@@ -2072,6 +2122,181 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs
     if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)passes * J.occs);
     __syncthreads();
   }
+}
+
+// One workgroup per repeat-rich string, without reading its interval (r03).  hunter.h:355-357 keeps the first `take` entries of
+// the sorted position list; r02's k_locate_big found them with 2-3 passes over the whole interval (an Alu-like string: 1.1 M
+// entries = 13 MB per string, 5.8 of the 9.4 ms of a step on the repeat-bearing genome).  Here the interval is cut into the
+// aligned blocks of FmView::samin (fan-out 8) and walked from the coarsest level that fits the LDS buffer down to the entries:
+//   invariant   the k smallest values of a set that is partitioned into blocks lie in the k blocks with the smallest minima
+//               (a value v in any other block b has the k minima of those blocks below min(b) <= v);
+//   per level   the candidates' minima sit in LDS; a radix select over them (256-bin histograms, LDS atomics) gives a threshold
+//               T with k <= #(minima <= T) <= KCAP; the blocks under T are expanded into their eight children (two 16-byte
+//               loads each), plus the < 8 blocks of the finer level that stick out at either end of the interval;
+//   entries     the select is carried on to the exact k-th value, the k survivors are sorted (bitonic) and written.
+// Reads: at most the top level's blocks (<= 9 232) and 8 * KCAP + 14 words per level below, whatever the interval holds.
+static constexpr u32 TOPK_KCAP = 1152;         // blocks kept per level: k plus slack, so that one histogram pass usually decides
+static constexpr u32 TOPK_VMAX = 8 * TOPK_KCAP + 16;
+static constexpr u32 TOPK_PAD = 0xFFFFFFFFu;
+struct TopkLds {
+  u32 val[TOPK_VMAX];
+  u32 cidx[2][TOPK_KCAP];
+  u32 eidx[16];
+  u32 hist[256];
+  u32 wsum[4];
+  u32 sh[4];
+  u32 n_kept, job;
+};
+// threshold T with k <= #(val <= T) <= limit (k <= limit < nv; limit == k: the exact k-th smallest).  All 256 lanes call it.
+DG_DEV u32 topk_threshold(TopkLds& S, u32 nv, u32 k, u32 limit) {
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 prefix = 0, mask = 0, kk = k - 1, below = 0;
+  for (int shift = 24;; shift -= 8) {
+    S.hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nv; i += 256) {
+      const u32 x = S.val[i];
+      if ((x & mask) == prefix) atomicAdd(&S.hist[(x >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    const u32 h = S.hist[threadIdx.x];
+    u32 incl = h;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 v = __shfl_up(incl, off);
+      if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) S.wsum[wave] = incl;
+    __syncthreads();
+    for (u32 w = 0; w < wave; ++w) incl += S.wsum[w];
+    const u32 excl = incl - h;
+    if (excl <= kk && kk < incl) {  // exactly one lane: the bin that holds the k-th smallest value
+      S.sh[0] = threadIdx.x;
+      S.sh[1] = excl;
+      S.sh[2] = h;
+    }
+    __syncthreads();
+    const u32 bin = S.sh[0], ex = S.sh[1], cnt = S.sh[2];
+    prefix |= bin << shift;
+    mask |= 255u << shift;
+    if (below + ex + cnt <= limit || shift == 0) return prefix | (shift ? (1u << shift) - 1u : 0u);
+    below += ex;
+    kk -= ex;
+  }
+}
+__global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, u32* next_job,
+                                                     HitSeed* seeds, Counters* ctr) {
+  __shared__ TopkLds S;
+  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+  const u32 lane = threadIdx.x & 63;
+  u64 reads = 0;
+  for (;;) {
+    __syncthreads();  // the previous job's buffers are free
+    if (threadIdx.x == 0) S.job = atomicAdd(next_job, 1u);
+    __syncthreads();
+    const u32 jb = S.job;
+    if (jb >= njobs) break;
+    const BigJob J = jobs[jb];
+    if (J.take > TOPK_KMAX) continue;  // k_locate_big's
+    const u32 k = J.take;
+    const u64 lo = J.lo, hi = (u64)J.lo + J.occs;
+    // full blocks of level j inside [lo, hi): [A(j), B(j))
+    auto A = [&](int j) -> u64 { return (lo + ((1ULL << (3 * j)) - 1)) >> (3 * j); };
+    auto B = [&](int j) -> u64 { return hi >> (3 * j); };
+    auto N = [&](int j) -> u64 { return B(j) > A(j) ? B(j) - A(j) : 0ULL; };
+    int L = 0;
+    while (L + 1 < (int)f.nlev && N(L) > TOPK_VMAX - 16) ++L;  // a level left with more than 9 216 blocks has > 1 000 in the next
+    if (N(L) > TOPK_VMAX - 16) continue;  // cannot happen: the top level of FmView::samin holds <= 64 blocks
+    u32 nv = (u32)N(L);
+    {
+      const u32* src = f.samin[L] + A(L);
+      for (u32 i = threadIdx.x; i < nv; i += 256) S.val[i] = src[i];
+      reads += nv;
+    }
+    u32 nc_prev = 0;
+    int cur = 0;
+    bool top = true;
+    __syncthreads();
+    for (int j = L;; --j) {
+      const u32 limit = j == 0 ? k : TOPK_KCAP;
+      const u32 T = nv > limit ? topk_threshold(S, nv, k, limit) : 0xFFFFFFFEu;
+      if (threadIdx.x == 0) S.n_kept = 0;
+      __syncthreads();
+      if (j == 0) {  // the survivors are the answer: collect, sort, write
+        u32* buf = &S.cidx[0][0];
+        for (u32 base = 0; base < nv; base += 256) {
+          const u32 p = base + threadIdx.x;
+          const u32 x = p < nv ? S.val[p] : TOPK_PAD;
+          const bool keep = x <= T && x != TOPK_PAD;
+          const unsigned long long mk = __ballot(keep);
+          u32 at = 0;
+          if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
+          at = __shfl(at, 0);
+          if (keep) buf[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = x;
+        }
+        __syncthreads();
+        const u32 have = S.n_kept;  // == k (positions are distinct) unless the whole interval is shorter
+        u32 n2 = 1;
+        while (n2 < have) n2 <<= 1;
+        for (u32 i = have + threadIdx.x; i < n2; i += 256) buf[i] = TOPK_PAD;
+        __syncthreads();
+        for (u32 kk = 2; kk <= n2; kk <<= 1)
+          for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (u32 i = threadIdx.x; i < n2; i += 256) {
+              const u32 l = i ^ jj;
+              if (l > i) {
+                const u32 a = buf[i], b2 = buf[l];
+                if ((a > b2) == ((i & kk) == 0)) {
+                  buf[i] = b2;
+                  buf[l] = a;
+                }
+              }
+            }
+            __syncthreads();
+          }
+        for (u32 i = threadIdx.x; i < k; i += 256) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len};
+        break;
+      }
+      // blocks of level j under the threshold -> cidx[cur ^ 1]
+      for (u32 base = 0; base < nv; base += 256) {
+        const u32 p = base + threadIdx.x;
+        const u32 x = p < nv ? S.val[p] : TOPK_PAD;
+        const bool keep = x <= T && x != TOPK_PAD;
+        u32 idx = 0;
+        if (keep) idx = top ? (u32)(A(L) + p) : (p < 8 * nc_prev ? S.cidx[cur][p >> 3] * 8u + (p & 7u) : S.eidx[p - 8 * nc_prev]);
+        const unsigned long long mk = __ballot(keep);
+        u32 at = 0;
+        if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
+        at = __shfl(at, 0);
+        if (keep) S.cidx[cur ^ 1][at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = idx;
+      }
+      __syncthreads();
+      const u32 nc = S.n_kept;
+      cur ^= 1;
+      top = false;
+      // their children, and the blocks of level j-1 that stick out at either end of the interval
+      const u32* lv = f.samin[j - 1];
+      const u64 nlow = j - 1 == 0 ? f.n : ~0ULL;  // level 0 is the suffix array itself: nothing beyond n
+      for (u32 i = threadIdx.x; i < nc; i += 256) {
+        const u64 c8 = (u64)S.cidx[cur][i] * 8;
+        const uint4 x = *reinterpret_cast<const uint4*>(lv + c8), y = *reinterpret_cast<const uint4*>(lv + c8 + 4);
+        u32 v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) S.val[8 * i + t] = c8 + t < nlow ? v[t] : TOPK_PAD;
+      }
+      const u64 a1 = A(j), b1 = B(j), a0 = A(j - 1), b0 = B(j - 1);
+      const u32 nl = (u32)(8 * a1 - a0), nr = (u32)(b0 - 8 * b1);
+      if (threadIdx.x < nl + nr) {
+        const u64 e = threadIdx.x < nl ? a0 + threadIdx.x : 8 * b1 + (threadIdx.x - nl);
+        S.eidx[threadIdx.x] = (u32)e;
+        S.val[8 * nc + threadIdx.x] = lv[e];
+      }
+      reads += 8ULL * nc + nl + nr;
+      nv = 8 * nc + nl + nr;
+      nc_prev = nc;
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2652,6 +2877,9 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     ra8[len >> 3] = wr;
     qa8[len >> 3] = wq;
   }
+  // a row longer than the stride run_batch derived (query + d gap columns) would have been cut above: fail the batch loudly
+  // (the host repeats it a few times and then reports a persisting overflow) rather than hand out a truncated row
+  if (len > a.stride) atomicOr(&ctr->overflow, 1u);
   chrpos += lead;
   out.start = chrpos + 1;
   out.aln_len = (u16)len;
@@ -2898,16 +3126,21 @@ struct CapScan {
   std::vector<u32> xs_gid;
   u64 looked_at = 0, fired = 0;
 };
-static void cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_params* p, bool count_mode, CapScan& cs) {
+// Returns DG_OK, DG_ELIMIT when the explicit patterns of this batch would not fit the host budget (the caller passes fewer
+// sequences per call: `dicey hunt` halves its chunk and retries), DG_ENOMEM when an enumeration ran out of memory.
+static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_params* p, bool count_mode, CapScan& cs) {
   const bool indel = !p->hamming;
   struct Job {
     size_t q;
     std::string fw, rv;
     u32 d;
-    std::vector<std::string> set[2];
+    // the set of each strand, flattened to codes as soon as its enumeration ends (the std::set-ordered strings are freed there)
+    std::vector<u8> bytes[2];
+    std::vector<u32> lens[2];
     bool fired[2] = {false, false};
   };
   std::vector<Job> jobs;
+  u64 worst_bytes = 0;  // what the explicit patterns could need if the cap fired on every strand looked at
   for (size_t q = 0; q < nq; ++q) {
     const u64 s = qoff[q], m = qoff[q + 1] - s;
     if (m < 10 && !count_mode) continue;  // hunter.h:299: not searched at all
@@ -2931,21 +3164,45 @@ static void cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt
       j.fw[i] = dna ? (char)ch : 'N';
       j.rv[m - 1 - i] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : 'N';
     }
+    // a fired strand holds < max_neighborhood + 10 (one position's worth) strings of <= m + d characters, + offset and group words
+    worst_bytes += (p->forward_only ? 1ull : 2ull) * ((u64)p->max_neighborhood + 16) * (m + d + 12);
     jobs.push_back(std::move(j));
   }
-  if (jobs.empty()) return;
+  if (jobs.empty()) return DG_OK;
+  u64 budget = 16ull << 30;
+  if (const char* e = std::getenv("DICEY_CAP_BUDGET_MB")) budget = (u64)std::max(1, std::atoi(e)) << 20;
+  if (worst_bytes > budget)
+    return fail(DG_ELIMIT, "%zu of the %zu sequences of this call can reach the maxNeighborhood cap (%u); their explicit neighbourhoods may need "
+                "%llu MB of host memory (budget %llu MB): pass fewer sequences per call", jobs.size(), nq, p->max_neighborhood,
+                (unsigned long long)(worst_bytes >> 20), (unsigned long long)(budget >> 20));
   const bool reverse = !p->forward_only;
   std::atomic<size_t> next{0};
+  std::atomic<int> oom{0};
   auto work = [&]() {
     for (;;) {
       const size_t k = next.fetch_add(1);
-      if (k >= jobs.size() * 2) return;
+      if (k >= jobs.size() * 2 || oom.load()) return;
       Job& j = jobs[k >> 1];
       const int strand = (int)(k & 1);
       if (strand && !reverse) continue;
-      bool fired = false;
-      j.set[strand] = CappedNeighborhood::enumerate(strand ? j.rv : j.fw, j.d, indel, p->max_neighborhood, fired);
-      j.fired[strand] = fired;
+      try {
+        bool fired = false;
+        const std::vector<std::string> set = CappedNeighborhood::enumerate(strand ? j.rv : j.fw, j.d, indel, p->max_neighborhood, fired);
+        j.fired[strand] = fired;
+        if (fired) {  // only a capped set travels; a silent one is what the kernel enumerates itself
+          size_t tot = 0;
+          for (const std::string& str : set) tot += str.size();
+          j.bytes[strand].reserve(tot);
+          j.lens[strand].reserve(set.size());
+          for (const std::string& str : set) {
+            for (char ch : str) j.bytes[strand].push_back(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4);
+            j.lens[strand].push_back((u32)str.size());
+          }
+        }
+      } catch (const std::bad_alloc&) {
+        oom.store(1);
+        return;
+      }
     }
   };
   unsigned nthreads = std::thread::hardware_concurrency();
@@ -2958,23 +3215,41 @@ static void cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt
     for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(work);
     for (auto& t : pool) t.join();
   }
-  cs.mode.assign(nq, (u8)QM_KERNEL);
-  cs.xs_off.assign(1, 0);
-  cs.looked_at = jobs.size();
-  for (Job& j : jobs) {
-    if (!j.fired[0] && !j.fired[1]) {
-      cs.mode[j.q] = QM_SILENT;
-      continue;
-    }
-    ++cs.fired;
-    cs.mode[j.q] = QM_EXPLICIT | QM_FIRED;
-    for (int strand = 0; strand < 2; ++strand)
-      for (const std::string& str : j.set[strand]) {
-        for (char ch : str) cs.xs_bytes.push_back(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4);
-        cs.xs_off.push_back(cs.xs_bytes.size());
-        cs.xs_gid.push_back((u32)(2 * j.q + strand));
+  if (oom.load()) return fail(DG_ENOMEM, "out of host memory while enumerating capped neighbourhoods; pass fewer sequences per call");
+  try {
+    cs.mode.assign(nq, (u8)QM_KERNEL);
+    cs.xs_off.assign(1, 0);
+    cs.looked_at = jobs.size();
+    for (Job& j : jobs) {
+      if (!j.fired[0] && !j.fired[1]) {
+        cs.mode[j.q] = QM_SILENT;
+        continue;
       }
+      ++cs.fired;
+      cs.mode[j.q] = QM_EXPLICIT | QM_FIRED;
+      for (int strand = 0; strand < 2; ++strand) {
+        if (strand && !reverse) continue;
+        if (!j.fired[strand]) {
+          // the other strand fired: this one's (silent) set travels as explicit patterns too, the query is off the kernel path
+          bool f2 = false;
+          for (const std::string& str : CappedNeighborhood::enumerate(strand ? j.rv : j.fw, j.d, indel, p->max_neighborhood, f2)) {
+            for (char ch : str) j.bytes[strand].push_back(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4);
+            j.lens[strand].push_back((u32)str.size());
+          }
+        }
+        cs.xs_bytes.insert(cs.xs_bytes.end(), j.bytes[strand].begin(), j.bytes[strand].end());
+        for (u32 l : j.lens[strand]) {
+          cs.xs_off.push_back(cs.xs_off.back() + l);
+          cs.xs_gid.push_back((u32)(2 * j.q + strand));
+        }
+        std::vector<u8>().swap(j.bytes[strand]);
+        std::vector<u32>().swap(j.lens[strand]);
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return fail(DG_ENOMEM, "out of host memory while collecting capped neighbourhoods; pass fewer sequences per call");
   }
+  return DG_OK;
 }
 
 // One batch through the five kernels.  All sizes that are only known on the device (number of leaves, number of hits)
@@ -3032,7 +3307,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       h_qbytes = hb.data();
       h_qoff = ho.data();
     }
-    cap_scan(h_qbytes, h_qoff, nq, p, group_counts != nullptr, cs);
+    DG_TRY(cap_scan(h_qbytes, h_qoff, nq, p, group_counts != nullptr, cs));
   }
   const u64 nxs = cs.xs_gid.size();
   if (nxs >= 0xFFFFFFFFull || cs.xs_bytes.size() > (48ull << 30))
@@ -3144,7 +3419,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_TRY(ws[WS_SEEDS].reserve((hit_cap + 1) * sizeof(HitSeed)));
     if (b.fastK && std::getenv("DICEY_FLAT1_SPLIT")) DG_TRY(ws[WS_MISC].reserve(((u64)NSHARD << surv_cap_log2) * 4 + 64));
     u32 surv_cap = 0xFFFFFFFFu;  // set where the survivor queue is used
-    DG_TRY(ws[WS_JOBS].reserve(std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
+    DG_TRY(ws[WS_JOBS].reserve(2 * std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
     DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
     DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
@@ -3254,16 +3529,32 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
     DG_HIP(hipEventRecord(ix->ev[5], st));
     {
-      // strings with many occurrences go to a job list served by one workgroup each
+      // strings with many occurrences go to two job lists: up to 256 occurrences for a wavefront each, more for a workgroup each
       static const bool no_block = std::getenv("DICEY_NO_BLOCK_LOCATE") != nullptr;  // debugging aid (per-lane path only)
       const u32 job_cap = (u32)std::min<u64>(leaf_slots, 1u << 20);
-      BigJob* jobs = no_block ? nullptr : ws[WS_JOBS].as<BigJob>();
-      u32* job_count = (u32*)&ctr->pad_[0];
-      hipLaunchKernelGGL(k_locate, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, ix->view, ws[WS_SEL].as<Sel>(), grp_off, nsel, ngrp,
-                         hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, jobs, job_cap, job_count);
-      if (!no_block)
-        hipLaunchKernelGGL(k_locate_big, dim3(1024), dim3(256), 0, st, ix->view, (const BigJob*)jobs, (const u32*)job_count, job_cap,
+      LocJobs lj;
+      lj.small = no_block ? nullptr : ws[WS_JOBS].as<BigJob>();
+      lj.big = no_block ? nullptr : ws[WS_JOBS].as<BigJob>() + job_cap;
+      lj.cap = job_cap;
+      lj.n_big = (u32*)&ctr->pad_[0];
+      lj.n_small = (u32*)&ctr->pad_[4];
+      // the record that shares a kept string's slot names its group: the packed leaf (qs behind 28 bytes) or the grouped leaf (qs first)
+      const u8* slot_qs = packed ? (const u8*)ws[WS_LEAFG].p + offsetof(PLeaf, qs) : (const u8*)ws[WS_LEAFG].p + offsetof(Leaf, qs);
+      const u32 slot_stride = packed ? (u32)sizeof(PLeaf) : (u32)sizeof(Leaf);
+      hipLaunchKernelGGL(k_locate, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ix->view, (const Sel*)ws[WS_SEL].as<Sel>(), slot_qs, slot_stride,
+                         (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj);
+      if (!no_block) {
+        hipLaunchKernelGGL(k_locate_small, dim3(8192), dim3(64), 0, st, ix->view, (const BigJob*)lj.small, (const u32*)lj.n_small, job_cap,
                            ws[WS_SEEDS].as<HitSeed>(), ctr);
+        // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
+        const bool topk = ix->view.nlev > 1;
+        if (topk)
+          hipLaunchKernelGGL(k_locate_topk, dim3(768), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
+                             (u32*)&ctr->pad_[3], ws[WS_SEEDS].as<HitSeed>(), ctr);
+        if (!topk || p->max_locations > TOPK_KMAX)
+          hipLaunchKernelGGL(k_locate_big, dim3(1024), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
+                             ws[WS_SEEDS].as<HitSeed>(), ctr, topk ? TOPK_KMAX : 0u);
+      }
     }
     DG_HIP(hipEventRecord(ix->ev[6], st));
     if (sx) {
@@ -3315,6 +3606,21 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (hsum.refused)
       return fail(DG_EINVAL, "internal error: %llu quer%s could reach the maxNeighborhood cap (%u) without having been enumerated on the host",
                   hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
+    if (const char* dj = std::getenv("DICEY_DUMP_JOBS")) {  // development aid: the repeat-rich strings of this batch (lo, occs, take, g, len, out)
+      u32 nj = 0;
+      DG_HIP(hipMemcpy(&nj, &ctr->pad_[0], 4, hipMemcpyDeviceToHost));
+      nj = std::min<u32>(nj, (u32)std::min<u64>(leaf_slots, 1u << 20));
+      std::vector<BigJob> hj(nj);
+      if (nj) DG_HIP(hipMemcpy(hj.data(), ws[WS_JOBS].as<BigJob>() + std::min<u64>(leaf_slots, 1u << 20), (size_t)nj * sizeof(BigJob), hipMemcpyDeviceToHost));
+      if (FILE* fj = std::fopen(dj, "wb")) {
+        std::fwrite(&nj, 4, 1, fj);
+        for (const BigJob& j : hj) {
+          const u32 rec[3] = {j.occs, j.take, j.len};
+          std::fwrite(rec, 4, 3, fj);
+        }
+        std::fclose(fj);
+      }
+    }
     nleaf = hsum.nleaf;
     nhits = hsum.nhits;
     if (surv_cap != 0xFFFFFFFFu && hsum.worst_surv > surv_cap) {
@@ -3520,22 +3826,32 @@ int dg_neighbors(const uint8_t* seq, uint32_t len, uint32_t distance, int hammin
   if (!seq || !out) return fail(DG_EINVAL, "dg_neighbors: null argument");
   *out = nullptr;
   if (len == 0 || len > 0xFFFFFFu) return fail(DG_EINVAL, "dg_neighbors: sequence length %u", len);
-  bool fired = false;
-  const std::vector<std::string> set = CappedNeighborhood::enumerate(std::string((const char*)seq, len), distance, !hamming, max_neighborhood, fired);
-  size_t bytes = 1;
-  for (const std::string& s : set) bytes += s.size() + 1;
-  char* buf = (char*)std::malloc(bytes);
-  if (!buf) return fail(DG_ENOMEM, "dg_neighbors: out of memory");
-  char* w = buf;
-  for (const std::string& s : set) {
-    std::memcpy(w, s.data(), s.size());
-    w += s.size();
-    *w++ = '\n';
+  // the enumeration is exponential in the distance and bounded only by the cap: keep to what the hunt path itself supports
+  if (distance > DMAX) return fail(DG_ELIMIT, "dg_neighbors: distance %u exceeds the supported maximum of %u", distance, DMAX);
+  if (distance >= len) return fail(DG_EINVAL, "dg_neighbors: distance %u must be smaller than the sequence length %u (hunter.h:312-315 clamps it first)", distance, len);
+  if (max_neighborhood > (1u << 24)) return fail(DG_ELIMIT, "dg_neighbors: max_neighborhood %u exceeds 2^24", max_neighborhood);
+  try {
+    bool fired = false;
+    const std::vector<std::string> set = CappedNeighborhood::enumerate(std::string((const char*)seq, len), distance, !hamming, max_neighborhood, fired);
+    size_t bytes = 1;
+    for (const std::string& s : set) bytes += s.size() + 1;
+    char* buf = (char*)std::malloc(bytes);
+    if (!buf) return fail(DG_ENOMEM, "dg_neighbors: out of memory");
+    char* w = buf;
+    for (const std::string& s : set) {
+      std::memcpy(w, s.data(), s.size());
+      w += s.size();
+      *w++ = '\n';
+    }
+    *w = 0;
+    *out = buf;
+    if (count) *count = set.size();
+    if (cap_fired) *cap_fired = fired;
+  } catch (const std::bad_alloc&) {
+    return fail(DG_ENOMEM, "dg_neighbors: out of memory");
+  } catch (const std::exception& e) {
+    return fail(DG_EINVAL, "dg_neighbors: %s", e.what());
   }
-  *w = 0;
-  *out = buf;
-  if (count) *count = set.size();
-  if (cap_fired) *cap_fired = fired;
   return DG_OK;
 }
 void dg_buffer_free(void* p) { std::free(p); }

@@ -443,6 +443,23 @@ __global__ void __launch_bounds__(256) k_kmer_table_wave(FmView f, uint2* tab, u
   if (kf2 && !(me2 >> 63) && (lane == 0 || prev2 != me2)) atomicOr(&kf2[me2 >> 5], 1u << (me2 & 31));
 }
 
+// Block minima of the suffix array, fan-out 8 (FmView::samin): one lane per block, two 16-byte loads.
+__global__ void __launch_bounds__(256) k_block_min8(const u32* in, u64 n_in, u32* out, u64 n_out, u64 n_out_padded) {
+  const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_out_padded) return;
+  u32 m = 0xFFFFFFFFu;
+  if (b < n_out) {
+    const u64 i0 = b * 8;
+    if (i0 + 8 <= n_in) {
+      const uint4 x = *reinterpret_cast<const uint4*>(in + i0), y = *reinterpret_cast<const uint4*>(in + i0 + 4);
+      m = min(min(min(x.x, x.y), min(x.z, x.w)), min(min(y.x, y.y), min(y.z, y.w)));
+    } else {
+      for (u64 i = i0; i < n_in; ++i) m = min(m, in[i]);
+    }
+  }
+  out[b] = m;
+}
+
 struct PhaseClock {  // DICEY_TIMING=1: host wall clock of the load phases on stderr
   bool on = std::getenv("DICEY_TIMING") != nullptr;
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -600,6 +617,27 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
       DG_TRY(build_filter(ix, f.kf2, K2, nullptr, f2));
       pc.lap("long presence filter");
     }
+  }
+  // block minima over the suffix array for the top-k locate (0.57 n bytes; one streaming pass over SA)
+  f.samin[0] = sa;
+  f.nlev = 1;
+  if (!std::getenv("DICEY_NO_SA_MINIMA")) {
+    u64 cnt = n;
+    const u32* prev = sa;
+    while (cnt > 8 && f.nlev < FmView::MAXLEV) {
+      const u64 nout = (cnt + 7) / 8, npad = ((nout + 7) & ~7ULL) + 8;
+      u32* lv = nullptr;
+      DG_HIP(big_alloc((void**)&lv, npad * 4, ix->stream));
+      ix->owned.push_back(lv);
+      ix->hbm_bytes += npad * 4;
+      hipLaunchKernelGGL(k_block_min8, dim3(ceil_div(npad, TB)), dim3(TB), 0, ix->stream, prev, cnt, lv, nout, npad);
+      f.samin[f.nlev++] = lv;
+      prev = lv;
+      cnt = nout;
+    }
+    DG_HIP(hipStreamSynchronize(ix->stream));
+    DG_HIP(hipGetLastError());
+    pc.lap("suffix-array block minima");
   }
   if (!(flags & DG_OPEN_NO_SELFCHECK)) {
     DG_HIP(hipMalloc((void**)&bad, 4));

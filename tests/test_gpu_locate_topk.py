@@ -1,0 +1,116 @@
+"""k_locate_topk (r03): the `max_locations` smallest positions of a repeat-rich interval through the suffix array's block
+minima instead of passes over the interval (hunter.h:355-357: locate, std::sort, first min(occs, max_locations) entries).
+Every case is compared with the oracle hit for hit; the genomes are built so that the walk starts at level 0, 1, 2 and 3 of the
+hierarchy, with positions spread, clustered (tandem array) and mixed."""
+import random
+
+import pytest
+
+try:
+    import torch
+    torch.cuda.is_available()
+except Exception:  # pragma: no cover
+    torch = None
+
+import oracle_lib as O
+from conftest import genome_text
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(ix, orc, g, qs, **kw):
+    got = ix.hunt(qs, g["seqlen"], **kw)
+    _, hits = orc.hunt(g["seqlen"], g["names"], qs, want_hits=True, **kw)
+    per = {}
+    for h in hits:
+        per.setdefault(h[0], []).append(h[1:])
+    for qi, qr in enumerate(got.queries):
+        a = [(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in qr.hits]
+        assert a == per.get(qi, []), (qi, qs[qi], kw, len(a), len(per.get(qi, [])))
+    return got
+
+
+def _planted(seed, copies, background, tandem=0, unit_len=20, divergent=0.0):
+    """two sequences: `copies` copies of a random unit at random places of a random background (+ a tandem array of `tandem` units)"""
+    rng = random.Random(seed)
+    unit = "".join(rng.choice("ACGT") for _ in range(unit_len))
+    n = background
+    bg = bytearray(rng.choice(b"ACGT") for _ in range(n))
+    taken = set()
+    for _ in range(copies):
+        p = rng.randrange(0, n - unit_len - 1)
+        u = unit
+        if divergent and rng.random() < divergent:
+            k = rng.randrange(unit_len)
+            u = u[:k] + rng.choice("ACGT") + u[k + 1:]
+        bg[p:p + unit_len] = u.encode()
+        taken.add(p)
+    s = bg.decode()
+    if tandem:
+        cut = n // 3
+        s = s[:cut] + unit * tandem + s[cut:]
+    half = len(s) // 2
+    return unit, [s[:half], s[half:]]
+
+
+def _index(tmp_path, seqs, name):
+    import dicey_amd
+    text = genome_text(seqs)
+    path = str(tmp_path / name)
+    dicey_amd.build_index(text, path, device=0)  # the GPU builder (byte-identical to the oracle's, tests/test_gpu_parity.py)
+    return path, {"seqlen": [len(s) + 1 for s in seqs], "names": ["r%d" % (i + 1) for i in range(len(seqs))]}
+
+
+@pytest.mark.parametrize("copies,background,tandem", [
+    (3000, 400_000, 0),        # level 0: the interval fits the LDS buffer
+    (40_000, 3_000_000, 0),    # starts at level 1
+    (150_000, 8_000_000, 0),   # starts at level 2, spread positions
+    (20_000, 2_000_000, 30_000),  # spread copies + a tandem array: most of the smallest positions share their top bytes
+])
+def test_topk_locate_equals_oracle(tmp_path, copies, background, tandem):
+    import dicey_amd
+    unit, seqs = _planted(copies + tandem, copies, background, tandem, divergent=0.2)
+    path, g = _index(tmp_path, seqs, "rep.fm9")
+    orc = O.Index(path)
+    sub = unit[:19] + ("A" if unit[19] != "A" else "C")
+    qs = [unit, sub, unit[1:] + "G", unit[:10] + unit[11:] + "T", seqs[0][5000:5020], unit[2:] + "AC"]
+    with dicey_amd.FmIndex(path) as ix:
+        for kw in (dict(distance=0, max_locations=1000), dict(distance=1, max_locations=1000), dict(distance=1, max_locations=3),
+                   dict(distance=0, max_locations=1024), dict(distance=0, max_locations=1025), dict(distance=1, max_locations=700),
+                   dict(distance=1, hamming=True, max_locations=40), dict(distance=0, max_locations=1, forward_only=True),
+                   dict(distance=1, max_locations=2500)):
+            got = _compare(ix, orc, g, qs, **kw)
+            assert len(got.queries[0].hits) == min(kw["max_locations"], len(got.queries[0].hits))
+        assert len(ix.hunt([unit], g["seqlen"], distance=0, max_locations=1000).queries[0].hits) == 1000
+
+
+def test_topk_locate_million_copy_family(tmp_path):
+    """an Alu-scale family: 1.1 M copies of a 20-mer over 40 Mb (level 3 of the hierarchy), the first 1000 positions"""
+    import dicey_amd
+    rng = random.Random(77)
+    unit = "".join(rng.choice("ACGT") for _ in range(20))
+    parts = []
+    for i in range(1_100_000):
+        parts.append(unit)
+        parts.append("".join(rng.choice("ACGT") for _ in range(rng.randint(8, 24))))
+    s = "".join(parts)
+    third = len(s) // 3
+    seqs = [s[:third], s[third:2 * third], s[2 * third:]]
+    path, g = _index(tmp_path, seqs, "alu.fm9")
+    text = genome_text(seqs)
+    # expected positions straight from the text (the oracle's locate of 1.1 M occurrences takes minutes)
+    want, p = [], text.find(unit.encode())
+    while p >= 0 and len(want) < 1000:
+        want.append(p)
+        p = text.find(unit.encode(), p + 1)
+    with dicey_amd.FmIndex(path) as ix:
+        for m in (1000, 7):
+            R = ix.hunt([unit], g["seqlen"], distance=0, max_locations=m, forward_only=True)
+            hits = R.queries[0].hits
+            assert len(hits) == m
+            cum = [0]
+            for x in g["seqlen"]:
+                cum.append(cum[-1] + x)
+            got = [cum[h.chr] + h.start - 1 for h in hits]
+            assert got == want[:m]
+            assert all(h.score == 0 and h.refalign == unit and h.queryalign == unit for h in hits)

@@ -17,14 +17,18 @@ DICEY = os.path.join(ROOT, "dicey_amd", "dicey")
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "padlock_golden.json")))
 
 
-@pytest.fixture(scope="module")
-def scenario(tmp_path_factory):
+def make_scenario(tmp_path_factory):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "dicey_amd", "cli"), "-s"])
     d = str(tmp_path_factory.mktemp("padlock"))
     sc = F.build(d)
     assert subprocess.run([DICEY, "index", sc["fa"]], capture_output=True).returncode == 0   # the GPU builder writes the .fm9
     sc["orc"] = O.Index(sc["fm9"])
     return sc
+
+
+@pytest.fixture(scope="module")
+def scenario(tmp_path_factory):
+    return make_scenario(tmp_path_factory)
 
 
 def run_binary(sc, case):

@@ -17,8 +17,7 @@ DICEY = os.path.join(ROOT, "dicey_amd", "dicey")
 needs_ref = pytest.mark.skipif(O.ref_libs() is None, reason="oracle/_ref (reference thal.h / json.hpp builds) not present")
 
 
-@pytest.fixture(scope="module")
-def pcr(tmp_path_factory):
+def make_pcr(tmp_path_factory):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "dicey_amd", "cli"), "-s"])
     d = tmp_path_factory.mktemp("pcr")
     seqs = make_genome(61, 3, 25000)
@@ -52,6 +51,11 @@ def pcr(tmp_path_factory):
     pf.write_text(fasta)
     return {"dir": d, "fa": str(fa), "fm9": str(d / "genome.fa.fm9"), "seqs": seqs, "names": names, "text": genome_text(seqs),
             "seqlen": [len(s) + 1 for s in seqs], "primers": str(pf), "fasta": fasta}
+
+
+@pytest.fixture(scope="module")
+def pcr(tmp_path_factory):
+    return make_pcr(tmp_path_factory)
 
 
 @needs_ref

@@ -4,10 +4,16 @@
 //   (1) the random-gather ceiling that puts roofline.frac into context;
 //   (2) a known byte count to calibrate rocprofv3 FETCH_SIZE for this access pattern (MI355X_MICROARCH.md §HBM).
 // usage: gather_bench <buffer_GiB> <lines_per_lane> <dependent:0|1> <lanes>
+//        gather_bench filter <copy_GiB> <strands> <lines_per_strand>   (r03)
+// `filter`: the access shape of k_search1p's probe phase — four copies of a presence filter (copy_GiB each), one lane per
+// (strand, position) with 20 positions per strand, eight independent 4-byte loads per lane; the 160 probes of a strand fall
+// into <lines_per_strand> distinct random 64-byte lines (neighbouring positions share lines, like the kernel's choice of copy
+// by edit position).  Reports lines/s and probes/s.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <cstring>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -38,26 +44,87 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* buf, uint64_t nline
   out[t] = acc;
 }
 
-int main(int argc, char** argv) {
-  double gib = argc > 1 ? atof(argv[1]) : 2.0;
-  int iters = argc > 2 ? atoi(argv[2]) : 256;
-  int dep = argc > 3 ? atoi(argv[3]) : 1;
-  uint64_t lanes = argc > 4 ? strtoull(argv[4], 0, 10) : 200000;
-  lanes = (lanes + 255) / 256 * 256;
-  uint64_t bytes = (uint64_t)(gib * (1ull << 30)) / 64 * 64, nlines = bytes / 64;
-  uint4* buf; uint64_t* out;
-  CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, lanes * 8));
+// one lane per (strand, position): 8 probes, spread over the strand's `lps` lines so that neighbouring positions share lines
+__global__ void __launch_bounds__(256) k_filter(const uint32_t* buf, uint64_t lines_per_copy, uint32_t lps, uint64_t nstrands, uint64_t* out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t strand = t / 20;
+  const uint32_t pos = (uint32_t)(t - strand * 20);
+  if (strand >= nstrands) return;
+  const uint32_t* addr[8];
+#pragma unroll
+  for (int op = 0; op < 8; ++op) {
+    const uint32_t slot = (pos * lps / 20 + (op >= 4 ? 1u : 0u)) % lps;  // two neighbouring line slots per position
+    const uint64_t h = mix(strand * 64 + slot + 1);
+    const uint64_t copy = slot * 4 / lps;  // line slots map to the four copies in turn, like edit positions do
+    const uint64_t line = copy * lines_per_copy + h % lines_per_copy;
+    addr[op] = buf + line * 16 + (mix(t * 8 + op) & 15);
+  }
+  uint32_t w[8];
+#pragma unroll
+  for (int op = 0; op < 8; ++op) w[op] = *addr[op];
+  uint32_t acc = 0;
+#pragma unroll
+  for (int op = 0; op < 8; ++op) acc += w[op];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+static int filter_main(int argc, char** argv) {
+  const double gib = argc > 2 ? atof(argv[2]) : 8.0;
+  const uint64_t strands = argc > 3 ? strtoull(argv[3], 0, 10) : 200000;
+  const uint32_t lps = argc > 4 ? (uint32_t)atoi(argv[4]) : 12;
+  const uint64_t lines_per_copy = (uint64_t)(gib * (1ull << 30)) / 64, bytes = lines_per_copy * 64 * 4;
+  uint32_t* buf; uint64_t* out;
+  CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, 64));
   CK(hipMemset(buf, 1, bytes));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int rep = 0; rep < 3; ++rep) {
+  const uint64_t lanes = (strands * 20 + 255) / 256 * 256;
+  for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(a, 0));
-    if (dep) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<true, 2>), dim3(lanes / 256), dim3(256), 0, 0, buf, nlines, iters, out);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<false, 2>), dim3(lanes / 256), dim3(256), 0, 0, buf, nlines, iters, out);
+    hipLaunchKernelGGL(k_filter, dim3(lanes / 256), dim3(256), 0, 0, buf, lines_per_copy, lps, strands, out);
     CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
-    double total = (double)lanes * iters * 2 * 64;
-    printf("{\"tool\":\"gather_bench\",\"buffer_GiB\":%.2f,\"lanes\":%llu,\"iters\":%d,\"dependent\":%d,\"bytes\":%.0f,\"ms\":%.3f,\"GBps\":%.1f,\"Glines_per_s\":%.2f}\n",
-           gib, (unsigned long long)lanes, iters, dep, total, ms, total / ms / 1e6, total / 64 / ms / 1e6);
+    printf("{\"tool\":\"gather_bench filter\",\"copies\":4,\"copy_GiB\":%.2f,\"strands\":%llu,\"lines_per_strand\":%u,\"probes\":%llu,\"ms\":%.4f,"
+           "\"Glines_per_s\":%.2f,\"Gprobes_per_s\":%.2f}\n", gib, (unsigned long long)strands, lps, (unsigned long long)(strands * 160), ms,
+           (double)strands * lps / ms / 1e6, (double)strands * 160 / ms / 1e6);
   }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "filter")) return filter_main(argc, argv);
+  double gib = argc > 1 ? atof(argv[1]) : 2.0;
+  int iters = argc > 2 ? atoi(argv[2]) : 256;
+  int dep_arg = argc > 3 ? atoi(argv[3]) : 1;  // 2 = both forms
+  // lanes: one value or a comma-separated list (one allocation serves all of them)
+  uint64_t lane_list[16];
+  int nl = 0;
+  {
+    const char* p = argc > 4 ? argv[4] : "200000";
+    while (*p && nl < 16) {
+      lane_list[nl++] = (strtoull(p, (char**)&p, 10) + 255) / 256 * 256;
+      if (*p == ',') ++p;
+    }
+  }
+  uint64_t max_lanes = 0;
+  for (int i = 0; i < nl; ++i) max_lanes = lane_list[i] > max_lanes ? lane_list[i] : max_lanes;
+  uint64_t bytes = (uint64_t)(gib * (1ull << 30)) / 64 * 64, nlines = bytes / 64;
+  uint4* buf; uint64_t* out;
+  CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, max_lanes * 8));
+  CK(hipMemset(buf, 1, bytes));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int li = 0; li < nl; ++li)
+    for (int dep = (dep_arg == 2 ? 0 : dep_arg); dep <= (dep_arg == 2 ? 1 : dep_arg); ++dep) {
+      const uint64_t lanes = lane_list[li];
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(a, 0));
+        if (dep) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<true, 2>), dim3(lanes / 256), dim3(256), 0, 0, buf, nlines, iters, out);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<false, 2>), dim3(lanes / 256), dim3(256), 0, 0, buf, nlines, iters, out);
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        double total = (double)lanes * iters * 2 * 64;
+        printf("{\"tool\":\"gather_bench\",\"buffer_GiB\":%.2f,\"lanes\":%llu,\"iters\":%d,\"dependent\":%d,\"bytes\":%.0f,\"ms\":%.3f,\"GBps\":%.1f,\"Glines_per_s\":%.2f}\n",
+               gib, (unsigned long long)lanes, iters, dep, total, ms, total / ms / 1e6, total / 64 / ms / 1e6);
+      }
+    }
   return 0;
 }

@@ -435,12 +435,13 @@ def main():
                                             C.c_void_p(d_off.data_ptr()), nq, len(qbytes), fetch, C.byref(rp)))
             R = rp.contents
             res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes,
-                   "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "aln_stride": R.aln_stride, "ms_total": R.ms_total, "ms_search": R.ms_search,
+                   "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify}
             if world > 1 and not fetch:
-                gather_parts([device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), dev),
-                              device_bytes(R.d_refalign, R.nhits * R.aln_stride, dev),
-                              device_bytes(R.d_queryalign, R.nhits * R.aln_stride, dev)])
+                parts = [device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), dev)]
+                if R.ops_per_hit and R.nhits:  # compact alignment description (dicey_gpu.h): 4 bytes per unit of distance
+                    parts.append(device_bytes(R.d_ops, R.nhits * R.ops_per_hit * 4, dev))
+                gather_parts(parts)
             L.dg_hunt_result_free(rp)
             return res
 
@@ -457,9 +458,10 @@ def main():
             torch.cuda.synchronize()
             dtf = time.perf_counter() - tp
             extras["value_with_d2h"] = {"value": nq * a.steps / dtf, "unit": "primers/s", "ms_per_step": dtf / a.steps * 1e3,
-                                        "note": "same steps with fetch=1: hit records, alignment rows, flags and normalised queries copied to "
-                                                "host memory after every batch (pageable host buffers, blocking copies)",
-                                        "hit_record_bytes_per_step": int(acc[-1]["nhits"]) * C.sizeof(_capi.Hit)}
+                                        "note": "same steps with fetch=1: hit records with their compact alignment description (20 + 4 d bytes per "
+                                                "hit; dg_hit_rows rebuilds the two rows), flags and normalised queries copied into a pinned "
+                                                "block from the library's pool after every batch",
+                                        "hit_bytes_per_step": int(acc[-1]["nhits"]) * (C.sizeof(_capi.Hit) + 4 * int(acc[-1]["ops_per_hit"]))}
             cli_job = (queries, distance)  # measured in the common tail, after this process has released its own index
         if world == 1 and a.pipeline > 1:
             import threading
@@ -597,16 +599,18 @@ def main():
             stage = max(("ms_search", "ms_select", "ms_locate", "ms_verify"), key=lambda k_: ph[k_])
             if stage in ("ms_locate", "ms_verify") and ph[stage] > 0:
                 hits, sa = mean("nhits"), mean("sa")
-                stride = int(acc[-1].get("aln_stride", 0)) or 24
+                oph = int(acc[-1].get("ops_per_hit", 0))
                 if stage == "ms_locate":
                     dom_kernel = "k_locate_topk (+ k_locate)"
-                    dom_bytes = 4.0 * sa + 12.0 * hits
-                    terms = {"sa_or_minima_words_read": sa, "bytes_per_word": 4, "hit_seeds_written": hits, "bytes_per_seed": 12}
+                    dom_bytes = 4.0 * sa + 16.0 * hits
+                    terms = {"sa_or_minima_words_read": sa, "bytes_per_word": 4, "hit_seeds_written": hits, "bytes_per_seed": 16}
                 else:
-                    dom_kernel = "k_verify_band<7>" if distance <= 1 else "k_verify_band<13>"
-                    dom_bytes = mean("win") + hits * (12.0 + 16.0 + 2.0 * stride)
-                    terms = {"window_bytes_read": mean("win"), "hits": hits, "bytes_per_hit": 12 + 16 + 2 * stride,
-                             "note": "12 B seed in, 16 B hit record + two alignment rows of aln_stride bytes out"}
+                    dom_kernel = "k_verify_memo<7>" if distance <= 1 else "k_verify_memo<13>"
+                    dom_bytes = mean("win") + hits * (16.0 + 20.0 + 4.0 * oph)
+                    terms = {"window_bytes": mean("win"), "hits": hits, "bytes_per_hit": 16 + 20 + 4 * oph,
+                             "note": "window bytes as the reference extracts them (hunter.h:371), 16 B seed in, 20 B hit record + 4 B "
+                                     "per unit of distance out; the kernel itself reads only the <= 2d context bytes of a hit and "
+                                     "aligns once per distinct window"}
                 dom_ach = dom_bytes / (ph[stage] * 1e-3) / 1e9
                 out["roofline_search"] = out["roofline"]
                 out["roofline"] = {"bound": "hbm", "kernel": dom_kernel, "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -160,6 +160,7 @@ class FmIndex:
         R = rp.contents
         qs = []
         seqbuf = C.string_at(R.qseq, R.qoff[R.nq]) if R.nq else b""
+        _capi.check(self._L, self._L.dg_hunt_rows(rp))  # the two rows of every hit from its compact description
         st = R.aln_stride
         for i in range(R.nq):
             q = QueryResult(seqbuf[R.qoff[i]:R.qoff[i + 1]].decode("latin-1"), R.qdistance[i], R.qflags[i], R.qnondna[i])

@@ -39,14 +39,15 @@ class Hit(C.Structure):
 
 class HuntResult(C.Structure):
     _fields_ = [("nq", C.c_size_t), ("nhits", C.c_uint64), ("hit_off", C.POINTER(C.c_uint64)), ("hits", C.POINTER(Hit)),
-                ("aln_stride", C.c_uint32), ("refalign", C.POINTER(C.c_char)), ("queryalign", C.POINTER(C.c_char)),
+                ("ops_per_hit", C.c_uint32), ("aln_stride", C.c_uint32), ("ops", C.POINTER(C.c_uint32)),
+                ("refalign", C.POINTER(C.c_char)), ("queryalign", C.POINTER(C.c_char)),
                 ("qflags", C.POINTER(C.c_uint32)), ("qdistance", C.POINTER(C.c_uint32)), ("qnondna", C.POINTER(C.c_uint32)),
                 ("qseq", C.POINTER(C.c_uint8)), ("qoff", C.POINTER(C.c_uint64)),
                 ("ctr_ext_steps", C.c_uint64), ("ctr_leaves", C.c_uint64), ("ctr_sa_reads", C.c_uint64),
                 ("ctr_win_bytes", C.c_uint64), ("ctr_tab_reads", C.c_uint64), ("ms_total", C.c_double), ("ms_search", C.c_double),
                 ("ms_select", C.c_double), ("ms_locate", C.c_double), ("ms_verify", C.c_double),
-                ("d_hits", C.c_void_p), ("d_refalign", C.c_void_p), ("d_queryalign", C.c_void_p),
-                ("ctr_filter_probes", C.c_uint64), ("ms_search_flat", C.c_double)]
+                ("d_hits", C.c_void_p), ("d_ops", C.c_void_p),
+                ("ctr_filter_probes", C.c_uint64), ("ms_search_flat", C.c_double), ("owner_", C.c_void_p)]
 
 
 class SearchParams(C.Structure):
@@ -88,7 +89,7 @@ SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_
            "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
            "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
            "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free", "dg_index_share",
-           "dg_neighbors", "dg_buffer_free"]
+           "dg_neighbors", "dg_buffer_free", "dg_hit_rows", "dg_hunt_rows"]
 
 _lib = None
 
@@ -131,6 +132,8 @@ def load(path=None):
                                  C.POINTER(C.POINTER(HuntResult))]
     L.dg_hunt_result_free.argtypes = [C.POINTER(HuntResult)]
     L.dg_hunt_result_free.restype = None
+    L.dg_hunt_rows.argtypes = [C.POINTER(HuntResult)]
+    L.dg_hit_rows.argtypes = [C.POINTER(Hit), u32p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p]
     L.dg_index_build.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p]
     L.dg_index_build_device.argtypes = [vp, C.c_uint64, C.c_int, C.c_char_p]
     L.dg_thal_open.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(vp)]

@@ -293,9 +293,15 @@ int hunter(int argc, char** argv) {
           m.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x + " neighbors are searched, results are likely incomplete!");
         }
         for (uint64_t h = R->hit_off[i]; h < R->hit_off[i + 1]; ++h) {
+          // the hit's two rows from its compact description (dicey_gpu.h "compact alignment"): built here, on the formatting threads
           const dg_hit& H = R->hits[h];
-          ht.push_back(DnaHit{H.score, H.chr, H.start, (char)H.strand, std::string(R->refalign + h * R->aln_stride, H.aln_len),
-                              std::string(R->queryalign + h * R->aln_stride, H.aln_len)});
+          std::string ra(H.aln_len, '\0'), qa(H.aln_len, '\0');
+          if (dg_hit_rows(&H, R->ops ? R->ops + h * R->ops_per_hit : nullptr, R->ops_per_hit, R->qseq + R->qoff[i],
+                          (uint32_t)(R->qoff[i + 1] - R->qoff[i]), ra.data(), qa.data()) != DG_OK) {
+            std::fprintf(stderr, "dicey hunt: %s\n", dg_last_error());
+            std::abort();
+          }
+          ht.push_back(DnaHit{H.score, H.chr, H.start, (char)H.strand, std::move(ra), std::move(qa)});
         }
         if (R->qflags[i] & DG_Q_MAX_MATCHES) {
           std::string x = std::to_string(c.max_locations);

@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -1919,7 +1920,8 @@ __global__ void k_select(Batch b, const Leaf* grouped, const u64* grp_off, Sel* 
 static constexpr u32 TOPK_KMAX = 1024;  // largest `take` k_locate_topk serves (its LDS holds 8 * 1 152 candidate minima)
 struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_topk / k_locate_big
   u32 lo, occs, take, g, len;
-  u64 out;  // first hit slot
+  u32 slot;  // of the kept string (HitSeed::sel)
+  u64 out;   // first hit slot
 };
 // One lane per kept string (r03; r02 walked the strings of a (query, strand) group in one lane — 170 hits per query on the
 // repeat-bearing genome made that a chain of several hundred dependent reads).  The lane finds its group through the packed /
@@ -1958,7 +1960,7 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
           v[j] = x;
         }
         reads += occs;
-        for (u32 i = 0; i < take; ++i) out[i] = HitSeed{v[i], g, S.len};
+        for (u32 i = 0; i < take; ++i) out[i] = HitSeed{v[i], g, S.len, (u32)t};
       } else if (jobs.big && take <= 16384) {
         BigJob bj;
         bj.lo = lo;
@@ -1966,6 +1968,7 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
         bj.take = take;
         bj.g = g;
         bj.len = S.len;
+        bj.slot = (u32)t;
         bj.out = out0;
         const bool small = occs <= LOC_SMALL_MAX;
         const u32 j = atomicAdd(small ? jobs.n_small : jobs.n_big, 1u);
@@ -1981,7 +1984,7 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
             if ((first || x > prev) && x < best) best = x;
           }
           reads += occs;
-          out[i] = HitSeed{best, g, S.len};
+          out[i] = HitSeed{best, g, S.len, (u32)t};
           prev = best;
           first = false;
         }
@@ -2020,7 +2023,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
         }
         __syncthreads();
       }
-    for (u32 i = threadIdx.x; i < J.take; i += 64) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len};
+    for (u32 i = threadIdx.x; i < J.take; i += 64) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
     __syncthreads();
   }
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
@@ -2118,7 +2121,7 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs
         }
         __syncthreads();
       }
-    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len};
+    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
     if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)passes * J.occs);
     __syncthreads();
   }
@@ -2253,7 +2256,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
             }
             __syncthreads();
           }
-        for (u32 i = threadIdx.x; i < k; i += 256) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len};
+        for (u32 i = threadIdx.x; i < k; i += 256) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
         break;
       }
       // blocks of level j under the threshold -> cidx[cur ^ 1]
@@ -2308,9 +2311,11 @@ struct VerifyArgs {
   const u64* cum;  // cum[r] = sum of seqlen[0..r)
   u32 nseq;
   dg_hit* hits;
-  char* refalign;
+  char* refalign;    // scratch rows of the full-matrix kernels (k_verify, k_verify_long); k_rows_to_ops turns them into ops
   char* queryalign;
   u32 stride;
+  u32* ops;          // [nhits * ops_per_hit] compact alignment description (ALN_OP_NONE = unused)
+  u32 ops_per_hit;   // the batch's largest effective distance
 };
 
 // SMALL = true (all queries of the batch <= 32 nt): the DP row lives in registers (columns fully unrolled) and each
@@ -2601,18 +2606,28 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
 // vertical: k + 1 of the previous row, horizontal: k - 1 of the same row, so one array is updated in place left to right.
 // The query slides through a byte window (one character enters per row).  Window and query come in as aligned 64-bit words,
 // the alignment rows leave as 64-bit words.
-template <int WB>
-__global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyArgs a, Counters* ctr) {
-  constexpr int MAXROW = 32 + 3 * 2 + 2;
-  using TR = typename std::conditional<(WB <= 8), u16, u32>::type;
-  __shared__ TR tr_lds[MAXROW * 128];  // [row][lane]: 2 bits per diagonal
-  // window bytes [0,40) and query codes [40,72) of every lane: the traceback and the row-writing pass index them with
-  // per-lane positions (a select chain over packed registers cost 15 instructions per character)
-  __shared__ __align__(8) u8 gq_lds[128 * 72];
-  u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u64 nh = *a.nhits;
-  if (ctr->overflow || nh > a.hit_cap || h >= nh) return;
-  const HitSeed sd = a.seeds[h];
+// The alignment is computed ONCE PER DISTINCT WINDOW, not once per hit (r03).  needle()'s result — score, rows, leading gap columns —
+// is a function of (query strand, window) = (kept string, context characters left and right of it): hits of the same kept string
+// differ only in their <= 2d context characters.  On a repeat-bearing genome a query has 170 hits from a handful of strings
+// (1.1 M copies of an Alu-like element): 17 M hits per 100 000 queries, 2.6 of the 5.2 ms of a step in r02's lane-per-hit kernel.
+// A workgroup takes 256 * CH consecutive hits (push order: the hits of one kept string are neighbours):
+//   1. per hit: seed, context characters (<= 2d byte loads), '\n' trimming, chromosome lookup; the key (kept string's slot,
+//      effective context lengths, context bytes) enters a hash table in LDS; the first lane to insert a key owns its class;
+//   2. per class: the banded matrix with traceback (band_align below), result (score, leading gap columns, row length, <= d
+//      edit columns) into LDS — the table's memory is reused for the trace;
+//   3. per hit: the class's result plus the hit's own chromosome coordinate -> dg_hit + ops.
+// What leaves is the COMPACT form of the alignment (ABI 4): the kept rows are the query strand's characters with at most
+// |score| <= d columns that are not a match, so a hit carries `ops_per_hit` = d 32-bit words {column, kind, reference byte}
+// instead of two rows of characters (68 -> 24 bytes per hit at distance 1); dg_hit_rows() rebuilds the rows.
+static constexpr u32 ALN_OP_NONE = 0xFFFFFFFFu;
+DG_DEV u32 aln_op(u32 col, u32 kind, u32 byte) { return (col & 0xFFFFu) | (kind << 16) | (byte << 24); }  // kind: DG_ALN_*
+struct AlnRes {
+  u32 info;  // (score & 255) | leading query-gap columns << 8 | kept columns << 16
+  u32 op[2];
+};
+
+template <int WB, typename TR>
+DG_DEV AlnRes band_align(const FmView& f, const Batch& b, const HitSeed sd, TR* tr /* [row * 256] */, u8* lds_g /* 72 bytes */, u32& fault) {
   const u64 q = sd.qs >> 1;
   const u32 strand = sd.qs & 1;
   const u64 qstart = b.qoff[q];
@@ -2621,6 +2636,8 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
   const u64 loc = sd.pos;
   const u32 mlen = sd.len;
   const u32 d = b.indel ? b.qdist[q] : 0u;
+  AlnRes res;
+  res.op[0] = res.op[1] = ALN_OP_NONE;
   // the whole possible window [loc - pre, loc + mlen + post) as aligned words, before its '\n' trimming is known
   u64 pre = d, post = d;
   if (pre > loc) pre = loc;
@@ -2660,15 +2677,6 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
       if ((i >> 3) == (u32)k) w = qw[k];
     return ascii_of((u32)(w >> (8 * (i & 7))) & 255u);
   };
-  // hunter.h:358-362: text position -> (refIndex, chrpos)
-  u32 lo_r = 0, hi_r = a.nseq - 1;
-  while (lo_r < hi_r) {
-    u32 mid = (lo_r + hi_r + 1) >> 1;
-    if (a.cum[mid] <= loc) lo_r = mid;  // (staging the starts in LDS behind a barrier was slower: 91 -> 105 us)
-    else hi_r = mid - 1;
-  }
-  const u32 ref = lo_r;
-  u32 chrpos = (u32)(loc - a.cum[ref]);
   // hunter.h:363-378: the context stops at sequence separators
   u32 pre_eff = 0;
   for (u32 i = 1; i <= pre; ++i) {
@@ -2682,7 +2690,6 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
   }
   const u32 skip = (u32)pre - pre_eff;         // genomicseq starts at byte `skip` of the maximal window
   const u32 mg = pre_eff + mlen + post_eff;    // rows
-  if (pre_eff < chrpos) chrpos -= pre_eff;     // hunter.h:382 (strict <)
   // genomicseq from byte 0 (gsh), the query codes with 7 = "outside" behind the last character (qwm); both also in LDS
   u64 gsh[5], qwm[QW];
 #pragma unroll
@@ -2693,7 +2700,6 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     const u64 km = keep >= 8 ? ~0ULL : (keep <= 0 ? 0ULL : (1ULL << (8 * keep)) - 1);
     qwm[i] = (qw[i] & km) | (0x0707070707070707ULL & ~km);
   }
-  u8* const lds_g = gq_lds + threadIdx.x * 72;
   u8* const lds_q = lds_g + 40;
 #pragma unroll
   for (int i = 0; i < 5; ++i) reinterpret_cast<u64*>(lds_g)[i] = gsh[i];
@@ -2702,37 +2708,28 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
   constexpr u64 ASCII_LUT = 0x4E54474341ULL;  // code 0..4 -> 'A','C','G','T','N'; codes 5..7 -> 0
   auto g_ch = [&](u32 i) -> u32 { return lds_g[i]; };                                     // genomicseq[i]
   auto q_ch = [&](u32 i) -> u32 { return (u32)(ASCII_LUT >> (8 * lds_q[i])) & 255u; };    // ASCII of query character i < n
-  char* ra = a.refalign + h * a.stride;
-  char* qa = a.queryalign + h * a.stride;
-  dg_hit out;
-  out.chr = ref;
-  out.query = (u32)q;
-  out.strand = strand ? '-' : '+';
-  out.reserved = 0;
-  atomicAdd(&ctr->win_bytes[blockIdx.x & (NSHARD - 1)], (unsigned long long)(pre + mlen + post));
-  u64* ra8 = reinterpret_cast<u64*>(ra);
-  u64* qa8 = reinterpret_cast<u64*>(qa);
+  u32 nops = 0;
+  auto push_op = [&](u32 col, u32 kind, u32 byte) {
+    const u32 o = aln_op(col, kind, byte);
+    if (nops == 0) res.op[0] = o;
+    else if (nops == 1) res.op[1] = o;
+    ++nops;
+  };
   if (!b.indel) {
     // hunter.h:79-88,404-405: score = -(mismatches), alignment rows are the raw strings (mg == mlen == n here)
     int sc = 0;
     const u32 k = mg < n ? mg : n;
-    for (u32 i = 0; i < k; ++i) sc -= (g_ch(i) != q_ch(i));
-    u64 wr = 0, wq = 0;
-    const u32 top = mg > n ? mg : n;
-    for (u32 i = 0; i < top; ++i) {
-      if (i < mg) wr |= (u64)g_ch(i) << (8 * (i & 7));
-      if (i < n) wq |= (u64)q_ch(i) << (8 * (i & 7));
-      if ((i & 7) == 7 || i + 1 == top) {
-        ra8[i >> 3] = wr;
-        qa8[i >> 3] = wq;
-        wr = wq = 0;
+    for (u32 i = 0; i < k; ++i) {
+      const u32 gc = g_ch(i);
+      if (gc != q_ch(i)) {
+        --sc;
+        push_op(i, DG_ALN_MISMATCH, gc);
       }
     }
-    out.score = sc;
-    out.start = chrpos + 1;
-    out.aln_len = (u16)top;
-    a.hits[h] = out;
-    return;
+    if (mg != n) fault = 1;  // a Hamming hit's window is the string itself
+    res.info = ((u32)sc & 255u) | (n << 16);
+    if (nops > 2) fault = 1;
+    return res;
   }
   constexpr int NEG = -1000;
   const int dm = (int)mg - (int)n + 2 * (int)d;  // largest diagonal r - c kept; k = c - r + dm
@@ -2765,7 +2762,6 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
       qs[w] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
     }
   }
-  TR* tr = tr_lds + threadIdx.x;
 #pragma unroll
   for (int w = 0; w < 5; ++w) {
     u64 gcur = gsh[w], qcur = qs[w];
@@ -2792,7 +2788,7 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
         left = val;
         bits |= code << (2 * k);
       }
-      tr[row * 128] = (TR)bits;
+      tr[row * 256] = (TR)bits;
       // slide the query window: drop byte 0, the character of column c0 + WB (next row's last diagonal) enters at the top
       const u64 nb = (ASCII_LUT >> (8 * ((u32)qcur & 255u))) & 255u;
       qcur >>= 8;
@@ -2806,8 +2802,7 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
 #pragma unroll
   for (int k = 0; k < WB; ++k)
     if (k == 2 * (int)d) fin = s[k];  // cell (mg, n)
-  out.score = fin;
-  // traceback into a move stack held in registers, then one forward pass that writes the kept columns
+  // traceback into a move stack held in registers, then one forward pass over the kept columns
   u64 mv0 = 0, mv1 = 0, mv2 = 0;
   u32 nmv = 0, trail = 0;
   bool seen_query = false;
@@ -2818,7 +2813,7 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
     else if (row == 0) code = 1u;
     else {
       const int k = (int)col - (int)row + dm;  // inside the band on every optimal path
-      code = (k >= 0 && k < WB) ? ((u32)tr[row * 128] >> (2 * k)) & 3u : 1u;
+      code = (k >= 0 && k < WB) ? ((u32)tr[row * 256] >> (2 * k)) & 3u : 1u;
     }
     if (code == 1) --col;
     else if (code == 2) --row;
@@ -2836,54 +2831,203 @@ __global__ void __launch_bounds__(128) k_verify_band(FmView f, Batch b, VerifyAr
   u32 r = 0, c = 0, len = 0, lead = 0;
   bool in_lead = true;
   const u32 stop = nmv - trail;
-  u64 wr = 0, wq = 0;
   for (u32 k = 0; k < stop; ++k) {
     const u32 code = (u32)mv0 & 3u;
     mv0 = (mv0 >> 2) | (mv1 << 62);
     mv1 = (mv1 >> 2) | (mv2 << 62);
     mv2 >>= 2;
-    u32 r0, r1;
-    if (code == 1) {
-      r0 = '-';
-      r1 = q_ch(c);
+    if (code == 1) {  // gap in the reference row
+      in_lead = false;
+      push_op(len, DG_ALN_REF_GAP, 0);
       ++c;
-    } else if (code == 2) {
-      r0 = g_ch(r);
-      r1 = '-';
+      ++len;
+    } else if (code == 2) {  // gap in the query row; leading ones only advance chrpos (hunter.h:391-401)
+      const u32 gc = g_ch(r);
       ++r;
-    } else {
-      r0 = g_ch(r);
-      r1 = q_ch(c);
-      ++r;
-      ++c;
-    }
-    if (r1 != '-') in_lead = false;
-    if (in_lead) {  // leading query-gap columns only advance chrpos (hunter.h:391-401)
-      ++lead;
-      continue;
-    }
-    wr |= (u64)r0 << (8 * (len & 7));
-    wq |= (u64)r1 << (8 * (len & 7));
-    if ((len & 7) == 7) {
-      if (len < a.stride) {  // always (see the stride's derivation in run_batch); never write past the row
-        ra8[len >> 3] = wr;
-        qa8[len >> 3] = wq;
+      if (in_lead) ++lead;
+      else {
+        push_op(len, DG_ALN_QUERY_GAP, gc);
+        ++len;
       }
-      wr = wq = 0;
+    } else {
+      in_lead = false;
+      const u32 gc = g_ch(r), qc = q_ch(c);
+      if (gc != qc) push_op(len, DG_ALN_MISMATCH, gc);
+      ++r;
+      ++c;
+      ++len;
     }
-    ++len;
   }
-  if ((len & 7) && len < a.stride) {
-    ra8[len >> 3] = wr;
-    qa8[len >> 3] = wq;
+  // every kept column that is not a match costs one (free vertical moves exist only in columns 0 and n, and those are the
+  // stripped ones): more operations than the score allows, or a score below -d, would contradict the band's premise
+  if (nops > 2 || (int)nops != -fin || fin < -(int)d) fault = 1;
+  res.info = ((u32)fin & 255u) | (lead << 8) | (len << 16);
+  return res;
+}
+
+// Dynamic LDS: max(hash table, rows * 256 trace words + 256 * 72 window / query bytes), rows = maxlen + 3 d + 2 of the batch.
+template <int WB, int CH>
+__global__ void __launch_bounds__(256) k_verify_memo(FmView f, Batch b, VerifyArgs a, Counters* ctr, u32 rows) {
+  using TR = typename std::conditional<(WB <= 8), u16, u32>::type;
+  constexpr u32 NH = 256u * CH;        // hits of a workgroup
+  constexpr u32 HCAP = 2 * NH;         // hash slots (a power of two)
+  constexpr u32 HSHIFT = 64 - (CH == 1 ? 9 : CH == 2 ? 10 : CH == 4 ? 11 : 12);
+  static_assert(CH == 1 || CH == 2 || CH == 4 || CH == 8, "hits per lane");
+  constexpr u32 DS = WB <= 8 ? 1 : 2;  // operations per class
+  extern __shared__ __align__(16) u8 u_lds[];  // phase 1: hash keys + values; phase 2: trace + window / query bytes
+  __shared__ u32 cls_info[NH];
+  __shared__ u32 cls_ops[NH * DS];
+  __shared__ u16 cls_owner[NH];
+  __shared__ u32 s_ncls, s_fault;
+  u64* const hkey = reinterpret_cast<u64*>(u_lds);
+  u16* const hval = reinterpret_cast<u16*>(u_lds + HCAP * 8);
+  constexpr u64 EMPTY = ~0ULL;
+  const u64 nh = *a.nhits;
+  if (ctr->overflow || nh > a.hit_cap) return;
+  const u64 base = (u64)blockIdx.x * NH;
+  if (base >= nh) return;
+  const u32 tid = threadIdx.x;
+  for (u32 i = tid; i < HCAP; i += 256) hkey[i] = EMPTY;
+  if (tid == 0) {
+    s_ncls = 0;
+    s_fault = 0;
   }
-  // a row longer than the stride run_batch derived (query + d gap columns) would have been cut above: fail the batch loudly
-  // (the host repeats it a few times and then reports a persisting overflow) rather than hand out a truncated row
-  if (len > a.stride) atomicOr(&ctr->overflow, 1u);
-  chrpos += lead;
-  out.start = chrpos + 1;
-  out.aln_len = (u16)len;
-  a.hits[h] = out;
+  // ---- phase 1: per hit
+  HitSeed sd[CH];
+  u32 dq[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const u64 h = base + (u32)j * 256u + tid;
+    const uint4 v = h < nh ? *reinterpret_cast<const uint4*>(a.seeds + h) : make_uint4(0, 0, 0, 0);
+    sd[j] = HitSeed{v.x, v.y, v.z, v.w};
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) dq[j] = b.indel ? b.qdist[sd[j].qs >> 1] : 0u;
+  u32 fl[CH];  // context bytes: left of the string at bits 0-15 (nearest first), right of it at bits 16-31
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const u64 h = base + (u32)j * 256u + tid;
+    const u64 loc = sd[j].pos, endp = loc + sd[j].len;
+    const u32 d = dq[j];
+    u32 x = 0;
+    if (h < nh) {
+      if (d >= 1 && loc >= 1) x |= (u32)f.text[loc - 1];
+      if (DS >= 2 && d >= 2 && loc >= 2) x |= (u32)f.text[loc - 2] << 8;
+      if (d >= 1 && endp + 1 <= f.n) x |= (u32)f.text[endp] << 16;
+      if (DS >= 2 && d >= 2 && endp + 2 <= f.n) x |= (u32)f.text[endp + 1] << 24;
+    }
+    fl[j] = x;
+  }
+  __syncthreads();  // the table is clear
+  u32 ref[CH], cpos[CH], slot[CH];
+  bool won[CH];
+  u64 wbytes = 0;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const u64 h = base + (u32)j * 256u + tid;
+    won[j] = false;
+    slot[j] = 0;
+    ref[j] = cpos[j] = 0;
+    if (h >= nh) continue;
+    const u64 loc = sd[j].pos, endp = loc + sd[j].len;
+    const u32 d = dq[j];
+    // hunter.h:358-362: text position -> (refIndex, chrpos)
+    u32 lo_r = 0, hi_r = a.nseq - 1;
+    while (lo_r < hi_r) {
+      const u32 mid = (lo_r + hi_r + 1) >> 1;
+      if (a.cum[mid] <= loc) lo_r = mid;
+      else hi_r = mid - 1;
+    }
+    ref[j] = lo_r;
+    u32 chrpos = (u32)(loc - a.cum[lo_r]);
+    // hunter.h:363-378: <= d context characters either side, clipped to the text, cut at sequence separators
+    u32 pre = d, post = d;
+    if (pre > loc) pre = (u32)loc;
+    if (endp + post > f.n) post = (u32)(f.n - endp);
+    u32 pre_eff = 0, post_eff = 0, pb = 0, qb = 0;
+#pragma unroll
+    for (u32 i = 0; i < DS; ++i) {
+      const u32 ch = (fl[j] >> (8 * i)) & 255u;
+      if (i < pre && pre_eff == i && ch != '\n') {
+        pre_eff = i + 1;
+        pb |= ch << (8 * i);
+      }
+      const u32 ch2 = (fl[j] >> (16 + 8 * i)) & 255u;
+      if (i < post && post_eff == i && ch2 != '\n') {
+        post_eff = i + 1;
+        qb |= ch2 << (8 * i);
+      }
+    }
+    if (pre_eff < chrpos) chrpos -= pre_eff;  // hunter.h:382 (strict <)
+    cpos[j] = chrpos;
+    wbytes += pre + sd[j].len + post;
+    const u32 local = (u32)j * 256u + tid;
+    // a class = (kept string, effective context lengths, context bytes); slots beyond 2^28 stay classes of their own
+    const u64 key = sd[j].sel < (1u << 28) ? ((u64)(sd[j].sel | (pre_eff << 28) | (post_eff << 30)) << 32) | (pb << 16) | qb
+                                           : ((u64)(0xC0000000u | local) << 32);
+    u32 sidx = (u32)((key * 0x9E3779B97F4A7C15ULL) >> HSHIFT);
+    for (;;) {
+      const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&hkey[sidx]), (unsigned long long)EMPTY, (unsigned long long)key);
+      if (old == EMPTY) {
+        won[j] = true;
+        break;
+      }
+      if (old == key) break;
+      sidx = (sidx + 1) & (HCAP - 1);
+    }
+    slot[j] = sidx;
+  }
+  wave_add(&ctr->win_bytes[blockIdx.x & (NSHARD - 1)], wbytes);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CH; ++j)
+    if (won[j]) {
+      const u32 c = atomicAdd(&s_ncls, 1u);
+      hval[slot[j]] = (u16)c;
+      cls_owner[c] = (u16)((u32)j * 256u + tid);
+    }
+  __syncthreads();
+  u32 cls[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) cls[j] = hval[slot[j]];
+  const u32 ncls = s_ncls;
+  __syncthreads();  // the table's memory becomes the trace
+  // ---- phase 2: per class
+  TR* const tr = reinterpret_cast<TR*>(u_lds) + tid;
+  u8* const lds_g = u_lds + rows * 256 * sizeof(TR) + tid * 72;
+  u32 fault = 0;
+  for (u32 c = tid; c < ncls; c += 256) {
+    const u32 own = cls_owner[c];
+    const uint4 v = *reinterpret_cast<const uint4*>(a.seeds + base + own);
+    const AlnRes r = band_align<WB, TR>(f, b, HitSeed{v.x, v.y, v.z, v.w}, tr, lds_g, fault);
+    cls_info[c] = r.info;
+    cls_ops[c * DS] = r.op[0];
+    if (DS > 1) cls_ops[c * DS + 1] = r.op[1];
+  }
+  if (fault) s_fault = 1;
+  __syncthreads();
+  if (s_fault) {  // never observed; fail the batch loudly rather than hand out a wrong alignment
+    if (tid == 0) atomicOr(&ctr->overflow, 2u);
+    return;
+  }
+  // ---- phase 3: per hit
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const u64 h = base + (u32)j * 256u + tid;
+    if (h >= nh) continue;
+    const u32 info = cls_info[cls[j]];
+    dg_hit out;
+    out.score = (int)(int8_t)(info & 255u);
+    out.chr = ref[j];
+    out.start = cpos[j] + ((info >> 8) & 255u) + 1;
+    out.query = sd[j].qs >> 1;
+    out.aln_len = (u16)(info >> 16);
+    out.strand = (sd[j].qs & 1) ? '-' : '+';
+    out.reserved = 0;
+    a.hits[h] = out;
+    if (a.ops_per_hit >= 1) a.ops[h * a.ops_per_hit] = cls_ops[cls[j] * DS];
+    if (DS > 1 && a.ops_per_hit >= 2) a.ops[h * a.ops_per_hit + 1] = cls_ops[cls[j] * DS + 1];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -3042,6 +3186,28 @@ __global__ void __launch_bounds__(64) k_verify_long(FmView f, Batch b, VerifyArg
 // ------------------------------------------------------------------------------------------------------------
 // Host orchestration
 // ------------------------------------------------------------------------------------------------------------
+
+// The full-matrix verify kernels (k_verify, k_verify_long: distance 3-4, queries above 32 nt) leave character rows in their scratch
+// buffers; this turns a hit's rows into the compact description every consumer reads.  A column whose two rows both hold '-' cannot
+// come out of needle(): it is a '-' byte of the genome over a gap of the query.
+__global__ void k_rows_to_ops(VerifyArgs a, Counters* ctr) {
+  const u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 nh = *a.nhits;
+  if (ctr->overflow || nh > a.hit_cap || h >= nh) return;
+  const char* ra = a.refalign + h * a.stride;
+  const char* qa = a.queryalign + h * a.stride;
+  const u32 len = a.hits[h].aln_len;
+  u32 nops = 0;
+  for (u32 i = 0; i < len; ++i) {
+    const u32 x = (u8)ra[i], y = (u8)qa[i];
+    if (x == y && x != '-') continue;
+    const u32 kind = y == '-' ? (u32)DG_ALN_QUERY_GAP : (x == '-' ? (u32)DG_ALN_REF_GAP : (u32)DG_ALN_MISMATCH);
+    if (nops < a.ops_per_hit) a.ops[h * a.ops_per_hit + nops] = aln_op(i, kind, kind == DG_ALN_REF_GAP ? 0u : x);
+    ++nops;
+  }
+  for (u32 i = nops; i < a.ops_per_hit; ++i) a.ops[h * a.ops_per_hit + i] = ALN_OP_NONE;
+  if (nops > a.ops_per_hit) atomicOr(&ctr->overflow, 2u);  // more edit columns than the distance allows: fail the batch loudly
+}
 
 static double ev_ms(hipEvent_t a, hipEvent_t b) {
   float ms = 0;
@@ -3252,6 +3418,58 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
   return DG_OK;
 }
 
+// Pinned host blocks for fetched results, recycled across batches.  hipHostMalloc of a few MB costs more than copying them, and
+// copies into pageable memory ran at a third of the link's speed (r02: 43 % of the un-fetched rate).  A result owns its block
+// until dg_hunt_result_free hands it back; blocks are never returned to the driver at exit (the runtime may be gone by then).
+struct PinnedBlock {
+  void* p;
+  size_t cap;
+};
+struct PinnedPool {
+  std::mutex mu;
+  std::vector<PinnedBlock*> free_;
+  size_t cached = 0;
+  static constexpr size_t KEEP = 8ull << 30;
+  PinnedBlock* get(size_t bytes) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      size_t best = (size_t)-1;
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i]->cap >= bytes && free_[i]->cap <= 4 * bytes + (1u << 20) && (best == (size_t)-1 || free_[i]->cap < free_[best]->cap)) best = i;
+      if (best != (size_t)-1) {
+        PinnedBlock* b = free_[best];
+        free_.erase(free_.begin() + (long)best);
+        cached -= b->cap;
+        return b;
+      }
+    }
+    size_t cap = 1u << 16;
+    while (cap < bytes + bytes / 4) cap <<= 1;  // head room: the next batch's hit count differs a little
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    return new PinnedBlock{p, cap};
+  }
+  void put(PinnedBlock* b) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (cached + b->cap <= KEEP) {
+        free_.push_back(b);
+        cached += b->cap;
+        return;
+      }
+    }
+    (void)hipHostFree(b->p);
+    delete b;
+  }
+};
+static PinnedPool& pinned_pool() {
+  static PinnedPool* P = new PinnedPool;  // leaked on purpose
+  return *P;
+}
+
 // One batch through the five kernels.  All sizes that are only known on the device (number of leaves, number of hits)
 // are handled with capacity guesses that the kernels check themselves; the host synchronises ONCE at the end, and
 // repeats the batch with larger buffers in the rare case a capacity was exceeded.
@@ -3284,7 +3502,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   // end of a buffer twice as long.  (r02: 56 -> 24 bytes per row for 20-mers — what travels to the host and over xGMI.)
   static const bool no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;
   const bool band_verify = !no_band && !sx && !group_counts && maxlen <= 32 && dmax_eff <= 2;
-  const u32 stride = band_verify ? (maxlen + 2 * dmax_eff + 7) & ~7u : ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
+  // scratch rows of the full-matrix kernels (built from the end of a buffer twice the row length); the banded kernel needs none
+  const u32 stride = band_verify ? 0u : ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
+  const u32 ops_per_hit = dmax_eff;  // compact alignment description: at most |score| <= d columns are not a match
   const u64 scan_tmp = ngrp / SCAN_CHUNK + ngrp / (SCAN_CHUNK * SCAN_CHUNK) + 64;
   DG_TRY(ws[WS_FW].reserve(total + 8));
   DG_TRY(ws[WS_RV].reserve(total + 8));
@@ -3421,7 +3641,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     u32 surv_cap = 0xFFFFFFFFu;  // set where the survivor queue is used
     DG_TRY(ws[WS_JOBS].reserve(2 * std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
-    DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
+    if (stride && !sx && !group_counts) DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
+    if (!sx && !group_counts) DG_TRY(ws[WS_OPS].reserve((hit_cap + 1) * (u64)ops_per_hit * 4 + 64));
     DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     DG_HIP(hipEventRecord(ix->ev[0], st));
     hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b);
@@ -3570,26 +3791,49 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       va.refalign = ws[WS_ALN].as<char>();
       va.queryalign = ws[WS_ALN].as<char>() + (hit_cap + 1) * (u64)stride;
       va.stride = stride;
+      va.ops = ws[WS_OPS].as<u32>();
+      va.ops_per_hit = ops_per_hit;
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
-      if (band_verify && dmax_eff <= 1)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_band<7>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
-      else if (band_verify)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_band<13>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
-      else if (maxlen > MAX_QLEN) {
-        const u32 rows_cap = maxlen + 3 * dmax_eff + 2;
-        const u64 tbytes = (hit_cap + 1) * (u64)rows_cap * 8;
-        if (tbytes > (64ull << 30))
-          return fail(DG_ELIMIT, "a batch with a %u nt query and room for %llu hits needs %llu GB of trace; pass long queries in smaller batches",
-                      maxlen, (unsigned long long)hit_cap, (unsigned long long)(tbytes >> 30));
-        DG_TRY(ws[WS_DP].reserve(tbytes + 64));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_long<6 * DMAX + 1>), dim3(ceil_div(hit_cap, 64)), dim3(64), 0, st, ix->view, b, va, ctr,
-                           ws[WS_DP].as<u64>(), rows_cap);
-      } else if (maxlen <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 24>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
-      else if (maxlen <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 32>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
-      else if (cells <= 32 * 160) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+      if (band_verify) {
+        // hits per lane: 1 while a query has a handful of hits (every window is its own class: nothing to share, smallest LDS
+        // footprint), 8 when the previous batch had dozens of hits per query (repeat families: ~240 hits per kept string)
+        static const int ch_env = std::getenv("DICEY_VERIFY_CH") ? std::atoi(std::getenv("DICEY_VERIFY_CH")) : 0;
+        const u64 per_q = hit_cap / std::max<u64>(nq, 1);
+        const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= 24 ? 8 : (per_q >= 8 ? 4 : 1));
+        const u32 rows = maxlen + 3 * dmax_eff + 2;
+        const bool wide = dmax_eff > 1;
+        const u32 nw_bytes = rows * 256 * (wide ? 4u : 2u) + 256 * 72, hash_bytes = 2u * 256u * (u32)ch * 10u;
+        const u32 lds = std::max(nw_bytes, hash_bytes);
+        const dim3 mgrid(ceil_div(hit_cap, (u64)256 * ch)), mblock(256);
+#define DG_LAUNCH_MEMO(WBV, CHV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_memo<WBV, CHV>), mgrid, mblock, lds, st, ix->view, b, va, ctr, rows)
+        if (!wide) {
+          if (ch == 8) DG_LAUNCH_MEMO(7, 8);
+          else if (ch == 4) DG_LAUNCH_MEMO(7, 4);
+          else DG_LAUNCH_MEMO(7, 1);
+        } else {
+          if (ch == 8) DG_LAUNCH_MEMO(13, 8);
+          else if (ch == 4) DG_LAUNCH_MEMO(13, 4);
+          else DG_LAUNCH_MEMO(13, 1);
+        }
+#undef DG_LAUNCH_MEMO
+      } else {
+        if (maxlen > MAX_QLEN) {
+          const u32 rows_cap = maxlen + 3 * dmax_eff + 2;
+          const u64 tbytes = (hit_cap + 1) * (u64)rows_cap * 8;
+          if (tbytes > (64ull << 30))
+            return fail(DG_ELIMIT, "a batch with a %u nt query and room for %llu hits needs %llu GB of trace; pass long queries in smaller batches",
+                        maxlen, (unsigned long long)hit_cap, (unsigned long long)(tbytes >> 30));
+          DG_TRY(ws[WS_DP].reserve(tbytes + 64));
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_long<6 * DMAX + 1>), dim3(ceil_div(hit_cap, 64)), dim3(64), 0, st, ix->view, b, va, ctr,
+                             ws[WS_DP].as<u64>(), rows_cap);
+        } else if (maxlen <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 24>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+        else if (maxlen <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<1, true, 32>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+        else if (cells <= 32 * 160) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
+        if (ops_per_hit) hipLaunchKernelGGL(k_rows_to_ops, dim3(ceil_div(hit_cap, 256)), dim3(256), 0, st, va, ctr);
+      }
     }
     DG_HIP(hipEventRecord(ix->ev[7], st));
     }
@@ -3646,40 +3890,50 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipStreamSynchronize(st));
   }
 
+  if (hsum.overflow & 2)
+    return fail(DG_EHIP, "internal error: an alignment left the band its hit guarantees (or needs more than %u edit columns)", ops_per_hit);
   dg_hunt_result* R = new dg_hunt_result;
   std::memset(R, 0, sizeof *R);
   R->nq = nq;
   R->nhits = nhits;
-  R->aln_stride = stride;
+  R->ops_per_hit = ops_per_hit;
   *out = R;
   if (fetch) {
-    R->hit_off = new uint64_t[nq + 1];
-    R->qflags = new uint32_t[nq];
-    R->qdistance = new uint32_t[nq];
-    R->qnondna = new uint32_t[nq];
-    R->hits = new dg_hit[nhits ? nhits : 1];
-    R->refalign = new char[(nhits ? nhits : 1) * (u64)stride];
-    R->queryalign = new char[(nhits ? nhits : 1) * (u64)stride];
-    R->qseq = new uint8_t[total ? total : 1];
-    R->qoff = new uint64_t[nq + 1];
+    // one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh hipHostMalloc per batch
+    // costs more than the copies): [hit_off | qoff | hits | ops | qdistance qflags qnondna | qseq]
+    const u64 o_hit_off = 0, o_qoff = o_hit_off + (nq + 1) * 8, o_hits = o_qoff + (nq + 1) * 8;
+    const u64 o_ops = (o_hits + nhits * sizeof(dg_hit) + 15) & ~15ull, o_meta = (o_ops + nhits * (u64)ops_per_hit * 4 + 15) & ~15ull;
+    const u64 o_qseq = o_meta + 3 * (u64)nq * 4, bytes = o_qseq + total + 64;
+    PinnedBlock* pb = pinned_pool().get(bytes);
+    if (!pb) {
+      delete R;
+      *out = nullptr;
+      return fail(DG_ENOMEM, "cannot allocate %llu bytes of pinned host memory for the results", (unsigned long long)bytes);
+    }
+    R->owner_ = pb;
+    u8* hb = (u8*)pb->p;
+    R->hit_off = (uint64_t*)(hb + o_hit_off);
+    R->qoff = (uint64_t*)(hb + o_qoff);
+    R->hits = (dg_hit*)(hb + o_hits);
+    R->ops = (uint32_t*)(hb + o_ops);
+    R->qdistance = (uint32_t*)(hb + o_meta);
+    R->qflags = R->qdistance + nq;
+    R->qnondna = R->qflags + nq;
+    R->qseq = hb + o_qseq;
     DG_HIP(hipMemcpyAsync(R->hit_off, hit_off, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
-    DG_HIP(hipMemcpyAsync(R->qdistance, b.qdist, nq * 4, hipMemcpyDeviceToHost, st));
-    DG_HIP(hipMemcpyAsync(R->qflags, b.qflags, nq * 4, hipMemcpyDeviceToHost, st));
-    DG_HIP(hipMemcpyAsync(R->qnondna, b.qnondna, nq * 4, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipMemcpyAsync(R->qdistance, b.qdist, 3 * (u64)nq * 4, hipMemcpyDeviceToHost, st));  // qdist, qflags, qnondna lie in this order
     if (nhits) {
       DG_HIP(hipMemcpyAsync(R->hits, ws[WS_HITS].p, nhits * sizeof(dg_hit), hipMemcpyDeviceToHost, st));
-      DG_HIP(hipMemcpyAsync(R->refalign, ws[WS_ALN].p, nhits * (u64)stride, hipMemcpyDeviceToHost, st));
-      DG_HIP(hipMemcpyAsync(R->queryalign, ws[WS_ALN].as<char>() + (hit_cap + 1) * (u64)stride, nhits * (u64)stride,
-                            hipMemcpyDeviceToHost, st));
+      if (ops_per_hit) DG_HIP(hipMemcpyAsync(R->ops, ws[WS_OPS].p, nhits * (u64)ops_per_hit * 4, hipMemcpyDeviceToHost, st));
     }
     if (total) DG_HIP(hipMemcpyAsync(R->qseq, b.qseq, total, hipMemcpyDeviceToHost, st));
-    DG_HIP(hipMemcpyAsync(R->qoff, d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (h_qoff) std::memcpy(R->qoff, h_qoff, (nq + 1) * 8);
+    else DG_HIP(hipMemcpyAsync(R->qoff, d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
     DG_HIP(hipStreamSynchronize(st));
     DG_HIP(hipGetLastError());
   }
   R->d_hits = ws[WS_HITS].p;
-  R->d_refalign = ws[WS_ALN].p;
-  R->d_queryalign = ws[WS_ALN].as<char>() + (hit_cap + 1) * (u64)stride;
+  R->d_ops = ops_per_hit ? ws[WS_OPS].p : nullptr;
   R->ctr_leaves = nleaf;
   R->ctr_ext_steps = hsum.steps;
   R->ctr_tab_reads = hsum.lookups;
@@ -3703,16 +3957,88 @@ extern "C" {
 
 void dg_hunt_result_free(dg_hunt_result* r) {
   if (!r) return;
-  delete[] r->hit_off;
-  delete[] r->hits;
-  delete[] r->refalign;
-  delete[] r->queryalign;
-  delete[] r->qflags;
-  delete[] r->qdistance;
-  delete[] r->qnondna;
-  delete[] r->qseq;
-  delete[] r->qoff;
+  if (r->owner_) pinned_pool().put((PinnedBlock*)r->owner_);
+  std::free(r->refalign);
+  std::free(r->queryalign);
   delete r;
+}
+
+int dg_hit_rows(const dg_hit* hit, const uint32_t* ops, uint32_t ops_per_hit, const uint8_t* qseq, uint32_t qlen, char* refalign,
+                char* queryalign) {
+  if (!hit || !qseq || !refalign || !queryalign || (ops_per_hit && !ops)) return fail(DG_EINVAL, "dg_hit_rows: null argument");
+  const bool rev = hit->strand == '-';
+  auto qch = [&](u32 i) -> char {  // character i of the strand the hit was aligned to (util.h:54-114 for the reverse strand)
+    if (!rev) return (char)qseq[i];
+    const u8 c = qseq[qlen - 1 - i];
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+  };
+  u32 qi = 0, k = 0;
+  for (u32 col = 0; col < hit->aln_len; ++col) {
+    const uint32_t op = k < ops_per_hit ? ops[k] : DG_ALN_NONE;
+    if (op != DG_ALN_NONE && DG_ALN_COL(op) == col) {
+      ++k;
+      const u32 kind = DG_ALN_KIND(op);
+      if (kind == DG_ALN_QUERY_GAP) {
+        refalign[col] = (char)DG_ALN_BYTE(op);
+        queryalign[col] = '-';
+        continue;
+      }
+      if (qi >= qlen) return fail(DG_EINVAL, "dg_hit_rows: the description consumes more than the query's %u characters", qlen);
+      refalign[col] = kind == DG_ALN_REF_GAP ? '-' : (char)DG_ALN_BYTE(op);
+      queryalign[col] = qch(qi++);
+    } else {
+      if (qi >= qlen) return fail(DG_EINVAL, "dg_hit_rows: the description consumes more than the query's %u characters", qlen);
+      refalign[col] = queryalign[col] = qch(qi++);
+    }
+  }
+  if (qi != qlen || (k < ops_per_hit && ops[k] != DG_ALN_NONE))
+    return fail(DG_EINVAL, "dg_hit_rows: %u of %u query characters and %u operations used by %u columns", qi, qlen, k, (u32)hit->aln_len);
+  return DG_OK;
+}
+
+int dg_hunt_rows(dg_hunt_result* r) {
+  if (!r) return fail(DG_EINVAL, "dg_hunt_rows: null result");
+  if (r->refalign) return DG_OK;
+  if (r->nhits && (!r->hits || !r->qseq || !r->qoff)) return fail(DG_EINVAL, "dg_hunt_rows: the result was not fetched to the host");
+  u32 longest = 0;
+  for (u64 h = 0; h < r->nhits; ++h) longest = std::max<u32>(longest, r->hits[h].aln_len);
+  const u32 stride = (longest + 7) & ~7u;
+  const u64 bytes = std::max<u64>(r->nhits * (u64)stride, 1);
+  char* ra = (char*)std::malloc(bytes);
+  char* qa = (char*)std::malloc(bytes);
+  if (!ra || !qa) {
+    std::free(ra);
+    std::free(qa);
+    return fail(DG_ENOMEM, "dg_hunt_rows: %llu bytes", (unsigned long long)(2 * bytes));
+  }
+  std::atomic<int> bad{0};
+  auto work = [&](u64 h0, u64 h1) {
+    for (u64 h = h0; h < h1; ++h) {
+      const dg_hit& H = r->hits[h];
+      const u64 q0 = r->qoff[H.query];
+      if (dg_hit_rows(&H, r->ops ? r->ops + h * r->ops_per_hit : nullptr, r->ops_per_hit, r->qseq + q0, (u32)(r->qoff[H.query + 1] - q0),
+                      ra + h * stride, qa + h * stride) != DG_OK)
+        bad.store(1);
+    }
+  };
+  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (r->nhits < 65536) nt = 1;
+  if (nt <= 1) work(0, r->nhits);
+  else {
+    std::vector<std::thread> pool;
+    const u64 per = (r->nhits + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, std::min<u64>(r->nhits, t * per), std::min<u64>(r->nhits, (t + 1) * per));
+    for (auto& t : pool) t.join();
+  }
+  if (bad.load()) {
+    std::free(ra);
+    std::free(qa);
+    return fail(DG_EINVAL, "dg_hunt_rows: a hit's alignment description does not fit its query");
+  }
+  r->refalign = ra;
+  r->queryalign = qa;
+  r->aln_stride = stride;
+  return DG_OK;
 }
 
 int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,

@@ -33,8 +33,10 @@ extern "C" {
 #endif
 
 /* 1: hunt/count/locate/extract/index build; 2: + thal, search sites, neighbourhood counts, padlock scan, shared handles;
- * 3: + dg_neighbors, capped neighbourhoods answered instead of refused, max_locations 0 */
-#define DG_ABI_VERSION 3
+ * 3: + dg_neighbors, capped neighbourhoods answered instead of refused, max_locations 0
+ * 4: hits carry their alignment in compact form (dg_hunt_result::ops; dg_hunt_rows / dg_hit_rows rebuild the two rows),
+ *    result buffers come from a pinned pool, dg_hunt_submit / dg_hunt_wait */
+#define DG_ABI_VERSION 4
 
 enum {
   DG_OK = 0,
@@ -116,13 +118,30 @@ typedef struct {
   uint8_t reserved;
 } dg_hit;
 
+/* Compact alignment (ABI 4).  The rows the reference pushes into DnaHit (hunter.h:391-405, 411-426) are the characters of the
+ * query strand the hit was found on, with at most |score| <= distance columns that are not a match: leading and trailing
+ * columns whose query row is a gap are stripped, and every other non-matching column costs one.  A hit therefore travels as
+ * dg_hit + `ops_per_hit` 32-bit words, one per non-matching column in column order, DG_ALN_NONE behind the last:
+ *   bits 0-15 column, bits 16-17 kind, bits 24-31 the reference byte of that column (kinds MISMATCH and QUERY_GAP)
+ * 24 bytes per hit at distance 1 instead of 68 with two character rows — what crosses PCIe and xGMI.  dg_hit_rows() /
+ * dg_hunt_rows() rebuild refalign / queryalign byte for byte. */
+#define DG_ALN_MISMATCH 0u  /* reference byte over a different query character */
+#define DG_ALN_REF_GAP 1u   /* '-' in refalign over a query character */
+#define DG_ALN_QUERY_GAP 2u /* reference byte over '-' in queryalign */
+#define DG_ALN_NONE 0xFFFFFFFFu
+#define DG_ALN_COL(op) ((op) & 0xFFFFu)
+#define DG_ALN_KIND(op) (((op) >> 16) & 3u)
+#define DG_ALN_BYTE(op) ((op) >> 24)
+
 typedef struct {
   size_t nq;
   uint64_t nhits;
   uint64_t* hit_off;      /* [nq+1]: hits of query i = hits[hit_off[i] .. hit_off[i+1]) in REFERENCE PUSH ORDER (pre-sort) */
   dg_hit* hits;           /* [nhits] */
-  uint32_t aln_stride;    /* bytes reserved per alignment row */
-  char* refalign;         /* row of hit h: refalign + h*aln_stride, aln_len bytes */
+  uint32_t ops_per_hit;   /* words of alignment description per hit: the batch's largest effective distance (0: every row is the query) */
+  uint32_t aln_stride;    /* bytes per row in refalign / queryalign (0 until dg_hunt_rows has run) */
+  uint32_t* ops;          /* [nhits * ops_per_hit] */
+  char* refalign;         /* NULL until dg_hunt_rows(): row of hit h = refalign + h*aln_stride, aln_len bytes */
   char* queryalign;       /* likewise */
   uint32_t* qflags;       /* [nq] DG_Q_* */
   uint32_t* qdistance;    /* [nq] effective (clamped) distance */
@@ -132,8 +151,8 @@ typedef struct {
   /* measurement: exact op counters of the executed device algorithm (DESIGN.md "algorithmic bytes") */
   uint64_t ctr_ext_steps; /* interval extensions (2 Occ-block reads each) */
   uint64_t ctr_leaves;    /* occurring neighbourhood strings emitted by the search kernel */
-  uint64_t ctr_sa_reads;  /* suffix-array entries read by locate */
-  uint64_t ctr_win_bytes; /* text window bytes read */
+  uint64_t ctr_sa_reads;  /* suffix-array entries (and block minima) read by locate */
+  uint64_t ctr_win_bytes; /* text window bytes the reference would extract (hunter.h:371), one window per hit */
   uint64_t ctr_tab_reads; /* K-mer jump-table entries read (8 B each) */
   double ms_total;        /* device time of the whole batch (HIP events on the index stream) */
   double ms_search;       /* of which: neighbourhood/backward-search kernel */
@@ -142,13 +161,22 @@ typedef struct {
   double ms_verify;       /* window fetch + Needleman-Wunsch */
   /* device-resident copies (HIP pointers on the index's device), valid until the next call on this index:
    * what a multi-GPU driver hands to RCCL to gather hit lists without a host round trip */
-  const void* d_hits;       /* dg_hit[nhits] */
-  const void* d_refalign;   /* nhits * aln_stride bytes */
-  const void* d_queryalign; /* nhits * aln_stride bytes */
+  const void* d_hits;     /* dg_hit[nhits] */
+  const void* d_ops;      /* uint32_t[nhits * ops_per_hit] */
   uint64_t ctr_filter_probes; /* K-mer presence-filter bits tested (one 4-byte word each); ctr_tab_reads counts the table
                                * entries actually read, i.e. the probes that found their K-mer present */
   double ms_search_flat;      /* part of ms_search spent in the flat kernel (k_search1p at distance 1, k_search2p at edit distance 2); 0 when none ran */
+  void* owner_;               /* library internal (pinned-pool bookkeeping) */
 } dg_hunt_result;
+
+/* The two alignment rows of one hit from its compact description.  qseq / qlen: the NORMALISED query (dg_hunt_result::qseq:
+ * A,C,G,T,N), forward strand — the reverse complement a '-' hit was aligned to is formed here (util.h:54-114).  ops: the hit's
+ * ops_per_hit words (NULL when ops_per_hit == 0).  Writes hit->aln_len bytes to each row (no terminator).  DG_EINVAL when the
+ * description does not fit the query (a corrupted record). */
+int dg_hit_rows(const dg_hit* hit, const uint32_t* ops, uint32_t ops_per_hit, const uint8_t* qseq, uint32_t qlen, char* refalign,
+                char* queryalign);
+/* Fills r->refalign / r->queryalign / r->aln_stride for every hit of a fetched result (several host threads). */
+int dg_hunt_rows(dg_hunt_result* r);
 
 /* Host-buffer entry point: queries are raw bytes as read from the FASTA/argv (any case), concatenated.
  * seqlen[i] = faidx length of sequence i + 1 (util.h:201), nseq sequences. */

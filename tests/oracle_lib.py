@@ -156,6 +156,23 @@ def needle(a1: str, a2: str):
     return sc, _take(r0).decode(), _take(r1).decode(), tg.value
 
 
+def needle_hunt(window: str, query: str):
+    """needle() followed by hunt's column stripping (hunter.h:391-401, _trailGap :69-77): (score, refalign, queryalign, leading
+    query-gap columns dropped)"""
+    sc, r0, r1, tg = needle(window, query)
+    stop = len(r1) - tg
+    ra, qa, lead, in_lead = [], [], 0, True
+    for j in range(stop):
+        if r1[j] != "-":
+            in_lead = False
+        if in_lead:
+            lead += 1
+        else:
+            ra.append(r0[j])
+            qa.append(r1[j])
+    return sc, "".join(ra), "".join(qa), lead
+
+
 def bf_locate(text: bytes, pat: bytes):
     n = lib().orc_bf_locate(text, len(text), pat, len(pat), None, 0)
     buf = (C.c_uint64 * max(1, n))()

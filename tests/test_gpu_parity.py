@@ -246,6 +246,13 @@ def test_device_pointer_view_for_the_rccl_gather(gpu_small, small_genome):
     hb = device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), torch.device("cuda", 0))
     host = bytes(C.string_at(C.addressof(R.hits.contents), R.nhits * C.sizeof(_capi.Hit)))
     assert R.nhits > 0 and bytes(hb.cpu().numpy().tobytes()) == host
+    # the compact alignment description travels the same way: one 32-bit word per hit at distance 1
+    assert R.ops_per_hit == 1 and R.d_ops
+    ob = device_bytes(R.d_ops, R.nhits * 4, torch.device("cuda", 0))
+    assert bytes(ob.cpu().numpy().tobytes()) == bytes(C.string_at(C.addressof(R.ops.contents), R.nhits * 4))
+    assert not R.refalign  # rows exist only after dg_hunt_rows
+    _capi.check(L, L.dg_hunt_rows(rp))
+    assert R.refalign and R.aln_stride >= 20
     L.dg_hunt_result_free(rp)
 
 

@@ -213,7 +213,7 @@ int hunter(int argc, char** argv) {
   // small FASTA is answered from the Occ blocks alone
   // a process that opens the index for one input keeps the table compact (DG_OPEN_COMPACT): the 137 GB form saves microseconds
   // per batch and costs seconds to allocate when the driver still has to wipe memory another process released
-  uint32_t open_flags = std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_DEFAULT : DG_OPEN_COMPACT;
+  uint32_t open_flags = std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_BIG_TABLE : DG_OPEN_DEFAULT;
   {
     struct stat ist;
     if (!(stat(c.input.c_str(), &ist) == 0 && S_ISREG(ist.st_mode) && ist.st_size > (1 << 20)) && !std::getenv("DICEY_KMER_K"))
@@ -549,7 +549,7 @@ int silica(int argc, char** argv) {
   }
   if (!seq_len_name(c.genome, seqlen, seqname)) return bail("Error: Could not retrieve sequence lengths!");
   const int dev = device_from_env();
-  if (dg_index_open((strip_last_extension(c.genome) + ".fm9").c_str(), dev, std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_DEFAULT : DG_OPEN_COMPACT, &ix) != DG_OK) {
+  if (dg_index_open((strip_last_extension(c.genome) + ".fm9").c_str(), dev, std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_BIG_TABLE : DG_OPEN_DEFAULT, &ix) != DG_OK) {
     std::cerr << "dicey: " << dg_last_error() << std::endl;
     ix = nullptr;
     return bail("Error: FM-Index cannot be loaded!");

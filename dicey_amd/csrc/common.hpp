@@ -46,6 +46,7 @@ int fail(int code, const char* fmt, ...);
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  unsigned long long gen = 0;  // bumped whenever the block is replaced: what it held is gone
   int reserve(size_t bytes) {
     if (bytes <= cap) return DG_OK;
     if (p) (void)hipFree(p);
@@ -58,6 +59,7 @@ struct DevBuf {
       return fail(DG_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
     }
     cap = want;
+    ++gen;
     return DG_OK;
   }
   void release() {

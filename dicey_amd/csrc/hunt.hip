@@ -98,19 +98,51 @@ DG_HD u64 neighbourhood_bound(u32 m, u32 d, bool indel, u32 nN = 0) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k_prepare(Batch b) {
+// (r03: the characters come in as aligned 64-bit words loaded together — the byte loop waited for one load per character, 20 us
+// for 100 000 20-mers — and the lane clears its query's group counters, which takes the place of a memset in front of the batch)
+__global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
+  grp_cnt[2 * q] = grp_cnt[2 * q + 1] = 0;
+  nsel[2 * q] = nsel[2 * q + 1] = 0;
   u64 s = b.qoff[q], e = b.qoff[q + 1];
   u32 m = (u32)(e - s), bad = 0, flags = 0;
-  for (u32 i = 0; i < m; ++i) {
-    u32 ch = b.qbytes[s + i];
-    if (ch >= 'a' && ch <= 'z') ch -= 32;  // boost::to_upper_copy, hunter.h:306
-    u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
-    bad += (code == 4);  // every replaced character raises one warning (util.h:214); a literal 'N' is replaced too
-    b.fw[s + i] = (u8)code;
-    b.qseq[s + i] = ascii_of(code);
-    b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);  // util.h:54-91,110-114
+  u64 pk_fw = 0, pk_rv = 0;  // 2-bit packed strands, q[i] at bits 2(m-1-i) (meaningful for m <= 32 without N)
+  constexpr u32 NREG = 40;   // queries up to this length travel through registers
+  if (m <= NREG) {
+    constexpr int NW = NREG / 8 + 1;
+    const u64 a0 = s & ~7ULL;
+    const u32 sh = (u32)(s & 7) * 8;
+    const u64* src = reinterpret_cast<const u64*>(b.qbytes + a0);
+    u64 w[NW + 1], x[NW];
+#pragma unroll
+    for (int i = 0; i <= NW; ++i) w[i] = (u32)(8 * i) < (u32)(s & 7) + m ? src[i] : 0ULL;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) x[i] = sh ? (w[i] >> sh) | (w[i + 1] << (64 - sh)) : w[i];
+#pragma unroll
+    for (u32 i = 0; i < NREG; ++i) {
+      if (i < m) {
+        u32 ch = (u32)(x[i >> 3] >> (8 * (i & 7))) & 255u;
+        if (ch >= 'a' && ch <= 'z') ch -= 32;  // boost::to_upper_copy, hunter.h:306
+        const u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+        bad += (code == 4);  // every replaced character raises one warning (util.h:214); a literal 'N' is replaced too
+        b.fw[s + i] = (u8)code;
+        b.qseq[s + i] = ascii_of(code);
+        b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);  // util.h:54-91,110-114
+        pk_fw = (pk_fw << 2) | (code & 3u);
+        pk_rv |= (u64)((3u - code) & 3u) << (2 * (i & 31u));
+      }
+    }
+  } else {
+    for (u32 i = 0; i < m; ++i) {
+      u32 ch = b.qbytes[s + i];
+      if (ch >= 'a' && ch <= 'z') ch -= 32;
+      u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+      bad += (code == 4);
+      b.fw[s + i] = (u8)code;
+      b.qseq[s + i] = ascii_of(code);
+      b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);
+    }
   }
   if (m > b.maxlen_bound) atomicAdd(b.too_long, 1u);
   u32 d = b.distance;
@@ -137,10 +169,7 @@ __global__ void k_prepare(Batch b) {
     gi.d_win = d | (bad == 0 ? 256u : 0u);
     if (b.fastK && gi.m && bad == 0 && d == 1 && m <= 31 && m >= b.fastK + 1) gi.d_win |= 512u;
     if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
-    if (bad == 0 && m <= 32) {
-      const u8* sq = (strand ? b.rv : b.fw) + s;
-      for (u32 i = 0; i < m; ++i) gi.qpk |= (u64)sq[i] << (2 * (m - 1 - i));
-    }
+    if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
     b.ginfo[2 * q + strand] = gi;
   }
 }
@@ -1297,6 +1326,7 @@ __global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap, u32 surv_cap) {  /
 // what the host needs at the end of a batch, in 64 bytes instead of the 36 KB of sharded counters
 struct Summary {
   unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow, refused, too_long, probes, worst_surv;
+  unsigned long long jobs_big, jobs_small;  // repeat-rich strings queued by k_locate (workgroup / wavefront jobs)
 };
 __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {  // NSHARD lanes
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1316,42 +1346,63 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
     out->too_long = ctr->pad_[2];
   }
 }
-// Production form: one workgroup, one lane per shard, totals straight into the pinned host record (no atomics over the bus,
-// no separate copy); the host reads it after the batch's single stream synchronisation.
-__global__ void __launch_bounds__(NSHARD) k_summary_block(const Counters* ctr, const u64* nhits, Summary* host_out) {
+// Production form: totals straight into the pinned host record (no atomics over the bus, no separate copy); the host reads it
+// after the batch's single stream synchronisation.  Run by ONE workgroup: k_summary_block, or the workgroup of the batch's last
+// kernel that finishes last (k_verify_memo) — there the counters were updated by other workgroups of the same launch, so they are
+// read with device-scope atomic loads (past this CU's caches).  The counters are left ZEROED for the next batch.
+DG_DEV unsigned long long ctr_ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DG_DEV u32 ctr_ld(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
   constexpr int NF = 8;  // fields 1 and 7 are maxima, the others sums
-  __shared__ unsigned long long part[NF][NSHARD / 64];
-  const u32 k = threadIdx.x;
-  unsigned long long v[NF] = {ctr->leaf_cnt[k], ctr->leaf_cnt[k], ctr->steps[k], ctr->lookups[k], ctr->sa_reads[k], ctr->win_bytes[k], ctr->probes[k],
-                              ctr->surv_cnt[k]};
+  __shared__ unsigned long long acc[NF];
+  if (threadIdx.x < NF) acc[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long v[NF] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (u32 k = threadIdx.x; k < NSHARD; k += blockDim.x) {
+    const unsigned long long lc = ctr_ld(&ctr->leaf_cnt[k]), sc = ctr_ld(&ctr->surv_cnt[k]);
+    v[0] += lc;
+    v[1] = lc > v[1] ? lc : v[1];
+    v[2] += ctr_ld(&ctr->steps[k]);
+    v[3] += ctr_ld(&ctr->lookups[k]);
+    v[4] += ctr_ld(&ctr->sa_reads[k]);
+    v[5] += ctr_ld(&ctr->win_bytes[k]);
+    v[6] += ctr_ld(&ctr->probes[k]);
+    v[7] = sc > v[7] ? sc : v[7];
+  }
   for (int f = 0; f < NF; ++f) {
     unsigned long long x = v[f];
     for (int off = 32; off > 0; off >>= 1) {
       const unsigned long long o = __shfl_xor(x, off);
       x = (f == 1 || f == 7) ? (o > x ? o : x) : x + o;
     }
-    if ((k & 63) == 0) part[f][k >> 6] = x;
+    if ((threadIdx.x & 63) == 0) {
+      if (f == 1 || f == 7) atomicMax(&acc[f], x);
+      else atomicAdd(&acc[f], x);
+    }
   }
   __syncthreads();
-  if (k == 0) {
-    unsigned long long t[NF] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int f = 0; f < NF; ++f)
-      for (u32 w = 0; w < NSHARD / 64; ++w) t[f] = (f == 1 || f == 7) ? (part[f][w] > t[f] ? part[f][w] : t[f]) : t[f] + part[f][w];
-    host_out->worst_surv = t[7];
-    host_out->nleaf = t[0];
-    host_out->worst_shard = t[1];
-    host_out->steps = t[2];
-    host_out->lookups = t[3];
-    host_out->sa_reads = t[4];
-    host_out->win_bytes = t[5];
-    host_out->probes = t[6];
+  if (threadIdx.x == 0) {
+    host_out->worst_surv = acc[7];
+    host_out->nleaf = acc[0];
+    host_out->worst_shard = acc[1];
+    host_out->steps = acc[2];
+    host_out->lookups = acc[3];
+    host_out->sa_reads = acc[4];
+    host_out->win_bytes = acc[5];
+    host_out->probes = acc[6];
     host_out->nhits = *nhits;
-    host_out->overflow = ctr->overflow;
-    host_out->refused = ctr->pad_[1];
-    host_out->too_long = ctr->pad_[2];
+    host_out->overflow = ctr_ld(&ctr->overflow);
+    host_out->refused = ctr_ld(&ctr->pad_[1]);
+    host_out->too_long = ctr_ld(&ctr->pad_[2]);
+    host_out->jobs_big = ctr_ld(&ctr->pad_[0]);
+    host_out->jobs_small = ctr_ld(&ctr->pad_[4]);
     __threadfence_system();
   }
+  __syncthreads();
+  u32* w = reinterpret_cast<u32*>(ctr);
+  for (u32 i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) w[i] = 0;
 }
+__global__ void __launch_bounds__(NSHARD) k_summary_block(Counters* ctr, const u64* nhits, Summary* host_out) { batch_finish(ctr, nhits, host_out); }
 // group leaves by (query,strand): dst = grp_off[qs] + slot
 __global__ void k_group(const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, Leaf* out) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1757,6 +1808,83 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
   }
   if (threadIdx.x == 0) nsel[g] = base;
 }
+// ---- single-launch scans (r03): tiles chained by decoupled look-back ----
+// Every tile publishes its total, then looks back over the tiles before it — a wavefront reads 64 descriptors at a time — until it
+// meets one that already knows its inclusive prefix.  Tile numbers come from a ticket counter, so a tile only ever waits for
+// workgroups that started before it.  A descriptor is one 64-bit word {epoch:22, flag:2, value:40}; the epoch changes with every
+// scan, so stale words of earlier scans read as "not there yet" and nothing has to be cleared between scans.
+struct ChainScan {
+  unsigned long long* desc;  // one word per tile
+  u32* ticket;               // zero between scans (the workgroup that draws the last ticket resets it)
+  u32 epoch;                 // 1 .. 2^22 - 1
+  u32 tiles;
+};
+static constexpr u64 CS_VAL = (1ULL << 40) - 1;
+DG_DEV unsigned long long cs_pack(u32 epoch, u32 flag, u64 v) { return ((u64)epoch << 42) | ((u64)flag << 40) | (v & CS_VAL); }
+DG_DEV u32 chain_ticket(const ChainScan& cs, u32* lds1) {  // all lanes of the workgroup
+  if (threadIdx.x == 0) {
+    const u32 t = atomicAdd(cs.ticket, 1u);
+    if (t + 1 == cs.tiles) __hip_atomic_store(cs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lds1 = t;
+  }
+  __syncthreads();
+  const u32 t = *lds1;
+  __syncthreads();
+  return t;
+}
+// sum of the totals of all tiles before `tile`; all lanes of the workgroup call it with the tile's own total
+DG_DEV u64 chain_prefix(const ChainScan& cs, u32 tile, u64 total, u64* lds1) {
+  if (threadIdx.x < 64) {
+    const u32 lane = threadIdx.x;
+    if (tile == 0) {
+      if (lane == 0) {
+        __hip_atomic_store(&cs.desc[0], cs_pack(cs.epoch, 2, total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        *lds1 = 0;
+      }
+    } else {
+      if (lane == 0) __hip_atomic_store(&cs.desc[tile], cs_pack(cs.epoch, 1, total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      u64 run = 0;
+      for (int pos = (int)tile - 1;; pos -= 64) {
+        const int idx = pos - (int)lane;
+        unsigned long long w = cs_pack(cs.epoch, 2, 0);  // in front of tile 0: an inclusive prefix of zero
+        if (idx >= 0) {
+          do w = __hip_atomic_load(&cs.desc[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          while ((u32)(w >> 42) != cs.epoch || ((w >> 40) & 3u) == 0);
+        }
+        const unsigned long long incl = __ballot(((w >> 40) & 3u) == 2u);  // never empty once idx < 0 lanes exist; may be empty otherwise
+        const int first = incl ? (int)__ffsll((long long)incl) - 1 : 63;
+        u64 c = (int)lane <= first ? (u64)(w & CS_VAL) : 0ULL;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor((unsigned long long)c, off);
+        run += c;
+        if (incl) break;
+      }
+      if (lane == 0) {
+        __hip_atomic_store(&cs.desc[tile], cs_pack(cs.epoch, 2, run + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        *lds1 = run;
+      }
+    }
+  }
+  __syncthreads();
+  const u64 r = *lds1;
+  __syncthreads();
+  return r;
+}
+// exclusive scan inside a 256-lane workgroup: returns the lane's exclusive prefix, `total` = the workgroup's sum
+DG_DEV u64 block_excl_256(u64 mine, u64& total, u64* lds4) {
+  u64 incl = mine;
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const u64 o = __shfl_up((unsigned long long)incl, off);
+    if ((int)lane >= off) incl += o;
+  }
+  if (lane == 63) lds4[wave] = incl;
+  __syncthreads();
+  u64 before = 0;
+  for (u32 w = 0; w < wave; ++w) before += lds4[w];
+  total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return before + incl - mine;
+}
 __global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u32* qhits, const Counters* ctr) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
@@ -1779,6 +1907,37 @@ __global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u
   }
   qhits[q] = (u32)hits;
   if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
+}
+
+// k_take and the scan of its per-query hit counts in one launch (lane per query, workgroups chained like k_scan_chain)
+__global__ void __launch_bounds__(256) k_take_scan(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u64* hit_off /*[nq+1]*/, const Counters* ctr,
+                                                    ChainScan cs) {
+  __shared__ u64 lds4[4];
+  __shared__ u64 lds1;
+  __shared__ u32 ldst;
+  const u32 tile = chain_ticket(cs, &ldst);
+  const u64 q = (u64)tile * 256 + threadIdx.x;
+  u64 hits = 0;
+  if (q < b.nq && !ctr->overflow) {
+    for (u32 strand = 0; strand < 2; ++strand) {
+      Sel* S = sel + grp_off[2 * q + strand];
+      const u32 ns = nsel[2 * q + strand];
+      for (u32 r = 0; r < ns; ++r) {
+        const u64 occs = (u64)S[r].hi - S[r].lo;
+        u64 take = 0;
+        if (hits < b.max_locations) take = occs < b.max_locations - hits ? occs : b.max_locations - hits;
+        S[r].take = (u32)take;
+        S[r].hbase = (u32)hits;
+        hits += take;
+      }
+    }
+    if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
+  }
+  u64 total;
+  const u64 excl = block_excl_256(hits, total, lds4);
+  const u64 at = chain_prefix(cs, tile, total, &lds1) + excl;
+  if (q < b.nq) hit_off[q] = at;
+  if (q + 1 == b.nq || (b.nq == 0 && q == 0)) hit_off[b.nq] = at + hits;
 }
 
 // count mode: occurrences of all kept strings of a (query, strand) group
@@ -1936,11 +2095,37 @@ struct LocJobs {
   u32* n_big;
 };
 static constexpr u32 LOC_SMALL_MAX = 256;
+// A string with up to N occurrences: N loads in flight, a bitonic network on registers (every index is a compile-time constant —
+// r02's insertion sort indexed a private array dynamically, i.e. through scratch memory), `take` stores.
+template <int N>
+DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out, u32 g, u32 len, u32 slot) {
+  u32 v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = (u32)i < occs ? sa[i] : 0xFFFFFFFFu;
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const u32 a = v[i], b2 = v[l], mn = a < b2 ? a : b2, mx = a < b2 ? b2 : a;
+          v[i] = (i & k) == 0 ? mn : mx;
+          v[l] = (i & k) == 0 ? mx : mn;
+        }
+      }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if ((u32)i < take) out[i] = HitSeed{v[i], g, len, slot};
+}
 __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const u8* slot_qs, u32 slot_stride, const u64* grp_off, const u32* nsel,
                                                 u64 ngroups, const u64* hit_off, HitSeed* seeds, Counters* ctr, u64 hit_cap, LocJobs jobs) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
   u64 reads = 0;
+  BigJob bj;
+  u32 queue = 0;  // 1: wavefront job, 2: workgroup job
   if (t < grp_off[ngroups]) {
     const u32 g = *reinterpret_cast<const u32*>(slot_qs + t * slot_stride);  // g = 2*query + strand
     const Sel S = sel[t];
@@ -1949,20 +2134,13 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
       const u32 lo = S.lo, occs = S.hi - S.lo;
       const u64 out0 = hit_off[g >> 1] + S.hbase;
       HitSeed* out = seeds + out0;
-      if (occs <= 24) {
-        u32 v[24];
-        for (u32 i = 0; i < occs; ++i) {  // insertion sort of a handful of values
-          u32 x = f.sa[lo + i], j = i;
-          while (j > 0 && v[j - 1] > x) {
-            v[j] = v[j - 1];
-            --j;
-          }
-          v[j] = x;
-        }
+      if (occs <= 4) {
+        locate_in_registers<4>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
         reads += occs;
-        for (u32 i = 0; i < take; ++i) out[i] = HitSeed{v[i], g, S.len, (u32)t};
+      } else if (occs <= 16) {
+        locate_in_registers<16>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
+        reads += occs;
       } else if (jobs.big && take <= 16384) {
-        BigJob bj;
         bj.lo = lo;
         bj.occs = occs;
         bj.take = take;
@@ -1970,25 +2148,48 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
         bj.len = S.len;
         bj.slot = (u32)t;
         bj.out = out0;
-        const bool small = occs <= LOC_SMALL_MAX;
-        const u32 j = atomicAdd(small ? jobs.n_small : jobs.n_big, 1u);
-        if (j < jobs.cap) (small ? jobs.small : jobs.big)[j] = bj;
+        queue = occs <= LOC_SMALL_MAX ? 1u : 2u;
       } else {
-        // fallback: selection by repeated minimum above the previous pick (positions are distinct)
-        u64 prev = 0;
-        bool first = true;
-        for (u32 i = 0; i < take; ++i) {
-          u32 best = 0xFFFFFFFFu;
-          for (u32 j = 0; j < occs; ++j) {
-            u32 x = f.sa[lo + j];
-            if ((first || x > prev) && x < best) best = x;
-          }
-          reads += occs;
-          out[i] = HitSeed{best, g, S.len, (u32)t};
-          prev = best;
-          first = false;
-        }
+        bj.lo = lo;
+        bj.occs = occs;
+        bj.take = take;
+        bj.g = g;
+        bj.len = S.len;
+        bj.slot = (u32)t;
+        bj.out = out0;
+        queue = 3u;  // served by this lane, below
       }
+    }
+  }
+  // job slots: one atomic per wavefront and list (every lane on the two list heads was what this kernel waited for)
+  const u32 lane = threadIdx.x & 63;
+  for (u32 which = 1; which <= 2; ++which) {
+    const unsigned long long mk = __ballot(queue == which);
+    if (!mk) continue;
+    u32 base = 0;
+    if (lane == (u32)__ffsll((long long)mk) - 1u) base = atomicAdd(which == 1 ? jobs.n_small : jobs.n_big, (u32)__popcll(mk));
+    base = __shfl(base, (int)__ffsll((long long)mk) - 1);
+    if (queue == which) {
+      const u32 j = base + (u32)__popcll(mk & ((1ULL << lane) - 1));
+      if (j < jobs.cap) (which == 1 ? jobs.small : jobs.big)[j] = bj;
+      else queue = 3u;  // a full list (more than 2^20 repeat-rich strings in one batch): nothing is dropped, the lane serves it
+    }
+  }
+  if (queue == 3u) {
+    // correct for any size, slow: selection by repeated minimum above the previous pick (positions are distinct).  Reached with
+    // hunt -m above 16 384, with DICEY_NO_BLOCK_LOCATE, and by the strings a full job list turned away.
+    u64 prev = 0;
+    bool first = true;
+    for (u32 i = 0; i < bj.take; ++i) {
+      u32 best = 0xFFFFFFFFu;
+      for (u32 j = 0; j < bj.occs; ++j) {
+        const u32 x = f.sa[bj.lo + j];
+        if ((first || x > prev) && x < best) best = x;
+      }
+      reads += bj.occs;
+      seeds[bj.out + i] = HitSeed{best, bj.g, bj.len, bj.slot};
+      prev = best;
+      first = false;
     }
   }
   wave_add(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], reads);
@@ -2150,6 +2351,50 @@ struct TopkLds {
   u32 sh[4];
   u32 n_kept, job;
 };
+// Bitonic sort of buf[0, n2) (n2 a power of two <= 1024, entries behind it count as TOPK_PAD) by a 256-lane workgroup with four
+// elements per lane in registers: element i lives in lane i / 4.  Partners at distance 1-2 are in the same lane, at distance
+// 4-128 in the same wavefront (one shuffle), only distances 256 and 512 cross wavefronts through LDS — 3 barrier rounds for
+// 1 024 elements where the compare-exchange-in-LDS form had 55.  Returns the sorted elements 4 tid .. 4 tid + 3.
+DG_DEV void block_sort4(u32* buf, u32 n2, u32 (&v)[4]) {
+  const u32 i0 = threadIdx.x * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = i0 + r < n2 ? buf[i0 + r] : TOPK_PAD;
+  for (u32 kk = 2; kk <= n2; kk <<= 1) {
+    const bool up = (i0 & kk) == 0;  // kk >= 4: the same for the lane's four elements; kk == 2 is handled per pair below
+    for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+      if (jj >= 256) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[i0 + r] = v[r];
+        __syncthreads();
+        const bool keep_min = ((i0 & jj) == 0) == up;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u32 o = buf[(i0 + r) ^ jj];
+          v[r] = keep_min ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+        }
+      } else if (jj >= 4) {
+        const bool keep_min = ((i0 & jj) == 0) == up;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u32 o = (u32)__shfl_xor((int)v[r], (int)(jj >> 2));
+          v[r] = keep_min ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int b2 = a ^ (int)jj;
+          if (b2 > a && (jj == 1 || jj == 2)) {
+            const bool upp = kk == 2 ? ((a & 2) == 0) : up;  // (i & kk) == 0 for i = i0 + a
+            const u32 x = v[a], y = v[b2], mn = x < y ? x : y, mx = x < y ? y : x;
+            v[a] = upp ? mn : mx;
+            v[b2] = upp ? mx : mn;
+          }
+        }
+      }
+    }
+  }
+}
 // threshold T with k <= #(val <= T) <= limit (k <= limit < nv; limit == k: the exact k-th smallest).  All 256 lanes call it.
 DG_DEV u32 topk_threshold(TopkLds& S, u32 nv, u32 k, u32 limit) {
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2238,25 +2483,15 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
         }
         __syncthreads();
         const u32 have = S.n_kept;  // == k (positions are distinct) unless the whole interval is shorter
-        u32 n2 = 1;
+        u32 n2 = 4;
         while (n2 < have) n2 <<= 1;
         for (u32 i = have + threadIdx.x; i < n2; i += 256) buf[i] = TOPK_PAD;
         __syncthreads();
-        for (u32 kk = 2; kk <= n2; kk <<= 1)
-          for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (u32 i = threadIdx.x; i < n2; i += 256) {
-              const u32 l = i ^ jj;
-              if (l > i) {
-                const u32 a = buf[i], b2 = buf[l];
-                if ((a > b2) == ((i & kk) == 0)) {
-                  buf[i] = b2;
-                  buf[l] = a;
-                }
-              }
-            }
-            __syncthreads();
-          }
-        for (u32 i = threadIdx.x; i < k; i += 256) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
+        u32 sv[4];
+        block_sort4(buf, n2, sv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (threadIdx.x * 4 + r < k) seeds[J.out + threadIdx.x * 4 + r] = HitSeed{sv[r], J.g, J.len, J.slot};
         break;
       }
       // blocks of level j under the threshold -> cidx[cur ^ 1]
@@ -2316,6 +2551,7 @@ struct VerifyArgs {
   u32 stride;
   u32* ops;          // [nhits * ops_per_hit] compact alignment description (ALN_OP_NONE = unused)
   u32 ops_per_hit;   // the batch's largest effective distance
+  Summary* host_summary;  // != nullptr: the kernel is the batch's last one and its last workgroup runs batch_finish
 };
 
 // SMALL = true (all queries of the batch <= 32 nt): the DP row lives in registers (columns fully unrolled) and each
@@ -2867,7 +3103,7 @@ DG_DEV AlnRes band_align(const FmView& f, const Batch& b, const HitSeed sd, TR* 
 
 // Dynamic LDS: max(hash table, rows * 256 trace words + 256 * 72 window / query bytes), rows = maxlen + 3 d + 2 of the batch.
 template <int WB, int CH>
-__global__ void __launch_bounds__(256) k_verify_memo(FmView f, Batch b, VerifyArgs a, Counters* ctr, u32 rows) {
+DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs& a, Counters* ctr, u32 rows) {
   using TR = typename std::conditional<(WB <= 8), u16, u32>::type;
   constexpr u32 NH = 256u * CH;        // hits of a workgroup
   constexpr u32 HCAP = 2 * NH;         // hash slots (a power of two)
@@ -3028,6 +3264,21 @@ __global__ void __launch_bounds__(256) k_verify_memo(FmView f, Batch b, VerifyAr
     if (a.ops_per_hit >= 1) a.ops[h * a.ops_per_hit] = cls_ops[cls[j] * DS];
     if (DS > 1 && a.ops_per_hit >= 2) a.ops[h * a.ops_per_hit + 1] = cls_ops[cls[j] * DS + 1];
   }
+}
+
+template <int WB, int CH>
+__global__ void __launch_bounds__(256) k_verify_memo(FmView f, Batch b, VerifyArgs a, Counters* ctr, u32 rows) {
+  verify_memo_block<WB, CH>(f, b, a, ctr, rows);
+  if (!a.host_summary) return;
+  // the workgroup that finishes last closes the batch (summary to the host, counters zeroed): one launch less per step
+  __shared__ u32 s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(&ctr->pad_[5], 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last) batch_finish(ctr, a.nhits, a.host_summary);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -3263,6 +3514,31 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const u32* in, u64 n, const 
   }
 }
 
+// grp_cnt -> grp_off in one launch; the workgroup with ticket 0 also checks the search kernels' buffers (k_leaf_overflow)
+__global__ void __launch_bounds__(256) k_scan_chain(const u32* in, u64 n, u64* out /*[n+1]*/, ChainScan cs, Counters* ctr, u32 shard_cap, u32 surv_cap) {
+  __shared__ u64 lds4[4];
+  __shared__ u64 lds1;
+  __shared__ u32 ldst;
+  const u32 tile = chain_ticket(cs, &ldst);
+  if (tile == 0 && ctr)
+    for (u32 k = threadIdx.x; k < NSHARD; k += 256)
+      if (ctr->leaf_cnt[k] > shard_cap || ctr->surv_cnt[k] > surv_cap) atomicOr(&ctr->overflow, 1u);
+  const u64 base = (u64)tile * SCAN_TILE + threadIdx.x * 4;
+  u32 v[4];
+  u64 mine = 0;
+  for (u32 k = 0; k < 4; ++k) {
+    v[k] = base + k < n ? in[base + k] : 0u;
+    mine += v[k];
+  }
+  u64 total;
+  const u64 excl = block_excl_256(mine, total, lds4);
+  u64 run = chain_prefix(cs, tile, total, &lds1) + excl;
+  for (u32 k = 0; k < 4; ++k) {
+    if (base + k <= n) out[base + k] = run;  // index n receives the total
+    run += v[k];
+  }
+}
+
 int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* tmp) {
   static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
   if (!lane_only && n <= ((u64)1 << 24)) {
@@ -3470,6 +3746,23 @@ static PinnedPool& pinned_pool() {
   return *P;
 }
 
+// descriptors + ticket of the chained scans: one small block per handle, cleared when it is created and when the epoch wraps
+static constexpr u32 CHAIN_MAX_TILES = 16400;
+static int chain_state(dg_index* ix, hipStream_t st, u32 tiles, ChainScan& cs) {
+  auto& wb = ix->ws[WS_SCAN];
+  DG_TRY(wb.reserve((u64)(CHAIN_MAX_TILES + 8) * 8));
+  if (ix->scan_gen != wb.gen || ++ix->scan_epoch >= (1u << 22)) {
+    DG_HIP(hipMemsetAsync(wb.p, 0, (u64)(CHAIN_MAX_TILES + 8) * 8, st));
+    ix->scan_gen = wb.gen;
+    ix->scan_epoch = 1;
+  }
+  cs.desc = wb.as<unsigned long long>();
+  cs.ticket = reinterpret_cast<u32*>(cs.desc + CHAIN_MAX_TILES);
+  cs.epoch = ix->scan_epoch;
+  cs.tiles = tiles;
+  return DG_OK;
+}
+
 // One batch through the five kernels.  All sizes that are only known on the device (number of leaves, number of hits)
 // are handled with capacity guesses that the kernels check themselves; the host synchronises ONCE at the end, and
 // repeats the batch with larger buffers in the rare case a capacity was exceeded.
@@ -3632,6 +3925,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   for (int attempt = 0;; ++attempt) {
     if (attempt > 4) return fail(DG_ENOMEM, "buffer overflow persists (%llu leaves, %llu hits)", (unsigned long long)nleaf, (unsigned long long)nhits);
     const u64 leaf_slots = (u64)NSHARD * shard_cap;
+    bool closed_by_verify = false, take_fused = false;
     DG_TRY(ws[WS_LEAF].reserve(leaf_slots * sizeof(Leaf)));
     DG_TRY(ws[WS_LEAFG].reserve((leaf_slots + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
     DG_TRY(ws[WS_SEL].reserve((leaf_slots + 1) * sizeof(Sel)));
@@ -3643,9 +3937,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
     if (stride && !sx && !group_counts) DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
     if (!sx && !group_counts) DG_TRY(ws[WS_OPS].reserve((hit_cap + 1) * (u64)ops_per_hit * 4 + 64));
-    DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
+    // counters: left zeroed by the previous batch's last kernel (batch_finish) unless they moved or that batch did not finish;
+    // group counters: cleared by k_prepare
+    static const bool lane_only_ = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
+    if (lane_only_ || ix->ctr_clean != (const void*)ctr || ix->ctr_clean_gen != ws[WS_GRP].gen) DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
+    ix->ctr_clean = nullptr;  // dirty until this attempt's last kernel has run
     DG_HIP(hipEventRecord(ix->ev[0], st));
-    hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b);
+    hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_cnt, nsel);
     DG_HIP(hipEventRecord(ix->ev[1], st));
     {
       SearchOut so;
@@ -3712,8 +4010,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (nxs) hipLaunchKernelGGL(k_explicit, dim3(ceil_div(nxs, TB)), dim3(TB), 0, st, ix->view, b, so);
     }
     DG_HIP(hipEventRecord(ix->ev[2], st));
-    hipLaunchKernelGGL(k_leaf_overflow, dim3(NSHARD / 256), dim3(256), 0, st, ctr, shard_cap, surv_cap);
-    DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf));
+    static const bool no_chain = std::getenv("DICEY_NO_CHAIN_SCAN") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
+    const u32 tiles1 = (u32)((ngrp + SCAN_TILE) / SCAN_TILE);  // covers index ngrp as well
+    if (!no_chain && tiles1 <= CHAIN_MAX_TILES) {  // one launch: buffer check + scan
+      ChainScan cs;
+      DG_TRY(chain_state(ix, st, tiles1, cs));
+      hipLaunchKernelGGL(k_scan_chain, dim3(tiles1), dim3(256), 0, st, (const u32*)grp_cnt, ngrp, grp_off, cs, ctr, shard_cap, surv_cap);
+    } else {
+      hipLaunchKernelGGL(k_leaf_overflow, dim3(NSHARD / 256), dim3(256), 0, st, ctr, shard_cap, surv_cap);
+      DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf));
+    }
     DG_HIP(hipEventRecord(ix->ev[3], st));
     if (packed) {
       u8* alive = ws[WS_SCR].as<u8>();
@@ -3730,7 +4036,15 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
                          (u32)indel, alive, ctr, above);
       hipLaunchKernelGGL(k_leaf_rank, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
                          (const u8*)alive, ws[WS_SEL].as<Sel>(), nsel, ctr, above);
-      hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_off, nsel, ws[WS_SEL].as<Sel>(), qhits, ctr);
+      const u32 tiles2 = std::max<u32>(1u, ceil_div(nq, 256));
+      take_fused = !no_chain && !group_counts && tiles2 <= CHAIN_MAX_TILES;
+      if (take_fused) {  // hunter.h:350,357 gating and the hit offsets in one launch
+        ChainScan cs;
+        DG_TRY(chain_state(ix, st, tiles2, cs));
+        hipLaunchKernelGGL(k_take_scan, dim3(tiles2), dim3(256), 0, st, b, (const u64*)grp_off, (const u32*)nsel, ws[WS_SEL].as<Sel>(), hit_off,
+                           (const Counters*)ctr, cs);
+      } else
+        hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_off, nsel, ws[WS_SEL].as<Sel>(), qhits, ctr);
     } else {
       hipLaunchKernelGGL(k_group, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr, grp_off,
                          ws[WS_LEAFG].as<Leaf>());
@@ -3747,7 +4061,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       DG_HIP(hipMemsetAsync(hit_off + nq, 0, 8, st));  // no hits in this mode
       for (int e = 5; e <= 7; ++e) DG_HIP(hipEventRecord(ix->ev[e], st));
     } else {
-    DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
+    if (!take_fused) DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
     DG_HIP(hipEventRecord(ix->ev[5], st));
     {
       // strings with many occurrences go to two job lists: up to 256 occurrences for a wavefront each, more for a workgroup each
@@ -3793,6 +4107,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       va.stride = stride;
       va.ops = ws[WS_OPS].as<u32>();
       va.ops_per_hit = ops_per_hit;
+      va.host_summary = nullptr;
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
@@ -3801,12 +4116,20 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         // footprint), 8 when the previous batch had dozens of hits per query (repeat families: ~240 hits per kept string)
         static const int ch_env = std::getenv("DICEY_VERIFY_CH") ? std::atoi(std::getenv("DICEY_VERIFY_CH")) : 0;
         const u64 per_q = hit_cap / std::max<u64>(nq, 1);
-        const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= 24 ? 8 : (per_q >= 8 ? 4 : 1));
+        // (distance 2 on an i.i.d. genome: 59 hits per query from ~50 strings — nothing to share, and the wider trace of 13 diagonals
+        //  leaves room for fewer workgroups: r03 measured 2.39 ms with 8 hits per lane against 1.83 ms for the lane-per-hit kernel)
+        const u64 share_at = dmax_eff > 1 ? 192 : 24;
+        const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= share_at ? 8 : (per_q >= share_at / 3 ? 4 : 1));
         const u32 rows = maxlen + 3 * dmax_eff + 2;
         const bool wide = dmax_eff > 1;
         const u32 nw_bytes = rows * 256 * (wide ? 4u : 2u) + 256 * 72, hash_bytes = 2u * 256u * (u32)ch * 10u;
         const u32 lds = std::max(nw_bytes, hash_bytes);
         const dim3 mgrid(ceil_div(hit_cap, (u64)256 * ch)), mblock(256);
+        static const bool lane_only2 = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
+        if (!lane_only2) {
+          va.host_summary = &hsum;  // the kernel's last workgroup closes the batch
+          closed_by_verify = true;
+        }
 #define DG_LAUNCH_MEMO(WBV, CHV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_memo<WBV, CHV>), mgrid, mblock, lds, st, ix->view, b, va, ctr, rows)
         if (!wide) {
           if (ch == 8) DG_LAUNCH_MEMO(7, 8);
@@ -3841,18 +4164,21 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (lane_only) {
       hipLaunchKernelGGL(k_summary, dim3(NSHARD / 256), dim3(256), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), d_sum);
       DG_HIP(hipMemcpyAsync(&hsum, d_sum, sizeof(Summary), hipMemcpyDeviceToHost, st));
-    } else {
-      hipLaunchKernelGGL(k_summary_block, dim3(1), dim3(NSHARD), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), &hsum);
+    } else if (!closed_by_verify) {
+      hipLaunchKernelGGL(k_summary_block, dim3(1), dim3(NSHARD), 0, st, ctr, (const u64*)(hit_off + nq), &hsum);
     }
     DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
     DG_HIP(hipGetLastError());
+    if (!lane_only) {  // batch_finish left the counters zeroed where they are
+      ix->ctr_clean = ctr;
+      ix->ctr_clean_gen = ws[WS_GRP].gen;
+    }
     if (hsum.too_long) return fail(DG_EINVAL, "%llu queries are longer than the %u nt this batch was sized for", hsum.too_long, maxlen);
     if (hsum.refused)
       return fail(DG_EINVAL, "internal error: %llu quer%s could reach the maxNeighborhood cap (%u) without having been enumerated on the host",
                   hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
     if (const char* dj = std::getenv("DICEY_DUMP_JOBS")) {  // development aid: the repeat-rich strings of this batch (lo, occs, take, g, len, out)
-      u32 nj = 0;
-      DG_HIP(hipMemcpy(&nj, &ctr->pad_[0], 4, hipMemcpyDeviceToHost));
+      u32 nj = (u32)hsum.jobs_big;
       nj = std::min<u32>(nj, (u32)std::min<u64>(leaf_slots, 1u << 20));
       std::vector<BigJob> hj(nj);
       if (nj) DG_HIP(hipMemcpy(hj.data(), ws[WS_JOBS].as<BigJob>() + std::min<u64>(leaf_slots, 1u << 20), (size_t)nj * sizeof(BigJob), hipMemcpyDeviceToHost));

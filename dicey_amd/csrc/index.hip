@@ -573,7 +573,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
         K2 = K + 2;
         need += f2_b;
       }
-      if (!(flags & DG_OPEN_COMPACT) && have && (1ULL << (2 * K)) < n * 2 && free_b > need - (8ULL << (2 * K)) + (8ULL << (2 * (K + 1)))) ++K;
+      if ((flags & DG_OPEN_BIG_TABLE) && have && (1ULL << (2 * K)) < n * 2 && free_b > need - (8ULL << (2 * K)) + (8ULL << (2 * (K + 1)))) ++K;
     }
     if (const char* ek = std::getenv("DICEY_KMER_K")) {  // tuning knobs: force the table order (8..17) / the long filter's (0 = none)
       int v = std::atoi(ek);

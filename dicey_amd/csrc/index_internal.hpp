@@ -13,7 +13,7 @@ struct dg_index {
   uint64_t file_bytes = 0, hbm_bytes = 0;
   double load_seconds = 0, derive_seconds = 0;
   // grow-only batch workspaces (see hunt.hip / seam.hip for the slot meaning)
-  static constexpr int NWS = 22;
+  static constexpr int NWS = 23;
   dg::DevBuf ws[NWS];
   hipEvent_t ev[9] = {nullptr};  // [8]: end of the flat distance-1 kernel
   uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
@@ -25,6 +25,12 @@ struct dg_index {
   uint64_t last_nq = 0, last_total = 0;
   uint32_t last_maxlen = 0;
   void* pinned = nullptr;             // 4 KB of pinned host memory for the end-of-batch summary
+  // the batch counters are left zeroed by the last kernel of a batch (hunt.hip batch_finish): the next batch skips its memset
+  // when they still sit where that kernel cleaned them
+  uint32_t scan_epoch = 0;            // of the chained scans' descriptors in WS_SCAN (hunt.hip ChainScan)
+  unsigned long long scan_gen = 0;
+  const void* ctr_clean = nullptr;
+  unsigned long long ctr_clean_gen = 0;
   std::vector<uint64_t> cum_cache;    // cumulative sequence starts currently resident in WS_CUM
   ~dg_index();
 };

@@ -55,8 +55,10 @@ typedef struct dg_index dg_index;
 #define DG_OPEN_DEFAULT 0u
 #define DG_OPEN_NO_SELFCHECK 1u /* skip the load-time self validation (C[] vs Occ totals, SA permutation spot checks) */
 #define DG_OPEN_NO_KMER_TABLE 2u /* do not derive the K-mer jump table (saves up to 34 GB of HBM; search is slower) */
-#define DG_OPEN_COMPACT 4u       /* keep the table at order ceil(log4 n) (34 GB on a 3.1 Gb genome instead of 137 GB): a few per cent
-                                    slower searches, less than half the HBM to allocate — for processes that open, answer once, exit */
+#define DG_OPEN_COMPACT 4u       /* accepted, no effect since ABI 4: the compact table is the default */
+#define DG_OPEN_BIG_TABLE 8u     /* table of order ceil(log4 n) + 1 when the device has room (137 GB instead of 34 GB on a 3.1 Gb genome):
+                                    the distance-1 search kernel gains ~5 % (0.175 -> 0.166 ms per 100 000 20-mers), the open takes longer
+                                    and the process holds 199 GB instead of 90 GB — for resident servers with HBM to spare */
 
 /* Parses the file written by `dicey index` (sdsl store_to_checked_file of csa_wt<>) unchanged, uploads it to
  * HBM on `device`, and derives the search layouts there (Occ blocks, full suffix array, text copy). */

@@ -465,6 +465,44 @@ def main():
                                                 "hit; dg_hit_rows rebuilds the two rows), flags and normalised queries copied into a pinned "
                                                 "block from the library's pool after every batch",
                                         "hit_bytes_per_step": int(acc[-1]["nhits"]) * (C.sizeof(_capi.Hit) + 4 * int(acc[-1]["ops_per_hit"]))}
+            # host to host with two batches in flight: dg_hunt_submit / dg_hunt_wait (the asynchronous C entry points) on two
+            # handles sharing the resident index — query bytes go up, fetched results come back, every step
+            try:
+                hbuf = C.create_string_buffer(qbytes, len(qbytes))
+                hoff = (C.c_uint64 * (nq + 1))(*[int(x) for x in off])
+                second = ix.share()
+                lanes2 = [ix.handle, second.handle]
+
+                def submit(k):
+                    t = C.c_void_p()
+                    _capi.check(L, L.dg_hunt_submit(lanes2[k % 2], C.byref(p), sl, len(seqlen), hbuf, hoff, nq, C.byref(t)))
+                    return t
+
+                def wait(t):
+                    rp2 = C.POINTER(_capi.HuntResult)()
+                    _capi.check(L, L.dg_hunt_wait(t, C.byref(rp2)))
+                    nh = rp2.contents.nhits
+                    L.dg_hunt_result_free(rp2)
+                    return nh
+                for k in range(2):  # warm both handles (workspaces, pinned blocks)
+                    wait(submit(k))
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                inflight = [submit(0), submit(1)] if a.steps > 1 else [submit(0)]
+                done = 0
+                for k in range(a.steps):
+                    nh = wait(inflight[k])
+                    if len(inflight) < a.steps:
+                        inflight.append(submit(len(inflight)))
+                    done += 1
+                dth = time.perf_counter() - tp
+                second.close()
+                extras["host_to_host_pipelined"] = {
+                    "value": nq * a.steps / dth, "unit": "primers/s", "ms_per_step": dth / a.steps * 1e3, "hits_last_step": int(nh),
+                    "note": "same steps through dg_hunt_submit / dg_hunt_wait, two batches in flight on two handles of one resident "
+                            "index: query bytes from host memory, results fetched into pinned blocks; one Python thread drives it"}
+            except Exception as e:  # never lose the headline over an extra
+                extras["host_to_host_pipelined"] = {"error": repr(e)}
             cli_job = (queries, distance)  # measured in the common tail, after this process has released its own index
         if world == 1 and a.pipeline > 1:
             import threading
@@ -588,8 +626,21 @@ def main():
                              "lines_per_strand": (fabric_reads / (2 * nq)) if fabric_reads else None,
                              "index_accesses_per_query": (2 * ext + tab + probe) / nq,
                              "index_accesses_per_s": (2 * ext + tab + probe) / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
-                             "gather_ceiling_note": "random 64-B lines top out at 26 G lines/s inside 4 GiB and 19 G lines/s (1.2 TB/s) above "
-                                                    "16 GiB on this chip (profiles/r01c_gather_bench.jsonl); this kernel is a gather, not a stream"},
+                             # the same launch in three conventions, side by side: this build's units (above), SURVEY 8(d)
+                             # units, and rank operations only (no byte is counted for a filter probe or a table entry)
+                             "frac_by_convention": {
+                                 "own_units": achieved / HBM_PEAK_GBS,
+                                 "survey_units": survey_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
+                                 "rank_ops_only": ext * 2 * avg_l * 24 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0},
+                             # measured reference rates of this chip for random 64-byte lines (tools/microbench/gather_bench, r03): NOT
+                             # ceilings for this kernel — its own line rate (fabric_reads_per_s) is above the uniform-random rate of
+                             # its footprint because two thirds of its lines are filter lines inside 4 x 8.6 GB
+                             "gather_reference": {
+                                 "uniform_random_lines_Glines_per_s": {"4GiB": 26.5, "16GiB": 19.7, "64GiB": 19.1, "170GiB": 19.0},
+                                 "with_200k_lanes_only": {"4GiB": 21.8, "16GiB": 16.7, "170GiB": 16.0},
+                                 "filter_geometry_4_copies_of_8.6GB": {"6_lines_per_strand": 20.8, "12_lines_per_strand": 9.4,
+                                                                         "24_lines_per_strand": 11.3},
+                                 "source": "profiles/r03a_gather_matrix.jsonl, profiles/r03a_gather_filter.jsonl"}},
                 "cpu_baseline": cpu, "cpu_baseline_parallel": cpu_par, "pipelined": pipelined, "parity_sample": parity,
                 "phases_ms": {k: mean(k) for k in ("ms_total", "ms_search", "ms_search_flat", "ms_select", "ms_locate", "ms_verify")},
                 "hits_per_step": int(acc[-1]["nhits"]), "leaves_per_step": int(acc[-1]["leaves"]),

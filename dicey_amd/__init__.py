@@ -191,6 +191,25 @@ class FmIndex:
             self._L.dg_hunt_result_free(rp)
 
 
+    def hunt_submit(self, queries: Sequence[str], seqlen: Sequence[int], distance: int = 1, hamming: bool = False,
+                    forward_only: bool = False, max_locations: int = 1000, max_neighborhood: int = 10000):
+        """dg_hunt_submit: the batch runs on a helper thread of the library; collect with hunt_wait (one per handle at a time)."""
+        buf, off = _pack([q.encode("latin-1") if isinstance(q, str) else q for q in queries])
+        sl = (C.c_uint32 * len(seqlen))(*seqlen)
+        p = _capi.HuntParams(distance, int(hamming), int(forward_only), max_locations, max_neighborhood)
+        t = C.c_void_p()
+        _capi.check(self._L, self._L.dg_hunt_submit(self._h, C.byref(p), sl, len(seqlen), buf, off, len(queries), C.byref(t)))
+        return t
+
+    def hunt_wait(self, ticket) -> HuntBatch:
+        rp = C.POINTER(_capi.HuntResult)()
+        _capi.check(self._L, self._L.dg_hunt_wait(ticket, C.byref(rp)))
+        try:
+            return self._unpack(rp)
+        finally:
+            self._L.dg_hunt_result_free(rp)
+
+
 class Thal:
     """primer3 thal() as `dicey search` uses it (src/silica.h:316-329,437,511): END1, temponly, 37 C."""
 

@@ -262,22 +262,16 @@ int hunter(int argc, char** argv) {
   hp.max_neighborhood = c.max_neighborhood;
   // queries [q0, q1) on one handle, chunk by chunk; sink(i, json line of query i) is called in query order
   auto run_slice = [&](dg_index* ix, size_t s0, size_t s1, const std::function<void(size_t, std::string&&)>& sink, std::string& err) -> bool {
-    const size_t CHUNK = 1u << 20;
-    for (size_t q0 = s0; q0 < s1; q0 += CHUNK) {
-      size_t q1 = std::min(s1, q0 + CHUNK), nq = q1 - q0;
-      std::string qb;
-      std::vector<uint64_t> off(nq + 1, 0);
-      for (size_t i = 0; i < nq; ++i) {
+    auto pack = [&](size_t q0, size_t q1, std::string& qb, std::vector<uint64_t>& off) {
+      qb.clear();
+      off.assign(q1 - q0 + 1, 0);
+      for (size_t i = 0; i < q1 - q0; ++i) {
         qb += queries[q0 + i].second;
         off[i + 1] = qb.size();
       }
-      dg_hunt_result* R = nullptr;
-      if (dg_hunt(ix, &hp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), nq, &R) != DG_OK) {
-        err = dg_last_error();  // outside the supported envelope: say so, never guess
-        return false;
-      }
-      // one JSON line per query: independent of each other, so a large chunk formats them on several host threads
-      // (100 000 lines are 0.4 s on one) and hands them to the sink in query order
+    };
+    // one JSON line per query of a finished chunk, handed to the sink in query order
+    auto format_chunk = [&](dg_hunt_result* R, size_t q0, size_t nq) {
       auto line_of = [&](size_t i) -> std::string {
         std::vector<std::string> m;
         std::vector<DnaHit> ht;
@@ -327,9 +321,80 @@ int hunter(int argc, char** argv) {
       } else {
         for (size_t i = 0; i < nq; ++i) sink(q0 + i, line_of(i));
       }
+    };
+    // a chunk through the blocking call; a chunk whose capped neighbourhoods would not fit the library's host budget (DG_ELIMIT,
+    // hunt.hip cap_scan: long primers at distance 2) is answered in halves — the reference answers that input too, slowly
+    std::function<bool(dg_index*, size_t, size_t)> run_sync = [&](dg_index* hx, size_t q0, size_t q1) -> bool {
+      std::string qb;
+      std::vector<uint64_t> off;
+      pack(q0, q1, qb, off);
+      dg_hunt_result* R = nullptr;
+      const int rc = dg_hunt(hx, &hp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), q1 - q0, &R);
+      if (rc == DG_ELIMIT && q1 - q0 > 1) {
+        const size_t mid = q0 + (q1 - q0) / 2;
+        return run_sync(hx, q0, mid) && run_sync(hx, mid, q1);
+      }
+      if (rc != DG_OK) {
+        err = dg_last_error();  // outside the supported envelope: say so, never guess
+        return false;
+      }
+      format_chunk(R, q0, q1 - q0);
       dg_hunt_result_free(R);
+      return true;
+    };
+    // Large inputs go chunk by chunk with TWO batches in flight (dg_hunt_submit / dg_hunt_wait on this handle and on a second
+    // one that shares the resident index): while the host formats the lines of chunk k, chunk k+1 is on the GPU.
+    const size_t CHUNK = (s1 - s0) > (1u << 18) ? (1u << 17) : (1u << 20);
+    std::vector<std::pair<size_t, size_t>> chunks;
+    for (size_t q0 = s0; q0 < s1; q0 += CHUNK) chunks.emplace_back(q0, std::min(s1, q0 + CHUNK));
+    if (chunks.size() < 2 || std::getenv("DICEY_NO_PIPELINE")) {
+      for (auto& ch : chunks)
+        if (!run_sync(ix, ch.first, ch.second)) return false;
+      return true;
     }
-    return true;
+    dg_index* second = nullptr;
+    if (dg_index_share(ix, &second) != DG_OK) second = nullptr;
+    dg_index* lanes[2] = {ix, second ? second : ix};
+    const size_t depth = second ? 2 : 1;
+    std::vector<dg_hunt_ticket*> tickets(chunks.size(), nullptr);
+    bool ok = true;
+    auto submit = [&](size_t k) -> bool {
+      std::string qb;
+      std::vector<uint64_t> off;
+      pack(chunks[k].first, chunks[k].second, qb, off);
+      if (dg_hunt_submit(lanes[k % depth], &hp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(),
+                         chunks[k].second - chunks[k].first, &tickets[k]) != DG_OK) {
+        err = dg_last_error();
+        return false;
+      }
+      return true;
+    };
+    size_t submitted = 0;
+    for (; submitted < std::min(depth, chunks.size()) && ok; ++submitted) ok = submit(submitted);
+    for (size_t k = 0; k < chunks.size(); ++k) {
+      if (!tickets[k]) break;
+      dg_hunt_result* R = nullptr;
+      const int rc = dg_hunt_wait(tickets[k], &R);
+      tickets[k] = nullptr;
+      if (ok && rc == DG_OK && submitted < chunks.size()) {  // the handle is free again: the next chunk starts before this one is formatted
+        ok = submit(submitted);
+        if (ok) ++submitted;
+      }
+      if (!ok) {
+        if (R) dg_hunt_result_free(R);
+        continue;  // keep collecting what is in flight
+      }
+      if (rc == DG_ELIMIT) ok = run_sync(lanes[k % depth], chunks[k].first, chunks[k].second);  // that handle is idle: its wait() has returned and nothing new was submitted to it
+      else if (rc != DG_OK) {
+        err = dg_last_error();
+        ok = false;
+      } else {
+        format_chunk(R, chunks[k].first, chunks[k].second - chunks[k].first);
+        dg_hunt_result_free(R);
+      }
+    }
+    if (second) dg_index_close(second);
+    return ok;
   };
   int rc_all = 0;
   if (G == 1) {

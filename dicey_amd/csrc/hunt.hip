@@ -1347,11 +1347,11 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
   }
 }
 // Production form: totals straight into the pinned host record (no atomics over the bus, no separate copy); the host reads it
-// after the batch's single stream synchronisation.  Run by ONE workgroup: k_summary_block, or the workgroup of the batch's last
-// kernel that finishes last (k_verify_memo) — there the counters were updated by other workgroups of the same launch, so they are
-// read with device-scope atomic loads (past this CU's caches).  The counters are left ZEROED for the next batch.
-DG_DEV unsigned long long ctr_ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DG_DEV u32 ctr_ld(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// after the batch's single stream synchronisation.  The batch's last kernel: it also leaves the counters ZEROED for the next
+// batch (which then needs no memset in front).  One workgroup.
+// (r03 tried to run this in "the workgroup of the verify kernel that finishes last": the device-scope fence every workgroup needs
+// before it reports in writes back its XCD's L2 — the 8 300 workgroups of a repeat-genome step went from 1.05 to 1.60 ms.  On
+// this part workgroups of one launch do not talk to each other cheaply; a 7 us kernel of its own is the better deal.)
 DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
   constexpr int NF = 8;  // fields 1 and 7 are maxima, the others sums
   __shared__ unsigned long long acc[NF];
@@ -1359,16 +1359,17 @@ DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
   __syncthreads();
   unsigned long long v[NF] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (u32 k = threadIdx.x; k < NSHARD; k += blockDim.x) {
-    const unsigned long long lc = ctr_ld(&ctr->leaf_cnt[k]), sc = ctr_ld(&ctr->surv_cnt[k]);
+    const unsigned long long lc = ctr->leaf_cnt[k], sc = ctr->surv_cnt[k];
     v[0] += lc;
     v[1] = lc > v[1] ? lc : v[1];
-    v[2] += ctr_ld(&ctr->steps[k]);
-    v[3] += ctr_ld(&ctr->lookups[k]);
-    v[4] += ctr_ld(&ctr->sa_reads[k]);
-    v[5] += ctr_ld(&ctr->win_bytes[k]);
-    v[6] += ctr_ld(&ctr->probes[k]);
+    v[2] += ctr->steps[k];
+    v[3] += ctr->lookups[k];
+    v[4] += ctr->sa_reads[k];
+    v[5] += ctr->win_bytes[k];
+    v[6] += ctr->probes[k];
     v[7] = sc > v[7] ? sc : v[7];
   }
+#pragma unroll
   for (int f = 0; f < NF; ++f) {
     unsigned long long x = v[f];
     for (int off = 32; off > 0; off >>= 1) {
@@ -1391,11 +1392,11 @@ DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
     host_out->win_bytes = acc[5];
     host_out->probes = acc[6];
     host_out->nhits = *nhits;
-    host_out->overflow = ctr_ld(&ctr->overflow);
-    host_out->refused = ctr_ld(&ctr->pad_[1]);
-    host_out->too_long = ctr_ld(&ctr->pad_[2]);
-    host_out->jobs_big = ctr_ld(&ctr->pad_[0]);
-    host_out->jobs_small = ctr_ld(&ctr->pad_[4]);
+    host_out->overflow = ctr->overflow;
+    host_out->refused = ctr->pad_[1];
+    host_out->too_long = ctr->pad_[2];
+    host_out->jobs_big = ctr->pad_[0];
+    host_out->jobs_small = ctr->pad_[4];
     __threadfence_system();
   }
   __syncthreads();
@@ -1808,83 +1809,6 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
   }
   if (threadIdx.x == 0) nsel[g] = base;
 }
-// ---- single-launch scans (r03): tiles chained by decoupled look-back ----
-// Every tile publishes its total, then looks back over the tiles before it — a wavefront reads 64 descriptors at a time — until it
-// meets one that already knows its inclusive prefix.  Tile numbers come from a ticket counter, so a tile only ever waits for
-// workgroups that started before it.  A descriptor is one 64-bit word {epoch:22, flag:2, value:40}; the epoch changes with every
-// scan, so stale words of earlier scans read as "not there yet" and nothing has to be cleared between scans.
-struct ChainScan {
-  unsigned long long* desc;  // one word per tile
-  u32* ticket;               // zero between scans (the workgroup that draws the last ticket resets it)
-  u32 epoch;                 // 1 .. 2^22 - 1
-  u32 tiles;
-};
-static constexpr u64 CS_VAL = (1ULL << 40) - 1;
-DG_DEV unsigned long long cs_pack(u32 epoch, u32 flag, u64 v) { return ((u64)epoch << 42) | ((u64)flag << 40) | (v & CS_VAL); }
-DG_DEV u32 chain_ticket(const ChainScan& cs, u32* lds1) {  // all lanes of the workgroup
-  if (threadIdx.x == 0) {
-    const u32 t = atomicAdd(cs.ticket, 1u);
-    if (t + 1 == cs.tiles) __hip_atomic_store(cs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *lds1 = t;
-  }
-  __syncthreads();
-  const u32 t = *lds1;
-  __syncthreads();
-  return t;
-}
-// sum of the totals of all tiles before `tile`; all lanes of the workgroup call it with the tile's own total
-DG_DEV u64 chain_prefix(const ChainScan& cs, u32 tile, u64 total, u64* lds1) {
-  if (threadIdx.x < 64) {
-    const u32 lane = threadIdx.x;
-    if (tile == 0) {
-      if (lane == 0) {
-        __hip_atomic_store(&cs.desc[0], cs_pack(cs.epoch, 2, total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        *lds1 = 0;
-      }
-    } else {
-      if (lane == 0) __hip_atomic_store(&cs.desc[tile], cs_pack(cs.epoch, 1, total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      u64 run = 0;
-      for (int pos = (int)tile - 1;; pos -= 64) {
-        const int idx = pos - (int)lane;
-        unsigned long long w = cs_pack(cs.epoch, 2, 0);  // in front of tile 0: an inclusive prefix of zero
-        if (idx >= 0) {
-          do w = __hip_atomic_load(&cs.desc[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-          while ((u32)(w >> 42) != cs.epoch || ((w >> 40) & 3u) == 0);
-        }
-        const unsigned long long incl = __ballot(((w >> 40) & 3u) == 2u);  // never empty once idx < 0 lanes exist; may be empty otherwise
-        const int first = incl ? (int)__ffsll((long long)incl) - 1 : 63;
-        u64 c = (int)lane <= first ? (u64)(w & CS_VAL) : 0ULL;
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor((unsigned long long)c, off);
-        run += c;
-        if (incl) break;
-      }
-      if (lane == 0) {
-        __hip_atomic_store(&cs.desc[tile], cs_pack(cs.epoch, 2, run + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        *lds1 = run;
-      }
-    }
-  }
-  __syncthreads();
-  const u64 r = *lds1;
-  __syncthreads();
-  return r;
-}
-// exclusive scan inside a 256-lane workgroup: returns the lane's exclusive prefix, `total` = the workgroup's sum
-DG_DEV u64 block_excl_256(u64 mine, u64& total, u64* lds4) {
-  u64 incl = mine;
-  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    const u64 o = __shfl_up((unsigned long long)incl, off);
-    if ((int)lane >= off) incl += o;
-  }
-  if (lane == 63) lds4[wave] = incl;
-  __syncthreads();
-  u64 before = 0;
-  for (u32 w = 0; w < wave; ++w) before += lds4[w];
-  total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-  __syncthreads();
-  return before + incl - mine;
-}
 __global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u32* qhits, const Counters* ctr) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
@@ -1907,37 +1831,6 @@ __global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u
   }
   qhits[q] = (u32)hits;
   if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
-}
-
-// k_take and the scan of its per-query hit counts in one launch (lane per query, workgroups chained like k_scan_chain)
-__global__ void __launch_bounds__(256) k_take_scan(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u64* hit_off /*[nq+1]*/, const Counters* ctr,
-                                                    ChainScan cs) {
-  __shared__ u64 lds4[4];
-  __shared__ u64 lds1;
-  __shared__ u32 ldst;
-  const u32 tile = chain_ticket(cs, &ldst);
-  const u64 q = (u64)tile * 256 + threadIdx.x;
-  u64 hits = 0;
-  if (q < b.nq && !ctr->overflow) {
-    for (u32 strand = 0; strand < 2; ++strand) {
-      Sel* S = sel + grp_off[2 * q + strand];
-      const u32 ns = nsel[2 * q + strand];
-      for (u32 r = 0; r < ns; ++r) {
-        const u64 occs = (u64)S[r].hi - S[r].lo;
-        u64 take = 0;
-        if (hits < b.max_locations) take = occs < b.max_locations - hits ? occs : b.max_locations - hits;
-        S[r].take = (u32)take;
-        S[r].hbase = (u32)hits;
-        hits += take;
-      }
-    }
-    if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
-  }
-  u64 total;
-  const u64 excl = block_excl_256(hits, total, lds4);
-  const u64 at = chain_prefix(cs, tile, total, &lds1) + excl;
-  if (q < b.nq) hit_off[q] = at;
-  if (q + 1 == b.nq || (b.nq == 0 && q == 0)) hit_off[b.nq] = at + hits;
 }
 
 // count mode: occurrences of all kept strings of a (query, strand) group
@@ -2437,9 +2330,11 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
   const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
   const u32 lane = threadIdx.x & 63;
   u64 reads = 0;
-  for (;;) {
+  // jobs: the first gridDim.x by workgroup number, the rest from a counter (an empty list costs no atomic: 768 workgroups on one
+  // word were 8 of the 10.7 us this kernel took on a batch without repeat-rich strings)
+  for (u32 round = 0;; ++round) {
     __syncthreads();  // the previous job's buffers are free
-    if (threadIdx.x == 0) S.job = atomicAdd(next_job, 1u);
+    if (threadIdx.x == 0) S.job = round == 0 ? blockIdx.x : gridDim.x + atomicAdd(next_job, 1u);
     __syncthreads();
     const u32 jb = S.job;
     if (jb >= njobs) break;
@@ -2551,7 +2446,7 @@ struct VerifyArgs {
   u32 stride;
   u32* ops;          // [nhits * ops_per_hit] compact alignment description (ALN_OP_NONE = unused)
   u32 ops_per_hit;   // the batch's largest effective distance
-  Summary* host_summary;  // != nullptr: the kernel is the batch's last one and its last workgroup runs batch_finish
+  u32 debug;              // DICEY_DBG_VERIFY (measurements only: 1 = skip the alignments, 2 = skip the context reads; results are wrong)
 };
 
 // SMALL = true (all queries of the batch <= 32 nt): the DP row lives in registers (columns fully unrolled) and each
@@ -3123,7 +3018,9 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
   const u64 base = (u64)blockIdx.x * NH;
   if (base >= nh) return;
   const u32 tid = threadIdx.x;
-  for (u32 i = tid; i < HCAP; i += 256) hkey[i] = EMPTY;
+  constexpr bool SHARE = CH > 1;  // CH == 1: no table, every hit is aligned by its own lane (batches with a handful of hits per query)
+  if (SHARE)
+    for (u32 i = tid; i < HCAP; i += 256) hkey[i] = EMPTY;
   if (tid == 0) {
     s_ncls = 0;
     s_fault = 0;
@@ -3146,7 +3043,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     const u64 loc = sd[j].pos, endp = loc + sd[j].len;
     const u32 d = dq[j];
     u32 x = 0;
-    if (h < nh) {
+    if (h < nh && !(a.debug & 2u)) {
       if (d >= 1 && loc >= 1) x |= (u32)f.text[loc - 1];
       if (DS >= 2 && d >= 2 && loc >= 2) x |= (u32)f.text[loc - 2] << 8;
       if (d >= 1 && endp + 1 <= f.n) x |= (u32)f.text[endp] << 16;
@@ -3198,6 +3095,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     cpos[j] = chrpos;
     wbytes += pre + sd[j].len + post;
     const u32 local = (u32)j * 256u + tid;
+    if (!SHARE) continue;
     // a class = (kept string, effective context lengths, context bytes); slots beyond 2^28 stay classes of their own
     const u64 key = sd[j].sel < (1u << 28) ? ((u64)(sd[j].sel | (pre_eff << 28) | (post_eff << 30)) << 32) | (pb << 16) | qb
                                            : ((u64)(0xC0000000u | local) << 32);
@@ -3214,31 +3112,44 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     slot[j] = sidx;
   }
   wave_add(&ctr->win_bytes[blockIdx.x & (NSHARD - 1)], wbytes);
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < CH; ++j)
-    if (won[j]) {
-      const u32 c = atomicAdd(&s_ncls, 1u);
-      hval[slot[j]] = (u16)c;
-      cls_owner[c] = (u16)((u32)j * 256u + tid);
-    }
-  __syncthreads();
   u32 cls[CH];
+  u32 ncls = 0;
+  if (SHARE) {
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < CH; ++j) cls[j] = hval[slot[j]];
-  const u32 ncls = s_ncls;
+    for (int j = 0; j < CH; ++j)
+      if (won[j]) {
+        const u32 c = atomicAdd(&s_ncls, 1u);
+        hval[slot[j]] = (u16)c;
+        cls_owner[c] = (u16)((u32)j * 256u + tid);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CH; ++j) cls[j] = hval[slot[j]];
+    ncls = s_ncls;
+  }
   __syncthreads();  // the table's memory becomes the trace
   // ---- phase 2: per class
   TR* const tr = reinterpret_cast<TR*>(u_lds) + tid;
   u8* const lds_g = u_lds + rows * 256 * sizeof(TR) + tid * 72;
   u32 fault = 0;
-  for (u32 c = tid; c < ncls; c += 256) {
-    const u32 own = cls_owner[c];
-    const uint4 v = *reinterpret_cast<const uint4*>(a.seeds + base + own);
-    const AlnRes r = band_align<WB, TR>(f, b, HitSeed{v.x, v.y, v.z, v.w}, tr, lds_g, fault);
-    cls_info[c] = r.info;
-    cls_ops[c * DS] = r.op[0];
-    if (DS > 1) cls_ops[c * DS + 1] = r.op[1];
+  if (!SHARE) {
+    cls[0] = tid;
+    if (base + tid < nh && !(a.debug & 1u)) {
+      const AlnRes r = band_align<WB, TR>(f, b, sd[0], tr, lds_g, fault);
+      cls_info[tid] = r.info;
+      cls_ops[tid * DS] = r.op[0];
+      if (DS > 1) cls_ops[tid * DS + 1] = r.op[1];
+    }
+  } else {
+    for (u32 c = tid; c < ncls && !(a.debug & 1u); c += 256) {
+      const u32 own = cls_owner[c];
+      const uint4 v = *reinterpret_cast<const uint4*>(a.seeds + base + own);
+      const AlnRes r = band_align<WB, TR>(f, b, HitSeed{v.x, v.y, v.z, v.w}, tr, lds_g, fault);
+      cls_info[c] = r.info;
+      cls_ops[c * DS] = r.op[0];
+      if (DS > 1) cls_ops[c * DS + 1] = r.op[1];
+    }
   }
   if (fault) s_fault = 1;
   __syncthreads();
@@ -3269,16 +3180,6 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
 template <int WB, int CH>
 __global__ void __launch_bounds__(256) k_verify_memo(FmView f, Batch b, VerifyArgs a, Counters* ctr, u32 rows) {
   verify_memo_block<WB, CH>(f, b, a, ctr, rows);
-  if (!a.host_summary) return;
-  // the workgroup that finishes last closes the batch (summary to the host, counters zeroed): one launch less per step
-  __shared__ u32 s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(&ctr->pad_[5], 1u) == gridDim.x - 1 ? 1u : 0u;
-  }
-  __syncthreads();
-  if (s_last) batch_finish(ctr, a.nhits, a.host_summary);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -3477,8 +3378,13 @@ DG_DEV u64 block_sum_256(u64 v, u64* lds4) {  // sum over a 256-lane workgroup, 
   __syncthreads();
   return r;
 }
-__global__ void __launch_bounds__(256) k_scan_tile_sums(const u32* in, u64 n, u64* sums) {
+// ctr != nullptr: the first workgroup also checks the search kernels' leaf / survivor regions (what k_leaf_overflow did in a launch
+// of its own): the flag is set before any kernel that reads leaves starts
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const u32* in, u64 n, u64* sums, Counters* ctr, u32 shard_cap, u32 surv_cap) {
   __shared__ u64 lds4[4];
+  if (ctr && blockIdx.x == 0)
+    for (u32 k = threadIdx.x; k < NSHARD; k += 256)
+      if (ctr->leaf_cnt[k] > shard_cap || ctr->surv_cnt[k] > surv_cap) atomicOr(&ctr->overflow, 1u);
   const u64 base = (u64)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
   u64 s = 0;
   for (u32 k = 0; k < 4; ++k)
@@ -3514,39 +3420,15 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const u32* in, u64 n, const 
   }
 }
 
-// grp_cnt -> grp_off in one launch; the workgroup with ticket 0 also checks the search kernels' buffers (k_leaf_overflow)
-__global__ void __launch_bounds__(256) k_scan_chain(const u32* in, u64 n, u64* out /*[n+1]*/, ChainScan cs, Counters* ctr, u32 shard_cap, u32 surv_cap) {
-  __shared__ u64 lds4[4];
-  __shared__ u64 lds1;
-  __shared__ u32 ldst;
-  const u32 tile = chain_ticket(cs, &ldst);
-  if (tile == 0 && ctr)
-    for (u32 k = threadIdx.x; k < NSHARD; k += 256)
-      if (ctr->leaf_cnt[k] > shard_cap || ctr->surv_cnt[k] > surv_cap) atomicOr(&ctr->overflow, 1u);
-  const u64 base = (u64)tile * SCAN_TILE + threadIdx.x * 4;
-  u32 v[4];
-  u64 mine = 0;
-  for (u32 k = 0; k < 4; ++k) {
-    v[k] = base + k < n ? in[base + k] : 0u;
-    mine += v[k];
-  }
-  u64 total;
-  const u64 excl = block_excl_256(mine, total, lds4);
-  u64 run = chain_prefix(cs, tile, total, &lds1) + excl;
-  for (u32 k = 0; k < 4; ++k) {
-    if (base + k <= n) out[base + k] = run;  // index n receives the total
-    run += v[k];
-  }
-}
-
-int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* tmp) {
+int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* tmp, Counters* ctr, u32 shard_cap, u32 surv_cap) {
   static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
   if (!lane_only && n <= ((u64)1 << 24)) {
     const u32 tiles = (u32)((n + SCAN_TILE) / SCAN_TILE);  // covers index n as well
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(256), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(256), 0, st, in, n, tmp, ctr, shard_cap, surv_cap);
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, in, n, (const u64*)tmp, out);
     return DG_OK;
   }
+  if (ctr) hipLaunchKernelGGL(k_leaf_overflow, dim3(NSHARD / 256), dim3(256), 0, st, ctr, shard_cap, surv_cap);
   const u64 n1 = (n + SCAN_CHUNK - 1) / SCAN_CHUNK, n2 = (n1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
   u64* p1 = tmp;
   u64* p2 = tmp + n1;
@@ -3746,23 +3628,6 @@ static PinnedPool& pinned_pool() {
   return *P;
 }
 
-// descriptors + ticket of the chained scans: one small block per handle, cleared when it is created and when the epoch wraps
-static constexpr u32 CHAIN_MAX_TILES = 16400;
-static int chain_state(dg_index* ix, hipStream_t st, u32 tiles, ChainScan& cs) {
-  auto& wb = ix->ws[WS_SCAN];
-  DG_TRY(wb.reserve((u64)(CHAIN_MAX_TILES + 8) * 8));
-  if (ix->scan_gen != wb.gen || ++ix->scan_epoch >= (1u << 22)) {
-    DG_HIP(hipMemsetAsync(wb.p, 0, (u64)(CHAIN_MAX_TILES + 8) * 8, st));
-    ix->scan_gen = wb.gen;
-    ix->scan_epoch = 1;
-  }
-  cs.desc = wb.as<unsigned long long>();
-  cs.ticket = reinterpret_cast<u32*>(cs.desc + CHAIN_MAX_TILES);
-  cs.epoch = ix->scan_epoch;
-  cs.tiles = tiles;
-  return DG_OK;
-}
-
 // One batch through the five kernels.  All sizes that are only known on the device (number of leaves, number of hits)
 // are handled with capacity guesses that the kernels check themselves; the host synchronises ONCE at the end, and
 // repeats the batch with larger buffers in the rare case a capacity was exceeded.
@@ -3922,10 +3787,50 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   if (std::getenv("DICEY_DEBUG_CAPS")) surv_cap_log2 = 1;
   u64 nleaf = 0, nhits = 0;
+  // Fetched results: one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh
+  // hipHostMalloc per batch costs more than the copies), laid out for `capn` hits:
+  // [hit_off | qoff | qdistance qflags qnondna | qseq | hits | ops].  When the previous fetched batch on this handle tells how many
+  // hits to expect, the copies are queued BEHIND the batch's kernels, before its one synchronisation (no second round trip);
+  // a batch with more hits than expected copies again after the synchronisation.
+  struct FetchLayout {
+    u64 o_hit_off, o_qoff, o_meta, o_qseq, o_hits, o_ops, bytes;
+  };
+  auto fetch_layout = [&](u64 capn) {
+    FetchLayout L;
+    L.o_hit_off = 0;
+    L.o_qoff = L.o_hit_off + (nq + 1) * 8;
+    L.o_meta = L.o_qoff + (nq + 1) * 8;
+    L.o_qseq = L.o_meta + 3 * (u64)nq * 4;
+    L.o_hits = (L.o_qseq + total + 15) & ~15ull;
+    L.o_ops = (L.o_hits + capn * sizeof(dg_hit) + 15) & ~15ull;
+    L.bytes = L.o_ops + capn * (u64)ops_per_hit * 4 + 64;
+    return L;
+  };
+  struct BlockGuard {  // hands an unused block back on every early return
+    PinnedBlock* pb = nullptr;
+    ~BlockGuard() {
+      if (pb) pinned_pool().put(pb);
+    }
+  } spec;
+  u64 spec_cap = 0;
+  auto queue_fetch = [&](PinnedBlock* pb, u64 capn, u64 ncopy) -> int {
+    const FetchLayout L = fetch_layout(capn);
+    u8* hb = (u8*)pb->p;
+    DG_HIP(hipMemcpyAsync(hb + L.o_hit_off, ws[WS_GRP].as<u8>() + (ngrp + 1) * 8, (nq + 1) * 8, hipMemcpyDeviceToHost, st));  // hit_off
+    DG_HIP(hipMemcpyAsync(hb + L.o_meta, ws[WS_QMETA].as<u32>() + nq, 3 * (u64)nq * 4, hipMemcpyDeviceToHost, st));  // qdist, qflags, qnondna lie in this order
+    if (ncopy) {
+      DG_HIP(hipMemcpyAsync(hb + L.o_hits, ws[WS_HITS].p, ncopy * sizeof(dg_hit), hipMemcpyDeviceToHost, st));
+      if (ops_per_hit) DG_HIP(hipMemcpyAsync(hb + L.o_ops, ws[WS_OPS].p, ncopy * (u64)ops_per_hit * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (total) DG_HIP(hipMemcpyAsync(hb + L.o_qseq, ws[WS_QSEQ].p, total, hipMemcpyDeviceToHost, st));
+    if (h_qoff) std::memcpy(hb + L.o_qoff, h_qoff, (nq + 1) * 8);
+    else DG_HIP(hipMemcpyAsync(hb + L.o_qoff, d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
+    return DG_OK;
+  };
   for (int attempt = 0;; ++attempt) {
     if (attempt > 4) return fail(DG_ENOMEM, "buffer overflow persists (%llu leaves, %llu hits)", (unsigned long long)nleaf, (unsigned long long)nhits);
     const u64 leaf_slots = (u64)NSHARD * shard_cap;
-    bool closed_by_verify = false, take_fused = false;
+
     DG_TRY(ws[WS_LEAF].reserve(leaf_slots * sizeof(Leaf)));
     DG_TRY(ws[WS_LEAFG].reserve((leaf_slots + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
     DG_TRY(ws[WS_SEL].reserve((leaf_slots + 1) * sizeof(Sel)));
@@ -4010,16 +3915,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (nxs) hipLaunchKernelGGL(k_explicit, dim3(ceil_div(nxs, TB)), dim3(TB), 0, st, ix->view, b, so);
     }
     DG_HIP(hipEventRecord(ix->ev[2], st));
-    static const bool no_chain = std::getenv("DICEY_NO_CHAIN_SCAN") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
-    const u32 tiles1 = (u32)((ngrp + SCAN_TILE) / SCAN_TILE);  // covers index ngrp as well
-    if (!no_chain && tiles1 <= CHAIN_MAX_TILES) {  // one launch: buffer check + scan
-      ChainScan cs;
-      DG_TRY(chain_state(ix, st, tiles1, cs));
-      hipLaunchKernelGGL(k_scan_chain, dim3(tiles1), dim3(256), 0, st, (const u32*)grp_cnt, ngrp, grp_off, cs, ctr, shard_cap, surv_cap);
-    } else {
-      hipLaunchKernelGGL(k_leaf_overflow, dim3(NSHARD / 256), dim3(256), 0, st, ctr, shard_cap, surv_cap);
-      DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf));
-    }
+    // (r03 tried single-launch scans chained by decoupled look-back, and k_take fused with its scan: 17 us against 2 x 4.3 us, and
+    //  47 us against 7 + 9 us — descriptor polling with device-scope acquire / release is slow across the XCDs' L2s.  What stays of
+    //  that round: the first scan kernel also checks the search kernels' buffers, which was a launch of its own.)
+    DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf, ctr, shard_cap, surv_cap));
     DG_HIP(hipEventRecord(ix->ev[3], st));
     if (packed) {
       u8* alive = ws[WS_SCR].as<u8>();
@@ -4036,15 +3935,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
                          (u32)indel, alive, ctr, above);
       hipLaunchKernelGGL(k_leaf_rank, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
                          (const u8*)alive, ws[WS_SEL].as<Sel>(), nsel, ctr, above);
-      const u32 tiles2 = std::max<u32>(1u, ceil_div(nq, 256));
-      take_fused = !no_chain && !group_counts && tiles2 <= CHAIN_MAX_TILES;
-      if (take_fused) {  // hunter.h:350,357 gating and the hit offsets in one launch
-        ChainScan cs;
-        DG_TRY(chain_state(ix, st, tiles2, cs));
-        hipLaunchKernelGGL(k_take_scan, dim3(tiles2), dim3(256), 0, st, b, (const u64*)grp_off, (const u32*)nsel, ws[WS_SEL].as<Sel>(), hit_off,
-                           (const Counters*)ctr, cs);
-      } else
-        hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_off, nsel, ws[WS_SEL].as<Sel>(), qhits, ctr);
+      hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_off, nsel, ws[WS_SEL].as<Sel>(), qhits, ctr);
     } else {
       hipLaunchKernelGGL(k_group, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr, grp_off,
                          ws[WS_LEAFG].as<Leaf>());
@@ -4061,7 +3952,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       DG_HIP(hipMemsetAsync(hit_off + nq, 0, 8, st));  // no hits in this mode
       for (int e = 5; e <= 7; ++e) DG_HIP(hipEventRecord(ix->ev[e], st));
     } else {
-    if (!take_fused) DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
+    DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
     DG_HIP(hipEventRecord(ix->ev[5], st));
     {
       // strings with many occurrences go to two job lists: up to 256 occurrences for a wavefront each, more for a workgroup each
@@ -4107,7 +3998,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       va.stride = stride;
       va.ops = ws[WS_OPS].as<u32>();
       va.ops_per_hit = ops_per_hit;
-      va.host_summary = nullptr;
+      static const u32 dbg_verify = std::getenv("DICEY_DBG_VERIFY") ? (u32)std::atoi(std::getenv("DICEY_DBG_VERIFY")) : 0u;
+      va.debug = dbg_verify;
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
@@ -4125,11 +4017,6 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         const u32 nw_bytes = rows * 256 * (wide ? 4u : 2u) + 256 * 72, hash_bytes = 2u * 256u * (u32)ch * 10u;
         const u32 lds = std::max(nw_bytes, hash_bytes);
         const dim3 mgrid(ceil_div(hit_cap, (u64)256 * ch)), mblock(256);
-        static const bool lane_only2 = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
-        if (!lane_only2) {
-          va.host_summary = &hsum;  // the kernel's last workgroup closes the batch
-          closed_by_verify = true;
-        }
 #define DG_LAUNCH_MEMO(WBV, CHV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_memo<WBV, CHV>), mgrid, mblock, lds, st, ix->view, b, va, ctr, rows)
         if (!wide) {
           if (ch == 8) DG_LAUNCH_MEMO(7, 8);
@@ -4164,8 +4051,17 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (lane_only) {
       hipLaunchKernelGGL(k_summary, dim3(NSHARD / 256), dim3(256), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), d_sum);
       DG_HIP(hipMemcpyAsync(&hsum, d_sum, sizeof(Summary), hipMemcpyDeviceToHost, st));
-    } else if (!closed_by_verify) {
+    } else {
       hipLaunchKernelGGL(k_summary_block, dim3(1), dim3(NSHARD), 0, st, ctr, (const u64*)(hit_off + nq), &hsum);
+    }
+    if (fetch && !group_counts && !sx && ix->fetch_hits_hint) {
+      const u64 capn = std::min<u64>(hit_cap, ix->fetch_hits_hint);
+      if (!spec.pb || spec_cap != capn) {
+        if (spec.pb) pinned_pool().put(spec.pb);
+        spec.pb = pinned_pool().get(fetch_layout(capn).bytes);
+        spec_cap = capn;
+      }
+      if (spec.pb) DG_TRY(queue_fetch(spec.pb, capn, capn));
     }
     DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
     DG_HIP(hipGetLastError());
@@ -4225,38 +4121,37 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->ops_per_hit = ops_per_hit;
   *out = R;
   if (fetch) {
-    // one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh hipHostMalloc per batch
-    // costs more than the copies): [hit_off | qoff | hits | ops | qdistance qflags qnondna | qseq]
-    const u64 o_hit_off = 0, o_qoff = o_hit_off + (nq + 1) * 8, o_hits = o_qoff + (nq + 1) * 8;
-    const u64 o_ops = (o_hits + nhits * sizeof(dg_hit) + 15) & ~15ull, o_meta = (o_ops + nhits * (u64)ops_per_hit * 4 + 15) & ~15ull;
-    const u64 o_qseq = o_meta + 3 * (u64)nq * 4, bytes = o_qseq + total + 64;
-    PinnedBlock* pb = pinned_pool().get(bytes);
-    if (!pb) {
-      delete R;
-      *out = nullptr;
-      return fail(DG_ENOMEM, "cannot allocate %llu bytes of pinned host memory for the results", (unsigned long long)bytes);
+    PinnedBlock* pb = nullptr;
+    u64 capn = 0;
+    if (spec.pb && nhits <= spec_cap) {  // everything is on the host already
+      pb = spec.pb;
+      capn = spec_cap;
+      spec.pb = nullptr;
+    } else {
+      capn = nhits;
+      pb = pinned_pool().get(fetch_layout(capn).bytes);
+      if (!pb) {
+        delete R;
+        *out = nullptr;
+        return fail(DG_ENOMEM, "cannot allocate %llu bytes of pinned host memory for the results", (unsigned long long)fetch_layout(capn).bytes);
+      }
+      R->owner_ = pb;  // released with the result on the error paths below
+      DG_TRY(queue_fetch(pb, capn, nhits));
+      DG_HIP(hipStreamSynchronize(st));
+      DG_HIP(hipGetLastError());
     }
     R->owner_ = pb;
+    const FetchLayout L = fetch_layout(capn);
     u8* hb = (u8*)pb->p;
-    R->hit_off = (uint64_t*)(hb + o_hit_off);
-    R->qoff = (uint64_t*)(hb + o_qoff);
-    R->hits = (dg_hit*)(hb + o_hits);
-    R->ops = (uint32_t*)(hb + o_ops);
-    R->qdistance = (uint32_t*)(hb + o_meta);
+    R->hit_off = (uint64_t*)(hb + L.o_hit_off);
+    R->qoff = (uint64_t*)(hb + L.o_qoff);
+    R->hits = (dg_hit*)(hb + L.o_hits);
+    R->ops = (uint32_t*)(hb + L.o_ops);
+    R->qdistance = (uint32_t*)(hb + L.o_meta);
     R->qflags = R->qdistance + nq;
     R->qnondna = R->qflags + nq;
-    R->qseq = hb + o_qseq;
-    DG_HIP(hipMemcpyAsync(R->hit_off, hit_off, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
-    DG_HIP(hipMemcpyAsync(R->qdistance, b.qdist, 3 * (u64)nq * 4, hipMemcpyDeviceToHost, st));  // qdist, qflags, qnondna lie in this order
-    if (nhits) {
-      DG_HIP(hipMemcpyAsync(R->hits, ws[WS_HITS].p, nhits * sizeof(dg_hit), hipMemcpyDeviceToHost, st));
-      if (ops_per_hit) DG_HIP(hipMemcpyAsync(R->ops, ws[WS_OPS].p, nhits * (u64)ops_per_hit * 4, hipMemcpyDeviceToHost, st));
-    }
-    if (total) DG_HIP(hipMemcpyAsync(R->qseq, b.qseq, total, hipMemcpyDeviceToHost, st));
-    if (h_qoff) std::memcpy(R->qoff, h_qoff, (nq + 1) * 8);
-    else DG_HIP(hipMemcpyAsync(R->qoff, d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
-    DG_HIP(hipStreamSynchronize(st));
-    DG_HIP(hipGetLastError());
+    R->qseq = hb + L.o_qseq;
+    ix->fetch_hits_hint = nhits + nhits / 32 + 1024;
   }
   R->d_hits = ws[WS_HITS].p;
   R->d_ops = ops_per_hit ? ws[WS_OPS].p : nullptr;
@@ -4392,6 +4287,61 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
     *out = nullptr;
   }
   return rc;
+}
+
+// Asynchronous form of dg_hunt (ABI 4).  The batch is driven by a helper thread of the library: copies, kernels, the batch's one
+// synchronisation, the copy of the results into a pinned block.  The caller goes on — typically formatting the previous batch — and
+// collects with dg_hunt_wait.  One batch per handle at a time; a second handle from dg_index_share runs its batch concurrently on
+// its own stream, which is how a single-threaded host keeps two batches in flight.
+struct dg_hunt_ticket {
+  dg_index* ix = nullptr;
+  dg_hunt_params p;
+  std::vector<uint32_t> seqlen;
+  std::vector<uint8_t> qbytes;
+  std::vector<uint64_t> qoff;
+  std::thread th;
+  int rc = DG_OK;
+  std::string err;
+  dg_hunt_result* res = nullptr;
+};
+
+int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
+                   const uint64_t* qoff, size_t nq, dg_hunt_ticket** out) {
+  if (!ix || !p || !seqlen || !qoff || !out || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_hunt_submit: null argument");
+  *out = nullptr;
+  if (!nq) return fail(DG_EINVAL, "dg_hunt_submit: empty batch");
+  if (ix->busy.exchange(true)) return fail(DG_EINVAL, "dg_hunt_submit: this handle already has a batch in flight (use dg_index_share for a second one)");
+  dg_hunt_ticket* t = nullptr;
+  try {
+    t = new dg_hunt_ticket;
+    t->ix = ix;
+    t->p = *p;
+    t->seqlen.assign(seqlen, seqlen + nseq);
+    t->qoff.assign(qoff, qoff + nq + 1);
+    t->qbytes.assign(qbytes, qbytes + qoff[nq]);  // the caller's buffers are free again when this call returns
+    t->th = std::thread([t] {
+      t->rc = dg_hunt(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), t->qbytes.data(), t->qoff.data(), t->qoff.size() - 1, &t->res);
+      if (t->rc != DG_OK) t->err = dg_last_error();  // the message is thread-local: carried over to the waiting thread
+    });
+  } catch (const std::exception& e) {
+    delete t;
+    ix->busy.store(false);
+    return fail(DG_ENOMEM, "dg_hunt_submit: %s", e.what());
+  }
+  *out = t;
+  return DG_OK;
+}
+
+int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out) {
+  if (!t || !out) return fail(DG_EINVAL, "dg_hunt_wait: null argument");
+  t->th.join();
+  t->ix->busy.store(false);
+  *out = t->res;
+  const int rc = t->rc;
+  const std::string err = t->err;
+  delete t;
+  if (rc != DG_OK) return fail(rc, "%s", err.c_str());
+  return DG_OK;
 }
 
 int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t max_neighborhood, const uint8_t* qbytes,

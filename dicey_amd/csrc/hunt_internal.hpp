@@ -74,7 +74,7 @@ struct HitSeed {  // 16 bytes, read as one uint4
   u32 sel;  // slot of the kept string (Sel) the hit stems from: hits of one slot share query, strand and string
 };
 
-enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO, WS_XS, WS_OPS, WS_SCAN };
+enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO, WS_XS, WS_OPS };
 
 // one located hit after the `dicey search` stage
 struct SiteRaw {
@@ -106,7 +106,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
               size_t nq, u64 total, u32 maxlen, int fetch, dg_hunt_result** out, SearchExtra* sx = nullptr,
               uint64_t* group_counts = nullptr, const uint8_t* h_qbytes = nullptr, const uint64_t* h_qoff = nullptr);
 // hunt.hip: exclusive prefix sums of n 32-bit counts into 64-bit offsets (out[n] = total); tmp: n/64 + 64 words
-int device_scan(hipStream_t st, const u32* in, u64 n, u64* out, u64* tmp);
+int device_scan(hipStream_t st, const u32* in, u64 n, u64* out, u64* tmp, Counters* ctr = nullptr, u32 shard_cap = 0, u32 surv_cap = 0);
 // search.hip: launches k_site over the located hits (capacity hit_cap) and fills sx's result pointers
 int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSeed* seeds, const u64* hit_off, u64 hit_cap,
                       const u64* cum, u32 nseq, u32 dmax_eff, u32 maxlen, Counters* ctr);

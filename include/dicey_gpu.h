@@ -186,6 +186,16 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
             const uint64_t* qoff, size_t nq, dg_hunt_result** out);
 void dg_hunt_result_free(dg_hunt_result* r);
 
+/* Asynchronous form: dg_hunt_submit returns as soon as the batch is handed to the library (the query buffers are copied, the
+ * caller may reuse them at once); dg_hunt_wait blocks until the result is on the host (a pinned block, like dg_hunt's) and releases
+ * the ticket.  One batch per handle at a time (DG_EINVAL otherwise): a second handle from dg_index_share runs its batch
+ * concurrently on its own stream — submit A, submit B, wait A, format A while B computes, submit A, wait B, ...  Every ticket must
+ * be waited for before its handle is closed. */
+typedef struct dg_hunt_ticket dg_hunt_ticket;
+int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
+                   const uint64_t* qoff, size_t nq, dg_hunt_ticket** out);
+int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out);
+
 /* Device-resident entry point used by bench.py: d_qbytes / d_qoff are HIP device pointers on the index's device.
  * The result stays in HBM; only the counters/timings and nhits are copied back.  `fetch` != 0 additionally
  * copies hits to host like dg_hunt.  The offsets are read back once to size the batch; a repeated call with the same

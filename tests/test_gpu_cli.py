@@ -146,3 +146,27 @@ def test_baseline_config0_single_18mer_hamming0_on_a_4_6_mb_genome(tmp_path):
     starts = sorted((h["chr"], h["start"], h["strand"]) for h in doc["data"])
     want = [("U00096.3", 1000001, "+"), ("U00096.3", 3001001, "+")]
     assert [s for s in starts if s[2] == "+"] == want, starts
+
+
+def test_large_input_runs_chunks_in_a_pipeline(cli_genome):
+    """More than 2^18 queries: the binary cuts the input into chunks and keeps two batches in flight (dg_hunt_submit / dg_hunt_wait
+    on two handles of one resident index).  Output must be the bytes of the chunk-after-chunk form, in query order; a sample of the
+    lines is held against the checker."""
+    g = cli_genome
+    base = make_queries(9, g["text"], 3000)
+    qs = (base * 90)[:270000]  # > 2^18 -> three chunks of 2^17
+    fa = g["dir"] / "many.fa"
+    with open(fa, "w") as f:
+        for i, s in enumerate(qs):
+            f.write(">m%d\n%s\n" % (i, s))
+    env = dict(os.environ, DICEY_KMER_K="9")  # a large input asks for the K-mer table: keep it tiny on this 60 kb genome
+    r = subprocess.run([DICEY, "hunt", "-g", g["fa"], str(fa)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r2 = subprocess.run([DICEY, "hunt", "-g", g["fa"], str(fa)], capture_output=True, text=True, env=dict(env, DICEY_NO_PIPELINE="1"))
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert r.stdout == r2.stdout
+    lines = r.stdout.split("\n")
+    assert len(lines) == len(qs) + 1 and lines[-1] == ""
+    pick = list(range(0, 50)) + list(range(131050, 131100)) + list(range(269950, 270000))
+    want = _oracle_json(g, [qs[i] for i in pick], ["m%d" % i for i in pick], distance=1).split("\n")
+    assert [lines[i] for i in pick] == want[:-1]

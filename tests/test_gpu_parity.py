@@ -386,3 +386,25 @@ def test_device_entry_point_rechecks_a_cached_length_bound(gpu_small, small_geno
     assert run(qa) == first and len(first) >= 3          # second call: cached bound, same answer
     want = [(i, h.chr, h.start, h.score) for i, q in enumerate(gpu_small.hunt(qb, small_genome["seqlen"]).queries) for h in q.hits]
     assert run(qb) == want and any(h[0] == 1 for h in want)   # the 36-mer exceeds the cached 20: detected, redone
+
+
+def test_submit_wait_on_two_handles_equals_the_blocking_call(gpu_small, small_genome):
+    """dg_hunt_submit / dg_hunt_wait (ABI 4): two batches in flight on two handles of one resident index, a third submit on a busy
+    handle is refused, results equal dg_hunt's."""
+    import dicey_amd
+    g = small_genome
+    qa = make_queries(31, g["text"], 400)
+    qb = make_queries(32, g["text"], 300)
+    key = lambda R: [[(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in q.hits] + [q.flags, q.nondna] for q in R.queries]
+    want_a, want_b = key(gpu_small.hunt(qa, g["seqlen"], distance=1)), key(gpu_small.hunt(qb, g["seqlen"], distance=2))
+    other = gpu_small.share()
+    try:
+        for _ in range(3):
+            ta = gpu_small.hunt_submit(qa, g["seqlen"], distance=1)
+            tb = other.hunt_submit(qb, g["seqlen"], distance=2)
+            with pytest.raises(dicey_amd.DgError):
+                gpu_small.hunt_submit(qb, g["seqlen"], distance=1)  # one batch per handle
+            assert key(other.hunt_wait(tb)) == want_b
+            assert key(gpu_small.hunt_wait(ta)) == want_a
+    finally:
+        other.close()

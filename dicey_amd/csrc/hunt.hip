@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <mutex>
 #include <set>
 #include <string>
@@ -47,6 +48,8 @@ struct Sel {  // a kept neighbourhood string, in search order
   u32 len;    // string length
   u32 take;   // how many of its occurrences become hits
   u32 hbase;  // first hit slot, relative to the query's first hit
+  u32 g;      // 2*query + strand (set for the strings of the flat region, where no leaf record names the group)
+  u32 bref;   // index of the string's context bounds (k_sel_bounds), 0xFFFFFFFF = none; set by k_locate for every kept string
 };
 
 // Largest number of distinct strings neighbors() can hold for a query of length m with nN letters outside A/C/G/T (they
@@ -100,13 +103,14 @@ DG_HD u64 neighbourhood_bound(u32 m, u32 d, bool indel, u32 nN = 0) {
 // ------------------------------------------------------------------------------------------------------------
 // (r03: the characters come in as aligned 64-bit words loaded together — the byte loop waited for one load per character, 20 us
 // for 100 000 20-mers — and the lane clears its query's group counters, which takes the place of a memset in front of the batch)
-__global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel) {
+__global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
   grp_cnt[2 * q] = grp_cnt[2 * q + 1] = 0;
   nsel[2 * q] = nsel[2 * q + 1] = 0;
+  selbase[2 * q] = selbase[2 * q + 1] = 0xFFFFFFFFu;  // "generic path" until k_search1s claims the group
   u64 s = b.qoff[q], e = b.qoff[q + 1];
-  u32 m = (u32)(e - s), bad = 0, flags = 0;
+  u32 m = (u32)(e - s), bad = 0, flags = 0, generic = 0;
   u64 pk_fw = 0, pk_rv = 0;  // 2-bit packed strands, q[i] at bits 2(m-1-i) (meaningful for m <= 32 without N)
   constexpr u32 NREG = 40;   // queries up to this length travel through registers
   if (m <= NREG) {
@@ -171,7 +175,11 @@ __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel) {
     if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
     if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
     b.ginfo[2 * q + strand] = gi;
+    generic += (gi.m != 0 && !(gi.d_win & 512u));
   }
+  // groups the flat distance-1 kernel does not take: the host launches the generic kernels for them (and repeats a batch it
+  // started without, run_batch).  A flag, not a count: every lane that has one stores the same 1.
+  if (generic && b.fastK) *n_generic = 1u;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -628,6 +636,259 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
     if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
     if (nhead) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nhead);
+  }
+}
+
+// k_search1p WITH the select stage (r03).  A workgroup owns whole (query, strand) groups — floor(256 / positions) of them — so
+// every string of a group that occurs ends up in this workgroup's LDS (2-bit packed, with its interval), and the group's
+// duplicates / substring-minimal filter / std::set order (neighbors.h:29-45, hunter.h:349) are settled right here: leaves never
+// travel to HBM, and the scan of the group counts, k_group_pack, k_leaf_alive and k_leaf_rank (62 of the 380 us of a step) have
+// nothing left to do.  Kept strings go to the FLAT region of the Sel array — per-shard slices, one atomic per workgroup — and
+// selbase[g] / nsel[g] tell the later kernels where a group's strings are.  A workgroup whose strings do not fit the LDS list
+// (512; a dozen low-complexity queries side by side) sends its leaves down the generic path like k_search1p does.
+struct FlatSel {
+  Sel* sel;        // flat region: NSHARD slices of `cap` entries
+  u32 cap;
+  u32* selbase;    // [2 nq] first Sel slot of a group served here (0xFFFFFFFF: generic path, grp_off based)
+  u32* nsel;       // [2 nq]
+};
+static constexpr u32 FUSED_LCAP = 512;  // 15 KB of LDS per workgroup: eight wavefronts per SIMD stay resident (1 024 left six)
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap) {
+  __shared__ u16 q_ent[2048];  // lane | operation << 8
+  __shared__ u32 q_n, c_probe, l_n, s_total, s_base;
+  __shared__ unsigned long long l_key[FUSED_LCAP];
+  __shared__ u32 l_lo[FUSED_LCAP], l_hi[FUSED_LCAP];
+  __shared__ u16 l_meta[FUSED_LCAP];  // length | local group << 6 | alive << 15
+  __shared__ u16 l_pos[FUSED_LCAP], l_ord[FUSED_LCAP];
+  __shared__ u32 g_cnt[16], g_start[16], g_alive[16], g_base[16];
+  constexpr u32 NOPS = INDEL ? 8u : 4u;
+  if (threadIdx.x == 0) {
+    q_n = 0;
+    c_probe = 0;
+    l_n = 0;
+  }
+  if (threadIdx.x < 16) g_cnt[threadIdx.x] = g_alive[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1;
+  const u32 lane = threadIdx.x & 63;
+  const u32 ngrp2 = (u32)(2 * b.nq);
+  const u32 g_first = blockIdx.x * gpw;
+  u32 mask8 = 0, nprobe = 0;
+  {
+    const u32 lg = (threadIdx.x * magic) >> 16, pos = threadIdx.x - lg * ipg + 1;
+    const u32 gid = g_first + lg;
+    if (lg < gpw && gid < ngrp2) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+      const u64 qpk = (u64)raw.y << 32 | raw.x;
+      const u32 m = raw.z, d_win = raw.w;
+      if (m && (d_win & 512u) && pos <= m) {
+        const u32 R = m - pos;
+        const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
+        const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
+        const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+        const u32* const idle = reinterpret_cast<const u32*>(f.ktab);
+        const u32* addr[NOPS];
+        u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          u64 s_pk;
+          u32 mlen, ow;
+          const bool ok = cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow);
+          const bool use2 = K2 && mlen >= K2;
+          const bool pr = ok && (use2 || f.kf.nr);
+          KfCopy c;
+          c.base = use2 ? c2.base : c1.base;
+          c.s = use2 ? c2.s : c1.s;
+          const u32* a = kf_word(c, use2 ? s_pk & mask2 : s_pk & kmask, bit[op]);
+          addr[op] = pr ? a : idle;
+          valid |= (u32)ok << op;
+          probe |= (u32)pr << op;
+        }
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
+          mask8 |= (((valid >> op) & 1u) & present) << op;
+        }
+        nprobe = (u32)__popc(probe);
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+  if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
+  while (mask8) {
+    const u32 op = (u32)__ffs((int)mask8) - 1u;
+    mask8 &= mask8 - 1;
+    const u32 at = atomicAdd(&q_n, 1u);
+    q_ent[at] = (u16)(threadIdx.x | (op << 8));
+  }
+  __syncthreads();
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  if (threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
+  const u32 qn = q_n;
+  u32 steps = 0, nlook = 0, nhead = 0;
+  // the dense phase: survivors rebuilt, table entry, extension; occurring strings to the LDS list (to_lds) or, on the second pass of
+  // a workgroup whose list overflowed, to the generic leaf buffer exactly like k_search1p
+  auto dense = [&](const bool to_lds) {
+    for (u32 e0 = 0; e0 < qn; e0 += 256) {
+      if (e0 + (threadIdx.x & ~63u) >= qn) break;
+      const u32 e = e0 + threadIdx.x;
+      if (e < qn) {
+        const u32 ent = q_ent[e], sl = ent & 255u, op = ent >> 8;
+        const u32 lg = (sl * magic) >> 16, pos = sl - lg * ipg + 1;
+        const u32 gid = g_first + lg;
+        const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+        u64 s_pk;
+        u32 mlen, ow;
+        (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
+        u32 lo = 0, hi = 0;
+        if (to_lds) nhead += (K2 && mlen > K2);
+        if (head_window_occurs(f, s_pk, mlen, raw.z - pos)) {
+          const uint2 iv = f.ktab[s_pk & kmask];
+          if (to_lds) ++nlook;
+          lo = iv.x;
+          hi = iv.y;
+        }
+        u64 rs = s_pk >> (2 * K);
+        u32 n = mlen - K;
+        while (n && lo < hi) {
+          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+          rs >>= 2;
+          --n;
+          if (to_lds) ++steps;
+        }
+        if (lo < hi) {
+          if (to_lds) {
+            const u32 at = atomicAdd(&l_n, 1u);
+            if (at < FUSED_LCAP) {
+              l_key[at] = s_pk;
+              l_lo[at] = lo;
+              l_hi[at] = hi;
+              l_meta[at] = (u16)(mlen | (lg << 6));
+            }
+          } else {
+            const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+            const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+            if (at < o.shard_cap) {
+              Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+              lf->qs = gid;
+              lf->slot = slot;
+              lf->lo = lo;
+              lf->hi = hi;
+              lf->nops = ow >> 28;
+              lf->ops[0] = ow & 0x0FFFFFFFu;
+#pragma unroll
+              for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+            }
+          }
+        }
+      }
+    }
+  };
+  dense(true);
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    nlook += __shfl_xor(nlook, off);
+    nhead += __shfl_xor(nhead, off);
+  }
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+    if (nhead) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nhead);
+  }
+  __syncthreads();
+  const u32 nl = l_n;
+  if (nl > lcap) {  // rare: this workgroup's groups take the generic path (selbase stays "generic"); lcap <= FUSED_LCAP
+    dense(false);
+    return;
+  }
+  // ---- select, per group, in LDS
+  for (u32 i = threadIdx.x; i < nl; i += 256) l_pos[i] = (u16)atomicAdd(&g_cnt[(l_meta[i] >> 6) & 15u], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (u32 g = 0; g < gpw; ++g) {
+      g_start[g] = run;
+      run += g_cnt[g];
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < nl; i += 256) l_ord[g_start[(l_meta[i] >> 6) & 15u] + l_pos[i]] = (u16)i;
+  __syncthreads();
+  // alive: no other string of the group is a proper substring, and of equal strings the first of the list stays
+  for (u32 i = threadIdx.x; i < nl; i += 256) {
+    const u32 meta = l_meta[i], alen = meta & 63u, lg = (meta >> 6) & 15u;
+    bool ok = true;
+    if (INDEL) {
+      const u64 a = l_key[i];
+      const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
+      for (u32 j = s0; j < s1 && ok; ++j) {
+        const u32 x = l_ord[j];
+        if (x == i) continue;
+        const u32 xlen = l_meta[x] & 63u;
+        if (xlen > alen) continue;
+        const u64 xk = l_key[x], xm = xlen >= 32 ? ~0ULL : ((1ULL << (2 * xlen)) - 1);
+        bool hit = false;
+        for (u32 sh = 0; sh <= alen - xlen; ++sh) hit = hit || (((a >> (2 * sh)) & xm) == xk);
+        if (hit) ok = (xlen == alen) && (i < x);
+      }
+    }
+    if (ok) {
+      l_meta[i] = (u16)(meta | 0x8000u);
+      atomicAdd(&g_alive[lg], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 total = 0;
+    for (u32 g = 0; g < gpw; ++g) {
+      g_base[g] = total;
+      total += g_alive[g];
+    }
+    s_total = total;
+    s_base = total ? atomicAdd(&o.ctr->sel_cnt[shard], total) : 0u;
+  }
+  __syncthreads();
+  const u32 wbase = s_base;
+  const bool room = wbase + s_total <= fs.cap;  // an overflowing slice repeats the batch (Summary::worst_sel) ...
+  if (!room && threadIdx.x == 0) atomicOr(&o.ctr->overflow, 1u);  // ... and the kernels behind this one do nothing
+  if (threadIdx.x == 0 && nl) atomicAdd(&o.ctr->fused_leaves[shard], (unsigned long long)nl);
+  // rank among the group's survivors in std::string order (A < C < G < T = code order; a proper prefix sorts first) -> Sel
+  for (u32 i = threadIdx.x; i < nl; i += 256) {
+    const u32 meta = l_meta[i];
+    if (!(meta & 0x8000u)) continue;
+    const u32 alen = meta & 63u, lg = (meta >> 6) & 15u;
+    const u64 ak = l_key[i] << (64 - 2 * alen);
+    const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
+    u32 r = 0;
+    for (u32 j = s0; j < s1; ++j) {
+      const u32 x = l_ord[j], xm = l_meta[x];
+      if (x == i || !(xm & 0x8000u)) continue;
+      const u32 xlen = xm & 63u;
+      const u64 xk = l_key[x] << (64 - 2 * xlen);
+      r += (xk < ak) || (xk == ak && xlen < alen);
+    }
+    if (room) {
+      Sel sv;
+      sv.lo = l_lo[i];
+      sv.hi = l_hi[i];
+      sv.len = alen;
+      sv.take = 0;
+      sv.hbase = 0;
+      sv.g = g_first + lg;
+      fs.sel[(u64)shard * fs.cap + wbase + g_base[lg] + r] = sv;
+    }
+  }
+  if (threadIdx.x < gpw && g_first + threadIdx.x < ngrp2) {
+    const u32 gid = g_first + threadIdx.x;
+    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+    if (raw.z && (raw.w & 512u)) {  // groups this kernel searches: their strings are in the flat region, also when there are none
+      fs.nsel[gid] = room ? g_alive[threadIdx.x] : 0u;
+      fs.selbase[gid] = shard * fs.cap + wbase + g_base[threadIdx.x];
+    }
   }
 }
 
@@ -1327,6 +1588,9 @@ __global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap, u32 surv_cap) {  /
 struct Summary {
   unsigned long long nleaf, worst_shard, steps, lookups, sa_reads, win_bytes, nhits, overflow, refused, too_long, probes, worst_surv;
   unsigned long long jobs_big, jobs_small;  // repeat-rich strings queued by k_locate (workgroup / wavefront jobs)
+  unsigned long long worst_sel;             // fullest slice of the flat Sel region (k_search1s)
+  unsigned long long fused_leaves;          // occurring strings k_search1s kept in LDS (they never became Leaf records)
+  unsigned long long n_generic;             // groups searched outside the flat distance-1 kernel (k_prepare)
 };
 __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {  // NSHARD lanes
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1339,7 +1603,9 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
   if (ctr->win_bytes[k]) atomicAdd(&out->win_bytes, ctr->win_bytes[k]);
   if (ctr->probes[k]) atomicAdd(&out->probes, ctr->probes[k]);
   atomicMax(&out->worst_surv, (unsigned long long)ctr->surv_cnt[k]);
+  atomicMax(&out->worst_sel, (unsigned long long)ctr->sel_cnt[k]);
   if (k == 0) {
+    out->n_generic = ctr->pad_[6];
     out->nhits = *nhits;
     out->overflow = ctr->overflow;
     out->refused = ctr->pad_[1];
@@ -1353,13 +1619,15 @@ __global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {
 // before it reports in writes back its XCD's L2 — the 8 300 workgroups of a repeat-genome step went from 1.05 to 1.60 ms.  On
 // this part workgroups of one launch do not talk to each other cheaply; a 7 us kernel of its own is the better deal.)
 DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
-  constexpr int NF = 8;  // fields 1 and 7 are maxima, the others sums
+  constexpr int NF = 10;  // fields 1, 7 and 8 are maxima, the others sums
   __shared__ unsigned long long acc[NF];
   if (threadIdx.x < NF) acc[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long v[NF] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long v[NF] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (u32 k = threadIdx.x; k < NSHARD; k += blockDim.x) {
-    const unsigned long long lc = ctr->leaf_cnt[k], sc = ctr->surv_cnt[k];
+    const unsigned long long lc = ctr->leaf_cnt[k], sc = ctr->surv_cnt[k], sl = ctr->sel_cnt[k];
+    v[8] = sl > v[8] ? sl : v[8];
+    v[9] += ctr->fused_leaves[k];
     v[0] += lc;
     v[1] = lc > v[1] ? lc : v[1];
     v[2] += ctr->steps[k];
@@ -1374,10 +1642,10 @@ DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
     unsigned long long x = v[f];
     for (int off = 32; off > 0; off >>= 1) {
       const unsigned long long o = __shfl_xor(x, off);
-      x = (f == 1 || f == 7) ? (o > x ? o : x) : x + o;
+      x = (f == 1 || f == 7 || f == 8) ? (o > x ? o : x) : x + o;
     }
     if ((threadIdx.x & 63) == 0) {
-      if (f == 1 || f == 7) atomicMax(&acc[f], x);
+      if (f == 1 || f == 7 || f == 8) atomicMax(&acc[f], x);
       else atomicAdd(&acc[f], x);
     }
   }
@@ -1397,6 +1665,9 @@ DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
     host_out->too_long = ctr->pad_[2];
     host_out->jobs_big = ctr->pad_[0];
     host_out->jobs_small = ctr->pad_[4];
+    host_out->worst_sel = acc[8];
+    host_out->fused_leaves = acc[9];
+    host_out->n_generic = ctr->pad_[6];
     __threadfence_system();
   }
   __syncthreads();
@@ -1809,7 +2080,12 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
   }
   if (threadIdx.x == 0) nsel[g] = base;
 }
-__global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u32* qhits, const Counters* ctr) {
+// first Sel slot of group g: the flat region (k_search1s set selbase) or flat_slots + grp_off[g] (generic path)
+DG_DEV u64 sel_base_of(const u32* selbase, const u64* grp_off, u64 flat_slots, u64 g) {
+  const u32 sb = selbase[g];
+  return sb != 0xFFFFFFFFu ? (u64)sb : flat_slots + grp_off[g];
+}
+__global__ void k_take(Batch b, const u64* grp_off, const u32* selbase, u64 flat_slots, const u32* nsel, Sel* sel, u32* qhits, const Counters* ctr) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
   if (ctr->overflow) {
@@ -1818,8 +2094,9 @@ __global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u
   }
   u64 hits = 0;
   for (u32 strand = 0; strand < 2; ++strand) {
-    Sel* S = sel + grp_off[2 * q + strand];
     const u32 ns = nsel[2 * q + strand];
+    if (!ns) continue;  // (grp_off is not even computed when the generic kernels were left out)
+    Sel* S = sel + sel_base_of(selbase, grp_off, flat_slots, 2 * q + strand);
     for (u32 r = 0; r < ns; ++r) {
       u64 occs = (u64)S[r].hi - S[r].lo;
       u64 take = 0;
@@ -1834,13 +2111,13 @@ __global__ void k_take(Batch b, const u64* grp_off, const u32* nsel, Sel* sel, u
 }
 
 // count mode: occurrences of all kept strings of a (query, strand) group
-__global__ void k_group_count(const u64* grp_off, const u32* nsel, const Sel* sel, u64 ngrp, u64* out, const Counters* ctr) {
+__global__ void k_group_count(const u64* grp_off, const u32* selbase, u64 flat_slots, const u32* nsel, const Sel* sel, u64 ngrp, u64* out, const Counters* ctr) {
   u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ngrp) return;
   u64 sum = 0;
   if (!ctr->overflow) {
-    const Sel* S = sel + grp_off[g];
     const u32 ns = nsel[g];
+    const Sel* S = ns ? sel + sel_base_of(selbase, grp_off, flat_slots, g) : sel;
     for (u32 r = 0; r < ns; ++r) sum += (u64)S[r].hi - S[r].lo;
   }
   out[g] = sum;
@@ -1980,6 +2257,16 @@ struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_t
 // grouped leaf of the same slot (slot_qs: address of that record's `qs` field, slot_stride: record size), serves strings of up to
 // 24 occurrences itself and queues the others: up to 256 occurrences for one wavefront (k_locate_small), more for one
 // workgroup (k_locate_topk / k_locate_big).
+static constexpr u32 BOUNDS_MIN_TAKE = 192;  // hits a kept string needs before its context bounds pay (8 binary searches)
+static constexpr u32 SAI_NONE = 0xFFFFFFFFu;
+struct BoundsJob {
+  u32 lo, occs, len, slot;
+};
+struct BoundsJobs {
+  BoundsJob* jobs;  // nullptr: no bounds in this batch
+  u32* count;
+  u32 cap;
+};
 struct LocJobs {
   BigJob* small;
   BigJob* big;
@@ -1991,10 +2278,12 @@ static constexpr u32 LOC_SMALL_MAX = 256;
 // A string with up to N occurrences: N loads in flight, a bitonic network on registers (every index is a compile-time constant —
 // r02's insertion sort indexed a private array dynamically, i.e. through scratch memory), `take` stores.
 template <int N>
-DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out, u32 g, u32 len, u32 slot) {
-  u32 v[N];
+DG_DEV void locate_in_registers(const u32* sa, u32 lo, u32 occs, u32 take, HitSeed* out, u32* sai_out, u32 g, u32 len, u32 slot) {
+  // (position, suffix-array index) pairs: the index travels with the hit — k_verify_memo reads the character in front of the hit
+  // from the BWT at that index instead of the text (r03)
+  u64 v[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = (u32)i < occs ? sa[i] : 0xFFFFFFFFu;
+  for (int i = 0; i < N; ++i) v[i] = (u32)i < occs ? ((u64)sa[lo + i] << 32) | (u32)i : ~0ULL;
 #pragma unroll
   for (int k = 2; k <= N; k <<= 1)
 #pragma unroll
@@ -2003,35 +2292,67 @@ DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out,
       for (int i = 0; i < N; ++i) {
         const int l = i ^ j;
         if (l > i) {
-          const u32 a = v[i], b2 = v[l], mn = a < b2 ? a : b2, mx = a < b2 ? b2 : a;
+          const u64 a = v[i], b2 = v[l], mn = a < b2 ? a : b2, mx = a < b2 ? b2 : a;
           v[i] = (i & k) == 0 ? mn : mx;
           v[l] = (i & k) == 0 ? mx : mn;
         }
       }
 #pragma unroll
   for (int i = 0; i < N; ++i)
-    if ((u32)i < take) out[i] = HitSeed{v[i], g, len, slot};
+    if ((u32)i < take) {
+      out[i] = HitSeed{(u32)(v[i] >> 32), g, len, slot};
+      sai_out[i] = lo + (u32)v[i];
+    }
 }
+// Slots [0, flat_slots): the flat region (k_search1s; NSHARD slices of flat_cap entries, a slice holds ctr->sel_cnt[shard] strings,
+// each naming its group); slots behind it: the generic path's (grp_off based; only when generic_on).
 __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const u8* slot_qs, u32 slot_stride, const u64* grp_off, const u32* nsel,
-                                                u64 ngroups, const u64* hit_off, HitSeed* seeds, Counters* ctr, u64 hit_cap, LocJobs jobs) {
+                                                u64 ngroups, const u64* hit_off, HitSeed* seeds, Counters* ctr, u64 hit_cap, LocJobs jobs,
+                                                u64 flat_slots, u32 flat_cap, u32 generic_on, u32* sai, Sel* sel_rw, BoundsJobs bj_out,
+                                                const u32* qdist, u32 indel) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
   u64 reads = 0;
   BigJob bj;
   u32 queue = 0;  // 1: wavefront job, 2: workgroup job
-  if (t < grp_off[ngroups]) {
-    const u32 g = *reinterpret_cast<const u32*>(slot_qs + t * slot_stride);  // g = 2*query + strand
-    const Sel S = sel[t];
-    const u32 take = (t - grp_off[g]) < nsel[g] ? S.take : 0u;  // slots behind the group's kept strings hold nothing
+  bool have = false;
+  u32 g = 0;
+  Sel S;
+  if (t < flat_slots) {
+    const u32 shard = (u32)(t / flat_cap);
+    if ((u32)(t - (u64)shard * flat_cap) < ctr->sel_cnt[shard]) {
+      S = sel[t];
+      g = S.g;
+      have = true;
+    }
+  } else if (generic_on && t - flat_slots < grp_off[ngroups]) {
+    const u64 tg = t - flat_slots;
+    g = *reinterpret_cast<const u32*>(slot_qs + tg * slot_stride);  // g = 2*query + strand
+    S = sel[t];
+    have = (tg - grp_off[g]) < nsel[g];  // slots behind the group's kept strings hold nothing
+  }
+  bool want_bounds = false;
+  BoundsJob bjob;
+  if (have) {
+    const u32 take = S.take;
+    // strings with many hits at edit distance 1: k_sel_bounds finds where, inside the string's interval, the character BEHIND the
+    // string changes, so that k_verify_memo need not read the text for it
+    want_bounds = bj_out.jobs && indel && take >= BOUNDS_MIN_TAKE && qdist[g >> 1] == 1;
+    if (want_bounds) {
+      bjob.lo = S.lo;
+      bjob.occs = S.hi - S.lo;
+      bjob.len = S.len;
+      bjob.slot = (u32)t;
+    } else sel_rw[t].bref = 0xFFFFFFFFu;
     if (take) {
       const u32 lo = S.lo, occs = S.hi - S.lo;
       const u64 out0 = hit_off[g >> 1] + S.hbase;
       HitSeed* out = seeds + out0;
       if (occs <= 4) {
-        locate_in_registers<4>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
+        locate_in_registers<4>(f.sa, lo, occs, take, out, sai + out0, g, S.len, (u32)t);
         reads += occs;
       } else if (occs <= 16) {
-        locate_in_registers<16>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
+        locate_in_registers<16>(f.sa, lo, occs, take, out, sai + out0, g, S.len, (u32)t);
         reads += occs;
       } else if (jobs.big && take <= 16384) {
         bj.lo = lo;
@@ -2054,8 +2375,23 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
       }
     }
   }
-  // job slots: one atomic per wavefront and list (every lane on the two list heads was what this kernel waited for)
   const u32 lane = threadIdx.x & 63;
+  {
+    const unsigned long long mk = __ballot(want_bounds);
+    if (mk) {
+      u32 base = 0;
+      if (lane == (u32)__ffsll((long long)mk) - 1u) base = atomicAdd(bj_out.count, (u32)__popcll(mk));
+      base = __shfl(base, (int)__ffsll((long long)mk) - 1);
+      if (want_bounds) {
+        const u32 j = base + (u32)__popcll(mk & ((1ULL << lane) - 1));
+        if (j < bj_out.cap) {
+          bj_out.jobs[j] = bjob;
+          sel_rw[t].bref = j;
+        } else sel_rw[t].bref = 0xFFFFFFFFu;
+      }
+    }
+  }
+  // job slots: one atomic per wavefront and list (every lane on the two list heads was what this kernel waited for)
   for (u32 which = 1; which <= 2; ++which) {
     const unsigned long long mk = __ballot(queue == which);
     if (!mk) continue;
@@ -2074,13 +2410,17 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
     u64 prev = 0;
     bool first = true;
     for (u32 i = 0; i < bj.take; ++i) {
-      u32 best = 0xFFFFFFFFu;
+      u32 best = 0xFFFFFFFFu, at = 0;
       for (u32 j = 0; j < bj.occs; ++j) {
         const u32 x = f.sa[bj.lo + j];
-        if ((first || x > prev) && x < best) best = x;
+        if ((first || x > prev) && x < best) {
+          best = x;
+          at = j;
+        }
       }
       reads += bj.occs;
       seeds[bj.out + i] = HitSeed{best, bj.g, bj.len, bj.slot};
+      sai[bj.out + i] = bj.lo + at;
       prev = best;
       first = false;
     }
@@ -2091,8 +2431,9 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
 // One WAVEFRONT per string of 25..256 occurrences (most of the queued strings on a repeat-bearing genome: 54 k of 72 k per
 // 100 000 queries): the interval is read once, sorted in LDS by the wavefront alone (bitonic, no workgroup barrier to wait
 // for), the first `take` values are written.  Jobs are taken in grid order: they all cost about the same.
-__global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, Counters* ctr) {
-  __shared__ u32 buf[LOC_SMALL_MAX];
+__global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, u32* sai,
+                                                     Counters* ctr) {
+  __shared__ unsigned long long buf[LOC_SMALL_MAX];  // (position << 32) | offset in the interval
   const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
   u64 reads = 0;
   for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
@@ -2100,7 +2441,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
     u32 n2 = 32;
     while (n2 < J.occs) n2 <<= 1;
     const u32* sa = f.sa + J.lo;
-    for (u32 i = threadIdx.x; i < n2; i += 64) buf[i] = i < J.occs ? sa[i] : 0xFFFFFFFFu;
+    for (u32 i = threadIdx.x; i < n2; i += 64) buf[i] = i < J.occs ? ((u64)sa[i] << 32) | i : ~0ULL;
     reads += J.occs;
     __syncthreads();
     for (u32 kk = 2; kk <= n2; kk <<= 1)
@@ -2108,7 +2449,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
         for (u32 i = threadIdx.x; i < n2; i += 64) {
           const u32 l = i ^ jj;
           if (l > i) {
-            const u32 a = buf[i], b2 = buf[l];
+            const u64 a = buf[i], b2 = buf[l];
             if ((a > b2) == ((i & kk) == 0)) {
               buf[i] = b2;
               buf[l] = a;
@@ -2117,7 +2458,10 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
         }
         __syncthreads();
       }
-    for (u32 i = threadIdx.x; i < J.take; i += 64) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
+    for (u32 i = threadIdx.x; i < J.take; i += 64) {
+      seeds[J.out + i] = HitSeed{(u32)(buf[i] >> 32), J.g, J.len, J.slot};
+      sai[J.out + i] = J.lo + (u32)buf[i];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
@@ -2129,7 +2473,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
 // of that bin fits the LDS buffer (on a genome-wide repeat family that is after the first pass: positions spread over the
 // whole text, so one top-byte bin holds occs/185 values).  One more pass collects those values, a bitonic sort orders
 // them.  2-3 coalesced passes over the interval instead of 33 (r02: 33 ms -> see DESIGN.md on the repeat-rich genome).
-__global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds,
+__global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, u32* sai,
                                                     Counters* ctr, u32 topk_kmax) {
   constexpr u32 CAP = 16384;
   __shared__ u32 buf[CAP];
@@ -2215,7 +2559,10 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs
         }
         __syncthreads();
       }
-    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
+    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) {
+      seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
+      sai[J.out + i] = SAI_NONE;  // (hunt -m above 1 024: the verify kernel reads the text for these)
+    }
     if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)passes * J.occs);
     __syncthreads();
   }
@@ -2239,38 +2586,44 @@ struct TopkLds {
   u32 val[TOPK_VMAX];
   u32 cidx[2][TOPK_KCAP];
   u32 eidx[16];
+  u16 keep_p[TOPK_KMAX + 128];  // entries: where in val[] the survivors of the last select sit
   u32 hist[256];
   u32 wsum[4];
   u32 sh[4];
   u32 n_kept, job;
 };
-// Bitonic sort of buf[0, n2) (n2 a power of two <= 1024, entries behind it count as TOPK_PAD) by a 256-lane workgroup with four
-// elements per lane in registers: element i lives in lane i / 4.  Partners at distance 1-2 are in the same lane, at distance
-// 4-128 in the same wavefront (one shuffle), only distances 256 and 512 cross wavefronts through LDS — 3 barrier rounds for
-// 1 024 elements where the compare-exchange-in-LDS form had 55.  Returns the sorted elements 4 tid .. 4 tid + 3.
-DG_DEV void block_sort4(u32* buf, u32 n2, u32 (&v)[4]) {
+// Bitonic sort of n2 keys (n2 a power of two <= 1024; keys behind n2 must be the type's maximum) by a 256-lane workgroup with four
+// keys per lane in registers: key i lives in lane i / 4.  Partners at distance 1-2 are in the same lane, at distance 4-128 in the
+// same wavefront (one shuffle), only distances 256 and 512 cross wavefronts through LDS (xbuf: 1 024 keys) — 3 barrier rounds for
+// 1 024 keys where the compare-exchange-in-LDS form had 55.  v[r] = key 4 tid + r, in and out.
+template <class T>
+DG_DEV T shfl_xor_key(T x, int m);
+template <>
+DG_DEV u32 shfl_xor_key<u32>(u32 x, int m) { return (u32)__shfl_xor((int)x, m); }
+template <>
+DG_DEV u64 shfl_xor_key<u64>(u64 x, int m) { return (u64)__shfl_xor((unsigned long long)x, m); }
+template <class T>
+DG_DEV void block_sort4(T* xbuf, u32 n2, T (&v)[4]) {
   const u32 i0 = threadIdx.x * 4;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = i0 + r < n2 ? buf[i0 + r] : TOPK_PAD;
   for (u32 kk = 2; kk <= n2; kk <<= 1) {
-    const bool up = (i0 & kk) == 0;  // kk >= 4: the same for the lane's four elements; kk == 2 is handled per pair below
+    const bool up = (i0 & kk) == 0;  // kk >= 4: the same for the lane's four keys; kk == 2 is handled per pair below
     for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
       if (jj >= 256) {
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) buf[i0 + r] = v[r];
+        for (int r = 0; r < 4; ++r) xbuf[i0 + r] = v[r];
         __syncthreads();
         const bool keep_min = ((i0 & jj) == 0) == up;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const u32 o = buf[(i0 + r) ^ jj];
+          const T o = xbuf[(i0 + r) ^ jj];
           v[r] = keep_min ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
         }
       } else if (jj >= 4) {
         const bool keep_min = ((i0 & jj) == 0) == up;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const u32 o = (u32)__shfl_xor((int)v[r], (int)(jj >> 2));
+          const T o = shfl_xor_key<T>(v[r], (int)(jj >> 2));
           v[r] = keep_min ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
         }
       } else {
@@ -2279,7 +2632,7 @@ DG_DEV void block_sort4(u32* buf, u32 n2, u32 (&v)[4]) {
           const int b2 = a ^ (int)jj;
           if (b2 > a && (jj == 1 || jj == 2)) {
             const bool upp = kk == 2 ? ((a & 2) == 0) : up;  // (i & kk) == 0 for i = i0 + a
-            const u32 x = v[a], y = v[b2], mn = x < y ? x : y, mx = x < y ? y : x;
+            const T x = v[a], y = v[b2], mn = x < y ? x : y, mx = x < y ? y : x;
             v[a] = upp ? mn : mx;
             v[b2] = upp ? mx : mn;
           }
@@ -2325,7 +2678,7 @@ DG_DEV u32 topk_threshold(TopkLds& S, u32 nv, u32 k, u32 limit) {
   }
 }
 __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, u32* next_job,
-                                                     HitSeed* seeds, Counters* ctr) {
+                                                     HitSeed* seeds, u32* sai, Counters* ctr) {
   __shared__ TopkLds S;
   const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
   const u32 lane = threadIdx.x & 63;
@@ -2360,12 +2713,13 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
     bool top = true;
     __syncthreads();
     for (int j = L;; --j) {
-      const u32 limit = j == 0 ? k : TOPK_KCAP;
+      // at the entries: up to 96 values more than asked for may survive (the sort drops them) — an exact k-th value costs the
+      // radix select all four byte passes, a little slack usually ends it after two
+      const u32 limit = j == 0 ? (k + 96 < TOPK_KMAX ? k + 96 : (k > TOPK_KMAX ? k : TOPK_KMAX)) : TOPK_KCAP;
       const u32 T = nv > limit ? topk_threshold(S, nv, k, limit) : 0xFFFFFFFEu;
       if (threadIdx.x == 0) S.n_kept = 0;
       __syncthreads();
-      if (j == 0) {  // the survivors are the answer: collect, sort, write
-        u32* buf = &S.cidx[0][0];
+      if (j == 0) {  // the survivors are the answer: collect, sort (position, suffix-array index) pairs, write
         for (u32 base = 0; base < nv; base += 256) {
           const u32 p = base + threadIdx.x;
           const u32 x = p < nv ? S.val[p] : TOPK_PAD;
@@ -2374,19 +2728,32 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
           u32 at = 0;
           if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
           at = __shfl(at, 0);
-          if (keep) buf[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = x;
+          if (keep) S.keep_p[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = (u16)p;
         }
         __syncthreads();
-        const u32 have = S.n_kept;  // == k (positions are distinct) unless the whole interval is shorter
+        const u32 have = S.n_kept;  // k .. k + 96 values (fewer when the whole interval is shorter); the k smallest are written
         u32 n2 = 4;
         while (n2 < have) n2 <<= 1;
-        for (u32 i = have + threadIdx.x; i < n2; i += 256) buf[i] = TOPK_PAD;
-        __syncthreads();
-        u32 sv[4];
-        block_sort4(buf, n2, sv);
+        u64 sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u32 e = threadIdx.x * 4 + r;
+          sv[r] = ~0ULL;
+          if (e < have) {
+            const u32 p = S.keep_p[e];
+            // entry p of val[] is suffix-array entry idx (level 0 of samin is the suffix array itself)
+            const u32 idx = top ? (u32)(A(L) + p) : (p < 8 * nc_prev ? S.cidx[cur][p >> 3] * 8u + (p & 7u) : S.eidx[p - 8 * nc_prev]);
+            sv[r] = ((u64)S.val[p] << 32) | idx;
+          }
+        }
+        __syncthreads();  // val[] is free: the sort exchanges keys through it
+        block_sort4<u64>(reinterpret_cast<u64*>(S.val), n2, sv);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (threadIdx.x * 4 + r < k) seeds[J.out + threadIdx.x * 4 + r] = HitSeed{sv[r], J.g, J.len, J.slot};
+          if (threadIdx.x * 4 + r < k) {
+            seeds[J.out + threadIdx.x * 4 + r] = HitSeed{(u32)(sv[r] >> 32), J.g, J.len, J.slot};
+            sai[J.out + threadIdx.x * 4 + r] = (u32)sv[r];
+          }
         break;
       }
       // blocks of level j under the threshold -> cidx[cur ^ 1]
@@ -2432,6 +2799,41 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
 }
 
+// Context characters without the text (r03).  At edit distance 1 a hit's window is the kept string plus ONE character either side
+// (hunter.h:363-371).  On a repeat-bearing genome those two characters were 19 M random 64-byte lines per 100 000 queries — the
+// whole cost of k_verify_memo.  Both are in the index already:
+//   in front   T[SA[i] - 1] is the BWT symbol at the hit's suffix-array index i: one word of an Occ line, and the lines of one
+//              string's interval are neighbours (L2 hits);
+//   behind     the suffixes of [lo, hi) are sorted by what follows the string, so "the character behind the string is c" is a
+//              sub-interval: eight binary searches per string (first index whose next byte is >= 'A','B','C','D','G','H','T','U')
+//              bracket the four bases; an index outside the brackets ('\n', N, another letter) falls back to reading the text.
+// One 16-lane group per string with at least BOUNDS_MIN_TAKE hits (k_locate queues them), lanes 0-7 search.
+__global__ void __launch_bounds__(256) k_sel_bounds(FmView f, const BoundsJob* jobs, const u32* count, u32 cap, u32* bounds /* [cap * 8] */) {
+  const u32 njobs = *count < cap ? *count : cap;
+  const u32 w = threadIdx.x & 15u;
+  for (u32 job = blockIdx.x * 16u + (threadIdx.x >> 4); job < njobs; job += gridDim.x * 16u) {
+    if (w >= 8) continue;
+    const BoundsJob J = jobs[job];
+    const u32 th = w == 0 ? 'A' : w == 1 ? 'B' : w == 2 ? 'C' : w == 3 ? 'D' : w == 4 ? 'G' : w == 5 ? 'H' : w == 6 ? 'T' : 'U';
+    u32 a = 0, b2 = J.occs;  // first offset whose next byte is >= th (a string never ends behind n - 1: text[n - 1] = 0 sorts first)
+    while (a < b2) {
+      const u32 mid = (a + b2) >> 1;
+      const u32 nb = f.text[(u64)f.sa[J.lo + mid] + J.len];
+      if (nb >= th) b2 = mid;
+      else a = mid + 1;
+    }
+    bounds[(u64)job * 8 + w] = J.lo + a;
+  }
+}
+// BWT symbol class at suffix-array index i (index.hip Occ lines: three 128-bit planes of 3-bit codes): 0-3 A,C,G,T, 4 N, 5 '\n',
+// 6 sentinel (the suffix starts the text), 7 another byte
+DG_DEV u32 bwt_code_at(const FmView& f, u32 i) {
+  const u64* line = reinterpret_cast<const u64*>(f.occ + (i >> 7));
+  const u32 o = i & 127u, wsel = o >> 6, bit = o & 63u;
+  const u64 p0 = line[2 + wsel], p1 = line[4 + wsel], p2 = line[6 + wsel];
+  return (u32)((p0 >> bit) & 1u) | ((u32)((p1 >> bit) & 1u) << 1) | ((u32)((p2 >> bit) & 1u) << 2);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Verify: one lane per hit.
 struct VerifyArgs {
@@ -2446,7 +2848,11 @@ struct VerifyArgs {
   u32 stride;
   u32* ops;          // [nhits * ops_per_hit] compact alignment description (ALN_OP_NONE = unused)
   u32 ops_per_hit;   // the batch's largest effective distance
-  u32 debug;              // DICEY_DBG_VERIFY (measurements only: 1 = skip the alignments, 2 = skip the context reads; results are wrong)
+  u32 debug;              // DICEY_DBG_VERIFY (measurements: 1 = skip the alignments, 2 = skip the context reads — wrong results; 4 = check the
+                          // index-derived context characters against the text and fail the batch on a difference)
+  const u32* sai;         // [nhits] suffix-array index of each hit (SAI_NONE = unknown), nullptr = not recorded
+  const Sel* sel;         // kept strings (Sel::bref -> bounds)
+  const u32* bounds;      // k_sel_bounds' brackets, eight words per string
 };
 
 // SMALL = true (all queries of the batch <= 32 nt): the DP row lives in registers (columns fully unrolled) and each
@@ -3037,6 +3443,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
 #pragma unroll
   for (int j = 0; j < CH; ++j) dq[j] = b.indel ? b.qdist[sd[j].qs >> 1] : 0u;
   u32 fl[CH];  // context bytes: left of the string at bits 0-15 (nearest first), right of it at bits 16-31
+  u32 ctx_fault = 0;
 #pragma unroll
   for (int j = 0; j < CH; ++j) {
     const u64 h = base + (u32)j * 256u + tid;
@@ -3044,10 +3451,31 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     const u32 d = dq[j];
     u32 x = 0;
     if (h < nh && !(a.debug & 2u)) {
-      if (d >= 1 && loc >= 1) x |= (u32)f.text[loc - 1];
-      if (DS >= 2 && d >= 2 && loc >= 2) x |= (u32)f.text[loc - 2] << 8;
-      if (d >= 1 && endp + 1 <= f.n) x |= (u32)f.text[endp] << 16;
-      if (DS >= 2 && d >= 2 && endp + 2 <= f.n) x |= (u32)f.text[endp + 1] << 24;
+      bool from_text = true;
+      u32 xi = 0;
+      if (SHARE && DS == 1 && d == 1 && a.sai) {  // both characters from the index (k_sel_bounds), when the string has its brackets
+        const u32 si = a.sai[h];
+        const u32 br = si != SAI_NONE ? a.sel[sd[j].sel].bref : 0xFFFFFFFFu;
+        if (br != 0xFFFFFFFFu) {
+          const uint4 b0 = *reinterpret_cast<const uint4*>(a.bounds + (u64)br * 8), b1 = *reinterpret_cast<const uint4*>(a.bounds + (u64)br * 8 + 4);
+          const u32 post = (si >= b0.x && si < b0.y) ? 'A' : (si >= b0.z && si < b0.w) ? 'C' : (si >= b1.x && si < b1.y) ? 'G'
+                           : (si >= b1.z && si < b1.w) ? 'T' : 0u;
+          const u32 code = bwt_code_at(f, si);
+          const u32 pre = code < 4 ? ((0x54474341u >> (8 * code)) & 255u) : code == 4 ? 'N' : code == 5 ? '\n' : 0u;
+          if (post && (code <= 6)) {
+            xi = (loc >= 1 ? pre : 0u) | (post << 16);  // code 6: the hit starts the text, nothing in front of it
+            from_text = false;
+          }
+        }
+      }
+      if (from_text || (a.debug & 4u)) {
+        if (d >= 1 && loc >= 1) x |= (u32)f.text[loc - 1];
+        if (DS >= 2 && d >= 2 && loc >= 2) x |= (u32)f.text[loc - 2] << 8;
+        if (d >= 1 && endp + 1 <= f.n) x |= (u32)f.text[endp] << 16;
+        if (DS >= 2 && d >= 2 && endp + 2 <= f.n) x |= (u32)f.text[endp + 1] << 24;
+        if (!from_text && x != xi) ctx_fault = 1;
+      }
+      if (!from_text) x = xi;
     }
     fl[j] = x;
   }
@@ -3151,7 +3579,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
       if (DS > 1) cls_ops[c * DS + 1] = r.op[1];
     }
   }
-  if (fault) s_fault = 1;
+  if (fault || ctx_fault) s_fault = 1;
   __syncthreads();
   if (s_fault) {  // never observed; fail the batch loudly rather than hand out a wrong alignment
     if (tid == 0) atomicOr(&ctr->overflow, 2u);
@@ -3669,7 +4097,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   DG_TRY(ws[WS_QSEQ].reserve(total + 8));
   DG_TRY(ws[WS_QMETA].reserve(nq * 16 + 64));
   DG_TRY(ws[WS_GINFO].reserve(ngrp * sizeof(GidInfo) + 64));
-  DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 2 + nq * 4 + scan_tmp * 8 + sizeof(Counters) + sizeof(Summary) + 512));
+  DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 3 + nq * 4 + scan_tmp * 8 + sizeof(Counters) + sizeof(Summary) + 512));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   // Could any query of this batch reach the cap?  (the bound grows with the length and with the number of N's)
   CapScan cs;
@@ -3755,6 +4183,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   u32* nsel = (u32*)gp;
   gp += ngrp * 4;
   const size_t zero_bytes = (size_t)(gp - zero_from);
+  u32* selbase = (u32*)gp;  // first Sel slot of the groups k_search1s serves (set by k_prepare / k_search1s)
+  gp += ngrp * 4;
   b.refused = &ctr->pad_[1];
   b.too_long = &ctr->pad_[2];
   b.maxlen_bound = maxlen;
@@ -3787,6 +4217,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   if (std::getenv("DICEY_DEBUG_CAPS")) surv_cap_log2 = 1;
   u64 nleaf = 0, nhits = 0;
+  bool force_generic = false;
   // Fetched results: one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh
   // hipHostMalloc per batch costs more than the copies), laid out for `capn` hits:
   // [hit_off | qoff | qdistance qflags qnondna | qseq | hits | ops].  When the previous fetched batch on this handle tells how many
@@ -3831,11 +4262,24 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (attempt > 4) return fail(DG_ENOMEM, "buffer overflow persists (%llu leaves, %llu hits)", (unsigned long long)nleaf, (unsigned long long)nhits);
     const u64 leaf_slots = (u64)NSHARD * shard_cap;
 
+    // Distance 1, every string in 128 bits: k_search1s settles the select stage inside the search kernel (flat Sel region of
+    // NSHARD slices).  The generic kernels (k_search for N-containing / long queries, k_explicit, scan, pack, alive, rank) run
+    // when the previous batch of this handle had work for them; a batch that turns out to need them after all is repeated.
+    static const bool no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr || std::getenv("DICEY_FLAT1_PER_OP") != nullptr ||
+                                std::getenv("DICEY_FLAT1_SPLIT") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
+    const bool fused = b.fastK && packed && !no_fuse && !std::getenv("DICEY_NO_FUSED_SELECT_NOW");
+    const u32 flat_cap = fused ? shard_cap : 0u;
+    const u64 flat_slots = (u64)NSHARD * flat_cap;
+    const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
     DG_TRY(ws[WS_LEAF].reserve(leaf_slots * sizeof(Leaf)));
     DG_TRY(ws[WS_LEAFG].reserve((leaf_slots + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
-    DG_TRY(ws[WS_SEL].reserve((leaf_slots + 1) * sizeof(Sel)));
+    DG_TRY(ws[WS_SEL].reserve((flat_slots + leaf_slots + 1) * sizeof(Sel)));
+    Sel* const sel_all = ws[WS_SEL].as<Sel>();
+    Sel* const sel_gen = sel_all + flat_slots;  // the generic path's slots: grp_off based, behind the flat region
     DG_TRY(ws[WS_SCR].reserve((leaf_slots + 1) * 5 + 64));
     DG_TRY(ws[WS_SEEDS].reserve((hit_cap + 1) * sizeof(HitSeed)));
+    DG_TRY(ws[WS_SAI].reserve((hit_cap + 1) * 4 + 64));
+    const u32* d_bounds_used = nullptr;
     if (b.fastK && std::getenv("DICEY_FLAT1_SPLIT")) DG_TRY(ws[WS_MISC].reserve(((u64)NSHARD << surv_cap_log2) * 4 + 64));
     u32 surv_cap = 0xFFFFFFFFu;  // set where the survivor queue is used
     DG_TRY(ws[WS_JOBS].reserve(2 * std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
@@ -3848,7 +4292,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (lane_only_ || ix->ctr_clean != (const void*)ctr || ix->ctr_clean_gen != ws[WS_GRP].gen) DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     ix->ctr_clean = nullptr;  // dirty until this attempt's last kernel has run
     DG_HIP(hipEventRecord(ix->ev[0], st));
-    hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_cnt, nsel);
+    hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_cnt, nsel, selbase, (u32*)&ctr->pad_[6]);
     DG_HIP(hipEventRecord(ix->ev[1], st));
     {
       SearchOut so;
@@ -3858,7 +4302,19 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       so.grp_cnt = grp_cnt;
       if (b.fastK) {  // distance 1: the flat kernel takes every query that qualifies, k_search (one lane per strand) the rest
         static const bool per_op = std::getenv("DICEY_FLAT1_PER_OP") != nullptr;  // the lane-per-operation form (A/B runs)
-        if (per_op) {
+        if (fused) {
+          const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg, gpw = std::min(16u, 256u / ipg);
+          FlatSel fs;
+          fs.sel = sel_all;
+          fs.cap = flat_cap;
+          fs.selbase = selbase;
+          fs.nsel = nsel;
+          const dim3 g1(ceil_div(ngrp, gpw)), b1(256);
+          // tests: DICEY_FUSED_LCAP lowers the LDS list's capacity so that ordinary batches exercise the hand-over to the generic path
+          static const u32 lcap = std::getenv("DICEY_FUSED_LCAP") ? std::min<u32>(FUSED_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP"))) : FUSED_LCAP;
+          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true>), g1, b1, 0, st, ix->view, b, so, fs, ipg, magic, gpw, lcap);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false>), g1, b1, 0, st, ix->view, b, so, fs, ipg, magic, gpw, lcap);
+        } else if (per_op) {
           const u32 ipg = std::min(maxlen, 31u) * (indel ? 8u : 4u);  // longer queries stay with k_search
           const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
           if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
@@ -3866,12 +4322,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         } else {
           // probe + finish in one kernel unless DICEY_FLAT1_SPLIT asks for the two-kernel form (r02 A/B: 0.25 ms fused, 0.21 +
           // 0.19 ms split — both halves run at the memory system's random-access rate, cutting the chain gained nothing)
-          static const bool fused = std::getenv("DICEY_FLAT1_SPLIT") == nullptr;
+          static const bool one_kernel = std::getenv("DICEY_FLAT1_SPLIT") == nullptr;
           const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg;  // longer queries stay with k_search
           static const u32 tb1 = std::getenv("DICEY_FLAT1_TB") ? (u32)std::atoi(std::getenv("DICEY_FLAT1_TB")) : 256u;
-          const u32 TB1 = fused && (tb1 == 64 || tb1 == 128) ? tb1 : TB;
+          const u32 TB1 = one_kernel && (tb1 == 64 || tb1 == 128) ? tb1 : TB;
           const dim3 g1(ceil_div(ngrp * ipg, TB1)), b1(TB1);
-          if (fused) {
+          if (one_kernel) {
             if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<false>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
           } else {
@@ -3896,6 +4352,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         else hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
+      if (generic_on) {
       // root-level work split (see k_search): only with the table and with at least one edit to place
       const u32 items = (ix->view.K && dmax_eff >= 1 && !b.fastK) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
       const dim3 grid(ceil_div(ngrp * items, TB)), block(TB);
@@ -3913,14 +4370,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       }
 #undef DG_LAUNCH_SEARCH
       if (nxs) hipLaunchKernelGGL(k_explicit, dim3(ceil_div(nxs, TB)), dim3(TB), 0, st, ix->view, b, so);
+      }
     }
     DG_HIP(hipEventRecord(ix->ev[2], st));
     // (r03 tried single-launch scans chained by decoupled look-back, and k_take fused with its scan: 17 us against 2 x 4.3 us, and
     //  47 us against 7 + 9 us — descriptor polling with device-scope acquire / release is slow across the XCDs' L2s.  What stays of
     //  that round: the first scan kernel also checks the search kernels' buffers, which was a launch of its own.)
-    DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf, ctr, shard_cap, surv_cap));
+    if (generic_on) DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf, ctr, shard_cap, surv_cap));
     DG_HIP(hipEventRecord(ix->ev[3], st));
     if (packed) {
+      if (generic_on) {
       u8* alive = ws[WS_SCR].as<u8>();
       hipLaunchKernelGGL(k_group_pack, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr,
                          grp_off, ws[WS_LEAFG].as<PLeaf>());
@@ -3930,25 +4389,27 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (above)
         // (one wavefront per group was tried: 1.95 -> 2.5 ms, the second wavefront's share of the window searches is worth more than the barriers)
         hipLaunchKernelGGL(k_group_select, dim3((u32)ngrp), dim3(128), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, (u32)indel,
-                           ws[WS_SEL].as<Sel>(), nsel, ctr);
+                           sel_gen, nsel, ctr);
       hipLaunchKernelGGL(k_leaf_alive, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
                          (u32)indel, alive, ctr, above);
       hipLaunchKernelGGL(k_leaf_rank, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
-                         (const u8*)alive, ws[WS_SEL].as<Sel>(), nsel, ctr, above);
-      hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_off, nsel, ws[WS_SEL].as<Sel>(), qhits, ctr);
+                         (const u8*)alive, sel_gen, nsel, ctr, above);
+      }
+      hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, (const u64*)grp_off, (const u32*)selbase, flat_slots, (const u32*)nsel, sel_all,
+                         qhits, ctr);
     } else {
       hipLaunchKernelGGL(k_group, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr, grp_off,
                          ws[WS_LEAFG].as<Leaf>());
       u32* scr_rank = ws[WS_SCR].as<u32>();
       u8* scr_keep = (u8*)(scr_rank + leaf_slots + 1);
-      hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, ws[WS_SEL].as<Sel>(),
+      hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, sel_gen,
                          nsel, qhits, scr_keep, scr_rank, ctr);
     }
     DG_HIP(hipEventRecord(ix->ev[4], st));
     if (group_counts) {
       DG_TRY(ws[WS_HITS].reserve(ngrp * 8 + 64));
-      hipLaunchKernelGGL(k_group_count, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, grp_off, nsel, ws[WS_SEL].as<Sel>(), ngrp,
-                         ws[WS_HITS].as<u64>(), ctr);
+      hipLaunchKernelGGL(k_group_count, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, (const u64*)grp_off, (const u32*)selbase, flat_slots,
+                         (const u32*)nsel, (const Sel*)sel_all, ngrp, ws[WS_HITS].as<u64>(), ctr);
       DG_HIP(hipMemsetAsync(hit_off + nq, 0, 8, st));  // no hits in this mode
       for (int e = 5; e <= 7; ++e) DG_HIP(hipEventRecord(ix->ev[e], st));
     } else {
@@ -3967,19 +4428,35 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       // the record that shares a kept string's slot names its group: the packed leaf (qs behind 28 bytes) or the grouped leaf (qs first)
       const u8* slot_qs = packed ? (const u8*)ws[WS_LEAFG].p + offsetof(PLeaf, qs) : (const u8*)ws[WS_LEAFG].p + offsetof(Leaf, qs);
       const u32 slot_stride = packed ? (u32)sizeof(PLeaf) : (u32)sizeof(Leaf);
-      hipLaunchKernelGGL(k_locate, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ix->view, (const Sel*)ws[WS_SEL].as<Sel>(), slot_qs, slot_stride,
-                         (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj);
+      // context bounds (k_sel_bounds): edit distance 1 through the banded verify only; jobs + eight words per string in WS_BOUNDS
+      const bool no_bounds = std::getenv("DICEY_NO_CTX_BOUNDS") != nullptr;
+      BoundsJobs bjs;
+      bjs.cap = (u32)std::min<u64>(flat_slots + leaf_slots, 1u << 18);
+      bjs.count = (u32*)&ctr->pad_[7];
+      bjs.jobs = nullptr;
+      u32* d_bounds = nullptr;
+      if (band_verify && indel && dmax_eff == 1 && !no_bounds && !no_block) {
+        DG_TRY(ws[WS_BOUNDS].reserve((u64)bjs.cap * (sizeof(BoundsJob) + 32) + 64));
+        bjs.jobs = ws[WS_BOUNDS].as<BoundsJob>();
+        d_bounds = reinterpret_cast<u32*>(ws[WS_BOUNDS].as<u8>() + (u64)bjs.cap * sizeof(BoundsJob));
+      }
+      d_bounds_used = d_bounds;
+      hipLaunchKernelGGL(k_locate, dim3(ceil_div(flat_slots + (generic_on ? leaf_slots : 0), TB)), dim3(TB), 0, st, ix->view, (const Sel*)sel_all, slot_qs,
+                         slot_stride, (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj,
+                         flat_slots, flat_cap, (u32)generic_on, ws[WS_SAI].as<u32>(), sel_all, bjs, (const u32*)b.qdist, (u32)indel);
+      if (bjs.jobs)
+        hipLaunchKernelGGL(k_sel_bounds, dim3(1024), dim3(256), 0, st, ix->view, (const BoundsJob*)bjs.jobs, (const u32*)bjs.count, bjs.cap, d_bounds);
       if (!no_block) {
         hipLaunchKernelGGL(k_locate_small, dim3(8192), dim3(64), 0, st, ix->view, (const BigJob*)lj.small, (const u32*)lj.n_small, job_cap,
-                           ws[WS_SEEDS].as<HitSeed>(), ctr);
+                           ws[WS_SEEDS].as<HitSeed>(), ws[WS_SAI].as<u32>(), ctr);
         // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
         const bool topk = ix->view.nlev > 1;
         if (topk)
           hipLaunchKernelGGL(k_locate_topk, dim3(768), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
-                             (u32*)&ctr->pad_[3], ws[WS_SEEDS].as<HitSeed>(), ctr);
+                             (u32*)&ctr->pad_[3], ws[WS_SEEDS].as<HitSeed>(), ws[WS_SAI].as<u32>(), ctr);
         if (!topk || p->max_locations > TOPK_KMAX)
           hipLaunchKernelGGL(k_locate_big, dim3(1024), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
-                             ws[WS_SEEDS].as<HitSeed>(), ctr, topk ? TOPK_KMAX : 0u);
+                             ws[WS_SEEDS].as<HitSeed>(), ws[WS_SAI].as<u32>(), ctr, topk ? TOPK_KMAX : 0u);
       }
     }
     DG_HIP(hipEventRecord(ix->ev[6], st));
@@ -3998,8 +4475,11 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       va.stride = stride;
       va.ops = ws[WS_OPS].as<u32>();
       va.ops_per_hit = ops_per_hit;
-      static const u32 dbg_verify = std::getenv("DICEY_DBG_VERIFY") ? (u32)std::atoi(std::getenv("DICEY_DBG_VERIFY")) : 0u;
+      const u32 dbg_verify = std::getenv("DICEY_DBG_VERIFY") ? (u32)std::atoi(std::getenv("DICEY_DBG_VERIFY")) : 0u;  // read per batch: tests switch the check on
       va.debug = dbg_verify;
+      va.sai = d_bounds_used ? ws[WS_SAI].as<u32>() : nullptr;
+      va.sel = sel_all;
+      va.bounds = d_bounds_used;
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
@@ -4093,11 +4573,19 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       while (surv_cap_log2 < 30 && (1ull << surv_cap_log2) < hsum.worst_surv + hsum.worst_surv / 4) ++surv_cap_log2;
       continue;
     }
-    const u32 worst = (u32)hsum.worst_shard;
+    // the generic kernels were left out, and the batch had work for them after all (queries with N, longer than 31 nt, a workgroup
+    // of k_search1s whose strings did not fit its LDS list): once more, with them
+    if (fused && !generic_on && (hsum.nleaf > 0 || hsum.n_generic > 0)) {
+      ix->generic_hint = true;
+      force_generic = true;
+      continue;
+    }
+    const u32 worst = (u32)std::max<unsigned long long>(hsum.worst_shard, fused ? hsum.worst_sel : 0ULL);  // leaf regions and flat Sel slices share one capacity
     if (worst > shard_cap) {
       shard_cap = worst + worst / 4 + 64;
       continue;
     }
+    if (fused) ix->generic_hint = hsum.nleaf > 0 || hsum.n_generic > 0 || nxs > 0;
     if (nhits > hit_cap) {
       hit_cap = nhits + nhits / 4 + 1024;
       continue;
@@ -4155,7 +4643,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   R->d_hits = ws[WS_HITS].p;
   R->d_ops = ops_per_hit ? ws[WS_OPS].p : nullptr;
-  R->ctr_leaves = nleaf;
+  R->ctr_leaves = nleaf + hsum.fused_leaves;
   R->ctr_ext_steps = hsum.steps;
   R->ctr_tab_reads = hsum.lookups;
   R->ctr_filter_probes = hsum.probes;
@@ -4289,21 +4777,59 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
   return rc;
 }
 
-// Asynchronous form of dg_hunt (ABI 4).  The batch is driven by a helper thread of the library: copies, kernels, the batch's one
-// synchronisation, the copy of the results into a pinned block.  The caller goes on — typically formatting the previous batch — and
-// collects with dg_hunt_wait.  One batch per handle at a time; a second handle from dg_index_share runs its batch concurrently on
-// its own stream, which is how a single-threaded host keeps two batches in flight.
+// Asynchronous form of dg_hunt (ABI 4).  The batch is driven by the handle's helper thread (created at the first submit, alive
+// until the handle closes — a fresh thread per batch paid HIP's per-thread start-up every time: 2.5 ms per 100 000-query batch in
+// the first r03 measurement): copies, kernels, the batch's one synchronisation, the results into a pinned block.  The caller goes
+// on — typically formatting the previous batch — and collects with dg_hunt_wait.  One batch per handle at a time; a second handle
+// from dg_index_share runs its batch concurrently on its own stream, which is how a single-threaded host keeps two in flight.
 struct dg_hunt_ticket {
   dg_index* ix = nullptr;
   dg_hunt_params p;
   std::vector<uint32_t> seqlen;
   std::vector<uint8_t> qbytes;
   std::vector<uint64_t> qoff;
-  std::thread th;
   int rc = DG_OK;
   std::string err;
   dg_hunt_result* res = nullptr;
+  bool done = false;
 };
+struct dg_index::Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  dg_hunt_ticket* job = nullptr;  // handed over, not yet taken
+  bool quit = false;
+  void loop() {
+    for (;;) {
+      dg_hunt_ticket* t = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return job || quit; });
+        if (!job) return;
+        t = job;
+        job = nullptr;
+      }
+      t->rc = dg_hunt(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), t->qbytes.data(), t->qoff.data(), t->qoff.size() - 1, &t->res);
+      if (t->rc != DG_OK) t->err = dg_last_error();  // the message is thread-local: carried over to the waiting thread
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        t->done = true;
+      }
+      cv.notify_all();
+    }
+  }
+};
+void dg_index::stop_worker() {
+  if (!worker) return;
+  {
+    std::lock_guard<std::mutex> lk(worker->mu);
+    worker->quit = true;
+  }
+  worker->cv.notify_all();
+  if (worker->th.joinable()) worker->th.join();
+  delete worker;
+  worker = nullptr;
+}
 
 int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
                    const uint64_t* qoff, size_t nq, dg_hunt_ticket** out) {
@@ -4319,10 +4845,15 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     t->seqlen.assign(seqlen, seqlen + nseq);
     t->qoff.assign(qoff, qoff + nq + 1);
     t->qbytes.assign(qbytes, qbytes + qoff[nq]);  // the caller's buffers are free again when this call returns
-    t->th = std::thread([t] {
-      t->rc = dg_hunt(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), t->qbytes.data(), t->qoff.data(), t->qoff.size() - 1, &t->res);
-      if (t->rc != DG_OK) t->err = dg_last_error();  // the message is thread-local: carried over to the waiting thread
-    });
+    if (!ix->worker) {
+      ix->worker = new dg_index::Worker;
+      ix->worker->th = std::thread([w = ix->worker] { w->loop(); });
+    }
+    {
+      std::lock_guard<std::mutex> lk(ix->worker->mu);
+      ix->worker->job = t;
+    }
+    ix->worker->cv.notify_all();
   } catch (const std::exception& e) {
     delete t;
     ix->busy.store(false);
@@ -4334,8 +4865,12 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
 
 int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out) {
   if (!t || !out) return fail(DG_EINVAL, "dg_hunt_wait: null argument");
-  t->th.join();
-  t->ix->busy.store(false);
+  dg_index* ix = t->ix;
+  {
+    std::unique_lock<std::mutex> lk(ix->worker->mu);
+    ix->worker->cv.wait(lk, [&] { return t->done; });
+  }
+  ix->busy.store(false);
   *out = t->res;
   const int rc = t->rc;
   const std::string err = t->err;

@@ -65,6 +65,8 @@ struct Counters {
   u32 leaf_cnt[NSHARD];  // leaves allocated in each shard's region of the leaf buffer
   unsigned long long steps[NSHARD], lookups[NSHARD], sa_reads[NSHARD], win_bytes[NSHARD], probes[NSHARD];
   u32 surv_cnt[NSHARD];  // filter survivors queued in each shard's region of the survivor buffer (k_probe1 -> k_finish1)
+  u32 sel_cnt[NSHARD];   // kept strings in each shard's slice of the flat Sel region (k_search1s)
+  unsigned long long fused_leaves[NSHARD];  // occurring strings k_search1s settled in LDS
 };
 
 struct HitSeed {  // 16 bytes, read as one uint4
@@ -74,7 +76,7 @@ struct HitSeed {  // 16 bytes, read as one uint4
   u32 sel;  // slot of the kept string (Sel) the hit stems from: hits of one slot share query, strand and string
 };
 
-enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO, WS_XS, WS_OPS };
+enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO, WS_XS, WS_OPS, WS_SAI, WS_BOUNDS };
 
 // one located hit after the `dicey search` stage
 struct SiteRaw {

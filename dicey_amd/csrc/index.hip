@@ -730,6 +730,7 @@ static int open_impl(const char* path, int device, u32 flags, dg_index* ix) {
 using namespace dg;
 
 dg_index::~dg_index() {
+  stop_worker();
   for (void* p : owned) dg::big_free(p, stream);
   if (stream) (void)hipStreamSynchronize(stream);
   for (auto& w : ws) w.release();

@@ -14,11 +14,12 @@ struct dg_index {
   uint64_t file_bytes = 0, hbm_bytes = 0;
   double load_seconds = 0, derive_seconds = 0;
   // grow-only batch workspaces (see hunt.hip / seam.hip for the slot meaning)
-  static constexpr int NWS = 22;
+  static constexpr int NWS = 24;
   dg::DevBuf ws[NWS];
   hipEvent_t ev[9] = {nullptr};  // [8]: end of the flat distance-1 kernel
   uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
   uint64_t hit_cap_hint = 0;
+  bool generic_hint = true;      // the previous distance-1 batch had work for the kernels outside k_search1s (hunt.hip run_batch)
   uint64_t fetch_hits_hint = 0;  // hits of the previous fetched batch (+3 %): this many are copied to the host before the batch's synchronisation
   uint32_t surv_cap_log2_hint = 0;  // survivor-queue capacity per shard (log2) that was enough for the previous batch
   // dg_hunt_device: the (offsets pointer, count, bytes) of the previous call and the longest query it held; a repeated
@@ -30,6 +31,9 @@ struct dg_index {
   // the batch counters are left zeroed by the last kernel of a batch (hunt.hip batch_finish): the next batch skips its memset
   // when they still sit where that kernel cleaned them
   std::atomic<bool> busy{false};      // a dg_hunt_submit batch is in flight on this handle
+  struct Worker;                      // the helper thread that drives dg_hunt_submit batches (hunt.hip)
+  Worker* worker = nullptr;
+  void stop_worker();
   const void* ctr_clean = nullptr;
   unsigned long long ctr_clean_gen = 0;
   std::vector<uint64_t> cum_cache;    // cumulative sequence starts currently resident in WS_CUM

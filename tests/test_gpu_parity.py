@@ -408,3 +408,33 @@ def test_submit_wait_on_two_handles_equals_the_blocking_call(gpu_small, small_ge
             assert key(gpu_small.hunt_wait(ta)) == want_a
     finally:
         other.close()
+
+
+@pytest.mark.parametrize("lcap", [None, "3", "0"])
+def test_fused_select_and_its_hand_over_to_the_generic_kernels(small_genome, monkeypatch, lcap):
+    """Distance 1: k_search1s settles the select stage inside the search kernel and the generic kernels (k_search for queries
+    with N / above 31 nt, scan, pack, alive, rank) are left out once a batch had no work for them.  A later batch that needs them
+    is repeated with them; a workgroup whose strings overflow its LDS list (forced here with DICEY_FUSED_LCAP) hands its groups
+    over the same way.  Every batch must equal the checker, whatever the handle saw before."""
+    import dicey_amd
+    if lcap is not None:
+        monkeypatch.setenv("DICEY_FUSED_LCAP", lcap)
+    g = small_genome
+    orc = O.Index(g["fm9"])
+    rng = random.Random(404)
+    pure = make_queries(41, g["text"], 600, (20,))
+    pure = [q for q in pure if set(q) <= set("ACGT")]
+    low = ["A" * 20, "AC" * 10, "ACG" * 7, g["seqs"][0][100:120], "T" * 19 + "G"] * 3
+    mixed = pure[:150] + ["ACGTNACGTACGTACGTACG", g["seqs"][1][50:90], "acgtacgtacgtacgtacgtnn", g["seqs"][2][7:19]] + pure[150:200]
+    rng.shuffle(mixed)
+    monkeypatch.setenv("DICEY_KMER_K", "9")
+    with dicey_amd.FmIndex(g["fm9"]) as ix:
+        for qs, kw in [(pure, dict(distance=1)), (pure[:300], dict(distance=1)), (mixed, dict(distance=1)), (pure[300:], dict(distance=1)),
+                       (pure[:200], dict(distance=1, hamming=True)), (low, dict(distance=1)), (mixed, dict(distance=1, hamming=True)),
+                       (pure[:100], dict(distance=1, max_locations=2)), (pure[:64], dict(distance=1, forward_only=True))]:
+            _compare(ix, orc, g, qs, **kw)
+        # count mode (padlock.h:396-421) goes through the same kept strings
+        rc = lambda q: q[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        for q, (gf, gr) in zip(pure[:40], ix.neighborhood_count([q.encode() for q in pure[:40]], distance=1)):
+            assert gf == sum(orc.count(s.encode()) for s in O.neighbors(q, 1, True)), q
+            assert gr == sum(orc.count(s.encode()) for s in O.neighbors(rc(q), 1, True)), q

@@ -578,7 +578,9 @@ def main():
             mean = lambda k: float(np.mean([r[k] for r in acc]))  # noqa: E731
             ext, tab, probe = mean("ext"), mean("tab"), mean("probe")
             flat = mean("ms_search_flat")
-            kernel = ("k_search1p<true>" if distance == 1 else "k_search2p") if flat > 0 else f"k_search<true,{distance}>"
+            # distance 1: k_search1s = the flat search with the select stage inside (r03); DICEY_NO_FUSED_SELECT gives k_search1p
+            k1 = "k_search1p<true>" if os.environ.get("DICEY_NO_FUSED_SELECT") else "k_search1s<true>"
+            kernel = (k1 if distance == 1 else "k_search2p") if flat > 0 else f"k_search<true,{distance}>"
             kernel_ms = flat if flat > 0 else mean("ms_search")
             alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
             # the same launch in SURVEY.md §8(d) units: a backward step on c = 2 L(c) rank ops of 24 B on the sdsl layout

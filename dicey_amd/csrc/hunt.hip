@@ -49,7 +49,6 @@ struct Sel {  // a kept neighbourhood string, in search order
   u32 take;   // how many of its occurrences become hits
   u32 hbase;  // first hit slot, relative to the query's first hit
   u32 g;      // 2*query + strand (set for the strings of the flat region, where no leaf record names the group)
-  u32 bref;   // index of the string's context bounds (k_sel_bounds), 0xFFFFFFFF = none; set by k_locate for every kept string
 };
 
 // Largest number of distinct strings neighbors() can hold for a query of length m with nN letters outside A/C/G/T (they
@@ -805,8 +804,13 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
     dense(false);
     return;
   }
-  // ---- select, per group, in LDS
-  for (u32 i = threadIdx.x; i < nl; i += 256) l_pos[i] = (u16)atomicAdd(&g_cnt[(l_meta[i] >> 6) & 15u], 1u);
+  // ---- select, per group, in LDS.  Up to 64 strings (the usual workgroup: 12 groups of two or three): by the first wavefront
+  // alone — the other three are done, a barrier only waits for wavefronts that have not ended, and their slots go to the next
+  // workgroup's probes while a few dozen strings are sorted here.  More strings (repeat families: hundreds per workgroup): all four
+  // wavefronts share the pair loops (one wavefront alone took 0.74 instead of 0.51 ms per step on the repeats genome).
+  const u32 sstep = nl <= 64 ? 64u : 256u;
+  if (threadIdx.x >= sstep) return;
+  for (u32 i = threadIdx.x; i < nl; i += sstep) l_pos[i] = (u16)atomicAdd(&g_cnt[(l_meta[i] >> 6) & 15u], 1u);
   __syncthreads();
   if (threadIdx.x == 0) {
     u32 run = 0;
@@ -816,10 +820,10 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
     }
   }
   __syncthreads();
-  for (u32 i = threadIdx.x; i < nl; i += 256) l_ord[g_start[(l_meta[i] >> 6) & 15u] + l_pos[i]] = (u16)i;
+  for (u32 i = threadIdx.x; i < nl; i += sstep) l_ord[g_start[(l_meta[i] >> 6) & 15u] + l_pos[i]] = (u16)i;
   __syncthreads();
   // alive: no other string of the group is a proper substring, and of equal strings the first of the list stays
-  for (u32 i = threadIdx.x; i < nl; i += 256) {
+  for (u32 i = threadIdx.x; i < nl; i += sstep) {
     const u32 meta = l_meta[i], alen = meta & 63u, lg = (meta >> 6) & 15u;
     bool ok = true;
     if (INDEL) {
@@ -857,7 +861,7 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
   if (!room && threadIdx.x == 0) atomicOr(&o.ctr->overflow, 1u);  // ... and the kernels behind this one do nothing
   if (threadIdx.x == 0 && nl) atomicAdd(&o.ctr->fused_leaves[shard], (unsigned long long)nl);
   // rank among the group's survivors in std::string order (A < C < G < T = code order; a proper prefix sorts first) -> Sel
-  for (u32 i = threadIdx.x; i < nl; i += 256) {
+  for (u32 i = threadIdx.x; i < nl; i += sstep) {
     const u32 meta = l_meta[i];
     if (!(meta & 0x8000u)) continue;
     const u32 alen = meta & 63u, lg = (meta >> 6) & 15u;
@@ -2257,16 +2261,6 @@ struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_t
 // grouped leaf of the same slot (slot_qs: address of that record's `qs` field, slot_stride: record size), serves strings of up to
 // 24 occurrences itself and queues the others: up to 256 occurrences for one wavefront (k_locate_small), more for one
 // workgroup (k_locate_topk / k_locate_big).
-static constexpr u32 BOUNDS_MIN_TAKE = 192;  // hits a kept string needs before its context bounds pay (8 binary searches)
-static constexpr u32 SAI_NONE = 0xFFFFFFFFu;
-struct BoundsJob {
-  u32 lo, occs, len, slot;
-};
-struct BoundsJobs {
-  BoundsJob* jobs;  // nullptr: no bounds in this batch
-  u32* count;
-  u32 cap;
-};
 struct LocJobs {
   BigJob* small;
   BigJob* big;
@@ -2278,12 +2272,10 @@ static constexpr u32 LOC_SMALL_MAX = 256;
 // A string with up to N occurrences: N loads in flight, a bitonic network on registers (every index is a compile-time constant —
 // r02's insertion sort indexed a private array dynamically, i.e. through scratch memory), `take` stores.
 template <int N>
-DG_DEV void locate_in_registers(const u32* sa, u32 lo, u32 occs, u32 take, HitSeed* out, u32* sai_out, u32 g, u32 len, u32 slot) {
-  // (position, suffix-array index) pairs: the index travels with the hit — k_verify_memo reads the character in front of the hit
-  // from the BWT at that index instead of the text (r03)
-  u64 v[N];
+DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out, u32 g, u32 len, u32 slot) {
+  u32 v[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = (u32)i < occs ? ((u64)sa[lo + i] << 32) | (u32)i : ~0ULL;
+  for (int i = 0; i < N; ++i) v[i] = (u32)i < occs ? sa[i] : 0xFFFFFFFFu;
 #pragma unroll
   for (int k = 2; k <= N; k <<= 1)
 #pragma unroll
@@ -2292,24 +2284,20 @@ DG_DEV void locate_in_registers(const u32* sa, u32 lo, u32 occs, u32 take, HitSe
       for (int i = 0; i < N; ++i) {
         const int l = i ^ j;
         if (l > i) {
-          const u64 a = v[i], b2 = v[l], mn = a < b2 ? a : b2, mx = a < b2 ? b2 : a;
+          const u32 a = v[i], b2 = v[l], mn = a < b2 ? a : b2, mx = a < b2 ? b2 : a;
           v[i] = (i & k) == 0 ? mn : mx;
           v[l] = (i & k) == 0 ? mx : mn;
         }
       }
 #pragma unroll
   for (int i = 0; i < N; ++i)
-    if ((u32)i < take) {
-      out[i] = HitSeed{(u32)(v[i] >> 32), g, len, slot};
-      sai_out[i] = lo + (u32)v[i];
-    }
+    if ((u32)i < take) out[i] = HitSeed{v[i], g, len, slot};
 }
 // Slots [0, flat_slots): the flat region (k_search1s; NSHARD slices of flat_cap entries, a slice holds ctr->sel_cnt[shard] strings,
 // each naming its group); slots behind it: the generic path's (grp_off based; only when generic_on).
 __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const u8* slot_qs, u32 slot_stride, const u64* grp_off, const u32* nsel,
                                                 u64 ngroups, const u64* hit_off, HitSeed* seeds, Counters* ctr, u64 hit_cap, LocJobs jobs,
-                                                u64 flat_slots, u32 flat_cap, u32 generic_on, u32* sai, Sel* sel_rw, BoundsJobs bj_out,
-                                                const u32* qdist, u32 indel) {
+                                                u64 flat_slots, u32 flat_cap, u32 generic_on) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
   u64 reads = 0;
@@ -2331,28 +2319,17 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
     S = sel[t];
     have = (tg - grp_off[g]) < nsel[g];  // slots behind the group's kept strings hold nothing
   }
-  bool want_bounds = false;
-  BoundsJob bjob;
   if (have) {
     const u32 take = S.take;
-    // strings with many hits at edit distance 1: k_sel_bounds finds where, inside the string's interval, the character BEHIND the
-    // string changes, so that k_verify_memo need not read the text for it
-    want_bounds = bj_out.jobs && indel && take >= BOUNDS_MIN_TAKE && qdist[g >> 1] == 1;
-    if (want_bounds) {
-      bjob.lo = S.lo;
-      bjob.occs = S.hi - S.lo;
-      bjob.len = S.len;
-      bjob.slot = (u32)t;
-    } else sel_rw[t].bref = 0xFFFFFFFFu;
     if (take) {
       const u32 lo = S.lo, occs = S.hi - S.lo;
       const u64 out0 = hit_off[g >> 1] + S.hbase;
       HitSeed* out = seeds + out0;
       if (occs <= 4) {
-        locate_in_registers<4>(f.sa, lo, occs, take, out, sai + out0, g, S.len, (u32)t);
+        locate_in_registers<4>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
         reads += occs;
       } else if (occs <= 16) {
-        locate_in_registers<16>(f.sa, lo, occs, take, out, sai + out0, g, S.len, (u32)t);
+        locate_in_registers<16>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
         reads += occs;
       } else if (jobs.big && take <= 16384) {
         bj.lo = lo;
@@ -2376,21 +2353,6 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
     }
   }
   const u32 lane = threadIdx.x & 63;
-  {
-    const unsigned long long mk = __ballot(want_bounds);
-    if (mk) {
-      u32 base = 0;
-      if (lane == (u32)__ffsll((long long)mk) - 1u) base = atomicAdd(bj_out.count, (u32)__popcll(mk));
-      base = __shfl(base, (int)__ffsll((long long)mk) - 1);
-      if (want_bounds) {
-        const u32 j = base + (u32)__popcll(mk & ((1ULL << lane) - 1));
-        if (j < bj_out.cap) {
-          bj_out.jobs[j] = bjob;
-          sel_rw[t].bref = j;
-        } else sel_rw[t].bref = 0xFFFFFFFFu;
-      }
-    }
-  }
   // job slots: one atomic per wavefront and list (every lane on the two list heads was what this kernel waited for)
   for (u32 which = 1; which <= 2; ++which) {
     const unsigned long long mk = __ballot(queue == which);
@@ -2410,17 +2372,13 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
     u64 prev = 0;
     bool first = true;
     for (u32 i = 0; i < bj.take; ++i) {
-      u32 best = 0xFFFFFFFFu, at = 0;
+      u32 best = 0xFFFFFFFFu;
       for (u32 j = 0; j < bj.occs; ++j) {
         const u32 x = f.sa[bj.lo + j];
-        if ((first || x > prev) && x < best) {
-          best = x;
-          at = j;
-        }
+        if ((first || x > prev) && x < best) best = x;
       }
       reads += bj.occs;
       seeds[bj.out + i] = HitSeed{best, bj.g, bj.len, bj.slot};
-      sai[bj.out + i] = bj.lo + at;
       prev = best;
       first = false;
     }
@@ -2431,9 +2389,8 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
 // One WAVEFRONT per string of 25..256 occurrences (most of the queued strings on a repeat-bearing genome: 54 k of 72 k per
 // 100 000 queries): the interval is read once, sorted in LDS by the wavefront alone (bitonic, no workgroup barrier to wait
 // for), the first `take` values are written.  Jobs are taken in grid order: they all cost about the same.
-__global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, u32* sai,
-                                                     Counters* ctr) {
-  __shared__ unsigned long long buf[LOC_SMALL_MAX];  // (position << 32) | offset in the interval
+__global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, Counters* ctr) {
+  __shared__ u32 buf[LOC_SMALL_MAX];
   const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
   u64 reads = 0;
   for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
@@ -2441,7 +2398,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
     u32 n2 = 32;
     while (n2 < J.occs) n2 <<= 1;
     const u32* sa = f.sa + J.lo;
-    for (u32 i = threadIdx.x; i < n2; i += 64) buf[i] = i < J.occs ? ((u64)sa[i] << 32) | i : ~0ULL;
+    for (u32 i = threadIdx.x; i < n2; i += 64) buf[i] = i < J.occs ? sa[i] : 0xFFFFFFFFu;
     reads += J.occs;
     __syncthreads();
     for (u32 kk = 2; kk <= n2; kk <<= 1)
@@ -2449,7 +2406,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
         for (u32 i = threadIdx.x; i < n2; i += 64) {
           const u32 l = i ^ jj;
           if (l > i) {
-            const u64 a = buf[i], b2 = buf[l];
+            const u32 a = buf[i], b2 = buf[l];
             if ((a > b2) == ((i & kk) == 0)) {
               buf[i] = b2;
               buf[l] = a;
@@ -2458,10 +2415,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
         }
         __syncthreads();
       }
-    for (u32 i = threadIdx.x; i < J.take; i += 64) {
-      seeds[J.out + i] = HitSeed{(u32)(buf[i] >> 32), J.g, J.len, J.slot};
-      sai[J.out + i] = J.lo + (u32)buf[i];
-    }
+    for (u32 i = threadIdx.x; i < J.take; i += 64) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
     __syncthreads();
   }
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
@@ -2473,7 +2427,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
 // of that bin fits the LDS buffer (on a genome-wide repeat family that is after the first pass: positions spread over the
 // whole text, so one top-byte bin holds occs/185 values).  One more pass collects those values, a bitonic sort orders
 // them.  2-3 coalesced passes over the interval instead of 33 (r02: 33 ms -> see DESIGN.md on the repeat-rich genome).
-__global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, u32* sai,
+__global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds,
                                                     Counters* ctr, u32 topk_kmax) {
   constexpr u32 CAP = 16384;
   __shared__ u32 buf[CAP];
@@ -2559,10 +2513,7 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs
         }
         __syncthreads();
       }
-    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) {
-      seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
-      sai[J.out + i] = SAI_NONE;  // (hunt -m above 1 024: the verify kernel reads the text for these)
-    }
+    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
     if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)passes * J.occs);
     __syncthreads();
   }
@@ -2586,7 +2537,6 @@ struct TopkLds {
   u32 val[TOPK_VMAX];
   u32 cidx[2][TOPK_KCAP];
   u32 eidx[16];
-  u16 keep_p[TOPK_KMAX + 128];  // entries: where in val[] the survivors of the last select sit
   u32 hist[256];
   u32 wsum[4];
   u32 sh[4];
@@ -2678,7 +2628,7 @@ DG_DEV u32 topk_threshold(TopkLds& S, u32 nv, u32 k, u32 limit) {
   }
 }
 __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, u32* next_job,
-                                                     HitSeed* seeds, u32* sai, Counters* ctr) {
+                                                     HitSeed* seeds, Counters* ctr) {
   __shared__ TopkLds S;
   const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
   const u32 lane = threadIdx.x & 63;
@@ -2719,7 +2669,8 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
       const u32 T = nv > limit ? topk_threshold(S, nv, k, limit) : 0xFFFFFFFEu;
       if (threadIdx.x == 0) S.n_kept = 0;
       __syncthreads();
-      if (j == 0) {  // the survivors are the answer: collect, sort (position, suffix-array index) pairs, write
+      if (j == 0) {  // the survivors are the answer: collect, sort, write
+        u32* buf = &S.cidx[0][0];
         for (u32 base = 0; base < nv; base += 256) {
           const u32 p = base + threadIdx.x;
           const u32 x = p < nv ? S.val[p] : TOPK_PAD;
@@ -2728,32 +2679,19 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
           u32 at = 0;
           if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
           at = __shfl(at, 0);
-          if (keep) S.keep_p[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = (u16)p;
+          if (keep) buf[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = x;
         }
         __syncthreads();
         const u32 have = S.n_kept;  // k .. k + 96 values (fewer when the whole interval is shorter); the k smallest are written
         u32 n2 = 4;
         while (n2 < have) n2 <<= 1;
-        u64 sv[4];
+        u32 sv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const u32 e = threadIdx.x * 4 + r;
-          sv[r] = ~0ULL;
-          if (e < have) {
-            const u32 p = S.keep_p[e];
-            // entry p of val[] is suffix-array entry idx (level 0 of samin is the suffix array itself)
-            const u32 idx = top ? (u32)(A(L) + p) : (p < 8 * nc_prev ? S.cidx[cur][p >> 3] * 8u + (p & 7u) : S.eidx[p - 8 * nc_prev]);
-            sv[r] = ((u64)S.val[p] << 32) | idx;
-          }
-        }
-        __syncthreads();  // val[] is free: the sort exchanges keys through it
-        block_sort4<u64>(reinterpret_cast<u64*>(S.val), n2, sv);
+        for (int r = 0; r < 4; ++r) sv[r] = threadIdx.x * 4 + r < have ? buf[threadIdx.x * 4 + r] : TOPK_PAD;
+        block_sort4<u32>(buf, n2, sv);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (threadIdx.x * 4 + r < k) {
-            seeds[J.out + threadIdx.x * 4 + r] = HitSeed{(u32)(sv[r] >> 32), J.g, J.len, J.slot};
-            sai[J.out + threadIdx.x * 4 + r] = (u32)sv[r];
-          }
+          if (threadIdx.x * 4 + r < k) seeds[J.out + threadIdx.x * 4 + r] = HitSeed{sv[r], J.g, J.len, J.slot};
         break;
       }
       // blocks of level j under the threshold -> cidx[cur ^ 1]
@@ -2799,41 +2737,6 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
 }
 
-// Context characters without the text (r03).  At edit distance 1 a hit's window is the kept string plus ONE character either side
-// (hunter.h:363-371).  On a repeat-bearing genome those two characters were 19 M random 64-byte lines per 100 000 queries — the
-// whole cost of k_verify_memo.  Both are in the index already:
-//   in front   T[SA[i] - 1] is the BWT symbol at the hit's suffix-array index i: one word of an Occ line, and the lines of one
-//              string's interval are neighbours (L2 hits);
-//   behind     the suffixes of [lo, hi) are sorted by what follows the string, so "the character behind the string is c" is a
-//              sub-interval: eight binary searches per string (first index whose next byte is >= 'A','B','C','D','G','H','T','U')
-//              bracket the four bases; an index outside the brackets ('\n', N, another letter) falls back to reading the text.
-// One 16-lane group per string with at least BOUNDS_MIN_TAKE hits (k_locate queues them), lanes 0-7 search.
-__global__ void __launch_bounds__(256) k_sel_bounds(FmView f, const BoundsJob* jobs, const u32* count, u32 cap, u32* bounds /* [cap * 8] */) {
-  const u32 njobs = *count < cap ? *count : cap;
-  const u32 w = threadIdx.x & 15u;
-  for (u32 job = blockIdx.x * 16u + (threadIdx.x >> 4); job < njobs; job += gridDim.x * 16u) {
-    if (w >= 8) continue;
-    const BoundsJob J = jobs[job];
-    const u32 th = w == 0 ? 'A' : w == 1 ? 'B' : w == 2 ? 'C' : w == 3 ? 'D' : w == 4 ? 'G' : w == 5 ? 'H' : w == 6 ? 'T' : 'U';
-    u32 a = 0, b2 = J.occs;  // first offset whose next byte is >= th (a string never ends behind n - 1: text[n - 1] = 0 sorts first)
-    while (a < b2) {
-      const u32 mid = (a + b2) >> 1;
-      const u32 nb = f.text[(u64)f.sa[J.lo + mid] + J.len];
-      if (nb >= th) b2 = mid;
-      else a = mid + 1;
-    }
-    bounds[(u64)job * 8 + w] = J.lo + a;
-  }
-}
-// BWT symbol class at suffix-array index i (index.hip Occ lines: three 128-bit planes of 3-bit codes): 0-3 A,C,G,T, 4 N, 5 '\n',
-// 6 sentinel (the suffix starts the text), 7 another byte
-DG_DEV u32 bwt_code_at(const FmView& f, u32 i) {
-  const u64* line = reinterpret_cast<const u64*>(f.occ + (i >> 7));
-  const u32 o = i & 127u, wsel = o >> 6, bit = o & 63u;
-  const u64 p0 = line[2 + wsel], p1 = line[4 + wsel], p2 = line[6 + wsel];
-  return (u32)((p0 >> bit) & 1u) | ((u32)((p1 >> bit) & 1u) << 1) | ((u32)((p2 >> bit) & 1u) << 2);
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // Verify: one lane per hit.
 struct VerifyArgs {
@@ -2848,11 +2751,7 @@ struct VerifyArgs {
   u32 stride;
   u32* ops;          // [nhits * ops_per_hit] compact alignment description (ALN_OP_NONE = unused)
   u32 ops_per_hit;   // the batch's largest effective distance
-  u32 debug;              // DICEY_DBG_VERIFY (measurements: 1 = skip the alignments, 2 = skip the context reads — wrong results; 4 = check the
-                          // index-derived context characters against the text and fail the batch on a difference)
-  const u32* sai;         // [nhits] suffix-array index of each hit (SAI_NONE = unknown), nullptr = not recorded
-  const Sel* sel;         // kept strings (Sel::bref -> bounds)
-  const u32* bounds;      // k_sel_bounds' brackets, eight words per string
+  u32 debug;              // DICEY_DBG_VERIFY (measurements only: 1 = skip the alignments, 2 = skip the context reads; results are wrong)
 };
 
 // SMALL = true (all queries of the batch <= 32 nt): the DP row lives in registers (columns fully unrolled) and each
@@ -3424,6 +3323,10 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
   const u64 base = (u64)blockIdx.x * NH;
   if (base >= nh) return;
   const u32 tid = threadIdx.x;
+  __shared__ u64 s_cum[512];
+  const bool cum_in_lds = CH > 1 && a.nseq <= 512;
+  if (cum_in_lds)
+    for (u32 i = tid; i < a.nseq; i += 256) s_cum[i] = a.cum[i];
   constexpr bool SHARE = CH > 1;  // CH == 1: no table, every hit is aligned by its own lane (batches with a handful of hits per query)
   if (SHARE)
     for (u32 i = tid; i < HCAP; i += 256) hkey[i] = EMPTY;
@@ -3443,7 +3346,6 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
 #pragma unroll
   for (int j = 0; j < CH; ++j) dq[j] = b.indel ? b.qdist[sd[j].qs >> 1] : 0u;
   u32 fl[CH];  // context bytes: left of the string at bits 0-15 (nearest first), right of it at bits 16-31
-  u32 ctx_fault = 0;
 #pragma unroll
   for (int j = 0; j < CH; ++j) {
     const u64 h = base + (u32)j * 256u + tid;
@@ -3451,31 +3353,10 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     const u32 d = dq[j];
     u32 x = 0;
     if (h < nh && !(a.debug & 2u)) {
-      bool from_text = true;
-      u32 xi = 0;
-      if (SHARE && DS == 1 && d == 1 && a.sai) {  // both characters from the index (k_sel_bounds), when the string has its brackets
-        const u32 si = a.sai[h];
-        const u32 br = si != SAI_NONE ? a.sel[sd[j].sel].bref : 0xFFFFFFFFu;
-        if (br != 0xFFFFFFFFu) {
-          const uint4 b0 = *reinterpret_cast<const uint4*>(a.bounds + (u64)br * 8), b1 = *reinterpret_cast<const uint4*>(a.bounds + (u64)br * 8 + 4);
-          const u32 post = (si >= b0.x && si < b0.y) ? 'A' : (si >= b0.z && si < b0.w) ? 'C' : (si >= b1.x && si < b1.y) ? 'G'
-                           : (si >= b1.z && si < b1.w) ? 'T' : 0u;
-          const u32 code = bwt_code_at(f, si);
-          const u32 pre = code < 4 ? ((0x54474341u >> (8 * code)) & 255u) : code == 4 ? 'N' : code == 5 ? '\n' : 0u;
-          if (post && (code <= 6)) {
-            xi = (loc >= 1 ? pre : 0u) | (post << 16);  // code 6: the hit starts the text, nothing in front of it
-            from_text = false;
-          }
-        }
-      }
-      if (from_text || (a.debug & 4u)) {
-        if (d >= 1 && loc >= 1) x |= (u32)f.text[loc - 1];
-        if (DS >= 2 && d >= 2 && loc >= 2) x |= (u32)f.text[loc - 2] << 8;
-        if (d >= 1 && endp + 1 <= f.n) x |= (u32)f.text[endp] << 16;
-        if (DS >= 2 && d >= 2 && endp + 2 <= f.n) x |= (u32)f.text[endp + 1] << 24;
-        if (!from_text && x != xi) ctx_fault = 1;
-      }
-      if (!from_text) x = xi;
+      if (d >= 1 && loc >= 1) x |= (u32)f.text[loc - 1];
+      if (DS >= 2 && d >= 2 && loc >= 2) x |= (u32)f.text[loc - 2] << 8;
+      if (d >= 1 && endp + 1 <= f.n) x |= (u32)f.text[endp] << 16;
+      if (DS >= 2 && d >= 2 && endp + 2 <= f.n) x |= (u32)f.text[endp + 1] << 24;
     }
     fl[j] = x;
   }
@@ -3492,15 +3373,24 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     if (h >= nh) continue;
     const u64 loc = sd[j].pos, endp = loc + sd[j].len;
     const u32 d = dq[j];
-    // hunter.h:358-362: text position -> (refIndex, chrpos)
+    // hunter.h:358-362: text position -> (refIndex, chrpos); the sequence starts sit in LDS when there are at most 512 of them
+    // (GRCh38: 194; the table is filled in front of the barrier the hash table needs anyway)
     u32 lo_r = 0, hi_r = a.nseq - 1;
-    while (lo_r < hi_r) {
-      const u32 mid = (lo_r + hi_r + 1) >> 1;
-      if (a.cum[mid] <= loc) lo_r = mid;
-      else hi_r = mid - 1;
+    if (cum_in_lds) {
+      while (lo_r < hi_r) {
+        const u32 mid = (lo_r + hi_r + 1) >> 1;
+        if (s_cum[mid] <= loc) lo_r = mid;
+        else hi_r = mid - 1;
+      }
+    } else {
+      while (lo_r < hi_r) {
+        const u32 mid = (lo_r + hi_r + 1) >> 1;
+        if (a.cum[mid] <= loc) lo_r = mid;
+        else hi_r = mid - 1;
+      }
     }
     ref[j] = lo_r;
-    u32 chrpos = (u32)(loc - a.cum[lo_r]);
+    u32 chrpos = (u32)(loc - (cum_in_lds ? s_cum[lo_r] : a.cum[lo_r]));
     // hunter.h:363-378: <= d context characters either side, clipped to the text, cut at sequence separators
     u32 pre = d, post = d;
     if (pre > loc) pre = (u32)loc;
@@ -3579,7 +3469,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
       if (DS > 1) cls_ops[c * DS + 1] = r.op[1];
     }
   }
-  if (fault || ctx_fault) s_fault = 1;
+  if (fault) s_fault = 1;
   __syncthreads();
   if (s_fault) {  // never observed; fail the batch loudly rather than hand out a wrong alignment
     if (tid == 0) atomicOr(&ctr->overflow, 2u);
@@ -3787,6 +3677,32 @@ __global__ void k_rows_to_ops(VerifyArgs a, Counters* ctr) {
   }
   for (u32 i = nops; i < a.ops_per_hit; ++i) a.ops[h * a.ops_per_hit + i] = ALN_OP_NONE;
   if (nops > a.ops_per_hit) atomicOr(&ctr->overflow, 2u);  // more edit columns than the distance allows: fail the batch loudly
+}
+
+// Fetched results leave the device as ONE block: this kernel lays the pieces (hit offsets, query offsets, the three per-query
+// arrays, normalised queries, hits, operation words) out behind each other exactly as the host block holds them, and one copy
+// follows (r03: six copies of 0.8-4.7 MB each paid their own start-up, 0.39 ms per 100 000 queries for 10 MB).
+struct PackArgs {
+  const u32* src[6];
+  u64 dst_word[6];  // offset in the block, in 32-bit words
+  u64 nwords[6];    // hits / ops: capacity; the kernel stops at the batch's hit count
+  const u64* nhits;
+  u32 hit_words, op_words;  // words per hit in segments 4 and 5
+};
+__global__ void __launch_bounds__(256) k_pack_results(PackArgs a, u32* dst) {
+  const u64 nh = *a.nhits;
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    u64 n = a.nwords[s];
+    if (t < n) {
+      if (s == 4) n = nh * a.hit_words < n ? nh * a.hit_words : n;
+      if (s == 5) n = nh * a.op_words < n ? nh * a.op_words : n;
+      if (t < n && a.src[s]) dst[a.dst_word[s] + t] = a.src[s][t];
+      return;
+    }
+    t -= n;
+  }
 }
 
 static double ev_ms(hipEvent_t a, hipEvent_t b) {
@@ -4244,18 +4160,29 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     }
   } spec;
   u64 spec_cap = 0;
-  auto queue_fetch = [&](PinnedBlock* pb, u64 capn, u64 ncopy) -> int {
+  auto queue_fetch = [&](PinnedBlock* pb, u64 capn) -> int {
     const FetchLayout L = fetch_layout(capn);
-    u8* hb = (u8*)pb->p;
-    DG_HIP(hipMemcpyAsync(hb + L.o_hit_off, ws[WS_GRP].as<u8>() + (ngrp + 1) * 8, (nq + 1) * 8, hipMemcpyDeviceToHost, st));  // hit_off
-    DG_HIP(hipMemcpyAsync(hb + L.o_meta, ws[WS_QMETA].as<u32>() + nq, 3 * (u64)nq * 4, hipMemcpyDeviceToHost, st));  // qdist, qflags, qnondna lie in this order
-    if (ncopy) {
-      DG_HIP(hipMemcpyAsync(hb + L.o_hits, ws[WS_HITS].p, ncopy * sizeof(dg_hit), hipMemcpyDeviceToHost, st));
-      if (ops_per_hit) DG_HIP(hipMemcpyAsync(hb + L.o_ops, ws[WS_OPS].p, ncopy * (u64)ops_per_hit * 4, hipMemcpyDeviceToHost, st));
+    DG_TRY(ws[WS_PACK].reserve(L.bytes + 64));
+    PackArgs pa;
+    const u32* srcs[6] = {reinterpret_cast<const u32*>(ws[WS_GRP].as<u8>() + (ngrp + 1) * 8),  // hit_off
+                          h_qoff ? nullptr : reinterpret_cast<const u32*>(d_qoff),               // the host has its own copy
+                          ws[WS_QMETA].as<u32>() + nq,                                           // qdist, qflags, qnondna lie in this order
+                          ws[WS_QSEQ].as<u32>(), ws[WS_HITS].as<u32>(), ws[WS_OPS].as<u32>()};
+    const u64 offs[6] = {L.o_hit_off, L.o_qoff, L.o_meta, L.o_qseq, L.o_hits, L.o_ops};
+    const u64 words[6] = {(nq + 1) * 2, (nq + 1) * 2, 3 * (u64)nq, (total + 3) / 4, capn * (sizeof(dg_hit) / 4), capn * (u64)ops_per_hit};
+    u64 all = 0;
+    for (int k = 0; k < 6; ++k) {
+      pa.src[k] = srcs[k];
+      pa.dst_word[k] = offs[k] / 4;
+      pa.nwords[k] = words[k];
+      all += words[k];
     }
-    if (total) DG_HIP(hipMemcpyAsync(hb + L.o_qseq, ws[WS_QSEQ].p, total, hipMemcpyDeviceToHost, st));
-    if (h_qoff) std::memcpy(hb + L.o_qoff, h_qoff, (nq + 1) * 8);
-    else DG_HIP(hipMemcpyAsync(hb + L.o_qoff, d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (!ops_per_hit) pa.src[5] = nullptr;
+    pa.nhits = (const u64*)(ws[WS_GRP].as<u8>() + (ngrp + 1) * 8) + nq;  // hit_off[nq]
+    pa.hit_words = (u32)(sizeof(dg_hit) / 4);
+    pa.op_words = ops_per_hit;
+    hipLaunchKernelGGL(k_pack_results, dim3(ceil_div(all, 256)), dim3(256), 0, st, pa, ws[WS_PACK].as<u32>());
+    DG_HIP(hipMemcpyAsync(pb->p, ws[WS_PACK].p, L.bytes, hipMemcpyDeviceToHost, st));
     return DG_OK;
   };
   for (int attempt = 0;; ++attempt) {
@@ -4278,8 +4205,6 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     Sel* const sel_gen = sel_all + flat_slots;  // the generic path's slots: grp_off based, behind the flat region
     DG_TRY(ws[WS_SCR].reserve((leaf_slots + 1) * 5 + 64));
     DG_TRY(ws[WS_SEEDS].reserve((hit_cap + 1) * sizeof(HitSeed)));
-    DG_TRY(ws[WS_SAI].reserve((hit_cap + 1) * 4 + 64));
-    const u32* d_bounds_used = nullptr;
     if (b.fastK && std::getenv("DICEY_FLAT1_SPLIT")) DG_TRY(ws[WS_MISC].reserve(((u64)NSHARD << surv_cap_log2) * 4 + 64));
     u32 surv_cap = 0xFFFFFFFFu;  // set where the survivor queue is used
     DG_TRY(ws[WS_JOBS].reserve(2 * std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
@@ -4428,35 +4353,20 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       // the record that shares a kept string's slot names its group: the packed leaf (qs behind 28 bytes) or the grouped leaf (qs first)
       const u8* slot_qs = packed ? (const u8*)ws[WS_LEAFG].p + offsetof(PLeaf, qs) : (const u8*)ws[WS_LEAFG].p + offsetof(Leaf, qs);
       const u32 slot_stride = packed ? (u32)sizeof(PLeaf) : (u32)sizeof(Leaf);
-      // context bounds (k_sel_bounds): edit distance 1 through the banded verify only; jobs + eight words per string in WS_BOUNDS
-      const bool no_bounds = std::getenv("DICEY_NO_CTX_BOUNDS") != nullptr;
-      BoundsJobs bjs;
-      bjs.cap = (u32)std::min<u64>(flat_slots + leaf_slots, 1u << 18);
-      bjs.count = (u32*)&ctr->pad_[7];
-      bjs.jobs = nullptr;
-      u32* d_bounds = nullptr;
-      if (band_verify && indel && dmax_eff == 1 && !no_bounds && !no_block) {
-        DG_TRY(ws[WS_BOUNDS].reserve((u64)bjs.cap * (sizeof(BoundsJob) + 32) + 64));
-        bjs.jobs = ws[WS_BOUNDS].as<BoundsJob>();
-        d_bounds = reinterpret_cast<u32*>(ws[WS_BOUNDS].as<u8>() + (u64)bjs.cap * sizeof(BoundsJob));
-      }
-      d_bounds_used = d_bounds;
       hipLaunchKernelGGL(k_locate, dim3(ceil_div(flat_slots + (generic_on ? leaf_slots : 0), TB)), dim3(TB), 0, st, ix->view, (const Sel*)sel_all, slot_qs,
                          slot_stride, (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj,
-                         flat_slots, flat_cap, (u32)generic_on, ws[WS_SAI].as<u32>(), sel_all, bjs, (const u32*)b.qdist, (u32)indel);
-      if (bjs.jobs)
-        hipLaunchKernelGGL(k_sel_bounds, dim3(1024), dim3(256), 0, st, ix->view, (const BoundsJob*)bjs.jobs, (const u32*)bjs.count, bjs.cap, d_bounds);
+                         flat_slots, flat_cap, (u32)generic_on);
       if (!no_block) {
         hipLaunchKernelGGL(k_locate_small, dim3(8192), dim3(64), 0, st, ix->view, (const BigJob*)lj.small, (const u32*)lj.n_small, job_cap,
-                           ws[WS_SEEDS].as<HitSeed>(), ws[WS_SAI].as<u32>(), ctr);
+                           ws[WS_SEEDS].as<HitSeed>(), ctr);
         // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
         const bool topk = ix->view.nlev > 1;
         if (topk)
           hipLaunchKernelGGL(k_locate_topk, dim3(768), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
-                             (u32*)&ctr->pad_[3], ws[WS_SEEDS].as<HitSeed>(), ws[WS_SAI].as<u32>(), ctr);
+                             (u32*)&ctr->pad_[3], ws[WS_SEEDS].as<HitSeed>(), ctr);
         if (!topk || p->max_locations > TOPK_KMAX)
           hipLaunchKernelGGL(k_locate_big, dim3(1024), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
-                             ws[WS_SEEDS].as<HitSeed>(), ws[WS_SAI].as<u32>(), ctr, topk ? TOPK_KMAX : 0u);
+                             ws[WS_SEEDS].as<HitSeed>(), ctr, topk ? TOPK_KMAX : 0u);
       }
     }
     DG_HIP(hipEventRecord(ix->ev[6], st));
@@ -4477,9 +4387,6 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       va.ops_per_hit = ops_per_hit;
       const u32 dbg_verify = std::getenv("DICEY_DBG_VERIFY") ? (u32)std::atoi(std::getenv("DICEY_DBG_VERIFY")) : 0u;  // read per batch: tests switch the check on
       va.debug = dbg_verify;
-      va.sai = d_bounds_used ? ws[WS_SAI].as<u32>() : nullptr;
-      va.sel = sel_all;
-      va.bounds = d_bounds_used;
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
@@ -4541,7 +4448,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         spec.pb = pinned_pool().get(fetch_layout(capn).bytes);
         spec_cap = capn;
       }
-      if (spec.pb) DG_TRY(queue_fetch(spec.pb, capn, capn));
+      if (spec.pb) DG_TRY(queue_fetch(spec.pb, capn));
     }
     DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
     DG_HIP(hipGetLastError());
@@ -4624,13 +4531,14 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         return fail(DG_ENOMEM, "cannot allocate %llu bytes of pinned host memory for the results", (unsigned long long)fetch_layout(capn).bytes);
       }
       R->owner_ = pb;  // released with the result on the error paths below
-      DG_TRY(queue_fetch(pb, capn, nhits));
+      DG_TRY(queue_fetch(pb, capn));
       DG_HIP(hipStreamSynchronize(st));
       DG_HIP(hipGetLastError());
     }
     R->owner_ = pb;
     const FetchLayout L = fetch_layout(capn);
     u8* hb = (u8*)pb->p;
+    if (h_qoff) std::memcpy(hb + L.o_qoff, h_qoff, (nq + 1) * 8);
     R->hit_off = (uint64_t*)(hb + L.o_hit_off);
     R->qoff = (uint64_t*)(hb + L.o_qoff);
     R->hits = (dg_hit*)(hb + L.o_hits);
@@ -4767,9 +4675,25 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
   DG_HIP(hipSetDevice(ix->device));
   DG_TRY(ix->ws[WS_QB].reserve(total + 8));
   DG_TRY(ix->ws[WS_QOFF].reserve((nq + 1) * 8));
-  if (total) DG_HIP(hipMemcpyAsync(ix->ws[WS_QB].p, qbytes, total, hipMemcpyHostToDevice, ix->stream));
-  DG_HIP(hipMemcpyAsync(ix->ws[WS_QOFF].p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
-  int rc = run_batch(ix, p, seqlen, nseq, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, 1, out, nullptr, nullptr, qbytes, qoff);
+  // the queries go up through a pinned block of the pool: copies from pageable memory are staged by the runtime one by one and
+  // held up the other handle's stream as well (r03: 3.8 ms per batch with two batches in flight)
+  const u64 o_off = (total + 63) & ~63ull;
+  PinnedBlock* stage = pinned_pool().get(o_off + (nq + 1) * 8 + 64);
+  if (stage) {
+    if (total) std::memcpy(stage->p, qbytes, total);
+    std::memcpy((u8*)stage->p + o_off, qoff, (nq + 1) * 8);
+  }
+  const void* src_q = stage ? stage->p : (const void*)qbytes;
+  const void* src_o = stage ? (const void*)((u8*)stage->p + o_off) : (const void*)qoff;
+  int rc = DG_OK;
+  if (total && hipMemcpyAsync(ix->ws[WS_QB].p, src_q, total, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = fail(DG_EHIP, "dg_hunt: query upload failed");
+  if (rc == DG_OK && hipMemcpyAsync(ix->ws[WS_QOFF].p, src_o, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess)
+    rc = fail(DG_EHIP, "dg_hunt: offset upload failed");
+  if (rc == DG_OK) rc = run_batch(ix, p, seqlen, nseq, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, 1, out, nullptr, nullptr, qbytes, qoff);
+  if (stage) {
+    (void)hipStreamSynchronize(ix->stream);  // (run_batch has synchronised already unless it failed early)
+    pinned_pool().put(stage);
+  }
   if (rc != DG_OK && *out) {
     dg_hunt_result_free(*out);
     *out = nullptr;

@@ -115,37 +115,3 @@ def test_topk_locate_million_copy_family(tmp_path):
             assert got == want[:m]
             assert all(h.score == 0 and h.refalign == unit and h.queryalign == unit for h in hits)
 
-
-def test_context_characters_from_the_index_equal_the_text(tmp_path, monkeypatch):
-    """Edit distance 1, strings with hundreds of hits: the character in front of a hit comes from the BWT at the hit's suffix-array
-    index, the one behind it from the brackets k_sel_bounds finds inside the string's interval.  DICEY_DBG_VERIFY=4 makes the
-    kernel read the text as well and fail the batch on any difference; the hits are compared with the checker besides.  Context
-    taken from every class: the four bases, N, other IUPAC letters, sequence ends on either side, the first position of the text."""
-    import dicey_amd
-    rng = random.Random(909)
-    unit = "".join(rng.choice("ACGT") for _ in range(20))
-    other = unit[:7] + ("A" if unit[7] != "A" else "G") + unit[8:]
-    seqs = []
-    for c in range(3):
-        parts = [unit] if c == 0 else []  # a copy at text position 0
-        for i in range(1500):
-            parts.append("".join(rng.choice("ACGT") for _ in range(rng.randint(3, 40))))
-            parts.append(rng.choice("ACGTACGTACGTNNRYKM"))
-            parts.append(unit if rng.random() < 0.8 else other)
-            parts.append(rng.choice("ACGTACGTACGTNNRYSW"))
-        parts.append(unit)  # a copy that ends its sequence
-        seqs.append("".join(parts))
-    path, g = _index(tmp_path, seqs, "ctx.fm9")
-    orc = O.Index(path)
-    qs = [unit, other, unit[1:] + "A", "C" + unit[:19], seqs[1][100:120]]
-    with dicey_amd.FmIndex(path) as ix:
-        for check in ("4", None):
-            if check:
-                monkeypatch.setenv("DICEY_DBG_VERIFY", check)
-            else:
-                monkeypatch.delenv("DICEY_DBG_VERIFY")
-            for kw in (dict(distance=1, max_locations=1000), dict(distance=1, max_locations=5000), dict(distance=1, max_locations=300, forward_only=True)):
-                got = _compare(ix, orc, g, qs, **kw)
-                assert len(got.queries[0].hits) >= 300
-        monkeypatch.setenv("DICEY_NO_CTX_BOUNDS", "1")  # the text route alone gives the same
-        _compare(ix, orc, g, qs, distance=1, max_locations=1000)

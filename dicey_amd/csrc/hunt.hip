@@ -3060,6 +3060,7 @@ DG_DEV u32 aln_op(u32 col, u32 kind, u32 byte) { return (col & 0xFFFFu) | (kind 
 struct AlnRes {
   u32 info;  // (score & 255) | leading query-gap columns << 8 | kept columns << 16
   u32 op[2];
+  u32 pre_eff;  // context characters in front of the string that survived the '\n' trimming (the lane-per-hit path needs it for hunter.h:382)
 };
 
 template <int WB, typename TR>
@@ -3124,6 +3125,7 @@ DG_DEV AlnRes band_align(const FmView& f, const Batch& b, const HitSeed sd, TR* 
     if (gw_at((u32)pre + mlen + i) == '\n') break;
     post_eff = i + 1;
   }
+  res.pre_eff = pre_eff;
   const u32 skip = (u32)pre - pre_eff;         // genomicseq starts at byte `skip` of the maximal window
   const u32 mg = pre_eff + mlen + post_eff;    // rows
   // genomicseq from byte 0 (gsh), the query codes with 7 = "outside" behind the last character (qwm); both also in LDS
@@ -3352,7 +3354,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     const u64 loc = sd[j].pos, endp = loc + sd[j].len;
     const u32 d = dq[j];
     u32 x = 0;
-    if (h < nh && !(a.debug & 2u)) {
+    if (SHARE && h < nh && !(a.debug & 2u)) {  // (the lane-per-hit path takes its context from the window band_align loads anyway)
       if (d >= 1 && loc >= 1) x |= (u32)f.text[loc - 1];
       if (DS >= 2 && d >= 2 && loc >= 2) x |= (u32)f.text[loc - 2] << 8;
       if (d >= 1 && endp + 1 <= f.n) x |= (u32)f.text[endp] << 16;
@@ -3409,7 +3411,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
         qb |= ch2 << (8 * i);
       }
     }
-    if (pre_eff < chrpos) chrpos -= pre_eff;  // hunter.h:382 (strict <)
+    if (SHARE && pre_eff < chrpos) chrpos -= pre_eff;  // hunter.h:382 (strict <); lane-per-hit path: behind its alignment, below
     cpos[j] = chrpos;
     wbytes += pre + sd[j].len + post;
     const u32 local = (u32)j * 256u + tid;
@@ -3455,6 +3457,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     cls[0] = tid;
     if (base + tid < nh && !(a.debug & 1u)) {
       const AlnRes r = band_align<WB, TR>(f, b, sd[0], tr, lds_g, fault);
+      if (r.pre_eff < cpos[0]) cpos[0] -= r.pre_eff;  // hunter.h:382 (strict <)
       cls_info[tid] = r.info;
       cls_ops[tid * DS] = r.op[0];
       if (DS > 1) cls_ops[tid * DS + 1] = r.op[1];

@@ -433,6 +433,15 @@ def test_fused_select_and_its_hand_over_to_the_generic_kernels(small_genome, mon
                        (pure[:200], dict(distance=1, hamming=True)), (low, dict(distance=1)), (mixed, dict(distance=1, hamming=True)),
                        (pure[:100], dict(distance=1, max_locations=2)), (pure[:64], dict(distance=1, forward_only=True))]:
             _compare(ix, orc, g, qs, **kw)
+        # edit distance 2: k_search2p settles the select stage of its group the same way (one workgroup per group)
+        O.fast_neighbors(True)
+        try:
+            short = [q[:m] for q, m in zip(pure[:48], [14, 16, 18, 20] * 12)]
+            for qs2 in (short, short[:10] + ["ACGTNACGTACGTACG", g["seqs"][1][50:90]] + short[10:20], low[:5]):
+                _compare(ix, orc, g, qs2, distance=2)
+            _compare(ix, orc, g, short[:24], distance=2, max_locations=3)
+        finally:
+            O.fast_neighbors(False)
         # count mode (padlock.h:396-421) goes through the same kept strings
         rc = lambda q: q[::-1].translate(str.maketrans("ACGT", "TGCA"))
         for q, (gf, gr) in zip(pure[:40], ix.neighborhood_count([q.encode() for q in pure[:40]], distance=1)):

@@ -250,6 +250,33 @@ def host_cpu_info():
     return model, (len(cores) or (os.cpu_count() or 1))
 
 
+def thal_counter_block(cfg, kernel, thal_calls, stage_ms):
+    """k_site_wave against the fp64 vector peak and the LDS: instruction counters of the committed PMC pass
+    on this workload (tools/prof_thal.sh -> profiles/r03_thal_counters.json), scaled to this run's thal() count and stage time.
+    fp64 FLOP/s is an UPPER bound (every lane of every fp64 wavefront instruction counted as active; an FMA as two)."""
+    try:
+        tc = json.load(open(os.path.join(ROOT, "profiles", "r03_thal_counters.json")))[cfg]
+        k = [v for n, v in tc["kernels"].items() if kernel in n][0]
+        ref_calls = tc["bench"]["site_stage"]["thal_calls_per_step"]
+    except Exception:
+        return None
+    if not thal_calls or not stage_ms:
+        return None
+    scale = thal_calls / ref_calls
+    f64 = (k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_TRANS_F64"]) * scale
+    flops = (k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + 2 * k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_TRANS_F64"]) * 64 * scale
+    t = stage_ms * 1e-3
+    valu_peak = 256 * 4 * 2.4e9 / 4  # wavefront instructions per second: 1 024 SIMDs, one wave64 instruction per four cycles
+    return {"source": "profiles/r03_thal_counters.json (rocprofv3 --pmc on this workload), scaled by thal() calls",
+            "fp64_wave_instructions_per_thal": f64 / thal_calls, "valu_wave_instructions_per_thal": k["SQ_INSTS_VALU"] * scale / thal_calls,
+            "lds_wave_instructions_per_thal": k["SQ_INSTS_LDS"] * scale / thal_calls,
+            "fp64_TFLOPs_upper_bound": flops / t / 1e12, "fp64_vector_peak_TFLOPs": 78.6, "fp64_frac_upper_bound": flops / t / 78.6e12,
+            "valu_issue_frac": k["SQ_INSTS_VALU"] * scale / t / valu_peak,
+            "lds_bank_conflict_cycles_over_active": k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"],
+            "note": "the kernel issues VALU instructions at about two thirds of the chip's rate, one in nine of them fp64: bound by "
+                    "instruction issue of the loop-candidate evaluation (compares, selects, address arithmetic), not by the fp64 units"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -737,11 +764,12 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "k_search1<true> (FM search of the 15-mer neighbourhoods)", "achieved": achieved,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                              "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ms_fm,
-                             "note": "the step is dominated by k_site_wave (one wavefront per located hit: f64 thal() DP in LDS), which is bound by "
-                                     "fp64 VALU issue and LDS latency — neither the HBM nor the MFMA roofline applies to it; see site_stage"},
+                             "note": "the step is dominated by k_site_wave (one wavefront per located hit: f64 thal() DP in LDS); site_stage.fp64_and_lds "
+                                     "places it against the fp64 vector peak, the VALU issue rate and the LDS"},
                 "site_stage": {"kernel": "k_site_wave", "ms": mean("ms_site"), "thal_calls_per_step": mean("nhits"),
                                "thal_per_s": mean("nhits") / (mean("ms_site") * 1e-3) if mean("ms_site") > 0 else 0.0,
-                               "binding_sites_per_step": mean("nsites")},
+                               "binding_sites_per_step": mean("nsites"),
+                               "fp64_and_lds": thal_counter_block("search", "k_site_wave", mean("nhits"), mean("ms_site"))},
                 "cpu_baseline": cpu,
                 "phases_ms": {"ms_device": mean("ms_device"), "ms_fm_search": ms_fm, "ms_site_stage": mean("ms_site")},
             })

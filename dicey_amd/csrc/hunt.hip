@@ -174,11 +174,11 @@ __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n
     if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
     if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
     b.ginfo[2 * q + strand] = gi;
-    generic += (gi.m != 0 && !(gi.d_win & (512u | 1024u)));
+    generic += (gi.m != 0 && !(gi.d_win & 512u));
   }
   // groups the flat distance-1 kernel does not take: the host launches the generic kernels for them (and repeats a batch it
   // started without, run_batch).  A flag, not a count: every lane that has one stores the same 1.
-  if (generic && (b.fastK || b.fast2K)) *n_generic = 1u;
+  if (generic && b.fastK) *n_generic = 1u;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1234,16 +1234,7 @@ DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... ho
   p2 = (u32)a + 1;
   p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
 }
-// FUSED (r03): the workgroup owns its group anyway, so the strings that occur stay in an LDS list (512 entries) and the select stage
-// — duplicates, substring-minimal filter, std::set order — is settled here like in k_search1s; kept strings go to the flat Sel
-// region.  A group with more strings than the list holds spills to the generic leaf buffer (list first) and takes the generic
-// kernels.
-template <bool FUSED>
-__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o, FlatSel fs, u32 lcap) {
-  __shared__ unsigned long long l_key[FUSED ? FUSED_LCAP : 1];
-  __shared__ u32 l_lo[FUSED ? FUSED_LCAP : 1], l_hi[FUSED ? FUSED_LCAP : 1], l_w1[FUSED ? FUSED_LCAP : 1], l_w2[FUSED ? FUSED_LCAP : 1];
-  __shared__ u16 l_meta[FUSED ? FUSED_LCAP : 1];  // length | alive << 15
-  __shared__ u32 l_n, s_alive, s_base;
+__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o) {
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
   // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
@@ -1257,11 +1248,7 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
   const u32 m = raw.z, d_win = raw.w;
   if (!m || !(d_win & 1024u)) return;  // uniform for the workgroup
   const u64 qpk = (u64)raw.y << 32 | raw.x;
-  if (threadIdx.x == 0) {
-    g_slots = 0;
-    l_n = 0;
-    s_alive = 0;
-  }
+  if (threadIdx.x == 0) g_slots = 0;
   __syncthreads();
   const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
   const u64 kmask = (1ULL << (2 * K)) - 1, mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
@@ -1348,8 +1335,7 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
       if (e0 + (threadIdx.x & ~63u) >= qn) break;  // wavefront without work
       const u32 e = e0 + threadIdx.x;
       bool leaf = false;
-      u32 lo = 0, hi = 0, w1 = 0, w2 = 0, l2k = 0;
-      u64 s2k = 0;
+      u32 lo = 0, hi = 0, w1 = 0, w2 = 0;
       if (e < qn) {
         // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
         u32 L = 0;
@@ -1380,27 +1366,12 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
           ++steps;
         }
         leaf = lo < hi;
-        s2k = s2;
-        l2k = l2;
       }
-      u32 lat = 0xFFFFFFFFu;
-      if (FUSED && leaf) {
-        lat = atomicAdd(&l_n, 1u);
-        if (lat < lcap) {
-          l_key[lat] = s2k;
-          l_lo[lat] = lo;
-          l_hi[lat] = hi;
-          l_w1[lat] = w1;
-          l_w2[lat] = w2;
-          l_meta[lat] = (u16)l2k;
-        }
-      }
-      const bool spill = leaf && (!FUSED || lat >= lcap);  // straight to the generic leaf buffer
-      const unsigned long long lm = __ballot(spill);
+      const unsigned long long lm = __ballot(leaf);
       u32 lbase = 0;
       if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
       lbase = __shfl(lbase, 0);
-      if (spill) {
+      if (leaf) {
         const u32 slot = atomicAdd(&g_slots, 1u);
         const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
         if (la < o.shard_cap) {
@@ -1429,87 +1400,7 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
     if (nprobe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nprobe);
   }
-  if (!FUSED) {
-    if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
-    return;
-  }
-  __syncthreads();
-  const u32 nl = l_n;
-  if (nl > lcap) {  // the list overflowed: its entries follow the spilled ones into the generic leaf buffer, the group stays generic
-    for (u32 i = threadIdx.x; i < lcap; i += 256) {
-      const u32 la = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
-      const u32 slot = atomicAdd(&g_slots, 1u);
-      if (la < o.shard_cap) {
-        Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
-        lf->qs = gid;
-        lf->slot = slot;
-        lf->lo = l_lo[i];
-        lf->hi = l_hi[i];
-        lf->nops = 2;
-        lf->ops[0] = l_w1[i];
-        lf->ops[1] = l_w2[i];
-#pragma unroll
-        for (int k = 2; k < (int)DMAX; ++k) lf->ops[k] = 0u;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
-    return;
-  }
-  // alive: no other string of the group is a proper substring; of equal strings the first of the list stays (neighbors.h:29-45)
-  for (u32 i = threadIdx.x; i < nl; i += 256) {
-    const u32 alen = l_meta[i] & 63u;
-    const u64 a = l_key[i];
-    bool ok = true;
-    for (u32 x = 0; x < nl && ok; ++x) {
-      if (x == i) continue;
-      const u32 xlen = l_meta[x] & 63u;
-      if (xlen > alen) continue;
-      const u64 xk = l_key[x], xm = xlen >= 32 ? ~0ULL : ((1ULL << (2 * xlen)) - 1);
-      bool hit = false;
-      for (u32 sh = 0; sh <= alen - xlen; ++sh) hit = hit || (((a >> (2 * sh)) & xm) == xk);
-      if (hit) ok = (xlen == alen) && (i < x);
-    }
-    if (ok) {
-      l_meta[i] = (u16)(alen | 0x8000u);
-      atomicAdd(&s_alive, 1u);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) s_base = s_alive ? atomicAdd(&o.ctr->sel_cnt[shard], s_alive) : 0u;
-  __syncthreads();
-  const u32 wbase = s_base, na = s_alive;
-  const bool room = wbase + na <= fs.cap;
-  if (!room && threadIdx.x == 0) atomicOr(&o.ctr->overflow, 1u);
-  if (threadIdx.x == 0 && nl) atomicAdd(&o.ctr->fused_leaves[shard], (unsigned long long)nl);
-  for (u32 i = threadIdx.x; i < nl; i += 256) {
-    const u32 meta = l_meta[i];
-    if (!(meta & 0x8000u)) continue;
-    const u32 alen = meta & 63u;
-    const u64 ak = l_key[i] << (64 - 2 * alen);
-    u32 r = 0;
-    for (u32 x = 0; x < nl; ++x) {
-      const u32 xm = l_meta[x];
-      if (x == i || !(xm & 0x8000u)) continue;
-      const u32 xlen = xm & 63u;
-      const u64 xk = l_key[x] << (64 - 2 * xlen);
-      r += (xk < ak) || (xk == ak && xlen < alen);
-    }
-    if (room) {
-      Sel sv;
-      sv.lo = l_lo[i];
-      sv.hi = l_hi[i];
-      sv.len = alen;
-      sv.take = 0;
-      sv.hbase = 0;
-      sv.g = gid;
-      fs.sel[(u64)shard * fs.cap + wbase + r] = sv;
-    }
-  }
-  if (threadIdx.x == 0) {
-    fs.nsel[gid] = room ? na : 0u;
-    fs.selbase[gid] = shard * fs.cap + wbase;
-  }
+  if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
 }
 
 template <bool INDEL, int D>
@@ -4306,7 +4197,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     // when the previous batch of this handle had work for them; a batch that turns out to need them after all is repeated.
     static const bool no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr || std::getenv("DICEY_FLAT1_PER_OP") != nullptr ||
                                 std::getenv("DICEY_FLAT1_SPLIT") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
-    const bool fused = (b.fastK || b.fast2K) && packed && !no_fuse && !(b.fast2K && std::getenv("DICEY_FLAT2_PER_OP")) && !(b.fast2K && std::getenv("DICEY_NO_FUSED_SELECT2"));
+    const bool fused = b.fastK && packed && !no_fuse;
     const u32 flat_cap = fused ? shard_cap : 0u;
     const u64 flat_slots = (u64)NSHARD * flat_cap;
     const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
@@ -4386,16 +4277,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (b.fast2K) {  // edit distance 2: one workgroup per (query, strand) for every query that qualifies
         static const bool per_op = std::getenv("DICEY_FLAT2_PER_OP") != nullptr;  // the lane-per-operation-pair form (A/B runs)
         if (per_op) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2<4>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
-        else {
-          FlatSel fs;
-          fs.sel = sel_all;
-          fs.cap = flat_cap;
-          fs.selbase = selbase;
-          fs.nsel = nsel;
-          static const u32 lcap2 = std::getenv("DICEY_FUSED_LCAP") ? std::min<u32>(FUSED_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP"))) : FUSED_LCAP;
-          if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, fs, lcap2);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, fs, 0u);
-        }
+        else hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       if (generic_on) {

@@ -433,13 +433,12 @@ def test_fused_select_and_its_hand_over_to_the_generic_kernels(small_genome, mon
                        (pure[:200], dict(distance=1, hamming=True)), (low, dict(distance=1)), (mixed, dict(distance=1, hamming=True)),
                        (pure[:100], dict(distance=1, max_locations=2)), (pure[:64], dict(distance=1, forward_only=True))]:
             _compare(ix, orc, g, qs, **kw)
-        # edit distance 2: k_search2p settles the select stage of its group the same way (one workgroup per group)
+        # edit distance 2 on the same handle (generic select kernels; r03 measured the select stage inside k_search2p as well:
+        # 10.9 ms against 8.3 + 2.4 ms, no gain, removed)
         O.fast_neighbors(True)
         try:
-            short = [q[:m] for q, m in zip(pure[:48], [14, 16, 18, 20] * 12)]
-            for qs2 in (short, short[:10] + ["ACGTNACGTACGTACG", g["seqs"][1][50:90]] + short[10:20], low[:5]):
-                _compare(ix, orc, g, qs2, distance=2)
-            _compare(ix, orc, g, short[:24], distance=2, max_locations=3)
+            short = [q[:m] for q, m in zip(pure[:24], [14, 16, 18, 20] * 6)]
+            _compare(ix, orc, g, short + ["ACGTNACGTACGTACG"], distance=2)
         finally:
             O.fast_neighbors(False)
         # count mode (padlock.h:396-421) goes through the same kept strings

@@ -569,11 +569,18 @@ def main():
             probe_n = 100 if distance < 2 else 2
             dt, _, _ = orc.hunt_timed(seqlen, qstr[:probe_n], threads=1, distance=distance)
             per = max(dt / probe_n, 1e-6)
-            ns = int(min(nq, max(probe_n, a.cpu_seconds / per)))
-            dt, octr, _ = orc.hunt_timed(seqlen, qstr[:ns], threads=1, distance=distance)
+            # three repeats of a third of the budget each, median reported (r02: one run, 25 % spread between lines)
+            ns = int(min(nq, max(probe_n, a.cpu_seconds / 3.0 / per)))
+            runs = []
+            for _ in range(3 if distance < 2 else 1):
+                dt, octr, _ = orc.hunt_timed(seqlen, qstr[:ns], threads=1, distance=distance)
+                runs.append(dt)
+            dt = sorted(runs)[len(runs) // 2]
             cpu = {"value": ns / dt, "unit": "primers/s", "cores": 1, "kind": "port",
                    "sample": f"first {ns} of the {nq} bench queries, oracle hunt_one (restated hunter.h:291-444) on 1 host thread, "
-                             f"{dt:.1f} s, index load excluded", "host_cpus": os.cpu_count(), "host_physical_cores": phys_cores,
+                             f"median of {len(runs)} runs ({', '.join('%.2f' % x for x in runs)} s), index load excluded",
+                   "runs_primers_per_s": [ns / x for x in runs],
+                   "host_cpus": os.cpu_count(), "host_physical_cores": phys_cores,
                    "cpu_model": cpu_model, "oracle_ops": octr}
             # the same loop on every physical core over query shards (the reference itself has no threads)
             if phys_cores > 1:

@@ -2531,11 +2531,11 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs
 //   entries     the select is carried on to the exact k-th value, the k survivors are sorted (bitonic) and written.
 // Reads: at most the top level's blocks (<= 9 232) and 8 * KCAP + 14 words per level below, whatever the interval holds.
 static constexpr u32 TOPK_KCAP = 1152;         // blocks kept per level: k plus slack, so that one histogram pass usually decides
-static constexpr u32 TOPK_VMAX = 8 * TOPK_KCAP + 16;
 static constexpr u32 TOPK_PAD = 0xFFFFFFFFu;
-struct TopkLds {
-  u32 val[TOPK_VMAX];
-  u32 cidx[2][TOPK_KCAP];
+template <u32 KC>
+struct TopkLdsT {
+  u32 val[8 * KC + 16];
+  u32 cidx[2][KC];
   u32 eidx[16];
   u32 hist[256];
   u32 wsum[4];
@@ -2592,7 +2592,8 @@ DG_DEV void block_sort4(T* xbuf, u32 n2, T (&v)[4]) {
   }
 }
 // threshold T with k <= #(val <= T) <= limit (k <= limit < nv; limit == k: the exact k-th smallest).  All 256 lanes call it.
-DG_DEV u32 topk_threshold(TopkLds& S, u32 nv, u32 k, u32 limit) {
+template <class LDS>
+DG_DEV u32 topk_threshold(LDS& S, u32 nv, u32 k, u32 limit) {
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32 prefix = 0, mask = 0, kk = k - 1, below = 0;
   for (int shift = 24;; shift -= 8) {
@@ -2627,9 +2628,15 @@ DG_DEV u32 topk_threshold(TopkLds& S, u32 nv, u32 k, u32 limit) {
     kk -= ex;
   }
 }
+// KC = TOPK_KCAP: any interval (walks the hierarchy).  KC = TOPK_KCAP_MID (r03): intervals that fit the smaller buffer whole (level 0
+// only, no expansion) — 24 instead of 46 KB of LDS, six instead of three workgroups per CU; on the repeats genome two thirds of the
+// 17 000 jobs of a step are of that kind.  Both walk the same job list and skip what belongs to the other (occ_lo < occs <= occ_hi).
+static constexpr u32 TOPK_KCAP_MID = 576;
+template <u32 KC>
 __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, u32* next_job,
-                                                     HitSeed* seeds, Counters* ctr) {
-  __shared__ TopkLds S;
+                                                     HitSeed* seeds, Counters* ctr, u32 occ_lo, u32 occ_hi) {
+  constexpr u32 VMAXT = 8 * KC + 16;
+  __shared__ TopkLdsT<KC> S;
   const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
   const u32 lane = threadIdx.x & 63;
   u64 reads = 0;
@@ -2642,7 +2649,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
     const u32 jb = S.job;
     if (jb >= njobs) break;
     const BigJob J = jobs[jb];
-    if (J.take > TOPK_KMAX) continue;  // k_locate_big's
+    if (J.take > TOPK_KMAX || J.occs <= occ_lo || J.occs > occ_hi) continue;  // k_locate_big's / the other buffer size's
     const u32 k = J.take;
     const u64 lo = J.lo, hi = (u64)J.lo + J.occs;
     // full blocks of level j inside [lo, hi): [A(j), B(j))
@@ -2650,8 +2657,8 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
     auto B = [&](int j) -> u64 { return hi >> (3 * j); };
     auto N = [&](int j) -> u64 { return B(j) > A(j) ? B(j) - A(j) : 0ULL; };
     int L = 0;
-    while (L + 1 < (int)f.nlev && N(L) > TOPK_VMAX - 16) ++L;  // a level left with more than 9 216 blocks has > 1 000 in the next
-    if (N(L) > TOPK_VMAX - 16) continue;  // cannot happen: the top level of FmView::samin holds <= 64 blocks
+    while (L + 1 < (int)f.nlev && N(L) > VMAXT - 16) ++L;  // a level left with more than 9 216 blocks has > 1 000 in the next
+    if (N(L) > VMAXT - 16) continue;  // cannot happen: the top level of FmView::samin holds <= 64 blocks
     u32 nv = (u32)N(L);
     {
       const u32* src = f.samin[L] + A(L);
@@ -2665,7 +2672,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
     for (int j = L;; --j) {
       // at the entries: up to 96 values more than asked for may survive (the sort drops them) — an exact k-th value costs the
       // radix select all four byte passes, a little slack usually ends it after two
-      const u32 limit = j == 0 ? (k + 96 < TOPK_KMAX ? k + 96 : (k > TOPK_KMAX ? k : TOPK_KMAX)) : TOPK_KCAP;
+      const u32 limit = j == 0 ? (k + 96 < TOPK_KMAX ? k + 96 : (k > TOPK_KMAX ? k : TOPK_KMAX)) : KC;
       const u32 T = nv > limit ? topk_threshold(S, nv, k, limit) : 0xFFFFFFFEu;
       if (threadIdx.x == 0) S.n_kept = 0;
       __syncthreads();
@@ -3362,7 +3369,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     }
     fl[j] = x;
   }
-  __syncthreads();  // the table is clear
+  if (SHARE) __syncthreads();  // the table is clear (the lane-per-hit path has no barrier at all: its lanes share nothing)
   u32 ref[CH], cpos[CH], slot[CH];
   bool won[CH];
   u64 wbytes = 0;
@@ -3448,7 +3455,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     for (int j = 0; j < CH; ++j) cls[j] = hval[slot[j]];
     ncls = s_ncls;
   }
-  __syncthreads();  // the table's memory becomes the trace
+  if (SHARE) __syncthreads();  // the table's memory becomes the trace
   // ---- phase 2: per class
   TR* const tr = reinterpret_cast<TR*>(u_lds) + tid;
   u8* const lds_g = u_lds + rows * 256 * sizeof(TR) + tid * 72;
@@ -3472,10 +3479,15 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
       if (DS > 1) cls_ops[c * DS + 1] = r.op[1];
     }
   }
-  if (fault) s_fault = 1;
-  __syncthreads();
-  if (s_fault) {  // never observed; fail the batch loudly rather than hand out a wrong alignment
-    if (tid == 0) atomicOr(&ctr->overflow, 2u);
+  if (SHARE) {
+    if (fault) s_fault = 1;
+    __syncthreads();
+    if (s_fault) {  // never observed; fail the batch loudly rather than hand out a wrong alignment
+      if (tid == 0) atomicOr(&ctr->overflow, 2u);
+      return;
+    }
+  } else if (fault) {
+    atomicOr(&ctr->overflow, 2u);
     return;
   }
   // ---- phase 3: per hit
@@ -4365,8 +4377,17 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
         const bool topk = ix->view.nlev > 1;
         if (topk)
-          hipLaunchKernelGGL(k_locate_topk, dim3(768), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
-                             (u32*)&ctr->pad_[3], ws[WS_SEEDS].as<HitSeed>(), ctr);
+        {
+          static const bool one_size = std::getenv("DICEY_TOPK_ONE_SIZE") != nullptr;
+          // intervals up to 4 608 entries: the small-buffer form — launched when the previous batch of this handle had enough
+          // repeat-rich strings to fill the chip (an empty launch is 4 us of a 350 us step otherwise)
+          const u32 mid_max = (one_size || ix->jobs_big_hint < 2048) ? 0u : 8 * TOPK_KCAP_MID;
+          if (mid_max)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_locate_topk<TOPK_KCAP_MID>), dim3(1536), dim3(256), 0, st, ix->view, (const BigJob*)lj.big,
+                               (const u32*)lj.n_big, job_cap, (u32*)&ctr->pad_[8], ws[WS_SEEDS].as<HitSeed>(), ctr, 0u, mid_max);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_locate_topk<TOPK_KCAP>), dim3(768), dim3(256), 0, st, ix->view, (const BigJob*)lj.big,
+                             (const u32*)lj.n_big, job_cap, (u32*)&ctr->pad_[3], ws[WS_SEEDS].as<HitSeed>(), ctr, mid_max, 0xFFFFFFFFu);
+        }
         if (!topk || p->max_locations > TOPK_KMAX)
           hipLaunchKernelGGL(k_locate_big, dim3(1024), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
                              ws[WS_SEEDS].as<HitSeed>(), ctr, topk ? TOPK_KMAX : 0u);
@@ -4401,7 +4422,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         // (distance 2 on an i.i.d. genome: 59 hits per query from ~50 strings — nothing to share, and the wider trace of 13 diagonals
         //  leaves room for fewer workgroups: r03 measured 2.39 ms with 8 hits per lane against 1.83 ms for the lane-per-hit kernel)
         const u64 share_at = dmax_eff > 1 ? 192 : 24;
-        const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= share_at ? 8 : (per_q >= share_at / 3 ? 4 : 1));
+        const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= share_at ? 8 : (per_q >= share_at / 2 ? 4 : 1));
         const u32 rows = maxlen + 3 * dmax_eff + 2;
         const bool wide = dmax_eff > 1;
         const u32 nw_bytes = rows * 256 * (wide ? 4u : 2u) + 256 * 72, hash_bytes = 2u * 256u * (u32)ch * 10u;
@@ -4503,6 +4524,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     break;
   }
   ix->shard_cap_hint = shard_cap;
+  ix->jobs_big_hint = hsum.jobs_big;
   if (b.fastK) ix->surv_cap_log2_hint = surv_cap_log2;
   ix->hit_cap_hint = std::max<u64>(ix->hit_cap_hint, nhits + nhits / 4 + 1024);
   if (group_counts) {

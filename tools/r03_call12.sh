@@ -17,6 +17,6 @@ for l in open("gpurun_out/r03n/bench.json"):
         print("default:", round(d["value"]), d["ms_per_step"], {k: round(v, 4) for k, v in d["phases_ms"].items()}, d.get("parity_sample"))
         print(" d2h:", d.get("value_with_d2h"), "\n h2h:", d.get("host_to_host_pipelined"), "\n cli:", (d.get("cli_end_to_end") or {}).get("value"), (d.get("cli_end_to_end_after_release") or {}).get("value"))
         print(" cpu:", (d.get("cpu_baseline") or {}).get("value"), (d.get("cpu_baseline_parallel") or {}).get("value"))
-        for k, v in (d.get("extra_configs") or {}).items():
+        for k, v in ((kk, vv) for kk, vv in (d.get("extra_configs") or {}).items() if isinstance(vv, dict)):
             print(k, {a: v.get(a) for a in ("value", "unit", "ms_per_step", "phases_ms", "parity_sample", "error", "wall_s")})
 PY

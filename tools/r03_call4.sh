@@ -14,6 +14,6 @@ for l in open("gpurun_out/r03f/bench.json"):
     if l.startswith("{"):
         d = json.loads(l)
         print("default:", d["value"], d["ms_per_step"], d["phases_ms"], d.get("parity_sample"))
-        for k, v in (d.get("extra_configs") or {}).items():
+        for k, v in ((kk, vv) for kk, vv in (d.get("extra_configs") or {}).items() if isinstance(vv, dict)):
             print(k, {a: v.get(a) for a in ("value", "unit", "ms_per_step", "phases_ms", "parity_sample", "error", "wall_s")})
 PY

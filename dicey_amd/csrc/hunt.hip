@@ -4372,16 +4372,18 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
                          slot_stride, (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj,
                          flat_slots, flat_cap, (u32)generic_on);
       if (!no_block) {
-        hipLaunchKernelGGL(k_locate_small, dim3(8192), dim3(64), 0, st, ix->view, (const BigJob*)lj.small, (const u32*)lj.n_small, job_cap,
-                           ws[WS_SEEDS].as<HitSeed>(), ctr);
         // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
         const bool topk = ix->view.nlev > 1;
-        if (topk)
-        {
-          static const bool one_size = std::getenv("DICEY_TOPK_ONE_SIZE") != nullptr;
-          // intervals up to 4 608 entries: the small-buffer form — launched when the previous batch of this handle had enough
-          // repeat-rich strings to fill the chip (an empty launch is 4 us of a 350 us step otherwise)
-          const u32 mid_max = (one_size || ix->jobs_big_hint < 2048) ? 0u : 8 * TOPK_KCAP_MID;
+        static const bool one_size = std::getenv("DICEY_TOPK_ONE_SIZE") != nullptr;
+        // A batch with thousands of repeat-rich strings (the previous batch of this handle tells): intervals up to 4 608 entries go
+        // to the small-buffer form of k_locate_topk.  (r03 also ran the three job kernels side by side on helper streams: each
+        // slowed down by what the others took — 114 / 220 / 228 us alone, 220 / 494 / 268 us together — and the stage gained
+        // 0.08 of 0.91 ms; not worth two more streams per handle.)
+        const bool rich = topk && !one_size && ix->jobs_big_hint >= 2048;
+        const u32 mid_max = rich ? 8 * TOPK_KCAP_MID : 0u;
+        hipLaunchKernelGGL(k_locate_small, dim3(8192), dim3(64), 0, st, ix->view, (const BigJob*)lj.small, (const u32*)lj.n_small, job_cap,
+                           ws[WS_SEEDS].as<HitSeed>(), ctr);
+        if (topk) {
           if (mid_max)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_locate_topk<TOPK_KCAP_MID>), dim3(1536), dim3(256), 0, st, ix->view, (const BigJob*)lj.big,
                                (const u32*)lj.n_big, job_cap, (u32*)&ctr->pad_[8], ws[WS_SEEDS].as<HitSeed>(), ctr, 0u, mid_max);

@@ -736,6 +736,7 @@ dg_index::~dg_index() {
   for (auto& w : ws) w.release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
+
   if (pinned) (void)hipHostFree(pinned);
   if (stream) (void)hipStreamDestroy(stream);
 }

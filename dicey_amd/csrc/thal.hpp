@@ -10,7 +10,7 @@
 #pragma once
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(DG_HOSTEMU)
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define DG_HD __host__ __device__ inline
 #else

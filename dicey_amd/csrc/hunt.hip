@@ -2297,7 +2297,7 @@ DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out,
 // each naming its group); slots behind it: the generic path's (grp_off based; only when generic_on).
 __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const u8* slot_qs, u32 slot_stride, const u64* grp_off, const u32* nsel,
                                                 u64 ngroups, const u64* hit_off, HitSeed* seeds, Counters* ctr, u64 hit_cap, LocJobs jobs,
-                                                u64 flat_slots, u32 flat_cap, u32 generic_on) {
+                                                u64 flat_slots, u32 flat_cap, u32 generic_on, u32 jobs_on) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
   u64 reads = 0;
@@ -2357,6 +2357,9 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
   for (u32 which = 1; which <= 2; ++which) {
     const unsigned long long mk = __ballot(queue == which);
     if (!mk) continue;
+    // the job kernels were left out of this attempt: nobody will write these strings' hits, so the verify kernel must not run
+    // (the host sees the job counts and repeats the batch with the job kernels)
+    if (!jobs_on && lane == (u32)__ffsll((long long)mk) - 1u) atomicOr(&ctr->overflow, 4u);
     u32 base = 0;
     if (lane == (u32)__ffsll((long long)mk) - 1u) base = atomicAdd(which == 1 ? jobs.n_small : jobs.n_big, (u32)__popcll(mk));
     base = __shfl(base, (int)__ffsll((long long)mk) - 1);
@@ -4148,7 +4151,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   if (std::getenv("DICEY_DEBUG_CAPS")) surv_cap_log2 = 1;
   u64 nleaf = 0, nhits = 0;
-  bool force_generic = false;
+  bool force_generic = false, force_jobs = false;
   // Fetched results: one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh
   // hipHostMalloc per batch costs more than the copies), laid out for `capn` hits:
   // [hit_off | qoff | qdistance qflags qnondna | qseq | hits | ops].  When the previous fetched batch on this handle tells how many
@@ -4213,6 +4216,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     const u32 flat_cap = fused ? shard_cap : 0u;
     const u64 flat_slots = (u64)NSHARD * flat_cap;
     const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
+    bool jobs_on = false;
     DG_TRY(ws[WS_LEAF].reserve(leaf_slots * sizeof(Leaf)));
     DG_TRY(ws[WS_LEAFG].reserve((leaf_slots + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
     DG_TRY(ws[WS_SEL].reserve((flat_slots + leaf_slots + 1) * sizeof(Sel)));
@@ -4370,8 +4374,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       const u32 slot_stride = packed ? (u32)sizeof(PLeaf) : (u32)sizeof(Leaf);
       hipLaunchKernelGGL(k_locate, dim3(ceil_div(flat_slots + (generic_on ? leaf_slots : 0), TB)), dim3(TB), 0, st, ix->view, (const Sel*)sel_all, slot_qs,
                          slot_stride, (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj,
-                         flat_slots, flat_cap, (u32)generic_on);
-      if (!no_block) {
+                         flat_slots, flat_cap, (u32)generic_on, (u32)(no_block || ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX));
+      // The job kernels (strings of more than 16 occurrences) are launched when the previous batch of this handle queued any job;
+      // k_locate queues and counts whether or not they run, and a batch that had jobs after one that had none is repeated with
+      // them (the same device as for capacity guesses).  Uniform batches on a genome without repeats never launch them.
+      jobs_on = !no_block && (ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX);
+      if (jobs_on) {
         // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
         const bool topk = ix->view.nlev > 1;
         static const bool one_size = std::getenv("DICEY_TOPK_ONE_SIZE") != nullptr;
@@ -4513,12 +4521,18 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       force_generic = true;
       continue;
     }
+    if (!jobs_on && !group_counts && !std::getenv("DICEY_NO_BLOCK_LOCATE") && (hsum.jobs_small > 0 || hsum.jobs_big > 0)) {  // strings were queued and nobody served them
+      ix->jobs_hint = true;
+      force_jobs = true;
+      continue;
+    }
     const u32 worst = (u32)std::max<unsigned long long>(hsum.worst_shard, fused ? hsum.worst_sel : 0ULL);  // leaf regions and flat Sel slices share one capacity
     if (worst > shard_cap) {
       shard_cap = worst + worst / 4 + 64;
       continue;
     }
     if (fused) ix->generic_hint = hsum.nleaf > 0 || hsum.n_generic > 0 || nxs > 0;
+    if (!group_counts) ix->jobs_hint = hsum.jobs_small > 0 || hsum.jobs_big > 0;
     if (nhits > hit_cap) {
       hit_cap = nhits + nhits / 4 + 1024;
       continue;

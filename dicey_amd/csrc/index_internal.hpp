@@ -20,6 +20,7 @@ struct dg_index {
   uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
   uint64_t hit_cap_hint = 0;
   bool generic_hint = true;      // the previous distance-1 batch had work for the kernels outside k_search1s (hunt.hip run_batch)
+  bool jobs_hint = true;         // the previous batch queued strings for the locate job kernels
   uint64_t jobs_big_hint = 0;    // repeat-rich strings (workgroup locate jobs) of the previous batch
   uint64_t fetch_hits_hint = 0;  // hits of the previous fetched batch (+3 %): this many are copied to the host before the batch's synchronisation
   uint32_t surv_cap_log2_hint = 0;  // survivor-queue capacity per shard (log2) that was enough for the previous batch

@@ -115,3 +115,18 @@ def test_topk_locate_million_copy_family(tmp_path):
             assert got == want[:m]
             assert all(h.score == 0 and h.refalign == unit and h.queryalign == unit for h in hits)
 
+
+
+def test_job_kernels_come_back_after_a_batch_without_repeat_rich_strings(tmp_path):
+    """The locate job kernels are left out when the previous batch of the handle queued no job; a batch that then needs them is
+    repeated with them (and until then the verify kernel must not touch hit slots nobody wrote)."""
+    import dicey_amd
+    unit, seqs = _planted(5, 3000, 400_000, divergent=0.1)
+    path, g = _index(tmp_path, seqs, "hint.fm9")
+    orc = O.Index(path)
+    rng = random.Random(12)
+    plain = ["".join(rng.choice("ACGT") for _ in range(20)) for _ in range(64)]  # random 20-mers: at most a stray hit, no job
+    rich = [unit, unit[1:] + "A", seqs[1][777:797]]
+    with dicey_amd.FmIndex(path) as ix:
+        for qs in (plain, rich, plain, plain, rich, rich):
+            _compare(ix, orc, g, qs, distance=1, max_locations=1000)

@@ -4699,8 +4699,10 @@ int dg_hunt_rows(dg_hunt_result* r) {
   return DG_OK;
 }
 
-int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
-            const uint64_t* qoff, size_t nq, dg_hunt_result** out) {
+// dg_hunt's body.  prestaged != nullptr: the queries already lie in that pinned block (bytes at 0, offsets at (total + 63) & ~63 —
+// dg_hunt_submit copied them there once, and qbytes / qoff point into it).
+static int hunt_host(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
+                     const uint64_t* qoff, size_t nq, dg_hunt_result** out, PinnedBlock* prestaged) {
   if (!ix || !p || !seqlen || !qoff || !out || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_hunt: null argument");
   *out = nullptr;
   if (!nq) return fail(DG_EINVAL, "dg_hunt: empty batch");
@@ -4719,8 +4721,8 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
   // the queries go up through a pinned block of the pool: copies from pageable memory are staged by the runtime one by one and
   // held up the other handle's stream as well (r03: 3.8 ms per batch with two batches in flight)
   const u64 o_off = (total + 63) & ~63ull;
-  PinnedBlock* stage = pinned_pool().get(o_off + (nq + 1) * 8 + 64);
-  if (stage) {
+  PinnedBlock* stage = prestaged ? prestaged : pinned_pool().get(o_off + (nq + 1) * 8 + 64);
+  if (stage && !prestaged) {
     if (total) std::memcpy(stage->p, qbytes, total);
     std::memcpy((u8*)stage->p + o_off, qoff, (nq + 1) * 8);
   }
@@ -4733,13 +4735,18 @@ int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint3
   if (rc == DG_OK) rc = run_batch(ix, p, seqlen, nseq, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, nq, total, maxlen, 1, out, nullptr, nullptr, qbytes, qoff);
   if (stage) {
     (void)hipStreamSynchronize(ix->stream);  // (run_batch has synchronised already unless it failed early)
-    pinned_pool().put(stage);
+    if (!prestaged) pinned_pool().put(stage);
   }
   if (rc != DG_OK && *out) {
     dg_hunt_result_free(*out);
     *out = nullptr;
   }
   return rc;
+}
+
+int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
+            const uint64_t* qoff, size_t nq, dg_hunt_result** out) {
+  return hunt_host(ix, p, seqlen, nseq, qbytes, qoff, nq, out, nullptr);
 }
 
 // Asynchronous form of dg_hunt (ABI 4).  The batch is driven by the handle's helper thread (created at the first submit, alive
@@ -4751,8 +4758,9 @@ struct dg_hunt_ticket {
   dg_index* ix = nullptr;
   dg_hunt_params p;
   std::vector<uint32_t> seqlen;
-  std::vector<uint8_t> qbytes;
-  std::vector<uint64_t> qoff;
+  PinnedBlock* stage = nullptr;  // the queries, copied once at submit: bytes at 0, offsets at off_at
+  uint64_t off_at = 0;
+  size_t nq = 0;
   int rc = DG_OK;
   std::string err;
   dg_hunt_result* res = nullptr;
@@ -4774,7 +4782,8 @@ struct dg_index::Worker {
         t = job;
         job = nullptr;
       }
-      t->rc = dg_hunt(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), t->qbytes.data(), t->qoff.data(), t->qoff.size() - 1, &t->res);
+      t->rc = hunt_host(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), (const uint8_t*)t->stage->p,
+                        (const uint64_t*)((const uint8_t*)t->stage->p + t->off_at), t->nq, &t->res, t->stage);
       if (t->rc != DG_OK) t->err = dg_last_error();  // the message is thread-local: carried over to the waiting thread
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -4808,8 +4817,16 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     t->ix = ix;
     t->p = *p;
     t->seqlen.assign(seqlen, seqlen + nseq);
-    t->qoff.assign(qoff, qoff + nq + 1);
-    t->qbytes.assign(qbytes, qbytes + qoff[nq]);  // the caller's buffers are free again when this call returns
+    t->nq = nq;
+    t->off_at = (qoff[nq] + 63) & ~63ull;
+    t->stage = pinned_pool().get(t->off_at + (nq + 1) * 8 + 64);  // the caller's buffers are free again when this call returns
+    if (!t->stage) {
+      delete t;
+      ix->busy.store(false);
+      return fail(DG_ENOMEM, "dg_hunt_submit: no pinned memory for %llu query bytes", (unsigned long long)qoff[nq]);
+    }
+    if (qoff[nq]) std::memcpy(t->stage->p, qbytes, qoff[nq]);
+    std::memcpy((uint8_t*)t->stage->p + t->off_at, qoff, (nq + 1) * 8);
     if (!ix->worker) {
       ix->worker = new dg_index::Worker;
       ix->worker->th = std::thread([w = ix->worker] { w->loop(); });
@@ -4820,6 +4837,7 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     }
     ix->worker->cv.notify_all();
   } catch (const std::exception& e) {
+    if (t && t->stage) pinned_pool().put(t->stage);
     delete t;
     ix->busy.store(false);
     return fail(DG_ENOMEM, "dg_hunt_submit: %s", e.what());
@@ -4839,6 +4857,7 @@ int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out) {
   *out = t->res;
   const int rc = t->rc;
   const std::string err = t->err;
+  if (t->stage) pinned_pool().put(t->stage);
   delete t;
   if (rc != DG_OK) return fail(rc, "%s", err.c_str());
   return DG_OK;

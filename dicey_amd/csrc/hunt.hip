@@ -4204,7 +4204,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     return DG_OK;
   };
   for (int attempt = 0;; ++attempt) {
-    if (attempt > 4) return fail(DG_ENOMEM, "buffer overflow persists (%llu leaves, %llu hits)", (unsigned long long)nleaf, (unsigned long long)nhits);
+    if (attempt > 8) return fail(DG_ENOMEM, "buffer overflow persists (%llu leaves, %llu hits)", (unsigned long long)nleaf, (unsigned long long)nhits);
     const u64 leaf_slots = (u64)NSHARD * shard_cap;
 
     // Distance 1, every string in 128 bits: k_search1s settles the select stage inside the search kernel (flat Sel region of
@@ -4510,33 +4510,36 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     }
     nleaf = hsum.nleaf;
     nhits = hsum.nhits;
+    // Everything this attempt found wanting is put right before the batch is repeated (one repeat usually serves several causes).
+    bool again = false;
     if (surv_cap != 0xFFFFFFFFu && hsum.worst_surv > surv_cap) {
       while (surv_cap_log2 < 30 && (1ull << surv_cap_log2) < hsum.worst_surv + hsum.worst_surv / 4) ++surv_cap_log2;
-      continue;
+      again = true;
     }
     // the generic kernels were left out, and the batch had work for them after all (queries with N, longer than 31 nt, a workgroup
     // of k_search1s whose strings did not fit its LDS list): once more, with them
     if (fused && !generic_on && (hsum.nleaf > 0 || hsum.n_generic > 0)) {
       ix->generic_hint = true;
       force_generic = true;
-      continue;
+      again = true;
     }
     if (!jobs_on && !group_counts && !std::getenv("DICEY_NO_BLOCK_LOCATE") && (hsum.jobs_small > 0 || hsum.jobs_big > 0)) {  // strings were queued and nobody served them
       ix->jobs_hint = true;
       force_jobs = true;
-      continue;
+      again = true;
     }
     const u32 worst = (u32)std::max<unsigned long long>(hsum.worst_shard, fused ? hsum.worst_sel : 0ULL);  // leaf regions and flat Sel slices share one capacity
     if (worst > shard_cap) {
       shard_cap = worst + worst / 4 + 64;
-      continue;
+      again = true;
     }
+    if (!(hsum.overflow & 1) && nhits > hit_cap) {  // (after a buffer overflow the hit count is not this batch's)
+      hit_cap = nhits + nhits / 4 + 1024;
+      again = true;
+    }
+    if (again) continue;
     if (fused) ix->generic_hint = hsum.nleaf > 0 || hsum.n_generic > 0 || nxs > 0;
     if (!group_counts) ix->jobs_hint = hsum.jobs_small > 0 || hsum.jobs_big > 0;
-    if (nhits > hit_cap) {
-      hit_cap = nhits + nhits / 4 + 1024;
-      continue;
-    }
     break;
   }
   ix->shard_cap_hint = shard_cap;

@@ -3893,7 +3893,7 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
   };
   unsigned nthreads = std::thread::hardware_concurrency();
   if (nthreads == 0) nthreads = 1;
-  nthreads = (unsigned)std::min<size_t>(std::min<unsigned>(nthreads, 64u), jobs.size() * 2);
+  nthreads = (unsigned)std::min<size_t>(std::min<unsigned>(nthreads, 256u), jobs.size() * 2);
   if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthreads = (unsigned)std::max(1, std::atoi(e));
   if (nthreads <= 1) work();
   else {

@@ -297,8 +297,8 @@ def main():
     ap.add_argument("--parity-queries", type=int, default=-1, help="size of the full-size parity sample (default 300; 1000 for hunt_d2)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default run only (hunt_d1, i.i.d. genome, N=1): skip the compact sub-lines of the other configurations "
-                         "(extra_configs: hunt_d1_repeats, hunt_d2, search, padlock), which are measured by re-running this script")
-    ap.add_argument("--extra-budget-s", type=float, default=210.0, help="wall-clock budget of the extra_configs block")
+                         "(extra_configs: hunt_d1_repeats, hunt_d2, hunt_d2_25mers, search, padlock), which are measured by re-running this script")
+    ap.add_argument("--extra-budget-s", type=float, default=240.0, help="wall-clock budget of the extra_configs block")
     ap.add_argument("--big-table", action="store_true",
                     help="open the index with DG_OPEN_BIG_TABLE (K-mer table one order larger: 199 GB instead of 90 GB resident on the "
                          "GRCh38-size genome, search kernel ~5 %% faster); the default is the library's default layout")
@@ -889,6 +889,10 @@ def run_extra_configs(a, fm9):
     t_start = time.time()
     plan = [("hunt_d1_repeats", ["--config", "hunt_d1", "--genome", "repeats", "--steps", "5", "--warmup", "2", "--cpu-seconds", "6", "--parity-queries", "300"], False),
             ("hunt_d2", ["--config", "hunt_d2", "--steps", "3", "--warmup", "1", "--cpu-seconds", "4", "--parity-queries", "150"], True),
+            # cap-prone primers: 25-mers at distance 2 — the maxNeighborhood cap can fire, so every strand is
+            # enumerated on the host in the reference's order first (nbhd_host.hpp) and searched as explicit patterns
+            ("hunt_d2_25mers", ["--config", "hunt_d2", "--qlen", "25", "--queries", "2000", "--steps", "1", "--warmup", "1", "--cpu-seconds", "6",
+                                "--parity-queries", "4"], True),
             ("search", ["--config", "search", "--steps", "2", "--warmup", "1", "--cpu-seconds", "6"], True),
             ("padlock", ["--config", "padlock", "--steps", "3", "--warmup", "1", "--cpu-seconds", "6"], True)]
     keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "roofline_search", "cpu_baseline", "parity_sample",

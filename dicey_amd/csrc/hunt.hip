@@ -3893,7 +3893,10 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
   };
   unsigned nthreads = std::thread::hardware_concurrency();
   if (nthreads == 0) nthreads = 1;
-  nthreads = (unsigned)std::min<size_t>(std::min<unsigned>(nthreads, 256u), jobs.size() * 2);
+  // 32 threads: the enumeration is a chain of hash probes in ~5 MB per strand, i.e. bound by cache misses — on 2 x EPYC 9575F
+  // (128 cores) a 25-mer strand at distance 2 takes 0.24 ms of wall time with 32 threads, 0.39 with 64, 0.49 with 256
+  // (tools/nbhd_scaling.py)
+  nthreads = (unsigned)std::min<size_t>(std::min<unsigned>(nthreads, 32u), jobs.size() * 2);
   if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthreads = (unsigned)std::max(1, std::atoi(e));
   if (nthreads <= 1) work();
   else {
@@ -3902,6 +3905,42 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
     for (auto& t : pool) t.join();
   }
   if (oom.load()) return fail(DG_ENOMEM, "out of host memory while enumerating capped neighbourhoods; pass fewer sequences per call");
+  // Second pass, in parallel as well: a query with ONE capped strand is off the kernel path altogether, so its other (silent)
+  // strand travels as explicit patterns too.  (r03: this ran inside the serial collection loop below — a third of the 25-mers at
+  // distance 2 fire on one strand only, and 2 000 of them took 3 s where the enumeration itself needs 0.4 s on 128 cores.)
+  {
+    std::vector<size_t> todo;
+    for (size_t k = 0; k < jobs.size(); ++k)
+      for (int strand = 0; strand < 2; ++strand)
+        if (!(strand && !reverse) && !jobs[k].fired[strand] && jobs[k].fired[strand ^ 1]) todo.push_back(2 * k + (size_t)strand);
+    std::atomic<size_t> nx{0};
+    auto work2 = [&]() {
+      for (;;) {
+        const size_t t = nx.fetch_add(1);
+        if (t >= todo.size() || oom.load()) return;
+        Job& j = jobs[todo[t] >> 1];
+        const int strand = (int)(todo[t] & 1);
+        try {
+          bool f2 = false;
+          for (const std::string& str : CappedNeighborhood::enumerate(strand ? j.rv : j.fw, j.d, indel, p->max_neighborhood, f2)) {
+            for (char ch : str) j.bytes[strand].push_back(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4);
+            j.lens[strand].push_back((u32)str.size());
+          }
+        } catch (const std::bad_alloc&) {
+          oom.store(1);
+          return;
+        }
+      }
+    };
+    const unsigned nt2 = (unsigned)std::min<size_t>(nthreads, todo.size());
+    if (nt2 <= 1) work2();
+    else {
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < nt2; ++t) pool.emplace_back(work2);
+      for (auto& t : pool) t.join();
+    }
+    if (oom.load()) return fail(DG_ENOMEM, "out of host memory while enumerating capped neighbourhoods; pass fewer sequences per call");
+  }
   try {
     cs.mode.assign(nq, (u8)QM_KERNEL);
     cs.xs_off.assign(1, 0);
@@ -3915,14 +3954,6 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
       cs.mode[j.q] = QM_EXPLICIT | QM_FIRED;
       for (int strand = 0; strand < 2; ++strand) {
         if (strand && !reverse) continue;
-        if (!j.fired[strand]) {
-          // the other strand fired: this one's (silent) set travels as explicit patterns too, the query is off the kernel path
-          bool f2 = false;
-          for (const std::string& str : CappedNeighborhood::enumerate(strand ? j.rv : j.fw, j.d, indel, p->max_neighborhood, f2)) {
-            for (char ch : str) j.bytes[strand].push_back(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4);
-            j.lens[strand].push_back((u32)str.size());
-          }
-        }
         cs.xs_bytes.insert(cs.xs_bytes.end(), j.bytes[strand].begin(), j.bytes[strand].end());
         for (u32 l : j.lens[strand]) {
           cs.xs_off.push_back(cs.xs_off.back() + l);

@@ -4170,9 +4170,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
 
   u32 shard_cap = std::max<u32>(ix->shard_cap_hint, (u32)std::max<u64>(64, (16 * (u64)nq + nxs / 8) / NSHARD));
   u64 hit_cap = std::max<u64>(ix->hit_cap_hint, 4 * (u64)nq + 1024);
+  // slices of the flat Sel region (k_search1s): what the previous batch's fullest slice needed plus a quarter — kept strings are a
+  // third of the leaf estimate above, and k_locate walks every slot of the region
+  u32 flat_req = ix->flat_cap_hint ? ix->flat_cap_hint : shard_cap;
   if (const char* e = std::getenv("DICEY_DEBUG_CAPS")) {  // tests: start from tiny capacities to exercise the retry path
     shard_cap = (u32)std::max(1, std::atoi(e));
     hit_cap = (u64)std::max(1, std::atoi(e));
+    flat_req = shard_cap;
   }
   // survivor queue of the distance-1 kernels: per shard, a power of two; ~6 survivors per strand on a 3.1 Gb genome
   u32 surv_cap_log2 = ix->surv_cap_log2_hint;
@@ -4244,7 +4248,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     static const bool no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr || std::getenv("DICEY_FLAT1_PER_OP") != nullptr ||
                                 std::getenv("DICEY_FLAT1_SPLIT") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
     const bool fused = b.fastK && packed && !no_fuse;
-    const u32 flat_cap = fused ? shard_cap : 0u;
+    const u32 flat_cap = fused ? flat_req : 0u;
     const u64 flat_slots = (u64)NSHARD * flat_cap;
     const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
     bool jobs_on = false;
@@ -4559,9 +4563,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       force_jobs = true;
       again = true;
     }
-    const u32 worst = (u32)std::max<unsigned long long>(hsum.worst_shard, fused ? hsum.worst_sel : 0ULL);  // leaf regions and flat Sel slices share one capacity
+    const u32 worst = (u32)hsum.worst_shard;
     if (worst > shard_cap) {
       shard_cap = worst + worst / 4 + 64;
+      again = true;
+    }
+    if (fused && hsum.worst_sel > flat_cap) {
+      flat_req = (u32)(hsum.worst_sel + hsum.worst_sel / 4 + 64);
       again = true;
     }
     if (!(hsum.overflow & 1) && nhits > hit_cap) {  // (after a buffer overflow the hit count is not this batch's)
@@ -4574,6 +4582,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     break;
   }
   ix->shard_cap_hint = shard_cap;
+  if (b.fastK && hsum.worst_sel) ix->flat_cap_hint = (u32)std::max<unsigned long long>(ix->flat_cap_hint, hsum.worst_sel + hsum.worst_sel / 4 + 64);
   ix->jobs_big_hint = hsum.jobs_big;
   if (b.fastK) ix->surv_cap_log2_hint = surv_cap_log2;
   ix->hit_cap_hint = std::max<u64>(ix->hit_cap_hint, nhits + nhits / 4 + 1024);

@@ -17,6 +17,7 @@ struct dg_index {
   static constexpr int NWS = 23;
   dg::DevBuf ws[NWS];
   hipEvent_t ev[9] = {nullptr};  // [8]: end of the flat distance-1 kernel
+  uint32_t flat_cap_hint = 0;   // slice capacity of the flat Sel region that was enough so far (hunt.hip)
   uint32_t shard_cap_hint = 0;  // capacities that were enough for the previous batch (hunt.hip)
   uint64_t hit_cap_hint = 0;
   bool generic_hint = true;      // the previous distance-1 batch had work for the kernels outside k_search1s (hunt.hip run_batch)

@@ -184,6 +184,36 @@ def synth_queries(text: torch.Tensor, nq: int, m: int, seed: int):
     return [bytes(qs[i].tobytes()) for i in order]
 
 
+def synth_query_batch(text: torch.Tensor, nq: int, m: int, seed: int) -> np.ndarray:
+    """The same mixture as synth_queries (80 % genome windows, half of them with one random substitution / deletion / insertion,
+    20 % uniform random), drawn with array operations: one call per batch of the rotating stream (r04).  Returns uint8 [nq, m]."""
+    rng = np.random.default_rng(seed)
+    n = text.numel()
+    n_genome = int(nq * 0.8)
+    rows = []
+    need = n_genome
+    while need > 0:
+        k = int(need * 1.3) + 16
+        pos = torch.from_numpy(rng.integers(0, n - m - 1, size=k)).to(text.device)
+        win = text[pos[:, None] + torch.arange(m + 1, device=text.device)[None, :]].cpu().numpy()
+        ok = np.all((win != 78) & (win != 10), axis=1)
+        rows.append(win[ok][:need])
+        need -= len(rows[-1])
+    win = np.concatenate(rows, axis=0)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    col = np.arange(m)[None, :]
+    k = rng.integers(0, m, size=n_genome)[:, None]
+    kind = rng.integers(0, 3, size=n_genome)[:, None]
+    kind = np.where((np.arange(n_genome) % 2 == 0)[:, None], kind, 3)      # every second window stays as it is
+    base = acgt[rng.integers(0, 4, size=n_genome)][:, None]
+    src = np.where(kind == 1, col + (col >= k), np.where(kind == 2, col - (col > k), col))  # deletion pulls the next genome base in
+    q = np.take_along_axis(win, src, axis=1)
+    q = np.where(((kind == 0) | (kind == 2)) & (col == k), base, q)
+    rnd = acgt[rng.integers(0, 4, size=(nq - n_genome, m))]
+    allq = np.concatenate([q, rnd], axis=0)
+    return np.ascontiguousarray(allq[rng.permutation(nq)])
+
+
 COMP = bytes.maketrans(b"ACGT", b"TGCA")
 
 
@@ -304,6 +334,10 @@ def main():
                          "GRCh38-size genome, search kernel ~5 %% faster); the default is the library's default layout")
     ap.add_argument("--fm9", default="", help="reuse an existing index file instead of building the synthetic one")
     ap.add_argument("--keep-index", action="store_true")
+    ap.add_argument("--batches", type=int, default=16,
+                    help="hunt configs: distinct query batches resident in HBM that the warm-up and timed steps cycle through (step k "
+                         "searches batch k mod B; hunter.h:291 searches every query once, so the headline never replays a batch within "
+                         "B launches); 1 = the replayed-batch run of r01-r03, which the default run still reports as value_same_batch")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="optional extra measurement after the timed region (hunt, N=1 only): the same steps with this many batches in "
                          "flight, one host thread + one handle on the shared index each (dg_index_share).  Off by default so that "
@@ -366,10 +400,12 @@ def main():
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
     fm9 = a.fm9 or os.path.join(shm, f"dicey_bench_{os.environ.get('MASTER_PORT', 'p')}_{a.genome}_{int(a.genome_size)}.fm9")
     meta_path = fm9 + f".{cfg}.{units}.meta.json"
+    batches_path = fm9 + f".{cfg}.{units}.q{a.qlen}.b{a.batches}.npy"
     t0 = time.time()
     info = {}
     host_text = None
-    if rank == 0 and not (a.fm9 and os.path.exists(meta_path)):
+    have_meta = os.path.exists(meta_path) and (cfg not in ("hunt_d1", "hunt_d2") or a.batches <= 1 or os.path.exists(batches_path))
+    if rank == 0 and not (a.fm9 and have_meta):
         text, lens = synth_genome(int(a.genome_size), 24, seed=1, device=dev, repeats=a.genome == "repeats")
         torch.cuda.synchronize()
         info["t_genome_s"] = time.time() - t0
@@ -383,6 +419,11 @@ def main():
             meta["queries"] = [[q.decode() for q in synth_queries(text, units, a.qlen, seed=qseed + r)] for r in range(world)]
             if os.environ.get("DICEY_BENCH_SORT"):  # experiment: queries in the order of their forward filter window (page locality)
                 meta["queries"] = [sorted(qs, key=lambda q: q[1:]) for qs in meta["queries"]]
+            # the other batches of the rotating stream (batch 0 is the list above, the r01-r03 batch): [world, B - 1, units, qlen]
+            if a.batches > 1:
+                more = np.stack([np.stack([synth_query_batch(text, units, a.qlen, seed=qseed + r + 1000 * b) for b in range(1, a.batches)])
+                                 for r in range(world)])
+                np.save(batches_path, more)
         elif cfg == "search":
             meta["primers"] = [synth_primer_pairs(text, units // 2, seed=qseed + 100 * r) for r in range(world)]
         else:
@@ -458,11 +499,24 @@ def main():
         d_q = torch.frombuffer(bytearray(qbytes), dtype=torch.uint8).to(dev)  # inputs resident in HBM
         d_off = torch.from_numpy(off.view(np.int64)).to(dev)
         p = _capi.HuntParams(distance, 0, 0, 1000, 10000)
+        # The stream of distinct batches (r04): B batches resident in HBM, each with its own bytes and offsets
+        # buffer; step k searches batch k mod B, warm-up included, so no batch recurs within B launches.
+        dev_batches = [(d_q, d_off, len(qbytes))]
+        if a.batches > 1:
+            more = np.load(batches_path, mmap_mode="r")
+            more = more[rank if rank < more.shape[0] else 0]
+            for bi in range(more.shape[0]):
+                arr = np.ascontiguousarray(more[bi])
+                dev_batches.append((torch.from_numpy(arr.reshape(-1).copy()).to(dev), torch.from_numpy(off.view(np.int64).copy()).to(dev),
+                                    int(arr.size)))
+        rot = {"k": 0, "on": True}
 
         def step(fetch=0, handle=None):
+            bq, bo, bbytes = dev_batches[rot["k"] % len(dev_batches)] if rot["on"] else dev_batches[0]
+            rot["k"] += 1
             rp = C.POINTER(_capi.HuntResult)()
-            _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(p), sl, len(seqlen), C.c_void_p(d_q.data_ptr()),
-                                            C.c_void_p(d_off.data_ptr()), nq, len(qbytes), fetch, C.byref(rp)))
+            _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(p), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
+                                            C.c_void_p(bo.data_ptr()), nq, bbytes, fetch, C.byref(rp)))
             R = rp.contents
             res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes,
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
@@ -479,6 +533,21 @@ def main():
 
         # ---------------- extras, outside the timed region (N=1): what delivery costs
         extras = {}
+        if world == 1 and len(dev_batches) > 1:
+            # the replayed-batch figure of r01-r03 beside the headline: the same K steps on batch 0 only (its lines stay in the caches)
+            rot["on"] = False
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            acc_same = [step() for _ in range(a.steps)]
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - tp
+            extras["value_same_batch"] = {"value": nq * a.steps / dts, "unit": "primers/s", "ms_per_step": dts / a.steps * 1e3,
+                                          "kernel_ms": float(np.mean([r["ms_search_flat"] for r in acc_same])),
+                                          "note": "the r01-r03 measurement: one batch replayed K times (its 310 MB of index lines are "
+                                                  "re-read every step); the headline cycles through %d distinct batches" % len(dev_batches)}
+            rot["on"] = True
         pipelined = None
         if world == 1 and not a.no_extras:
             torch.cuda.synchronize()
@@ -644,7 +713,10 @@ def main():
                                        f"-m 1000 -x 10000 (BASELINE.json configs[{1 if cfg == 'hunt_d1' else 3}])",
                            "genome": genome_desc,
                            "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
-                           "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU"},
+                           "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
+                           "distinct_batches": len(dev_batches),
+                           "stream": f"step k searches batch k mod {len(dev_batches)} of {len(dev_batches)} distinct batches resident in HBM "
+                                     "(seeds 42 + 1000 b), warm-up included" if len(dev_batches) > 1 else "one batch replayed every step"},
                 "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                              "algorithmic_bytes_per_launch": alg_bytes, "ext_steps_per_launch": ext,

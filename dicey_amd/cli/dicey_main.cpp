@@ -369,28 +369,45 @@ int hunter(int argc, char** argv) {
       }
       return true;
     };
+    // Invariant: chunk k runs on lane k % depth, and while everything is fine chunk k + depth is submitted as soon as chunk k's
+    // lane is idle again — right after its wait() when the chunk was answered (the next one is on the GPU while this one is
+    // formatted), or after the blocking halves when the library refused the chunk's size (DG_ELIMIT: the lane must be idle for
+    // run_sync).  A missing ticket while `ok` holds is a bug of this loop and ends the run with an error, never with silence.
     size_t submitted = 0;
-    for (; submitted < std::min(depth, chunks.size()) && ok; ++submitted) ok = submit(submitted);
-    for (size_t k = 0; k < chunks.size(); ++k) {
-      if (!tickets[k]) break;
-      dg_hunt_result* R = nullptr;
-      const int rc = dg_hunt_wait(tickets[k], &R);
-      tickets[k] = nullptr;
-      if (ok && rc == DG_OK && submitted < chunks.size()) {  // the handle is free again: the next chunk starts before this one is formatted
+    auto top_up = [&]() {
+      if (ok && submitted < chunks.size()) {
         ok = submit(submitted);
         if (ok) ++submitted;
       }
+    };
+    for (; submitted < std::min(depth, chunks.size()) && ok;) top_up();
+    for (size_t k = 0; k < chunks.size(); ++k) {
+      if (!tickets[k]) {
+        if (ok) {
+          err = "internal error: chunk " + std::to_string(k) + " of " + std::to_string(chunks.size()) + " was never submitted";
+          ok = false;
+        }
+        continue;
+      }
+      dg_hunt_result* R = nullptr;
+      const int rc = dg_hunt_wait(tickets[k], &R);
+      tickets[k] = nullptr;
       if (!ok) {
         if (R) dg_hunt_result_free(R);
         continue;  // keep collecting what is in flight
       }
-      if (rc == DG_ELIMIT) ok = run_sync(lanes[k % depth], chunks[k].first, chunks[k].second);  // that handle is idle: its wait() has returned and nothing new was submitted to it
-      else if (rc != DG_OK) {
-        err = dg_last_error();
-        ok = false;
-      } else {
+      if (rc == DG_OK) {
+        top_up();  // the lane is free again: the next chunk starts before this one is formatted
         format_chunk(R, chunks[k].first, chunks[k].second - chunks[k].first);
         dg_hunt_result_free(R);
+      } else if (rc == DG_ELIMIT) {
+        if (R) dg_hunt_result_free(R);
+        ok = run_sync(lanes[k % depth], chunks[k].first, chunks[k].second);  // that lane is idle: its wait() has returned and nothing new was submitted to it
+        top_up();
+      } else {
+        err = dg_last_error();
+        ok = false;
+        if (R) dg_hunt_result_free(R);
       }
     }
     if (second) dg_index_close(second);

@@ -4066,19 +4066,24 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   // Could any query of this batch reach the cap?  (the bound grows with the length and with the number of N's)
   CapScan cs;
+  // the caller's host copy of the offsets (nullptr on the dg_hunt_device path).  The read-back below serves cap_scan only and must not
+  // outlive it: queue_fetch and the result's qoff distinguish "the caller has the offsets" from "pack them on the device" by this.
+  const uint64_t* const caller_qoff = h_qoff;
   if (maxlen >= 1 && neighbourhood_bound(maxlen, dmax_eff, indel, maxlen) >= p->max_neighborhood) {
     std::vector<u8> hb;
     std::vector<u64> ho;
-    if (!h_qbytes || !h_qoff) {
+    const uint8_t* sb = h_qbytes;
+    const uint64_t* so = h_qoff;
+    if (!sb || !so) {
       hb.resize(total + 1);
       ho.resize(nq + 1);
       if (total) DG_HIP(hipMemcpyAsync(hb.data(), d_qbytes, total, hipMemcpyDeviceToHost, st));
       DG_HIP(hipMemcpyAsync(ho.data(), d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
       DG_HIP(hipStreamSynchronize(st));
-      h_qbytes = hb.data();
-      h_qoff = ho.data();
+      sb = hb.data();
+      so = ho.data();
     }
-    DG_TRY(cap_scan(h_qbytes, h_qoff, nq, p, group_counts != nullptr, cs));
+    DG_TRY(cap_scan(sb, so, nq, p, group_counts != nullptr, cs));
   }
   const u64 nxs = cs.xs_gid.size();
   if (nxs >= 0xFFFFFFFFull || cs.xs_bytes.size() > (48ull << 30))
@@ -4218,7 +4223,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_TRY(ws[WS_PACK].reserve(L.bytes + 64));
     PackArgs pa;
     const u32* srcs[6] = {reinterpret_cast<const u32*>(ws[WS_GRP].as<u8>() + (ngrp + 1) * 8),  // hit_off
-                          h_qoff ? nullptr : reinterpret_cast<const u32*>(d_qoff),               // the host has its own copy
+                          caller_qoff ? nullptr : reinterpret_cast<const u32*>(d_qoff),          // the host has its own copy
                           ws[WS_QMETA].as<u32>() + nq,                                           // qdist, qflags, qnondna lie in this order
                           ws[WS_QSEQ].as<u32>(), ws[WS_HITS].as<u32>(), ws[WS_OPS].as<u32>()};
     const u64 offs[6] = {L.o_hit_off, L.o_qoff, L.o_meta, L.o_qseq, L.o_hits, L.o_ops};
@@ -4622,7 +4627,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     R->owner_ = pb;
     const FetchLayout L = fetch_layout(capn);
     u8* hb = (u8*)pb->p;
-    if (h_qoff) std::memcpy(hb + L.o_qoff, h_qoff, (nq + 1) * 8);
+    if (caller_qoff) std::memcpy(hb + L.o_qoff, caller_qoff, (nq + 1) * 8);
     R->hit_off = (uint64_t*)(hb + L.o_hit_off);
     R->qoff = (uint64_t*)(hb + L.o_qoff);
     R->hits = (dg_hit*)(hb + L.o_hits);
@@ -5031,8 +5036,11 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
   // back (a 0.1 ms host round trip per batch); k_prepare counts queries that exceed the bound, in which case the batch is
   // repeated with the offsets read afresh.
   u32 maxlen = 0;
-  const bool cached = ix->last_qoff == d_qoff && ix->last_nq == nq && ix->last_total == total_qbytes && ix->last_maxlen > 0;
-  if (cached) maxlen = ix->last_maxlen;
+  dg_index::QoffSeen* hit = nullptr;
+  for (auto& e : ix->seen)
+    if (e.qoff == d_qoff && e.nq == nq && e.total == total_qbytes && e.maxlen > 0) hit = &e;
+  const bool cached = hit != nullptr;
+  if (cached) maxlen = hit->maxlen;
   else {
     std::vector<u64> hoff(nq + 1);
     DG_HIP(hipMemcpyAsync(hoff.data(), d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
@@ -5044,17 +5052,18 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
       if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "query %zu is too long", i);
       maxlen = std::max<u32>(maxlen, (u32)l);
     }
-    ix->last_qoff = d_qoff;
-    ix->last_nq = nq;
-    ix->last_total = total_qbytes;
-    ix->last_maxlen = maxlen;
+    hit = &ix->seen[ix->seen_next++ % dg_index::NSEEN];
+    hit->qoff = d_qoff;
+    hit->nq = nq;
+    hit->total = total_qbytes;
+    hit->maxlen = maxlen;
   }
   int rc = run_batch(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, maxlen, fetch, out);
   if (rc != DG_OK && *out) {
     dg_hunt_result_free(*out);
     *out = nullptr;
   }
-  if (rc != DG_OK) ix->last_qoff = nullptr;  // whatever went wrong, the next call reads the offsets again
+  if (rc != DG_OK) hit->qoff = nullptr;  // whatever went wrong, the next call reads the offsets again
   if (rc == DG_EINVAL && cached) return dg_hunt_device(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, fetch, out);
   return rc;
 }

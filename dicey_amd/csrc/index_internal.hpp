@@ -27,9 +27,15 @@ struct dg_index {
   uint32_t surv_cap_log2_hint = 0;  // survivor-queue capacity per shard (log2) that was enough for the previous batch
   // dg_hunt_device: the (offsets pointer, count, bytes) of the previous call and the longest query it held; a repeated
   // call skips reading the offsets back, and k_prepare reports any query longer than this bound (hunt.hip)
-  const void* last_qoff = nullptr;
-  uint64_t last_nq = 0, last_total = 0;
-  uint32_t last_maxlen = 0;
+  // (r04: a small table, not one entry — a caller that cycles through a ring of resident batches finds each of them again)
+  struct QoffSeen {
+    const void* qoff = nullptr;
+    uint64_t nq = 0, total = 0;
+    uint32_t maxlen = 0;
+  };
+  static constexpr int NSEEN = 32;
+  QoffSeen seen[NSEEN];
+  uint32_t seen_next = 0;
   void* pinned = nullptr;             // 4 KB of pinned host memory for the end-of-batch summary
   // the batch counters are left zeroed by the last kernel of a batch (hunt.hip batch_finish): the next batch skips its memset
   // when they still sit where that kernel cleaned them

@@ -9,13 +9,14 @@ OUT=gpurun_out/kstats_$TAG
 rm -rf $OUT; mkdir -p $OUT
 (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/trace -o trace --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras "$@" > $GRAFT_REPO_ROOT/$OUT/bench.json 2> $GRAFT_REPO_ROOT/$OUT/bench.err)
 python - "$OUT" <<'PY'
-import csv, re, sys
+import csv, re, sys, os
+sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'tools'))
+from profnames import short_kernel_name
 out = sys.argv[1]
 rows = list(csv.DictReader(open(out + "/trace/trace_kernel_stats.csv")))
 keep = []
 for r in rows:
-    n = re.sub(r"\(.*", "", r["Name"]).replace("void ", "")
-    if "rocprim" in n: n = "rocprim::" + re.sub(r".*detail::", "", re.sub(r"<.*", "", n))
+    n = short_kernel_name(r["Name"])
     keep.append((n[:70], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
 with open(out + "/kernel_stats_short.csv", "w") as f:
     f.write("kernel,calls,total_ms,avg_us\n")

@@ -4,7 +4,7 @@
 //   (1) the random-gather ceiling that puts roofline.frac into context;
 //   (2) a known byte count to calibrate rocprofv3 FETCH_SIZE for this access pattern (MI355X_MICROARCH.md §HBM).
 // usage: gather_bench <buffer_GiB> <lines_per_lane> <dependent:0|1> <lanes>
-//        gather_bench filter <copy_GiB> <strands> <lines_per_strand>   (r03)
+//        gather_bench filter <copy_GiB> <strands> <lines_per_strand> [rotate:0|1] [reps]   (r03; rotate r04)
 // `filter`: the access shape of k_search1p's probe phase — four copies of a presence filter (copy_GiB each), one lane per
 // (strand, position) with 20 positions per strand, eight independent 4-byte loads per lane; the 160 probes of a strand fall
 // into <lines_per_strand> distinct random 64-byte lines (neighbouring positions share lines, like the kernel's choice of copy
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* buf, uint64_t nline
 }
 
 // one lane per (strand, position): 8 probes, spread over the strand's `lps` lines so that neighbouring positions share lines
-__global__ void __launch_bounds__(256) k_filter(const uint32_t* buf, uint64_t lines_per_copy, uint32_t lps, uint64_t nstrands, uint64_t* out) {
+__global__ void __launch_bounds__(256) k_filter(const uint32_t* buf, uint64_t lines_per_copy, uint32_t lps, uint64_t nstrands, uint64_t* out, uint64_t salt) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t strand = t / 20;
   const uint32_t pos = (uint32_t)(t - strand * 20);
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_filter(const uint32_t* buf, uint64_t li
 #pragma unroll
   for (int op = 0; op < 8; ++op) {
     const uint32_t slot = (pos * lps / 20 + (op >= 4 ? 1u : 0u)) % lps;  // two neighbouring line slots per position
-    const uint64_t h = mix(strand * 64 + slot + 1);
+    const uint64_t h = mix((strand + salt) * 64 + slot + 1);
     const uint64_t copy = slot * 4 / lps;  // line slots map to the four copies in turn, like edit positions do
     const uint64_t line = copy * lines_per_copy + h % lines_per_copy;
     addr[op] = buf + line * 16 + (mix(t * 8 + op) & 15);
@@ -72,19 +72,23 @@ static int filter_main(int argc, char** argv) {
   const double gib = argc > 2 ? atof(argv[2]) : 8.0;
   const uint64_t strands = argc > 3 ? strtoull(argv[3], 0, 10) : 200000;
   const uint32_t lps = argc > 4 ? (uint32_t)atoi(argv[4]) : 12;
+  // r04: rotate = 1 gives every repetition its own addresses (a stream of distinct batches); 0 replays the same lines, which the
+  // 256 MiB Infinity Cache then serves (r03's numbers: first repetition 10 G lines/s, replays 21 G at 6 lines per strand)
+  const int rotate = argc > 5 ? atoi(argv[5]) : 0;
+  const int reps = argc > 6 ? atoi(argv[6]) : 4;
   const uint64_t lines_per_copy = (uint64_t)(gib * (1ull << 30)) / 64, bytes = lines_per_copy * 64 * 4;
   uint32_t* buf; uint64_t* out;
   CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, 64));
   CK(hipMemset(buf, 1, bytes));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const uint64_t lanes = (strands * 20 + 255) / 256 * 256;
-  for (int rep = 0; rep < 4; ++rep) {
+  for (int rep = 0; rep < reps; ++rep) {
     CK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL(k_filter, dim3(lanes / 256), dim3(256), 0, 0, buf, lines_per_copy, lps, strands, out);
+    hipLaunchKernelGGL(k_filter, dim3(lanes / 256), dim3(256), 0, 0, buf, lines_per_copy, lps, strands, out, rotate ? (uint64_t)rep * strands : 0ull);
     CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
-    printf("{\"tool\":\"gather_bench filter\",\"copies\":4,\"copy_GiB\":%.2f,\"strands\":%llu,\"lines_per_strand\":%u,\"probes\":%llu,\"ms\":%.4f,"
-           "\"Glines_per_s\":%.2f,\"Gprobes_per_s\":%.2f}\n", gib, (unsigned long long)strands, lps, (unsigned long long)(strands * 160), ms,
+    printf("{\"tool\":\"gather_bench filter\",\"copies\":4,\"copy_GiB\":%.2f,\"strands\":%llu,\"lines_per_strand\":%u,\"probes\":%llu,\"rotate\":%d,\"rep\":%d,\"ms\":%.4f,"
+           "\"Glines_per_s\":%.2f,\"Gprobes_per_s\":%.2f}\n", gib, (unsigned long long)strands, lps, (unsigned long long)(strands * 160), rotate, rep, ms,
            (double)strands * lps / ms / 1e6, (double)strands * 160 / ms / 1e6);
   }
   return 0;

@@ -26,17 +26,19 @@ SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_
 LIST
 python - "$OUT" <<'PY'
 import csv, glob, re, sys, os
+sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'tools'))
+from profnames import short_kernel_name
 out = sys.argv[1]
 with open(os.path.join(out, "kernel_stats.csv"), "w") as f:
     f.write("kernel,calls,total_ms,avg_us\n")
     for r in csv.DictReader(open(os.path.join(out, "trace", "trace_kernel_stats.csv"))):
-        n = re.sub(r"\(.*", "", r["Name"]).replace("void ", "")
+        n = short_kernel_name(r["Name"])
         if "dg::" not in n: continue
         f.write('"%s",%s,%.3f,%.2f\n' % (n[:80], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
 acc = {}
 for d in sorted(glob.glob(os.path.join(out, "pmc_*", "pmc_counter_collection.csv"))):
     for r in csv.DictReader(open(d)):
-        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+        k = short_kernel_name(r["Kernel_Name"])
         if "dg::" not in k: continue
         acc.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 with open(os.path.join(out, "pmc_summary.csv"), "w") as f:

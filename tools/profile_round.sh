@@ -8,7 +8,7 @@ OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 R=${1:-r02}
 # 1. the bench line itself (un-profiled)
-timeout 900 python bench.py --keep-index > $OUT/bench_$R.json 2> $OUT/bench_$R.err
+timeout 900 python bench.py --keep-index --no-extra-configs > $OUT/bench_$R.json 2> $OUT/bench_$R.err
 FM9=$(ls /dev/shm/dicey_bench_*.fm9 | head -1)
 echo "index: $FM9" > $OUT/notes.txt
 # 2. kernel trace + stats of the same command (index reused so the trace holds the search path, not the builder)

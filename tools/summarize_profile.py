@@ -4,6 +4,8 @@
 roofline.traffic: HBM bytes of the dominant kernel per launch, FETCH_SIZE corrected by the calibration factor measured on a
 known byte count of random 64-byte lines + WRITE_SIZE)."""
 import csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from profnames import short_kernel_name
 R = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P, OUT = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles")
@@ -14,17 +16,14 @@ with open(os.path.join(OUT, f"{R}_bench_kernel_stats.csv"), "w") as f:  # long t
     f.write("# rocprofv3 --kernel-trace --stats of `python bench.py --fm9 <index of the bench run> --no-cpu-baseline --no-extras`\n")
     f.write("kernel,calls,total_ms,avg_us,min_us,max_us\n")
     for r in csv.DictReader(open(os.path.join(P, "trace", "trace_kernel_stats.csv"))):
-        n = re.sub(r"\(.*", "", r["Name"]).replace("void ", "")
-        if "rocprim" in n:
-            n = "rocprim::" + re.sub(r".*detail::", "", re.sub(r"<.*", "", n))
-        n = re.sub(r"at::native::.*", "at::native::(torch kernel of the synthetic input generator)", n)
+        n = short_kernel_name(r["Name"])
         f.write('"%s",%s,%.3f,%.2f,%.2f,%.2f\n' % (n[:90], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
                                                  float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 rows, means = [], {}
 for d in sorted(glob.glob(os.path.join(P, "pmc_*", "pmc_counter_collection.csv"))):
     acc = {}
     for r in csv.DictReader(open(d)):
-        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+        k = short_kernel_name(r["Kernel_Name"])
         if "dg::" not in k and "gather" not in k: continue
         acc.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     for (k, c), v in sorted(acc.items()):

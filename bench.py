@@ -498,7 +498,10 @@ def main():
         off[1:] = np.cumsum([len(q) for q in queries])
         d_q = torch.frombuffer(bytearray(qbytes), dtype=torch.uint8).to(dev)  # inputs resident in HBM
         d_off = torch.from_numpy(off.view(np.int64)).to(dev)
-        p = _capi.HuntParams(distance, 0, 0, 1000, 10000)
+        # max_query_len: the bench knows its primers' length, like a primer-design caller does — the library then sizes the batch
+        # without reading the offsets back (a host round trip per new buffer; r04a: 0.17 ms of a 0.51 ms step on unseen buffers)
+        p = _capi.HuntParams(distance, 0, 0, 1000, 10000, a.qlen, 0)
+        p_compact = _capi.HuntParams(distance, 0, 0, 1000, 10000, a.qlen, _capi.DG_HUNT_COMPACT)
         # The stream of distinct batches (r04): B batches resident in HBM, each with its own bytes and offsets
         # buffer; step k searches batch k mod B, warm-up included, so no batch recurs within B launches.
         dev_batches = [(d_q, d_off, len(qbytes))]
@@ -511,20 +514,23 @@ def main():
                                     int(arr.size)))
         rot = {"k": 0, "on": True}
 
-        def step(fetch=0, handle=None):
+        def step(fetch=0, handle=None, params=None):
             bq, bo, bbytes = dev_batches[rot["k"] % len(dev_batches)] if rot["on"] else dev_batches[0]
             rot["k"] += 1
             rp = C.POINTER(_capi.HuntResult)()
-            _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(p), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
+            _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(params or p_compact), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
                                             C.c_void_p(bo.data_ptr()), nq, bbytes, fetch, C.byref(rp)))
             R = rp.contents
             res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes,
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify}
             if world > 1 and not fetch:
-                parts = [device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), dev)]
-                if R.ops_per_hit and R.nhits:  # compact alignment description (dicey_gpu.h): 4 bytes per unit of distance
-                    parts.append(device_bytes(R.d_ops, R.nhits * R.ops_per_hit * 4, dev))
+                if R.compact:  # ABI 5 records: position, packed word, d operation words = 12 bytes per hit at distance 1
+                    parts = [device_bytes(R.d_hits, R.nhits * 4 * (2 + R.ops_per_hit), dev)]
+                else:
+                    parts = [device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), dev)]
+                    if R.ops_per_hit and R.nhits:  # alignment description (dicey_gpu.h): 4 bytes per unit of distance
+                        parts.append(device_bytes(R.d_ops, R.nhits * R.ops_per_hit * 4, dev))
                 gather_parts(parts)
             L.dg_hunt_result_free(rp)
             return res
@@ -550,28 +556,32 @@ def main():
             rot["on"] = True
         pipelined = None
         if world == 1 and not a.no_extras:
+            for _ in range(2):
+                step(fetch=1, params=p_compact)
             torch.cuda.synchronize()
             tp = time.perf_counter()
             for _ in range(a.steps):
-                step(fetch=1)
+                rlast = step(fetch=1, params=p_compact)
             torch.cuda.synchronize()
             dtf = time.perf_counter() - tp
+            words = 2 + int(rlast["ops_per_hit"])
             extras["value_with_d2h"] = {"value": nq * a.steps / dtf, "unit": "primers/s", "ms_per_step": dtf / a.steps * 1e3,
-                                        "note": "same steps with fetch=1: hit records with their compact alignment description (20 + 4 d bytes per "
-                                                "hit; dg_hit_rows rebuilds the two rows), flags and normalised queries copied into a pinned "
-                                                "block from the library's pool after every batch",
-                                        "hit_bytes_per_step": int(acc[-1]["nhits"]) * (C.sizeof(_capi.Hit) + 4 * int(acc[-1]["ops_per_hit"]))}
-            # host to host with two batches in flight: dg_hunt_submit / dg_hunt_wait (the asynchronous C entry points) on two
-            # handles sharing the resident index — query bytes go up, fetched results come back, every step
+                                        "note": "same steps (rotating batches) with fetch=1 and DG_HUNT_COMPACT: per hit the text position, one "
+                                                "packed word and d operation words (dg_chit_unpack / dg_hit_rows rebuild every DnaHit), per "
+                                                "query one word of flags + its hit count, in ONE copy into a pinned block of the library's pool",
+                                        "bytes_per_step": int(rlast["nhits"]) * 4 * words + 8 * nq}
+            # host to host: dg_hunt_submit / dg_hunt_wait on ONE handle, two batches in flight on the library's two internal lanes —
+            # query bytes of 16 distinct host batches go up, compact results come back, every step; one Python thread drives it
             try:
-                hbuf = C.create_string_buffer(qbytes, len(qbytes))
+                host_batches = []
                 hoff = (C.c_uint64 * (nq + 1))(*[int(x) for x in off])
-                second = ix.share()
-                lanes2 = [ix.handle, second.handle]
+                for bq, _, bbytes in dev_batches:
+                    host_batches.append(C.create_string_buffer(bq.cpu().numpy().tobytes(), bbytes))
 
                 def submit(k):
                     t = C.c_void_p()
-                    _capi.check(L, L.dg_hunt_submit(lanes2[k % 2], C.byref(p), sl, len(seqlen), hbuf, hoff, nq, C.byref(t)))
+                    _capi.check(L, L.dg_hunt_submit(ix.handle, C.byref(p_compact), sl, len(seqlen), host_batches[k % len(host_batches)], hoff, nq,
+                                                    C.byref(t)))
                     return t
 
                 def wait(t):
@@ -580,23 +590,22 @@ def main():
                     nh = rp2.contents.nhits
                     L.dg_hunt_result_free(rp2)
                     return nh
-                for k in range(2):  # warm both handles (workspaces, pinned blocks)
+                for k in range(4):  # warm both lanes (workspaces, pinned blocks)
                     wait(submit(k))
                 torch.cuda.synchronize()
+                nst = max(a.steps, 2 * len(host_batches))
                 tp = time.perf_counter()
-                inflight = [submit(0), submit(1)] if a.steps > 1 else [submit(0)]
-                done = 0
-                for k in range(a.steps):
+                inflight = [submit(0), submit(1)]
+                for k in range(nst):
                     nh = wait(inflight[k])
-                    if len(inflight) < a.steps:
+                    if len(inflight) < nst:
                         inflight.append(submit(len(inflight)))
-                    done += 1
                 dth = time.perf_counter() - tp
-                second.close()
                 extras["host_to_host_pipelined"] = {
-                    "value": nq * a.steps / dth, "unit": "primers/s", "ms_per_step": dth / a.steps * 1e3, "hits_last_step": int(nh),
-                    "note": "same steps through dg_hunt_submit / dg_hunt_wait, two batches in flight on two handles of one resident "
-                            "index: query bytes from host memory, results fetched into pinned blocks; one Python thread drives it"}
+                    "value": nq * nst / dth, "unit": "primers/s", "ms_per_step": dth / nst * 1e3, "steps": nst, "hits_last_step": int(nh),
+                    "note": "dg_hunt_submit / dg_hunt_wait on one handle (ABI 5: two batches in flight on the library's two internal "
+                            "lanes), DG_HUNT_COMPACT, max_query_len given: query bytes of %d distinct host batches up, compact results "
+                            "down into pinned blocks; one Python thread drives it" % len(host_batches)}
             except Exception as e:  # never lose the headline over an extra
                 extras["host_to_host_pipelined"] = {"error": repr(e)}
             cli_job = (queries, distance)  # measured in the common tail, after this process has released its own index
@@ -715,6 +724,7 @@ def main():
                            "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
                            "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
                            "distinct_batches": len(dev_batches),
+                           "results": "compact records (DG_HUNT_COMPACT: 8 + 4 d bytes per hit) left in HBM (N = 1) / gathered to rank 0 (N > 1)",
                            "stream": f"step k searches batch k mod {len(dev_batches)} of {len(dev_batches)} distinct batches resident in HBM "
                                      "(seeds 42 + 1000 b), warm-up included" if len(dev_batches) > 1 else "one batch replayed every step"},
                 "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

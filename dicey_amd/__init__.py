@@ -7,6 +7,7 @@ Thin Python mirror of the C ABI in include/dicey_gpu.h.  Names follow the refere
 All compute happens in hand-written HIP kernels inside libdiceygpu.so — there is no fallback path.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -157,8 +158,10 @@ class FmIndex:
         raw = out.raw
         return [raw[off[i]:off[i] + (ranges[i][1] - ranges[i][0] + 1)] for i in range(n)]
 
-    def _unpack(self, rp) -> HuntBatch:
+    def _unpack(self, rp, buf=None, off=None) -> HuntBatch:
         R = rp.contents
+        if R.compact:  # ABI 5: compact records -> the classic arrays, from the caller's own query bytes (dg_hunt_expand)
+            _capi.check(self._L, self._L.dg_hunt_expand(rp, buf, off))
         qs = []
         seqbuf = C.string_at(R.qseq, R.qoff[R.nq]) if R.nq else b""
         _capi.check(self._L, self._L.dg_hunt_rows(rp))  # the two rows of every hit from its compact description
@@ -177,35 +180,45 @@ class FmIndex:
               "verify": R.ms_verify}
         return HuntBatch(qs, ctr, tm)
 
+    @staticmethod
+    def _params(distance, hamming, forward_only, max_locations, max_neighborhood, compact, max_query_len):
+        if compact is None:  # the compact delivery of ABI 5 is what this mirror uses unless told otherwise (the GPU suite runs both)
+            compact = not os.environ.get("DICEY_CLASSIC_RESULTS")
+        return _capi.HuntParams(distance, int(hamming), int(forward_only), max_locations, max_neighborhood, int(max_query_len),
+                                _capi.DG_HUNT_COMPACT if compact else 0)
+
     def hunt(self, queries: Sequence[str], seqlen: Sequence[int], distance: int = 1, hamming: bool = False,
-             forward_only: bool = False, max_locations: int = 1000, max_neighborhood: int = 10000) -> HuntBatch:
+             forward_only: bool = False, max_locations: int = 1000, max_neighborhood: int = 10000, compact=None,
+             max_query_len: int = 0) -> HuntBatch:
         """seqlen[i] = faidx length + 1 (src/util.h:201)."""
         buf, off = _pack([q.encode("latin-1") if isinstance(q, str) else q for q in queries])
         sl = (C.c_uint32 * len(seqlen))(*seqlen)
-        p = _capi.HuntParams(distance, int(hamming), int(forward_only), max_locations, max_neighborhood)
+        p = self._params(distance, hamming, forward_only, max_locations, max_neighborhood, compact, max_query_len)
         rp = C.POINTER(_capi.HuntResult)()
         _capi.check(self._L, self._L.dg_hunt(self._h, C.byref(p), sl, len(seqlen), buf, off, len(queries), C.byref(rp)))
         try:
-            return self._unpack(rp)
+            return self._unpack(rp, buf, off)
         finally:
             self._L.dg_hunt_result_free(rp)
 
-
     def hunt_submit(self, queries: Sequence[str], seqlen: Sequence[int], distance: int = 1, hamming: bool = False,
-                    forward_only: bool = False, max_locations: int = 1000, max_neighborhood: int = 10000):
-        """dg_hunt_submit: the batch runs on a helper thread of the library; collect with hunt_wait (one per handle at a time)."""
+                    forward_only: bool = False, max_locations: int = 1000, max_neighborhood: int = 10000, compact=None,
+                    max_query_len: int = 0):
+        """dg_hunt_submit: the batch runs on a helper thread of the library; collect with hunt_wait (two per handle at a time,
+        waited for in the order they were submitted)."""
         buf, off = _pack([q.encode("latin-1") if isinstance(q, str) else q for q in queries])
         sl = (C.c_uint32 * len(seqlen))(*seqlen)
-        p = _capi.HuntParams(distance, int(hamming), int(forward_only), max_locations, max_neighborhood)
+        p = self._params(distance, hamming, forward_only, max_locations, max_neighborhood, compact, max_query_len)
         t = C.c_void_p()
         _capi.check(self._L, self._L.dg_hunt_submit(self._h, C.byref(p), sl, len(seqlen), buf, off, len(queries), C.byref(t)))
-        return t
+        return (t, buf, off)
 
     def hunt_wait(self, ticket) -> HuntBatch:
+        t, buf, off = ticket
         rp = C.POINTER(_capi.HuntResult)()
-        _capi.check(self._L, self._L.dg_hunt_wait(ticket, C.byref(rp)))
+        _capi.check(self._L, self._L.dg_hunt_wait(t, C.byref(rp)))
         try:
-            return self._unpack(rp)
+            return self._unpack(rp, buf, off)
         finally:
             self._L.dg_hunt_result_free(rp)
 

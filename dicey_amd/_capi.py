@@ -15,6 +15,7 @@ DG_OPEN_NO_KMER_TABLE = 2
 DG_OPEN_COMPACT = 4
 DG_OPEN_BIG_TABLE = 8
 DG_Q_TOO_SHORT, DG_Q_DIST_ADJUSTED, DG_Q_MAX_MATCHES, DG_Q_NBHD_EXCEEDED = 1, 2, 4, 8
+DG_HUNT_COMPACT = 1
 
 
 class DgError(RuntimeError):
@@ -30,7 +31,7 @@ class IndexStats(C.Structure):
 
 class HuntParams(C.Structure):
     _fields_ = [("distance", C.c_uint32), ("hamming", C.c_int32), ("forward_only", C.c_int32),
-                ("max_locations", C.c_uint64), ("max_neighborhood", C.c_uint32)]
+                ("max_locations", C.c_uint64), ("max_neighborhood", C.c_uint32), ("max_query_len", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class Hit(C.Structure):
@@ -48,7 +49,9 @@ class HuntResult(C.Structure):
                 ("ctr_win_bytes", C.c_uint64), ("ctr_tab_reads", C.c_uint64), ("ms_total", C.c_double), ("ms_search", C.c_double),
                 ("ms_select", C.c_double), ("ms_locate", C.c_double), ("ms_verify", C.c_double),
                 ("d_hits", C.c_void_p), ("d_ops", C.c_void_p),
-                ("ctr_filter_probes", C.c_uint64), ("ms_search_flat", C.c_double), ("owner_", C.c_void_p)]
+                ("ctr_filter_probes", C.c_uint64), ("ms_search_flat", C.c_double), ("owner_", C.c_void_p),
+                ("compact", C.c_uint32), ("nseq", C.c_uint32), ("chits", C.POINTER(C.c_uint32)), ("qinfo", C.POINTER(C.c_uint32)),
+                ("seq_start", C.POINTER(C.c_uint64)), ("expanded_", C.c_void_p)]
 
 
 class SearchParams(C.Structure):
@@ -90,7 +93,8 @@ SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_
            "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
            "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
            "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free", "dg_index_share",
-           "dg_neighbors", "dg_buffer_free", "dg_hit_rows", "dg_hunt_rows", "dg_hunt_submit", "dg_hunt_wait"]
+           "dg_neighbors", "dg_buffer_free", "dg_hit_rows", "dg_hunt_rows", "dg_hunt_submit", "dg_hunt_wait",
+           "dg_chit_unpack", "dg_normalize_query", "dg_hunt_expand"]
 
 _lib = None
 
@@ -136,6 +140,9 @@ def load(path=None):
     L.dg_hunt_rows.argtypes = [C.POINTER(HuntResult)]
     L.dg_hunt_submit.argtypes = [vp, C.POINTER(HuntParams), u32p, C.c_uint32, C.c_char_p, u64p, C.c_size_t, C.POINTER(vp)]
     L.dg_hunt_wait.argtypes = [vp, C.POINTER(C.POINTER(HuntResult))]
+    L.dg_chit_unpack.argtypes = [C.POINTER(HuntResult), C.c_uint64, C.c_uint32, C.POINTER(Hit), C.POINTER(u32p)]
+    L.dg_normalize_query.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, u32p]
+    L.dg_hunt_expand.argtypes = [C.POINTER(HuntResult), C.c_char_p, u64p]
     L.dg_hit_rows.argtypes = [C.POINTER(Hit), u32p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p]
     L.dg_index_build.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p]
     L.dg_index_build_device.argtypes = [vp, C.c_uint64, C.c_int, C.c_char_p]

@@ -254,7 +254,7 @@ int hunter(int argc, char** argv) {
     return 1;
   }
 
-  dg_hunt_params hp;
+  dg_hunt_params hp{};
   hp.distance = c.distance;
   hp.hamming = c.hamming;
   hp.forward_only = c.forward;
@@ -262,13 +262,19 @@ int hunter(int argc, char** argv) {
   hp.max_neighborhood = c.max_neighborhood;
   // queries [q0, q1) on one handle, chunk by chunk; sink(i, json line of query i) is called in query order
   auto run_slice = [&](dg_index* ix, size_t s0, size_t s1, const std::function<void(size_t, std::string&&)>& sink, std::string& err) -> bool {
-    auto pack = [&](size_t q0, size_t q1, std::string& qb, std::vector<uint64_t>& off) {
+    auto pack = [&](size_t q0, size_t q1, std::string& qb, std::vector<uint64_t>& off) -> dg_hunt_params {
       qb.clear();
       off.assign(q1 - q0 + 1, 0);
+      size_t longest = 0;
       for (size_t i = 0; i < q1 - q0; ++i) {
         qb += queries[q0 + i].second;
         off[i + 1] = qb.size();
+        longest = std::max(longest, queries[q0 + i].second.size());
       }
+      dg_hunt_params cp = hp;  // the chunk's own bound: the library sizes the batch without another pass over the offsets
+      cp.max_query_len = (uint32_t)std::min<size_t>(longest, 0xFFFFFFu);
+      cp.flags = DG_HUNT_COMPACT;
+      return cp;
     };
     // one JSON line per query of a finished chunk, handed to the sink in query order
     auto format_chunk = [&](dg_hunt_result* R, size_t q0, size_t nq) {
@@ -276,34 +282,44 @@ int hunter(int argc, char** argv) {
         std::vector<std::string> m;
         std::vector<DnaHit> ht;
         const std::string& qname = queries[q0 + i].first;
-        if (R->qflags[i] & DG_Q_TOO_SHORT) {
+        // compact results (DG_HUNT_COMPACT): one word per query; the normalised sequence is formed here from the query's own bytes
+        const uint32_t qw = R->qinfo[i], qfl = DG_QINFO_FLAGS(qw);
+        if (qfl & DG_Q_TOO_SHORT) {
           m.push_back("Error: Input sequence is shorter than 10 nucleotides!");
           return hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m);
         }
-        for (uint32_t k = 0; k < R->qnondna[i]; ++k) m.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
-        if (R->qflags[i] & DG_Q_DIST_ADJUSTED) m.push_back("Warning: Distance was adjusted to sequence length!");
-        if (R->qflags[i] & DG_Q_NBHD_EXCEEDED) {
+        const std::string& raw = queries[q0 + i].second;
+        std::string seq(raw.size(), '\0');
+        uint32_t nondna = 0;
+        (void)dg_normalize_query((const uint8_t*)raw.data(), (uint32_t)raw.size(), (uint8_t*)seq.data(), &nondna);
+        for (uint32_t k = 0; k < nondna; ++k) m.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
+        if (qfl & DG_Q_DIST_ADJUSTED) m.push_back("Warning: Distance was adjusted to sequence length!");
+        if (qfl & DG_Q_NBHD_EXCEEDED) {
           std::string x = std::to_string(c.max_neighborhood);
           m.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x + " neighbors are searched, results are likely incomplete!");
         }
         for (uint64_t h = R->hit_off[i]; h < R->hit_off[i + 1]; ++h) {
-          // the hit's two rows from its compact description (dicey_gpu.h "compact alignment"): built here, on the formatting threads
-          const dg_hit& H = R->hits[h];
+          // the hit from its compact record (dicey_gpu.h ABI 5: position, packed word, operation words) and its two rows from the
+          // operation words — built here, on the formatting threads
+          dg_hit H;
+          const uint32_t* hops = nullptr;
+          if (dg_chit_unpack(R, h, (uint32_t)i, &H, &hops) != DG_OK) {
+            std::fprintf(stderr, "dicey hunt: %s\n", dg_last_error());
+            std::abort();
+          }
           std::string ra(H.aln_len, '\0'), qa(H.aln_len, '\0');
-          if (dg_hit_rows(&H, R->ops ? R->ops + h * R->ops_per_hit : nullptr, R->ops_per_hit, R->qseq + R->qoff[i],
-                          (uint32_t)(R->qoff[i + 1] - R->qoff[i]), ra.data(), qa.data()) != DG_OK) {
+          if (dg_hit_rows(&H, hops, R->ops_per_hit, (const uint8_t*)seq.data(), (uint32_t)seq.size(), ra.data(), qa.data()) != DG_OK) {
             std::fprintf(stderr, "dicey hunt: %s\n", dg_last_error());
             std::abort();
           }
           ht.push_back(DnaHit{H.score, H.chr, H.start, (char)H.strand, std::move(ra), std::move(qa)});
         }
-        if (R->qflags[i] & DG_Q_MAX_MATCHES) {
+        if (qfl & DG_Q_MAX_MATCHES) {
           std::string x = std::to_string(c.max_locations);
           m.push_back("Warning: More than " + x + " matches found. Only first " + x + " matches are reported, results are likely incomplete!");
         }
         std::sort(ht.begin(), ht.end());  // hunter.h:440 — same comparator, same libstdc++ algorithm, same input order
-        std::string seq((const char*)R->qseq + R->qoff[i], R->qoff[i + 1] - R->qoff[i]);
-        return hunt_json(c, R->qdistance[i], seq, qname, seqname, ht, m);
+        return hunt_json(c, DG_QINFO_DISTANCE(qw), seq, qname, seqname, ht, m);
       };
       unsigned nthr = std::thread::hardware_concurrency();
       if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthr = (unsigned)std::max(1, std::atoi(e));
@@ -327,9 +343,9 @@ int hunter(int argc, char** argv) {
     std::function<bool(dg_index*, size_t, size_t)> run_sync = [&](dg_index* hx, size_t q0, size_t q1) -> bool {
       std::string qb;
       std::vector<uint64_t> off;
-      pack(q0, q1, qb, off);
+      const dg_hunt_params cp = pack(q0, q1, qb, off);
       dg_hunt_result* R = nullptr;
-      const int rc = dg_hunt(hx, &hp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), q1 - q0, &R);
+      const int rc = dg_hunt(hx, &cp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), q1 - q0, &R);
       if (rc == DG_ELIMIT && q1 - q0 > 1) {
         const size_t mid = q0 + (q1 - q0) / 2;
         return run_sync(hx, q0, mid) && run_sync(hx, mid, q1);
@@ -361,8 +377,8 @@ int hunter(int argc, char** argv) {
     auto submit = [&](size_t k) -> bool {
       std::string qb;
       std::vector<uint64_t> off;
-      pack(chunks[k].first, chunks[k].second, qb, off);
-      if (dg_hunt_submit(lanes[k % depth], &hp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(),
+      const dg_hunt_params cp = pack(chunks[k].first, chunks[k].second, qb, off);
+      if (dg_hunt_submit(lanes[k % depth], &cp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(),
                          chunks[k].second - chunks[k].first, &tickets[k]) != DG_OK) {
         err = dg_last_error();
         return false;

@@ -1,0 +1,257 @@
+// The banded Needleman-Wunsch of the verify stage as bit-plane arithmetic (r04), shared by the device kernels (hunt.hip) and by a
+// host harness (tests/host/band_bits_host.cpp) that holds it against the checker's needle() without a GPU.
+// Reference: needle.h:59-138 with AlignConfig<false,true> and DnaScore(0,-1,-1,-1) (hunter.h:383-389), the column stripping of
+// hunter.h:69-77,391-401.
+#pragma once
+#include <cstdint>
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#define DG_BB __device__ __forceinline__
+#else
+#define DG_BB inline
+#endif
+#include "../../include/dicey_gpu.h"
+
+namespace dg {
+using u8 = uint8_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+struct PosMasks {  // bit i of a / c / g / t <=> character i of the query strand is that base (an N sets none)
+  u32 a, c, g, t;
+};
+static constexpr u32 ALN_OP_NONE = 0xFFFFFFFFu;
+DG_BB u32 aln_op(u32 col, u32 kind, u32 byte) { return (col & 0xFFFFu) | (kind << 16) | (byte << 24); }  // kind: DG_ALN_*
+struct AlnRes {
+  u32 info;  // (score & 255) | leading query-gap columns << 8 | kept columns << 16
+  u32 op[2];
+  u32 pre_eff;  // context characters in front of the string that survived the '\n' trimming (the lane-per-hit path needs it for hunter.h:382)
+};
+
+
+// ---- r04: the same banded matrix with every cell of a row in ONE pair (d <= 1) or triple (d = 2) of bit masks.
+// band_align above spends ~20 vector instructions per cell (7 or 13 cells per row, one after the other): 65 us for the 234 k hits of
+// the default step, at the chip's instruction-issue rate (r03 verdict, weak #4; 112 bytes of scratch per lane on top).  Two facts
+// shrink a row to ~45 instructions for ALL its cells:
+//  (1) Costs saturate.  On an optimal path every prefix costs <= d (moves cost 0 or 1), and a candidate that costs more than d can
+//      neither win nor tie at a cell of such a path; so every cost above d may be stored as d + 1 ("dead") without changing the
+//      value or the tie order at any cell the traceback visits (clamp commutes with min and with adding a non-negative cost).
+//  (2) A cost in 0..d+1 is d + 1 thermometer bits: plane j holds, for every diagonal k of the band, "cost >= j".  Then
+//      cost + 1 -> shift the planes up by one; cost + (mask ? 1 : 0) -> P_j | (mask & P_{j-1}); min -> AND of planes;
+//      equality (the tie tests of needle.h:105-131: horizontal, then vertical, then diagonal) -> AND over planes of XNOR.
+//      The horizontal dependency inside a row runs over planes, not over cells: "cost >= j" of a cell needs "cost >= j - 1" of
+//      its left neighbour, so planes are settled in order j = 1 .. d + 1, every cell of a plane at once.
+// Bit k of a plane = diagonal k = c - r + dm exactly as in band_align.  The query enters as four position masks (bit i = "q[i]
+// is this base", k_prepare writes them per (query, strand); N = none of the four), so the mismatch mask of a row is one shift of
+// the mask that belongs to the row's reference byte.  The trace of a row is two masks (horizontal chosen / vertical chosen).
+// The traceback walks only until it has found as many non-matching columns as the cell (mg, n) says there are: what remains of an
+// optimal path then costs nothing, and between columns 0 and n only diagonal matches cost nothing.
+struct QMasks {
+  u64 a, c, g, t, n;  // position masks shifted left by 16 (rows shift them right by r + 15 - dm >= 0)
+};
+DG_BB u64 qmask_of(const QMasks& m, u32 byte) {
+  return byte == 'A' ? m.a : byte == 'C' ? m.c : byte == 'G' ? m.g : byte == 'T' ? m.t : byte == 'N' ? m.n : 0ULL;
+}
+template <int WB, typename TR, int TRS>
+DG_BB AlnRes band_align_bits(const u8* text, u64 text_n, bool indel, u64 loc, u32 mlen, u32 n, u32 d, PosMasks peq, TR* tr /* [row * TRS] */, u32& fault) {
+  constexpr u32 NP = WB <= 7 ? 2u : 3u;   // planes = largest distance served + 1
+  constexpr u32 WBM = (1u << WB) - 1u, TOP = 1u << (WB - 1);
+  constexpr u32 VSH = WB <= 8 ? 8u : 16u;  // the vertical mask's place in a trace word
+  AlnRes res;
+  res.op[0] = res.op[1] = ALN_OP_NONE;
+  if (d + 1 > NP) {
+    fault = 1;
+    d = NP - 1;
+  }
+  u64 pre = d, post = d;
+  if (pre > loc) pre = loc;
+  if (loc + mlen + post > text_n) post = text_n - loc - mlen;
+  constexpr int GW = (32 + 3 * 2 + 7) / 8 + 1;  // 38 bytes at any byte offset
+  u64 gw[GW];
+  {
+    const u64 g0 = loc - pre, a0 = g0 & ~7ULL;
+    const u32 sh = (u32)(g0 & 7) * 8;
+    const u64* src = reinterpret_cast<const u64*>(text + a0);
+    u64 w[GW + 1];
+#pragma unroll
+    for (int i = 0; i <= GW; ++i) w[i] = (u32)(8 * i) < (u32)(g0 & 7) + (u32)(pre + mlen + post) ? src[i] : 0ULL;
+#pragma unroll
+    for (int i = 0; i < GW; ++i) gw[i] = sh ? (w[i] >> sh) | (w[i + 1] << (64 - sh)) : w[i];
+  }
+  auto gw_at = [&](u32 i) -> u32 {  // byte i of the maximal window
+    u64 w = gw[0];
+#pragma unroll
+    for (int k = 1; k < GW; ++k)
+      if ((i >> 3) == (u32)k) w = gw[k];
+    return (u32)(w >> (8 * (i & 7))) & 255u;
+  };
+  // hunter.h:363-378: the context stops at sequence separators
+  u32 pre_eff = 0;
+  for (u32 i = 1; i <= pre; ++i) {
+    if (gw_at((u32)pre - i) == '\n') break;
+    pre_eff = i;
+  }
+  u32 post_eff = 0;
+  for (u32 i = 0; i < post; ++i) {
+    if (gw_at((u32)pre + mlen + i) == '\n') break;
+    post_eff = i + 1;
+  }
+  res.pre_eff = pre_eff;
+  const u32 skip = (u32)pre - pre_eff;       // genomicseq starts at byte `skip` of the maximal window
+  const u32 mg = pre_eff + mlen + post_eff;  // rows
+  u64 gsh[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) gsh[i] = skip ? (gw[i] >> (8 * skip)) | (gw[i + 1] << (64 - 8 * skip)) : gw[i];
+  auto g_ch = [&](u32 i) -> u32 {  // genomicseq[i]
+    u64 w = gsh[0];
+#pragma unroll
+    for (int k = 1; k < 5; ++k)
+      if ((i >> 3) == (u32)k) w = gsh[k];
+    return (u32)(w >> (8 * (i & 7))) & 255u;
+  };
+  QMasks qm;
+  {
+    const u32 lenmask = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    qm.a = (u64)peq.a << 16;
+    qm.c = (u64)peq.c << 16;
+    qm.g = (u64)peq.g << 16;
+    qm.t = (u64)peq.t << 16;
+    qm.n = (u64)(~(peq.a | peq.c | peq.g | peq.t) & lenmask) << 16;
+  }
+  u32 nops = 0;
+  u32 found[2] = {0u, 0u}, found_at[2] = {0u, 0u};  // operations in the order the backward walk meets them: kind | byte << 8, columns from the end
+  auto push_op = [&](u32 from_end, u32 kind, u32 byte) {
+    if (nops == 0) {
+      found[0] = kind | (byte << 8);
+      found_at[0] = from_end;
+    } else if (nops == 1) {
+      found[1] = kind | (byte << 8);
+      found_at[1] = from_end;
+    }
+    ++nops;
+  };
+  if (!indel) {
+    // hunter.h:79-88,404-405: score = -(mismatches), alignment rows are the raw strings (mg == mlen == n here)
+    int sc = 0;
+    const u32 k = mg < n ? mg : n;
+    for (u32 i = 0; i < k; ++i) {
+      const u32 gc = g_ch(i);
+      if (!((qmask_of(qm, gc) >> (i + 16)) & 1ULL)) {
+        --sc;
+        if (nops == 0) res.op[0] = aln_op(i, DG_ALN_MISMATCH, gc);
+        else if (nops == 1) res.op[1] = aln_op(i, DG_ALN_MISMATCH, gc);
+        ++nops;
+      }
+    }
+    if (mg != n) fault = 1;  // a Hamming hit's window is the string itself
+    res.info = ((u32)sc & 255u) | (n << 16);
+    if (nops > 2) fault = 1;
+    return res;
+  }
+  const u32 dm = mg - n + 2 * d;  // largest diagonal r - c kept; k = c - r + dm  (mg >= n - d, so dm >= d)
+  if (mg + d < n || dm + 2 * d + 1 > (u32)WB + 2 * d || dm >= (u32)WB) {  // (cannot happen for a hit of the <= d neighbourhood)
+    fault = 1;
+    res.info = 0;
+    return res;
+  }
+  // row 0: cost of cell (0, c) is c; columns left of 0 are dead
+  u32 S[NP];
+#pragma unroll
+  for (u32 j = 0; j < NP; ++j) S[j] = (((1u << dm) - 1u) | ~((1u << (dm + j + 1)) - 1u)) & WBM;
+  u32 v0 = 1u << dm;               // the bit of column 0 in the current row (0 once it has left the band)
+  u64 cn = 1ULL << (n + dm);       // the bit of column n in the current row (n + dm <= 42)
+#pragma unroll
+  for (int w = 0; w < 5; ++w) {
+    u64 gcur = gsh[w];
+    const u32 rend = mg < 8u * w + 8u ? mg : 8u * w + 8u;
+    for (u32 row = 8u * w + 1; row <= rend; ++row) {
+      const u32 gc = (u32)gcur & 255u;
+      gcur >>= 8;
+      v0 >>= 1;
+      cn >>= 1;
+      const u32 MM = ~(u32)(qmask_of(qm, gc) >> (row + 15u - dm)) & WBM;  // bit k: reference byte != q[c - 1]
+      const u32 inv = ((v0 ? v0 - 1u : 0u) | ~(u32)((cn << 1) - 1ULL)) & WBM;  // columns < 0 and > n
+      const u32 addv = ~(u32)cn;                                             // a vertical move costs 1 except in column n
+      u32 D[NP], U[NP], N[NP], H[NP];
+      D[0] = S[0] | MM;
+#pragma unroll
+      for (u32 j = 1; j < NP; ++j) D[j] = S[j] | (MM & S[j - 1]);
+      u32 up_prev = 0xFFFFFFFFu;
+#pragma unroll
+      for (u32 j = 0; j < NP; ++j) {
+        const u32 up = (S[j] >> 1) | TOP;
+        U[j] = up | (addv & up_prev);
+        up_prev = up;
+      }
+      U[0] = ((S[0] >> 1) | TOP) | addv;
+      u32 left = 0xFFFFFFFFu;  // "cost of the left neighbour + 1 >= j + 1" = its plane j - 1; plane 0 is all ones
+      u32 eqh = 0xFFFFFFFFu, eqv = 0xFFFFFFFFu;
+#pragma unroll
+      for (u32 j = 0; j < NP; ++j) {
+        H[j] = left;
+        N[j] = (((D[j] & U[j]) & H[j]) & ~v0) | inv;
+        left = (N[j] << 1) | 1u;
+        eqh &= ~(N[j] ^ H[j]);
+        eqv &= ~(N[j] ^ U[j]);
+      }
+      const u32 hb = eqh & WBM, vb = eqv & ~eqh & WBM;
+      tr[row * TRS] = (TR)(hb | (vb << VSH));
+#pragma unroll
+      for (u32 j = 0; j < NP; ++j) S[j] = N[j] & WBM;
+    }
+  }
+  u32 cost = 0;
+#pragma unroll
+  for (u32 j = 0; j < NP; ++j) cost += (S[j] >> (2 * d)) & 1u;  // cell (mg, n)
+  if (cost > d) {
+    fault = 1;
+    res.info = 0;
+    return res;
+  }
+  // traceback, from the end: trailing query-gap columns are dropped (_trailGap, hunter.h:69-77), then columns are counted from the
+  // end until every non-matching column has been met; the rest of the path is diagonal matches down to column 0, and the rows
+  // that remain there are the leading query-gap columns that only advance the coordinate (hunter.h:391-401)
+  u32 row = mg, col = n, e = 0;
+  bool seen_query = false;
+  while (col > 0 && (nops < cost || !seen_query)) {
+    u32 code;
+    if (row == 0) code = 1u;
+    else {
+      const u32 k = col - row + dm;  // inside the band on every optimal path
+      const u32 w = (u32)tr[row * TRS];
+      code = k < (u32)WB ? (((w >> k) & 1u) ? 1u : (((w >> (k + VSH)) & 1u) ? 2u : 0u)) : 1u;
+    }
+    if (code == 1) {  // gap in the reference row
+      push_op(e, DG_ALN_REF_GAP, 0);
+      ++e;
+      --col;
+      seen_query = true;
+    } else if (code == 2) {
+      if (seen_query) {
+        push_op(e, DG_ALN_QUERY_GAP, g_ch(row - 1));
+        ++e;
+      }
+      --row;
+    } else {
+      const u32 gc = g_ch(row - 1);
+      if (!((qmask_of(qm, gc) >> (col + 15u)) & 1ULL)) push_op(e, DG_ALN_MISMATCH, gc);
+      ++e;
+      --row;
+      --col;
+      seen_query = true;
+    }
+    if (nops > cost) break;
+  }
+  if (col > 0) {
+    if (row < col) fault = 1;
+    e += col;
+    row -= col;
+  }
+  const u32 lead = row, len = e;
+  if (nops != cost || nops > 2) fault = 1;
+  if (nops >= 1) res.op[nops >= 2 ? 1 : 0] = aln_op(len - 1 - found_at[0], found[0] & 255u, found[0] >> 8);
+  if (nops >= 2) res.op[0] = aln_op(len - 1 - found_at[1], found[1] & 255u, found[1] >> 8);
+  res.info = ((u32)(-(int)cost) & 255u) | (lead << 8) | (len << 16);
+  return res;
+}
+
+}  // namespace dg

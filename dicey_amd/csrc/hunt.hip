@@ -32,6 +32,7 @@
 #include "hunt_internal.hpp"
 #include "iupac.hpp"
 #include "nbhd_host.hpp"
+#include "band_bits.hpp"
 
 namespace dg {
 
@@ -111,6 +112,7 @@ __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n
   u64 s = b.qoff[q], e = b.qoff[q + 1];
   u32 m = (u32)(e - s), bad = 0, flags = 0, generic = 0;
   u64 pk_fw = 0, pk_rv = 0;  // 2-bit packed strands, q[i] at bits 2(m-1-i) (meaningful for m <= 32 without N)
+  u32 pm[4] = {0u, 0u, 0u, 0u};  // position masks of the forward strand: bit i of pm[x] <=> q[i] is base x (m <= 32; an N sets none)
   constexpr u32 NREG = 40;   // queries up to this length travel through registers
   if (m <= NREG) {
     constexpr int NW = NREG / 8 + 1;
@@ -134,6 +136,10 @@ __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n
         b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);  // util.h:54-91,110-114
         pk_fw = (pk_fw << 2) | (code & 3u);
         pk_rv |= (u64)((3u - code) & 3u) << (2 * (i & 31u));
+        if (i < 32) {
+#pragma unroll
+          for (u32 x = 0; x < 4; ++x) pm[x] |= (u32)(code == x) << i;
+        }
       }
     }
   } else {
@@ -174,6 +180,14 @@ __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n
     if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
     if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
     b.ginfo[2 * q + strand] = gi;
+    // the banded verify takes the query as position masks (band_align_bits); the reverse strand's character j is the complement
+    // of the forward strand's character m - 1 - j
+    if (m <= 32 && m >= 1) {
+      uint4 pq;
+      if (!strand) pq = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+      else pq = make_uint4(__brev(pm[3]) >> (32 - m), __brev(pm[2]) >> (32 - m), __brev(pm[1]) >> (32 - m), __brev(pm[0]) >> (32 - m));
+      b.gpeq[2 * q + strand] = pq;
+    }
     generic += (gi.m != 0 && !(gi.d_win & 512u));
   }
   // groups the flat distance-1 kernel does not take: the host launches the generic kernels for them (and repeats a batch it
@@ -299,165 +313,8 @@ DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m
 // exactly those of k_search<INDEL,1>: deletions, substitutions by another base and insertions between two characters
 // (neighbors.h:51-78; a leading insertion is dominated by the string without it, a trailing one is not generated), and in
 // Hamming mode the sequence itself.  Queries with an N, longer than 31 nt or shorter than K+1 stay with k_search.
-template <bool INDEL>
-__global__ void __launch_bounds__(256) k_search1(FmView f, Batch b, SearchOut o, u32 ipg) {
-  __shared__ unsigned long long q_code[256], q_rest[256];
-  __shared__ u32 q_gid[256], q_op[256];
-  __shared__ u32 q_n, c_probe, c_look;
-  // operations of one position: INDEL 0 = delete, 1-3 = substitute by (old + op) & 3, 4-7 = insert base op-4;
-  // Hamming 0 = the sequence itself (position 1 only), 1-3 = substitute
-  constexpr u32 NOPS = INDEL ? 8u : 4u;
-  if (threadIdx.x == 0) {
-    q_n = 0;
-    c_probe = 0;
-    c_look = 0;
-  }
-  __syncthreads();
-  // lane -> (group, item): one division per workgroup on the scalar unit, a short subtract loop per lane (the host keeps
-  // the launch below 2^32 lanes)
-  const u32 first = blockIdx.x * 256u;
-  u32 gid = first / ipg, item = first % ipg + threadIdx.x;
-  while (item >= ipg) {
-    item -= ipg;
-    ++gid;
-  }
-  const u32 K = f.K;
-  const u64 kmask = (1ULL << (2 * K)) - 1;
-  bool cand = false, probed = false, looked = false;
-  u64 code = 0, rest = 0;
-  u32 opword = 0;  // bits 0-27 Leaf::ops[0], bit 28: one op recorded
-  u32 nrest = 0;
-  if (gid < 2 * b.nq) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);  // the whole record in one load
-    const u64 qpk = (u64)raw.y << 32 | raw.x;
-    const u32 m = raw.z, d_win = raw.w;
-    const u32 pos = item / NOPS + 1, op = item % NOPS;  // the operation sits right of q[0..pos)
-    if (m && (d_win & 512u) && pos <= m) {
-      const u32 R = m - pos;  // unchanged characters right of it
-      const u64 low = qpk & ((1ULL << (2 * R)) - 1);
-      const u32 old = (u32)(qpk >> (2 * R)) & 3u;
-      u64 s_pk;
-      u32 mlen, kind = OP_S, c = (old + op) & 3u;
-      if (op == 0) {
-        if (INDEL) {
-          kind = OP_D;
-          c = 0;
-          s_pk = low | ((qpk >> (2 * R + 2)) << (2 * R));
-          mlen = m - 1;
-          cand = true;
-        } else {  // the sequence itself belongs to the Hamming set
-          s_pk = qpk;
-          mlen = m;
-          cand = pos == 1;
-        }
-      } else if (op < 4) {
-        s_pk = qpk ^ ((u64)(old ^ c) << (2 * R));  // neighbors.h:63: a different base
-        mlen = m;
-        cand = true;
-      } else {
-        kind = OP_I;
-        c = op - 4;
-        s_pk = low | ((u64)c << (2 * R)) | ((qpk >> (2 * R)) << (2 * R + 2));
-        mlen = m + 1;
-        cand = pos < m;  // neighbors.h:51: nothing after the last character
-      }
-      if (INDEL || op) opword = ((pos << 4) | (kind << 2) | c) | (1u << 28);
-      if (cand) {
-        code = s_pk & kmask;
-        rest = s_pk >> (2 * K);
-        nrest = mlen - K;
-        const u32 K2 = f.kf2.k;
-        if (f.kf2.nr && mlen >= K2) {  // the long filter first: nearly nothing that does not occur gets past it
-          probed = true;
-          cand = kf_present(f.kf2, s_pk & ((1ULL << (2 * K2)) - 1), R < K2 ? R : K2 - 1);
-        } else if (f.kf.nr) {
-          probed = true;
-          cand = kf_present(f.kf, code, R < K ? R : K - 1);
-        } else {
-          looked = true;
-          const uint2 iv = f.ktab[code];
-          cand = iv.x < iv.y;
-          code = (u64)iv.y << 32 | iv.x;
-          rest |= 1ULL << 55;  // `code` already holds the interval
-        }
-      }
-    }
-  }
-  // pack the survivors of the workgroup into its first lanes
-  const unsigned long long mask = __ballot(cand);
-  const u32 lane = threadIdx.x & 63;
-  const u32 np = (u32)__popcll(__ballot(probed)), nl = (u32)__popcll(__ballot(looked));
-  u32 base = 0;
-  if (lane == 0) {
-    if (mask) base = atomicAdd(&q_n, (u32)__popcll(mask));
-    if (np) atomicAdd(&c_probe, np);
-    if (nl) atomicAdd(&c_look, nl);
-  }
-  base = __shfl(base, 0);
-  if (cand) {
-    const u32 at = base + (u32)__popcll(mask & ((1ULL << lane) - 1));
-    q_code[at] = code;
-    q_rest[at] = rest | ((u64)nrest << 56);
-    q_gid[at] = gid;
-    q_op[at] = opword;
-  }
-  __syncthreads();
-  const u32 shard = blockIdx.x & (NSHARD - 1);
-  if (threadIdx.x == 0) {
-    if (c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
-    if (c_look) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)c_look);
-  }
-  const u32 qn = q_n;
-  if ((threadIdx.x & ~63u) >= qn) return;  // this wavefront has no survivor to work on
-  u32 steps = 0, nlook = 0;
-  const bool work = threadIdx.x < qn;
-  if (work) {
-    const u64 cd = q_code[threadIdx.x];
-    u64 rs = q_rest[threadIdx.x];
-    const u32 g = q_gid[threadIdx.x], ow = q_op[threadIdx.x];
-    u32 n = (u32)(rs >> 56);
-    const bool have_iv = (rs >> 55) & 1;
-    rs &= (1ULL << 55) - 1;
-    u32 lo, hi;
-    if (!have_iv) {
-      const uint2 iv = f.ktab[cd];
-      lo = iv.x;
-      hi = iv.y;
-      ++nlook;
-    } else {
-      lo = (u32)cd;
-      hi = (u32)(cd >> 32);
-    }
-    while (n && lo < hi) {
-      bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
-      rs >>= 2;
-      --n;
-      ++steps;
-    }
-    if (lo < hi) {
-      const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
-      const u32 slot = atomicAdd(o.grp_cnt + g, 1u);
-      if (at < o.shard_cap) {
-        Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
-        lf->qs = g;
-        lf->slot = slot;
-        lf->lo = lo;
-        lf->hi = hi;
-        lf->nops = ow >> 28;
-        lf->ops[0] = ow & 0x0FFFFFFFu;
-#pragma unroll
-        for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
-      }
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) steps += __shfl_xor(steps, off);
-  const u32 nwork = (u32)__popcll(__ballot(nlook != 0));
-  if (lane == 0) {
-    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
-    if (nwork) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nwork);
-  }
-}
-
+// (r02's first flat form gave every (position, operation) its own lane — ~200 vector instructions per candidate; it was
+// removed in r04.  What follows is the form that replaced it.)
 // The same search with one lane per (query, strand, POSITION): the lane builds all eight strings of its position from the
 // shared pieces (the characters right of the position, the query shifted by none / one character) in a fully unrolled loop —
 // the operation is a compile-time constant in every iteration, so nothing diverges — and issues its eight filter probes
@@ -651,16 +508,27 @@ struct FlatSel {
   u32* selbase;    // [2 nq] first Sel slot of a group served here (0xFFFFFFFF: generic path, grp_off based)
   u32* nsel;       // [2 nq]
 };
-static constexpr u32 FUSED_LCAP = 512;  // 15 KB of LDS per workgroup: eight wavefronts per SIMD stay resident (1 024 left six)
+// r04: (i) the three wavefronts that have nothing to do behind the probe phase END there instead of waiting at the barrier behind
+// the dense phase (the usual workgroup has ~40 survivors, one wavefront's worth): the r04a counters showed the kernel resident at
+// 6-7 of 8 wavefronts per SIMD, two thirds of the wave cycles waiting — three of four of those slots held by wavefronts parked at
+// that barrier; (ii) the LDS list is dynamic (lcap entries, 256 by default: 5.6 KB, 512 when the previous batch's workgroups held
+// more than ~64 strings on average) and the survivor queue holds 512 entries, filled in rounds when more survive, so that the
+// freed slots can be taken by new workgroups.
+static constexpr u32 FUSED_LCAP = 512;   // largest LDS list
+static constexpr u32 FUSED_QCAP = 512;   // survivor queue entries per round
+static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u); }
 template <bool INDEL>
 __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap) {
-  __shared__ u16 q_ent[2048];  // lane | operation << 8
+  __shared__ u16 q_ent[FUSED_QCAP];  // lane | operation << 8
   __shared__ u32 q_n, c_probe, l_n, s_total, s_base;
-  __shared__ unsigned long long l_key[FUSED_LCAP];
-  __shared__ u32 l_lo[FUSED_LCAP], l_hi[FUSED_LCAP];
-  __shared__ u16 l_meta[FUSED_LCAP];  // length | local group << 6 | alive << 15
-  __shared__ u16 l_pos[FUSED_LCAP], l_ord[FUSED_LCAP];
   __shared__ u32 g_cnt[16], g_start[16], g_alive[16], g_base[16];
+  DG_DYNAMIC_LDS(dyn);  // the list of occurring strings: lcap entries
+  unsigned long long* const l_key = reinterpret_cast<unsigned long long*>(dyn);
+  u32* const l_lo = reinterpret_cast<u32*>(dyn + (size_t)lcap * 8);
+  u32* const l_hi = l_lo + lcap;
+  u16* const l_meta = reinterpret_cast<u16*>(l_hi + lcap);  // length | local group << 6 | alive << 15
+  u16* const l_pos = l_meta + lcap;
+  u16* const l_ord = l_pos + lcap;
   constexpr u32 NOPS = INDEL ? 8u : 4u;
   if (threadIdx.x == 0) {
     q_n = 0;
@@ -674,7 +542,7 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
   const u32 lane = threadIdx.x & 63;
   const u32 ngrp2 = (u32)(2 * b.nq);
   const u32 g_first = blockIdx.x * gpw;
-  u32 mask8 = 0, nprobe = 0;
+  u32 mask_all = 0, nprobe = 0;
   {
     const u32 lg = (threadIdx.x * magic) >> 16, pos = threadIdx.x - lg * ipg + 1;
     const u32 gid = g_first + lg;
@@ -710,7 +578,7 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
 #pragma unroll
         for (u32 op = 0; op < NOPS; ++op) {
           const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
-          mask8 |= (((valid >> op) & 1u) & present) << op;
+          mask_all |= (((valid >> op) & 1u) & present) << op;
         }
         nprobe = (u32)__popc(probe);
       }
@@ -718,20 +586,11 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
   }
   for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
   if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
-  while (mask8) {
-    const u32 op = (u32)__ffs((int)mask8) - 1u;
-    mask8 &= mask8 - 1;
-    const u32 at = atomicAdd(&q_n, 1u);
-    q_ent[at] = (u16)(threadIdx.x | (op << 8));
-  }
-  __syncthreads();
   const u32 shard = blockIdx.x & (NSHARD - 1);
-  if (threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
-  const u32 qn = q_n;
   u32 steps = 0, nlook = 0, nhead = 0;
-  // the dense phase: survivors rebuilt, table entry, extension; occurring strings to the LDS list (to_lds) or, on the second pass of
-  // a workgroup whose list overflowed, to the generic leaf buffer exactly like k_search1p
-  auto dense = [&](const bool to_lds) {
+  // the dense phase over the queue's first qn entries: survivors rebuilt, table entry, extension; occurring strings to the LDS list
+  // (to_lds) or, for a workgroup whose list overflowed, to the generic leaf buffer exactly like k_search1p
+  auto dense = [&](const bool to_lds, const u32 qn) {
     for (u32 e0 = 0; e0 < qn; e0 += 256) {
       if (e0 + (threadIdx.x & ~63u) >= qn) break;
       const u32 e = e0 + threadIdx.x;
@@ -762,7 +621,7 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
         if (lo < hi) {
           if (to_lds) {
             const u32 at = atomicAdd(&l_n, 1u);
-            if (at < FUSED_LCAP) {
+            if (at < lcap) {
               l_key[at] = s_pk;
               l_lo[at] = lo;
               l_hi[at] = hi;
@@ -787,7 +646,38 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
       }
     }
   };
-  dense(true);
+  // survivors enter the queue in rounds of at most FUSED_QCAP; `gone`: this wavefront ended behind the probe phase
+  bool gone = false, single_round = false;
+  auto rounds = [&](const bool to_lds, const bool may_leave) {
+    u32 rem = mask_all;
+    for (u32 round = 0;; ++round) {
+      while (rem) {
+        const u32 op = (u32)__ffs((int)rem) - 1u;
+        const u32 at = atomicAdd(&q_n, 1u);
+        if (at >= FUSED_QCAP) break;  // next round
+        rem &= rem - 1;
+        q_ent[at] = (u16)(threadIdx.x | (op << 8));
+      }
+      __syncthreads();
+      const u32 raw_n = q_n, qn = raw_n < FUSED_QCAP ? raw_n : FUSED_QCAP;
+      if (round == 0) {
+        if (to_lds && threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
+        single_round = raw_n <= FUSED_QCAP;
+        // one wavefront's worth of survivors and nothing left over: the other wavefronts end here, their slots go to the next workgroup
+        if (may_leave && raw_n <= 64 && threadIdx.x >= 64) {
+          gone = true;
+          return;
+        }
+      }
+      dense(to_lds, qn);
+      if (raw_n <= FUSED_QCAP) return;
+      __syncthreads();
+      if (threadIdx.x == 0) q_n = 0;
+      __syncthreads();
+    }
+  };
+  rounds(true, true);
+  if (gone) return;
   for (int off = 32; off > 0; off >>= 1) {
     steps += __shfl_xor(steps, off);
     nlook += __shfl_xor(nlook, off);
@@ -800,14 +690,19 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
   }
   __syncthreads();
   const u32 nl = l_n;
-  if (nl > lcap) {  // rare: this workgroup's groups take the generic path (selbase stays "generic"); lcap <= FUSED_LCAP
-    dense(false);
+  if (nl > lcap) {  // this workgroup's groups take the generic path (selbase stays "generic")
+    if (single_round) dense(false, q_n < FUSED_QCAP ? q_n : FUSED_QCAP);  // the queue still holds every survivor
+    else {
+      __syncthreads();
+      if (threadIdx.x == 0) q_n = 0;
+      __syncthreads();
+      rounds(false, false);
+    }
     return;
   }
   // ---- select, per group, in LDS.  Up to 64 strings (the usual workgroup: 12 groups of two or three): by the first wavefront
-  // alone — the other three are done, a barrier only waits for wavefronts that have not ended, and their slots go to the next
-  // workgroup's probes while a few dozen strings are sorted here.  More strings (repeat families: hundreds per workgroup): all four
-  // wavefronts share the pair loops (one wavefront alone took 0.74 instead of 0.51 ms per step on the repeats genome).
+  // alone.  More strings (repeat families: hundreds per workgroup): all four wavefronts share the pair loops (one wavefront alone
+  // took 0.74 instead of 0.51 ms per step on the repeats genome).
   const u32 sstep = nl <= 64 ? 64u : 256u;
   if (threadIdx.x >= sstep) return;
   for (u32 i = threadIdx.x; i < nl; i += sstep) l_pos[i] = (u16)atomicAdd(&g_cnt[(l_meta[i] >> 6) & 15u], 1u);
@@ -896,133 +791,8 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
   }
 }
 
-// k_search1p cut in two kernels.  Its profile (r02): 5.0 M fabric reads and 47 M vector instructions in 0.28 ms — neither
-// the line rate nor the issue rate, but the chain "record, probe, barrier, record, table entry, 3-5 extensions" that every
-// workgroup walks once with a handful of survivors.  k_probe1 is the first half without barrier or LDS: survivors leave
-// as 32-bit (group, position, operation) entries in a sharded queue in HBM (one atomic per wavefront); k_finish1 is the second
-// half, one lane per queued survivor, so the whole batch's chains are in flight together.
-template <bool INDEL>
-__global__ void __launch_bounds__(256) k_probe1(FmView f, Batch b, Counters* ctr, u32* squeue, u32 scap_log2, u32 ipg, u32 magic, u32 dbg) {
-  constexpr u32 NOPS = INDEL ? 8u : 4u;
-  const u32 first = blockIdx.x * 256u;
-  const u32 g_first = first / ipg, r_first = first - g_first * ipg;
-  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
-  const u64 kmask = (1ULL << (2 * K)) - 1;
-  const u32 lane = threadIdx.x & 63;
-  const u32 ngrp2 = (u32)(2 * b.nq);
-  u32 mask8 = 0, nprobe = 0;
-  const u32 t = r_first + threadIdx.x, qd = (t * magic) >> 16;
-  const u32 gid = g_first + qd, pos = t - qd * ipg + 1;
-  if (gid < ngrp2) {
-    // dbg: timing experiments only (DICEY_DBG_PROBE): 1 = no filter loads, 2 = no queue writes, 4 = no record load
-    uint4 raw;
-    if (dbg & 4u) raw = make_uint4(gid * 2654435761u, gid * 40503u, ipg, 512u | 256u | 1u);
-    else raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
-    const u64 qpk = ((u64)raw.y << 32 | raw.x) & ((1ULL << (2 * raw.z)) - 1);
-    const u32 m = raw.z, d_win = raw.w;
-    if (m && (d_win & 512u) && pos <= m) {
-      const u32 R = m - pos;
-      const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
-      const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
-      const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
-#pragma unroll
-      for (u32 op = 0; op < NOPS; ++op) {
-        u64 s_pk;
-        u32 mlen, ow;
-        if (cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow)) {
-          bool pass = true;
-          if (dbg & 1u) {
-            pass = ((u32)(s_pk * 0x9E3779B97F4A7C15ULL >> 58)) == 0u;  // one in 64, no load
-          } else if (K2 && mlen >= K2) {
-            pass = kf_test(c2, s_pk & mask2);
-            ++nprobe;
-          } else if (f.kf.nr) {
-            pass = kf_test(c1, s_pk & kmask);
-            ++nprobe;
-          }
-          mask8 |= (u32)pass << op;
-        }
-      }
-    }
-  }
-  const u32 shard = blockIdx.x & (NSHARD - 1);
-  // queue space for the wavefront's survivors with one atomic: inclusive scan of the lanes' counts
-  const u32 mine = (u32)__popc(mask8);
-  u32 incl = mine;
-  for (int off = 1; off < 64; off <<= 1) {
-    const u32 v = __shfl_up(incl, off);
-    if ((int)lane >= off) incl += v;
-  }
-  const u32 total = __shfl(incl, 63);
-  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
-  u32 base = 0;
-  if (dbg & 2u) return;
-  if (lane == 63) {
-    if (total) base = atomicAdd(&ctr->surv_cnt[shard], total);
-    if (nprobe) atomicAdd(&ctr->probes[shard], (unsigned long long)nprobe);
-  }
-  base = __shfl(base, 63);
-  u32 at = base + incl - mine;
-  const u32 cap = 1u << scap_log2;
-  while (mask8) {
-    const u32 op = (u32)__ffs((int)mask8) - 1u;
-    mask8 &= mask8 - 1;
-    if (at < cap) squeue[((u64)shard << scap_log2) + at] = (gid << 8) | (pos << 3) | op;
-    ++at;
-  }
-}
-template <bool INDEL>
-__global__ void __launch_bounds__(256) k_finish1(FmView f, Batch b, SearchOut o, const u32* squeue, u32 scap_log2) {
-  const u64 t = (u64)blockIdx.x * 256u + threadIdx.x;
-  const u32 qshard = (u32)(t >> scap_log2), off = (u32)t & ((1u << scap_log2) - 1);
-  const u32 have = o.ctr->surv_cnt[qshard];
-  u32 steps = 0, nlook = 0;
-  const u32 shard = blockIdx.x & (NSHARD - 1);
-  if (have <= (1u << scap_log2) && off < have) {  // an overflowing queue repeats the batch (k_leaf_overflow)
-    const u32 ent = squeue[t], gid = ent >> 8, pos = (ent >> 3) & 31u, op = ent & 7u;
-    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
-    u64 s_pk;
-    u32 mlen, ow;
-    (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
-    const u32 K = f.K;
-    const uint2 iv = f.ktab[s_pk & ((1ULL << (2 * K)) - 1)];
-    ++nlook;
-    u32 lo = iv.x, hi = iv.y;
-    u64 rs = s_pk >> (2 * K);
-    u32 n = mlen - K;
-    while (n && lo < hi) {
-      bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
-      rs >>= 2;
-      --n;
-      ++steps;
-    }
-    if (lo < hi) {
-      const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
-      const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
-      if (at < o.shard_cap) {
-        Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
-        lf->qs = gid;
-        lf->slot = slot;
-        lf->lo = lo;
-        lf->hi = hi;
-        lf->nops = ow >> 28;
-        lf->ops[0] = ow & 0x0FFFFFFFu;
-#pragma unroll
-        for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
-      }
-    }
-  }
-  if (__ballot(nlook != 0) == 0) return;
-  for (int off2 = 32; off2 > 0; off2 >>= 1) {
-    steps += __shfl_xor(steps, off2);
-    nlook += __shfl_xor(nlook, off2);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
-    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
-  }
-}
-
+// (r02 also measured k_search1p cut in two kernels — probe, then finish from a survivor queue in HBM: 0.21 + 0.19 ms against 0.25 ms
+// fused; removed in r04.)
 // ------------------------------------------------------------------------------------------------------------
 // Distance 2 (edit mode) laid out flat as well.  r02 profile of the state machine at d = 2: 124 ms per 100 000 20-mers,
 // 1.7 G filter probes + 0.36 G table reads + 0.59 G interval extensions — issue bound like its d = 1 form was, and most of
@@ -1061,162 +831,8 @@ DG_DEV void apply_edit(u64 pk, u32 len, u32 pos, u32 op, u64& out, u32& olen, u3
   }
 }
 
-template <int U>
-__global__ void __launch_bounds__(256) k_search2(FmView f, Batch b, SearchOut o) {
-  constexpr u32 QCAP = 256 * U + 256;
-  __shared__ unsigned long long q_pk[QCAP];
-  __shared__ u32 q_meta[QCAP];  // bits 0-5 string length, 6-14 first operation (pos:5, kind:2, c:2), 15-23 second operation
-  __shared__ u32 q_n, g_slots, c_probe;
-  const u32 gid = blockIdx.x;
-  const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
-  const u32 m = raw.z, d_win = raw.w;
-  if (!m || !(d_win & 1024u)) return;  // uniform for the workgroup
-  const u64 qpk = (u64)raw.y << 32 | raw.x;
-  if (threadIdx.x == 0) {
-    q_n = 0;
-    g_slots = 0;
-    c_probe = 0;
-  }
-  __syncthreads();
-  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
-  const u64 kmask = (1ULL << (2 * K)) - 1;
-  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const u32 op1 = lane & 7u, op2 = lane >> 3;
-  const u32 npairs = m * (m + 1) / 2 - 1;  // p2 = 1..m-1, p1 = p2..m
-  const u32 shard = blockIdx.x & (NSHARD - 1);
-  u32 steps = 0, nlook = 0;
-  for (u32 base = 0; base < npairs; base += 4 * U) {
-    bool cand[U];
-    u64 pk[U];
-    u32 meta[U];
-    u32 nprobe = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const u32 w = base + (u32)u * 4 + wave;
-      cand[u] = false;
-      pk[u] = 0;
-      meta[u] = 0;
-      if (w < npairs) {
-        // w -> (p2, p1): rows p2 = 1, 2, ... hold m, m-1, ... pairs; row a = p2-1 starts at a(2m+1-a)/2
-        const float tm = (float)(2 * m + 1);
-        int a = (int)((tm - sqrtf(tm * tm - 8.0f * (float)w)) * 0.5f);
-        if (a < 0) a = 0;
-        if (a > (int)m - 2) a = (int)m - 2;
-        while (a > 0 && (u32)a * (2 * m + 1 - (u32)a) / 2 > w) --a;
-        while ((u32)(a + 1) * (2 * m - (u32)a) / 2 <= w) ++a;
-        const u32 p2 = (u32)a + 1, p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
-        const bool ins1 = op1 >= 4;
-        // the first operation must leave p2 characters to its left, and nothing is inserted after the last character
-        const bool ok = (p1 > p2 || ins1) && !(p1 == m && ins1);
-        if (ok) {
-          u64 s1, s2;
-          u32 l1, l2, w1, w2;
-          apply_edit(qpk, m, p1, op1, s1, l1, w1);
-          apply_edit(s1, l1, p2, op2, s2, l2, w2);
-          const u32 R1 = m - p1;
-          bool pass = true;
-          if (K2 && l2 >= K2) {
-            pass = kf_present(f.kf2, s2 & ((1ULL << (2 * K2)) - 1), R1 < K2 ? R1 : K2 - 1);
-            ++nprobe;
-          } else if (f.kf.nr) {
-            pass = kf_present(f.kf, s2 & kmask, R1 < K ? R1 : K - 1);
-            ++nprobe;
-          }
-          cand[u] = pass;
-          pk[u] = s2;
-          meta[u] = l2 | ((w1 & 511u) << 6) | ((w2 & 511u) << 15);
-        }
-      }
-    }
-    // push the survivors: one LDS atomic per wavefront
-    unsigned long long mk[U];
-    u32 tot = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      mk[u] = __ballot(cand[u]);
-      tot += (u32)__popcll(mk[u]);
-    }
-    for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
-    u32 at = 0;
-    if (lane == 0) {
-      if (tot) at = atomicAdd(&q_n, tot);
-      if (nprobe) atomicAdd(&c_probe, nprobe);
-    }
-    at = __shfl(at, 0);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (cand[u]) {
-        const u32 k = at + (u32)__popcll(mk[u] & ((1ULL << lane) - 1));
-        q_pk[k] = pk[u];
-        q_meta[k] = meta[u];
-      }
-      at += (u32)__popcll(mk[u]);
-    }
-    __syncthreads();  // the pushes are in place
-    u32 n = q_n;
-    __syncthreads();  // everybody has read the count before lane 0 rewrites it
-    const bool last = base + 4 * U >= npairs;
-    // pop 256 at a time while the stack holds that many (everything at the end); nothing is pushed meanwhile, so the rounds
-    // need no barrier between them and every lane follows the count on its own
-    while (n && (n >= 256 || last)) {
-      const u32 cnt = n < 256 ? n : 256u, start = n - cnt;
-      bool leaf = false;
-      u32 lo = 0, hi = 0, mt = 0;
-      if (threadIdx.x < cnt) {
-        const u64 sp = q_pk[start + threadIdx.x];
-        mt = q_meta[start + threadIdx.x];
-        const uint2 iv = f.ktab[sp & kmask];
-        ++nlook;
-        lo = iv.x;
-        hi = iv.y;
-        u64 rs = sp >> (2 * K);
-        u32 nr = (mt & 63u) - K;
-        while (nr && lo < hi) {
-          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
-          rs >>= 2;
-          --nr;
-          ++steps;
-        }
-        leaf = lo < hi;
-      }
-      const unsigned long long lm = __ballot(leaf);
-      u32 lbase = 0;
-      if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
-      lbase = __shfl(lbase, 0);
-      if (leaf) {
-        const u32 slot = atomicAdd(&g_slots, 1u);
-        const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
-        if (la < o.shard_cap) {
-          Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
-          lf->qs = gid;
-          lf->slot = slot;
-          lf->lo = lo;
-          lf->hi = hi;
-          lf->nops = 2;
-          lf->ops[0] = (mt >> 6) & 511u;
-          lf->ops[1] = (mt >> 15) & 511u;
-#pragma unroll
-          for (int k = 2; k < (int)DMAX; ++k) lf->ops[k] = 0u;
-        }
-      }
-      n = start;
-    }
-    if (threadIdx.x == 0) q_n = n;
-    __syncthreads();  // the popped part of the stack may be overwritten from here on
-  }
-  if (threadIdx.x == 0) {
-    if (g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
-    if (c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    steps += __shfl_xor(steps, off);
-    nlook += __shfl_xor(nlook, off);
-  }
-  if (lane == 0) {
-    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
-    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
-  }
-}
+// (the lane-per-operation-pair kernel described above — k_search2<U>, r02: 17.4 ms — was removed in r04; k_search2p below is the
+// same enumeration with one lane per pair of POSITIONS)
 
 // k_search2 with one lane per PAIR OF POSITIONS: the lane walks the 8 x 8 operations in two fully unrolled loops (every
 // operation is a compile-time constant where it is applied, the eight probes of an inner loop are independent loads), skips
@@ -1596,27 +1212,7 @@ struct Summary {
   unsigned long long fused_leaves;          // occurring strings k_search1s kept in LDS (they never became Leaf records)
   unsigned long long n_generic;             // groups searched outside the flat distance-1 kernel (k_prepare)
 };
-__global__ void k_summary(const Counters* ctr, const u64* nhits, Summary* out) {  // NSHARD lanes
-  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= NSHARD) return;
-  atomicAdd(&out->nleaf, (unsigned long long)ctr->leaf_cnt[k]);
-  atomicMax(&out->worst_shard, (unsigned long long)ctr->leaf_cnt[k]);
-  if (ctr->steps[k]) atomicAdd(&out->steps, ctr->steps[k]);
-  if (ctr->lookups[k]) atomicAdd(&out->lookups, ctr->lookups[k]);
-  if (ctr->sa_reads[k]) atomicAdd(&out->sa_reads, ctr->sa_reads[k]);
-  if (ctr->win_bytes[k]) atomicAdd(&out->win_bytes, ctr->win_bytes[k]);
-  if (ctr->probes[k]) atomicAdd(&out->probes, ctr->probes[k]);
-  atomicMax(&out->worst_surv, (unsigned long long)ctr->surv_cnt[k]);
-  atomicMax(&out->worst_sel, (unsigned long long)ctr->sel_cnt[k]);
-  if (k == 0) {
-    out->n_generic = ctr->pad_[6];
-    out->nhits = *nhits;
-    out->overflow = ctr->overflow;
-    out->refused = ctr->pad_[1];
-    out->too_long = ctr->pad_[2];
-  }
-}
-// Production form: totals straight into the pinned host record (no atomics over the bus, no separate copy); the host reads it
+// Totals straight into the pinned host record (no atomics over the bus, no separate copy); the host reads it
 // after the batch's single stream synchronisation.  The batch's last kernel: it also leaves the counters ZEROED for the next
 // batch (which then needs no memset in front).  One workgroup.
 // (r03 tried to run this in "the workgroup of the verify kernel that finishes last": the device-scope fence every workgroup needs
@@ -2111,7 +1707,12 @@ __global__ void k_take(Batch b, const u64* grp_off, const u32* selbase, u64 flat
     }
   }
   qhits[q] = (u32)hits;
-  if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
+  u32 fl = b.qflags[q];
+  if (hits >= b.max_locations && !(fl & DG_Q_TOO_SHORT)) {  // hunter.h:434
+    fl |= DG_Q_MAX_MATCHES;
+    b.qflags[q] = fl;
+  }
+  if (b.qinfo) b.qinfo[q] = (fl & 255u) | ((b.qdist[q] & 255u) << 8) | (b.qnondna[q] << 16);  // compact results (dicey_gpu.h DG_QINFO_*)
 }
 
 // count mode: occurrences of all kept strings of a (query, strand) group
@@ -2245,7 +1846,12 @@ __global__ void k_select(Batch b, const Leaf* grouped, const u64* grp_off, Sel* 
     nsel[2 * q + strand] = ns;
   }
   qhits[q] = (u32)hits;
-  if (hits >= b.max_locations && !(b.qflags[q] & DG_Q_TOO_SHORT)) b.qflags[q] |= DG_Q_MAX_MATCHES;  // hunter.h:434
+  u32 fl = b.qflags[q];
+  if (hits >= b.max_locations && !(fl & DG_Q_TOO_SHORT)) {  // hunter.h:434
+    fl |= DG_Q_MAX_MATCHES;
+    b.qflags[q] = fl;
+  }
+  if (b.qinfo) b.qinfo[q] = (fl & 255u) | ((b.qdist[q] & 255u) << 8) | (b.qnondna[q] << 16);  // compact results (dicey_gpu.h DG_QINFO_*)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2762,7 +2368,12 @@ struct VerifyArgs {
   u32* ops;          // [nhits * ops_per_hit] compact alignment description (ALN_OP_NONE = unused)
   u32 ops_per_hit;   // the batch's largest effective distance
   u32 debug;              // DICEY_DBG_VERIFY (measurements only: 1 = skip the alignments, 2 = skip the context reads; results are wrong)
+  u32* chits;             // != nullptr: compact records (dicey_gpu.h ABI 5: position, meta, ops) instead of dg_hit + ops
 };
+// the compact record's second word (dicey_gpu.h DG_CHIT_*): delta = DnaHit::start - 1 - (position - start of its sequence)
+DG_DEV u32 chit_meta(int score, u32 strand, int delta, u32 aln_len) {
+  return ((u32)(-score) & 15u) | ((strand & 1u) << 4) | (((u32)(delta + 32) & 127u) << 5) | (aln_len << 16);
+}
 
 // SMALL = true (all queries of the batch <= 32 nt): the DP row lives in registers (columns fully unrolled) and each
 // row's trace is one 64-bit word (2 bits per column 1..32; column 0 is implied: vertical below the origin).
@@ -3065,14 +2676,6 @@ __global__ void __launch_bounds__(256) k_verify(FmView f, Batch b, VerifyArgs a,
 // What leaves is the COMPACT form of the alignment (ABI 4): the kept rows are the query strand's characters with at most
 // |score| <= d columns that are not a match, so a hit carries `ops_per_hit` = d 32-bit words {column, kind, reference byte}
 // instead of two rows of characters (68 -> 24 bytes per hit at distance 1); dg_hit_rows() rebuilds the rows.
-static constexpr u32 ALN_OP_NONE = 0xFFFFFFFFu;
-DG_DEV u32 aln_op(u32 col, u32 kind, u32 byte) { return (col & 0xFFFFu) | (kind << 16) | (byte << 24); }  // kind: DG_ALN_*
-struct AlnRes {
-  u32 info;  // (score & 255) | leading query-gap columns << 8 | kept columns << 16
-  u32 op[2];
-  u32 pre_eff;  // context characters in front of the string that survived the '\n' trimming (the lane-per-hit path needs it for hunter.h:382)
-};
-
 template <int WB, typename TR>
 DG_DEV AlnRes band_align(const FmView& f, const Batch& b, const HitSeed sd, TR* tr /* [row * 256] */, u8* lds_g /* 72 bytes */, u32& fault) {
   const u64 q = sd.qs >> 1;
@@ -3313,7 +2916,7 @@ DG_DEV AlnRes band_align(const FmView& f, const Batch& b, const HitSeed sd, TR* 
   return res;
 }
 
-// Dynamic LDS: max(hash table, rows * 256 trace words + 256 * 72 window / query bytes), rows = maxlen + 3 d + 2 of the batch.
+// Dynamic LDS: max(hash table, rows * 256 trace words), rows = maxlen + 3 d + 2 of the batch.
 template <int WB, int CH>
 DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs& a, Counters* ctr, u32 rows) {
   using TR = typename std::conditional<(WB <= 8), u16, u32>::type;
@@ -3461,12 +3064,17 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
   if (SHARE) __syncthreads();  // the table's memory becomes the trace
   // ---- phase 2: per class
   TR* const tr = reinterpret_cast<TR*>(u_lds) + tid;
-  u8* const lds_g = u_lds + rows * 256 * sizeof(TR) + tid * 72;
   u32 fault = 0;
+  auto align = [&](const HitSeed& s0) -> AlnRes {
+    const u64 q = s0.qs >> 1;
+    const uint4 pq = b.gpeq[s0.qs];
+    return band_align_bits<WB, TR, 256>(f.text, f.n, b.indel != 0, (u64)s0.pos, s0.len, b.qlen[q], b.indel ? b.qdist[q] : 0u,
+                                        PosMasks{pq.x, pq.y, pq.z, pq.w}, tr, fault);
+  };
   if (!SHARE) {
     cls[0] = tid;
     if (base + tid < nh && !(a.debug & 1u)) {
-      const AlnRes r = band_align<WB, TR>(f, b, sd[0], tr, lds_g, fault);
+      const AlnRes r = align(sd[0]);
       if (r.pre_eff < cpos[0]) cpos[0] -= r.pre_eff;  // hunter.h:382 (strict <)
       cls_info[tid] = r.info;
       cls_ops[tid * DS] = r.op[0];
@@ -3476,7 +3084,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     for (u32 c = tid; c < ncls && !(a.debug & 1u); c += 256) {
       const u32 own = cls_owner[c];
       const uint4 v = *reinterpret_cast<const uint4*>(a.seeds + base + own);
-      const AlnRes r = band_align<WB, TR>(f, b, HitSeed{v.x, v.y, v.z, v.w}, tr, lds_g, fault);
+      const AlnRes r = align(HitSeed{v.x, v.y, v.z, v.w});
       cls_info[c] = r.info;
       cls_ops[c * DS] = r.op[0];
       if (DS > 1) cls_ops[c * DS + 1] = r.op[1];
@@ -3499,6 +3107,17 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     const u64 h = base + (u32)j * 256u + tid;
     if (h >= nh) continue;
     const u32 info = cls_info[cls[j]];
+    if (a.chits) {  // compact: the host finds the sequence from the position itself
+      const u32 chr0 = (u32)((u64)sd[j].pos - (cum_in_lds ? s_cum[ref[j]] : a.cum[ref[j]]));
+      const u32 W = 2u + a.ops_per_hit;
+      u32* rec = a.chits + h * W;
+      rec[0] = sd[j].pos;
+      rec[1] = chit_meta((int)(int8_t)(info & 255u), sd[j].qs & 1u, (int)(cpos[j] + ((info >> 8) & 255u)) - (int)chr0, info >> 16);
+      if (a.ops_per_hit >= 1) rec[2] = cls_ops[cls[j] * DS];
+      if (a.ops_per_hit >= 2) rec[3] = DS > 1 ? cls_ops[cls[j] * DS + 1] : ALN_OP_NONE;
+      for (u32 k = 2; k < a.ops_per_hit; ++k) rec[2 + k] = ALN_OP_NONE;
+      continue;
+    }
     dg_hit out;
     out.score = (int)(int8_t)(info & 255u);
     out.chr = ref[j];
@@ -3700,6 +3319,20 @@ __global__ void k_rows_to_ops(VerifyArgs a, Counters* ctr) {
 // Fetched results leave the device as ONE block: this kernel lays the pieces (hit offsets, query offsets, the three per-query
 // arrays, normalised queries, hits, operation words) out behind each other exactly as the host block holds them, and one copy
 // follows (r03: six copies of 0.8-4.7 MB each paid their own start-up, 0.39 ms per 100 000 queries for 10 MB).
+// compact records from dg_hit + ops, for the verify kernels that write the classic form (queries above 32 nt, distance above 2)
+__global__ void __launch_bounds__(256) k_hits_to_compact(VerifyArgs a, const Counters* ctr) {
+  const u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 nh = *a.nhits;
+  if (ctr->overflow || nh > a.hit_cap || h >= nh) return;
+  const dg_hit H = a.hits[h];
+  const u32 pos = a.seeds[h].pos;
+  const u32 W = 2u + a.ops_per_hit;
+  u32* rec = a.chits + h * W;
+  rec[0] = pos;
+  rec[1] = chit_meta(H.score, H.strand == '-' ? 1u : 0u, (int)(H.start - 1) - (int)(u32)((u64)pos - a.cum[H.chr]), H.aln_len);
+  for (u32 k = 0; k < a.ops_per_hit; ++k) rec[2 + k] = a.ops[h * a.ops_per_hit + k];
+}
+
 struct PackArgs {
   const u32* src[6];
   u64 dst_word[6];  // offset in the block, in 32-bit words
@@ -3723,6 +3356,9 @@ __global__ void __launch_bounds__(256) k_pack_results(PackArgs a, u32* dst) {
   }
 }
 
+static inline double host_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 static double ev_ms(hipEvent_t a, hipEvent_t b) {
   float ms = 0;
   (void)hipEventElapsedTime(&ms, a, b);
@@ -3783,8 +3419,7 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const u32* in, u64 n, const 
 }
 
 int device_scan(hipStream_t st, const u32* in, u64 n, u64* out /*[n+1]*/, u64* tmp, Counters* ctr, u32 shard_cap, u32 surv_cap) {
-  static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
-  if (!lane_only && n <= ((u64)1 << 24)) {
+  if (n <= ((u64)1 << 24)) {
     const u32 tiles = (u32)((n + SCAN_TILE) / SCAN_TILE);  // covers index n as well
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(256), 0, st, in, n, tmp, ctr, shard_cap, surv_cap);
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, in, n, (const u64*)tmp, out);
@@ -4041,6 +3676,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   if (dmax_eff > DMAX) return fail(DG_ELIMIT, "distance %u exceeds the supported maximum of %u", p->distance, DMAX);
   DG_HIP(hipSetDevice(ix->device));
   hipStream_t st = ix->stream;
+  const bool host_timing = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;  // host phases of every batch to stderr
+  const double t_enter = host_timing ? host_us() : 0.0;
+  double t_launched = 0, t_synced = 0;
   for (int i = 0; i < 9; ++i)
     if (!ix->ev[i]) DG_HIP(hipEventCreate(&ix->ev[i]));
   auto& ws = ix->ws;
@@ -4051,17 +3689,21 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   // gap columns inside the query (leading and trailing query-gap columns are stripped, hunter.h:391-401, and an optimal path has
   // score >= -d): maxlen + d bytes, rounded up to the 64-bit words it stores.  The other verify kernels build the row from the
   // end of a buffer twice as long.  (r02: 56 -> 24 bytes per row for 20-mers — what travels to the host and over xGMI.)
-  static const bool no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;
+  const bool no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;  // (test switches are read per batch: the GPU suite flips them inside one process)
   const bool band_verify = !no_band && !sx && !group_counts && maxlen <= 32 && dmax_eff <= 2;
   // scratch rows of the full-matrix kernels (built from the end of a buffer twice the row length); the banded kernel needs none
   const u32 stride = band_verify ? 0u : ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
   const u32 ops_per_hit = dmax_eff;  // compact alignment description: at most |score| <= d columns are not a match
+  // ABI 5: results as compact records (position, meta, ops) + one word per query, in ONE device block [qhits | qinfo | records]
+  // that a single copy brings to the host — no pack kernel, 12 instead of 24 bytes per hit at distance 1
+  const bool compact = (p->flags & DG_HUNT_COMPACT) && !sx && !group_counts;
+  const u32 chit_words = 2u + ops_per_hit;
   const u64 scan_tmp = ngrp / SCAN_CHUNK + ngrp / (SCAN_CHUNK * SCAN_CHUNK) + 64;
   DG_TRY(ws[WS_FW].reserve(total + 8));
   DG_TRY(ws[WS_RV].reserve(total + 8));
   DG_TRY(ws[WS_QSEQ].reserve(total + 8));
   DG_TRY(ws[WS_QMETA].reserve(nq * 16 + 64));
-  DG_TRY(ws[WS_GINFO].reserve(ngrp * sizeof(GidInfo) + 64));
+  DG_TRY(ws[WS_GINFO].reserve(ngrp * (sizeof(GidInfo) + sizeof(uint4)) + 64));
   DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 3 + nq * 4 + scan_tmp * 8 + sizeof(Counters) + sizeof(Summary) + 512));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   // Could any query of this batch reach the cap?  (the bound grows with the length and with the number of N's)
@@ -4108,10 +3750,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipMemcpyAsync(d_xs_off, cs.xs_off.data(), (nxs + 1) * 8, hipMemcpyHostToDevice, st));
     DG_HIP(hipStreamSynchronize(st));  // the host vectors go out of use only after the copies
   }
-  static const bool no_fast1 = std::getenv("DICEY_NO_FAST1") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
   Batch b;
-  b.fastK = (!no_fast1 && dmax_eff == 1 && ix->view.K && maxlen > ix->view.K && ngrp * (u64)std::min(maxlen, 31u) * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
-  b.fast2K = (!no_fast1 && indel && dmax_eff == 2 && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
+  b.fastK = (dmax_eff == 1 && ix->view.K && maxlen > ix->view.K && ngrp * (u64)std::min(maxlen, 31u) * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
+  b.fast2K = (indel && dmax_eff == 2 && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
   b.xs_off = d_xs_off;
@@ -4128,12 +3769,14 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   b.qdist = meta + nq;
   b.qflags = meta + 2 * nq;
   b.qnondna = meta + 3 * nq;
+  b.qinfo = nullptr;  // set per attempt (the compact block may move when the hit capacity grows)
   b.distance = p->distance;
   b.indel = indel;
   b.reverse = !p->forward_only;
   b.max_locations = p->max_locations;
   b.max_neighborhood = p->max_neighborhood;
   b.ginfo = ws[WS_GINFO].as<GidInfo>();
+  b.gpeq = reinterpret_cast<uint4*>(ws[WS_GINFO].as<GidInfo>() + ngrp);  // (GidInfo is 16 bytes: the masks stay 16-byte aligned)
   u8* gp = ws[WS_GRP].as<u8>();
   u64* grp_off = (u64*)gp;
   gp += (ngrp + 1) * 8;
@@ -4146,8 +3789,6 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   u8* const zero_from = gp;
   Counters* ctr = (Counters*)gp;
   gp += (sizeof(Counters) + 63) & ~(size_t)63;
-  Summary* d_sum = (Summary*)gp;
-  gp += (sizeof(Summary) + 63) & ~(size_t)63;
   u32* grp_cnt = (u32*)gp;
   gp += ngrp * 4;
   u32* nsel = (u32*)gp;
@@ -4158,7 +3799,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   b.refused = &ctr->pad_[1];
   b.too_long = &ctr->pad_[2];
   b.maxlen_bound = maxlen;
-  u32* qhits = (u32*)gp;
+  u32* qhits = (u32*)gp;  // (compact results: re-pointed into the compact block, per attempt)
   if (!ix->pinned) DG_HIP(hipHostMalloc((void**)&ix->pinned, 4096, 0));
   Summary& hsum = *(Summary*)ix->pinned;
   std::vector<u64> cum(nseq);
@@ -4183,13 +3824,6 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     hit_cap = (u64)std::max(1, std::atoi(e));
     flat_req = shard_cap;
   }
-  // survivor queue of the distance-1 kernels: per shard, a power of two; ~6 survivors per strand on a 3.1 Gb genome
-  u32 surv_cap_log2 = ix->surv_cap_log2_hint;
-  if (!surv_cap_log2) {
-    surv_cap_log2 = 6;
-    while (surv_cap_log2 < 24 && ((u64)NSHARD << surv_cap_log2) < 12 * ngrp) ++surv_cap_log2;
-  }
-  if (std::getenv("DICEY_DEBUG_CAPS")) surv_cap_log2 = 1;
   u64 nleaf = 0, nhits = 0;
   bool force_generic = false, force_jobs = false;
   // Fetched results: one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh
@@ -4202,6 +3836,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   };
   auto fetch_layout = [&](u64 capn) {
     FetchLayout L;
+    if (compact) {  // [hit_off (filled on the host) | qhits | qinfo | records]; o_qoff = qhits, o_meta = qinfo, o_hits = records
+      L.o_hit_off = 0;
+      L.o_qoff = (nq + 1) * 8;
+      L.o_meta = L.o_qoff + (u64)nq * 4;
+      L.o_qseq = L.o_meta + (u64)nq * 4;
+      L.o_hits = L.o_qseq;
+      L.o_ops = L.o_hits + capn * (u64)chit_words * 4;
+      L.bytes = L.o_ops + 64;
+      return L;
+    }
     L.o_hit_off = 0;
     L.o_qoff = L.o_hit_off + (nq + 1) * 8;
     L.o_meta = L.o_qoff + (nq + 1) * 8;
@@ -4220,6 +3864,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   u64 spec_cap = 0;
   auto queue_fetch = [&](PinnedBlock* pb, u64 capn) -> int {
     const FetchLayout L = fetch_layout(capn);
+    if (compact) {  // the device block already has the host layout behind hit_off
+      DG_HIP(hipMemcpyAsync((u8*)pb->p + L.o_qoff, ws[WS_PACK].p, L.o_ops - L.o_qoff, hipMemcpyDeviceToHost, st));
+      return DG_OK;
+    }
     DG_TRY(ws[WS_PACK].reserve(L.bytes + 64));
     PackArgs pa;
     const u32* srcs[6] = {reinterpret_cast<const u32*>(ws[WS_GRP].as<u8>() + (ngrp + 1) * 8),  // hit_off
@@ -4250,8 +3898,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     // Distance 1, every string in 128 bits: k_search1s settles the select stage inside the search kernel (flat Sel region of
     // NSHARD slices).  The generic kernels (k_search for N-containing / long queries, k_explicit, scan, pack, alive, rank) run
     // when the previous batch of this handle had work for them; a batch that turns out to need them after all is repeated.
-    static const bool no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr || std::getenv("DICEY_FLAT1_PER_OP") != nullptr ||
-                                std::getenv("DICEY_FLAT1_SPLIT") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
+    // DICEY_NO_FUSED_SELECT: the search without the select stage (k_search1p + the generic select kernels) — what batches with
+    // strings above 42 characters take anyway; the GPU tests run every distance-1 case both ways
+    const bool no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr;
     const bool fused = b.fastK && packed && !no_fuse;
     const u32 flat_cap = fused ? flat_req : 0u;
     const u64 flat_slots = (u64)NSHARD * flat_cap;
@@ -4264,16 +3913,21 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     Sel* const sel_gen = sel_all + flat_slots;  // the generic path's slots: grp_off based, behind the flat region
     DG_TRY(ws[WS_SCR].reserve((leaf_slots + 1) * 5 + 64));
     DG_TRY(ws[WS_SEEDS].reserve((hit_cap + 1) * sizeof(HitSeed)));
-    if (b.fastK && std::getenv("DICEY_FLAT1_SPLIT")) DG_TRY(ws[WS_MISC].reserve(((u64)NSHARD << surv_cap_log2) * 4 + 64));
-    u32 surv_cap = 0xFFFFFFFFu;  // set where the survivor queue is used
+    const u32 surv_cap = 0xFFFFFFFFu;  // (r02's survivor queue in HBM is gone with k_probe1 / k_finish1; the scan kernel's check keeps its argument)
     DG_TRY(ws[WS_JOBS].reserve(2 * std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
     if (stride && !sx && !group_counts) DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
     if (!sx && !group_counts) DG_TRY(ws[WS_OPS].reserve((hit_cap + 1) * (u64)ops_per_hit * 4 + 64));
+    u32* d_chits = nullptr;
+    if (compact) {
+      DG_TRY(ws[WS_PACK].reserve(2 * (u64)nq * 4 + (hit_cap + 1) * (u64)chit_words * 4 + 64));
+      qhits = ws[WS_PACK].as<u32>();
+      b.qinfo = qhits + nq;
+      d_chits = qhits + 2 * nq;
+    }
     // counters: left zeroed by the previous batch's last kernel (batch_finish) unless they moved or that batch did not finish;
     // group counters: cleared by k_prepare
-    static const bool lane_only_ = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
-    if (lane_only_ || ix->ctr_clean != (const void*)ctr || ix->ctr_clean_gen != ws[WS_GRP].gen) DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
+    if (ix->ctr_clean != (const void*)ctr || ix->ctr_clean_gen != ws[WS_GRP].gen) DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     ix->ctr_clean = nullptr;  // dirty until this attempt's last kernel has run
     DG_HIP(hipEventRecord(ix->ev[0], st));
     hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_cnt, nsel, selbase, (u32*)&ctr->pad_[6]);
@@ -4285,55 +3939,32 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       so.ctr = ctr;
       so.grp_cnt = grp_cnt;
       if (b.fastK) {  // distance 1: the flat kernel takes every query that qualifies, k_search (one lane per strand) the rest
-        static const bool per_op = std::getenv("DICEY_FLAT1_PER_OP") != nullptr;  // the lane-per-operation form (A/B runs)
+        const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg;  // longer queries stay with k_search
         if (fused) {
-          const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg, gpw = std::min(16u, 256u / ipg);
+          const u32 gpw = std::min(16u, 256u / ipg);
           FlatSel fs;
           fs.sel = sel_all;
           fs.cap = flat_cap;
           fs.selbase = selbase;
           fs.nsel = nsel;
           const dim3 g1(ceil_div(ngrp, gpw)), b1(256);
-          // tests: DICEY_FUSED_LCAP lowers the LDS list's capacity so that ordinary batches exercise the hand-over to the generic path
-          static const u32 lcap = std::getenv("DICEY_FUSED_LCAP") ? std::min<u32>(FUSED_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP"))) : FUSED_LCAP;
-          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true>), g1, b1, 0, st, ix->view, b, so, fs, ipg, magic, gpw, lcap);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false>), g1, b1, 0, st, ix->view, b, so, fs, ipg, magic, gpw, lcap);
-        } else if (per_op) {
-          const u32 ipg = std::min(maxlen, 31u) * (indel ? 8u : 4u);  // longer queries stay with k_search
-          const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
-          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<true>), g1, b1, 0, st, ix->view, b, so, ipg);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1<false>), g1, b1, 0, st, ix->view, b, so, ipg);
+          // LDS list of a workgroup: 256 entries unless the previous batch of this handle averaged more than 48 occurring strings
+          // per workgroup (repeat-bearing genomes), then 512; a workgroup whose strings do not fit hands its groups to the generic
+          // path.  tests: DICEY_FUSED_LCAP lowers the capacity so that ordinary batches exercise that hand-over
+          const u32 lcap_env = std::getenv("DICEY_FUSED_LCAP") ? std::max<u32>(1u, std::min<u32>(FUSED_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP")))) : 0u;
+          const u32 lcap = lcap_env ? lcap_env : (ix->fused_leaves_hint > 48ull * g1.x ? FUSED_LCAP : FUSED_LCAP / 2);
+          const u32 lds1 = fused_lds_bytes(lcap);
+          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap);
         } else {
-          // probe + finish in one kernel unless DICEY_FLAT1_SPLIT asks for the two-kernel form (r02 A/B: 0.25 ms fused, 0.21 +
-          // 0.19 ms split — both halves run at the memory system's random-access rate, cutting the chain gained nothing)
-          static const bool one_kernel = std::getenv("DICEY_FLAT1_SPLIT") == nullptr;
-          const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg;  // longer queries stay with k_search
-          static const u32 tb1 = std::getenv("DICEY_FLAT1_TB") ? (u32)std::atoi(std::getenv("DICEY_FLAT1_TB")) : 256u;
-          const u32 TB1 = one_kernel && (tb1 == 64 || tb1 == 128) ? tb1 : TB;
-          const dim3 g1(ceil_div(ngrp * ipg, TB1)), b1(TB1);
-          if (one_kernel) {
-            if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<false>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
-          } else {
-            u32* sq = ws[WS_MISC].as<u32>();
-            static const u32 dbg_probe = std::getenv("DICEY_DBG_PROBE") ? (u32)std::atoi(std::getenv("DICEY_DBG_PROBE")) : 0u;
-            const dim3 g2((u32)(((u64)NSHARD << surv_cap_log2) / TB));
-            surv_cap = 1u << surv_cap_log2;
-            if (indel) {
-              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe1<true>), g1, b1, 0, st, ix->view, b, ctr, sq, surv_cap_log2, ipg, magic, dbg_probe);
-              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_finish1<true>), g2, b1, 0, st, ix->view, b, so, (const u32*)sq, surv_cap_log2);
-            } else {
-              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe1<false>), g1, b1, 0, st, ix->view, b, ctr, sq, surv_cap_log2, ipg, magic, dbg_probe);
-              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_finish1<false>), g2, b1, 0, st, ix->view, b, so, (const u32*)sq, surv_cap_log2);
-            }
-          }
+          const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
+          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<false>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
         }
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       if (b.fast2K) {  // edit distance 2: one workgroup per (query, strand) for every query that qualifies
-        static const bool per_op = std::getenv("DICEY_FLAT2_PER_OP") != nullptr;  // the lane-per-operation-pair form (A/B runs)
-        if (per_op) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2<4>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
-        else hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
+        hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       if (generic_on) {
@@ -4368,8 +3999,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       hipLaunchKernelGGL(k_group_pack, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr,
                          grp_off, ws[WS_LEAFG].as<PLeaf>());
       // distance >= 2: groups of up to SELCAP strings are sorted by a workgroup each, the lane-per-leaf kernels keep the rest
-      static const bool no_gsel = std::getenv("DICEY_NO_GROUP_SELECT") != nullptr || std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;
-      const u32 above = (dmax_eff >= 2 && !no_gsel && ngrp < 0x7FFFFFFFull) ? SELCAP : 0u;
+      const u32 above = (dmax_eff >= 2 && ngrp < 0x7FFFFFFFull) ? SELCAP : 0u;
       if (above)
         // (one wavefront per group was tried: 1.95 -> 2.5 ms, the second wavefront's share of the window searches is worth more than the barriers)
         hipLaunchKernelGGL(k_group_select, dim3((u32)ngrp), dim3(128), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, (u32)indel,
@@ -4401,11 +4031,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipEventRecord(ix->ev[5], st));
     {
       // strings with many occurrences go to two job lists: up to 256 occurrences for a wavefront each, more for a workgroup each
-      static const bool no_block = std::getenv("DICEY_NO_BLOCK_LOCATE") != nullptr;  // debugging aid (per-lane path only)
       const u32 job_cap = (u32)std::min<u64>(leaf_slots, 1u << 20);
       LocJobs lj;
-      lj.small = no_block ? nullptr : ws[WS_JOBS].as<BigJob>();
-      lj.big = no_block ? nullptr : ws[WS_JOBS].as<BigJob>() + job_cap;
+      lj.small = ws[WS_JOBS].as<BigJob>();
+      lj.big = ws[WS_JOBS].as<BigJob>() + job_cap;
       lj.cap = job_cap;
       lj.n_big = (u32*)&ctr->pad_[0];
       lj.n_small = (u32*)&ctr->pad_[4];
@@ -4414,20 +4043,19 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       const u32 slot_stride = packed ? (u32)sizeof(PLeaf) : (u32)sizeof(Leaf);
       hipLaunchKernelGGL(k_locate, dim3(ceil_div(flat_slots + (generic_on ? leaf_slots : 0), TB)), dim3(TB), 0, st, ix->view, (const Sel*)sel_all, slot_qs,
                          slot_stride, (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj,
-                         flat_slots, flat_cap, (u32)generic_on, (u32)(no_block || ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX));
+                         flat_slots, flat_cap, (u32)generic_on, (u32)(ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX));
       // The job kernels (strings of more than 16 occurrences) are launched when the previous batch of this handle queued any job;
       // k_locate queues and counts whether or not they run, and a batch that had jobs after one that had none is repeated with
       // them (the same device as for capacity guesses).  Uniform batches on a genome without repeats never launch them.
-      jobs_on = !no_block && (ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX);
+      jobs_on = ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX;
       if (jobs_on) {
         // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
         const bool topk = ix->view.nlev > 1;
-        static const bool one_size = std::getenv("DICEY_TOPK_ONE_SIZE") != nullptr;
         // A batch with thousands of repeat-rich strings (the previous batch of this handle tells): intervals up to 4 608 entries go
         // to the small-buffer form of k_locate_topk.  (r03 also ran the three job kernels side by side on helper streams: each
         // slowed down by what the others took — 114 / 220 / 228 us alone, 220 / 494 / 268 us together — and the stage gained
         // 0.08 of 0.91 ms; not worth two more streams per handle.)
-        const bool rich = topk && !one_size && ix->jobs_big_hint >= 2048;
+        const bool rich = topk && ix->jobs_big_hint >= 2048;
         const u32 mid_max = rich ? 8 * TOPK_KCAP_MID : 0u;
         hipLaunchKernelGGL(k_locate_small, dim3(8192), dim3(64), 0, st, ix->view, (const BigJob*)lj.small, (const u32*)lj.n_small, job_cap,
                            ws[WS_SEEDS].as<HitSeed>(), ctr);
@@ -4459,15 +4087,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       va.stride = stride;
       va.ops = ws[WS_OPS].as<u32>();
       va.ops_per_hit = ops_per_hit;
-      const u32 dbg_verify = std::getenv("DICEY_DBG_VERIFY") ? (u32)std::atoi(std::getenv("DICEY_DBG_VERIFY")) : 0u;  // read per batch: tests switch the check on
-      va.debug = dbg_verify;
+      va.chits = nullptr;
+      va.debug = 0;
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);
       if (band_verify) {
+        va.chits = d_chits;  // the banded kernel writes compact records itself
         // hits per lane: 1 while a query has a handful of hits (every window is its own class: nothing to share, smallest LDS
         // footprint), 8 when the previous batch had dozens of hits per query (repeat families: ~240 hits per kept string)
-        static const int ch_env = std::getenv("DICEY_VERIFY_CH") ? std::atoi(std::getenv("DICEY_VERIFY_CH")) : 0;
+        const int ch_env = std::getenv("DICEY_VERIFY_CH") ? std::atoi(std::getenv("DICEY_VERIFY_CH")) : 0;
         const u64 per_q = hit_cap / std::max<u64>(nq, 1);
         // (distance 2 on an i.i.d. genome: 59 hits per query from ~50 strings — nothing to share, and the wider trace of 13 diagonals
         //  leaves room for fewer workgroups: r03 measured 2.39 ms with 8 hits per lane against 1.83 ms for the lane-per-hit kernel)
@@ -4475,7 +4104,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= share_at ? 8 : (per_q >= share_at / 2 ? 4 : 1));
         const u32 rows = maxlen + 3 * dmax_eff + 2;
         const bool wide = dmax_eff > 1;
-        const u32 nw_bytes = rows * 256 * (wide ? 4u : 2u) + 256 * 72, hash_bytes = 2u * 256u * (u32)ch * 10u;
+        const u32 nw_bytes = rows * 256 * (wide ? 4u : 2u), hash_bytes = 2u * 256u * (u32)ch * 10u;
         const u32 lds = std::max(nw_bytes, hash_bytes);
         const dim3 mgrid(ceil_div(hit_cap, (u64)256 * ch)), mblock(256);
 #define DG_LAUNCH_MEMO(WBV, CHV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_memo<WBV, CHV>), mgrid, mblock, lds, st, ix->view, b, va, ctr, rows)
@@ -4504,17 +4133,15 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         else if (cells <= 32 * 160) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<160, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify<2200, false>), vgrid, vblock, 0, st, ix->view, b, va, ctr);
         if (ops_per_hit) hipLaunchKernelGGL(k_rows_to_ops, dim3(ceil_div(hit_cap, 256)), dim3(256), 0, st, va, ctr);
+        if (compact) {
+          va.chits = d_chits;
+          hipLaunchKernelGGL(k_hits_to_compact, dim3(ceil_div(hit_cap, 256)), dim3(256), 0, st, va, (const Counters*)ctr);
+        }
       }
     }
     DG_HIP(hipEventRecord(ix->ev[7], st));
     }
-    static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
-    if (lane_only) {
-      hipLaunchKernelGGL(k_summary, dim3(NSHARD / 256), dim3(256), 0, st, (const Counters*)ctr, (const u64*)(hit_off + nq), d_sum);
-      DG_HIP(hipMemcpyAsync(&hsum, d_sum, sizeof(Summary), hipMemcpyDeviceToHost, st));
-    } else {
-      hipLaunchKernelGGL(k_summary_block, dim3(1), dim3(NSHARD), 0, st, ctr, (const u64*)(hit_off + nq), &hsum);
-    }
+    hipLaunchKernelGGL(k_summary_block, dim3(1), dim3(NSHARD), 0, st, ctr, (const u64*)(hit_off + nq), &hsum);
     if (fetch && !group_counts && !sx && ix->fetch_hits_hint) {
       const u64 capn = std::min<u64>(hit_cap, ix->fetch_hits_hint);
       if (!spec.pb || spec_cap != capn) {
@@ -4524,38 +4151,22 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       }
       if (spec.pb) DG_TRY(queue_fetch(spec.pb, capn));
     }
+    if (host_timing) t_launched = host_us();
     DG_HIP(hipStreamSynchronize(st));  // the only synchronisation of a batch
     DG_HIP(hipGetLastError());
-    if (!lane_only) {  // batch_finish left the counters zeroed where they are
-      ix->ctr_clean = ctr;
-      ix->ctr_clean_gen = ws[WS_GRP].gen;
-    }
-    if (hsum.too_long) return fail(DG_EINVAL, "%llu queries are longer than the %u nt this batch was sized for", hsum.too_long, maxlen);
+    if (host_timing) t_synced = host_us();
+    ix->ctr_clean = ctr;  // batch_finish left the counters zeroed where they are
+    ix->ctr_clean_gen = ws[WS_GRP].gen;
+    if (hsum.too_long)
+    return fail(DG_EINVAL, "%llu queries are longer than the %u nt this batch was sized for%s", hsum.too_long, maxlen,
+                p->max_query_len ? " (dg_hunt_params::max_query_len is not an upper bound of this batch, or its offsets decrease)" : "");
     if (hsum.refused)
       return fail(DG_EINVAL, "internal error: %llu quer%s could reach the maxNeighborhood cap (%u) without having been enumerated on the host",
                   hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
-    if (const char* dj = std::getenv("DICEY_DUMP_JOBS")) {  // development aid: the repeat-rich strings of this batch (lo, occs, take, g, len, out)
-      u32 nj = (u32)hsum.jobs_big;
-      nj = std::min<u32>(nj, (u32)std::min<u64>(leaf_slots, 1u << 20));
-      std::vector<BigJob> hj(nj);
-      if (nj) DG_HIP(hipMemcpy(hj.data(), ws[WS_JOBS].as<BigJob>() + std::min<u64>(leaf_slots, 1u << 20), (size_t)nj * sizeof(BigJob), hipMemcpyDeviceToHost));
-      if (FILE* fj = std::fopen(dj, "wb")) {
-        std::fwrite(&nj, 4, 1, fj);
-        for (const BigJob& j : hj) {
-          const u32 rec[3] = {j.occs, j.take, j.len};
-          std::fwrite(rec, 4, 3, fj);
-        }
-        std::fclose(fj);
-      }
-    }
     nleaf = hsum.nleaf;
     nhits = hsum.nhits;
     // Everything this attempt found wanting is put right before the batch is repeated (one repeat usually serves several causes).
     bool again = false;
-    if (surv_cap != 0xFFFFFFFFu && hsum.worst_surv > surv_cap) {
-      while (surv_cap_log2 < 30 && (1ull << surv_cap_log2) < hsum.worst_surv + hsum.worst_surv / 4) ++surv_cap_log2;
-      again = true;
-    }
     // the generic kernels were left out, and the batch had work for them after all (queries with N, longer than 31 nt, a workgroup
     // of k_search1s whose strings did not fit its LDS list): once more, with them
     if (fused && !generic_on && (hsum.nleaf > 0 || hsum.n_generic > 0)) {
@@ -4563,7 +4174,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       force_generic = true;
       again = true;
     }
-    if (!jobs_on && !group_counts && !std::getenv("DICEY_NO_BLOCK_LOCATE") && (hsum.jobs_small > 0 || hsum.jobs_big > 0)) {  // strings were queued and nobody served them
+    if (!jobs_on && !group_counts && (hsum.jobs_small > 0 || hsum.jobs_big > 0)) {  // strings were queued and nobody served them
       ix->jobs_hint = true;
       force_jobs = true;
       again = true;
@@ -4589,7 +4200,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   ix->shard_cap_hint = shard_cap;
   if (b.fastK && hsum.worst_sel) ix->flat_cap_hint = (u32)std::max<unsigned long long>(ix->flat_cap_hint, hsum.worst_sel + hsum.worst_sel / 4 + 64);
   ix->jobs_big_hint = hsum.jobs_big;
-  if (b.fastK) ix->surv_cap_log2_hint = surv_cap_log2;
+  if (b.fastK) ix->fused_leaves_hint = hsum.fused_leaves + nleaf;
   ix->hit_cap_hint = std::max<u64>(ix->hit_cap_hint, nhits + nhits / 4 + 1024);
   if (group_counts) {
     DG_HIP(hipMemcpyAsync(group_counts, ws[WS_HITS].p, ngrp * 8, hipMemcpyDeviceToHost, st));
@@ -4627,6 +4238,25 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     R->owner_ = pb;
     const FetchLayout L = fetch_layout(capn);
     u8* hb = (u8*)pb->p;
+    if (compact) {
+      R->compact = 1;
+      R->hit_off = (uint64_t*)(hb + L.o_hit_off);
+      const u32* qh = (const u32*)(hb + L.o_qoff);
+      u64 run2 = 0;
+      for (size_t i = 0; i < nq; ++i) {
+        R->hit_off[i] = run2;
+        run2 += qh[i];
+      }
+      R->hit_off[nq] = run2;
+      if (run2 != nhits) return fail(DG_EHIP, "internal error: per-query hit counts add up to %llu, the batch has %llu hits", (unsigned long long)run2, (unsigned long long)nhits);
+      R->qinfo = (uint32_t*)(hb + L.o_meta);
+      R->chits = (uint32_t*)(hb + L.o_hits);
+      R->nseq = nseq;
+      R->seq_start = (uint64_t*)std::malloc(std::max<size_t>(1, nseq) * 8);
+      if (!R->seq_start) return fail(DG_ENOMEM, "out of host memory");
+      std::memcpy(R->seq_start, cum.data(), (size_t)nseq * 8);
+      ix->fetch_hits_hint = nhits + nhits / 32 + 1024;
+    } else {
     if (caller_qoff) std::memcpy(hb + L.o_qoff, caller_qoff, (nq + 1) * 8);
     R->hit_off = (uint64_t*)(hb + L.o_hit_off);
     R->qoff = (uint64_t*)(hb + L.o_qoff);
@@ -4637,9 +4267,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     R->qnondna = R->qflags + nq;
     R->qseq = hb + L.o_qseq;
     ix->fetch_hits_hint = nhits + nhits / 32 + 1024;
+    }
   }
-  R->d_hits = ws[WS_HITS].p;
-  R->d_ops = ops_per_hit ? ws[WS_OPS].p : nullptr;
+  if (compact) {
+    R->compact = 1;
+    R->d_hits = ws[WS_PACK].as<u32>() + 2 * nq;  // compact records (chit_words each)
+    R->d_ops = nullptr;
+  } else {
+    R->d_hits = ws[WS_HITS].p;
+    R->d_ops = ops_per_hit ? ws[WS_OPS].p : nullptr;
+  }
   R->ctr_leaves = nleaf + hsum.fused_leaves;
   R->ctr_ext_steps = hsum.steps;
   R->ctr_tab_reads = hsum.lookups;
@@ -4652,6 +4289,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);
   R->ms_locate = ev_ms(ix->ev[5], ix->ev[6]);
   R->ms_verify = ev_ms(ix->ev[6], ix->ev[7]);
+  if (host_timing)
+    std::fprintf(stderr, "dicey timing: batch of %zu on stream %p: host %.0f us before the synchronisation (last attempt's launches included), "
+                 "%.0f us waiting, %.0f us after; device %.3f ms\n", nq, (void*)st, t_launched - t_enter, t_synced - t_launched,
+                 host_us() - t_synced, R->ms_total);
   return DG_OK;
 }
 
@@ -4664,6 +4305,8 @@ extern "C" {
 void dg_hunt_result_free(dg_hunt_result* r) {
   if (!r) return;
   if (r->owner_) pinned_pool().put((PinnedBlock*)r->owner_);
+  std::free(r->seq_start);
+  std::free(r->expanded_);
   std::free(r->refalign);
   std::free(r->queryalign);
   delete r;
@@ -4747,6 +4390,105 @@ int dg_hunt_rows(dg_hunt_result* r) {
   return DG_OK;
 }
 
+int dg_chit_unpack(const dg_hunt_result* r, uint64_t h, uint32_t query, dg_hit* out, const uint32_t** ops) {
+  if (!r || !out || !r->compact || !r->chits || !r->seq_start || h >= r->nhits) return fail(DG_EINVAL, "dg_chit_unpack: not a compact result, or hit out of range");
+  const u32 W = DG_CHIT_WORDS(r->ops_per_hit);
+  const u32* rec = r->chits + h * W;
+  const u64 pos = rec[0];
+  // hunter.h:358-362: the sequence that holds the position = the last one starting at or before it
+  u32 lo = 0, hi = r->nseq - 1;
+  while (lo < hi) {
+    const u32 mid = (lo + hi + 1) >> 1;
+    if (r->seq_start[mid] <= pos) lo = mid;
+    else hi = mid - 1;
+  }
+  const u32 meta = rec[1];
+  out->score = -(int32_t)DG_CHIT_NEG_SCORE(meta);
+  out->chr = lo;
+  out->start = (uint32_t)((int64_t)(pos - r->seq_start[lo]) + DG_CHIT_DELTA(meta) + 1);
+  out->query = query;
+  out->aln_len = (uint16_t)DG_CHIT_ALN_LEN(meta);
+  out->strand = (uint8_t)DG_CHIT_STRAND(meta);
+  out->reserved = 0;
+  if (ops) *ops = r->ops_per_hit ? rec + 2 : nullptr;
+  return DG_OK;
+}
+
+int dg_normalize_query(const uint8_t* in, uint32_t len, uint8_t* out, uint32_t* nondna) {
+  if ((!in || !out) && len) return fail(DG_EINVAL, "dg_normalize_query: null argument");
+  u32 bad = 0;
+  for (u32 i = 0; i < len; ++i) {
+    u32 ch = in[i];
+    if (ch >= 'a' && ch <= 'z') ch -= 32;  // boost::to_upper_copy, hunter.h:306
+    const bool dna = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+    bad += !dna;  // util.h:208-219: every character outside A,C,G,T is replaced, a literal 'N' included
+    out[i] = (uint8_t)(dna ? ch : 'N');
+  }
+  if (nondna) *nondna = bad;
+  return DG_OK;
+}
+
+int dg_hunt_expand(dg_hunt_result* r, const uint8_t* qbytes, const uint64_t* qoff) {
+  if (!r) return fail(DG_EINVAL, "dg_hunt_expand: null result");
+  if (!r->compact || r->hits || r->expanded_) return DG_OK;
+  if (!qoff || (!qbytes && r->nq && qoff[r->nq])) return fail(DG_EINVAL, "dg_hunt_expand: the batch's query bytes and offsets are needed");
+  if (!r->chits || !r->qinfo || !r->hit_off) return fail(DG_EINVAL, "dg_hunt_expand: the result was not fetched to the host");
+  const size_t nq = r->nq;
+  const u64 nh = r->nhits, total = qoff[nq];
+  const u32 oph = r->ops_per_hit;
+  // one allocation: hits | ops | qflags qdistance qnondna | qoff | qseq
+  size_t o_hits = 0, o_ops = (o_hits + nh * sizeof(dg_hit) + 15) & ~(size_t)15, o_meta = (o_ops + nh * oph * 4 + 15) & ~(size_t)15,
+         o_qoff = (o_meta + 3 * nq * 4 + 15) & ~(size_t)15, o_qseq = o_qoff + (nq + 1) * 8, bytes = o_qseq + total + 16;
+  u8* blk = (u8*)std::malloc(bytes);
+  if (!blk) return fail(DG_ENOMEM, "dg_hunt_expand: %zu bytes", bytes);
+  dg_hit* hits = (dg_hit*)(blk + o_hits);
+  u32* ops = (u32*)(blk + o_ops);
+  u32* qflags = (u32*)(blk + o_meta);
+  u32 *qdist = qflags + nq, *qnondna = qdist + nq;
+  u64* qo = (u64*)(blk + o_qoff);
+  u8* qseq = blk + o_qseq;
+  std::memcpy(qo, qoff, (nq + 1) * 8);
+  std::atomic<int> bad{0};
+  auto work = [&](size_t q0, size_t q1) {
+    for (size_t q = q0; q < q1; ++q) {
+      const u32 w = r->qinfo[q];
+      qflags[q] = DG_QINFO_FLAGS(w);
+      qdist[q] = DG_QINFO_DISTANCE(w);
+      u32 nd = 0;
+      (void)dg_normalize_query(qbytes + qoff[q], (u32)(qoff[q + 1] - qoff[q]), qseq + qoff[q], &nd);
+      qnondna[q] = DG_QINFO_NONDNA(w);
+      if ((nd & 0xFFFFu) != qnondna[q]) bad.store(1);  // the caller's bytes are not the ones the batch was run with
+      for (u64 h = r->hit_off[q]; h < r->hit_off[q + 1]; ++h) {
+        const u32* po = nullptr;
+        if (dg_chit_unpack(r, h, (u32)q, &hits[h], &po) != DG_OK) bad.store(1);
+        for (u32 k = 0; k < oph; ++k) ops[h * oph + k] = po[k];
+      }
+    }
+  };
+  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (nq < 4096) nt = 1;
+  if (nt <= 1) work(0, nq);
+  else {
+    std::vector<std::thread> pool;
+    const size_t per = (nq + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, std::min(nq, t * per), std::min(nq, (t + 1) * per));
+    for (auto& t : pool) t.join();
+  }
+  if (bad.load()) {
+    std::free(blk);
+    return fail(DG_EINVAL, "dg_hunt_expand: the query bytes do not match the batch this result belongs to");
+  }
+  r->expanded_ = blk;
+  r->hits = hits;
+  r->ops = oph ? ops : nullptr;
+  r->qflags = qflags;
+  r->qdistance = qdist;
+  r->qnondna = qnondna;
+  r->qoff = qo;
+  r->qseq = qseq;
+  return DG_OK;
+}
+
 // dg_hunt's body.  prestaged != nullptr: the queries already lie in that pinned block (bytes at 0, offsets at (total + 63) & ~63 —
 // dg_hunt_submit copied them there once, and qbytes / qoff point into it).
 static int hunt_host(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
@@ -4755,13 +4497,14 @@ static int hunt_host(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   *out = nullptr;
   if (!nq) return fail(DG_EINVAL, "dg_hunt: empty batch");
   u64 total = qoff[nq];
-  u32 maxlen = 0, minlen = ~0u;
-  for (size_t i = 0; i < nq; ++i) {
-    if (qoff[i + 1] < qoff[i]) return fail(DG_EINVAL, "dg_hunt: qoff must be non-decreasing");
-    u64 l = qoff[i + 1] - qoff[i];
-    if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "query %zu is too long", i);
-    maxlen = std::max<u32>(maxlen, (u32)l);
-    minlen = std::min<u32>(minlen, (u32)l);
+  u32 maxlen = p->max_query_len;  // the caller's bound: the kernels count the queries above it (k_prepare) and the batch fails if any
+  if (!maxlen) {
+    for (size_t i = 0; i < nq; ++i) {
+      if (qoff[i + 1] < qoff[i]) return fail(DG_EINVAL, "dg_hunt: qoff must be non-decreasing");
+      u64 l = qoff[i + 1] - qoff[i];
+      if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "query %zu is too long", i);
+      maxlen = std::max<u32>(maxlen, (u32)l);
+    }
   }
   DG_HIP(hipSetDevice(ix->device));
   DG_TRY(ix->ws[WS_QB].reserve(total + 8));
@@ -4794,6 +4537,8 @@ static int hunt_host(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
 
 int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
             const uint64_t* qoff, size_t nq, dg_hunt_result** out) {
+  // a submitted batch owns the lane's stream, workspaces and hints until its ticket has been waited for
+  if (ix && ix->busy.load()) return fail(DG_EINVAL, "dg_hunt: a dg_hunt_submit batch is in flight on this handle (dg_hunt_wait first)");
   return hunt_host(ix, p, seqlen, nseq, qbytes, qoff, nq, out, nullptr);
 }
 
@@ -4858,7 +4603,16 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
   if (!ix || !p || !seqlen || !qoff || !out || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_hunt_submit: null argument");
   *out = nullptr;
   if (!nq) return fail(DG_EINVAL, "dg_hunt_submit: empty batch");
-  if (ix->busy.exchange(true)) return fail(DG_EINVAL, "dg_hunt_submit: this handle already has a batch in flight (use dg_index_share for a second one)");
+  // two lanes per handle (ABI 5): the handle itself while it is idle, else its internal second lane (a shared handle: own stream,
+  // workspaces and helper thread on the same resident index; created at the first need).  A caller that keeps one batch in flight
+  // never leaves the first lane.
+  dg_index* const owner = ix;
+  if (ix->busy.exchange(true)) {
+    if (!owner->lane2 && dg_index_share(owner, &owner->lane2) != DG_OK) owner->lane2 = nullptr;
+    ix = owner->lane2;
+    if (!ix || ix->busy.exchange(true))
+      return fail(DG_EINVAL, "dg_hunt_submit: two batches are already in flight on this handle (wait for the older ticket first)");
+  }
   dg_hunt_ticket* t = nullptr;
   try {
     t = new dg_hunt_ticket;
@@ -4876,8 +4630,14 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     if (qoff[nq]) std::memcpy(t->stage->p, qbytes, qoff[nq]);
     std::memcpy((uint8_t*)t->stage->p + t->off_at, qoff, (nq + 1) * 8);
     if (!ix->worker) {
-      ix->worker = new dg_index::Worker;
-      ix->worker->th = std::thread([w = ix->worker] { w->loop(); });
+      dg_index::Worker* w = new dg_index::Worker;
+      try {
+        w->th = std::thread([w] { w->loop(); });
+      } catch (...) {  // no thread: no worker either, or later submissions would wait for one that never runs
+        delete w;
+        throw;
+      }
+      ix->worker = w;
     }
     {
       std::lock_guard<std::mutex> lk(ix->worker->mu);
@@ -4947,7 +4707,7 @@ int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t
     DG_TRY(ix->ws[WS_QOFF].reserve(off.size() * 8));
     DG_HIP(hipMemcpyAsync(ix->ws[WS_QB].p, buf.data(), buf.size(), hipMemcpyHostToDevice, ix->stream));
     DG_HIP(hipMemcpyAsync(ix->ws[WS_QOFF].p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ix->stream));
-    dg_hunt_params hp;
+    dg_hunt_params hp{};
     hp.distance = distance;
     hp.hamming = hamming;
     hp.forward_only = 0;
@@ -5030,6 +4790,7 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
   if (!ix || !p || !seqlen || !d_qbytes || !d_qoff || !out) return fail(DG_EINVAL, "dg_hunt_device: null argument");
   *out = nullptr;
   if (!nq) return fail(DG_EINVAL, "dg_hunt_device: empty batch");
+  if (ix->busy.load()) return fail(DG_EINVAL, "dg_hunt_device: a dg_hunt_submit batch is in flight on this handle (dg_hunt_wait first)");
   DG_HIP(hipSetDevice(ix->device));
   // Query lengths are needed on the host only to size buffers and to check the supported envelope.  A repeated call with the
   // same offsets buffer, count and byte total reuses the previous maximum as an upper bound instead of reading the offsets
@@ -5039,8 +4800,11 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
   dg_index::QoffSeen* hit = nullptr;
   for (auto& e : ix->seen)
     if (e.qoff == d_qoff && e.nq == nq && e.total == total_qbytes && e.maxlen > 0) hit = &e;
-  const bool cached = hit != nullptr;
-  if (cached) maxlen = hit->maxlen;
+  const bool cached = hit != nullptr && !p->max_query_len;
+  if (p->max_query_len) {
+    maxlen = p->max_query_len;  // no read-back at all: k_prepare counts queries above the caller's bound and the batch fails if any
+    hit = nullptr;
+  } else if (cached) maxlen = hit->maxlen;
   else {
     std::vector<u64> hoff(nq + 1);
     DG_HIP(hipMemcpyAsync(hoff.data(), d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
@@ -5063,7 +4827,7 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     dg_hunt_result_free(*out);
     *out = nullptr;
   }
-  if (rc != DG_OK) hit->qoff = nullptr;  // whatever went wrong, the next call reads the offsets again
+  if (rc != DG_OK && hit) hit->qoff = nullptr;  // whatever went wrong, the next call reads the offsets again
   if (rc == DG_EINVAL && cached) return dg_hunt_device(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, fetch, out);
   return rc;
 }

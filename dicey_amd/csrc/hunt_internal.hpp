@@ -22,6 +22,7 @@ struct Batch {  // device pointers of one batch
   u32* qdist;
   u32* qflags;
   u32* qnondna;
+  u32* qinfo;  // != nullptr: flags | distance << 8 | nondna << 16 per query, for compact results (written where the flags become final)
   u32 distance;
   u32 indel, reverse;
   u64 max_locations;
@@ -30,6 +31,7 @@ struct Batch {  // device pointers of one batch
   u32 maxlen_bound;      // the host sized the batch for queries up to this length ...
   u32* too_long;         // ... k_prepare counts the ones that are longer (only possible when the host trusted a cached bound)
   struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
+  uint4* gpeq;            // [2*nq] position masks of the strand (x, y, z, w: bit i <=> character i is A, C, G, T), queries up to 32 nt
   u32 fastK;              // != 0: the batch runs k_search1 (distance 1, table order fastK) for the queries that qualify
   u32 fast2K;             // != 0: the batch runs k_search2 (edit distance 2) for the queries that qualify
   // Queries whose neighbourhood could reach the cap are enumerated on the host (nbhd_host.hpp) before the batch starts:

@@ -731,6 +731,10 @@ using namespace dg;
 
 dg_index::~dg_index() {
   stop_worker();
+  if (lane2) {
+    delete lane2;
+    lane2 = nullptr;
+  }
   for (void* p : owned) dg::big_free(p, stream);
   if (stream) (void)hipStreamSynchronize(stream);
   for (auto& w : ws) w.release();
@@ -777,6 +781,11 @@ int dg_index_share(dg_index* src, dg_index** out) {
   ix->hbm_bytes = 0;
   ix->shard_cap_hint = src->shard_cap_hint;
   ix->hit_cap_hint = src->hit_cap_hint;
+  ix->flat_cap_hint = src->flat_cap_hint;
+  ix->generic_hint = src->generic_hint;
+  ix->jobs_hint = src->jobs_hint;
+  ix->fetch_hits_hint = src->fetch_hits_hint;
+  ix->fused_leaves_hint = src->fused_leaves_hint;
   if (hipStreamCreate(&ix->stream) != hipSuccess) {
     delete ix;
     return fail(DG_EHIP, "dg_index_share: cannot create a stream");

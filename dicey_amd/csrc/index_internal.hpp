@@ -23,8 +23,8 @@ struct dg_index {
   bool generic_hint = true;      // the previous distance-1 batch had work for the kernels outside k_search1s (hunt.hip run_batch)
   bool jobs_hint = true;         // the previous batch queued strings for the locate job kernels
   uint64_t jobs_big_hint = 0;    // repeat-rich strings (workgroup locate jobs) of the previous batch
+  uint64_t fused_leaves_hint = 0;  // occurring strings the previous distance-1 batch held in k_search1s' LDS lists (+ generic leaves)
   uint64_t fetch_hits_hint = 0;  // hits of the previous fetched batch (+3 %): this many are copied to the host before the batch's synchronisation
-  uint32_t surv_cap_log2_hint = 0;  // survivor-queue capacity per shard (log2) that was enough for the previous batch
   // dg_hunt_device: the (offsets pointer, count, bytes) of the previous call and the longest query it held; a repeated
   // call skips reading the offsets back, and k_prepare reports any query longer than this bound (hunt.hip)
   // (r04: a small table, not one entry — a caller that cycles through a ring of resident batches finds each of them again)
@@ -39,7 +39,10 @@ struct dg_index {
   void* pinned = nullptr;             // 4 KB of pinned host memory for the end-of-batch summary
   // the batch counters are left zeroed by the last kernel of a batch (hunt.hip batch_finish): the next batch skips its memset
   // when they still sit where that kernel cleaned them
-  std::atomic<bool> busy{false};      // a dg_hunt_submit batch is in flight on this handle
+  std::atomic<bool> busy{false};      // a dg_hunt_submit batch is in flight on this handle (lane)
+  // ABI 5: dg_hunt_submit keeps two batches in flight on one handle; a submission that finds the handle busy runs on this internal
+  // second lane (a shared handle: own stream, workspaces, helper thread; created at the first need, closed with the handle)
+  dg_index* lane2 = nullptr;
   struct Worker;                      // the helper thread that drives dg_hunt_submit batches (hunt.hip)
   Worker* worker = nullptr;
   void stop_worker();

@@ -531,7 +531,7 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   DG_HIP(hipMemcpyAsync(d_prv, prv.data(), ptotal, hipMemcpyHostToDevice, st));
   DG_HIP(hipMemcpyAsync(d_poff, poff, (np + 1) * 8, hipMemcpyHostToDevice, st));
   DG_HIP(hipMemcpyAsync(d_koff, koff.data(), np * 4, hipMemcpyHostToDevice, st));
-  dg_hunt_params hp;
+  dg_hunt_params hp{};
   hp.distance = p->distance;
   hp.hamming = p->hamming;
   hp.forward_only = 0;

@@ -35,8 +35,10 @@ extern "C" {
 /* 1: hunt/count/locate/extract/index build; 2: + thal, search sites, neighbourhood counts, padlock scan, shared handles;
  * 3: + dg_neighbors, capped neighbourhoods answered instead of refused, max_locations 0
  * 4: hits carry their alignment in compact form (dg_hunt_result::ops; dg_hunt_rows / dg_hit_rows rebuild the two rows),
- *    result buffers come from a pinned pool, dg_hunt_submit / dg_hunt_wait */
-#define DG_ABI_VERSION 4
+ *    result buffers come from a pinned pool, dg_hunt_submit / dg_hunt_wait
+ * 5: dg_hunt_params grows by max_query_len and flags; DG_HUNT_COMPACT: 8 + 4 d bytes per hit and 8 bytes per query cross PCIe / xGMI
+ *    (dg_chit_unpack, dg_hunt_expand, dg_normalize_query turn them back); dg_hunt_submit keeps two batches in flight on ONE handle */
+#define DG_ABI_VERSION 5
 
 enum {
   DG_OK = 0,
@@ -101,7 +103,13 @@ typedef struct {
   int32_t forward_only;      /* -f  (hunter.h:190) */
   uint64_t max_locations;    /* -m  (hunter.h:186, default 1000) */
   uint32_t max_neighborhood; /* -x  (hunter.h:187, default 10000) */
+  uint32_t max_query_len;    /* ABI 5: an upper bound of the batch's query lengths when the caller knows one (a primer design tool does);
+                              * 0 = the library finds out (the host entry points scan their offsets, dg_hunt_device reads its offsets
+                              * back: a host round trip per new buffer).  The kernels count queries above the bound and the call fails
+                              * with DG_EINVAL rather than answer them wrongly. */
+  uint32_t flags;            /* ABI 5: DG_HUNT_* */
 } dg_hunt_params;
+#define DG_HUNT_COMPACT 1u   /* results in compact form (below): what the host needs to rebuild every DnaHit, nothing it already has */
 
 /* per-query flag bits */
 #define DG_Q_TOO_SHORT 1u     /* < 10 nt: "Error: Input sequence is shorter than 10 nucleotides!" (hunter.h:299-303) */
@@ -134,6 +142,26 @@ typedef struct {
 #define DG_ALN_COL(op) ((op) & 0xFFFFu)
 #define DG_ALN_KIND(op) (((op) >> 16) & 3u)
 #define DG_ALN_BYTE(op) ((op) >> 24)
+
+/* Compact results (ABI 5, DG_HUNT_COMPACT).  Per hit 2 + ops_per_hit words, in push order, the hits of query i at
+ * chits + hit_off[i] * (2 + ops_per_hit):
+ *   word 0   text position of the neighbourhood string the hit stems from (what sdsl::locate returned, hunter.h:355): the
+ *            sequence is the one that holds this position (hunter.h:358-362, seq_start[] below), chrpos = position - its start
+ *   word 1   bits 0-3 -score, bit 4 strand (1 = '-'), bits 5-11 delta + 32 where DnaHit::start = chrpos + delta + 1 (the
+ *            context characters in front of the string, hunter.h:382 with its strict '<', and the leading gap columns of
+ *            hunter.h:391-401 are in delta), bits 16-31 aln_len
+ *   words 2.. the alignment description of ABI 4 (DG_ALN_*)
+ * Per query one word qinfo: bits 0-7 DG_Q_* flags, bits 8-15 effective distance, bits 16-31 characters replaced by 'N'.
+ * The normalised queries are NOT returned: dg_normalize_query applies util.h:208-219 + to_upper to the caller's own bytes.
+ * 12 bytes per hit at distance 1 (ABI 4: 24), 8 bytes per query (ABI 4: 12 + the sequence + 8 of offsets). */
+#define DG_CHIT_WORDS(ops_per_hit) (2u + (ops_per_hit))
+#define DG_CHIT_NEG_SCORE(meta) ((meta) & 15u)
+#define DG_CHIT_STRAND(meta) ((((meta) >> 4) & 1u) ? '-' : '+')
+#define DG_CHIT_DELTA(meta) ((int32_t)(((meta) >> 5) & 127u) - 32)
+#define DG_CHIT_ALN_LEN(meta) ((meta) >> 16)
+#define DG_QINFO_FLAGS(w) ((w) & 255u)
+#define DG_QINFO_DISTANCE(w) (((w) >> 8) & 255u)
+#define DG_QINFO_NONDNA(w) ((w) >> 16)
 
 typedef struct {
   size_t nq;
@@ -169,7 +197,25 @@ typedef struct {
                                * entries actually read, i.e. the probes that found their K-mer present */
   double ms_search_flat;      /* part of ms_search spent in the flat kernel (k_search1p at distance 1, k_search2p at edit distance 2); 0 when none ran */
   void* owner_;               /* library internal (pinned-pool bookkeeping) */
+  /* ABI 5.  compact != 0: chits / qinfo / seq_start are set, hit_off as always; hits, ops, qflags, qdistance, qnondna, qseq, qoff are
+   * NULL until dg_hunt_expand() builds them on the host; d_hits then points at the compact records in HBM and d_ops is NULL. */
+  uint32_t compact;
+  uint32_t nseq;
+  uint32_t* chits;            /* [nhits * DG_CHIT_WORDS(ops_per_hit)] */
+  uint32_t* qinfo;            /* [nq] */
+  uint64_t* seq_start;        /* [nseq] text position of every sequence's first character (prefix sums of seqlen) */
+  void* expanded_;            /* library internal (dg_hunt_expand's allocations) */
 } dg_hunt_result;
+
+/* One compact hit as a dg_hit (query = the query it belongs to, from hit_off) and a pointer to its ops words. */
+int dg_chit_unpack(const dg_hunt_result* r, uint64_t h, uint32_t query, dg_hit* out, const uint32_t** ops);
+/* hunter.h:306 + util.h:208-219: upper-case, every character outside A,C,G,T becomes 'N'; *nondna = how many were replaced
+ * (a literal 'N' counts: the reference warns once per replaced character). */
+int dg_normalize_query(const uint8_t* in, uint32_t len, uint8_t* out, uint32_t* nondna);
+/* Builds the ABI-4 arrays (hits, ops, qflags, qdistance, qnondna, qseq, qoff) of a compact result on the host, from the caller's
+ * own query bytes (the ones the batch was submitted with); several host threads.  Afterwards dg_hunt_rows / dg_hit_rows work as
+ * on a classic result.  A no-op on a classic result. */
+int dg_hunt_expand(dg_hunt_result* r, const uint8_t* qbytes, const uint64_t* qoff);
 
 /* The two alignment rows of one hit from its compact description.  qseq / qlen: the NORMALISED query (dg_hunt_result::qseq:
  * A,C,G,T,N), forward strand — the reverse complement a '-' hit was aligned to is formed here (util.h:54-114).  ops: the hit's
@@ -188,9 +234,10 @@ void dg_hunt_result_free(dg_hunt_result* r);
 
 /* Asynchronous form: dg_hunt_submit returns as soon as the batch is handed to the library (the query buffers are copied, the
  * caller may reuse them at once); dg_hunt_wait blocks until the result is on the host (a pinned block, like dg_hunt's) and releases
- * the ticket.  One batch per handle at a time (DG_EINVAL otherwise): a second handle from dg_index_share runs its batch
- * concurrently on its own stream — submit A, submit B, wait A, format A while B computes, submit A, wait B, ...  Every ticket must
- * be waited for before its handle is closed. */
+ * the ticket.  ABI 5: up to TWO batches may be in flight on one handle (the library runs them on two internal lanes — own stream,
+ * own workspaces, own helper thread each, the same resident index — so uploads, kernels and downloads of neighbouring batches
+ * overlap): submit A, submit B, wait A, submit C, wait B, ...  Tickets are waited for in the order they were submitted; a third
+ * submit before the first wait fails with DG_EINVAL.  Every ticket must be waited for before its handle is closed. */
 typedef struct dg_hunt_ticket dg_hunt_ticket;
 int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
                    const uint64_t* qoff, size_t nq, dg_hunt_ticket** out);

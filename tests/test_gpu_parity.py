@@ -294,11 +294,23 @@ def test_flat_distance_two_kernel(gpu_small, small_genome, monkeypatch):
         O.fast_neighbors(False)
 
 
-@pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13", "K9_nolong", "K9_long10", "K10_long14"])
+# library switches that survive r04's pruning (DESIGN.md §6 lists them): each one is a code path of the shipped library and runs
+# through the same matrix as the default
+SWITCHES = {"nofuse": {"DICEY_NO_FUSED_SELECT": "1"}, "noband": {"DICEY_NO_BAND_VERIFY": "1"}, "classic": {"DICEY_CLASSIC_RESULTS": "1"},
+            "ch4": {"DICEY_VERIFY_CH": "4"}, "ch8": {"DICEY_VERIFY_CH": "8"}, "caps": {"DICEY_DEBUG_CAPS": "3"},
+            "lcap2": {"DICEY_FUSED_LCAP": "2"}}
+
+
+@pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13", "K9_nolong", "K9_long10", "K10_long14"] + ["K9_long10+" + k for k in SWITCHES])
 def test_every_search_mode_gives_the_same_hits(small_genome, monkeypatch, mode):
     """Interval mode (no table), window mode with a table shorter than every query, and tables long enough that some
-    queries fall back to interval mode (10/11-mers against K=11/13) must all reproduce the oracle."""
+    queries fall back to interval mode (10/11-mers against K=11/13) must all reproduce the oracle — and so must every library
+    switch on top of the usual layout."""
     import dicey_amd
+    if "+" in mode:
+        mode, sw = mode.split("+")
+        for k, v in SWITCHES[sw].items():
+            monkeypatch.setenv(k, v)
     if mode != "no_table":
         monkeypatch.setenv("DICEY_KMER_K", mode[1:].split("_")[0])
     if mode.endswith("_nolong"):  # what a device short of HBM gets: the table and its own filter only
@@ -389,23 +401,37 @@ def test_device_entry_point_rechecks_a_cached_length_bound(gpu_small, small_geno
 
 
 def test_submit_wait_on_two_handles_equals_the_blocking_call(gpu_small, small_genome):
-    """dg_hunt_submit / dg_hunt_wait (ABI 4): two batches in flight on two handles of one resident index, a third submit on a busy
-    handle is refused, results equal dg_hunt's."""
+    """dg_hunt_submit / dg_hunt_wait: two batches in flight on ONE handle (ABI 5: the library's two internal lanes) and, as in
+    ABI 4, on a second handle of the same resident index; a third submit on a handle with two in flight is refused, a blocking
+    call on a handle with a batch in flight as well; results equal dg_hunt's in both result forms."""
     import dicey_amd
     g = small_genome
     qa = make_queries(31, g["text"], 400)
     qb = make_queries(32, g["text"], 300)
-    key = lambda R: [[(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in q.hits] + [q.flags, q.nondna] for q in R.queries]
+    qc = make_queries(33, g["text"], 200)
+    key = lambda R: [[(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in q.hits] + [q.flags, q.nondna, q.sequence, q.distance]
+                     for q in R.queries]
     want_a, want_b = key(gpu_small.hunt(qa, g["seqlen"], distance=1)), key(gpu_small.hunt(qb, g["seqlen"], distance=2))
+    want_c = key(gpu_small.hunt(qc, g["seqlen"], distance=1, hamming=True))
+    assert want_a == key(gpu_small.hunt(qa, g["seqlen"], distance=1, compact=False))
     other = gpu_small.share()
     try:
-        for _ in range(3):
-            ta = gpu_small.hunt_submit(qa, g["seqlen"], distance=1)
-            tb = other.hunt_submit(qb, g["seqlen"], distance=2)
+        for rnd in range(3):
+            cpt = rnd != 1
+            ta = gpu_small.hunt_submit(qa, g["seqlen"], distance=1, compact=cpt)
+            tb = gpu_small.hunt_submit(qb, g["seqlen"], distance=2, compact=cpt)      # second lane of the same handle
+            tc = other.hunt_submit(qc, g["seqlen"], distance=1, hamming=True, compact=cpt, max_query_len=64)
             with pytest.raises(dicey_amd.DgError):
-                gpu_small.hunt_submit(qb, g["seqlen"], distance=1)  # one batch per handle
-            assert key(other.hunt_wait(tb)) == want_b
+                gpu_small.hunt_submit(qb, g["seqlen"], distance=1)  # two batches per handle
+            with pytest.raises(dicey_amd.DgError):
+                gpu_small.hunt(qb, g["seqlen"], distance=1)         # the blocking call needs an idle handle
             assert key(gpu_small.hunt_wait(ta)) == want_a
+            td = gpu_small.hunt_submit(qc, g["seqlen"], distance=1, hamming=True, compact=cpt)  # lane of `ta` is free again
+            assert key(gpu_small.hunt_wait(tb)) == want_b
+            assert key(other.hunt_wait(tc)) == want_c
+            assert key(gpu_small.hunt_wait(td)) == want_c
+        with pytest.raises(dicey_amd.DgError):  # a bound that does not hold fails the batch loudly
+            gpu_small.hunt(qa, g["seqlen"], distance=1, max_query_len=12)
     finally:
         other.close()
 

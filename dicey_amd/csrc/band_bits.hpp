@@ -52,7 +52,8 @@ DG_BB u64 qmask_of(const QMasks& m, u32 byte) {
   return byte == 'A' ? m.a : byte == 'C' ? m.c : byte == 'G' ? m.g : byte == 'T' ? m.t : byte == 'N' ? m.n : 0ULL;
 }
 template <int WB, typename TR, int TRS>
-DG_BB AlnRes band_align_bits(const u8* text, u64 text_n, bool indel, u64 loc, u32 mlen, u32 n, u32 d, PosMasks peq, TR* tr /* [row * TRS] */, u32& fault) {
+DG_BB AlnRes band_align_bits(const u8* text, u64 text_n, bool indel, u64 loc, u32 mlen, u32 n, u32 d, PosMasks peq, TR* tr /* [row * TRS] */,
+                             u64* win /* [6 words * TRS]: the window's bytes for reads at computed offsets */, u32& fault) {
   constexpr u32 NP = WB <= 7 ? 2u : 3u;   // planes = largest distance served + 1
   constexpr u32 WBM = (1u << WB) - 1u, TOP = 1u << (WB - 1);
   constexpr u32 VSH = WB <= 8 ? 8u : 16u;  // the vertical mask's place in a trace word
@@ -77,12 +78,12 @@ DG_BB AlnRes band_align_bits(const u8* text, u64 text_n, bool indel, u64 loc, u3
 #pragma unroll
     for (int i = 0; i < GW; ++i) gw[i] = sh ? (w[i] >> sh) | (w[i + 1] << (64 - sh)) : w[i];
   }
-  auto gw_at = [&](u32 i) -> u32 {  // byte i of the maximal window
-    u64 w = gw[0];
+  // bytes at computed offsets come from the copy in `win` (LDS on the device): indexing the register array by a computed
+  // offset sends it to scratch memory (r04b ISA: 96 bytes of scratch per lane, loads on the traceback's critical path)
 #pragma unroll
-    for (int k = 1; k < GW; ++k)
-      if ((i >> 3) == (u32)k) w = gw[k];
-    return (u32)(w >> (8 * (i & 7))) & 255u;
+  for (int i = 0; i < GW; ++i) win[i * TRS] = gw[i];
+  auto gw_at = [&](u32 i) -> u32 {  // byte i of the maximal window
+    return (u32)(win[(i >> 3) * TRS] >> (8 * (i & 7))) & 255u;
   };
   // hunter.h:363-378: the context stops at sequence separators
   u32 pre_eff = 0;
@@ -101,13 +102,7 @@ DG_BB AlnRes band_align_bits(const u8* text, u64 text_n, bool indel, u64 loc, u3
   u64 gsh[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) gsh[i] = skip ? (gw[i] >> (8 * skip)) | (gw[i + 1] << (64 - 8 * skip)) : gw[i];
-  auto g_ch = [&](u32 i) -> u32 {  // genomicseq[i]
-    u64 w = gsh[0];
-#pragma unroll
-    for (int k = 1; k < 5; ++k)
-      if ((i >> 3) == (u32)k) w = gsh[k];
-    return (u32)(w >> (8 * (i & 7))) & 255u;
-  };
+  auto g_ch = [&](u32 i) -> u32 { return gw_at(i + skip); };  // genomicseq[i]
   QMasks qm;
   {
     const u32 lenmask = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
@@ -248,8 +243,13 @@ DG_BB AlnRes band_align_bits(const u8* text, u64 text_n, bool indel, u64 loc, u3
   }
   const u32 lead = row, len = e;
   if (nops != cost || nops > 2) fault = 1;
-  if (nops >= 1) res.op[nops >= 2 ? 1 : 0] = aln_op(len - 1 - found_at[0], found[0] & 255u, found[0] >> 8);
-  if (nops >= 2) res.op[0] = aln_op(len - 1 - found_at[1], found[1] & 255u, found[1] >> 8);
+  // operations in column order: the backward walk met the last one first (no dynamic index: it would send res to scratch memory)
+  const u32 opa = aln_op(len - 1 - found_at[0], found[0] & 255u, found[0] >> 8), opb = aln_op(len - 1 - found_at[1], found[1] & 255u, found[1] >> 8);
+  if (nops == 1) res.op[0] = opa;
+  if (nops >= 2) {
+    res.op[0] = opb;
+    res.op[1] = opa;
+  }
   res.info = ((u32)(-(int)cost) & 255u) | (lead << 8) | (len << 16);
   return res;
 }

@@ -33,6 +33,7 @@
 #include "iupac.hpp"
 #include "nbhd_host.hpp"
 #include "band_bits.hpp"
+#include "hunt_cap.hpp"
 
 namespace dg {
 
@@ -518,7 +519,7 @@ static constexpr u32 FUSED_LCAP = 512;   // largest LDS list
 static constexpr u32 FUSED_QCAP = 512;   // survivor queue entries per round
 static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u); }
 template <bool INDEL>
-__global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap) {
+__global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap, u32 leave) {
   __shared__ u16 q_ent[FUSED_QCAP];  // lane | operation << 8
   __shared__ u32 q_n, c_probe, l_n, s_total, s_base;
   __shared__ u32 g_cnt[16], g_start[16], g_alive[16], g_base[16];
@@ -676,7 +677,7 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
       __syncthreads();
     }
   };
-  rounds(true, true);
+  rounds(true, leave != 0);
   if (gone) return;
   for (int off = 32; off > 0; off >>= 1) {
     steps += __shfl_xor(steps, off);
@@ -2916,7 +2917,7 @@ DG_DEV AlnRes band_align(const FmView& f, const Batch& b, const HitSeed sd, TR* 
   return res;
 }
 
-// Dynamic LDS: max(hash table, rows * 256 trace words), rows = maxlen + 3 d + 2 of the batch.
+// Dynamic LDS: max(hash table, rows * 256 trace words + 6 * 256 window words), rows = maxlen + 3 d + 2 of the batch.
 template <int WB, int CH>
 DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs& a, Counters* ctr, u32 rows) {
   using TR = typename std::conditional<(WB <= 8), u16, u32>::type;
@@ -3064,12 +3065,13 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
   if (SHARE) __syncthreads();  // the table's memory becomes the trace
   // ---- phase 2: per class
   TR* const tr = reinterpret_cast<TR*>(u_lds) + tid;
+  u64* const win = reinterpret_cast<u64*>(u_lds + ((rows * 256 * sizeof(TR) + 7) & ~(size_t)7)) + tid;  // 6 words per lane, word-major
   u32 fault = 0;
   auto align = [&](const HitSeed& s0) -> AlnRes {
     const u64 q = s0.qs >> 1;
     const uint4 pq = b.gpeq[s0.qs];
     return band_align_bits<WB, TR, 256>(f.text, f.n, b.indel != 0, (u64)s0.pos, s0.len, b.qlen[q], b.indel ? b.qdist[q] : 0u,
-                                        PosMasks{pq.x, pq.y, pq.z, pq.w}, tr, fault);
+                                        PosMasks{pq.x, pq.y, pq.z, pq.w}, tr, win, fault);
   };
   if (!SHARE) {
     cls[0] = tid;
@@ -3449,7 +3451,10 @@ struct CapScan {
 };
 // Returns DG_OK, DG_ELIMIT when the explicit patterns of this batch would not fit the host budget (the caller passes fewer
 // sequences per call: `dicey hunt` halves its chunk and retries), DG_ENOMEM when an enumeration ran out of memory.
-static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_params* p, bool count_mode, CapScan& cs) {
+// dev_jobs != nullptr: queries that qualify for the device enumeration (k_cap_enum: edit mode, distance <= 2, A/C/G/T only,
+// length + distance <= 31) are listed there instead of being enumerated here.
+static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_params* p, bool count_mode, CapScan& cs,
+                    std::vector<u32>* dev_jobs = nullptr) {
   const bool indel = !p->hamming;
   struct Job {
     size_t q;
@@ -3473,6 +3478,10 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
       bad += !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
     }
     if (neighbourhood_bound((u32)m, d, indel, bad) < p->max_neighborhood) continue;
+    if (dev_jobs && indel && d >= 1 && d <= 2 && bad == 0 && m >= 10 && m + d <= cap::MAX_KEY_LEN && q < 0x7FFFFFFFull) {
+      dev_jobs->push_back((u32)q);
+      continue;
+    }
     Job j;
     j.q = q;
     j.d = d;
@@ -3489,7 +3498,13 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
     worst_bytes += (p->forward_only ? 1ull : 2ull) * ((u64)p->max_neighborhood + 16) * (m + d + 12);
     jobs.push_back(std::move(j));
   }
-  if (jobs.empty()) return DG_OK;
+  if (jobs.empty()) {
+    if (dev_jobs && !dev_jobs->empty()) {  // the device pass fills in its queries' modes and appends its patterns
+      cs.mode.assign(nq, (u8)QM_KERNEL);
+      cs.xs_off.assign(1, 0);
+    }
+    return DG_OK;
+  }
   u64 budget = 16ull << 30;
   if (const char* e = std::getenv("DICEY_CAP_BUDGET_MB")) budget = (u64)std::max(1, std::atoi(e)) << 20;
   if (worst_bytes > budget)
@@ -3708,6 +3723,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   // Could any query of this batch reach the cap?  (the bound grows with the length and with the number of N's)
   CapScan cs;
+  std::vector<u32> dev_jobs;  // queries whose capped neighbourhood is enumerated on the device (k_cap_enum)
   // the caller's host copy of the offsets (nullptr on the dg_hunt_device path).  The read-back below serves cap_scan only and must not
   // outlive it: queue_fetch and the result's qoff distinguish "the caller has the offsets" from "pack them on the device" by this.
   const uint64_t* const caller_qoff = h_qoff;
@@ -3725,17 +3741,30 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       sb = hb.data();
       so = ho.data();
     }
-    DG_TRY(cap_scan(sb, so, nq, p, group_counts != nullptr, cs));
+    // DICEY_CAP_HOST: every capped neighbourhood on the host (nbhd_host.hpp), as before r04 — the GPU suite runs both
+    DG_TRY(cap_scan(sb, so, nq, p, group_counts != nullptr, cs, std::getenv("DICEY_CAP_HOST") ? nullptr : &dev_jobs));
   }
-  const u64 nxs = cs.xs_gid.size();
-  if (nxs >= 0xFFFFFFFFull || cs.xs_bytes.size() > (48ull << 30))
+  u64 nxs = cs.xs_gid.size();
+  if (nxs >= 0x0FFFFFFFull || cs.xs_bytes.size() > (48ull << 30))
     return fail(DG_ELIMIT, "%llu explicit neighbourhood strings in one batch; pass fewer sequences per call", (unsigned long long)nxs);
+  // room for what k_cap_enum can append: <= max(maxsize, 1) strings of <= maxlen + d characters per strand of its queries
+  const u64 dev_strings = dev_jobs.size() * (p->forward_only ? 1ull : 2ull) * std::max<u64>(p->max_neighborhood, 1);
+  const u64 dev_bytes = dev_strings * (maxlen + dmax_eff);
+  if (!dev_jobs.empty()) {
+    u64 budget = 24ull << 30;
+    if (const char* e = std::getenv("DICEY_CAP_BUDGET_MB")) budget = (u64)std::max(1, std::atoi(e)) << 20;
+    if (dev_bytes + dev_strings * 12 > budget || nxs + dev_strings >= 0x0FFFFFFFull)
+      return fail(DG_ELIMIT, "%zu of the %zu sequences of this call can reach the maxNeighborhood cap (%u); their explicit neighbourhoods may need "
+                  "%llu MB of device memory (budget %llu MB): pass fewer sequences per call", dev_jobs.size(), nq, p->max_neighborhood,
+                  (unsigned long long)((dev_bytes + dev_strings * 12) >> 20), (unsigned long long)(budget >> 20));
+  }
   u8* d_qmode = nullptr;
   u8* d_xs_bytes = nullptr;
   u64* d_xs_off = nullptr;
   u32* d_xs_gid = nullptr;
   if (!cs.mode.empty()) {
-    const u64 a0 = (nq + 63) & ~63ull, a1 = a0 + ((cs.xs_bytes.size() + 63) & ~63ull), a2 = a1 + (nxs + 1) * 8, a3 = a2 + nxs * 4;
+    const u64 a0 = (nq + 63) & ~63ull, a1 = a0 + ((cs.xs_bytes.size() + dev_bytes + 63) & ~63ull), a2 = a1 + (nxs + dev_strings + 1) * 8,
+              a3 = a2 + (nxs + dev_strings) * 4;
     DG_TRY(ws[WS_XS].reserve(a3 + 64));
     u8* base = ws[WS_XS].as<u8>();
     d_qmode = base;
@@ -3749,6 +3778,55 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     }
     DG_HIP(hipMemcpyAsync(d_xs_off, cs.xs_off.data(), (nxs + 1) * 8, hipMemcpyHostToDevice, st));
     DG_HIP(hipStreamSynchronize(st));  // the host vectors go out of use only after the copies
+  }
+  if (!dev_jobs.empty()) {
+    // neighbors() with its cap on the device (hunt_cap.hpp): modes and explicit patterns of the listed queries, before k_prepare
+    // reads them.  One host round trip for the pattern count (launch sizes below depend on it).
+    const u32 njobs = (u32)dev_jobs.size();
+    const u32 nwg = std::min<u32>(njobs, 512u);
+    const u64 leaves = cap::total_leaves(std::min<u32>(maxlen, cap::MAX_KEY_LEN - dmax_eff), dmax_eff) + 2;
+    u32 tcap_log2 = 8;
+    while ((1ull << tcap_log2) < leaves * 5 / 2) ++tcap_log2;
+    const u32 evcap = (u32)((leaves + 2 + 63) & ~63ull);
+    const u64 o_tab = 0, o_ev = o_tab + (u64)nwg * 2 * (16ull << tcap_log2), o_jobs = o_ev + (u64)nwg * 2 * evcap * 4,
+              o_alloc = (o_jobs + (u64)njobs * 4 + 63) & ~63ull, o_end = o_alloc + 64;
+    DG_TRY(ws[WS_CAP].reserve(o_end));
+    u8* cb = ws[WS_CAP].as<u8>();
+    struct {
+      unsigned long long alloc;
+      u32 status, pad;
+    } h_al = {((unsigned long long)nxs << 36) | (unsigned long long)cs.xs_bytes.size(), 0u, 0u};
+    DG_HIP(hipMemcpyAsync(cb + o_jobs, dev_jobs.data(), (u64)njobs * 4, hipMemcpyHostToDevice, st));
+    DG_HIP(hipMemcpyAsync(cb + o_alloc, &h_al, sizeof h_al, hipMemcpyHostToDevice, st));
+    Batch qb{};  // k_cap_enum reads the raw queries only
+    qb.qbytes = (const u8*)d_qbytes;
+    qb.qoff = (const u64*)d_qoff;
+    qb.nq = nq;
+    CapDevArgs ca;
+    ca.jobs = (const u32*)(cb + o_jobs);
+    ca.njobs = njobs;
+    ca.tab = (u64*)(cb + o_tab);
+    ca.tcap_log2 = tcap_log2;
+    ca.ev = (int*)(cb + o_ev);
+    ca.evcap = evcap;
+    ca.qmode = d_qmode;
+    ca.xs_bytes = d_xs_bytes;
+    ca.xs_off = d_xs_off;
+    ca.xs_gid = d_xs_gid;
+    ca.alloc = (unsigned long long*)(cb + o_alloc);
+    ca.cap_strings = nxs + dev_strings;
+    ca.cap_bytes = cs.xs_bytes.size() + dev_bytes;
+    ca.status = (u32*)(cb + o_alloc + 8);
+    ca.maxsize = p->max_neighborhood;
+    ca.distance = p->distance;
+    ca.reverse = !p->forward_only;
+    hipLaunchKernelGGL(k_cap_enum, dim3(nwg), dim3(256), 0, st, qb, ca);
+    DG_HIP(hipMemcpyAsync(&h_al, cb + o_alloc, sizeof h_al, hipMemcpyDeviceToHost, st));
+    DG_HIP(hipStreamSynchronize(st));
+    DG_HIP(hipGetLastError());
+    if (h_al.status & 2u) return fail(DG_EHIP, "internal error: a hash table of the device neighbourhood enumeration overflowed");
+    if (h_al.status & 1u) return fail(DG_EHIP, "internal error: the device neighbourhood enumeration produced more strings than the cap allows");
+    nxs = h_al.alloc >> 36;
   }
   Batch b;
   b.fastK = (dmax_eff == 1 && ix->view.K && maxlen > ix->view.K && ngrp * (u64)std::min(maxlen, 31u) * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
@@ -3954,8 +4032,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           const u32 lcap_env = std::getenv("DICEY_FUSED_LCAP") ? std::max<u32>(1u, std::min<u32>(FUSED_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP")))) : 0u;
           const u32 lcap = lcap_env ? lcap_env : (ix->fused_leaves_hint > 48ull * g1.x ? FUSED_LCAP : FUSED_LCAP / 2);
           const u32 lds1 = fused_lds_bytes(lcap);
-          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap);
+          const u32 leave1 = std::getenv("DICEY_EXP_NOLEAVE") ? 0u : 1u;  // (r04 A/B: idle wavefronts end behind the probe phase or wait at the barrier)
+          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1);
         } else {
           const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
           if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
@@ -4104,7 +4183,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= share_at ? 8 : (per_q >= share_at / 2 ? 4 : 1));
         const u32 rows = maxlen + 3 * dmax_eff + 2;
         const bool wide = dmax_eff > 1;
-        const u32 nw_bytes = rows * 256 * (wide ? 4u : 2u), hash_bytes = 2u * 256u * (u32)ch * 10u;
+        const u32 nw_bytes = ((rows * 256 * (wide ? 4u : 2u) + 7u) & ~7u) + 6u * 256u * 8u, hash_bytes = 2u * 256u * (u32)ch * 10u;
         const u32 lds = std::max(nw_bytes, hash_bytes);
         const dim3 mgrid(ceil_div(hit_cap, (u64)256 * ch)), mblock(256);
 #define DG_LAUNCH_MEMO(WBV, CHV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_memo<WBV, CHV>), mgrid, mblock, lds, st, ix->view, b, va, ctr, rows)
@@ -4290,9 +4369,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->ms_locate = ev_ms(ix->ev[5], ix->ev[6]);
   R->ms_verify = ev_ms(ix->ev[6], ix->ev[7]);
   if (host_timing)
-    std::fprintf(stderr, "dicey timing: batch of %zu on stream %p: host %.0f us before the synchronisation (last attempt's launches included), "
-                 "%.0f us waiting, %.0f us after; device %.3f ms\n", nq, (void*)st, t_launched - t_enter, t_synced - t_launched,
-                 host_us() - t_synced, R->ms_total);
+    std::fprintf(stderr, "dicey timing: batch of %zu on stream %p entered at %.0f us: host %.0f us before the synchronisation (last attempt's "
+                 "launches included), %.0f us waiting, %.0f us after; device %.3f ms\n", nq, (void*)st, std::fmod(t_enter, 1e8), t_launched - t_enter,
+                 t_synced - t_launched, host_us() - t_synced, R->ms_total);
   return DG_OK;
 }
 
@@ -4575,9 +4654,12 @@ struct dg_index::Worker {
         t = job;
         job = nullptr;
       }
+      const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
+      const double t_take = tm ? host_us() : 0.0;
       t->rc = hunt_host(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), (const uint8_t*)t->stage->p,
                         (const uint64_t*)((const uint8_t*)t->stage->p + t->off_at), t->nq, &t->res, t->stage);
       if (t->rc != DG_OK) t->err = dg_last_error();  // the message is thread-local: carried over to the waiting thread
+      if (tm) std::fprintf(stderr, "dicey timing: worker %p took its batch at %.0f us, done at %.0f us\n", (void*)t->ix, std::fmod(t_take, 1e8), std::fmod(host_us(), 1e8));
       {
         std::lock_guard<std::mutex> lk(mu);
         t->done = true;
@@ -4603,6 +4685,8 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
   if (!ix || !p || !seqlen || !qoff || !out || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_hunt_submit: null argument");
   *out = nullptr;
   if (!nq) return fail(DG_EINVAL, "dg_hunt_submit: empty batch");
+  const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
+  const double t_sub = tm ? host_us() : 0.0;
   // two lanes per handle (ABI 5): the handle itself while it is idle, else its internal second lane (a shared handle: own stream,
   // workspaces and helper thread on the same resident index; created at the first need).  A caller that keeps one batch in flight
   // never leaves the first lane.
@@ -4651,17 +4735,21 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     return fail(DG_ENOMEM, "dg_hunt_submit: %s", e.what());
   }
   *out = t;
+  if (tm) std::fprintf(stderr, "dicey timing: submit to %p from %.0f to %.0f us\n", (void*)ix, std::fmod(t_sub, 1e8), std::fmod(host_us(), 1e8));
   return DG_OK;
 }
 
 int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out) {
   if (!t || !out) return fail(DG_EINVAL, "dg_hunt_wait: null argument");
   dg_index* ix = t->ix;
+  const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
+  const double t_w = tm ? host_us() : 0.0;
   {
     std::unique_lock<std::mutex> lk(ix->worker->mu);
     ix->worker->cv.wait(lk, [&] { return t->done; });
   }
   ix->busy.store(false);
+  if (tm) std::fprintf(stderr, "dicey timing: wait on %p from %.0f to %.0f us\n", (void*)ix, std::fmod(t_w, 1e8), std::fmod(host_us(), 1e8));
   *out = t->res;
   const int rc = t->rc;
   const std::string err = t->err;

@@ -14,7 +14,7 @@ struct dg_index {
   uint64_t file_bytes = 0, hbm_bytes = 0;
   double load_seconds = 0, derive_seconds = 0;
   // grow-only batch workspaces (see hunt.hip / seam.hip for the slot meaning)
-  static constexpr int NWS = 23;
+  static constexpr int NWS = 24;
   dg::DevBuf ws[NWS];
   hipEvent_t ev[9] = {nullptr};  // [8]: end of the flat distance-1 kernel
   uint32_t flat_cap_hint = 0;   // slice capacity of the flat Sel region that was enough so far (hunt.hip)

@@ -7,13 +7,14 @@
 extern "C" int bb_align(const uint8_t* text, uint64_t text_n, uint64_t loc, uint32_t mlen, uint32_t n, uint32_t d, int indel, int wide,
                         const uint32_t* masks /* a c g t */, uint32_t* info, uint32_t* ops /* [2] */, uint32_t* pre_eff) {
   std::vector<uint32_t> tr(64, 0);
+  uint64_t win[8] = {0};
   uint32_t fault = 0;
   dg::PosMasks pm{masks[0], masks[1], masks[2], masks[3]};
   dg::AlnRes r;
-  if (wide) r = dg::band_align_bits<13, uint32_t, 1>(text, text_n, indel != 0, loc, mlen, n, d, pm, tr.data(), fault);
+  if (wide) r = dg::band_align_bits<13, uint32_t, 1>(text, text_n, indel != 0, loc, mlen, n, d, pm, tr.data(), win, fault);
   else {
     std::vector<uint16_t> t16(64, 0);
-    r = dg::band_align_bits<7, uint16_t, 1>(text, text_n, indel != 0, loc, mlen, n, d, pm, t16.data(), fault);
+    r = dg::band_align_bits<7, uint16_t, 1>(text, text_n, indel != 0, loc, mlen, n, d, pm, t16.data(), win, fault);
   }
   *info = r.info;
   ops[0] = r.op[0];

@@ -32,6 +32,16 @@ def ix(small_genome):
     h.close()
 
 
+@pytest.fixture(params=["device", "host"], autouse=True)
+def cap_path(request, monkeypatch):
+    """r04: capped neighbourhoods of A/C/G/T sequences up to 29 nt (edit distance <= 2) are enumerated on the device (k_cap_enum);
+    DICEY_CAP_HOST keeps every one of them on the host enumerator (nbhd_host.hpp), which also serves the rest (N, longer, Hamming).
+    Every test of this module runs both ways."""
+    if request.param == "host":
+        monkeypatch.setenv("DICEY_CAP_HOST", "1")
+    return request.param
+
+
 def compare(ix, g, qs, **kw):
     """hits (push order) and messages of every query against the oracle's restated hunter.h loop"""
     got = ix.hunt(qs, g["seqlen"], **kw)
@@ -158,5 +168,20 @@ def test_edit2_long_primers_on_the_kernel_path_with_a_wide_cap(ix, small_genome)
     try:
         compare(ix, small_genome, qs, distance=2, max_neighborhood=200000)
         compare(ix, small_genome, qs[:6], distance=2, max_neighborhood=200000, max_locations=4, forward_only=True)
+    finally:
+        O.fast_neighbors(False)
+
+
+def test_many_capped_primers_on_the_device_path(ix, small_genome):
+    """200 primers of 21-29 nt at distance 2 (most of them reach the cap), low-complexity ones included, -x 10000 / 3000 / 64:
+    hits, order and messages against the checker's hash-set neighbourhoods (tested equal to the literal ones)"""
+    rng = random.Random(404)
+    qs = [sample(small_genome, rng, rng.choice([21, 23, 25, 25, 27, 29]), edits=rng.choice([0, 1, 2])) for _ in range(60)]
+    qs += ["A" * 25, "AC" * 13, "ACG" * 9, "AAAAACCCCCGGGGGTTTTTAAAAA", "T" * 21 + "G"]
+    O.fast_neighbors(True)
+    try:
+        compare(ix, small_genome, qs, distance=2)
+        compare(ix, small_genome, qs[:20], distance=2, max_neighborhood=3000, forward_only=True)
+        compare(ix, small_genome, qs[20:40], distance=2, max_neighborhood=64, max_locations=5)
     finally:
         O.fast_neighbors(False)

@@ -590,8 +590,10 @@ def main():
                     nh = rp2.contents.nhits
                     L.dg_hunt_result_free(rp2)
                     return nh
-                for k in range(4):  # warm both lanes (workspaces, pinned blocks)
-                    wait(submit(k))
+                for k in range(0, 8, 2):  # warm BOTH lanes (the second one exists only once two batches are in flight: workspaces, pinned blocks)
+                    ta, tb = submit(k), submit(k + 1)
+                    wait(ta)
+                    wait(tb)
                 torch.cuda.synchronize()
                 nst = max(a.steps, 2 * len(host_batches))
                 tp = time.perf_counter()

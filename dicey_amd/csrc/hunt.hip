@@ -104,10 +104,15 @@ DG_HD u64 neighbourhood_bound(u32 m, u32 d, bool indel, u32 nN = 0) {
 // ------------------------------------------------------------------------------------------------------------
 // (r03: the characters come in as aligned 64-bit words loaded together — the byte loop waited for one load per character, 20 us
 // for 100 000 20-mers — and the lane clears its query's group counters, which takes the place of a memset in front of the batch)
-__global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic) {
-  u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.nq) return;
-  grp_cnt[2 * q] = grp_cnt[2 * q + 1] = 0;
+// One query: hunter.h:299-315 + util.h:54-114,208-219.  write_bytes: the per-character arrays (fw / rv codes, normalised ASCII) are
+// only read by the generic kernels, the full-matrix verify and the classic result fetch; the flat distance-1 path with the
+// banded verify and compact results works from the packed records (GidInfo, position masks) alone.  grp_cnt may be null (the
+// generic path's group counters).  gi_out: the two strands' records, also stored to b.ginfo.
+struct PreparedQuery {
+  u32 flags, d, bad;
+};
+DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic, bool write_bytes, GidInfo* gi_out) {
+  if (grp_cnt) grp_cnt[2 * q] = grp_cnt[2 * q + 1] = 0;
   nsel[2 * q] = nsel[2 * q + 1] = 0;
   selbase[2 * q] = selbase[2 * q + 1] = 0xFFFFFFFFu;  // "generic path" until k_search1s claims the group
   u64 s = b.qoff[q], e = b.qoff[q + 1];
@@ -132,9 +137,11 @@ __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n
         if (ch >= 'a' && ch <= 'z') ch -= 32;  // boost::to_upper_copy, hunter.h:306
         const u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
         bad += (code == 4);  // every replaced character raises one warning (util.h:214); a literal 'N' is replaced too
-        b.fw[s + i] = (u8)code;
-        b.qseq[s + i] = ascii_of(code);
-        b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);  // util.h:54-91,110-114
+        if (write_bytes) {
+          b.fw[s + i] = (u8)code;
+          b.qseq[s + i] = ascii_of(code);
+          b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);  // util.h:54-91,110-114
+        }
         pk_fw = (pk_fw << 2) | (code & 3u);
         pk_rv |= (u64)((3u - code) & 3u) << (2 * (i & 31u));
         if (i < 32) {
@@ -181,6 +188,7 @@ __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n
     if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
     if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
     b.ginfo[2 * q + strand] = gi;
+    if (gi_out) gi_out[strand] = gi;
     // the banded verify takes the query as position masks (band_align_bits); the reverse strand's character j is the complement
     // of the forward strand's character m - 1 - j
     if (m <= 32 && m >= 1) {
@@ -194,6 +202,12 @@ __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n
   // groups the flat distance-1 kernel does not take: the host launches the generic kernels for them (and repeats a batch it
   // started without, run_batch).  A flag, not a count: every lane that has one stores the same 1.
   if (generic && b.fastK) *n_generic = 1u;
+  return PreparedQuery{flags, d, bad};
+}
+__global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic) {
+  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq) return;
+  (void)prepare_query(b, q, grp_cnt, nsel, selbase, n_generic, true, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -518,11 +532,22 @@ struct FlatSel {
 static constexpr u32 FUSED_LCAP = 512;   // largest LDS list
 static constexpr u32 FUSED_QCAP = 512;   // survivor queue entries per round
 static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u); }
-template <bool INDEL>
-__global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap, u32 leave) {
+// PREP (r04): the workgroup also does k_prepare's work for its own queries in front (gpw / 2 lanes, the records stay in LDS for
+// every later read) and k_take's behind (the occurrences of a query's kept strings in push order: take = what hunter.h:349-357
+// still accepts, a saturating prefix sum) — the two kernels, 17 + 12 us of a 0.34 ms step, are not launched.  Used when the whole
+// batch is on the flat path (no generic kernels); gpw is even then, so that both strands of a query sit in one workgroup.
+struct PrepOut {
+  u32* qhits;      // [nq] hits per query (k_take's output)
+  u32* n_generic;  // k_prepare's flag
+  u32 write_bytes;
+};
+template <bool INDEL, bool PREP>
+__global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap, u32 leave, PrepOut po) {  // 8 wavefronts per SIMD: the kernel is bound by requests in flight (r04: 106 SGPRs had left 7)
   __shared__ u16 q_ent[FUSED_QCAP];  // lane | operation << 8
   __shared__ u32 q_n, c_probe, l_n, s_total, s_base;
   __shared__ u32 g_cnt[16], g_start[16], g_alive[16], g_base[16];
+  __shared__ uint4 s_gi[16];                 // PREP: the groups' records (GidInfo as four words)
+  __shared__ unsigned long long g_occ[16];   // PREP: occurrences of a group's kept strings, each clamped to max_locations
   DG_DYNAMIC_LDS(dyn);  // the list of occurring strings: lcap entries
   unsigned long long* const l_key = reinterpret_cast<unsigned long long*>(dyn);
   u32* const l_lo = reinterpret_cast<u32*>(dyn + (size_t)lcap * 8);
@@ -536,19 +561,37 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
     c_probe = 0;
     l_n = 0;
   }
-  if (threadIdx.x < 16) g_cnt[threadIdx.x] = g_alive[threadIdx.x] = 0;
+  if (threadIdx.x < 16) {
+    g_cnt[threadIdx.x] = g_alive[threadIdx.x] = 0;
+    g_occ[threadIdx.x] = 0ULL;
+  }
+  const u32 ngrp2 = (u32)(2 * b.nq);
+  const u32 g_first = blockIdx.x * gpw;
+  PreparedQuery mine{0u, 0u, 0u};  // PREP: what the lane that prepared a query needs again when it writes the query's totals
+  if (PREP) {
+    if (threadIdx.x < gpw / 2) {
+      const u64 q = (u64)(g_first / 2) + threadIdx.x;
+      GidInfo gi[2];
+      gi[0].qpk = gi[1].qpk = 0;
+      gi[0].m = gi[1].m = 0;
+      gi[0].d_win = gi[1].d_win = 0;
+      if (q < b.nq) mine = prepare_query(b, q, nullptr, fs.nsel, fs.selbase, po.n_generic, po.write_bytes != 0, gi);
+#pragma unroll
+      for (u32 st2 = 0; st2 < 2; ++st2)
+        s_gi[2 * threadIdx.x + st2] = make_uint4((u32)gi[st2].qpk, (u32)(gi[st2].qpk >> 32), gi[st2].m, gi[st2].d_win);
+    }
+  }
   __syncthreads();
+  auto ginfo_of = [&](u32 lg, u32 gid) -> uint4 { return PREP ? s_gi[lg] : *reinterpret_cast<const uint4*>(b.ginfo + gid); };
   const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
   const u64 kmask = (1ULL << (2 * K)) - 1;
   const u32 lane = threadIdx.x & 63;
-  const u32 ngrp2 = (u32)(2 * b.nq);
-  const u32 g_first = blockIdx.x * gpw;
   u32 mask_all = 0, nprobe = 0;
   {
     const u32 lg = (threadIdx.x * magic) >> 16, pos = threadIdx.x - lg * ipg + 1;
     const u32 gid = g_first + lg;
     if (lg < gpw && gid < ngrp2) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+      const uint4 raw = ginfo_of(lg, gid);
       const u64 qpk = (u64)raw.y << 32 | raw.x;
       const u32 m = raw.z, d_win = raw.w;
       if (m && (d_win & 512u) && pos <= m) {
@@ -599,7 +642,7 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
         const u32 ent = q_ent[e], sl = ent & 255u, op = ent >> 8;
         const u32 lg = (sl * magic) >> 16, pos = sl - lg * ipg + 1;
         const u32 gid = g_first + lg;
-        const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+        const uint4 raw = ginfo_of(lg, gid);
         u64 s_pk;
         u32 mlen, ow;
         (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
@@ -739,6 +782,10 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
     if (ok) {
       l_meta[i] = (u16)(meta | 0x8000u);
       atomicAdd(&g_alive[lg], 1u);
+      if (PREP) {
+        const u64 occ = (u64)l_hi[i] - l_lo[i];
+        atomicAdd(&g_occ[lg], (unsigned long long)(occ < b.max_locations ? occ : b.max_locations));
+      }
     }
   }
   __syncthreads();
@@ -764,12 +811,18 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
     const u64 ak = l_key[i] << (64 - 2 * alen);
     const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
     u32 r = 0;
+    u64 before = (PREP && (lg & 1u)) ? g_occ[lg - 1] : 0ULL;  // PREP: occurrences (clamped) of the strings in front of this one in push order
     for (u32 j = s0; j < s1; ++j) {
       const u32 x = l_ord[j], xm = l_meta[x];
       if (x == i || !(xm & 0x8000u)) continue;
       const u32 xlen = xm & 63u;
       const u64 xk = l_key[x] << (64 - 2 * xlen);
-      r += (xk < ak) || (xk == ak && xlen < alen);
+      const bool first = (xk < ak) || (xk == ak && xlen < alen);
+      r += first;
+      if (PREP && first) {
+        const u64 occ = (u64)l_hi[x] - l_lo[x];
+        before += occ < b.max_locations ? occ : b.max_locations;
+      }
     }
     if (room) {
       Sel sv;
@@ -778,16 +831,36 @@ __global__ void __launch_bounds__(256) k_search1s(FmView f, Batch b, SearchOut o
       sv.len = alen;
       sv.take = 0;
       sv.hbase = 0;
+      if (PREP) {  // hunter.h:349-357: strings are located in set order, forward strand first, while hits < max_locations
+        const u64 M = b.max_locations, occ = (u64)sv.hi - sv.lo;
+        const u64 h0 = before < M ? before : M, h1 = before + occ < M ? before + occ : M;
+        sv.hbase = (u32)h0;
+        sv.take = (u32)(h1 - h0);
+      }
       sv.g = g_first + lg;
       fs.sel[(u64)shard * fs.cap + wbase + g_base[lg] + r] = sv;
     }
   }
   if (threadIdx.x < gpw && g_first + threadIdx.x < ngrp2) {
     const u32 gid = g_first + threadIdx.x;
-    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+    const uint4 raw = ginfo_of(threadIdx.x, gid);
     if (raw.z && (raw.w & 512u)) {  // groups this kernel searches: their strings are in the flat region, also when there are none
       fs.nsel[gid] = room ? g_alive[threadIdx.x] : 0u;
       fs.selbase[gid] = shard * fs.cap + wbase + g_base[threadIdx.x];
+    }
+  }
+  if (PREP && threadIdx.x < gpw / 2) {  // k_take's per-query part: the hit count, hunter.h:434, the compact results' word
+    const u64 q = (u64)(g_first / 2) + threadIdx.x;
+    if (q < b.nq) {
+      const u64 M = b.max_locations, tot = g_occ[2 * threadIdx.x] + g_occ[2 * threadIdx.x + 1];
+      const u64 hits = room ? (tot < M ? tot : M) : 0ULL;
+      po.qhits[q] = (u32)hits;
+      u32 fl = mine.flags;
+      if (hits >= M && !(fl & DG_Q_TOO_SHORT)) {
+        fl |= DG_Q_MAX_MATCHES;
+        b.qflags[q] = fl;
+      }
+      if (b.qinfo) b.qinfo[q] = (fl & 255u) | ((mine.d & 255u) << 8) | (mine.bad << 16);
     }
   }
 }
@@ -4008,7 +4081,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (ix->ctr_clean != (const void*)ctr || ix->ctr_clean_gen != ws[WS_GRP].gen) DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     ix->ctr_clean = nullptr;  // dirty until this attempt's last kernel has run
     DG_HIP(hipEventRecord(ix->ev[0], st));
-    hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_cnt, nsel, selbase, (u32*)&ctr->pad_[6]);
+    // the whole batch on the flat distance-1 path: k_search1s prepares its own queries and settles their `take` values itself
+    // (PREP form); DICEY_NO_PREP_FUSION keeps k_prepare / k_take as launches of their own (the GPU suite runs both)
+    const bool prep_in = fused && !generic_on && !group_counts && !std::getenv("DICEY_NO_PREP_FUSION");
+    if (!prep_in) hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_cnt, nsel, selbase, (u32*)&ctr->pad_[6]);
     DG_HIP(hipEventRecord(ix->ev[1], st));
     {
       SearchOut so;
@@ -4019,7 +4095,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (b.fastK) {  // distance 1: the flat kernel takes every query that qualifies, k_search (one lane per strand) the rest
         const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg;  // longer queries stay with k_search
         if (fused) {
-          const u32 gpw = std::min(16u, 256u / ipg);
+          const u32 gpw = prep_in ? (std::min(16u, 256u / ipg) & ~1u) : std::min(16u, 256u / ipg);  // PREP: both strands of a query in one workgroup
           FlatSel fs;
           fs.sel = sel_all;
           fs.cap = flat_cap;
@@ -4033,8 +4109,18 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           const u32 lcap = lcap_env ? lcap_env : (ix->fused_leaves_hint > 48ull * g1.x ? FUSED_LCAP : FUSED_LCAP / 2);
           const u32 lds1 = fused_lds_bytes(lcap);
           const u32 leave1 = std::getenv("DICEY_EXP_NOLEAVE") ? 0u : 1u;  // (r04 A/B: idle wavefronts end behind the probe phase or wait at the barrier)
-          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1);
+          PrepOut po;
+          po.qhits = qhits;
+          po.n_generic = (u32*)&ctr->pad_[6];
+          // the per-character arrays are read by the full-matrix verify kernels and by the classic result fetch only
+          po.write_bytes = (band_verify && (compact || !fetch)) ? 0u : 1u;
+          if (prep_in) {
+            if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true, true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1, po);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false, true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1, po);
+          } else {
+            if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true, false>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1, po);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false, false>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1, po);
+          }
         } else {
           const dim3 g1(ceil_div(ngrp * ipg, TB)), b1(TB);
           if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1p<true>), g1, b1, 0, st, ix->view, b, so, ipg, magic);
@@ -4088,8 +4174,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       hipLaunchKernelGGL(k_leaf_rank, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
                          (const u8*)alive, sel_gen, nsel, ctr, above);
       }
-      hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, (const u64*)grp_off, (const u32*)selbase, flat_slots, (const u32*)nsel, sel_all,
-                         qhits, ctr);
+      if (!prep_in)
+        hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, (const u64*)grp_off, (const u32*)selbase, flat_slots, (const u32*)nsel, sel_all,
+                           qhits, ctr);
     } else {
       hipLaunchKernelGGL(k_group, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr, grp_off,
                          ws[WS_LEAFG].as<Leaf>());

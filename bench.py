@@ -334,10 +334,17 @@ def main():
                          "GRCh38-size genome, search kernel ~5 %% faster); the default is the library's default layout")
     ap.add_argument("--fm9", default="", help="reuse an existing index file instead of building the synthetic one")
     ap.add_argument("--keep-index", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1, hunt configs: weak = every rank searches its own --queries per step (the default, what the driver's scaling "
+                         "run measures); strong = the N ranks share ONE batch of --queries by contiguous ranges (shard_range), e.g. "
+                         "--config hunt_d2 --queries 10000000 --scaling strong for BASELINE configs[3]")
     ap.add_argument("--batches", type=int, default=16,
                     help="hunt configs: distinct query batches resident in HBM that the warm-up and timed steps cycle through (step k "
                          "searches batch k mod B; hunter.h:291 searches every query once, so the headline never replays a batch within "
                          "B launches); 1 = the replayed-batch run of r01-r03, which the default run still reports as value_same_batch")
+    ap.add_argument("--cli-queries", type=int, default=10000000,
+                    help="hunt_d1 default run (N = 1): size of the large `dicey hunt` run timed after the bench released its index "
+                         "(BASELINE configs[3]'s 10 M queries through the binary: FASTA in, one JSON line per query out); 0 = skip")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="optional extra measurement after the timed region (hunt, N=1 only): the same steps with this many batches in "
                          "flight, one host thread + one handle on the shared index each (dg_index_share).  Off by default so that "
@@ -401,6 +408,7 @@ def main():
     fm9 = a.fm9 or os.path.join(shm, f"dicey_bench_{os.environ.get('MASTER_PORT', 'p')}_{a.genome}_{int(a.genome_size)}.fm9")
     meta_path = fm9 + f".{cfg}.{units}.meta.json"
     batches_path = fm9 + f".{cfg}.{units}.q{a.qlen}.b{a.batches}.npy"
+    cli_big_path = fm9 + f".cli{a.cli_queries}.q{a.qlen}.npy"
     t0 = time.time()
     info = {}
     host_text = None
@@ -424,6 +432,10 @@ def main():
                 more = np.stack([np.stack([synth_query_batch(text, units, a.qlen, seed=qseed + r + 1000 * b) for b in range(1, a.batches)])
                                  for r in range(world)])
                 np.save(batches_path, more)
+            # the large CLI run's queries (distinct draws, 100 000 at a time), while the text is here
+            if cfg == "hunt_d1" and world == 1 and a.cli_queries > 0 and not a.no_extras and not a.no_extra_configs:
+                big = np.concatenate([synth_query_batch(text, 100000, a.qlen, seed=5000 + i) for i in range((a.cli_queries + 99999) // 100000)])
+                np.save(cli_big_path, big[:a.cli_queries])
         elif cfg == "search":
             meta["primers"] = [synth_primer_pairs(text, units // 2, seed=qseed + 100 * r) for r in range(world)]
         else:
@@ -453,7 +465,7 @@ def main():
                     "L1-like 6 kb, 40 smaller families, microsatellites, segmental duplications; 0.5-30 % divergence per copy)") +
                    ", 5% N runs, seed 1 (no real genome is available offline)")
     base_out = {"metric": METRIC, "unit": "primers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+                "scaling": a.scaling, "vs_baseline": None, "data": "synthetic"}
     pipe = {"g": None}
     shared = [ix]
     th = None
@@ -480,9 +492,18 @@ def main():
         """result lists to rank 0 over RCCL/xGMI, overlapped with the next step (dicey_amd/shard.py)"""
         if pipe["g"] is None:  # first (warm-up) step: agree on a capacity once
             nbytes = sum(int(t.numel()) for t in parts)
-            pipe["g"] = PipelinedGather(int(nbytes * 1.25) + 4096, dev if a.backend == "nccl" else torch.device("cpu"))
-        pipe["g"].submit(parts)
-        torch.cuda.current_stream().synchronize()  # the library reuses its buffers in the next step, on its own stream
+            pipe["g"] = PipelinedGather(int(nbytes * 1.5) + 65536,  # a bound, not what travels: the gather moves each step's agreed payload size
+                                        dev if a.backend == "nccl" else torch.device("cpu"))
+        # staged on the library's own stream (dg_index_stream): the copies out of its result buffers are ordered in front of the
+        # next batch's kernels by the stream itself — no host synchronisation per step (r03 synchronised torch's stream here)
+        if pipe.get("ext") is None and a.backend == "nccl":
+            pipe["ext"] = torch.cuda.ExternalStream(int(L.dg_index_stream(ix.handle)), device=dev)
+        if pipe.get("ext") is not None:
+            with torch.cuda.stream(pipe["ext"]):
+                pipe["g"].submit(parts)
+        else:
+            pipe["g"].submit(parts)
+            torch.cuda.current_stream().synchronize()
         if a.dump_gather:
             pipe["last_local"] = torch.cat([t.reshape(-1) for t in parts]).cpu().numpy().tobytes()
 
@@ -491,7 +512,13 @@ def main():
     cli_job = None
     # =====================================================================================================================
     if cfg in ("hunt_d1", "hunt_d2"):
-        queries = [q.encode() for q in meta["queries"][rank if rank < len(meta["queries"]) else 0]]
+        strong = a.scaling == "strong" and world > 1
+        if strong:  # one batch for the whole job, cut into contiguous ranges in rank order (an empty range is a legal shard)
+            from dicey_amd.shard import shard_range
+            lo_q, hi_q = shard_range(len(meta["queries"][0]), rank, world)
+            queries = [q.encode() for q in meta["queries"][0][lo_q:hi_q]]
+        else:
+            queries = [q.encode() for q in meta["queries"][rank if rank < len(meta["queries"]) else 0]]
         nq = len(queries)
         qbytes = b"".join(queries)
         off = np.zeros(nq + 1, dtype=np.uint64)
@@ -507,7 +534,7 @@ def main():
         dev_batches = [(d_q, d_off, len(qbytes))]
         if a.batches > 1:
             more = np.load(batches_path, mmap_mode="r")
-            more = more[rank if rank < more.shape[0] else 0]
+            more = more[0][:, lo_q:hi_q] if strong else more[rank if rank < more.shape[0] else 0]
             for bi in range(more.shape[0]):
                 arr = np.ascontiguousarray(more[bi])
                 dev_batches.append((torch.from_numpy(arr.reshape(-1).copy()).to(dev), torch.from_numpy(off.view(np.int64).copy()).to(dev),
@@ -517,6 +544,11 @@ def main():
         def step(fetch=0, handle=None, params=None):
             bq, bo, bbytes = dev_batches[rot["k"] % len(dev_batches)] if rot["on"] else dev_batches[0]
             rot["k"] += 1
+            if nq == 0:  # strong scaling: a rank behind the end of the batch still takes part in every gather
+                if world > 1 and not fetch:
+                    gather_parts([torch.empty(0, dtype=torch.uint8, device=dev)])
+                return {k_: 0 for k_ in ("nhits", "ext", "leaves", "sa", "win", "tab", "probe", "ops_per_hit", "ms_total", "ms_search",
+                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify")}
             rp = C.POINTER(_capi.HuntResult)()
             _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(params or p_compact), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
                                             C.c_void_p(bo.data_ptr()), nq, bbytes, fetch, C.byref(rp)))
@@ -719,7 +751,7 @@ def main():
                     pass
             out = dict(base_out)
             out.update({
-                "value": world * nq * a.steps / elapsed, "ms_per_step": elapsed / a.steps * 1e3, "dtype": "u32",
+                "value": (len(meta["queries"][0]) if strong else world * nq) * a.steps / elapsed, "ms_per_step": elapsed / a.steps * 1e3, "dtype": "u32",
                 "config": {"workload": f"dicey hunt, {nq} synthetic {a.qlen}-mers per GPU, edit distance {distance}, both strands, "
                                        f"-m 1000 -x 10000 (BASELINE.json configs[{1 if cfg == 'hunt_d1' else 3}])",
                            "genome": genome_desc,
@@ -949,6 +981,20 @@ def main():
             out["cli_end_to_end_after_release"] = cli_end_to_end(fm9, meta, cli_job[0], cli_job[1])  # right after 199 GB were freed
             time.sleep(8)  # the driver wipes released VRAM at ~32 GiB/s; allocations of the next process wait for it
             out["cli_end_to_end"] = cli_end_to_end(fm9, meta, cli_job[0], cli_job[1])
+            if os.path.exists(cli_big_path):
+                try:
+                    big = np.load(cli_big_path)
+                    os.remove(cli_big_path)
+                    chk = None
+                    if not a.no_cpu_baseline:
+                        sys.path.insert(0, os.path.join(ROOT, "tests"))
+                        import oracle_lib as O
+                        chk = O.Index(fm9)
+                    out["cli_end_to_end_1M"] = cli_end_to_end(fm9, meta, big[:1000000], cli_job[1], oracle=chk, seqlen=seqlen)
+                    out["cli_end_to_end_10M" if len(big) == 10000000 else "cli_end_to_end_%d" % len(big)] = \
+                        cli_end_to_end(fm9, meta, big, cli_job[1], oracle=chk, seqlen=seqlen)
+                except Exception as e:
+                    out["cli_end_to_end_10M"] = {"error": repr(e)[:300]}
         if (world == 1 and cfg == "hunt_d1" and a.genome == "iid" and not a.no_extra_configs and not a.no_extras and not a.queries
                 and a.distance < 0 and a.qlen == 20):
             out["extra_configs"] = run_extra_configs(a, fm9)
@@ -1020,9 +1066,11 @@ def run_extra_configs(a, fm9):
     return res
 
 
-def cli_end_to_end(fm9, meta, queries, distance):
+def cli_end_to_end(fm9, meta, queries, distance, oracle=None, seqlen=None):
     """The process seam: `dicey hunt -g <genome> <queries.fa>` on the same queries, wall clock of the whole process (index
-    open + derivation, search, JSON for every query).  hunt reads only <genome>.fai and the .fm9 next to the genome."""
+    open + derivation, search, JSON for every query).  hunt reads only <genome>.fai and the .fm9 next to the genome.
+    queries: list of bytes, or a uint8 array [n, m] (the large runs).  oracle (large runs): three slices of 100 lines of THIS run's
+    output are compared byte for byte with the checker's JSON for those queries."""
     import subprocess
     binary = os.path.join(ROOT, "dicey_amd", "dicey")
     if not os.path.exists(binary):
@@ -1030,6 +1078,7 @@ def cli_end_to_end(fm9, meta, queries, distance):
     d = os.path.dirname(fm9)
     base = os.path.join(d, "dicey_cli_genome_%d.fa" % os.getpid())
     made = []
+    nq = len(queries)
     try:
         with open(base + ".gz.fai", "w") as f:
             offs = 0
@@ -1042,18 +1091,66 @@ def cli_end_to_end(fm9, meta, queries, distance):
         os.symlink(fm9, base + ".fm9")
         made.append(base + ".fm9")
         qf = base + ".queries.fa"
-        with open(qf, "w") as f:
-            for i, q in enumerate(queries):
-                f.write(">q%06d\n%s\n" % (i, q.decode()))
         made.append(qf)
+        if isinstance(queries, np.ndarray):  # ">q0000000\nACGT...\n" rows assembled as one byte matrix
+            m = queries.shape[1]
+            rows = np.empty((nq, 10 + m + 1), dtype=np.uint8)
+            rows[:, 0] = ord(">")
+            rows[:, 1] = ord("q")
+            idx = np.arange(nq, dtype=np.int64)
+            for k in range(7):
+                rows[:, 8 - k] = ord("0") + (idx // 10 ** k) % 10
+            rows[:, 9] = 10
+            rows[:, 10:10 + m] = queries
+            rows[:, 10 + m] = 10
+            rows.tofile(qf)
+            name_of = lambda i: "q%07d" % i  # noqa: E731
+            seq_of = lambda i: queries[i].tobytes().decode()  # noqa: E731
+        else:
+            with open(qf, "w") as f:
+                for i, q in enumerate(queries):
+                    f.write(">q%06d\n%s\n" % (i, q.decode()))
+            name_of = lambda i: "q%06d" % i  # noqa: E731
+            seq_of = lambda i: queries[i].decode()  # noqa: E731
         outp = base + ".out.jsonl"
         made.append(outp)
+        try:  # ~650 output bytes per query land in /dev/shm, i.e. in memory: a box short of it gets /dev/null (and no parity slices)
+            avail_kb = [int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0]
+            if avail_kb * 1024 < 3 * 700 * nq + (8 << 30):
+                outp = "/dev/null"
+                oracle = None
+        except Exception:
+            pass
         t = time.time()
         with open(outp, "wb") as o:
             r = subprocess.run([binary, "hunt", "-d", str(distance), "-g", base + ".gz", qf], stdout=o, stderr=subprocess.PIPE, timeout=900,
                                env=dict(os.environ, DICEY_TIMING="1"))
         dt = time.time() - t
-        lines = sum(1 for _ in open(outp, "rb"))
+        out_bytes = os.path.getsize(outp) if outp != "/dev/null" else None
+        lines = 0
+        checked = None
+        if oracle is not None and nq >= 1000:
+            want = {}
+            for s0 in (0, nq // 2 - 50, nq - 100):
+                ids = list(range(s0, s0 + 100))
+                js, _ = oracle.hunt(seqlen, ["s%d" % i for i in range(len(seqlen))], [seq_of(i) for i in ids], qnames=[name_of(i) for i in ids],
+                                    genome=base + ".gz", distance=distance)
+                for i, ln in zip(ids, js.split("\n")[:-1]):
+                    want[i] = (ln + "\n").encode()
+            bad = 0
+            with open(outp, "rb") as f:
+                for i, ln in enumerate(f):
+                    lines += 1
+                    if i in want and ln != want[i]:
+                        bad += 1
+            checked = {"lines_compared_with_the_checker": len(want), "differing": bad}
+        else:
+            with open(outp, "rb") as f:
+                while True:
+                    blk = f.read(1 << 24)
+                    if not blk:
+                        break
+                    lines += blk.count(b"\n")
         phases = {}
         for ln in r.stderr.decode(errors="replace").splitlines():  # "dicey timing: <phase>   <ms> ms" from the library's open
             if ln.startswith("dicey timing:") and ln.rstrip().endswith("ms"):
@@ -1062,9 +1159,13 @@ def cli_end_to_end(fm9, meta, queries, distance):
                     phases[name.strip()] = float(val)
                 except ValueError:
                     pass
-        return {"value": len(queries) / dt, "unit": "primers/s", "seconds": dt, "exit_code": r.returncode, "json_lines": lines,
-                "index_open_phases_ms": phases,
-                "note": "one process on a free GPU: index open + derivation of the HBM layouts, the whole batch, one JSON line per query on stdout"}
+        res = {"value": nq / dt, "unit": "primers/s", "seconds": dt, "queries": nq, "exit_code": r.returncode, "json_lines": lines,
+               "output_bytes": out_bytes, "index_open_phases_ms": phases,
+               "note": "one process on a free GPU: index open + derivation of the HBM layouts, FASTA in, the whole input in chunks with two "
+                       "batches in flight, one JSON line per query to a file in /dev/shm"}
+        if checked is not None:
+            res["parity_slices"] = checked
+        return res
     except Exception as e:  # an extra, never fatal for the bench line
         return {"error": str(e)[:200]}
     finally:

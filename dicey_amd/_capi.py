@@ -94,7 +94,7 @@ SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_
            "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
            "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free", "dg_index_share",
            "dg_neighbors", "dg_buffer_free", "dg_hit_rows", "dg_hunt_rows", "dg_hunt_submit", "dg_hunt_wait",
-           "dg_chit_unpack", "dg_normalize_query", "dg_hunt_expand"]
+           "dg_chit_unpack", "dg_normalize_query", "dg_hunt_expand", "dg_index_stream"]
 
 _lib = None
 
@@ -120,6 +120,8 @@ def load(path=None):
     L.dg_index_open.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(vp)]
     L.dg_index_share.argtypes = [vp, C.POINTER(vp)]
     L.dg_index_close.argtypes = [vp]
+    L.dg_index_stream.argtypes = [vp]
+    L.dg_index_stream.restype = vp
     L.dg_index_close.restype = None
     L.dg_index_stats.argtypes = [vp, C.POINTER(IndexStats)]
     L.dg_count.argtypes = [vp, C.c_char_p, u64p, C.c_size_t, u64p]

@@ -108,10 +108,11 @@ inline bool seq_len_name(const std::string& genome, std::vector<uint32_t>& seqle
 }
 
 // ------------------------------------------------------------------------------------------------ JSON (nlohmann 3.5.0 dump())
-inline std::string jstr(const std::string& s) {
+inline void jstr_append(std::string& o, const char* p, size_t n) {
   static const char* hex = "0123456789abcdef";
-  std::string o = "\"";
-  for (unsigned char c : s) {
+  o.push_back('"');
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned char c = (unsigned char)p[i];
     if (c == '"') o += "\\\"";
     else if (c == '\\') o += "\\\\";
     else if (c == '\b') o += "\\b";
@@ -126,7 +127,21 @@ inline std::string jstr(const std::string& s) {
     } else o.push_back((char)c);
   }
   o.push_back('"');
+}
+inline void jstr_append(std::string& o, const std::string& s) { jstr_append(o, s.data(), s.size()); }
+inline std::string jstr(const std::string& s) {
+  std::string o;
+  jstr_append(o, s);
   return o;
+}
+inline void uint_append(std::string& o, uint64_t v) {  // std::to_string without the temporary
+  char buf[24];
+  int n = 0;
+  do {
+    buf[n++] = (char)('0' + v % 10);
+    v /= 10;
+  } while (v);
+  while (n) o.push_back(buf[--n]);
 }
 
 // one gzip member per call, appended (hunter.h:162-170: gzip_compressor + file_sink(app))

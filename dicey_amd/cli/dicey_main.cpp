@@ -47,28 +47,44 @@ struct Config {
   uint32_t max_neighborhood = 10000, distance = 1;
 };
 
-// hunter.h:99-160
-std::string hunt_json(const Config& c, uint32_t distance, const std::string& sequence, const std::string& qname,
+// hunter.h:99-160 (r04: appended in place — at 10 M queries per run the temporaries of the first form were the run time)
+void hunt_json_append(std::string& o, const Config& c, uint32_t distance, const std::string& sequence, const std::string& qname,
                       const std::vector<std::string>& seqname, const std::vector<DnaHit>& ht, const std::vector<std::string>& msg) {
-  std::string o = "{\"errors\": [";
+  o += "{\"errors\": [";
   bool errors = false;
   for (size_t i = 0; i < msg.size(); ++i) {
     bool err = msg[i].compare(0, 5, "Error") == 0;
     errors = errors || err;
     if (i) o.push_back(',');
-    o += "{\"title\":" + jstr(msg[i]) + ",\"type\":" + (err ? "\"error\"" : "\"warning\"") + "}";
+    o += "{\"title\":";
+    jstr_append(o, msg[i]);
+    o += ",\"type\":";
+    o += err ? "\"error\"" : "\"warning\"";
+    o.push_back('}');
   }
   o.push_back(']');
   if (!errors) {
-    o += ",\"meta\":{\"distance\":" + std::to_string(distance);
-    o += std::string(",\"forwardonly\":") + (c.forward ? "true" : "false");
-    o += ",\"genome\":" + jstr(c.genome);
-    o += std::string(",\"hamming\":") + (c.hamming ? "true" : "false");
-    o += ",\"maxmatches\":" + std::to_string(c.max_locations);
-    if (!qname.empty()) o += ",\"name\":" + jstr(qname);
-    o += ",\"outfile\":" + jstr(c.outfile);
-    o += ",\"sequence\":" + jstr(sequence);
-    o += std::string(",\"subcommand\":\"hunt\",\"version\":\"") + kVersion + "\"},\"data\":[";
+    o += ",\"meta\":{\"distance\":";
+    uint_append(o, distance);
+    o += ",\"forwardonly\":";
+    o += c.forward ? "true" : "false";
+    o += ",\"genome\":";
+    jstr_append(o, c.genome);
+    o += ",\"hamming\":";
+    o += c.hamming ? "true" : "false";
+    o += ",\"maxmatches\":";
+    uint_append(o, c.max_locations);
+    if (!qname.empty()) {
+      o += ",\"name\":";
+      jstr_append(o, qname);
+    }
+    o += ",\"outfile\":";
+    jstr_append(o, c.outfile);
+    o += ",\"sequence\":";
+    jstr_append(o, sequence);
+    o += ",\"subcommand\":\"hunt\",\"version\":\"";
+    o += kVersion;
+    o += "\"},\"data\":[";
     uint32_t oldchr = 999999, oldstart = 0;
     bool first = true;
     for (const DnaHit& h : ht) {
@@ -77,10 +93,21 @@ std::string hunt_json(const Config& c, uint32_t distance, const std::string& seq
         first = false;
         uint32_t nuc = 0;
         for (char ch : h.refalign) nuc += ch != '-';
-        o += "{\"chr\":" + jstr(seqname[h.chr]) + ",\"distance\":" + std::to_string(std::abs(h.score));
-        o += ",\"end\":" + std::to_string(h.start + nuc - 1) + ",\"queryalign\":" + jstr(h.queryalign);
-        o += ",\"refalign\":" + jstr(h.refalign) + ",\"start\":" + std::to_string(h.start);
-        o += ",\"strand\":" + jstr(std::string(1, h.strand)) + "}";
+        o += "{\"chr\":";
+        jstr_append(o, seqname[h.chr]);
+        o += ",\"distance\":";
+        uint_append(o, (uint64_t)std::abs(h.score));
+        o += ",\"end\":";
+        uint_append(o, (uint32_t)(h.start + nuc - 1));
+        o += ",\"queryalign\":";
+        jstr_append(o, h.queryalign);
+        o += ",\"refalign\":";
+        jstr_append(o, h.refalign);
+        o += ",\"start\":";
+        uint_append(o, h.start);
+        o += ",\"strand\":\"";
+        o.push_back(h.strand);
+        o += "\"}";
       }
       oldchr = h.chr;
       oldstart = h.start;
@@ -88,6 +115,11 @@ std::string hunt_json(const Config& c, uint32_t distance, const std::string& seq
     o.push_back(']');
   }
   o += "}\n";
+}
+std::string hunt_json(const Config& c, uint32_t distance, const std::string& sequence, const std::string& qname,
+                      const std::vector<std::string>& seqname, const std::vector<DnaHit>& ht, const std::vector<std::string>& msg) {
+  std::string o;
+  hunt_json_append(o, c, distance, sequence, qname, seqname, ht, msg);
   return o;
 }
 
@@ -195,15 +227,31 @@ int hunter(int argc, char** argv) {
   if (is_regular(c.input)) {
     if (!is_fasta(c.input)) bad_fasta = true;
     else {
-      std::ifstream fa(c.input.c_str());
-      std::string line, fan, faseq;
-      while (std::getline(fa, line)) {
-        if (line.empty()) continue;
-        if (line[0] == '>') {
-          if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
-          faseq.clear();
-          fan = line.substr(1);
-        } else faseq += line;
+      // hunter.h:272-283 over the whole file in memory (10 M records: std::getline per line was seconds)
+      std::string buf;
+      if (FILE* f = std::fopen(c.input.c_str(), "rb")) {
+        std::fseek(f, 0, SEEK_END);
+        const long sz = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        buf.resize(sz > 0 ? (size_t)sz : 0);
+        if (sz > 0 && std::fread(&buf[0], 1, (size_t)sz, f) != (size_t)sz) buf.clear();
+        std::fclose(f);
+      }
+      queries.reserve(buf.size() / 28 + 16);
+      std::string fan, faseq;
+      const char* p0 = buf.data();
+      const char* const end = p0 + buf.size();
+      while (p0 < end) {
+        const char* nl = (const char*)std::memchr(p0, '\n', (size_t)(end - p0));
+        const char* e = nl ? nl : end;
+        if (e > p0) {  // (empty lines are skipped; std::getline keeps a '\r', so does this)
+          if (*p0 == '>') {
+            if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
+            faseq.clear();
+            fan.assign(p0 + 1, e);
+          } else faseq.append(p0, e);
+        }
+        p0 = nl ? nl + 1 : end;
       }
       if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
     }
@@ -261,7 +309,8 @@ int hunter(int argc, char** argv) {
   hp.max_locations = c.max_locations;
   hp.max_neighborhood = c.max_neighborhood;
   // queries [q0, q1) on one handle, chunk by chunk; sink(i, json line of query i) is called in query order
-  auto run_slice = [&](dg_index* ix, size_t s0, size_t s1, const std::function<void(size_t, std::string&&)>& sink, std::string& err) -> bool {
+  auto run_slice = [&](dg_index* ix, size_t s0, size_t s1, const std::function<void(size_t, std::string&&)>& sink, std::string& err,
+                       const std::function<void(std::string&&)>& bulk = nullptr) -> bool {
     auto pack = [&](size_t q0, size_t q1, std::string& qb, std::vector<uint64_t>& off) -> dg_hunt_params {
       qb.clear();
       off.assign(q1 - q0 + 1, 0);
@@ -323,7 +372,27 @@ int hunter(int argc, char** argv) {
       };
       unsigned nthr = std::thread::hardware_concurrency();
       if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthr = (unsigned)std::max(1, std::atoi(e));
-      nthr = (unsigned)std::min<size_t>(std::min<unsigned>(nthr ? nthr : 1u, 32u), nq / 32);
+      nthr = (unsigned)std::min<size_t>(std::min<unsigned>(nthr ? nthr : 1u, 64u), nq / 32);
+      if (nthr < 1) nthr = 1;
+      if (bulk) {
+        // stdout: every formatting thread appends its lines to one buffer, the buffers go out in order with one write each (the
+        // reference flushes after every line; the bytes are the same)
+        std::vector<std::string> blobs(nthr);
+        const size_t per_thr = (nq + nthr - 1) / nthr;
+        auto work = [&](unsigned t) {
+          std::string& o = blobs[t];
+          const size_t i0 = t * per_thr, i1 = std::min(nq, i0 + per_thr);
+          o.reserve((i1 > i0 ? i1 - i0 : 0) * 700);
+          for (size_t i = i0; i < i1; ++i) o += line_of(i);
+        };
+        if (nthr > 1) {
+          std::vector<std::thread> fmt;
+          for (unsigned t = 0; t < nthr; ++t) fmt.emplace_back(work, t);
+          for (auto& th : fmt) th.join();
+        } else work(0);
+        for (std::string& o : blobs) bulk(std::move(o));
+        return;
+      }
       if (nthr > 1) {
         std::vector<std::string> lines(nq);
         std::vector<std::thread> fmt;
@@ -432,7 +501,13 @@ int hunter(int argc, char** argv) {
   int rc_all = 0;
   if (G == 1) {
     std::string err;
-    if (!run_slice(handles[0], 0, queries.size(), [&](size_t, std::string&& js) { emit(c, js); }, err)) {
+    std::function<void(std::string&&)> bulk;
+    if (!c.has_outfile)  // (the gzip outfile is one member per query, hunter.h:162-170: written line by line)
+      bulk = [&](std::string&& blob) {
+        std::fwrite(blob.data(), 1, blob.size(), stdout);
+        std::fflush(stdout);
+      };
+    if (!run_slice(handles[0], 0, queries.size(), [&](size_t, std::string&& js) { emit(c, js); }, err, bulk)) {
       std::cerr << "dicey: " << err << std::endl;
       rc_all = 2;
     }

@@ -865,6 +865,251 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
   }
 }
 
+// ---- TEMPORARY (r04 A/B): the r03 form of k_search1s, launched with DICEY_EXP_OLD1S
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_search1s_r03(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap) {
+  __shared__ u16 q_ent[2048];  // lane | operation << 8
+  __shared__ u32 q_n, c_probe, l_n, s_total, s_base;
+  __shared__ unsigned long long l_key[512];
+  __shared__ u32 l_lo[512], l_hi[512];
+  __shared__ u16 l_meta[512];  // length | local group << 6 | alive << 15
+  __shared__ u16 l_pos[512], l_ord[512];
+  __shared__ u32 g_cnt[16], g_start[16], g_alive[16], g_base[16];
+  constexpr u32 NOPS = INDEL ? 8u : 4u;
+  if (threadIdx.x == 0) {
+    q_n = 0;
+    c_probe = 0;
+    l_n = 0;
+  }
+  if (threadIdx.x < 16) g_cnt[threadIdx.x] = g_alive[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1;
+  const u32 lane = threadIdx.x & 63;
+  const u32 ngrp2 = (u32)(2 * b.nq);
+  const u32 g_first = blockIdx.x * gpw;
+  u32 mask8 = 0, nprobe = 0;
+  {
+    const u32 lg = (threadIdx.x * magic) >> 16, pos = threadIdx.x - lg * ipg + 1;
+    const u32 gid = g_first + lg;
+    if (lg < gpw && gid < ngrp2) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+      const u64 qpk = (u64)raw.y << 32 | raw.x;
+      const u32 m = raw.z, d_win = raw.w;
+      if (m && (d_win & 512u) && pos <= m) {
+        const u32 R = m - pos;
+        const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
+        const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
+        const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+        const u32* const idle = reinterpret_cast<const u32*>(f.ktab);
+        const u32* addr[NOPS];
+        u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          u64 s_pk;
+          u32 mlen, ow;
+          const bool ok = cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow);
+          const bool use2 = K2 && mlen >= K2;
+          const bool pr = ok && (use2 || f.kf.nr);
+          KfCopy c;
+          c.base = use2 ? c2.base : c1.base;
+          c.s = use2 ? c2.s : c1.s;
+          const u32* a = kf_word(c, use2 ? s_pk & mask2 : s_pk & kmask, bit[op]);
+          addr[op] = pr ? a : idle;
+          valid |= (u32)ok << op;
+          probe |= (u32)pr << op;
+        }
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
+          mask8 |= (((valid >> op) & 1u) & present) << op;
+        }
+        nprobe = (u32)__popc(probe);
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+  if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
+  while (mask8) {
+    const u32 op = (u32)__ffs((int)mask8) - 1u;
+    mask8 &= mask8 - 1;
+    const u32 at = atomicAdd(&q_n, 1u);
+    q_ent[at] = (u16)(threadIdx.x | (op << 8));
+  }
+  __syncthreads();
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  if (threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
+  const u32 qn = q_n;
+  u32 steps = 0, nlook = 0, nhead = 0;
+  // the dense phase: survivors rebuilt, table entry, extension; occurring strings to the LDS list (to_lds) or, on the second pass of
+  // a workgroup whose list overflowed, to the generic leaf buffer exactly like k_search1p
+  auto dense = [&](const bool to_lds) {
+    for (u32 e0 = 0; e0 < qn; e0 += 256) {
+      if (e0 + (threadIdx.x & ~63u) >= qn) break;
+      const u32 e = e0 + threadIdx.x;
+      if (e < qn) {
+        const u32 ent = q_ent[e], sl = ent & 255u, op = ent >> 8;
+        const u32 lg = (sl * magic) >> 16, pos = sl - lg * ipg + 1;
+        const u32 gid = g_first + lg;
+        const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+        u64 s_pk;
+        u32 mlen, ow;
+        (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
+        u32 lo = 0, hi = 0;
+        if (to_lds) nhead += (K2 && mlen > K2);
+        if (head_window_occurs(f, s_pk, mlen, raw.z - pos)) {
+          const uint2 iv = f.ktab[s_pk & kmask];
+          if (to_lds) ++nlook;
+          lo = iv.x;
+          hi = iv.y;
+        }
+        u64 rs = s_pk >> (2 * K);
+        u32 n = mlen - K;
+        while (n && lo < hi) {
+          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+          rs >>= 2;
+          --n;
+          if (to_lds) ++steps;
+        }
+        if (lo < hi) {
+          if (to_lds) {
+            const u32 at = atomicAdd(&l_n, 1u);
+            if (at < 512u) {
+              l_key[at] = s_pk;
+              l_lo[at] = lo;
+              l_hi[at] = hi;
+              l_meta[at] = (u16)(mlen | (lg << 6));
+            }
+          } else {
+            const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+            const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+            if (at < o.shard_cap) {
+              Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+              lf->qs = gid;
+              lf->slot = slot;
+              lf->lo = lo;
+              lf->hi = hi;
+              lf->nops = ow >> 28;
+              lf->ops[0] = ow & 0x0FFFFFFFu;
+#pragma unroll
+              for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+            }
+          }
+        }
+      }
+    }
+  };
+  dense(true);
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    nlook += __shfl_xor(nlook, off);
+    nhead += __shfl_xor(nhead, off);
+  }
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+    if (nhead) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nhead);
+  }
+  __syncthreads();
+  const u32 nl = l_n;
+  if (nl > lcap) {  // rare: this workgroup's groups take the generic path (selbase stays "generic"); lcap <= 512u
+    dense(false);
+    return;
+  }
+  // ---- select, per group, in LDS.  Up to 64 strings (the usual workgroup: 12 groups of two or three): by the first wavefront
+  // alone — the other three are done, a barrier only waits for wavefronts that have not ended, and their slots go to the next
+  // workgroup's probes while a few dozen strings are sorted here.  More strings (repeat families: hundreds per workgroup): all four
+  // wavefronts share the pair loops (one wavefront alone took 0.74 instead of 0.51 ms per step on the repeats genome).
+  const u32 sstep = nl <= 64 ? 64u : 256u;
+  if (threadIdx.x >= sstep) return;
+  for (u32 i = threadIdx.x; i < nl; i += sstep) l_pos[i] = (u16)atomicAdd(&g_cnt[(l_meta[i] >> 6) & 15u], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (u32 g = 0; g < gpw; ++g) {
+      g_start[g] = run;
+      run += g_cnt[g];
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < nl; i += sstep) l_ord[g_start[(l_meta[i] >> 6) & 15u] + l_pos[i]] = (u16)i;
+  __syncthreads();
+  // alive: no other string of the group is a proper substring, and of equal strings the first of the list stays
+  for (u32 i = threadIdx.x; i < nl; i += sstep) {
+    const u32 meta = l_meta[i], alen = meta & 63u, lg = (meta >> 6) & 15u;
+    bool ok = true;
+    if (INDEL) {
+      const u64 a = l_key[i];
+      const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
+      for (u32 j = s0; j < s1 && ok; ++j) {
+        const u32 x = l_ord[j];
+        if (x == i) continue;
+        const u32 xlen = l_meta[x] & 63u;
+        if (xlen > alen) continue;
+        const u64 xk = l_key[x], xm = xlen >= 32 ? ~0ULL : ((1ULL << (2 * xlen)) - 1);
+        bool hit = false;
+        for (u32 sh = 0; sh <= alen - xlen; ++sh) hit = hit || (((a >> (2 * sh)) & xm) == xk);
+        if (hit) ok = (xlen == alen) && (i < x);
+      }
+    }
+    if (ok) {
+      l_meta[i] = (u16)(meta | 0x8000u);
+      atomicAdd(&g_alive[lg], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 total = 0;
+    for (u32 g = 0; g < gpw; ++g) {
+      g_base[g] = total;
+      total += g_alive[g];
+    }
+    s_total = total;
+    s_base = total ? atomicAdd(&o.ctr->sel_cnt[shard], total) : 0u;
+  }
+  __syncthreads();
+  const u32 wbase = s_base;
+  const bool room = wbase + s_total <= fs.cap;  // an overflowing slice repeats the batch (Summary::worst_sel) ...
+  if (!room && threadIdx.x == 0) atomicOr(&o.ctr->overflow, 1u);  // ... and the kernels behind this one do nothing
+  if (threadIdx.x == 0 && nl) atomicAdd(&o.ctr->fused_leaves[shard], (unsigned long long)nl);
+  // rank among the group's survivors in std::string order (A < C < G < T = code order; a proper prefix sorts first) -> Sel
+  for (u32 i = threadIdx.x; i < nl; i += sstep) {
+    const u32 meta = l_meta[i];
+    if (!(meta & 0x8000u)) continue;
+    const u32 alen = meta & 63u, lg = (meta >> 6) & 15u;
+    const u64 ak = l_key[i] << (64 - 2 * alen);
+    const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
+    u32 r = 0;
+    for (u32 j = s0; j < s1; ++j) {
+      const u32 x = l_ord[j], xm = l_meta[x];
+      if (x == i || !(xm & 0x8000u)) continue;
+      const u32 xlen = xm & 63u;
+      const u64 xk = l_key[x] << (64 - 2 * xlen);
+      r += (xk < ak) || (xk == ak && xlen < alen);
+    }
+    if (room) {
+      Sel sv;
+      sv.lo = l_lo[i];
+      sv.hi = l_hi[i];
+      sv.len = alen;
+      sv.take = 0;
+      sv.hbase = 0;
+      sv.g = g_first + lg;
+      fs.sel[(u64)shard * fs.cap + wbase + g_base[lg] + r] = sv;
+    }
+  }
+  if (threadIdx.x < gpw && g_first + threadIdx.x < ngrp2) {
+    const u32 gid = g_first + threadIdx.x;
+    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+    if (raw.z && (raw.w & 512u)) {  // groups this kernel searches: their strings are in the flat region, also when there are none
+      fs.nsel[gid] = room ? g_alive[threadIdx.x] : 0u;
+      fs.selbase[gid] = shard * fs.cap + wbase + g_base[threadIdx.x];
+    }
+  }
+}
+
 // (r02 also measured k_search1p cut in two kernels — probe, then finish from a survivor queue in HBM: 0.21 + 0.19 ms against 0.25 ms
 // fused; removed in r04.)
 // ------------------------------------------------------------------------------------------------------------
@@ -4114,7 +4359,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           po.n_generic = (u32*)&ctr->pad_[6];
           // the per-character arrays are read by the full-matrix verify kernels and by the classic result fetch only
           po.write_bytes = (band_verify && (compact || !fetch)) ? 0u : 1u;
-          if (prep_in) {
+          if (std::getenv("DICEY_EXP_OLD1S") && !prep_in && indel) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s_r03<true>), g1, b1, 0, st, ix->view, b, so, fs, ipg, magic, gpw, 512u);
+          } else if (prep_in) {
             if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true, true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1, po);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false, true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1, po);
           } else {

@@ -794,6 +794,8 @@ int dg_index_share(dg_index* src, dg_index** out) {
   return DG_OK;
 }
 
+void* dg_index_stream(dg_index* ix) { return ix ? (void*)ix->stream : nullptr; }
+
 void dg_index_close(dg_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);

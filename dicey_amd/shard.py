@@ -51,29 +51,40 @@ def device_bytes(ptr: int, nbytes: int, device) -> torch.Tensor:
 
 
 class PipelinedGather:
-    """Gather of per-step hit lists to rank `dst` that overlaps with the next step's kernels.
+    """Gather of per-step hit lists to rank `dst` that overlaps with the next step's kernels, and moves the PAYLOAD, not a capacity.
 
-    Every submit() stages the payload (so the library may reuse its buffers), prefixes its length, and starts an
-    asynchronous gather of fixed-capacity byte tensors on the collective's own stream; at most `depth` gathers are in
-    flight; finish() waits for all of them.  Capacity is agreed once (all_reduce MAX) outside any timed region."""
+    submit(k) stages step k's payload (so the library may reuse its buffers), prefixes its length and starts an asynchronous
+    all_reduce(MAX) of the length; the gather of step k - 1 is launched right behind it, with the size its own all_reduce has
+    agreed on by then (rounded up to 64 KiB) — every rank sends and rank `dst` receives exactly that many bytes.  r03 gathered
+    a fixed capacity (1.25 x the first step) every step.  No host synchronisation on a collective that was launched in the same
+    call; at most `depth` steps are staged or in flight; finish() launches what is left and waits for everything.  `capacity`
+    bounds a step's payload (buffers are allocated once, outside any timed region: all_reduce MAX over the ranks)."""
+
+    ROUND = 1 << 16
 
     def __init__(self, capacity: int, device, dst: int = 0, depth: int = 2, group=None):
-        self.group, self.dst, self.depth = group, dst, depth
+        self.group, self.dst, self.depth = group, dst, max(2, depth)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         cap = torch.tensor([int(capacity)], dtype=torch.int64, device=device)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
         self.cap = int(cap.item())
-        self.send = [torch.zeros(self.cap + 8, dtype=torch.uint8, device=device) for _ in range(depth)]
-        self.recv = ([[torch.empty(self.cap + 8, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(depth)]
+        alloc = (self.cap + self.ROUND - 1) // self.ROUND * self.ROUND + 8
+        self.send = [torch.zeros(alloc, dtype=torch.uint8, device=device) for _ in range(self.depth)]
+        self.recv = ([[torch.empty(alloc, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(self.depth)]
                      if self.rank == dst else None)
         # length prefixes come from pinned host memory with a stream-ordered copy: a pageable source would block the host for
         # a tiny transfer once per step
         self.is_cuda = torch.device(device).type == "cuda"
         self.prefix = [torch.zeros(1, dtype=torch.int64).pin_memory() if self.is_cuda else torch.zeros(1, dtype=torch.int64)
-                       for _ in range(depth)]
-        self.work = [None] * depth
-        self.n = 0
+                       for _ in range(self.depth)]
+        self.size = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.depth)]
+        self.size_work = [None] * self.depth
+        self.work = [None] * self.depth
+        self.sent = [0] * self.depth       # bytes per rank of the slot's gather (the agreed, rounded size + prefix)
+        self.n = 0                          # steps staged
+        self.launched = 0                   # steps whose gather has been launched
         self.bytes_received = 0
+        self.bytes_moved = 0                # what rank dst took in over the wire, padding included
         self.last_slot = None  # receive buffers of the most recently completed gather (rank dst)
 
     def _drain(self, slot):
@@ -83,6 +94,19 @@ class PipelinedGather:
             if self.rank == self.dst:  # lengths are read only now: no host synchronisation on the submit path
                 for buf in self.recv[slot]:
                     self.bytes_received += int(buf[:8].view(torch.int64).item())
+                self.bytes_moved += self.sent[slot] * self.world
+
+    def _launch(self, step):
+        """gather of a staged step: its size agreement was started one submit ago"""
+        slot = step % self.depth
+        self.size_work[slot].wait()
+        self.size_work[slot] = None
+        n = int(self.size[slot].item())
+        n = min((n + self.ROUND - 1) // self.ROUND * self.ROUND, self.send[slot].numel() - 8) + 8
+        self.sent[slot] = n
+        self.work[slot] = dist.gather(self.send[slot][:n], [r[:n] for r in self.recv[slot]] if self.rank == self.dst else None,
+                                      dst=self.dst, group=self.group, async_op=True)
+        self.launched = step + 1
 
     def last_received(self) -> List[bytes]:
         """Rank dst, after finish(): the payload every rank sent in the last completed gather, in rank order."""
@@ -105,17 +129,21 @@ class PipelinedGather:
         buf = self.send[slot]
         self.prefix[slot][0] = total  # slot's previous gather has been drained, so its prefix copy is long done
         buf[:8].copy_(self.prefix[slot].view(torch.uint8), non_blocking=self.is_cuda)
+        self.size[slot].copy_(self.prefix[slot], non_blocking=self.is_cuda)
         at = 8
         for t in parts:
             # staging buffer on another device (the gloo/CPU path): a blocking copy, so the bytes are there before the gather
             # reads them; same device: an ordinary stream-ordered copy
             buf[at:at + t.numel()] = t.to(buf.device) if t.device != buf.device else t
             at += int(t.numel())
-        self.work[slot] = dist.gather(buf, self.recv[slot] if self.rank == self.dst else None, dst=self.dst, group=self.group,
-                                      async_op=True)
+        self.size_work[slot] = dist.all_reduce(self.size[slot], op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         self.n += 1
+        while self.launched < self.n - 1:  # the step before this one: its size has been agreed on while this step computed
+            self._launch(self.launched)
 
     def finish(self) -> int:
+        while self.launched < self.n:
+            self._launch(self.launched)
         for k in range(self.depth):  # oldest first
             self._drain((self.n + k) % self.depth)
         if self.n and self.rank == self.dst:

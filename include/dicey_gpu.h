@@ -70,6 +70,10 @@ void dg_index_close(dg_index* ix);
  * thread can run batches concurrently (the small tail kernels of one batch overlap with the search kernel of the other).
  * No index data is copied.  Close every shared handle before the handle it was taken from. */
 int dg_index_share(dg_index* src, dg_index** out);
+/* The handle's HIP stream (a hipStream_t).  Work a caller enqueues on it is ordered with the handle's batches: a device-side copy
+ * out of dg_hunt_result::d_hits issued on this stream is complete before the next batch overwrites the buffer, with no host
+ * synchronisation (bench.py stages its RCCL gather this way). */
+void* dg_index_stream(dg_index* ix);
 
 typedef struct {
   uint64_t n;              /* fm_index.size(): text length + 1 (sentinel) */

@@ -204,10 +204,10 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
   if (generic && b.fastK) *n_generic = 1u;
   return PreparedQuery{flags, d, bad};
 }
-__global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic) {
+__global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic, u32 write_bytes) {
   const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
-  (void)prepare_query(b, q, grp_cnt, nsel, selbase, n_generic, true, nullptr);
+  (void)prepare_query(b, q, grp_cnt, nsel, selbase, n_generic, write_bytes != 0, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -532,22 +532,20 @@ struct FlatSel {
 static constexpr u32 FUSED_LCAP = 512;   // largest LDS list
 static constexpr u32 FUSED_QCAP = 512;   // survivor queue entries per round
 static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u); }
-// PREP (r04): the workgroup also does k_prepare's work for its own queries in front (gpw / 2 lanes, the records stay in LDS for
-// every later read) and k_take's behind (the occurrences of a query's kept strings in push order: take = what hunter.h:349-357
-// still accepts, a saturating prefix sum) — the two kernels, 17 + 12 us of a 0.34 ms step, are not launched.  Used when the whole
-// batch is on the flat path (no generic kernels); gpw is even then, so that both strands of a query sit in one workgroup.
+// TAKE (r04): the workgroup also does k_take's work for its own queries (the occurrences of a query's kept strings in push order:
+// take = what hunter.h:349-357 still accepts, a saturating prefix sum) — k_take, 12 us of a 0.34 ms step, is not launched.  Used
+// when the whole batch is on the flat path (no generic kernels); gpw is even then, so that both strands of a query sit in one
+// workgroup.  (The same round measured k_prepare's work inside this kernel as well: the six lanes that prepare a workgroup's
+// queries hold its other 250 up — 0.187 -> 0.247 ms for 17 + 12 us of launches saved; k_prepare stays a launch of its own.)
 struct PrepOut {
   u32* qhits;      // [nq] hits per query (k_take's output)
-  u32* n_generic;  // k_prepare's flag
-  u32 write_bytes;
 };
-template <bool INDEL, bool PREP>
+template <bool INDEL, bool TAKE>
 __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap, u32 leave, PrepOut po) {  // 8 wavefronts per SIMD: the kernel is bound by requests in flight (r04: 106 SGPRs had left 7)
   __shared__ u16 q_ent[FUSED_QCAP];  // lane | operation << 8
   __shared__ u32 q_n, c_probe, l_n, s_total, s_base;
   __shared__ u32 g_cnt[16], g_start[16], g_alive[16], g_base[16];
-  __shared__ uint4 s_gi[16];                 // PREP: the groups' records (GidInfo as four words)
-  __shared__ unsigned long long g_occ[16];   // PREP: occurrences of a group's kept strings, each clamped to max_locations
+  __shared__ unsigned long long g_occ[16];   // TAKE: occurrences of a group's kept strings, each clamped to max_locations
   DG_DYNAMIC_LDS(dyn);  // the list of occurring strings: lcap entries
   unsigned long long* const l_key = reinterpret_cast<unsigned long long*>(dyn);
   u32* const l_lo = reinterpret_cast<u32*>(dyn + (size_t)lcap * 8);
@@ -567,22 +565,8 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
   }
   const u32 ngrp2 = (u32)(2 * b.nq);
   const u32 g_first = blockIdx.x * gpw;
-  PreparedQuery mine{0u, 0u, 0u};  // PREP: what the lane that prepared a query needs again when it writes the query's totals
-  if (PREP) {
-    if (threadIdx.x < gpw / 2) {
-      const u64 q = (u64)(g_first / 2) + threadIdx.x;
-      GidInfo gi[2];
-      gi[0].qpk = gi[1].qpk = 0;
-      gi[0].m = gi[1].m = 0;
-      gi[0].d_win = gi[1].d_win = 0;
-      if (q < b.nq) mine = prepare_query(b, q, nullptr, fs.nsel, fs.selbase, po.n_generic, po.write_bytes != 0, gi);
-#pragma unroll
-      for (u32 st2 = 0; st2 < 2; ++st2)
-        s_gi[2 * threadIdx.x + st2] = make_uint4((u32)gi[st2].qpk, (u32)(gi[st2].qpk >> 32), gi[st2].m, gi[st2].d_win);
-    }
-  }
   __syncthreads();
-  auto ginfo_of = [&](u32 lg, u32 gid) -> uint4 { return PREP ? s_gi[lg] : *reinterpret_cast<const uint4*>(b.ginfo + gid); };
+  auto ginfo_of = [&](u32, u32 gid) -> uint4 { return *reinterpret_cast<const uint4*>(b.ginfo + gid); };
   const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
   const u64 kmask = (1ULL << (2 * K)) - 1;
   const u32 lane = threadIdx.x & 63;
@@ -782,7 +766,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
     if (ok) {
       l_meta[i] = (u16)(meta | 0x8000u);
       atomicAdd(&g_alive[lg], 1u);
-      if (PREP) {
+      if (TAKE) {
         const u64 occ = (u64)l_hi[i] - l_lo[i];
         atomicAdd(&g_occ[lg], (unsigned long long)(occ < b.max_locations ? occ : b.max_locations));
       }
@@ -811,7 +795,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
     const u64 ak = l_key[i] << (64 - 2 * alen);
     const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
     u32 r = 0;
-    u64 before = (PREP && (lg & 1u)) ? g_occ[lg - 1] : 0ULL;  // PREP: occurrences (clamped) of the strings in front of this one in push order
+    u64 before = (TAKE && (lg & 1u)) ? g_occ[lg - 1] : 0ULL;  // TAKE: occurrences (clamped) of the strings in front of this one in push order
     for (u32 j = s0; j < s1; ++j) {
       const u32 x = l_ord[j], xm = l_meta[x];
       if (x == i || !(xm & 0x8000u)) continue;
@@ -819,7 +803,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       const u64 xk = l_key[x] << (64 - 2 * xlen);
       const bool first = (xk < ak) || (xk == ak && xlen < alen);
       r += first;
-      if (PREP && first) {
+      if (TAKE && first) {
         const u64 occ = (u64)l_hi[x] - l_lo[x];
         before += occ < b.max_locations ? occ : b.max_locations;
       }
@@ -831,7 +815,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       sv.len = alen;
       sv.take = 0;
       sv.hbase = 0;
-      if (PREP) {  // hunter.h:349-357: strings are located in set order, forward strand first, while hits < max_locations
+      if (TAKE) {  // hunter.h:349-357: strings are located in set order, forward strand first, while hits < max_locations
         const u64 M = b.max_locations, occ = (u64)sv.hi - sv.lo;
         const u64 h0 = before < M ? before : M, h1 = before + occ < M ? before + occ : M;
         sv.hbase = (u32)h0;
@@ -849,263 +833,18 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       fs.selbase[gid] = shard * fs.cap + wbase + g_base[threadIdx.x];
     }
   }
-  if (PREP && threadIdx.x < gpw / 2) {  // k_take's per-query part: the hit count, hunter.h:434, the compact results' word
+  if (TAKE && threadIdx.x < gpw / 2) {  // k_take's per-query part: the hit count, hunter.h:434, the compact results' word
     const u64 q = (u64)(g_first / 2) + threadIdx.x;
     if (q < b.nq) {
       const u64 M = b.max_locations, tot = g_occ[2 * threadIdx.x] + g_occ[2 * threadIdx.x + 1];
       const u64 hits = room ? (tot < M ? tot : M) : 0ULL;
       po.qhits[q] = (u32)hits;
-      u32 fl = mine.flags;
+      u32 fl = b.qflags[q];
       if (hits >= M && !(fl & DG_Q_TOO_SHORT)) {
         fl |= DG_Q_MAX_MATCHES;
         b.qflags[q] = fl;
       }
-      if (b.qinfo) b.qinfo[q] = (fl & 255u) | ((mine.d & 255u) << 8) | (mine.bad << 16);
-    }
-  }
-}
-
-// ---- TEMPORARY (r04 A/B): the r03 form of k_search1s, launched with DICEY_EXP_OLD1S
-template <bool INDEL>
-__global__ void __launch_bounds__(256) k_search1s_r03(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap) {
-  __shared__ u16 q_ent[2048];  // lane | operation << 8
-  __shared__ u32 q_n, c_probe, l_n, s_total, s_base;
-  __shared__ unsigned long long l_key[512];
-  __shared__ u32 l_lo[512], l_hi[512];
-  __shared__ u16 l_meta[512];  // length | local group << 6 | alive << 15
-  __shared__ u16 l_pos[512], l_ord[512];
-  __shared__ u32 g_cnt[16], g_start[16], g_alive[16], g_base[16];
-  constexpr u32 NOPS = INDEL ? 8u : 4u;
-  if (threadIdx.x == 0) {
-    q_n = 0;
-    c_probe = 0;
-    l_n = 0;
-  }
-  if (threadIdx.x < 16) g_cnt[threadIdx.x] = g_alive[threadIdx.x] = 0;
-  __syncthreads();
-  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
-  const u64 kmask = (1ULL << (2 * K)) - 1;
-  const u32 lane = threadIdx.x & 63;
-  const u32 ngrp2 = (u32)(2 * b.nq);
-  const u32 g_first = blockIdx.x * gpw;
-  u32 mask8 = 0, nprobe = 0;
-  {
-    const u32 lg = (threadIdx.x * magic) >> 16, pos = threadIdx.x - lg * ipg + 1;
-    const u32 gid = g_first + lg;
-    if (lg < gpw && gid < ngrp2) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
-      const u64 qpk = (u64)raw.y << 32 | raw.x;
-      const u32 m = raw.z, d_win = raw.w;
-      if (m && (d_win & 512u) && pos <= m) {
-        const u32 R = m - pos;
-        const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
-        const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
-        const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
-        const u32* const idle = reinterpret_cast<const u32*>(f.ktab);
-        const u32* addr[NOPS];
-        u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
-#pragma unroll
-        for (u32 op = 0; op < NOPS; ++op) {
-          u64 s_pk;
-          u32 mlen, ow;
-          const bool ok = cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow);
-          const bool use2 = K2 && mlen >= K2;
-          const bool pr = ok && (use2 || f.kf.nr);
-          KfCopy c;
-          c.base = use2 ? c2.base : c1.base;
-          c.s = use2 ? c2.s : c1.s;
-          const u32* a = kf_word(c, use2 ? s_pk & mask2 : s_pk & kmask, bit[op]);
-          addr[op] = pr ? a : idle;
-          valid |= (u32)ok << op;
-          probe |= (u32)pr << op;
-        }
-#pragma unroll
-        for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
-#pragma unroll
-        for (u32 op = 0; op < NOPS; ++op) {
-          const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
-          mask8 |= (((valid >> op) & 1u) & present) << op;
-        }
-        nprobe = (u32)__popc(probe);
-      }
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
-  if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
-  while (mask8) {
-    const u32 op = (u32)__ffs((int)mask8) - 1u;
-    mask8 &= mask8 - 1;
-    const u32 at = atomicAdd(&q_n, 1u);
-    q_ent[at] = (u16)(threadIdx.x | (op << 8));
-  }
-  __syncthreads();
-  const u32 shard = blockIdx.x & (NSHARD - 1);
-  if (threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
-  const u32 qn = q_n;
-  u32 steps = 0, nlook = 0, nhead = 0;
-  // the dense phase: survivors rebuilt, table entry, extension; occurring strings to the LDS list (to_lds) or, on the second pass of
-  // a workgroup whose list overflowed, to the generic leaf buffer exactly like k_search1p
-  auto dense = [&](const bool to_lds) {
-    for (u32 e0 = 0; e0 < qn; e0 += 256) {
-      if (e0 + (threadIdx.x & ~63u) >= qn) break;
-      const u32 e = e0 + threadIdx.x;
-      if (e < qn) {
-        const u32 ent = q_ent[e], sl = ent & 255u, op = ent >> 8;
-        const u32 lg = (sl * magic) >> 16, pos = sl - lg * ipg + 1;
-        const u32 gid = g_first + lg;
-        const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
-        u64 s_pk;
-        u32 mlen, ow;
-        (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
-        u32 lo = 0, hi = 0;
-        if (to_lds) nhead += (K2 && mlen > K2);
-        if (head_window_occurs(f, s_pk, mlen, raw.z - pos)) {
-          const uint2 iv = f.ktab[s_pk & kmask];
-          if (to_lds) ++nlook;
-          lo = iv.x;
-          hi = iv.y;
-        }
-        u64 rs = s_pk >> (2 * K);
-        u32 n = mlen - K;
-        while (n && lo < hi) {
-          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
-          rs >>= 2;
-          --n;
-          if (to_lds) ++steps;
-        }
-        if (lo < hi) {
-          if (to_lds) {
-            const u32 at = atomicAdd(&l_n, 1u);
-            if (at < 512u) {
-              l_key[at] = s_pk;
-              l_lo[at] = lo;
-              l_hi[at] = hi;
-              l_meta[at] = (u16)(mlen | (lg << 6));
-            }
-          } else {
-            const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
-            const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
-            if (at < o.shard_cap) {
-              Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
-              lf->qs = gid;
-              lf->slot = slot;
-              lf->lo = lo;
-              lf->hi = hi;
-              lf->nops = ow >> 28;
-              lf->ops[0] = ow & 0x0FFFFFFFu;
-#pragma unroll
-              for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
-            }
-          }
-        }
-      }
-    }
-  };
-  dense(true);
-  for (int off = 32; off > 0; off >>= 1) {
-    steps += __shfl_xor(steps, off);
-    nlook += __shfl_xor(nlook, off);
-    nhead += __shfl_xor(nhead, off);
-  }
-  if (lane == 0) {
-    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
-    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
-    if (nhead) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nhead);
-  }
-  __syncthreads();
-  const u32 nl = l_n;
-  if (nl > lcap) {  // rare: this workgroup's groups take the generic path (selbase stays "generic"); lcap <= 512u
-    dense(false);
-    return;
-  }
-  // ---- select, per group, in LDS.  Up to 64 strings (the usual workgroup: 12 groups of two or three): by the first wavefront
-  // alone — the other three are done, a barrier only waits for wavefronts that have not ended, and their slots go to the next
-  // workgroup's probes while a few dozen strings are sorted here.  More strings (repeat families: hundreds per workgroup): all four
-  // wavefronts share the pair loops (one wavefront alone took 0.74 instead of 0.51 ms per step on the repeats genome).
-  const u32 sstep = nl <= 64 ? 64u : 256u;
-  if (threadIdx.x >= sstep) return;
-  for (u32 i = threadIdx.x; i < nl; i += sstep) l_pos[i] = (u16)atomicAdd(&g_cnt[(l_meta[i] >> 6) & 15u], 1u);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u32 run = 0;
-    for (u32 g = 0; g < gpw; ++g) {
-      g_start[g] = run;
-      run += g_cnt[g];
-    }
-  }
-  __syncthreads();
-  for (u32 i = threadIdx.x; i < nl; i += sstep) l_ord[g_start[(l_meta[i] >> 6) & 15u] + l_pos[i]] = (u16)i;
-  __syncthreads();
-  // alive: no other string of the group is a proper substring, and of equal strings the first of the list stays
-  for (u32 i = threadIdx.x; i < nl; i += sstep) {
-    const u32 meta = l_meta[i], alen = meta & 63u, lg = (meta >> 6) & 15u;
-    bool ok = true;
-    if (INDEL) {
-      const u64 a = l_key[i];
-      const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
-      for (u32 j = s0; j < s1 && ok; ++j) {
-        const u32 x = l_ord[j];
-        if (x == i) continue;
-        const u32 xlen = l_meta[x] & 63u;
-        if (xlen > alen) continue;
-        const u64 xk = l_key[x], xm = xlen >= 32 ? ~0ULL : ((1ULL << (2 * xlen)) - 1);
-        bool hit = false;
-        for (u32 sh = 0; sh <= alen - xlen; ++sh) hit = hit || (((a >> (2 * sh)) & xm) == xk);
-        if (hit) ok = (xlen == alen) && (i < x);
-      }
-    }
-    if (ok) {
-      l_meta[i] = (u16)(meta | 0x8000u);
-      atomicAdd(&g_alive[lg], 1u);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u32 total = 0;
-    for (u32 g = 0; g < gpw; ++g) {
-      g_base[g] = total;
-      total += g_alive[g];
-    }
-    s_total = total;
-    s_base = total ? atomicAdd(&o.ctr->sel_cnt[shard], total) : 0u;
-  }
-  __syncthreads();
-  const u32 wbase = s_base;
-  const bool room = wbase + s_total <= fs.cap;  // an overflowing slice repeats the batch (Summary::worst_sel) ...
-  if (!room && threadIdx.x == 0) atomicOr(&o.ctr->overflow, 1u);  // ... and the kernels behind this one do nothing
-  if (threadIdx.x == 0 && nl) atomicAdd(&o.ctr->fused_leaves[shard], (unsigned long long)nl);
-  // rank among the group's survivors in std::string order (A < C < G < T = code order; a proper prefix sorts first) -> Sel
-  for (u32 i = threadIdx.x; i < nl; i += sstep) {
-    const u32 meta = l_meta[i];
-    if (!(meta & 0x8000u)) continue;
-    const u32 alen = meta & 63u, lg = (meta >> 6) & 15u;
-    const u64 ak = l_key[i] << (64 - 2 * alen);
-    const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
-    u32 r = 0;
-    for (u32 j = s0; j < s1; ++j) {
-      const u32 x = l_ord[j], xm = l_meta[x];
-      if (x == i || !(xm & 0x8000u)) continue;
-      const u32 xlen = xm & 63u;
-      const u64 xk = l_key[x] << (64 - 2 * xlen);
-      r += (xk < ak) || (xk == ak && xlen < alen);
-    }
-    if (room) {
-      Sel sv;
-      sv.lo = l_lo[i];
-      sv.hi = l_hi[i];
-      sv.len = alen;
-      sv.take = 0;
-      sv.hbase = 0;
-      sv.g = g_first + lg;
-      fs.sel[(u64)shard * fs.cap + wbase + g_base[lg] + r] = sv;
-    }
-  }
-  if (threadIdx.x < gpw && g_first + threadIdx.x < ngrp2) {
-    const u32 gid = g_first + threadIdx.x;
-    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
-    if (raw.z && (raw.w & 512u)) {  // groups this kernel searches: their strings are in the flat region, also when there are none
-      fs.nsel[gid] = room ? g_alive[threadIdx.x] : 0u;
-      fs.selbase[gid] = shard * fs.cap + wbase + g_base[threadIdx.x];
+      if (b.qinfo) b.qinfo[q] = (fl & 255u) | ((b.qdist[q] & 255u) << 8) | (b.qnondna[q] << 16);
     }
   }
 }
@@ -4326,10 +4065,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (ix->ctr_clean != (const void*)ctr || ix->ctr_clean_gen != ws[WS_GRP].gen) DG_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     ix->ctr_clean = nullptr;  // dirty until this attempt's last kernel has run
     DG_HIP(hipEventRecord(ix->ev[0], st));
-    // the whole batch on the flat distance-1 path: k_search1s prepares its own queries and settles their `take` values itself
-    // (PREP form); DICEY_NO_PREP_FUSION keeps k_prepare / k_take as launches of their own (the GPU suite runs both)
+    // the whole batch on the flat distance-1 path: k_search1s settles the `take` values of its own queries (TAKE form);
+    // DICEY_NO_PREP_FUSION keeps k_take a launch of its own (the GPU suite runs both)
     const bool prep_in = fused && !generic_on && !group_counts && !std::getenv("DICEY_NO_PREP_FUSION");
-    if (!prep_in) hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_cnt, nsel, selbase, (u32*)&ctr->pad_[6]);
+    // the per-character arrays (fw / rv codes, normalised ASCII) are read by the generic kernels, the full-matrix verify kernels and
+    // the classic result fetch only: 60 byte stores per query that the flat path with compact results does without
+    const u32 write_bytes = (prep_in && band_verify && (compact || !fetch)) ? 0u : 1u;
+    hipLaunchKernelGGL(k_prepare, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, grp_cnt, nsel, selbase, (u32*)&ctr->pad_[6], write_bytes);
     DG_HIP(hipEventRecord(ix->ev[1], st));
     {
       SearchOut so;
@@ -4340,7 +4082,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (b.fastK) {  // distance 1: the flat kernel takes every query that qualifies, k_search (one lane per strand) the rest
         const u32 ipg = std::min(maxlen, 31u), magic = (65536u + ipg - 1) / ipg;  // longer queries stay with k_search
         if (fused) {
-          const u32 gpw = prep_in ? (std::min(16u, 256u / ipg) & ~1u) : std::min(16u, 256u / ipg);  // PREP: both strands of a query in one workgroup
+          const u32 gpw = prep_in ? (std::min(16u, 256u / ipg) & ~1u) : std::min(16u, 256u / ipg);  // TAKE: both strands of a query in one workgroup
           FlatSel fs;
           fs.sel = sel_all;
           fs.cap = flat_cap;
@@ -4356,12 +4098,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           const u32 leave1 = std::getenv("DICEY_EXP_NOLEAVE") ? 0u : 1u;  // (r04 A/B: idle wavefronts end behind the probe phase or wait at the barrier)
           PrepOut po;
           po.qhits = qhits;
-          po.n_generic = (u32*)&ctr->pad_[6];
-          // the per-character arrays are read by the full-matrix verify kernels and by the classic result fetch only
-          po.write_bytes = (band_verify && (compact || !fetch)) ? 0u : 1u;
-          if (std::getenv("DICEY_EXP_OLD1S") && !prep_in && indel) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s_r03<true>), g1, b1, 0, st, ix->view, b, so, fs, ipg, magic, gpw, 512u);
-          } else if (prep_in) {
+          if (prep_in) {
             if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<true, true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1, po);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search1s<false, true>), g1, b1, lds1, st, ix->view, b, so, fs, ipg, magic, gpw, lcap, leave1, po);
           } else {
@@ -4606,8 +4343,19 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       again = true;
     }
     if (again) continue;
-    if (fused) ix->generic_hint = hsum.nleaf > 0 || hsum.n_generic > 0 || nxs > 0;
-    if (!group_counts) ix->jobs_hint = hsum.jobs_small > 0 || hsum.jobs_big > 0;
+    // The hints are sticky: a kernel family that a batch needed stays on for the next eight batches of the handle, so that a stream
+    // that alternates (chunks with and without N-containing queries, with and without repeat-rich strings) does not pay a repeated
+    // batch at every change (r03 advice; r04 repeats genome: 4 of 14 rotating steps ran twice).
+    if (fused) {
+      if (hsum.nleaf > 0 || hsum.n_generic > 0 || nxs > 0) ix->generic_sticky = 8;
+      else if (ix->generic_sticky) --ix->generic_sticky;
+      ix->generic_hint = ix->generic_sticky > 0;
+    }
+    if (!group_counts) {
+      if (hsum.jobs_small > 0 || hsum.jobs_big > 0) ix->jobs_sticky = 8;
+      else if (ix->jobs_sticky) --ix->jobs_sticky;
+      ix->jobs_hint = ix->jobs_sticky > 0;
+    }
     break;
   }
   ix->shard_cap_hint = shard_cap;

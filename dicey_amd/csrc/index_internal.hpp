@@ -22,6 +22,7 @@ struct dg_index {
   uint64_t hit_cap_hint = 0;
   bool generic_hint = true;      // the previous distance-1 batch had work for the kernels outside k_search1s (hunt.hip run_batch)
   bool jobs_hint = true;         // the previous batch queued strings for the locate job kernels
+  uint32_t generic_sticky = 1, jobs_sticky = 1;  // batches the two hints stay on after the last batch that needed them
   uint64_t jobs_big_hint = 0;    // repeat-rich strings (workgroup locate jobs) of the previous batch
   uint64_t fused_leaves_hint = 0;  // occurring strings the previous distance-1 batch held in k_search1s' LDS lists (+ generic leaves)
   uint64_t fetch_hits_hint = 0;  // hits of the previous fetched batch (+3 %): this many are copied to the host before the batch's synchronisation

@@ -284,11 +284,17 @@ def thal_counter_block(cfg, kernel, thal_calls, stage_ms):
     """k_site_wave against the fp64 vector peak and the LDS: instruction counters of the committed PMC pass
     on this workload (tools/prof_thal.sh -> profiles/r03_thal_counters.json), scaled to this run's thal() count and stage time.
     fp64 FLOP/s is an UPPER bound (every lane of every fp64 wavefront instruction counted as active; an FMA as two)."""
-    try:
-        tc = json.load(open(os.path.join(ROOT, "profiles", "r03_thal_counters.json")))[cfg]
-        k = [v for n, v in tc["kernels"].items() if kernel in n][0]
-        ref_calls = tc["bench"]["site_stage"]["thal_calls_per_step"]
-    except Exception:
+    tc = k = ref_calls = src = None
+    for src in ("r04_thal_counters.json", "r03_thal_counters.json"):  # the newest committed pass that holds this kernel
+        try:
+            tc = json.load(open(os.path.join(ROOT, "profiles", src)))[cfg]
+            k = [v for n, v in tc["kernels"].items() if kernel in n][0]
+            ref_calls = (tc["bench"].get("site_stage") or {}).get("thal_calls_per_step") or \
+                (tc["bench"]["arm_thal_per_step"] + tc["bench"]["probe_thal_per_step"])
+            break
+        except Exception:
+            k = None
+    if k is None:
         return None
     if not thal_calls or not stage_ms:
         return None
@@ -297,7 +303,7 @@ def thal_counter_block(cfg, kernel, thal_calls, stage_ms):
     flops = (k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + 2 * k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_TRANS_F64"]) * 64 * scale
     t = stage_ms * 1e-3
     valu_peak = 256 * 4 * 2.4e9 / 4  # wavefront instructions per second: 1 024 SIMDs, one wave64 instruction per four cycles
-    return {"source": "profiles/r03_thal_counters.json (rocprofv3 --pmc on this workload), scaled by thal() calls",
+    return {"source": "profiles/%s (rocprofv3 --pmc on this workload), scaled by thal() calls" % src,
             "fp64_wave_instructions_per_thal": f64 / thal_calls, "valu_wave_instructions_per_thal": k["SQ_INSTS_VALU"] * scale / thal_calls,
             "lds_wave_instructions_per_thal": k["SQ_INSTS_LDS"] * scale / thal_calls,
             "fp64_TFLOPs_upper_bound": flops / t / 1e12, "fp64_vector_peak_TFLOPs": 78.6, "fp64_frac_upper_bound": flops / t / 78.6e12,
@@ -548,14 +554,15 @@ def main():
                 if world > 1 and not fetch:
                     gather_parts([torch.empty(0, dtype=torch.uint8, device=dev)])
                 return {k_: 0 for k_ in ("nhits", "ext", "leaves", "sa", "win", "tab", "probe", "ops_per_hit", "ms_total", "ms_search",
-                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify")}
+                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns")}
             rp = C.POINTER(_capi.HuntResult)()
             _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(params or p_compact), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
                                             C.c_void_p(bo.data_ptr()), nq, bbytes, fetch, C.byref(rp)))
             R = rp.contents
             res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes,
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
-                   "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify}
+                   "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
+                   "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns}
             if world > 1 and not fetch:
                 if R.compact:  # ABI 5 records: position, packed word, d operation words = 12 bytes per hit at distance 1
                     parts = [device_bytes(R.d_hits, R.nhits * 4 * (2 + R.ops_per_hit), dev)]
@@ -702,7 +709,7 @@ def main():
                            "sample": f"first {nsp} bench queries, {phys_cores} host threads (one per physical core) over query shards, {dtp:.1f} s"}
             # parity at full genome size: GPU hits (push order) == oracle hits for a sample; at distance 2 the checker
             # enumerates neighbourhoods with its hash-set form (tested equal to the literal restatement, tests/test_oracle.py)
-            npar = min(a.parity_queries if a.parity_queries >= 0 else (300 if distance < 2 else 1000), nq)
+            npar = min(a.parity_queries if a.parity_queries >= 0 else (1000 if distance < 2 else 300), nq)
             if npar:
                 O.fast_neighbors(distance >= 2)
                 try:
@@ -798,6 +805,30 @@ def main():
                 "hits_per_step": int(acc[-1]["nhits"]), "leaves_per_step": int(acc[-1]["leaves"]),
             })
             out.update(extras)
+            # Capped neighbourhoods (neighbors.h:50) are settled in front of the batch: on the device (k_cap_enum) for A/C/G/T primers up to
+            # 29 nt at edit distance <= 2, on the host otherwise.  When that stage is the longest of the step its kernel is the dominant one.
+            cap_ms = mean("ms_cap")
+            if cap_ms > 0:
+                out["cap_stage"] = {"ms": cap_ms, "queries_on_device": int(mean("cap_dev")), "queries_on_host": int(mean("cap_host")),
+                                    "explicit_patterns": int(mean("cap_patterns")),
+                                    "note": "host wall clock of the stage (classification of the batch, k_cap_enum, the read-back of the pattern count)"}
+            if cap_ms > max(out["phases_ms"][k_] for k_ in ("ms_search", "ms_select", "ms_locate", "ms_verify")) and mean("cap_dev") > 0:
+                m_ = a.qlen
+                strands = 2 * mean("cap_dev")
+                leaves = 32 * m_ * m_ + 8 * m_ + 1 if distance >= 2 else 8 * m_ + 1
+                tcap = 256
+                while tcap < leaves * 5 // 2:
+                    tcap *= 2
+                per_strand = tcap * 16 + leaves * 16 + leaves * 14 * 16 + (leaves + 2) * 4  # table clear, births, <= 14 substring probes per string, events
+                cb = strands * per_strand
+                out["roofline_search"] = out["roofline"]
+                out["roofline"] = {"bound": "hbm", "kernel": "k_cap_enum", "achieved": cb / (cap_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": cb / (cap_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": cb,
+                                   "kernel_ms": cap_ms, "stage": "cap_stage",
+                                   "note": "upper bound of the hash-table bytes per (query, strand): table clear + 16 B per leaf of the reference's trie "
+                                           "(births) + 14 substring probes of 16 B per string (deaths) + the event array; the tables of a workgroup "
+                                           "(1 MB + 128 KB) live in L2 while it works on them, so HBM is not what bounds this kernel — its chain of "
+                                           "dependent atomics and probes is"}
             # The roofline block above describes the search kernel.  When another stage takes longer (the repeat-bearing genome:
             # hundreds of hits per query), the step's dominant kernel is that stage's, and it gets its own block under the same key;
             # the search kernel's block moves to roofline_search.
@@ -951,8 +982,13 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "k_thal_self_wave", "achieved": win_bytes / (elapsed / a.steps) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": win_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "algorithmic_bytes_per_launch": win_bytes,
-                             "note": "window bytes in / 8 B out per thal(): the scan is bound by fp64 VALU issue and LDS latency of the thal() DP "
-                                     "(one wavefront per window), not by HBM or MFMA; the fraction is reported for completeness"},
+                             "note": "window bytes in / 8 B out per thal(): the scan is bound by VALU issue of the thal() DP (one wavefront per "
+                                     "window; thal_stage.fp64_and_lds.valu_issue_frac is the fraction that applies), not by HBM or MFMA"},
+                # what bounds the scan: the thal() wave kernel against the chip's VALU issue rate and fp64 peak (counters of the committed
+                # PMC pass on this workload, scaled by thal() calls); the HBM fraction above only says that memory is not the limit
+                "thal_stage": {"kernel": "k_thal_self_wave", "thal_per_s": (mean("arm_thal") + mean("probe_thal")) / (elapsed / a.steps),
+                               "fp64_and_lds": thal_counter_block("padlock", "k_thal_self_wave", mean("arm_thal") + mean("probe_thal"),
+                                                                  elapsed / a.steps * 1e3)},
                 "positions_per_s": world * npos * a.steps / elapsed, "arm_thal_per_step": mean("arm_thal"), "probe_thal_per_step": mean("probe_thal"),
                 "arms_counted_per_step": mean("arms_counted"), "cpu_baseline": cpu,
             })
@@ -998,6 +1034,14 @@ def main():
         if (world == 1 and cfg == "hunt_d1" and a.genome == "iid" and not a.no_extra_configs and not a.no_extras and not a.queries
                 and a.distance < 0 and a.qlen == 20):
             out["extra_configs"] = run_extra_configs(a, fm9)
+            # compact top-level summaries of the sub-lines (the driver's record keeps top-level keys whole)
+            for name_ in ("hunt_d1_repeats", "hunt_d2", "hunt_d2_25mers", "search", "padlock"):
+                sub_ = out["extra_configs"].get(name_)
+                if isinstance(sub_, dict) and "value" in sub_:
+                    rf_ = sub_.get("roofline") or {}
+                    out["summary_" + name_] = {"value": sub_["value"], "unit": sub_.get("unit"), "ms_per_step": sub_.get("ms_per_step"),
+                                               "dominant_kernel": rf_.get("kernel"), "frac": rf_.get("frac"),
+                                               "parity": sub_.get("parity_sample")}
         print(json.dumps(out), flush=True)
     barrier()
     if rank == 0 and not a.fm9 and not a.keep_index:
@@ -1018,14 +1062,14 @@ def run_extra_configs(a, fm9):
     import subprocess
     t_start = time.time()
     plan = [("hunt_d1_repeats", ["--config", "hunt_d1", "--genome", "repeats", "--steps", "5", "--warmup", "2", "--cpu-seconds", "6", "--parity-queries", "300"], False),
-            ("hunt_d2", ["--config", "hunt_d2", "--steps", "3", "--warmup", "1", "--cpu-seconds", "4", "--parity-queries", "150"], True),
+            ("hunt_d2", ["--config", "hunt_d2", "--steps", "3", "--warmup", "1", "--cpu-seconds", "4", "--parity-queries", "300"], True),
             # cap-prone primers: 25-mers at distance 2 — the maxNeighborhood cap can fire, so every strand is
             # enumerated on the host in the reference's order first (nbhd_host.hpp) and searched as explicit patterns
             ("hunt_d2_25mers", ["--config", "hunt_d2", "--qlen", "25", "--queries", "2000", "--steps", "1", "--warmup", "1", "--cpu-seconds", "6",
-                                "--parity-queries", "4"], True),
+                                "--parity-queries", "100"], True),
             ("search", ["--config", "search", "--steps", "2", "--warmup", "1", "--cpu-seconds", "6"], True),
             ("padlock", ["--config", "padlock", "--steps", "3", "--warmup", "1", "--cpu-seconds", "6"], True)]
-    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "roofline_search", "cpu_baseline", "parity_sample",
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "roofline_search", "cpu_baseline", "parity_sample", "cap_stage",
             "phases_ms", "hits_per_step", "site_stage", "positions_per_s", "value_with_d2h")
     res = {}
     for name, args, reuse in plan:

@@ -1228,11 +1228,56 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
 // left (sdsl::count, hunter.h:353); occurring strings become leaves of their (query, strand) group like k_search's.
 __global__ void __launch_bounds__(256) k_explicit(FmView f, Batch b, SearchOut o) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u64 steps = 0;
+  u64 steps = 0, lookups = 0, probes = 0;
   if (i < b.nxs) {
     const u64 s = b.xs_off[i], e = b.xs_off[i + 1];
     u32 lo = 0, hi = (u32)f.n;
-    for (u64 k = e; k > s && lo < hi; --k) {
+    u64 k = e;
+    // r04: like every other search kernel, a pattern first asks the long presence filter about its last K2 characters (96 of 100
+    // random 18-mers of a 3.1 Gb genome end there, for one line instead of ~13 interval extensions from the full range), then its
+    // first K2 characters, then takes the interval of its last K characters from the table.  r03 searched the 40 M patterns of
+    // 2 000 capped 25-mers character by character: ~1 G random Occ lines, most of the 51 ms step.
+    const u32 len = (u32)(e - s), K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u, W = K2 > K ? K2 : K;
+    if (K && len >= W && W <= 32) {
+      u64 code = 0;  // the last W characters, last character in the lowest bits
+      bool plain = true;
+      for (u32 t = 0; t < W; ++t) {
+        const u32 c = b.xs_bytes[e - 1 - t];
+        plain = plain && c < 4;
+        code |= (u64)(c & 3u) << (2 * t);
+      }
+      if (plain) {
+        bool alive = true;
+        if (K2) {
+          ++probes;
+          alive = kf_present(f.kf2, code & ((1ULL << (2 * K2)) - 1), 0u);
+          if (alive && len > K2) {  // the first K2 characters as well
+            u64 head = 0;
+            bool hp = true;
+            for (u32 t = 0; t < K2; ++t) {
+              const u32 c = b.xs_bytes[s + K2 - 1 - t];
+              hp = hp && c < 4;
+              head |= (u64)(c & 3u) << (2 * t);
+            }
+            if (hp) {
+              ++probes;
+              alive = kf_present(f.kf2, head, K2 - 1);
+            }
+          }
+        } else if (f.kf.nr) {
+          ++probes;
+          alive = kf_present(f.kf, code & ((1ULL << (2 * K)) - 1), 0u);
+        }
+        if (alive) {
+          const uint2 iv = f.ktab[code & ((1ULL << (2 * K)) - 1)];
+          ++lookups;
+          lo = iv.x;
+          hi = iv.y;
+        } else lo = hi = 0;
+        k = e - K;
+      }
+    }
+    for (; k > s && lo < hi; --k) {
       const u32 code = b.xs_bytes[k - 1];
       bs_extend_sym(f, lo, hi, 'N', code);
       ++steps;
@@ -1256,6 +1301,8 @@ __global__ void __launch_bounds__(256) k_explicit(FmView f, Batch b, SearchOut o
     }
   }
   wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
+  wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
+  wave_add(&o.ctr->probes[blockIdx.x & (NSHARD - 1)], probes);
 }
 
 __global__ void k_leaf_overflow(Counters* ctr, u32 shard_cap, u32 surv_cap) {  // NSHARD lanes
@@ -3779,6 +3826,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   DG_TRY(ws[WS_GRP].reserve((ngrp + 1) * 8 + (nq + 1) * 8 + ngrp * 4 * 3 + nq * 4 + scan_tmp * 8 + sizeof(Counters) + sizeof(Summary) + 512));
   DG_TRY(ws[WS_CUM].reserve((u64)nseq * 8 + 8));
   // Could any query of this batch reach the cap?  (the bound grows with the length and with the number of N's)
+  const double t_cap0 = host_us();
   CapScan cs;
   std::vector<u32> dev_jobs;  // queries whose capped neighbourhood is enumerated on the device (k_cap_enum)
   // the caller's host copy of the offsets (nullptr on the dg_hunt_device path).  The read-back below serves cap_scan only and must not
@@ -3885,6 +3933,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (h_al.status & 1u) return fail(DG_EHIP, "internal error: the device neighbourhood enumeration produced more strings than the cap allows");
     nxs = h_al.alloc >> 36;
   }
+  const double ms_cap = (cs.mode.empty() && dev_jobs.empty()) ? 0.0 : (host_us() - t_cap0) * 1e-3;
   Batch b;
   b.fastK = (dmax_eff == 1 && ix->view.K && maxlen > ix->view.K && ngrp * (u64)std::min(maxlen, 31u) * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
   b.fast2K = (indel && dmax_eff == 2 && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
@@ -4450,6 +4499,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);
   R->ms_locate = ev_ms(ix->ev[5], ix->ev[6]);
   R->ms_verify = ev_ms(ix->ev[6], ix->ev[7]);
+  R->ms_cap = ms_cap;
+  R->cap_queries_device = dev_jobs.size();
+  R->cap_queries_host = cs.looked_at;
+  R->cap_patterns = nxs;
   if (host_timing)
     std::fprintf(stderr, "dicey timing: batch of %zu on stream %p entered at %.0f us: host %.0f us before the synchronisation (last attempt's "
                  "launches included), %.0f us waiting, %.0f us after; device %.3f ms\n", nq, (void*)st, std::fmod(t_enter, 1e8), t_launched - t_enter,

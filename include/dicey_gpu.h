@@ -209,6 +209,9 @@ typedef struct {
   uint32_t* qinfo;            /* [nq] */
   uint64_t* seq_start;        /* [nseq] text position of every sequence's first character (prefix sums of seqlen) */
   void* expanded_;            /* library internal (dg_hunt_expand's allocations) */
+  /* measurement: the capped-neighbourhood stage in front of the batch (hunt_cap.hpp / nbhd_host.hpp), host wall clock, and what it did */
+  double ms_cap;              /* 0 when no query of the batch could reach the cap */
+  uint64_t cap_queries_device, cap_queries_host, cap_patterns; /* queries enumerated on the device / on the host, explicit patterns searched */
 } dg_hunt_result;
 
 /* One compact hit as a dg_hit (query = the query it belongs to, from hit_off) and a pointer to its ops words. */

@@ -26,14 +26,16 @@ LIST
 done
 python - "$OUT" <<'PY'
 import csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'tools'))
+from profnames import short_kernel_name
 out = sys.argv[1]
 res = {}
 for cfg in ("search", "padlock"):
     acc = {}
     for d in sorted(glob.glob(os.path.join(out, cfg + "_pmc_*", "pmc_counter_collection.csv"))):
         for r in csv.DictReader(open(d)):
-            k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
-            if "wave" not in k: continue
+            k = short_kernel_name(r["Kernel_Name"])
+            if "wave" not in k or "kmer_table" in k: continue
             acc.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     ks = {}
     for (k, c), v in acc.items():
@@ -43,7 +45,7 @@ for cfg in ("search", "padlock"):
         bench = [json.loads(l) for l in open(os.path.join(out, "bench_%s.json" % cfg)) if l.startswith("{")][-1]
     except Exception:
         pass
-    res[cfg] = {"kernels": ks, "bench": {k: bench.get(k) for k in ("value", "unit", "ms_per_step", "phases_ms", "site_stage")} if bench else None}
+    res[cfg] = {"kernels": ks, "bench": {k: bench.get(k) for k in ("value", "unit", "ms_per_step", "phases_ms", "site_stage", "arm_thal_per_step", "probe_thal_per_step")} if bench else None}
 json.dump(res, open(os.path.join(out, "thal_counters.json"), "w"), indent=1)
 print(json.dumps(res)[:3000])
 PY

@@ -1,0 +1,507 @@
+// Locate stage of the hunt pipeline (included by hunt.hip only): the `take` smallest suffix-array values of every kept interval
+// (sdsl::locate + std::sort + the first max_locations entries, hunter.h:355-357).
+#pragma once
+#include "hunt_select.hpp"
+
+namespace dg {
+
+// ------------------------------------------------------------------------------------------------------------
+// Locate: the `take` smallest SA values of [lo,hi), ascending (locate + std::sort + first min(occs,max) entries).
+static constexpr u32 TOPK_KMAX = 1024;  // largest `take` k_locate_topk serves (its LDS holds 8 * 1 152 candidate minima)
+struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_topk / k_locate_big
+  u32 lo, occs, take, g, len;
+  u32 slot;  // of the kept string (HitSeed::sel)
+  u64 out;   // first hit slot
+};
+// One lane per kept string (r03; r02 walked the strings of a (query, strand) group in one lane — 170 hits per query on the
+// repeat-bearing genome made that a chain of several hundred dependent reads).  The lane finds its group through the packed /
+// grouped leaf of the same slot (slot_qs: address of that record's `qs` field, slot_stride: record size), serves strings of up to
+// 24 occurrences itself and queues the others: up to 256 occurrences for one wavefront (k_locate_small), more for one
+// workgroup (k_locate_topk / k_locate_big).
+struct LocJobs {
+  BigJob* small;
+  BigJob* big;
+  u32 cap;  // of each list
+  u32* n_small;
+  u32* n_big;
+};
+static constexpr u32 LOC_SMALL_MAX = 256;
+// A string with up to N occurrences: N loads in flight, a bitonic network on registers (every index is a compile-time constant —
+// r02's insertion sort indexed a private array dynamically, i.e. through scratch memory), `take` stores.
+template <int N>
+DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out, u32 g, u32 len, u32 slot) {
+  u32 v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = (u32)i < occs ? sa[i] : 0xFFFFFFFFu;
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const u32 a = v[i], b2 = v[l], mn = a < b2 ? a : b2, mx = a < b2 ? b2 : a;
+          v[i] = (i & k) == 0 ? mn : mx;
+          v[l] = (i & k) == 0 ? mx : mn;
+        }
+      }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if ((u32)i < take) out[i] = HitSeed{v[i], g, len, slot};
+}
+// Slots [0, flat_slots): the flat region (k_search1s; NSHARD slices of flat_cap entries, a slice holds ctr->sel_cnt[shard] strings,
+// each naming its group); slots behind it: the generic path's (grp_off based; only when generic_on).
+__global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const u8* slot_qs, u32 slot_stride, const u64* grp_off, const u32* nsel,
+                                                u64 ngroups, const u64* hit_off, HitSeed* seeds, Counters* ctr, u64 hit_cap, LocJobs jobs,
+                                                u64 flat_slots, u32 flat_cap, u32 generic_on, u32 jobs_on) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
+  u64 reads = 0;
+  BigJob bj;
+  u32 queue = 0;  // 1: wavefront job, 2: workgroup job
+  bool have = false;
+  u32 g = 0;
+  Sel S;
+  if (t < flat_slots) {
+    const u32 shard = (u32)(t / flat_cap);
+    if ((u32)(t - (u64)shard * flat_cap) < ctr->sel_cnt[shard]) {
+      S = sel[t];
+      g = S.g;
+      have = true;
+    }
+  } else if (generic_on && t - flat_slots < grp_off[ngroups]) {
+    const u64 tg = t - flat_slots;
+    g = *reinterpret_cast<const u32*>(slot_qs + tg * slot_stride);  // g = 2*query + strand
+    S = sel[t];
+    have = (tg - grp_off[g]) < nsel[g];  // slots behind the group's kept strings hold nothing
+  }
+  if (have) {
+    const u32 take = S.take;
+    if (take) {
+      const u32 lo = S.lo, occs = S.hi - S.lo;
+      const u64 out0 = hit_off[g >> 1] + S.hbase;
+      HitSeed* out = seeds + out0;
+      if (occs <= 4) {
+        locate_in_registers<4>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
+        reads += occs;
+      } else if (occs <= 16) {
+        locate_in_registers<16>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
+        reads += occs;
+      } else if (jobs.big && take <= 16384) {
+        bj.lo = lo;
+        bj.occs = occs;
+        bj.take = take;
+        bj.g = g;
+        bj.len = S.len;
+        bj.slot = (u32)t;
+        bj.out = out0;
+        queue = occs <= LOC_SMALL_MAX ? 1u : 2u;
+      } else {
+        bj.lo = lo;
+        bj.occs = occs;
+        bj.take = take;
+        bj.g = g;
+        bj.len = S.len;
+        bj.slot = (u32)t;
+        bj.out = out0;
+        queue = 3u;  // served by this lane, below
+      }
+    }
+  }
+  const u32 lane = threadIdx.x & 63;
+  // job slots: one atomic per wavefront and list (every lane on the two list heads was what this kernel waited for)
+  for (u32 which = 1; which <= 2; ++which) {
+    const unsigned long long mk = __ballot(queue == which);
+    if (!mk) continue;
+    // the job kernels were left out of this attempt: nobody will write these strings' hits, so the verify kernel must not run
+    // (the host sees the job counts and repeats the batch with the job kernels)
+    if (!jobs_on && lane == (u32)__ffsll((long long)mk) - 1u) atomicOr(&ctr->overflow, 4u);
+    u32 base = 0;
+    if (lane == (u32)__ffsll((long long)mk) - 1u) base = atomicAdd(which == 1 ? jobs.n_small : jobs.n_big, (u32)__popcll(mk));
+    base = __shfl(base, (int)__ffsll((long long)mk) - 1);
+    if (queue == which) {
+      const u32 j = base + (u32)__popcll(mk & ((1ULL << lane) - 1));
+      if (j < jobs.cap) (which == 1 ? jobs.small : jobs.big)[j] = bj;
+      else queue = 3u;  // a full list (more than 2^20 repeat-rich strings in one batch): nothing is dropped, the lane serves it
+    }
+  }
+  if (queue == 3u) {
+    // correct for any size, slow: selection by repeated minimum above the previous pick (positions are distinct).  Reached with
+    // hunt -m above 16 384, with DICEY_NO_BLOCK_LOCATE, and by the strings a full job list turned away.
+    u64 prev = 0;
+    bool first = true;
+    for (u32 i = 0; i < bj.take; ++i) {
+      u32 best = 0xFFFFFFFFu;
+      for (u32 j = 0; j < bj.occs; ++j) {
+        const u32 x = f.sa[bj.lo + j];
+        if ((first || x > prev) && x < best) best = x;
+      }
+      reads += bj.occs;
+      seeds[bj.out + i] = HitSeed{best, bj.g, bj.len, bj.slot};
+      prev = best;
+      first = false;
+    }
+  }
+  wave_add(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], reads);
+}
+
+// One WAVEFRONT per string of 25..256 occurrences (most of the queued strings on a repeat-bearing genome: 54 k of 72 k per
+// 100 000 queries): the interval is read once, sorted in LDS by the wavefront alone (bitonic, no workgroup barrier to wait
+// for), the first `take` values are written.  Jobs are taken in grid order: they all cost about the same.
+__global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, Counters* ctr) {
+  __shared__ u32 buf[LOC_SMALL_MAX];
+  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+  u64 reads = 0;
+  for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
+    const BigJob J = jobs[jb];
+    u32 n2 = 32;
+    while (n2 < J.occs) n2 <<= 1;
+    const u32* sa = f.sa + J.lo;
+    for (u32 i = threadIdx.x; i < n2; i += 64) buf[i] = i < J.occs ? sa[i] : 0xFFFFFFFFu;
+    reads += J.occs;
+    __syncthreads();
+    for (u32 kk = 2; kk <= n2; kk <<= 1)
+      for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+        for (u32 i = threadIdx.x; i < n2; i += 64) {
+          const u32 l = i ^ jj;
+          if (l > i) {
+            const u32 a = buf[i], b2 = buf[l];
+            if ((a > b2) == ((i & kk) == 0)) {
+              buf[i] = b2;
+              buf[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    for (u32 i = threadIdx.x; i < J.take; i += 64) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
+}
+
+// One workgroup per repeat-rich string: the `take` smallest suffix-array values of its interval, ascending.
+// Radix select, one byte per pass from the top: a 256-bin histogram (LDS atomics) of the values that still match the
+// prefix found so far tells which bin holds the take-th smallest value; the passes stop as soon as everything up to the end
+// of that bin fits the LDS buffer (on a genome-wide repeat family that is after the first pass: positions spread over the
+// whole text, so one top-byte bin holds occs/185 values).  One more pass collects those values, a bitonic sort orders
+// them.  2-3 coalesced passes over the interval instead of 33 (r02: 33 ms -> see DESIGN.md on the repeat-rich genome).
+__global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds,
+                                                    Counters* ctr, u32 topk_kmax) {
+  constexpr u32 CAP = 16384;
+  __shared__ u32 buf[CAP];
+  __shared__ u32 hist[256];
+  __shared__ u32 fill, s_prefix, s_mask, s_k, s_below, s_done;
+  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+  for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
+    const BigJob J = jobs[jb];
+    if (f.nlev > 1 && J.take <= topk_kmax) continue;  // k_locate_topk's
+    const u32* sa = f.sa + J.lo;
+    // refine until at most `limit` values are left to sort: sorting costs n log^2 n, another pass over the interval does not
+    const u32 limit = 2 * J.take > CAP ? CAP : (2 * J.take < 1024 ? 1024u : 2 * J.take);
+    if (threadIdx.x == 0) {
+      s_prefix = 0;
+      s_mask = 0;
+      s_k = J.take - 1;  // rank (among the values matching the prefix) of the largest value we keep
+      s_below = 0;       // values smaller than every value matching the prefix
+      s_done = J.occs <= limit ? 1u : 0u;  // a short interval is sorted whole
+    }
+    __syncthreads();
+    u32 passes = 0;
+    u32 upper = 0xFFFFFFFFu;  // everything <= upper is collected
+    if (!s_done) {
+      for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const u32 prefix = s_prefix, mask = s_mask;
+        for (u32 i = threadIdx.x; i < J.occs; i += blockDim.x) {
+          const u32 x = sa[i];
+          if ((x & mask) == prefix) atomicAdd(&hist[(x >> shift) & 255u], 1u);
+        }
+        ++passes;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          u32 k = s_k, cum = 0, bin = 0;
+          for (; bin < 256; ++bin) {
+            if (k < cum + hist[bin]) break;
+            cum += hist[bin];
+          }
+          s_k = k - cum;
+          s_below += cum;
+          s_prefix = prefix | (bin << shift);
+          s_mask = mask | (255u << shift);
+          if (s_below + hist[bin] <= limit || shift == 0) s_done = (u32)shift + 1;  // remember where we stopped
+        }
+        __syncthreads();
+        if (s_done) {
+          const u32 sh = s_done - 1;
+          upper = s_prefix | (sh ? ((1u << sh) - 1) : 0u);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) fill = 0;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < J.occs; i += blockDim.x) {
+      const u32 x = sa[i];
+      if (x <= upper) {
+        const u32 at = atomicAdd(&fill, 1u);
+        if (at < CAP) buf[at] = x;
+      }
+    }
+    ++passes;
+    __syncthreads();
+    const u32 have = fill < CAP ? fill : CAP;  // >= take by construction
+    u32 n2 = 1;
+    while (n2 < have) n2 <<= 1;
+    for (u32 i = have + threadIdx.x; i < n2; i += blockDim.x) buf[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 kk = 2; kk <= n2; kk <<= 1)
+      for (u32 j = kk >> 1; j > 0; j >>= 1) {
+        for (u32 i = threadIdx.x; i < n2; i += blockDim.x) {
+          u32 l = i ^ j;
+          if (l > i) {
+            u32 a = buf[i], b2 = buf[l];
+            bool up = (i & kk) == 0;
+            if ((a > b2) == up) {
+              buf[i] = b2;
+              buf[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
+    if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)passes * J.occs);
+    __syncthreads();
+  }
+}
+
+// One workgroup per repeat-rich string, without reading its interval (r03).  hunter.h:355-357 keeps the first `take` entries of
+// the sorted position list; r02's k_locate_big found them with 2-3 passes over the whole interval (an Alu-like string: 1.1 M
+// entries = 13 MB per string, 5.8 of the 9.4 ms of a step on the repeat-bearing genome).  Here the interval is cut into the
+// aligned blocks of FmView::samin (fan-out 8) and walked from the coarsest level that fits the LDS buffer down to the entries:
+//   invariant   the k smallest values of a set that is partitioned into blocks lie in the k blocks with the smallest minima
+//               (a value v in any other block b has the k minima of those blocks below min(b) <= v);
+//   per level   the candidates' minima sit in LDS; a radix select over them (256-bin histograms, LDS atomics) gives a threshold
+//               T with k <= #(minima <= T) <= KCAP; the blocks under T are expanded into their eight children (two 16-byte
+//               loads each), plus the < 8 blocks of the finer level that stick out at either end of the interval;
+//   entries     the select is carried on to the exact k-th value, the k survivors are sorted (bitonic) and written.
+// Reads: at most the top level's blocks (<= 9 232) and 8 * KCAP + 14 words per level below, whatever the interval holds.
+static constexpr u32 TOPK_KCAP = 1152;         // blocks kept per level: k plus slack, so that one histogram pass usually decides
+static constexpr u32 TOPK_PAD = 0xFFFFFFFFu;
+template <u32 KC>
+struct TopkLdsT {
+  u32 val[8 * KC + 16];
+  u32 cidx[2][KC];
+  u32 eidx[16];
+  u32 hist[256];
+  u32 wsum[4];
+  u32 sh[4];
+  u32 n_kept, job;
+};
+// Bitonic sort of n2 keys (n2 a power of two <= 1024; keys behind n2 must be the type's maximum) by a 256-lane workgroup with four
+// keys per lane in registers: key i lives in lane i / 4.  Partners at distance 1-2 are in the same lane, at distance 4-128 in the
+// same wavefront (one shuffle), only distances 256 and 512 cross wavefronts through LDS (xbuf: 1 024 keys) — 3 barrier rounds for
+// 1 024 keys where the compare-exchange-in-LDS form had 55.  v[r] = key 4 tid + r, in and out.
+template <class T>
+DG_DEV T shfl_xor_key(T x, int m);
+template <>
+DG_DEV u32 shfl_xor_key<u32>(u32 x, int m) { return (u32)__shfl_xor((int)x, m); }
+template <>
+DG_DEV u64 shfl_xor_key<u64>(u64 x, int m) { return (u64)__shfl_xor((unsigned long long)x, m); }
+template <class T>
+DG_DEV void block_sort4(T* xbuf, u32 n2, T (&v)[4]) {
+  const u32 i0 = threadIdx.x * 4;
+  for (u32 kk = 2; kk <= n2; kk <<= 1) {
+    const bool up = (i0 & kk) == 0;  // kk >= 4: the same for the lane's four keys; kk == 2 is handled per pair below
+    for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+      if (jj >= 256) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xbuf[i0 + r] = v[r];
+        __syncthreads();
+        const bool keep_min = ((i0 & jj) == 0) == up;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const T o = xbuf[(i0 + r) ^ jj];
+          v[r] = keep_min ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+        }
+      } else if (jj >= 4) {
+        const bool keep_min = ((i0 & jj) == 0) == up;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const T o = shfl_xor_key<T>(v[r], (int)(jj >> 2));
+          v[r] = keep_min ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int b2 = a ^ (int)jj;
+          if (b2 > a && (jj == 1 || jj == 2)) {
+            const bool upp = kk == 2 ? ((a & 2) == 0) : up;  // (i & kk) == 0 for i = i0 + a
+            const T x = v[a], y = v[b2], mn = x < y ? x : y, mx = x < y ? y : x;
+            v[a] = upp ? mn : mx;
+            v[b2] = upp ? mx : mn;
+          }
+        }
+      }
+    }
+  }
+}
+// threshold T with k <= #(val <= T) <= limit (k <= limit < nv; limit == k: the exact k-th smallest).  All 256 lanes call it.
+template <class LDS>
+DG_DEV u32 topk_threshold(LDS& S, u32 nv, u32 k, u32 limit) {
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 prefix = 0, mask = 0, kk = k - 1, below = 0;
+  for (int shift = 24;; shift -= 8) {
+    S.hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nv; i += 256) {
+      const u32 x = S.val[i];
+      if ((x & mask) == prefix) atomicAdd(&S.hist[(x >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    const u32 h = S.hist[threadIdx.x];
+    u32 incl = h;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 v = __shfl_up(incl, off);
+      if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) S.wsum[wave] = incl;
+    __syncthreads();
+    for (u32 w = 0; w < wave; ++w) incl += S.wsum[w];
+    const u32 excl = incl - h;
+    if (excl <= kk && kk < incl) {  // exactly one lane: the bin that holds the k-th smallest value
+      S.sh[0] = threadIdx.x;
+      S.sh[1] = excl;
+      S.sh[2] = h;
+    }
+    __syncthreads();
+    const u32 bin = S.sh[0], ex = S.sh[1], cnt = S.sh[2];
+    prefix |= bin << shift;
+    mask |= 255u << shift;
+    if (below + ex + cnt <= limit || shift == 0) return prefix | (shift ? (1u << shift) - 1u : 0u);
+    below += ex;
+    kk -= ex;
+  }
+}
+// KC = TOPK_KCAP: any interval (walks the hierarchy).  KC = TOPK_KCAP_MID (r03): intervals that fit the smaller buffer whole (level 0
+// only, no expansion) — 24 instead of 46 KB of LDS, six instead of three workgroups per CU; on the repeats genome two thirds of the
+// 17 000 jobs of a step are of that kind.  Both walk the same job list and skip what belongs to the other (occ_lo < occs <= occ_hi).
+static constexpr u32 TOPK_KCAP_MID = 576;
+template <u32 KC>
+__global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, u32* next_job,
+                                                     HitSeed* seeds, Counters* ctr, u32 occ_lo, u32 occ_hi) {
+  constexpr u32 VMAXT = 8 * KC + 16;
+  __shared__ TopkLdsT<KC> S;
+  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+  const u32 lane = threadIdx.x & 63;
+  u64 reads = 0;
+  // jobs: the first gridDim.x by workgroup number, the rest from a counter (an empty list costs no atomic: 768 workgroups on one
+  // word were 8 of the 10.7 us this kernel took on a batch without repeat-rich strings)
+  for (u32 round = 0;; ++round) {
+    __syncthreads();  // the previous job's buffers are free
+    if (threadIdx.x == 0) S.job = round == 0 ? blockIdx.x : gridDim.x + atomicAdd(next_job, 1u);
+    __syncthreads();
+    const u32 jb = S.job;
+    if (jb >= njobs) break;
+    const BigJob J = jobs[jb];
+    if (J.take > TOPK_KMAX || J.occs <= occ_lo || J.occs > occ_hi) continue;  // k_locate_big's / the other buffer size's
+    const u32 k = J.take;
+    const u64 lo = J.lo, hi = (u64)J.lo + J.occs;
+    // full blocks of level j inside [lo, hi): [A(j), B(j))
+    auto A = [&](int j) -> u64 { return (lo + ((1ULL << (3 * j)) - 1)) >> (3 * j); };
+    auto B = [&](int j) -> u64 { return hi >> (3 * j); };
+    auto N = [&](int j) -> u64 { return B(j) > A(j) ? B(j) - A(j) : 0ULL; };
+    int L = 0;
+    while (L + 1 < (int)f.nlev && N(L) > VMAXT - 16) ++L;  // a level left with more than 9 216 blocks has > 1 000 in the next
+    if (N(L) > VMAXT - 16) continue;  // cannot happen: the top level of FmView::samin holds <= 64 blocks
+    u32 nv = (u32)N(L);
+    {
+      const u32* src = f.samin[L] + A(L);
+      for (u32 i = threadIdx.x; i < nv; i += 256) S.val[i] = src[i];
+      reads += nv;
+    }
+    u32 nc_prev = 0;
+    int cur = 0;
+    bool top = true;
+    __syncthreads();
+    for (int j = L;; --j) {
+      // at the entries: up to 96 values more than asked for may survive (the sort drops them) — an exact k-th value costs the
+      // radix select all four byte passes, a little slack usually ends it after two
+      const u32 limit = j == 0 ? (k + 96 < TOPK_KMAX ? k + 96 : (k > TOPK_KMAX ? k : TOPK_KMAX)) : KC;
+      const u32 T = nv > limit ? topk_threshold(S, nv, k, limit) : 0xFFFFFFFEu;
+      if (threadIdx.x == 0) S.n_kept = 0;
+      __syncthreads();
+      if (j == 0) {  // the survivors are the answer: collect, sort, write
+        u32* buf = &S.cidx[0][0];
+        for (u32 base = 0; base < nv; base += 256) {
+          const u32 p = base + threadIdx.x;
+          const u32 x = p < nv ? S.val[p] : TOPK_PAD;
+          const bool keep = x <= T && x != TOPK_PAD;
+          const unsigned long long mk = __ballot(keep);
+          u32 at = 0;
+          if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
+          at = __shfl(at, 0);
+          if (keep) buf[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = x;
+        }
+        __syncthreads();
+        const u32 have = S.n_kept;  // k .. k + 96 values (fewer when the whole interval is shorter); the k smallest are written
+        u32 n2 = 4;
+        while (n2 < have) n2 <<= 1;
+        u32 sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = threadIdx.x * 4 + r < have ? buf[threadIdx.x * 4 + r] : TOPK_PAD;
+        block_sort4<u32>(buf, n2, sv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (threadIdx.x * 4 + r < k) seeds[J.out + threadIdx.x * 4 + r] = HitSeed{sv[r], J.g, J.len, J.slot};
+        break;
+      }
+      // blocks of level j under the threshold -> cidx[cur ^ 1]
+      for (u32 base = 0; base < nv; base += 256) {
+        const u32 p = base + threadIdx.x;
+        const u32 x = p < nv ? S.val[p] : TOPK_PAD;
+        const bool keep = x <= T && x != TOPK_PAD;
+        u32 idx = 0;
+        if (keep) idx = top ? (u32)(A(L) + p) : (p < 8 * nc_prev ? S.cidx[cur][p >> 3] * 8u + (p & 7u) : S.eidx[p - 8 * nc_prev]);
+        const unsigned long long mk = __ballot(keep);
+        u32 at = 0;
+        if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
+        at = __shfl(at, 0);
+        if (keep) S.cidx[cur ^ 1][at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = idx;
+      }
+      __syncthreads();
+      const u32 nc = S.n_kept;
+      cur ^= 1;
+      top = false;
+      // their children, and the blocks of level j-1 that stick out at either end of the interval
+      const u32* lv = f.samin[j - 1];
+      const u64 nlow = j - 1 == 0 ? f.n : ~0ULL;  // level 0 is the suffix array itself: nothing beyond n
+      for (u32 i = threadIdx.x; i < nc; i += 256) {
+        const u64 c8 = (u64)S.cidx[cur][i] * 8;
+        const uint4 x = *reinterpret_cast<const uint4*>(lv + c8), y = *reinterpret_cast<const uint4*>(lv + c8 + 4);
+        u32 v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) S.val[8 * i + t] = c8 + t < nlow ? v[t] : TOPK_PAD;
+      }
+      const u64 a1 = A(j), b1 = B(j), a0 = A(j - 1), b0 = B(j - 1);
+      const u32 nl = (u32)(8 * a1 - a0), nr = (u32)(b0 - 8 * b1);
+      if (threadIdx.x < nl + nr) {
+        const u64 e = threadIdx.x < nl ? a0 + threadIdx.x : 8 * b1 + (threadIdx.x - nl);
+        S.eidx[threadIdx.x] = (u32)e;
+        S.val[8 * nc + threadIdx.x] = lv[e];
+      }
+      reads += 8ULL * nc + nl + nr;
+      nv = 8 * nc + nl + nr;
+      nc_prev = nc;
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
+}
+
+}  // namespace dg

@@ -1,0 +1,1278 @@
+// Search stage of the hunt pipeline (included by hunt.hip only): query preparation (hunter.h:299-315), the flat distance-1 kernels
+// (k_search1p, k_search1s with the select stage inside), the flat edit-distance-2 kernel (k_search2p), the general walker (k_search)
+// and the explicit-pattern search of capped neighbourhoods (k_explicit).  neighbors.h:29-92 + hunter.h:353.
+#pragma once
+#include "hunt_internal.hpp"
+#include "iupac.hpp"
+
+namespace dg {
+
+struct Leaf {
+  u32 qs;    // 2*query + strand
+  u32 slot;  // running number within its (query,strand) group
+  u32 lo, hi;
+  u32 nops;
+  u32 ops[DMAX];  // pos<<4 | kind<<2 | code, in right-to-left order of application
+};
+
+struct Sel {  // a kept neighbourhood string, in search order
+  u32 lo, hi;
+  u32 len;    // string length
+  u32 take;   // how many of its occurrences become hits
+  u32 hbase;  // first hit slot, relative to the query's first hit
+  u32 g;      // 2*query + strand (set for the strings of the flat region, where no leaf record names the group)
+};
+
+// Largest number of distinct strings neighbors() can hold for a query of length m with nN letters outside A/C/G/T (they
+// are 'N' after replaceNonDna and can be substituted by all four bases instead of three); used to prove that the
+// maxNeighborhood early return (neighbors.h:50) cannot fire.  Returns ~0 when no such proof is available.
+DG_HD u64 neighbourhood_bound(u32 m, u32 d, bool indel, u32 nN = 0) {
+  auto binom = [](u64 n, u64 k) {
+    u64 r = 1;
+    for (u64 i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return r;
+  };
+  if (nN > m) nN = m;
+  if (!indel) {  // exactly: i substituted positions, j of them at an N (4 letters) and i-j elsewhere (3 letters)
+    u64 t = 0;
+    for (u32 i = 0; i <= d && i <= m; ++i)
+      for (u32 j = 0; j <= i && j <= nN; ++j) {
+        if (i - j > m - nN) continue;
+        u64 term = binom(nN, j) * binom(m - nN, i - j);
+        for (u32 k = 0; k < j; ++k) term *= 4;
+        for (u32 k = 0; k < i - j; ++k) term *= 3;
+        t += term;
+        if (t > (1ULL << 40)) return ~0ULL;
+      }
+    return t;
+  }
+  // Edit mode.  With N positions: strings that need the fourth letter at an N position spend one edit on that substitution
+  // and reach at most G(d-1) strings with the rest, G(0) = 1, G(1) = 1 + m deletions + 4m substitutions + 4(m+1)
+  // insertions; everything else obeys the three-letter count below.
+  u64 extra = 0;
+  if (nN) {
+    if (d == 1) extra = nN;
+    else if (d == 2) extra = (u64)nN * (9ULL * m + 5);
+    else if (d > 2) return ~0ULL;
+  }
+  if (d == 0) return 1;
+  if (d == 1) return 7ULL * m + 5 + extra;  // 1 + 3m substitutions + m deletions + (3m+4) insertions
+  if (d == 2) {
+    // Distinct strings within two edits, by length class (DESIGN.md "neighbourhood size bound"); M = m-1 is the query
+    // without its last character, which every string of L must still align to (no insertion after the last column).
+    const u64 M = m - 1;
+    u64 len_m2 = binom(m, 2);                                              // two deletions
+    u64 len_m1 = m + 3ULL * m * (m - 1);                                   // D, D+S
+    u64 len_0 = 1 + 3ULL * m + 9 * binom(m, 2) + m * (3ULL * (m - 1) + 4) - (3ULL * m + 1);  // q, S, SS, D+I (q and S counted once)
+    u64 len_p1 = (3 * M + 4) * (1 + 3 * M) - 6 * M - 3 * M + 3 * (3 * M + 4);  // I, I+S; last column M or S
+    u64 len_p2 = 1 + 3 * (m + 1) + 9 * binom(m + 1, 2);                    // supersequences of q[0..m-1) of length m+1, then q[m-1]
+    return len_m2 + len_m1 + len_0 + len_p1 + len_p2 + extra;
+  }
+  return ~0ULL;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// (r03: the characters come in as aligned 64-bit words loaded together — the byte loop waited for one load per character, 20 us
+// for 100 000 20-mers — and the lane clears its query's group counters, which takes the place of a memset in front of the batch)
+// One query: hunter.h:299-315 + util.h:54-114,208-219.  write_bytes: the per-character arrays (fw / rv codes, normalised ASCII) are
+// only read by the generic kernels, the full-matrix verify and the classic result fetch; the flat distance-1 path with the
+// banded verify and compact results works from the packed records (GidInfo, position masks) alone.  grp_cnt may be null (the
+// generic path's group counters).  gi_out: the two strands' records, also stored to b.ginfo.
+struct PreparedQuery {
+  u32 flags, d, bad;
+};
+DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic, bool write_bytes, GidInfo* gi_out) {
+  if (grp_cnt) grp_cnt[2 * q] = grp_cnt[2 * q + 1] = 0;
+  nsel[2 * q] = nsel[2 * q + 1] = 0;
+  selbase[2 * q] = selbase[2 * q + 1] = 0xFFFFFFFFu;  // "generic path" until k_search1s claims the group
+  u64 s = b.qoff[q], e = b.qoff[q + 1];
+  u32 m = (u32)(e - s), bad = 0, flags = 0, generic = 0;
+  u64 pk_fw = 0, pk_rv = 0;  // 2-bit packed strands, q[i] at bits 2(m-1-i) (meaningful for m <= 32 without N)
+  u32 pm[4] = {0u, 0u, 0u, 0u};  // position masks of the forward strand: bit i of pm[x] <=> q[i] is base x (m <= 32; an N sets none)
+  constexpr u32 NREG = 40;   // queries up to this length travel through registers
+  if (m <= NREG) {
+    constexpr int NW = NREG / 8 + 1;
+    const u64 a0 = s & ~7ULL;
+    const u32 sh = (u32)(s & 7) * 8;
+    const u64* src = reinterpret_cast<const u64*>(b.qbytes + a0);
+    u64 w[NW + 1], x[NW];
+#pragma unroll
+    for (int i = 0; i <= NW; ++i) w[i] = (u32)(8 * i) < (u32)(s & 7) + m ? src[i] : 0ULL;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) x[i] = sh ? (w[i] >> sh) | (w[i + 1] << (64 - sh)) : w[i];
+#pragma unroll
+    for (u32 i = 0; i < NREG; ++i) {
+      if (i < m) {
+        u32 ch = (u32)(x[i >> 3] >> (8 * (i & 7))) & 255u;
+        if (ch >= 'a' && ch <= 'z') ch -= 32;  // boost::to_upper_copy, hunter.h:306
+        const u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+        bad += (code == 4);  // every replaced character raises one warning (util.h:214); a literal 'N' is replaced too
+        if (write_bytes) {
+          b.fw[s + i] = (u8)code;
+          b.qseq[s + i] = ascii_of(code);
+          b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);  // util.h:54-91,110-114
+        }
+        pk_fw = (pk_fw << 2) | (code & 3u);
+        pk_rv |= (u64)((3u - code) & 3u) << (2 * (i & 31u));
+        if (i < 32) {
+#pragma unroll
+          for (u32 x = 0; x < 4; ++x) pm[x] |= (u32)(code == x) << i;
+        }
+      }
+    }
+  } else {
+    for (u32 i = 0; i < m; ++i) {
+      u32 ch = b.qbytes[s + i];
+      if (ch >= 'a' && ch <= 'z') ch -= 32;
+      u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+      bad += (code == 4);
+      b.fw[s + i] = (u8)code;
+      b.qseq[s + i] = ascii_of(code);
+      b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);
+    }
+  }
+  if (m > b.maxlen_bound) atomicAdd(b.too_long, 1u);
+  u32 d = b.distance;
+  if (m < 10) flags |= DG_Q_TOO_SHORT;  // hunter.h:299
+  else if (d >= m) {                    // hunter.h:312-315
+    d = m - 1;
+    flags |= DG_Q_DIST_ADJUSTED;
+  }
+  // If the cap could fire for a query, the reference's answer depends on its generation order, which k_search does not
+  // reproduce: the host has enumerated such queries beforehand (qmode).  A query that could reach the cap without the host
+  // having looked at it is a bookkeeping error of this library and stops the batch.
+  const u32 mode = b.qmode ? b.qmode[q] : (u32)QM_KERNEL;
+  const bool explicit_set = (mode & 15u) == QM_EXPLICIT;
+  if ((mode & 15u) == QM_KERNEL && m >= 10 && neighbourhood_bound(m, d, b.indel != 0, bad) >= b.max_neighborhood) atomicAdd(b.refused, 1u);
+  if ((mode & QM_FIRED) && m >= 10) flags |= DG_Q_NBHD_EXCEEDED;  // hunter.h:342-345
+  b.qlen[q] = m;
+  b.qdist[q] = d;
+  b.qflags[q] = flags;
+  b.qnondna[q] = bad;
+  for (u32 strand = 0; strand < 2; ++strand) {
+    GidInfo gi;
+    gi.qpk = 0;
+    gi.m = ((flags & DG_Q_TOO_SHORT) || explicit_set || (strand && !b.reverse) || m > b.maxlen_bound) ? 0u : m;
+    gi.d_win = d | (bad == 0 ? 256u : 0u);
+    if (b.fastK && gi.m && bad == 0 && d == 1 && m <= 31 && m >= b.fastK + 1) gi.d_win |= 512u;
+    if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
+    if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
+    b.ginfo[2 * q + strand] = gi;
+    if (gi_out) gi_out[strand] = gi;
+    // the banded verify takes the query as position masks (band_align_bits); the reverse strand's character j is the complement
+    // of the forward strand's character m - 1 - j
+    if (m <= 32 && m >= 1) {
+      uint4 pq;
+      if (!strand) pq = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+      else pq = make_uint4(__brev(pm[3]) >> (32 - m), __brev(pm[2]) >> (32 - m), __brev(pm[1]) >> (32 - m), __brev(pm[0]) >> (32 - m));
+      b.gpeq[2 * q + strand] = pq;
+    }
+    generic += (gi.m != 0 && !(gi.d_win & 512u));
+  }
+  // groups the flat distance-1 kernel does not take: the host launches the generic kernels for them (and repeats a batch it
+  // started without, run_batch).  A flag, not a count: every lane that has one stores the same 1.
+  if (generic && b.fastK) *n_generic = 1u;
+  return PreparedQuery{flags, d, bad};
+}
+__global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic, u32 write_bytes) {
+  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq) return;
+  (void)prepare_query(b, q, grp_cnt, nsel, selbase, n_generic, write_bytes != 0, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Search.  State machine: every loop iteration performs at most one index access (an interval extension = two
+// Occ-block reads, or one K-mer table read), whatever trie level the lane is on, so a wavefront stays converged on the
+// memory operation.  Frames live in registers (fully unrolled selects over the <= D+1 levels, no scratch).
+//
+// K-mer table ("window mode"): while fewer than K characters have been emitted the lane only accumulates their 2-bit
+// codes; the K-th character turns the code into an SA interval with ONE table read, replacing K extensions.  Once a
+// branch has spent its whole budget the rest of the window is copied from the query in O(1).  Lanes whose strings may
+// be shorter than K, or whose query holds an N, run the same loop in interval mode from the start.
+struct Frame {
+  u32 pos;  // query characters still to consume (q[0..pos))
+  u32 lo;   // interval mode: SA interval [lo,hi);  window mode: (hi:lo) = accumulated 2-bit codes (up to 34 bits)
+  u32 hi;
+  u32 st;   // bits 0-3 next edit operation, bits 4-8 emitted count (window mode), bit 9 window mode
+};
+enum : u32 { ST_WIN = 1u << 9 };
+
+template <int D>
+struct FrameStack {
+  Frame fr[D + 1];
+  DG_DEV Frame get(u32 L) const {
+    Frame f = fr[0];
+#pragma unroll
+    for (int k = 1; k <= D; ++k)
+      if (L == (u32)k) f = fr[k];
+    return f;
+  }
+  DG_DEV void set(u32 L, const Frame& f) {
+#pragma unroll
+    for (int k = 0; k <= D; ++k)
+      if (L == (u32)k) fr[k] = f;
+  }
+};
+template <int D>
+struct OpStack {
+  u32 v[D > 0 ? D : 1] = {0};
+  DG_DEV void set(u32 L, u32 x) {
+#pragma unroll
+    for (int k = 0; k < (D > 0 ? D : 1); ++k)
+      if (L == (u32)k) v[k] = x;
+  }
+};
+
+struct SearchOut {
+  Leaf* leaves;   // NSHARD regions of shard_cap entries
+  u32 shard_cap;
+  Counters* ctr;
+  u32* grp_cnt;
+};
+
+// emit one character (code 0..3) in front of what the frame stands for; returns false when the branch is dead
+// K-mer code -> SA interval: the presence filter first (one bit, FmView::kf), the table entry only for K-mers that occur
+DG_DEV uint2 kmer_interval(const FmView& f, u64 code, u32 edit_at, u64& lookups, u64& probes) {
+  if (f.kf.nr) {
+    ++probes;
+    if (!kf_present(f.kf, code, edit_at)) return make_uint2(0u, 0u);
+  }
+  ++lookups;
+  return f.ktab[code];
+}
+DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& lookups, u64& probes) {
+  if (fr.st & ST_WIN) {
+    u32 e = (fr.st >> 4) & 31;
+    u64 code = ((u64)fr.hi << 32 | fr.lo) | ((u64)c << (2 * e));
+    fr.lo = (u32)code;
+    fr.hi = (u32)(code >> 32);
+    ++e;
+    if (e == f.K) {
+      uint2 iv = kmer_interval(f, code, e - 1, lookups, probes);
+      fr.lo = iv.x;
+      fr.hi = iv.y;
+      fr.st &= ~(ST_WIN | (31u << 4));
+      return iv.x < iv.y;
+    }
+    fr.st = (fr.st & ~(31u << 4)) | (e << 4);
+    return true;
+  }
+  bs_extend_code(f, fr.lo, fr.hi, c);
+  ++steps;
+  return fr.lo < fr.hi;
+}
+// window mode with no budget left: the remaining K-e characters are the query's own; one table read
+DG_DEV bool frame_finish_window(const FmView& f, Frame& fr, const u8* seq, u32 m, u64 qpk, u64& lookups, u64& probes) {
+  const u32 e = (fr.st >> 4) & 31, need = f.K - e;
+  u64 code = (u64)fr.hi << 32 | fr.lo;
+  if (m <= 32) {  // qpk holds q[i] at bits 2(m-1-i): the next character to emit is at the bottom after the shift
+    u64 w = qpk >> (2 * (m - fr.pos));
+    u64 mask = need >= 32 ? ~0ULL : ((1ULL << (2 * need)) - 1);
+    code |= (w & mask) << (2 * e);
+  } else {
+    for (u32 t = 0; t < need; ++t) code |= (u64)seq[fr.pos - 1 - t] << (2 * (e + t));
+  }
+  fr.pos -= need;
+  uint2 iv = kmer_interval(f, code, e ? e - 1 : 0u, lookups, probes);  // the last edit sits just right of the copied characters
+  fr.lo = iv.x;
+  fr.hi = iv.y;
+  fr.st &= ~(ST_WIN | (31u << 4));
+  return iv.x < iv.y;
+}
+
+// Work split: with the table, the root level of the trie is cut into independent items — one lane per
+// (query, strand, window offset j of the first edit, operation), plus one "rest" lane that owns the unedited window and
+// every first edit to the left of it.  An item lane jumps straight to its node (the j characters right of the edit are
+// the query's own), applies its single operation and explores that subtree only.  ~K*NOPS+1 times more lanes, each with
+// a handful of dependent index reads instead of hundreds: the kernel becomes throughput- instead of latency-bound.
+// ------------------------------------------------------------------------------------------------------------
+// Distance 1, the common case, without the state machine.  Profiling the general kernel (SQ counters, r02) showed it is
+// bound by instruction issue, not by memory: ~1400 instructions per wavefront at 45 % lane utilisation, because every lane
+// sits in a different state of the walker.  With one edit the work is flat, so it is laid out flat:
+//   phase A, one lane per (query, strand, position, operation): build the edited string in a 64-bit register (2 bits per
+//            character), take its last K characters as the table code and test the presence filter (or the table itself
+//            when there is no filter) — a dozen instructions and one memory access; about four lanes in five stop here;
+//   phase B: the survivors of the workgroup are packed through LDS into its first lanes, which read the table entry and
+//            extend the interval over the characters left of the window (two Occ lines per step).
+// Every lane of phase B has the same few steps ahead of it, so wavefronts stay full and short.  Strings and leaves are
+// exactly those of k_search<INDEL,1>: deletions, substitutions by another base and insertions between two characters
+// (neighbors.h:51-78; a leading insertion is dominated by the string without it, a trailing one is not generated), and in
+// Hamming mode the sequence itself.  Queries with an N, longer than 31 nt or shorter than K+1 stay with k_search.
+// (r02's first flat form gave every (position, operation) its own lane — ~200 vector instructions per candidate; it was
+// removed in r04.  What follows is the form that replaced it.)
+// The same search with one lane per (query, strand, POSITION): the lane builds all eight strings of its position from the
+// shared pieces (the characters right of the position, the query shifted by none / one character) in a fully unrolled loop —
+// the operation is a compile-time constant in every iteration, so nothing diverges — and issues its eight filter probes
+// back to back.  The lane-per-operation form above spends ~200 vector instructions per candidate (every lane runs the code
+// of all three operation kinds, the (group, item) decode and the record load for one string) and was bound by instruction
+// issue once the long filter had removed most of its memory accesses (r02: 0.39 ms whatever the filter / table orders);
+// this form needs ~25 per candidate.  Survivors are queued in LDS as (lane, operation) and rebuilt by the dense phase.
+template <bool INDEL>
+DG_DEV bool cand1(u64 qpk, u32 m, u32 pos, u32 op, u64& s_pk, u32& mlen, u32& opword) {
+  const u32 R = m - pos;  // unchanged characters right of the operation
+  const u64 low = qpk & ((1ULL << (2 * R)) - 1);
+  const u32 old = (u32)(qpk >> (2 * R)) & 3u;
+  if (op == 0) {
+    if (INDEL) {
+      s_pk = low | ((qpk >> (2 * R + 2)) << (2 * R));
+      mlen = m - 1;
+      opword = ((pos << 4) | (OP_D << 2)) | (1u << 28);
+      // deleting either of two equal neighbours gives the same string: the right-most character of a run does it
+      return !(R >= 1 && ((u32)(qpk >> (2 * R - 2)) & 3u) == old);
+    }
+    s_pk = qpk;  // the sequence itself belongs to the Hamming set
+    mlen = m;
+    opword = 0;
+    return pos == 1;
+  }
+  if (op < 4) {
+    const u32 c = (old + op) & 3u;  // neighbors.h:63: a different base
+    s_pk = qpk ^ ((u64)(old ^ c) << (2 * R));
+    mlen = m;
+    opword = ((pos << 4) | (OP_S << 2) | c) | (1u << 28);
+    return true;
+  }
+  const u32 c = op - 4;
+  s_pk = low | ((u64)c << (2 * R)) | ((qpk >> (2 * R)) << (2 * R + 2));
+  mlen = m + 1;
+  opword = ((pos << 4) | (OP_I << 2) | c) | (1u << 28);
+  // neighbors.h:51: nothing after the last character; and a base inserted right of an equal one is the string of the
+  // insertion one position further left (which exists from the second position on)
+  return pos < m && !(pos >= 2 && c == old);
+}
+// Second look at a survivor that is longer than the long filter's order: its FIRST K2 characters must occur as well.  The two
+// windows overlap in all but (length - K2) characters, yet on a 3.1 Gb genome three of four random survivors end here — for one
+// line instead of the table entry and 3-5 Occ lines.  R = characters right of the (last) edit, for the choice of the copy.
+DG_DEV bool head_window_occurs(const FmView& f, u64 s_pk, u32 mlen, u32 R) {
+  const u32 K2 = f.kf2.k;
+  if (!f.kf2.nr || mlen <= K2) return true;
+  const u32 cut = mlen - K2;
+  const u32 t = R > cut ? R - cut : 0u;
+  return kf_present(f.kf2, (s_pk >> (2 * cut)) & ((1ULL << (2 * K2)) - 1), t < K2 ? t : K2 - 1);
+}
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o, u32 ipg, u32 magic) {
+  __shared__ u16 q_ent[2048];  // lane | operation << 8
+  __shared__ u32 q_n, c_probe;
+  constexpr u32 NOPS = INDEL ? 8u : 4u;
+  if (threadIdx.x == 0) {
+    q_n = 0;
+    c_probe = 0;
+  }
+  __syncthreads();
+  // lane -> (group, position): one division per workgroup, a multiplication per lane (exact for the < 512 values it sees)
+  const u32 TBX = blockDim.x;  // 64, 128 or 256
+  const u32 first = blockIdx.x * TBX;
+  const u32 g_first = first / ipg, r_first = first - g_first * ipg;
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1;
+  const u32 lane = threadIdx.x & 63;
+  const u32 ngrp2 = (u32)(2 * b.nq);
+  u32 mask8 = 0, nprobe = 0;
+  {
+    const u32 t = r_first + threadIdx.x, qd = (t * magic) >> 16;
+    const u32 gid = g_first + qd, pos = t - qd * ipg + 1;
+    if (gid < ngrp2) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+      const u64 qpk = (u64)raw.y << 32 | raw.x;
+      const u32 m = raw.z, d_win = raw.w;
+      if (m && (d_win & 512u) && pos <= m) {
+        const u32 R = m - pos;
+        const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
+        const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
+        const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+        // all addresses first, then the eight loads back to back, then the bits
+        const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
+        const u32* addr[NOPS];
+        u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          u64 s_pk;
+          u32 mlen, ow;
+          const bool ok = cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow);
+          const bool use2 = K2 && mlen >= K2;
+          const bool pr = ok && (use2 || f.kf.nr);
+          KfCopy c;
+          c.base = use2 ? c2.base : c1.base;
+          c.s = use2 ? c2.s : c1.s;
+          const u32* a = kf_word(c, use2 ? s_pk & mask2 : s_pk & kmask, bit[op]);
+          addr[op] = pr ? a : idle;
+          valid |= (u32)ok << op;
+          probe |= (u32)pr << op;
+        }
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
+          mask8 |= (((valid >> op) & 1u) & present) << op;
+        }
+        nprobe = (u32)__popc(probe);
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+  if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
+  while (mask8) {
+    const u32 op = (u32)__ffs((int)mask8) - 1u;
+    mask8 &= mask8 - 1;
+    const u32 at = atomicAdd(&q_n, 1u);
+    q_ent[at] = (u16)(threadIdx.x | (op << 8));  // at < 2048: eight operations of 256 lanes
+  }
+  __syncthreads();
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  if (threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
+  const u32 qn = q_n;
+  u32 steps = 0, nlook = 0, nhead = 0;
+  for (u32 e0 = 0; e0 < qn; e0 += TBX) {
+    if (e0 + (threadIdx.x & ~63u) >= qn) break;  // this wavefront has no survivor to work on
+    const u32 e = e0 + threadIdx.x;
+    if (e < qn) {
+      const u32 ent = q_ent[e], sl = ent & 255u, op = ent >> 8;
+      const u32 t = r_first + sl, qd = (t * magic) >> 16;
+      const u32 gid = g_first + qd, pos = t - qd * ipg + 1;
+      const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+      u64 s_pk;
+      u32 mlen, ow;
+      (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
+      u32 lo = 0, hi = 0;
+      nhead += (K2 && mlen > K2);
+      if (head_window_occurs(f, s_pk, mlen, raw.z - pos)) {
+        const uint2 iv = f.ktab[s_pk & kmask];
+        ++nlook;
+        lo = iv.x;
+        hi = iv.y;
+      }
+      u64 rs = s_pk >> (2 * K);
+      u32 n = mlen - K;
+      while (n && lo < hi) {
+        bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+        rs >>= 2;
+        --n;
+        ++steps;
+      }
+      if (lo < hi) {
+        const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+        const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+        if (at < o.shard_cap) {
+          Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+          lf->qs = gid;
+          lf->slot = slot;
+          lf->lo = lo;
+          lf->hi = hi;
+          lf->nops = ow >> 28;
+          lf->ops[0] = ow & 0x0FFFFFFFu;
+#pragma unroll
+          for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+        }
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    nlook += __shfl_xor(nlook, off);
+    nhead += __shfl_xor(nhead, off);
+  }
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+    if (nhead) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nhead);
+  }
+}
+
+// k_search1p WITH the select stage (r03).  A workgroup owns whole (query, strand) groups — floor(256 / positions) of them — so
+// every string of a group that occurs ends up in this workgroup's LDS (2-bit packed, with its interval), and the group's
+// duplicates / substring-minimal filter / std::set order (neighbors.h:29-45, hunter.h:349) are settled right here: leaves never
+// travel to HBM, and the scan of the group counts, k_group_pack, k_leaf_alive and k_leaf_rank (62 of the 380 us of a step) have
+// nothing left to do.  Kept strings go to the FLAT region of the Sel array — per-shard slices, one atomic per workgroup — and
+// selbase[g] / nsel[g] tell the later kernels where a group's strings are.  A workgroup whose strings do not fit the LDS list
+// (512; a dozen low-complexity queries side by side) sends its leaves down the generic path like k_search1p does.
+struct FlatSel {
+  Sel* sel;        // flat region: NSHARD slices of `cap` entries
+  u32 cap;
+  u32* selbase;    // [2 nq] first Sel slot of a group served here (0xFFFFFFFF: generic path, grp_off based)
+  u32* nsel;       // [2 nq]
+};
+// r04: (i) the three wavefronts that have nothing to do behind the probe phase END there instead of waiting at the barrier behind
+// the dense phase (the usual workgroup has ~40 survivors, one wavefront's worth): the r04a counters showed the kernel resident at
+// 6-7 of 8 wavefronts per SIMD, two thirds of the wave cycles waiting — three of four of those slots held by wavefronts parked at
+// that barrier; (ii) the LDS list is dynamic (lcap entries, 256 by default: 5.6 KB, 512 when the previous batch's workgroups held
+// more than ~64 strings on average) and the survivor queue holds 512 entries, filled in rounds when more survive, so that the
+// freed slots can be taken by new workgroups.
+static constexpr u32 FUSED_LCAP = 512;   // largest LDS list
+static constexpr u32 FUSED_QCAP = 512;   // survivor queue entries per round
+static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u); }
+// TAKE (r04): the workgroup also does k_take's work for its own queries (the occurrences of a query's kept strings in push order:
+// take = what hunter.h:349-357 still accepts, a saturating prefix sum) — k_take, 12 us of a 0.34 ms step, is not launched.  Used
+// when the whole batch is on the flat path (no generic kernels); gpw is even then, so that both strands of a query sit in one
+// workgroup.  (The same round measured k_prepare's work inside this kernel as well: the six lanes that prepare a workgroup's
+// queries hold its other 250 up — 0.187 -> 0.247 ms for 17 + 12 us of launches saved; k_prepare stays a launch of its own.)
+struct PrepOut {
+  u32* qhits;      // [nq] hits per query (k_take's output)
+};
+template <bool INDEL, bool TAKE>
+__global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOut o, FlatSel fs, u32 ipg, u32 magic, u32 gpw, u32 lcap, u32 leave, PrepOut po) {  // 8 wavefronts per SIMD: the kernel is bound by requests in flight (r04: 106 SGPRs had left 7)
+  __shared__ u16 q_ent[FUSED_QCAP];  // lane | operation << 8
+  __shared__ u32 q_n, c_probe, l_n, s_total, s_base;
+  __shared__ u32 g_cnt[16], g_start[16], g_alive[16], g_base[16];
+  __shared__ unsigned long long g_occ[16];   // TAKE: occurrences of a group's kept strings, each clamped to max_locations
+  DG_DYNAMIC_LDS(dyn);  // the list of occurring strings: lcap entries
+  unsigned long long* const l_key = reinterpret_cast<unsigned long long*>(dyn);
+  u32* const l_lo = reinterpret_cast<u32*>(dyn + (size_t)lcap * 8);
+  u32* const l_hi = l_lo + lcap;
+  u16* const l_meta = reinterpret_cast<u16*>(l_hi + lcap);  // length | local group << 6 | alive << 15
+  u16* const l_pos = l_meta + lcap;
+  u16* const l_ord = l_pos + lcap;
+  constexpr u32 NOPS = INDEL ? 8u : 4u;
+  if (threadIdx.x == 0) {
+    q_n = 0;
+    c_probe = 0;
+    l_n = 0;
+  }
+  if (threadIdx.x < 16) {
+    g_cnt[threadIdx.x] = g_alive[threadIdx.x] = 0;
+    g_occ[threadIdx.x] = 0ULL;
+  }
+  const u32 ngrp2 = (u32)(2 * b.nq);
+  const u32 g_first = blockIdx.x * gpw;
+  __syncthreads();
+  auto ginfo_of = [&](u32, u32 gid) -> uint4 { return *reinterpret_cast<const uint4*>(b.ginfo + gid); };
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1;
+  const u32 lane = threadIdx.x & 63;
+  u32 mask_all = 0, nprobe = 0;
+  {
+    const u32 lg = (threadIdx.x * magic) >> 16, pos = threadIdx.x - lg * ipg + 1;
+    const u32 gid = g_first + lg;
+    if (lg < gpw && gid < ngrp2) {
+      const uint4 raw = ginfo_of(lg, gid);
+      const u64 qpk = (u64)raw.y << 32 | raw.x;
+      const u32 m = raw.z, d_win = raw.w;
+      if (m && (d_win & 512u) && pos <= m) {
+        const u32 R = m - pos;
+        const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
+        const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
+        const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+        const u32* const idle = reinterpret_cast<const u32*>(f.ktab);
+        const u32* addr[NOPS];
+        u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          u64 s_pk;
+          u32 mlen, ow;
+          const bool ok = cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow);
+          const bool use2 = K2 && mlen >= K2;
+          const bool pr = ok && (use2 || f.kf.nr);
+          KfCopy c;
+          c.base = use2 ? c2.base : c1.base;
+          c.s = use2 ? c2.s : c1.s;
+          const u32* a = kf_word(c, use2 ? s_pk & mask2 : s_pk & kmask, bit[op]);
+          addr[op] = pr ? a : idle;
+          valid |= (u32)ok << op;
+          probe |= (u32)pr << op;
+        }
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) {
+          const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
+          mask_all |= (((valid >> op) & 1u) & present) << op;
+        }
+        nprobe = (u32)__popc(probe);
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+  if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  u32 steps = 0, nlook = 0, nhead = 0;
+  // the dense phase over the queue's first qn entries: survivors rebuilt, table entry, extension; occurring strings to the LDS list
+  // (to_lds) or, for a workgroup whose list overflowed, to the generic leaf buffer exactly like k_search1p
+  auto dense = [&](const bool to_lds, const u32 qn) {
+    for (u32 e0 = 0; e0 < qn; e0 += 256) {
+      if (e0 + (threadIdx.x & ~63u) >= qn) break;
+      const u32 e = e0 + threadIdx.x;
+      if (e < qn) {
+        const u32 ent = q_ent[e], sl = ent & 255u, op = ent >> 8;
+        const u32 lg = (sl * magic) >> 16, pos = sl - lg * ipg + 1;
+        const u32 gid = g_first + lg;
+        const uint4 raw = ginfo_of(lg, gid);
+        u64 s_pk;
+        u32 mlen, ow;
+        (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
+        u32 lo = 0, hi = 0;
+        if (to_lds) nhead += (K2 && mlen > K2);
+        if (head_window_occurs(f, s_pk, mlen, raw.z - pos)) {
+          const uint2 iv = f.ktab[s_pk & kmask];
+          if (to_lds) ++nlook;
+          lo = iv.x;
+          hi = iv.y;
+        }
+        u64 rs = s_pk >> (2 * K);
+        u32 n = mlen - K;
+        while (n && lo < hi) {
+          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+          rs >>= 2;
+          --n;
+          if (to_lds) ++steps;
+        }
+        if (lo < hi) {
+          if (to_lds) {
+            const u32 at = atomicAdd(&l_n, 1u);
+            if (at < lcap) {
+              l_key[at] = s_pk;
+              l_lo[at] = lo;
+              l_hi[at] = hi;
+              l_meta[at] = (u16)(mlen | (lg << 6));
+            }
+          } else {
+            const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+            const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+            if (at < o.shard_cap) {
+              Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+              lf->qs = gid;
+              lf->slot = slot;
+              lf->lo = lo;
+              lf->hi = hi;
+              lf->nops = ow >> 28;
+              lf->ops[0] = ow & 0x0FFFFFFFu;
+#pragma unroll
+              for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+            }
+          }
+        }
+      }
+    }
+  };
+  // survivors enter the queue in rounds of at most FUSED_QCAP; `gone`: this wavefront ended behind the probe phase
+  bool gone = false, single_round = false;
+  auto rounds = [&](const bool to_lds, const bool may_leave) {
+    u32 rem = mask_all;
+    for (u32 round = 0;; ++round) {
+      while (rem) {
+        const u32 op = (u32)__ffs((int)rem) - 1u;
+        const u32 at = atomicAdd(&q_n, 1u);
+        if (at >= FUSED_QCAP) break;  // next round
+        rem &= rem - 1;
+        q_ent[at] = (u16)(threadIdx.x | (op << 8));
+      }
+      __syncthreads();
+      const u32 raw_n = q_n, qn = raw_n < FUSED_QCAP ? raw_n : FUSED_QCAP;
+      if (round == 0) {
+        if (to_lds && threadIdx.x == 0 && c_probe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)c_probe);
+        single_round = raw_n <= FUSED_QCAP;
+        // one wavefront's worth of survivors and nothing left over: the other wavefronts end here, their slots go to the next workgroup
+        if (may_leave && raw_n <= 64 && threadIdx.x >= 64) {
+          gone = true;
+          return;
+        }
+      }
+      dense(to_lds, qn);
+      if (raw_n <= FUSED_QCAP) return;
+      __syncthreads();
+      if (threadIdx.x == 0) q_n = 0;
+      __syncthreads();
+    }
+  };
+  rounds(true, leave != 0);
+  if (gone) return;
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    nlook += __shfl_xor(nlook, off);
+    nhead += __shfl_xor(nhead, off);
+  }
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+    if (nhead) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nhead);
+  }
+  __syncthreads();
+  const u32 nl = l_n;
+  if (nl > lcap) {  // this workgroup's groups take the generic path (selbase stays "generic")
+    if (single_round) dense(false, q_n < FUSED_QCAP ? q_n : FUSED_QCAP);  // the queue still holds every survivor
+    else {
+      __syncthreads();
+      if (threadIdx.x == 0) q_n = 0;
+      __syncthreads();
+      rounds(false, false);
+    }
+    return;
+  }
+  // ---- select, per group, in LDS.  Up to 64 strings (the usual workgroup: 12 groups of two or three): by the first wavefront
+  // alone.  More strings (repeat families: hundreds per workgroup): all four wavefronts share the pair loops (one wavefront alone
+  // took 0.74 instead of 0.51 ms per step on the repeats genome).
+  const u32 sstep = nl <= 64 ? 64u : 256u;
+  if (threadIdx.x >= sstep) return;
+  for (u32 i = threadIdx.x; i < nl; i += sstep) l_pos[i] = (u16)atomicAdd(&g_cnt[(l_meta[i] >> 6) & 15u], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (u32 g = 0; g < gpw; ++g) {
+      g_start[g] = run;
+      run += g_cnt[g];
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < nl; i += sstep) l_ord[g_start[(l_meta[i] >> 6) & 15u] + l_pos[i]] = (u16)i;
+  __syncthreads();
+  // alive: no other string of the group is a proper substring, and of equal strings the first of the list stays
+  for (u32 i = threadIdx.x; i < nl; i += sstep) {
+    const u32 meta = l_meta[i], alen = meta & 63u, lg = (meta >> 6) & 15u;
+    bool ok = true;
+    if (INDEL) {
+      const u64 a = l_key[i];
+      const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
+      for (u32 j = s0; j < s1 && ok; ++j) {
+        const u32 x = l_ord[j];
+        if (x == i) continue;
+        const u32 xlen = l_meta[x] & 63u;
+        if (xlen > alen) continue;
+        const u64 xk = l_key[x], xm = xlen >= 32 ? ~0ULL : ((1ULL << (2 * xlen)) - 1);
+        bool hit = false;
+        for (u32 sh = 0; sh <= alen - xlen; ++sh) hit = hit || (((a >> (2 * sh)) & xm) == xk);
+        if (hit) ok = (xlen == alen) && (i < x);
+      }
+    }
+    if (ok) {
+      l_meta[i] = (u16)(meta | 0x8000u);
+      atomicAdd(&g_alive[lg], 1u);
+      if (TAKE) {
+        const u64 occ = (u64)l_hi[i] - l_lo[i];
+        atomicAdd(&g_occ[lg], (unsigned long long)(occ < b.max_locations ? occ : b.max_locations));
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 total = 0;
+    for (u32 g = 0; g < gpw; ++g) {
+      g_base[g] = total;
+      total += g_alive[g];
+    }
+    s_total = total;
+    s_base = total ? atomicAdd(&o.ctr->sel_cnt[shard], total) : 0u;
+  }
+  __syncthreads();
+  const u32 wbase = s_base;
+  const bool room = wbase + s_total <= fs.cap;  // an overflowing slice repeats the batch (Summary::worst_sel) ...
+  if (!room && threadIdx.x == 0) atomicOr(&o.ctr->overflow, 1u);  // ... and the kernels behind this one do nothing
+  if (threadIdx.x == 0 && nl) atomicAdd(&o.ctr->fused_leaves[shard], (unsigned long long)nl);
+  // rank among the group's survivors in std::string order (A < C < G < T = code order; a proper prefix sorts first) -> Sel
+  for (u32 i = threadIdx.x; i < nl; i += sstep) {
+    const u32 meta = l_meta[i];
+    if (!(meta & 0x8000u)) continue;
+    const u32 alen = meta & 63u, lg = (meta >> 6) & 15u;
+    const u64 ak = l_key[i] << (64 - 2 * alen);
+    const u32 s0 = g_start[lg], s1 = s0 + g_cnt[lg];
+    u32 r = 0;
+    u64 before = (TAKE && (lg & 1u)) ? g_occ[lg - 1] : 0ULL;  // TAKE: occurrences (clamped) of the strings in front of this one in push order
+    for (u32 j = s0; j < s1; ++j) {
+      const u32 x = l_ord[j], xm = l_meta[x];
+      if (x == i || !(xm & 0x8000u)) continue;
+      const u32 xlen = xm & 63u;
+      const u64 xk = l_key[x] << (64 - 2 * xlen);
+      const bool first = (xk < ak) || (xk == ak && xlen < alen);
+      r += first;
+      if (TAKE && first) {
+        const u64 occ = (u64)l_hi[x] - l_lo[x];
+        before += occ < b.max_locations ? occ : b.max_locations;
+      }
+    }
+    if (room) {
+      Sel sv;
+      sv.lo = l_lo[i];
+      sv.hi = l_hi[i];
+      sv.len = alen;
+      sv.take = 0;
+      sv.hbase = 0;
+      if (TAKE) {  // hunter.h:349-357: strings are located in set order, forward strand first, while hits < max_locations
+        const u64 M = b.max_locations, occ = (u64)sv.hi - sv.lo;
+        const u64 h0 = before < M ? before : M, h1 = before + occ < M ? before + occ : M;
+        sv.hbase = (u32)h0;
+        sv.take = (u32)(h1 - h0);
+      }
+      sv.g = g_first + lg;
+      fs.sel[(u64)shard * fs.cap + wbase + g_base[lg] + r] = sv;
+    }
+  }
+  if (threadIdx.x < gpw && g_first + threadIdx.x < ngrp2) {
+    const u32 gid = g_first + threadIdx.x;
+    const uint4 raw = ginfo_of(threadIdx.x, gid);
+    if (raw.z && (raw.w & 512u)) {  // groups this kernel searches: their strings are in the flat region, also when there are none
+      fs.nsel[gid] = room ? g_alive[threadIdx.x] : 0u;
+      fs.selbase[gid] = shard * fs.cap + wbase + g_base[threadIdx.x];
+    }
+  }
+  if (TAKE && threadIdx.x < gpw / 2) {  // k_take's per-query part: the hit count, hunter.h:434, the compact results' word
+    const u64 q = (u64)(g_first / 2) + threadIdx.x;
+    if (q < b.nq) {
+      const u64 M = b.max_locations, tot = g_occ[2 * threadIdx.x] + g_occ[2 * threadIdx.x + 1];
+      const u64 hits = room ? (tot < M ? tot : M) : 0ULL;
+      po.qhits[q] = (u32)hits;
+      u32 fl = b.qflags[q];
+      if (hits >= M && !(fl & DG_Q_TOO_SHORT)) {
+        fl |= DG_Q_MAX_MATCHES;
+        b.qflags[q] = fl;
+      }
+      if (b.qinfo) b.qinfo[q] = (fl & 255u) | ((b.qdist[q] & 255u) << 8) | (b.qnondna[q] << 16);
+    }
+  }
+}
+
+// (r02 also measured k_search1p cut in two kernels — probe, then finish from a survivor queue in HBM: 0.21 + 0.19 ms against 0.25 ms
+// fused; removed in r04.)
+// ------------------------------------------------------------------------------------------------------------
+// Distance 2 (edit mode) laid out flat as well.  r02 profile of the state machine at d = 2: 124 ms per 100 000 20-mers,
+// 1.7 G filter probes + 0.36 G table reads + 0.59 G interval extensions — issue bound like its d = 1 form was, and most of
+// its memory accesses belong to strings that do not occur.  Here:
+//   * one WORKGROUP per (query, strand); its four wavefronts walk the pairs of edit positions (p2 <= p1, counted as "the
+//     operation sits right of q[0..p)"), one wavefront per pair, one LANE per pair of operations (8 x 8: delete, substitute
+//     by the three other bases, insert A/C/G/T) — every two-operation path of the trie k_search<true,2> walks
+//     (neighbors.h:47-83), so the same strings, duplicates included, reach the select stage;
+//   * a lane applies its two operations to the 2-bit packed query with shifts and masks and asks the LONG presence filter
+//     (order K2, FmView::kf2) about the last K2 characters; strings shorter than K2 ask the table's filter.  U pairs per
+//     wavefront are in flight at once (the probes are independent loads).  Neighbouring pairs differ in p1 only, lanes pick
+//     the filter copy by p1's window position, so the probes of a workgroup keep hitting the lines it already has in L1/L2;
+//   * survivors (about 1 % of the candidates behind a 19-mer filter on a 3.1 Gb genome) are pushed on an LDS stack; whenever
+//     it holds 256 of them the workgroup pops 256 and runs them densely: table entry, interval extension over the
+//     characters left of the table window, leaf record.  Leaf slots of the group come from an LDS counter, leaf space from
+//     one atomic per wavefront.
+// Taken: queries of 2-edit budget without N, up to 30 nt (the edited string fits 64 bits) and at least K + 2 long.
+DG_DEV void apply_edit(u64 pk, u32 len, u32 pos, u32 op, u64& out, u32& olen, u32& word) {
+  const u32 R = len - pos;  // characters right of the operation
+  const u64 low = pk & ((1ULL << (2 * R)) - 1);
+  const u32 old = (u32)(pk >> (2 * R)) & 3u;
+  if (op == 0) {
+    out = low | ((pk >> (2 * R + 2)) << (2 * R));
+    olen = len - 1;
+    word = (pos << 4) | (OP_D << 2);
+  } else if (op < 4) {
+    const u32 c = (old + op) & 3u;  // neighbors.h:63: a different base
+    out = pk ^ ((u64)(old ^ c) << (2 * R));
+    olen = len;
+    word = (pos << 4) | (OP_S << 2) | c;
+  } else {
+    const u32 c = op - 4;
+    out = low | ((u64)c << (2 * R)) | ((pk >> (2 * R)) << (2 * R + 2));
+    olen = len + 1;
+    word = (pos << 4) | (OP_I << 2) | c;
+  }
+}
+
+// (the lane-per-operation-pair kernel described above — k_search2<U>, r02: 17.4 ms — was removed in r04; k_search2p below is the
+// same enumeration with one lane per pair of POSITIONS)
+
+// k_search2 with one lane per PAIR OF POSITIONS: the lane walks the 8 x 8 operations in two fully unrolled loops (every
+// operation is a compile-time constant where it is applied, the eight probes of an inner loop are independent loads), skips
+// the operations that only repeat another lane's string — deleting the left one of two equal neighbours, inserting a base
+// right of an equal one; checked against the reference's minimal set on random and low-complexity queries — and queues
+// survivors as (pair, operation, operation) for the dense phase, which rebuilds them.  ~30 vector instructions per candidate
+// instead of ~150, and a fifth fewer candidates (12 160 -> ~9 700 for a 20-mer).
+DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... hold m, m-1, ... pairs; row a = p2-1 starts at a(2m+1-a)/2
+  const float tm = (float)(2 * m + 1);
+  int a = (int)((tm - sqrtf(tm * tm - 8.0f * (float)w)) * 0.5f);
+  if (a < 0) a = 0;
+  if (a > (int)m - 2) a = (int)m - 2;
+  while (a > 0 && (u32)a * (2 * m + 1 - (u32)a) / 2 > w) --a;
+  while ((u32)(a + 1) * (2 * m - (u32)a) / 2 <= w) ++a;
+  p2 = (u32)a + 1;
+  p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
+}
+__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o) {
+  // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
+  // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
+  // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
+  // over the lanes and finds its e-th one by a binary search over the prefix plus a select inside the lane's mask.
+  __shared__ unsigned long long q_mask[256];
+  __shared__ u32 q_ex[256 + 1];  // exclusive prefix of the lanes' survivor counts, [256] = total
+  __shared__ u32 q_wave[4];
+  __shared__ u32 g_slots;
+  const u32 gid = blockIdx.x;
+  const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+  const u32 m = raw.z, d_win = raw.w;
+  if (!m || !(d_win & 1024u)) return;  // uniform for the workgroup
+  const u64 qpk = (u64)raw.y << 32 | raw.x;
+  if (threadIdx.x == 0) g_slots = 0;
+  __syncthreads();
+  const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
+  const u64 kmask = (1ULL << (2 * K)) - 1, mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+  const u32 lane = threadIdx.x & 63;
+  const u32 npairs = m * (m + 1) / 2 - 1;  // p2 = 1..m-1, p1 = p2..m
+  const u32 shard = blockIdx.x & (NSHARD - 1);
+  u32 steps = 0, nlook = 0, nprobe = 0;
+  for (u32 w0 = 0; w0 < npairs; w0 += 256) {
+    const u32 w = w0 + threadIdx.x;
+    u64 surv = 0;
+    if (w < npairs) {
+      u32 p1, p2;
+      pair_of(w, m, p2, p1);
+      const u32 R1 = m - p1;
+      const KfCopy c2 = kf_copy(f.kf2, R1 < K2 ? R1 : (K2 ? K2 - 1 : 0u));
+      const KfCopy c1 = kf_copy(f.kf, R1 < K ? R1 : K - 1);
+      const u32 qa = (u32)(qpk >> (2 * R1)) & 3u;                       // q[p1-1]
+      const u32 qb = R1 ? (u32)(qpk >> (2 * R1 - 2)) & 3u : 4u;         // q[p1], 4 = none
+      const u32 q2a = (u32)(qpk >> (2 * (m - p2))) & 3u;                // q[p2-1]
+      const u32 q2b = (u32)(qpk >> (2 * (m - p2) - 2)) & 3u;            // q[p2] (p2 < m)
+#pragma unroll
+      for (u32 op1 = 0; op1 < 8; ++op1) {
+        const bool ins1 = op1 >= 4;
+        // the first operation leaves p2 characters to its left; nothing is inserted after the last character
+        bool v1 = (p1 > p2 || ins1) && !(p1 == m && ins1);
+        if (op1 == 0) v1 = v1 && qb != qa;
+        if (ins1) v1 = v1 && !(p1 >= 2 && qa == op1 - 4 && p2 + 2 <= p1);
+        if (v1) {
+          u64 s1;
+          u32 l1, w1;
+          apply_edit(qpk, m, p1, op1, s1, l1, w1);
+          const u32 posp = ins1 ? p1 : p1 - 1;  // characters left of the first operation
+          u32 mask8 = 0;
+          // all addresses first, then the eight loads back to back, then the bits
+          const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
+          const u32* addr[8];
+          u32 bit[8], word[8], valid = 0, probe = 0;
+#pragma unroll
+          for (u32 op2 = 0; op2 < 8; ++op2) {
+            bool v2 = true;
+            if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
+            if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
+            u64 s2;
+            u32 l2, w2;
+            apply_edit(s1, l1, p2, op2, s2, l2, w2);
+            const bool use2 = K2 && l2 >= K2;
+            const bool pr = v2 && (use2 || f.kf.nr);
+            KfCopy c;
+            c.base = use2 ? c2.base : c1.base;
+            c.s = use2 ? c2.s : c1.s;
+            const u32* a = kf_word(c, use2 ? s2 & mask2 : s2 & kmask, bit[op2]);
+            addr[op2] = pr ? a : idle;
+            valid |= (u32)v2 << op2;
+            probe |= (u32)pr << op2;
+          }
+#pragma unroll
+          for (u32 op2 = 0; op2 < 8; ++op2) word[op2] = *addr[op2];
+#pragma unroll
+          for (u32 op2 = 0; op2 < 8; ++op2) {
+            const u32 present = ((probe >> op2) & 1u) ? (word[op2] >> bit[op2]) & 1u : 1u;
+            mask8 |= (((valid >> op2) & 1u) & present) << op2;
+          }
+          nprobe += (u32)__popc(probe);
+          surv |= (u64)mask8 << (8 * op1);
+        }
+      }
+    }
+    // number the survivors: inclusive scan of the lanes' counts inside the wavefront, wavefront totals through LDS
+    const u32 mine = (u32)__popcll(surv);
+    u32 incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 v = __shfl_up(incl, off);
+      if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) q_wave[threadIdx.x >> 6] = incl;
+    q_mask[threadIdx.x] = surv;
+    __syncthreads();
+    u32 before = 0;
+    for (u32 k = 0; k < (threadIdx.x >> 6); ++k) before += q_wave[k];
+    q_ex[threadIdx.x] = before + incl - mine;
+    const u32 qn = q_wave[0] + q_wave[1] + q_wave[2] + q_wave[3];
+    __syncthreads();
+    for (u32 e0 = 0; e0 < qn; e0 += 256) {
+      if (e0 + (threadIdx.x & ~63u) >= qn) break;  // wavefront without work
+      const u32 e = e0 + threadIdx.x;
+      bool leaf = false;
+      u32 lo = 0, hi = 0, w1 = 0, w2 = 0;
+      if (e < qn) {
+        // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
+        u32 L = 0;
+#pragma unroll
+        for (u32 step = 128; step > 0; step >>= 1)
+          if (q_ex[L + step] <= e) L += step;
+        unsigned long long mk = q_mask[L];
+        for (u32 r = e - q_ex[L]; r > 0; --r) mk &= mk - 1;
+        const u32 bitno = (u32)__ffsll((long long)mk) - 1u;
+        u32 p1, p2, l1, l2;
+        u64 s1, s2;
+        pair_of(w0 + L, m, p2, p1);
+        apply_edit(qpk, m, p1, bitno >> 3, s1, l1, w1);
+        apply_edit(s1, l1, p2, bitno & 7u, s2, l2, w2);
+        nprobe += (K2 && l2 > K2);
+        if (head_window_occurs(f, s2, l2, l1 - p2)) {
+          const uint2 iv = f.ktab[s2 & kmask];
+          ++nlook;
+          lo = iv.x;
+          hi = iv.y;
+        }
+        u64 rs = s2 >> (2 * K);
+        u32 nr = l2 - K;
+        while (nr && lo < hi) {
+          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+          rs >>= 2;
+          --nr;
+          ++steps;
+        }
+        leaf = lo < hi;
+      }
+      const unsigned long long lm = __ballot(leaf);
+      u32 lbase = 0;
+      if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
+      lbase = __shfl(lbase, 0);
+      if (leaf) {
+        const u32 slot = atomicAdd(&g_slots, 1u);
+        const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
+        if (la < o.shard_cap) {
+          Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
+          lf->qs = gid;
+          lf->slot = slot;
+          lf->lo = lo;
+          lf->hi = hi;
+          lf->nops = 2;
+          lf->ops[0] = w1;
+          lf->ops[1] = w2;
+#pragma unroll
+          for (int k = 2; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+        }
+      }
+    }
+    __syncthreads();  // the masks and prefixes of this pass are not needed any more
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    nlook += __shfl_xor(nlook, off);
+    nprobe += __shfl_xor(nprobe, off);
+  }
+  if (lane == 0) {
+    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
+    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
+    if (nprobe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nprobe);
+  }
+  if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
+}
+
+template <bool INDEL, int D>
+__global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, u32 items) {
+  // lane layout: the long-running "rest" lanes come first, packed densely (a rest lane among 63 short item lanes
+  // would pin its whole wavefront); item lanes follow, (items-1) consecutive lanes per (query, strand)
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 ngrp = b.nq * 2;
+  u64 gid;   // 2*query + strand
+  u32 item;  // items-1 = the rest lane
+  if (t < ngrp || items == 1) {
+    gid = t;
+    item = items - 1;
+  } else {
+    gid = (t - ngrp) / (items - 1);
+    item = (u32)((t - ngrp) % (items - 1));
+  }
+  u64 steps = 0, lookups = 0, probes = 0;
+  constexpr u32 NOPS = INDEL ? 9u : 4u;  // INDEL: D, S(A,C,G,T), I(A,C,G,T);  Hamming: S(A,C,G,T)
+  bool active = gid < ngrp;
+  const u64 q = gid >> 1;
+  const u32 strand = (u32)(gid & 1);
+  GidInfo gi;
+  gi.qpk = 0;
+  gi.m = 0;
+  gi.d_win = 0;
+  if (active) gi = b.ginfo[gid];
+  if (gi.m == 0 || (gi.d_win & (512u | 1024u))) active = false;  // not searched, or taken by a flat kernel
+  if (active) {
+    const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
+    const u32 m = gi.m;
+    u32 d = gi.d_win & 255;
+    if (d > (u32)D) d = D;  // cannot happen: the host instantiates D >= the largest effective distance
+    const bool use_win = f.K != 0 && m >= f.K + d && (gi.d_win & 256);
+    const bool rest = item == items - 1;
+    // lanes of a split launch: without the table (or without budget) only the rest lane works, as a full search
+    if (!rest && (!use_win || d == 0)) active = false;
+    if (active) {
+      const u64 qpk = gi.qpk;
+      FrameStack<D> S;
+      OpStack<D> ops;
+      u32 L = 0;
+      bool single = false;  // an item lane: exactly one root operation
+      u32 single_op = 0;
+      {
+        Frame r;
+        r.pos = m;
+        r.lo = 0;
+        r.hi = use_win ? 0u : (u32)f.n;
+        r.st = use_win ? ST_WIN : 0u;
+        if (use_win && items > 1) {
+          if (rest) {
+            // the unedited window in one table read; first edits left of the window follow in interval mode
+            if (!frame_finish_window(f, r, seq, m, qpk, lookups, probes)) active = false;
+          } else {
+            const u32 j = item / NOPS;  // characters right of the edit
+            single_op = item % NOPS;
+            single = true;
+            u64 code = 0;
+            if (m <= 32) code = qpk & (j >= 32 ? ~0ULL : ((1ULL << (2 * j)) - 1));
+            else
+              for (u32 k = 0; k < j; ++k) code |= (u64)seq[m - 1 - k] << (2 * k);
+            r.pos = m - j;
+            r.lo = (u32)code;
+            r.hi = (u32)(code >> 32);
+            r.st = ST_WIN | (j << 4) | single_op;
+          }
+        }
+        S.set(0, r);
+      }
+      while (active) {
+        Frame F = S.get(L);
+        const u32 budget = d - L;
+        if (F.pos == 0) {
+          // a complete neighbourhood string whose interval is non-empty (strings are never shorter than K in window mode)
+          if (!INDEL || budget == 0) {
+            const u32 shard = blockIdx.x & (NSHARD - 1);
+            u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+            u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+            if (at < o.shard_cap) {
+              Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+              lf->qs = (u32)gid;
+              lf->slot = slot;
+              lf->lo = F.lo;
+              lf->hi = F.hi;
+              lf->nops = L;
+#pragma unroll
+              for (int k = 0; k < (int)DMAX; ++k) lf->ops[k] = (k < D && (u32)k < L) ? ops.v[k < D ? k : 0] : 0u;
+            }
+          }
+          if (L == 0) break;
+          --L;
+          continue;
+        }
+        const u32 pos = F.pos;
+        // the query character: from the packed copy when there is one (no memory access on the critical path)
+        const u32 here = (m <= 32 && (gi.d_win & 256)) ? (u32)(qpk >> (2 * (m - pos))) & 3u : (u32)seq[pos - 1];
+        const u32 op = F.st & 15;
+        if (single && L == 0 && op != single_op) break;  // the item's one operation has been explored
+        if (budget > 0 && op < NOPS) {
+          F.st += 1;  // next operation of this node
+          S.set(L, F);
+          u32 kind, c;
+          if (INDEL) {
+            kind = op == 0 ? OP_D : (op <= 4 ? OP_S : OP_I);
+            c = op == 0 ? 0u : (op - 1) & 3;
+          } else {
+            kind = OP_S;
+            c = op;
+          }
+          if (kind == OP_S && c == here) continue;           // a substitution changes the character (neighbors.h:63)
+          if (kind == OP_I && L == 0 && pos == m) continue;   // nothing may be inserted after the last character (neighbors.h:51)
+          Frame ch = F;
+          ch.st &= ~15u;
+          if (kind != OP_D && !frame_emit(f, ch, c, steps, lookups, probes)) continue;
+          ch.pos = kind == OP_I ? pos : pos - 1;
+          if (budget == 1 && (ch.st & ST_WIN) && !frame_finish_window(f, ch, seq, m, qpk, lookups, probes)) continue;
+          ops.set(L, (pos << 4) | (kind << 2) | c);
+          ++L;
+          S.set(L, ch);
+          continue;
+        }
+        // keep the query character(s)
+        bool alive;
+        if (budget == 0 && (F.st & ST_WIN)) alive = frame_finish_window(f, F, seq, m, qpk, lookups, probes);  // only a d = 0 root
+        else {
+          F.st &= ~15u;
+          if (here < 4) alive = frame_emit(f, F, here, steps, lookups, probes);
+          else {  // an N in the query (never in window mode): through the wavelet tree like sdsl
+            bs_extend_sym(f, F.lo, F.hi, 'N', here);
+            ++steps;
+            alive = F.lo < F.hi;
+          }
+          F.pos = pos - 1;
+        }
+        if (!alive) {
+          if (L == 0) break;
+          --L;
+          continue;
+        }
+        S.set(L, F);
+      }
+    }
+  }
+  wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
+  wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
+  wave_add(&o.ctr->probes[blockIdx.x & (NSHARD - 1)], probes);
+}
+
+// Explicit patterns (the host-enumerated capped neighbourhoods): one lane per string, plain backward search right to
+// left (sdsl::count, hunter.h:353); occurring strings become leaves of their (query, strand) group like k_search's.
+__global__ void __launch_bounds__(256) k_explicit(FmView f, Batch b, SearchOut o) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 steps = 0, lookups = 0, probes = 0;
+  if (i < b.nxs) {
+    const u64 s = b.xs_off[i], e = b.xs_off[i + 1];
+    u32 lo = 0, hi = (u32)f.n;
+    u64 k = e;
+    // r04: like every other search kernel, a pattern first asks the long presence filter about its last K2 characters (96 of 100
+    // random 18-mers of a 3.1 Gb genome end there, for one line instead of ~13 interval extensions from the full range), then its
+    // first K2 characters, then takes the interval of its last K characters from the table.  r03 searched the 40 M patterns of
+    // 2 000 capped 25-mers character by character: ~1 G random Occ lines, most of the 51 ms step.
+    const u32 len = (u32)(e - s), K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u, W = K2 > K ? K2 : K;
+    if (K && len >= W && W <= 32) {
+      u64 code = 0;  // the last W characters, last character in the lowest bits
+      bool plain = true;
+      for (u32 t = 0; t < W; ++t) {
+        const u32 c = b.xs_bytes[e - 1 - t];
+        plain = plain && c < 4;
+        code |= (u64)(c & 3u) << (2 * t);
+      }
+      if (plain) {
+        bool alive = true;
+        if (K2) {
+          ++probes;
+          alive = kf_present(f.kf2, code & ((1ULL << (2 * K2)) - 1), 0u);
+          if (alive && len > K2) {  // the first K2 characters as well
+            u64 head = 0;
+            bool hp = true;
+            for (u32 t = 0; t < K2; ++t) {
+              const u32 c = b.xs_bytes[s + K2 - 1 - t];
+              hp = hp && c < 4;
+              head |= (u64)(c & 3u) << (2 * t);
+            }
+            if (hp) {
+              ++probes;
+              alive = kf_present(f.kf2, head, K2 - 1);
+            }
+          }
+        } else if (f.kf.nr) {
+          ++probes;
+          alive = kf_present(f.kf, code & ((1ULL << (2 * K)) - 1), 0u);
+        }
+        if (alive) {
+          const uint2 iv = f.ktab[code & ((1ULL << (2 * K)) - 1)];
+          ++lookups;
+          lo = iv.x;
+          hi = iv.y;
+        } else lo = hi = 0;
+        k = e - K;
+      }
+    }
+    for (; k > s && lo < hi; --k) {
+      const u32 code = b.xs_bytes[k - 1];
+      bs_extend_sym(f, lo, hi, 'N', code);
+      ++steps;
+    }
+    if (lo < hi) {
+      const u32 gid = b.xs_gid[i];
+      const u32 shard = blockIdx.x & (NSHARD - 1);
+      const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+      const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+      if (at < o.shard_cap) {
+        Leaf* lf = o.leaves + (u64)shard * o.shard_cap + at;
+        lf->qs = gid;
+        lf->slot = slot;
+        lf->lo = lo;
+        lf->hi = hi;
+        lf->nops = LEAF_EXPLICIT;
+        lf->ops[0] = (u32)i;
+#pragma unroll
+        for (int k = 1; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+      }
+    }
+  }
+  wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
+  wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
+  wave_add(&o.ctr->probes[blockIdx.x & (NSHARD - 1)], probes);
+}
+
+}  // namespace dg

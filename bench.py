@@ -715,7 +715,21 @@ def main():
                 try:
                     t4 = time.time()
                     got = ix.hunt(qstr[:npar], seqlen, distance=distance)
-                    _, ohits = orc.hunt(seqlen, ["s%d" % i for i in range(len(seqlen))], qstr[:npar], distance=distance, want_hits=True)
+                    # the checker on the host's cores: contiguous slices of the sample on up to 32 threads (its loop is single-threaded
+                    # like the reference's; a cap-firing 25-mer at distance 2 costs it 2.5 s)
+                    from concurrent.futures import ThreadPoolExecutor
+                    nthr = max(1, min(32, phys_cores, npar // 4 or 1))
+                    per_t = (npar + nthr - 1) // nthr
+                    names_ = ["s%d" % i for i in range(len(seqlen))]
+
+                    def _slice(t_):
+                        lo_, hi_ = t_ * per_t, min(npar, (t_ + 1) * per_t)
+                        if lo_ >= hi_:
+                            return []
+                        _, hh = orc.hunt(seqlen, names_, qstr[lo_:hi_], distance=distance, want_hits=True)
+                        return [(h[0] + lo_,) + tuple(h[1:]) for h in hh]
+                    with ThreadPoolExecutor(nthr) as ex:
+                        ohits = [h for part in ex.map(_slice, range(nthr)) for h in part]
                 finally:
                     O.fast_neighbors(False)
                 perq = {}

@@ -534,7 +534,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     // neighbors() with its cap on the device (hunt_cap.hpp): modes and explicit patterns of the listed queries, before k_prepare
     // reads them.  One host round trip for the pattern count (launch sizes below depend on it).
     const u32 njobs = (u32)dev_jobs.size();
-    const u32 nwg = std::min<u32>(njobs, 512u);
+    // persistent workgroups; the kernel is chains of atomics and probes per workgroup, so its time falls with the number of
+    // workgroups in flight and the independent accesses each keeps in flight (r04 first form: 512 workgroups, one access at a
+    // time per lane: 46.7 ms per 2 000 25-mers)
+    const u32 nwg = std::min<u32>(njobs, 1024u);  // four per CU fit (113 VGPRs)
     const u64 leaves = cap::total_leaves(std::min<u32>(maxlen, cap::MAX_KEY_LEN - dmax_eff), dmax_eff) + 2;
     u32 tcap_log2 = 8;
     while ((1ull << tcap_log2) < leaves * 5 / 2) ++tcap_log2;
@@ -790,7 +793,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           const u32 lcap_env = std::getenv("DICEY_FUSED_LCAP") ? std::max<u32>(1u, std::min<u32>(FUSED_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP")))) : 0u;
           const u32 lcap = lcap_env ? lcap_env : (ix->fused_leaves_hint > 48ull * g1.x ? FUSED_LCAP : FUSED_LCAP / 2);
           const u32 lds1 = fused_lds_bytes(lcap);
-          const u32 leave1 = std::getenv("DICEY_EXP_NOLEAVE") ? 0u : 1u;  // (r04 A/B: idle wavefronts end behind the probe phase or wait at the barrier)
+          const u32 leave1 = 1u;  // idle wavefronts end behind the probe phase (r04 A/B on one box: 0.2188 ms with, 0.2194 without — harmless, kept)
           PrepOut po;
           po.qhits = qhits;
           if (prep_in) {
@@ -1008,6 +1011,20 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (hsum.refused)
       return fail(DG_EINVAL, "internal error: %llu quer%s could reach the maxNeighborhood cap (%u) without having been enumerated on the host",
                   hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
+    if (const char* dj = std::getenv("DICEY_DUMP_JOBS")) {  // development aid: (lo, occs, take) of the batch's locate jobs, small then big
+      const u32 jc = (u32)std::min<u64>(leaf_slots, 1u << 20);
+      const u32 ns_ = (u32)std::min<u64>(hsum.jobs_small, jc), nb_ = (u32)std::min<u64>(hsum.jobs_big, jc);
+      std::vector<BigJob> hj((size_t)ns_ + nb_);
+      if (ns_) DG_HIP(hipMemcpy(hj.data(), ws[WS_JOBS].as<BigJob>(), (size_t)ns_ * sizeof(BigJob), hipMemcpyDeviceToHost));
+      if (nb_) DG_HIP(hipMemcpy(hj.data() + ns_, ws[WS_JOBS].as<BigJob>() + jc, (size_t)nb_ * sizeof(BigJob), hipMemcpyDeviceToHost));
+      if (FILE* fj = std::fopen(dj, "wb")) {
+        for (const BigJob& j : hj) {
+          const u32 rec[4] = {j.lo, j.occs, j.take, j.len};
+          std::fwrite(rec, 4, 4, fj);
+        }
+        std::fclose(fj);
+      }
+    }
     nleaf = hsum.nleaf;
     nhits = hsum.nhits;
     // Everything this attempt found wanting is put right before the batch is repeated (one repeat usually serves several causes).

@@ -339,7 +339,6 @@ static void kf_layout(KFilter& kf, u32 k) {
   const u32 bits = 2 * k;
   u32 nr = bits <= 9 ? 1u : (bits - 9 + 7) / 8 + 1;
   if (nr > 4) nr = 4;
-  if (const char* e = std::getenv("DICEY_KF_COPIES")) nr = (u32)std::min(4, std::max(1, std::atoi(e)));  // experiments
   kf.k = k;
   kf.nr = nr;
   for (u32 r = 0; r < 4; ++r) kf.s[r] = (nr > 1 && r < nr) ? (r * (bits - 9) + (nr - 1) / 2) / (nr - 1) : 0u;
@@ -370,7 +369,6 @@ static int build_filter(dg_index* ix, KFilter& kf, u32 k, const uint2* tab, u32*
   kf_layout(kf, k);
   const u32 nr = kf.nr;
   kf.nr = 0;  // until the copies exist
-  static const bool generic = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (barrier-free kernels only)
   const u32 TB = 256;
   for (u32 r = 0; r < nr; ++r) {
     const u32 s = kf.s[r];
@@ -383,32 +381,15 @@ static int build_filter(dg_index* ix, KFilter& kf, u32 k, const uint2* tab, u32*
     }
     if (r == 0 && copy0) {
       // filled by the caller
-    } else if (r == 0 && !generic) {
+    } else if (r == 0) {
       hipLaunchKernelGGL(k_kf_from_table, dim3((u32)std::min<u64>(entries / TB, 1u << 20)), dim3(TB), 0, ix->stream, tab, entries, bm);
-    } else if (generic || s < 8) {
+    } else if (s < 8) {
       if (tab) hipLaunchKernelGGL(k_kf_generic, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, tab, bits, s, bm, nwords);
       else hipLaunchKernelGGL(k_kf_generic0, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, (const u32*)kf.cp[0], bits, s, bm, nwords);
     } else {
       hipLaunchKernelGGL(k_kf_transpose, dim3((u32)(entries >> 17)), dim3(512), 0, ix->stream, kf.cp[0], bm, s);
     }
     kf.cp[r] = bm;
-    if (std::getenv("DICEY_KF_VERIFY") && !(r == 0 && copy0)) {  // debugging aid: the fast builders against the one-lane-per-word builder
-      u32* ref = nullptr;
-      u32* bad = nullptr;
-      DG_HIP(hipMalloc((void**)&ref, nwords * 4 + 64));
-      DG_HIP(hipMalloc((void**)&bad, 4));
-      DG_HIP(hipMemsetAsync(bad, 0, 4, ix->stream));
-      if (tab) hipLaunchKernelGGL(k_kf_generic, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, tab, bits, s, ref, nwords);
-      else hipLaunchKernelGGL(k_kf_generic0, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, (const u32*)kf.cp[0], bits, s, ref, nwords);
-      hipLaunchKernelGGL(k_kf_compare, dim3(ceil_div(nwords, TB)), dim3(TB), 0, ix->stream, (const u32*)bm, (const u32*)ref, nwords, bad);
-      u32 hbad = 0;
-      DG_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ix->stream));
-      DG_HIP(hipStreamSynchronize(ix->stream));
-      DG_HIP(hipFree(ref));
-      DG_HIP(hipFree(bad));
-      std::fprintf(stderr, "DICEY_KF_VERIFY: order %u copy %u (s=%u): %u of %llu words differ\n", k, r, s, hbad, (unsigned long long)nwords);
-      if (hbad) return fail(DG_EHIP, "presence filter (order %u) copy %u differs from its definition in %u words", k, r, hbad);
-    }
   }
   DG_HIP(hipStreamSynchronize(ix->stream));
   DG_HIP(hipGetLastError());
@@ -522,7 +503,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
   DG_HIP(big_alloc((void**)&sa, n * 4 + 64, ix->stream));
   ix->owned.push_back(sa);
   bool sorted_sa = false;
-  if (!std::getenv("DICEY_NO_BLOCK_SCAN") && !std::getenv("DICEY_SA_BY_WALK") && n > (1u << 16)) {
+  if (n > (1u << 16)) {
     // text and inverse suffix array in one walk, suffix array by sorting (isa[p], p)
     u32* isa = nullptr;
     if (big_alloc((void**)&isa, n * 4 + 64, ix->stream) == hipSuccess) {
@@ -602,9 +583,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
       ix->hbm_bytes += f2_bytes;
       DG_HIP(hipMemsetAsync(f2, 0, f2_bytes, ix->stream));
     }
-    static const bool lane_only = std::getenv("DICEY_NO_BLOCK_SCAN") != nullptr;  // debugging aid (no wave collectives)
-    if (lane_only) hipLaunchKernelGGL(k_kmer_table, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K, K2, f2);
-    else hipLaunchKernelGGL(k_kmer_table_wave, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K, K2, f2);
+    hipLaunchKernelGGL(k_kmer_table_wave, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, f, tab, K, K2, f2);
     DG_HIP(hipStreamSynchronize(ix->stream));
     DG_HIP(hipGetLastError());
     f.ktab = tab;

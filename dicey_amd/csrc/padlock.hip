@@ -68,7 +68,7 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     R->probe_gc[i] = 0;
     R->arm_count[i] = R->arm_nbcount[i] = -1;
   }
-  static const bool timing = std::getenv("DICEY_DEBUG_TIMING") != nullptr;  // debugging aid: host-side phase times on stderr
+  static const bool timing = std::getenv("DICEY_TIMING") != nullptr;  // debugging aid: host-side phase times on stderr
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!timing) return;

@@ -318,7 +318,7 @@ void dg_thal_close(dg_thal* th) {
 int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t npairs, double* temp, int32_t* end1, int32_t* end2) {
   if (!th || !seqs || !off || !temp) return fail(DG_EINVAL, "dg_thal_batch: null argument");
   if (!npairs) return DG_OK;
-  static const bool timing = std::getenv("DICEY_DEBUG_TIMING") != nullptr;
+  static const bool timing = std::getenv("DICEY_TIMING") != nullptr;
   auto t_start = std::chrono::steady_clock::now();
   std::vector<PairDesc> pd(npairs);
   u64 ncode = 0, ndp = 0;

@@ -539,8 +539,11 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     // time per lane: 46.7 ms per 2 000 25-mers)
     const u32 nwg = std::min<u32>(njobs, 1024u);  // four per CU fit (113 VGPRs)
     const u64 leaves = cap::total_leaves(std::min<u32>(maxlen, cap::MAX_KEY_LEN - dmax_eff), dmax_eff) + 2;
+    // table slots: twice the number of DISTINCT strings a strand can hold (neighbourhood_bound; 15 705 for a 25-mer at distance 2
+    // against 20 201 leaves) — 512 KB per strand instead of 1 MB for 25-mers
+    const u64 distinct = std::min<u64>(leaves, neighbourhood_bound(std::min<u32>(maxlen, cap::MAX_KEY_LEN - dmax_eff), dmax_eff, true, 0));
     u32 tcap_log2 = 8;
-    while ((1ull << tcap_log2) < leaves * 5 / 2) ++tcap_log2;
+    while ((1ull << tcap_log2) < 2 * distinct) ++tcap_log2;
     const u32 evcap = (u32)((leaves + 2 + 63) & ~63ull);
     const u64 o_tab = 0, o_ev = o_tab + (u64)nwg * 2 * (16ull << tcap_log2), o_jobs = o_ev + (u64)nwg * 2 * evcap * 4,
               o_alloc = (o_jobs + (u64)njobs * 4 + 63) & ~63ull, o_end = o_alloc + 64;
@@ -738,7 +741,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     const u32 flat_cap = fused ? flat_req : 0u;
     const u64 flat_slots = (u64)NSHARD * flat_cap;
     const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
-    bool jobs_on = false;
+    bool jobs_on = false, walker_on = true;
     DG_TRY(ws[WS_LEAF].reserve(leaf_slots * sizeof(Leaf)));
     DG_TRY(ws[WS_LEAFG].reserve((leaf_slots + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
     DG_TRY(ws[WS_SEL].reserve((flat_slots + leaf_slots + 1) * sizeof(Sel)));
@@ -814,7 +817,11 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
-      if (generic_on) {
+      // edit distance 2: the walker (k_search) only serves the groups k_search2p does not take (N in the query, above 30 nt); it is
+      // launched when the previous batch of the handle had such groups — 0.17 ms of the 13 ms step on batches that have none — and
+      // a batch that has some after all is repeated with it, like the generic kernels at distance 1
+      walker_on = !(b.fast2K && !ix->generic_hint && !force_generic && nxs == 0);
+      if (generic_on && walker_on) {
       // root-level work split (see k_search): only with the table and with at least one edit to place
       const u32 items = (ix->view.K && dmax_eff >= 1 && !b.fastK) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
       const dim3 grid(ceil_div(ngrp * items, TB)), block(TB);
@@ -1036,6 +1043,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       force_generic = true;
       again = true;
     }
+    if (!walker_on && hsum.n_generic > 0) {  // edit distance 2: groups for the walker after all
+      ix->generic_hint = true;
+      ix->generic_sticky = 8;
+      force_generic = true;
+      again = true;
+    }
     if (!jobs_on && !group_counts && (hsum.jobs_small > 0 || hsum.jobs_big > 0)) {  // strings were queued and nobody served them
       ix->jobs_hint = true;
       force_jobs = true;
@@ -1058,6 +1071,11 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     // The hints are sticky: a kernel family that a batch needed stays on for the next eight batches of the handle, so that a stream
     // that alternates (chunks with and without N-containing queries, with and without repeat-rich strings) does not pay a repeated
     // batch at every change (r03 advice; r04 repeats genome: 4 of 14 rotating steps ran twice).
+    if (b.fast2K && !fused) {
+      if (hsum.n_generic > 0 || nxs > 0) ix->generic_sticky = 8;
+      else if (ix->generic_sticky) --ix->generic_sticky;
+      ix->generic_hint = ix->generic_sticky > 0;
+    }
     if (fused) {
       if (hsum.nleaf > 0 || hsum.n_generic > 0 || nxs > 0) ix->generic_sticky = 8;
       else if (ix->generic_sticky) --ix->generic_sticky;

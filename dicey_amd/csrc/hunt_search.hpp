@@ -167,11 +167,11 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
       else pq = make_uint4(__brev(pm[3]) >> (32 - m), __brev(pm[2]) >> (32 - m), __brev(pm[1]) >> (32 - m), __brev(pm[0]) >> (32 - m));
       b.gpeq[2 * q + strand] = pq;
     }
-    generic += (gi.m != 0 && !(gi.d_win & 512u));
+    generic += (gi.m != 0 && !(gi.d_win & (512u | 1024u)));
   }
   // groups the flat distance-1 kernel does not take: the host launches the generic kernels for them (and repeats a batch it
   // started without, run_batch).  A flag, not a count: every lane that has one stores the same 1.
-  if (generic && b.fastK) *n_generic = 1u;
+  if (generic && (b.fastK || b.fast2K)) *n_generic = 1u;
   return PreparedQuery{flags, d, bad};
 }
 __global__ void k_prepare(Batch b, u32* grp_cnt, u32* nsel, u32* selbase, u32* n_generic, u32 write_bytes) {

@@ -66,9 +66,13 @@ def _index(tmp_path, seqs, name):
     (40_000, 3_000_000, 0),    # starts at level 1
     (150_000, 8_000_000, 0),   # starts at level 2, spread positions
     (20_000, 2_000_000, 30_000),  # spread copies + a tandem array: most of the smallest positions share their top bytes
+    (-3000, 400_000, 0),       # DICEY_NO_SA_MINIMA: no block minima, repeat-rich strings by radix select over the interval (k_locate_big)
 ])
-def test_topk_locate_equals_oracle(tmp_path, copies, background, tandem):
+def test_topk_locate_equals_oracle(tmp_path, monkeypatch, copies, background, tandem):
     import dicey_amd
+    if copies < 0:
+        copies = -copies
+        monkeypatch.setenv("DICEY_NO_SA_MINIMA", "1")
     unit, seqs = _planted(copies + tandem, copies, background, tandem, divergent=0.2)
     path, g = _index(tmp_path, seqs, "rep.fm9")
     orc = O.Index(path)

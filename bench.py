@@ -575,6 +575,27 @@ def main():
             return res
 
         acc, elapsed, gathered = timed(step)
+        # the stages' times (HIP events between the kernels, DG_HUNT_PHASE_TIMES) are taken in a pass of their own behind the timed
+        # region: every event record is a marker packet in the stream, and the timed steps run without them (the batch total and the
+        # search kernel's own time — what roofline.kernel_ms is — are measured in every step)
+        p_phase = _capi.HuntParams(distance, 0, 0, 1000, 10000, a.qlen, _capi.DG_HUNT_COMPACT | _capi.DG_HUNT_PHASE_TIMES)
+        acc_ph = []
+        if rank == 0:
+            gp_saved, pipe["g"] = pipe["g"], None
+            try:
+                for _ in range(max(3, min(a.steps, 10))):
+                    rp = C.POINTER(_capi.HuntResult)()
+                    bq, bo, bbytes = dev_batches[rot["k"] % len(dev_batches)]
+                    rot["k"] += 1
+                    if nq:
+                        _capi.check(L, L.dg_hunt_device(ix.handle, C.byref(p_phase), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
+                                                        C.c_void_p(bo.data_ptr()), nq, bbytes, 0, C.byref(rp)))
+                        R = rp.contents
+                        acc_ph.append({"ms_total": R.ms_total, "ms_search": R.ms_search, "ms_search_flat": R.ms_search_flat,
+                                       "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify})
+                        L.dg_hunt_result_free(rp)
+            finally:
+                pipe["g"] = gp_saved
 
         # ---------------- extras, outside the timed region (N=1): what delivery costs
         extras = {}
@@ -746,9 +767,9 @@ def main():
             ext, tab, probe = mean("ext"), mean("tab"), mean("probe")
             flat = mean("ms_search_flat")
             # distance 1: k_search1s = the flat search with the select stage inside (r03); DICEY_NO_FUSED_SELECT gives k_search1p
-            k1 = "k_search1p<true>" if os.environ.get("DICEY_NO_FUSED_SELECT") else "k_search1s<true>"
+            k1 = "k_search1p<true>" if os.environ.get("DICEY_NO_FUSED_SELECT") else "k_search1s<true, true>"
             kernel = (k1 if distance == 1 else "k_search2p") if flat > 0 else f"k_search<true,{distance}>"
-            kernel_ms = flat if flat > 0 else mean("ms_search")
+            kernel_ms = flat if flat > 0 else (float(np.mean([r["ms_search"] for r in acc_ph])) if acc_ph else mean("ms_search"))
             alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
             # the same launch in SURVEY.md §8(d) units: a backward step on c = 2 L(c) rank ops of 24 B on the sdsl layout
             # (L = Huffman code length in the loaded wavelet tree), small reads by their payload
@@ -815,7 +836,9 @@ def main():
                                                                          "24_lines_per_strand": 11.3},
                                  "source": "profiles/r03a_gather_matrix.jsonl, profiles/r03a_gather_filter.jsonl"}},
                 "cpu_baseline": cpu, "cpu_baseline_parallel": cpu_par, "pipelined": pipelined, "parity_sample": parity,
-                "phases_ms": {k: mean(k) for k in ("ms_total", "ms_search", "ms_search_flat", "ms_select", "ms_locate", "ms_verify")},
+                "phases_ms": ({k: float(np.mean([r[k] for r in acc_ph])) for k in ("ms_total", "ms_search", "ms_search_flat", "ms_select", "ms_locate", "ms_verify")}
+                              if acc_ph else {k: mean(k) for k in ("ms_total", "ms_search", "ms_search_flat", "ms_select", "ms_locate", "ms_verify")}),
+                "ms_total_timed_steps": mean("ms_total"),
                 "hits_per_step": int(acc[-1]["nhits"]), "leaves_per_step": int(acc[-1]["leaves"]),
             })
             out.update(extras)

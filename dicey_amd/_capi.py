@@ -16,6 +16,7 @@ DG_OPEN_COMPACT = 4
 DG_OPEN_BIG_TABLE = 8
 DG_Q_TOO_SHORT, DG_Q_DIST_ADJUSTED, DG_Q_MAX_MATCHES, DG_Q_NBHD_EXCEEDED = 1, 2, 4, 8
 DG_HUNT_COMPACT = 1
+DG_HUNT_PHASE_TIMES = 2
 
 
 class DgError(RuntimeError):

@@ -442,6 +442,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   DG_HIP(hipSetDevice(ix->device));
   hipStream_t st = ix->stream;
   const bool host_timing = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;  // host phases of every batch to stderr
+  // HIP events between the stages (ms_select / ms_locate / ms_verify of the result) only on request: every record is a marker packet
+  // the next kernel waits behind; the batch's total and the flat search kernel's time are always measured (four events)
+  const bool phase_events = (p->flags & DG_HUNT_PHASE_TIMES) != 0 || sx || group_counts;
   const double t_enter = host_timing ? host_us() : 0.0;
   double t_launched = 0, t_synced = 0;
   for (int i = 0; i < 9; ++i)
@@ -841,12 +844,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (nxs) hipLaunchKernelGGL(k_explicit, dim3(ceil_div(nxs, TB)), dim3(TB), 0, st, ix->view, b, so);
       }
     }
-    DG_HIP(hipEventRecord(ix->ev[2], st));
+    if (phase_events) DG_HIP(hipEventRecord(ix->ev[2], st));
     // (r03 tried single-launch scans chained by decoupled look-back, and k_take fused with its scan: 17 us against 2 x 4.3 us, and
     //  47 us against 7 + 9 us — descriptor polling with device-scope acquire / release is slow across the XCDs' L2s.  What stays of
     //  that round: the first scan kernel also checks the search kernels' buffers, which was a launch of its own.)
     if (generic_on) DG_TRY(device_scan(st, grp_cnt, ngrp, grp_off, scan_buf, ctr, shard_cap, surv_cap));
-    DG_HIP(hipEventRecord(ix->ev[3], st));
+    if (phase_events) DG_HIP(hipEventRecord(ix->ev[3], st));
     if (packed) {
       if (generic_on) {
       u8* alive = ws[WS_SCR].as<u8>();
@@ -874,16 +877,17 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       hipLaunchKernelGGL(k_select, dim3(ceil_div(nq, 64)), dim3(64), 0, st, b, ws[WS_LEAFG].as<Leaf>(), grp_off, sel_gen,
                          nsel, qhits, scr_keep, scr_rank, ctr);
     }
-    DG_HIP(hipEventRecord(ix->ev[4], st));
+    if (phase_events) DG_HIP(hipEventRecord(ix->ev[4], st));
     if (group_counts) {
       DG_TRY(ws[WS_HITS].reserve(ngrp * 8 + 64));
       hipLaunchKernelGGL(k_group_count, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, (const u64*)grp_off, (const u32*)selbase, flat_slots,
                          (const u32*)nsel, (const Sel*)sel_all, ngrp, ws[WS_HITS].as<u64>(), ctr);
       DG_HIP(hipMemsetAsync(hit_off + nq, 0, 8, st));  // no hits in this mode
-      for (int e = 5; e <= 7; ++e) DG_HIP(hipEventRecord(ix->ev[e], st));
+      for (int e = 5; e <= 7; ++e)
+        if (phase_events || e == 7) DG_HIP(hipEventRecord(ix->ev[e], st));
     } else {
     DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
-    DG_HIP(hipEventRecord(ix->ev[5], st));
+    if (phase_events) DG_HIP(hipEventRecord(ix->ev[5], st));
     {
       // strings with many occurrences go to two job lists: up to 256 occurrences for a wavefront each, more for a workgroup each
       const u32 job_cap = (u32)std::min<u64>(leaf_slots, 1u << 20);
@@ -926,7 +930,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
                              ws[WS_SEEDS].as<HitSeed>(), ctr, topk ? TOPK_KMAX : 0u);
       }
     }
-    DG_HIP(hipEventRecord(ix->ev[6], st));
+    if (phase_events) DG_HIP(hipEventRecord(ix->ev[6], st));
     if (sx) {
       DG_TRY(launch_site_stage(ix, sx, b, ws[WS_SEEDS].as<HitSeed>(), hit_off, hit_cap, ws[WS_CUM].as<u64>(), nseq, dmax_eff, maxlen, ctr));
     } else {
@@ -1175,11 +1179,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->ctr_sa_reads = hsum.sa_reads;
   R->ctr_win_bytes = hsum.win_bytes;
   R->ms_total = ev_ms(ix->ev[0], ix->ev[7]);
-  R->ms_search = ev_ms(ix->ev[1], ix->ev[2]);
   R->ms_search_flat = (b.fastK || b.fast2K) ? ev_ms(ix->ev[1], ix->ev[8]) : 0.0;
-  R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);
-  R->ms_locate = ev_ms(ix->ev[5], ix->ev[6]);
-  R->ms_verify = ev_ms(ix->ev[6], ix->ev[7]);
+  if (phase_events) {
+    R->ms_search = ev_ms(ix->ev[1], ix->ev[2]);
+    R->ms_select = ev_ms(ix->ev[3], ix->ev[4]);
+    R->ms_locate = ev_ms(ix->ev[5], ix->ev[6]);
+    R->ms_verify = ev_ms(ix->ev[6], ix->ev[7]);
+  } else R->ms_search = R->ms_search_flat;
   R->ms_cap = ms_cap;
   R->cap_queries_device = dev_jobs.size();
   R->cap_queries_host = cs.looked_at;

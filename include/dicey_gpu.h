@@ -114,6 +114,8 @@ typedef struct {
   uint32_t flags;            /* ABI 5: DG_HUNT_* */
 } dg_hunt_params;
 #define DG_HUNT_COMPACT 1u   /* results in compact form (below): what the host needs to rebuild every DnaHit, nothing it already has */
+#define DG_HUNT_PHASE_TIMES 2u /* measure ms_select / ms_locate / ms_verify too (HIP events between the stages: a few microseconds of
+                                * stream markers per batch); ms_total and ms_search_flat are always measured */
 
 /* per-query flag bits */
 #define DG_Q_TOO_SHORT 1u     /* < 10 nt: "Error: Input sequence is shorter than 10 nucleotides!" (hunter.h:299-303) */

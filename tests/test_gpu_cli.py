@@ -170,3 +170,24 @@ def test_large_input_runs_chunks_in_a_pipeline(cli_genome):
     pick = list(range(0, 50)) + list(range(131050, 131100)) + list(range(269950, 270000))
     want = _oracle_json(g, [qs[i] for i in pick], ["m%d" % i for i in pick], distance=1).split("\n")
     assert [lines[i] for i in pick] == want[:-1]
+
+
+def test_chunks_refused_for_their_size_are_answered_in_halves_and_none_is_dropped(cli_genome):
+    """r03 advice: a chunk the library refuses with DG_ELIMIT (its capped neighbourhoods would not fit the memory budget) is answered
+    in halves by the blocking call — and the chunks BEHIND it must still be submitted.  Three chunks of cap-prone queries (-x 50: every
+    20-mer's 145-string neighbourhood reaches the cap) under a 1 MB budget: every chunk is refused, every query must be answered."""
+    g = cli_genome
+    base = make_queries(19, g["text"], 2000, (20,))
+    qs = (base * 140)[:270000]
+    fa = g["dir"] / "capped_many.fa"
+    with open(fa, "w") as f:
+        for i, s in enumerate(qs):
+            f.write(">c%d\n%s\n" % (i, s))
+    env = dict(os.environ, DICEY_KMER_K="9", DICEY_CAP_BUDGET_MB="1")
+    r = subprocess.run([DICEY, "hunt", "-x", "50", "-g", g["fa"], str(fa)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.split("\n")
+    assert len(lines) == len(qs) + 1 and lines[-1] == ""
+    pick = list(range(0, 30)) + list(range(131060, 131090)) + list(range(269970, 270000))
+    want = _oracle_json(g, [qs[i] for i in pick], ["c%d" % i for i in pick], distance=1, max_neighborhood=50).split("\n")
+    assert [lines[i] for i in pick] == want[:-1]

@@ -49,6 +49,8 @@ t = {"workload": f"{m.group(1)}x{m.group(2)}mer_d{m.group(3)}_n3100000000_{gen}"
      "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
      "hbm_bytes_per_launch": fetch / cal["factor"] + write, "fetch_size_calibration": cal,
      "tcc": {"hit": means.get((ks, "TCC_HIT_sum")), "miss": means.get((ks, "TCC_MISS_sum")), "ea_rdreq": means.get((ks, "TCC_EA0_RDREQ_sum")),
-             "req": means.get((ks, "TCC_REQ_sum"))}}
+             "req": means.get((ks, "TCC_REQ_sum")), "ea_rdreq_32B": means.get((ks, "TCC_EA0_RDREQ_32B_sum")),
+             "ea_rdreq_dram": means.get((ks, "TCC_EA0_RDREQ_DRAM_sum")), "ea_wrreq": means.get((ks, "TCC_EA0_WRREQ_sum"))},
+     "distinct_batches": bench["config"].get("distinct_batches")}
 json.dump(t, open(os.path.join(OUT, "traffic_k_search.json"), "w"), indent=1)
 print(json.dumps(t)[:600])

@@ -344,6 +344,10 @@ def main():
                     help="N > 1, hunt configs: weak = every rank searches its own --queries per step (the default, what the driver's scaling "
                          "run measures); strong = the N ranks share ONE batch of --queries by contiguous ranges (shard_range), e.g. "
                          "--config hunt_d2 --queries 10000000 --scaling strong for BASELINE configs[3]")
+    ap.add_argument("--gather-single", action="store_true",
+                    help="testing aid for a 1-GPU box: a process group of ONE rank on the chosen backend, and every hunt step stages and "
+                         "gathers its hit list exactly as ranks of an N > 1 job do (the RCCL path: staging on the library's stream, the "
+                         "size agreement, the gather) — n_gpus stays 1")
     ap.add_argument("--batches", type=int, default=16,
                     help="hunt configs: distinct query batches resident in HBM that the warm-up and timed steps cycle through (step k "
                          "searches batch k mod B; hunter.h:291 searches every query once, so the headline never replays a batch within "
@@ -387,7 +391,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if a.gather_single and world == 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+    if world > 1 or a.gather_single:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -551,7 +561,7 @@ def main():
             bq, bo, bbytes = dev_batches[rot["k"] % len(dev_batches)] if rot["on"] else dev_batches[0]
             rot["k"] += 1
             if nq == 0:  # strong scaling: a rank behind the end of the batch still takes part in every gather
-                if world > 1 and not fetch:
+                if (world > 1 or a.gather_single) and not fetch:
                     gather_parts([torch.empty(0, dtype=torch.uint8, device=dev)])
                 return {k_: 0 for k_ in ("nhits", "ext", "leaves", "sa", "win", "tab", "probe", "ops_per_hit", "ms_total", "ms_search",
                                          "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns")}
@@ -563,7 +573,7 @@ def main():
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
                    "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns}
-            if world > 1 and not fetch:
+            if (world > 1 or a.gather_single) and not fetch:
                 if R.compact:  # ABI 5 records: position, packed word, d operation words = 12 bytes per hit at distance 1
                     parts = [device_bytes(R.d_hits, R.nhits * 4 * (2 + R.ops_per_hit), dev)]
                 else:
@@ -1041,8 +1051,10 @@ def main():
         out["index"] = {"n": st["n"], "file_bytes": st["file_bytes"], "hbm_bytes": st["hbm_bytes"],
                         "load_s": st["load_seconds"], "derive_s": st["derive_seconds"]}
         out["setup_s"] = info
-        if world > 1:
+        if world > 1 or a.gather_single:
             out["gathered_bytes_per_step"] = gathered / max(1, a.steps)
+            if pipe["g"] is not None:
+                out["gather_bytes_moved_per_step"] = pipe["g"].bytes_moved / max(1, a.steps + max(a.warmup, 1))
     for h in shared[1:]:
         h.close()
     if th is not None:
@@ -1087,7 +1099,7 @@ def main():
                 os.remove(f)
             except OSError:
                 pass
-    if world > 1:
+    if world > 1 or a.gather_single:
         dist.destroy_process_group()
 
 

@@ -817,7 +817,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       if (b.fast2K) {  // edit distance 2: one workgroup per (query, strand) for every query that qualifies
-        hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, std::getenv("DICEY_EXP_COPY_P1") ? 0u : 1u);
+        hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       // edit distance 2: the walker (k_search) only serves the groups k_search2p does not take (N in the query, above 30 nt); it is

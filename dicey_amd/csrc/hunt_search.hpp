@@ -878,7 +878,7 @@ DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... ho
   p2 = (u32)a + 1;
   p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
 }
-__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o, u32 copy_by_second) {
+__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o) {
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
   // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
@@ -925,13 +925,9 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
           u32 l1, w1;
           apply_edit(qpk, m, p1, op1, s1, l1, w1);
           const u32 posp = ins1 ? p1 : p1 - 1;  // characters left of the first operation
-          // r04: the copy of the filter is picked by the SECOND operation's position — the eight probes of the inner loop differ in
-          // that operation, so with its position inside the line's field the three substitutions share a line, the four
-          // insertions another (picked by the first operation's position, every one of the eight had a line of its own
-          // whenever the two positions lie in different fields)
-          const u32 R2 = l1 - p2;
-          const KfCopy cc2 = copy_by_second ? kf_copy(f.kf2, R2 < K2 ? R2 : (K2 ? K2 - 1 : 0u)) : c2;
-          const KfCopy cc1 = copy_by_second ? kf_copy(f.kf, R2 < K ? R2 : K - 1) : c1;
+          // (r04 measured the copy of the filter picked by the SECOND operation's position instead — the inner loop's eight probes then
+          //  share three lines: 161 M instead of 175 M fabric reads per launch, but the L2 hits between neighbouring lanes' probes go
+          //  (175 M -> 46 M) and the kernel takes 8.93 instead of 8.20 ms; profiles/r04_d2b_pmc_summary.csv.  Not kept.)
           u32 mask8 = 0;
           // all addresses first, then the eight loads back to back, then the bits
           const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
@@ -948,8 +944,8 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
             const bool use2 = K2 && l2 >= K2;
             const bool pr = v2 && (use2 || f.kf.nr);
             KfCopy c;
-            c.base = use2 ? cc2.base : cc1.base;
-            c.s = use2 ? cc2.s : cc1.s;
+            c.base = use2 ? c2.base : c1.base;
+            c.s = use2 ? c2.s : c1.s;
             const u32* a = kf_word(c, use2 ? s2 & mask2 : s2 & kmask, bit[op2]);
             addr[op2] = pr ? a : idle;
             valid |= (u32)v2 << op2;

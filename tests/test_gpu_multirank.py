@@ -43,6 +43,27 @@ def test_bench_gpus2_spawns_ranks_and_gathers_hit_lists(tmp_path, batches):
         assert abs(out["gathered_bytes_per_step"] - total) < 1e-6 * total + 1  # the same queries every step
 
 
+def test_bench_rccl_gather_path_with_one_rank(tmp_path):
+    """The RCCL form of the gather as bench.py drives it at N > 1 — compact records staged on the library's own stream
+    (dg_index_stream as a torch ExternalStream), the asynchronous size agreement, the gather one step behind — with a process group
+    of one rank on the `nccl` backend (two ranks cannot share the one GPU of this box under RCCL)."""
+    dump = str(tmp_path / "gather1")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gather-single", "--backend", "nccl", "--genome-size", "2e6", "--queries", "2000",
+           "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-extra-configs", "--batches", "3", "--dump-gather", dump]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["gathered_bytes_per_step"] > 0
+    local = open(os.path.join(dump, "local_0.bin"), "rb").read()
+    got = open(os.path.join(dump, "gathered_0.bin"), "rb").read()
+    assert local and got == local
+    # what travelled is the payload's 64 KiB size class, not a capacity
+    assert out["gather_bytes_moved_per_step"] <= out["gathered_bytes_per_step"] + 65536 + 8
+
+
 def test_cli_shards_a_batch_over_dicey_devices(tmp_path):
     """`dicey hunt` with DICEY_DEVICES=0,0,0: three host threads, three index replicas, contiguous query shards
     (SURVEY.md 8(e)); stdout and the gz outfile must be byte-identical to the single-device run, capped queries included"""

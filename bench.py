@@ -510,16 +510,13 @@ def main():
             nbytes = sum(int(t.numel()) for t in parts)
             pipe["g"] = PipelinedGather(int(nbytes * 1.5) + 65536,  # a bound, not what travels: the gather moves each step's agreed payload size
                                         dev if a.backend == "nccl" else torch.device("cpu"))
-        # staged on the library's own stream (dg_index_stream): the copies out of its result buffers are ordered in front of the
-        # next batch's kernels by the stream itself — no host synchronisation per step (r03 synchronised torch's stream here)
-        if pipe.get("ext") is None and a.backend == "nccl":
-            pipe["ext"] = torch.cuda.ExternalStream(int(L.dg_index_stream(ix.handle)), device=dev)
-        if pipe.get("ext") is not None:
-            with torch.cuda.stream(pipe["ext"]):
-                pipe["g"].submit(parts)
-        else:
-            pipe["g"].submit(parts)
-            torch.cuda.current_stream().synchronize()
+        # The staging copies read the library's result buffers, which its next batch overwrites: they must be done before the next
+        # dg_hunt_device.  torch's stream is synchronised for that (the copies are the only work on it: a few microseconds).  Staging
+        # on the library's own stream (dg_index_stream as a torch ExternalStream) would need no host synchronisation, but torch's wheel
+        # brings its own HIP runtime and a stream handle of the system runtime behind libdiceygpu is not a stream to it (r04: the
+        # process dies); a C++ host that links one runtime can do it.
+        pipe["g"].submit(parts)
+        torch.cuda.current_stream().synchronize()
         if a.dump_gather:
             pipe["last_local"] = torch.cat([t.reshape(-1) for t in parts]).cpu().numpy().tobytes()
 

@@ -89,6 +89,12 @@ struct FmView {
   // SA[b * 8^j, min(n, (b+1) * 8^j)), j = 1..nlev-1; every level is padded with 0xFFFFFFFF to a multiple of eight entries
   // (+8), so the eight children of a block are two 16-byte loads.  k_locate_topk walks it to take the smallest positions of a
   // repeat-rich interval without reading the interval (hunter.h:355-357 keeps the first max_locations of the sorted list).
+  // Preceding characters (derived at load with the K-mer table, r04): pre5[i] = the five text characters in front of suffix SA[i],
+  // three bits each (bits 0-2: T[SA[i]-1], bits 3-5: T[SA[i]-2], ...; 0..3 = A,C,G,T, 7 = anything else or before the text).  A
+  // string of K + r characters (r <= 5) whose last K characters have the table interval [lo, hi) occurs exactly at SA[i] - r for
+  // the i in [lo, hi) whose entry spells its first r characters: ONE line of this array instead of r dependent Occ lines when the
+  // interval is narrow (k_search1s).  nullptr = not built.
+  const u16* pre5;
   static constexpr u32 MAXLEV = 10;
   const u32* samin[MAXLEV];
   u32 nlev;  // levels present, including level 0; 0 = no hierarchy

@@ -28,11 +28,13 @@ struct LocJobs {
 static constexpr u32 LOC_SMALL_MAX = 256;
 // A string with up to N occurrences: N loads in flight, a bitonic network on registers (every index is a compile-time constant —
 // r02's insertion sort indexed a private array dynamically, i.e. through scratch memory), `take` stores.
+// mask / back: the filtered form of a kept string (Sel, r04) — only the suffixes whose bit is set count, and the string starts
+// `back` characters in front of them; mask = all ones, back = 0 for an ordinary interval
 template <int N>
-DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out, u32 g, u32 len, u32 slot) {
+DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out, u32 g, u32 len, u32 slot, u32 mask, u32 back) {
   u32 v[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = (u32)i < occs ? sa[i] : 0xFFFFFFFFu;
+  for (int i = 0; i < N; ++i) v[i] = ((u32)i < occs && ((mask >> i) & 1u)) ? sa[i] - back : 0xFFFFFFFFu;
 #pragma unroll
   for (int k = 2; k <= N; k <<= 1)
 #pragma unroll
@@ -79,21 +81,22 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
   if (have) {
     const u32 take = S.take;
     if (take) {
-      const u32 lo = S.lo, occs = S.hi - S.lo;
+      const u32 lo = S.lo, occs = S.hi - S.lo;  // suffixes to read (a filtered interval holds <= 16 and keeps those in its mask)
+      const u32 fmask = sel_filtered(S) ? sel_mask(S) : 0xFFFFFFFFu, back = sel_filtered(S) ? sel_pre(S) : 0u, slen = sel_strlen(S);
       const u64 out0 = hit_off[g >> 1] + S.hbase;
       HitSeed* out = seeds + out0;
       if (occs <= 4) {
-        locate_in_registers<4>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
+        locate_in_registers<4>(f.sa + lo, occs, take, out, g, slen, (u32)t, fmask, back);
         reads += occs;
       } else if (occs <= 16) {
-        locate_in_registers<16>(f.sa + lo, occs, take, out, g, S.len, (u32)t);
+        locate_in_registers<16>(f.sa + lo, occs, take, out, g, slen, (u32)t, fmask, back);
         reads += occs;
       } else if (jobs.big && take <= 16384) {
         bj.lo = lo;
         bj.occs = occs;
         bj.take = take;
         bj.g = g;
-        bj.len = S.len;
+        bj.len = slen;
         bj.slot = (u32)t;
         bj.out = out0;
         queue = occs <= LOC_SMALL_MAX ? 1u : 2u;
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
         bj.occs = occs;
         bj.take = take;
         bj.g = g;
-        bj.len = S.len;
+        bj.len = slen;
         bj.slot = (u32)t;
         bj.out = out0;
         queue = 3u;  // served by this lane, below

@@ -17,11 +17,27 @@ struct Leaf {
 
 struct Sel {  // a kept neighbourhood string, in search order
   u32 lo, hi;
-  u32 len;    // string length
+  u32 len;    // string length (bits 0-7); r04 filtered form (bit 11): [lo, hi) is the interval of the string's LAST len - pre characters,
+              // pre = bits 8-10, and bits 16-31 say which of its <= 16 suffixes are preceded by the first pre characters (sel_* below)
   u32 take;   // how many of its occurrences become hits
   u32 hbase;  // first hit slot, relative to the query's first hit
   u32 g;      // 2*query + strand (set for the strings of the flat region, where no leaf record names the group)
 };
+
+DG_HD u32 sel_len_filtered(u32 len, u32 pre, u32 mask) { return (len & 255u) | ((pre & 7u) << 8) | (1u << 11) | (mask << 16); }
+DG_HD bool sel_filtered(const Sel& s) { return (s.len & (1u << 11)) != 0; }
+DG_HD u32 sel_strlen(const Sel& s) { return s.len & 255u; }
+DG_HD u32 sel_pre(const Sel& s) { return (s.len >> 8) & 7u; }
+DG_HD u32 sel_mask(const Sel& s) { return s.len >> 16; }
+DG_HD u64 sel_occ(const Sel& s) {  // occurrences of the string (sdsl::count)
+  if (!sel_filtered(s)) return (u64)s.hi - s.lo;
+  u32 m = sel_mask(s), c = 0;
+  while (m) {
+    m &= m - 1;
+    ++c;
+  }
+  return c;
+}
 
 // Largest number of distinct strings neighbors() can hold for a query of length m with nN letters outside A/C/G/T (they
 // are 'N' after replaceNonDna and can be substituted by all four bases instead of three); used to prove that the
@@ -501,7 +517,7 @@ struct FlatSel {
 // freed slots can be taken by new workgroups.
 static constexpr u32 FUSED_LCAP = 512;   // largest LDS list
 static constexpr u32 FUSED_QCAP = 512;   // survivor queue entries per round
-static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u); }
+static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u + 2u); }
 // TAKE (r04): the workgroup also does k_take's work for its own queries (the occurrences of a query's kept strings in push order:
 // take = what hunter.h:349-357 still accepts, a saturating prefix sum) — k_take, 12 us of a 0.34 ms step, is not launched.  Used
 // when the whole batch is on the flat path (no generic kernels); gpw is even then, so that both strands of a query sit in one
@@ -523,6 +539,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
   u16* const l_meta = reinterpret_cast<u16*>(l_hi + lcap);  // length | local group << 6 | alive << 15
   u16* const l_pos = l_meta + lcap;
   u16* const l_ord = l_pos + lcap;
+  u16* const l_mask = l_ord + lcap;  // filtered intervals (FmView::pre5): which entries of [lo, hi) spell the string's first characters
   constexpr u32 NOPS = INDEL ? 8u : 4u;
   if (threadIdx.x == 0) {
     q_n = 0;
@@ -610,6 +627,26 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
         }
         u64 rs = s_pk >> (2 * K);
         u32 n = mlen - K;
+        // r04: a narrow table interval (<= 16 suffixes, the usual case on a genome without repeats) is not extended character by
+        // character — mlen - K dependent Occ lines — but FILTERED: the entries of FmView::pre5 say which of its suffixes are
+        // preceded by the string's first mlen - K characters (one line, two when the interval straddles); the string then
+        // occurs at SA[i] - (mlen - K) for exactly those i, and travels as (interval, mask) instead of its own interval
+        u32 fmask = 0, fpre = 0;
+        if (to_lds && f.pre5 && n >= 1 && n <= 5 && lo < hi && hi - lo <= 16) {
+          const u32 w = hi - lo;
+          u32 want = 0;
+          for (u32 k2 = 0; k2 < n; ++k2) want |= ((u32)(rs >> (2 * k2)) & 3u) << (3 * k2);
+          const u32 wmask = (1u << (3 * n)) - 1u;
+          u32 ent16[16];
+#pragma unroll
+          for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
+#pragma unroll
+          for (u32 j = 0; j < 16; ++j) fmask |= (u32)((ent16[j] & wmask) == want && j < w) << j;
+          ++nlook;
+          fpre = n;
+          n = 0;
+          if (!fmask) lo = hi = 0;
+        }
         while (n && lo < hi) {
           bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
           rs >>= 2;
@@ -623,7 +660,8 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
               l_key[at] = s_pk;
               l_lo[at] = lo;
               l_hi[at] = hi;
-              l_meta[at] = (u16)(mlen | (lg << 6));
+              l_meta[at] = (u16)(mlen | (lg << 6) | (fpre << 10) | (fpre ? 0x2000u : 0u));
+              l_mask[at] = (u16)fmask;
             }
           } else {
             const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
@@ -737,7 +775,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       l_meta[i] = (u16)(meta | 0x8000u);
       atomicAdd(&g_alive[lg], 1u);
       if (TAKE) {
-        const u64 occ = (u64)l_hi[i] - l_lo[i];
+        const u64 occ = (meta & 0x2000u) ? (u64)__popc((u32)l_mask[i]) : (u64)l_hi[i] - l_lo[i];
         atomicAdd(&g_occ[lg], (unsigned long long)(occ < b.max_locations ? occ : b.max_locations));
       }
     }
@@ -774,7 +812,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       const bool first = (xk < ak) || (xk == ak && xlen < alen);
       r += first;
       if (TAKE && first) {
-        const u64 occ = (u64)l_hi[x] - l_lo[x];
+        const u64 occ = (xm & 0x2000u) ? (u64)__popc((u32)l_mask[x]) : (u64)l_hi[x] - l_lo[x];
         before += occ < b.max_locations ? occ : b.max_locations;
       }
     }
@@ -782,11 +820,11 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       Sel sv;
       sv.lo = l_lo[i];
       sv.hi = l_hi[i];
-      sv.len = alen;
+      sv.len = (meta & 0x2000u) ? sel_len_filtered(alen, (meta >> 10) & 7u, (u32)l_mask[i]) : alen;
       sv.take = 0;
       sv.hbase = 0;
       if (TAKE) {  // hunter.h:349-357: strings are located in set order, forward strand first, while hits < max_locations
-        const u64 M = b.max_locations, occ = (u64)sv.hi - sv.lo;
+        const u64 M = b.max_locations, occ = sel_occ(sv);
         const u64 h0 = before < M ? before : M, h1 = before + occ < M ? before + occ : M;
         sv.hbase = (u32)h0;
         sv.take = (u32)(h1 - h0);

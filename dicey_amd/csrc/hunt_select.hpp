@@ -503,7 +503,7 @@ __global__ void k_take(Batch b, const u64* grp_off, const u32* selbase, u64 flat
     if (!ns) continue;  // (grp_off is not even computed when the generic kernels were left out)
     Sel* S = sel + sel_base_of(selbase, grp_off, flat_slots, 2 * q + strand);
     for (u32 r = 0; r < ns; ++r) {
-      u64 occs = (u64)S[r].hi - S[r].lo;
+      u64 occs = sel_occ(S[r]);
       u64 take = 0;
       if (hits < b.max_locations) take = occs < b.max_locations - hits ? occs : b.max_locations - hits;
       S[r].take = (u32)take;
@@ -528,7 +528,7 @@ __global__ void k_group_count(const u64* grp_off, const u32* selbase, u64 flat_s
   if (!ctr->overflow) {
     const u32 ns = nsel[g];
     const Sel* S = ns ? sel + sel_base_of(selbase, grp_off, flat_slots, g) : sel;
-    for (u32 r = 0; r < ns; ++r) sum += (u64)S[r].hi - S[r].lo;
+    for (u32 r = 0; r < ns; ++r) sum += sel_occ(S[r]);
   }
   out[g] = sum;
 }

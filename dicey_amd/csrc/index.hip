@@ -424,6 +424,24 @@ __global__ void __launch_bounds__(256) k_kmer_table_wave(FmView f, uint2* tab, u
   if (kf2 && !(me2 >> 63) && (lane == 0 || prev2 != me2)) atomicOr(&kf2[me2 >> 5], 1u << (me2 & 31));
 }
 
+// FmView::pre5: the five characters in front of every suffix, in suffix-array order (one text gather per lane)
+__global__ void __launch_bounds__(256) k_pre5(const u32* sa, const u8* text, u64 n, u16* out) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 p = sa[i];
+  u32 v = 0;
+#pragma unroll
+  for (u32 k = 1; k <= 5; ++k) {
+    u32 c = 7u;
+    if (p >= k) {
+      const u32 b = text[p - k];
+      c = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 7u;
+    }
+    v |= c << (3 * (k - 1));
+  }
+  out[i] = (u16)v;
+}
+
 // Block minima of the suffix array, fan-out 8 (FmView::samin): one lane per block, two 16-byte loads.
 __global__ void __launch_bounds__(256) k_block_min8(const u32* in, u64 n_in, u32* out, u64 n_out, u64 n_out_padded) {
   const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -595,6 +613,19 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
     if (K2) {
       DG_TRY(build_filter(ix, f.kf2, K2, nullptr, f2));
       pc.lap("long presence filter");
+    }
+    // the characters in front of every suffix (2 n bytes): built with the table, i.e. for handles that search batches
+    if (!std::getenv("DICEY_NO_PRE5")) {
+      u16* pre = nullptr;
+      if (big_alloc((void**)&pre, n * 2 + 64, ix->stream) == hipSuccess) {
+        ix->owned.push_back(pre);
+        ix->hbm_bytes += n * 2 + 64;
+        hipLaunchKernelGGL(k_pre5, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, (const u32*)sa, (const u8*)text, n, pre);
+        DG_HIP(hipStreamSynchronize(ix->stream));
+        DG_HIP(hipGetLastError());
+        f.pre5 = pre;
+        pc.lap("preceding characters");
+      } else (void)hipGetLastError();
     }
   }
   // block minima over the suffix array for the top-k locate (0.57 n bytes; one streaming pass over SA)

@@ -298,7 +298,7 @@ def test_flat_distance_two_kernel(gpu_small, small_genome, monkeypatch):
 # through the same matrix as the default
 SWITCHES = {"nofuse": {"DICEY_NO_FUSED_SELECT": "1"}, "noband": {"DICEY_NO_BAND_VERIFY": "1"}, "classic": {"DICEY_CLASSIC_RESULTS": "1"},
             "ch4": {"DICEY_VERIFY_CH": "4"}, "ch8": {"DICEY_VERIFY_CH": "8"}, "caps": {"DICEY_DEBUG_CAPS": "3"},
-            "lcap2": {"DICEY_FUSED_LCAP": "2"}, "noprep": {"DICEY_NO_PREP_FUSION": "1"}, "caphost": {"DICEY_CAP_HOST": "1"}, "nominima": {"DICEY_NO_SA_MINIMA": "1"}}
+            "lcap2": {"DICEY_FUSED_LCAP": "2"}, "noprep": {"DICEY_NO_PREP_FUSION": "1"}, "caphost": {"DICEY_CAP_HOST": "1"}, "nominima": {"DICEY_NO_SA_MINIMA": "1"}, "nopre5": {"DICEY_NO_PRE5": "1"}}
 
 
 @pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13", "K9_nolong", "K9_long10", "K10_long14"] + ["K9_long10+" + k for k in SWITCHES])

@@ -815,6 +815,8 @@ def main():
                              "algorithmic_bytes_per_launch": alg_bytes, "ext_steps_per_launch": ext,
                              "bytes_per_ext_step": BYTES_PER_EXT, "table_reads_per_launch": tab,
                              "bytes_per_table_read": BYTES_PER_TAB_READ, "filter_probes_per_launch": probe,
+                             "table_reads_note": "K-mer table entries (8 B) and, since r04, reads of the preceding-characters array (2 B per suffix of a "
+                                                 "narrow interval, <= 32 B) counted together at 8 B each",
                              "bytes_per_filter_probe": BYTES_PER_FILTER_PROBE, "kernel_ms": kernel_ms,
                              "survey_units": {"bytes_per_launch": survey_bytes, "avg_code_len": avg_l,
                                               "achieved": survey_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
@@ -825,6 +827,11 @@ def main():
                              "fabric_reads_per_launch": fabric_reads, "traffic_from_profile_round": traffic_round,
                              "fabric_reads_per_s": (fabric_reads / (kernel_ms * 1e-3)) if (fabric_reads and kernel_ms > 0) else None,
                              "lines_per_strand": (fabric_reads / (2 * nq)) if fabric_reads else None,
+                             # what bounds this kernel: L2-to-fabric requests per second against the chip's measured rate for independent
+                             # random 64-byte lines (gather_reference below, 4 GiB footprint; the byte fraction above is what the contract
+                             # asks for and falls whenever the kernel is taught to need fewer bytes)
+                             "request_rate": ({"fabric_requests_per_s": fabric_reads / (kernel_ms * 1e-3), "reference_requests_per_s": 26.5e9,
+                                               "frac": fabric_reads / (kernel_ms * 1e-3) / 26.5e9} if (fabric_reads and kernel_ms > 0) else None),
                              "index_accesses_per_query": (2 * ext + tab + probe) / nq,
                              "index_accesses_per_s": (2 * ext + tab + probe) / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
                              # the same launch in three conventions, side by side: this build's units (above), SURVEY 8(d)

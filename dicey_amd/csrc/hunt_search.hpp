@@ -17,18 +17,18 @@ struct Leaf {
 
 struct Sel {  // a kept neighbourhood string, in search order
   u32 lo, hi;
-  u32 len;    // string length (bits 0-7); r04 filtered form (bit 11): [lo, hi) is the interval of the string's LAST len - pre characters,
-              // pre = bits 8-10, and bits 16-31 say which of its <= 16 suffixes are preceded by the first pre characters (sel_* below)
+  u32 len;    // string length; r04 filtered form (bit 31 set): bits 0-7 length, [lo, hi) is the interval of the string's LAST len - pre
+              // characters, pre = bits 8-10, and bits 11-26 say which of its <= 16 suffixes are preceded by the first pre characters
   u32 take;   // how many of its occurrences become hits
   u32 hbase;  // first hit slot, relative to the query's first hit
   u32 g;      // 2*query + strand (set for the strings of the flat region, where no leaf record names the group)
 };
 
-DG_HD u32 sel_len_filtered(u32 len, u32 pre, u32 mask) { return (len & 255u) | ((pre & 7u) << 8) | (1u << 11) | (mask << 16); }
-DG_HD bool sel_filtered(const Sel& s) { return (s.len & (1u << 11)) != 0; }
-DG_HD u32 sel_strlen(const Sel& s) { return s.len & 255u; }
+DG_HD u32 sel_len_filtered(u32 len, u32 pre, u32 mask) { return (len & 255u) | ((pre & 7u) << 8) | ((mask & 0xFFFFu) << 11) | (1u << 31); }
+DG_HD bool sel_filtered(const Sel& s) { return (s.len >> 31) != 0; }
+DG_HD u32 sel_strlen(const Sel& s) { return sel_filtered(s) ? (s.len & 255u) : s.len; }  // (an ordinary string may have 30 000 characters)
 DG_HD u32 sel_pre(const Sel& s) { return (s.len >> 8) & 7u; }
-DG_HD u32 sel_mask(const Sel& s) { return s.len >> 16; }
+DG_HD u32 sel_mask(const Sel& s) { return (s.len >> 11) & 0xFFFFu; }
 DG_HD u64 sel_occ(const Sel& s) {  // occurrences of the string (sdsl::count)
   if (!sel_filtered(s)) return (u64)s.hi - s.lo;
   u32 m = sel_mask(s), c = 0;

@@ -492,10 +492,12 @@ def main():
         if pipe["g"] is not None:
             pipe["g"].finish()
             pipe["g"].bytes_received = 0
+            pipe["g"].bytes_moved = 0
         barrier()
         t_start = time.perf_counter()
         acc = [step() for _ in range(a.steps)]
         gathered = pipe["g"].finish() if pipe["g"] is not None else 0  # every gather completes inside the timed region
+        pipe.setdefault("moved", pipe["g"].bytes_moved if pipe["g"] is not None else 0)  # the headline's (later passes gather too)
         barrier()
         elapsed = time.perf_counter() - t_start
         if world > 1:
@@ -1058,7 +1060,7 @@ def main():
         if world > 1 or a.gather_single:
             out["gathered_bytes_per_step"] = gathered / max(1, a.steps)
             if pipe["g"] is not None:
-                out["gather_bytes_moved_per_step"] = pipe["g"].bytes_moved / max(1, a.steps + max(a.warmup, 1))
+                out["gather_bytes_moved_per_step"] = pipe.get("moved", 0) / max(1, a.steps)
     for h in shared[1:]:
         h.close()
     if th is not None:

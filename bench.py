@@ -348,6 +348,9 @@ def main():
                     help="testing aid for a 1-GPU box: a process group of ONE rank on the chosen backend, and every hunt step stages and "
                          "gathers its hit list exactly as ranks of an N > 1 job do (the RCCL path: staging on the library's stream, the "
                          "size agreement, the gather) — n_gpus stays 1")
+    ap.add_argument("--in-flight", type=int, default=2, choices=(1, 2),
+                    help="hunt configs: batches in flight per GPU in the timed region: 2 = dg_hunt_device_submit / dg_hunt_wait on the handle's "
+                         "two lanes (step k is submitted, step k - 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a)")
     ap.add_argument("--batches", type=int, default=16,
                     help="hunt configs: distinct query batches resident in HBM that the warm-up and timed steps cycle through (step k "
                          "searches batch k mod B; hunter.h:291 searches every query once, so the headline never replays a batch within "
@@ -486,9 +489,13 @@ def main():
     shared = [ix]
     th = None
 
-    def timed(step):
+    def timed(step, flush=None):
+        """flush: steps that keep a batch in flight hand in what is outstanding (a list of step results); called behind the warm-up
+        and inside the timed region, so that exactly K batches start and end there"""
         for _ in range(max(a.warmup, 1 if world > 1 else 0)):
             step()
+        if flush:
+            flush()
         if pipe["g"] is not None:
             pipe["g"].finish()
             pipe["g"].bytes_received = 0
@@ -496,6 +503,8 @@ def main():
         barrier()
         t_start = time.perf_counter()
         acc = [step() for _ in range(a.steps)]
+        if flush:
+            acc = [r for r in acc + flush() if r is not None]
         gathered = pipe["g"].finish() if pipe["g"] is not None else 0  # every gather completes inside the timed region
         pipe.setdefault("moved", pipe["g"].bytes_moved if pipe["g"] is not None else 0)  # the headline's (later passes gather too)
         barrier()
@@ -583,7 +592,49 @@ def main():
             L.dg_hunt_result_free(rp)
             return res
 
-        acc, elapsed, gathered = timed(step)
+        # Two batches in flight (r04): step k is handed to one of the handle's two lanes (dg_hunt_device_submit: own stream, workspaces
+        # and helper thread each), then step k - 1 is collected (dg_hunt_wait) and, at N > 1, its records go to the gather.  One
+        # batch's launch-bound tail — locate, verify, the summary's read-back, the host's turn-around — runs beside the next
+        # batch's search kernel; every batch is still one complete pass of the path, and all K start and end inside the timed region.
+        inflight = []
+
+        def collect(tk):
+            rp = C.POINTER(_capi.HuntResult)()
+            _capi.check(L, L.dg_hunt_wait(tk, C.byref(rp)))
+            R = rp.contents
+            res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes,
+                   "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
+                   "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
+                   "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns}
+            if world > 1 or a.gather_single:
+                # the lane that ran this batch stays idle until the next step's submit: its result buffers are staged before that
+                gather_parts([device_bytes(R.d_hits, R.nhits * 4 * (2 + R.ops_per_hit), dev)] if R.compact else
+                             [device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), dev)] +
+                             ([device_bytes(R.d_ops, R.nhits * R.ops_per_hit * 4, dev)] if R.ops_per_hit and R.nhits else []))
+            L.dg_hunt_result_free(rp)
+            return res
+
+        def step_pipe():
+            if nq == 0:
+                return step()
+            bq, bo, bbytes = dev_batches[rot["k"] % len(dev_batches)]
+            rot["k"] += 1
+            tk = C.c_void_p()
+            _capi.check(L, L.dg_hunt_device_submit(ix.handle, C.byref(p_compact), sl, len(seqlen), C.c_void_p(bq.data_ptr()), C.c_void_p(bo.data_ptr()),
+                                                   nq, bbytes, 0, C.byref(tk)))
+            inflight.append(tk)
+            return collect(inflight.pop(0)) if len(inflight) > 1 else None
+
+        def flush_pipe():
+            out_ = []
+            while inflight:
+                out_.append(collect(inflight.pop(0)))
+            return out_
+
+        if a.in_flight == 2:
+            acc, elapsed, gathered = timed(step_pipe, flush_pipe)
+        else:
+            acc, elapsed, gathered = timed(step)
         # the stages' times (HIP events between the kernels, DG_HUNT_PHASE_TIMES) are taken in a pass of their own behind the timed
         # region: every event record is a marker packet in the stream, and the timed steps run without them (the batch total and the
         # search kernel's own time — what roofline.kernel_ms is — are measured in every step)
@@ -623,6 +674,18 @@ def main():
                                           "note": "the r01-r03 measurement: one batch replayed K times (its 310 MB of index lines are "
                                                   "re-read every step); the headline cycles through %d distinct batches" % len(dev_batches)}
             rot["on"] = True
+        if world == 1 and a.in_flight == 2:
+            # the r01-r04a form beside the headline: one batch at a time through dg_hunt_device (rotating batches)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            acc_one = [step() for _ in range(a.steps)]
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - tp
+            extras["value_one_in_flight"] = {"value": nq * a.steps / dts, "unit": "primers/s", "ms_per_step": dts / a.steps * 1e3,
+                                             "kernel_ms": float(np.mean([r["ms_search_flat"] for r in acc_one])),
+                                             "note": "dg_hunt_device, one batch at a time: the kernel's duration without another lane's kernels beside it"}
         pipelined = None
         if world == 1 and not a.no_extras:
             for _ in range(2):
@@ -777,7 +840,10 @@ def main():
             flat = mean("ms_search_flat")
             # distance 1: k_search1s = the flat search with the select stage inside (r03); DICEY_NO_FUSED_SELECT gives k_search1p
             k1 = "k_search1p<true>" if os.environ.get("DICEY_NO_FUSED_SELECT") else "k_search1s<true, true>"
-            kernel = (k1 if distance == 1 else "k_search2p") if flat > 0 else f"k_search<true,{distance}>"
+            # distance 2: k_search2p with the select stage inside (r04), whole batch on the flat path = the per-query form <true, true>
+            k2 = ("k_search2p<false, false>" if (os.environ.get("DICEY_NO_FUSED_SELECT") or os.environ.get("DICEY_NO_FUSED_SELECT2"))
+                  else "k_search2p<true, true>")
+            kernel = (k1 if distance == 1 else k2) if flat > 0 else f"k_search<true,{distance}>"
             kernel_ms = flat if flat > 0 else (float(np.mean([r["ms_search"] for r in acc_ph])) if acc_ph else mean("ms_search"))
             alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
             # the same launch in SURVEY.md §8(d) units: a backward step on c = 2 L(c) rank ops of 24 B on the sdsl layout
@@ -810,6 +876,9 @@ def main():
                            "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
                            "distinct_batches": len(dev_batches),
                            "results": "compact records (DG_HUNT_COMPACT: 8 + 4 d bytes per hit) left in HBM (N = 1) / gathered to rank 0 (N > 1)",
+                           "in_flight": (f"{a.in_flight} batches per GPU (dg_hunt_device_submit / dg_hunt_wait on the handle's two lanes: step k is submitted, "
+                                         "then step k - 1 collected; K batches start and end inside the timed region)" if a.in_flight == 2
+                                         else "1 batch per GPU (dg_hunt_device)"),
                            "stream": f"step k searches batch k mod {len(dev_batches)} of {len(dev_batches)} distinct batches resident in HBM "
                                      "(seeds 42 + 1000 b), warm-up included" if len(dev_batches) > 1 else "one batch replayed every step"},
                 "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1049,6 +1118,7 @@ def main():
     # ---------------- common tail
     if a.dump_gather and pipe["g"] is not None:
         os.makedirs(a.dump_gather, exist_ok=True)
+        pipe["g"].finish()  # the passes behind the timed region gathered too: what is compared is the last payload every rank staged
         open(os.path.join(a.dump_gather, f"local_{rank}.bin"), "wb").write(pipe.get("last_local", b""))
         if rank == 0:
             for r, payload in enumerate(pipe["g"].last_received()):

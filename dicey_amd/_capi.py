@@ -95,7 +95,7 @@ SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_
            "dg_index_build_device", "dg_last_error", "dg_abi_version", "dg_device_count",
            "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
            "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free", "dg_index_share",
-           "dg_neighbors", "dg_buffer_free", "dg_hit_rows", "dg_hunt_rows", "dg_hunt_submit", "dg_hunt_wait",
+           "dg_neighbors", "dg_buffer_free", "dg_hit_rows", "dg_hunt_rows", "dg_hunt_submit", "dg_hunt_wait", "dg_hunt_device_submit",
            "dg_chit_unpack", "dg_normalize_query", "dg_hunt_expand", "dg_index_stream"]
 
 _lib = None
@@ -144,6 +144,7 @@ def load(path=None):
     L.dg_hunt_rows.argtypes = [C.POINTER(HuntResult)]
     L.dg_hunt_submit.argtypes = [vp, C.POINTER(HuntParams), u32p, C.c_uint32, C.c_char_p, u64p, C.c_size_t, C.POINTER(vp)]
     L.dg_hunt_wait.argtypes = [vp, C.POINTER(C.POINTER(HuntResult))]
+    L.dg_hunt_device_submit.argtypes = [vp, C.POINTER(HuntParams), u32p, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(vp)]
     L.dg_chit_unpack.argtypes = [C.POINTER(HuntResult), C.c_uint64, C.c_uint32, C.POINTER(Hit), C.POINTER(u32p)]
     L.dg_normalize_query.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, u32p]
     L.dg_hunt_expand.argtypes = [C.POINTER(HuntResult), C.c_char_p, u64p]

@@ -740,7 +740,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     // DICEY_NO_FUSED_SELECT: the search without the select stage (k_search1p + the generic select kernels) — what batches with
     // strings above 42 characters take anyway; the GPU tests run every distance-1 case both ways
     const bool no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr;
-    const bool fused = b.fastK && packed && !no_fuse;
+    // r04: the same at edit distance 2 (k_search2p<true, .>: one workgroup per group or per query); DICEY_NO_FUSED_SELECT2 keeps the
+    // generic select kernels for that distance only
+    const bool fused = (b.fastK || (b.fast2K && !std::getenv("DICEY_NO_FUSED_SELECT2"))) && packed && !no_fuse;
     const u32 flat_cap = fused ? flat_req : 0u;
     const u64 flat_slots = (u64)NSHARD * flat_cap;
     const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
@@ -817,7 +819,20 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       if (b.fast2K) {  // edit distance 2: one workgroup per (query, strand) for every query that qualifies
-        hipLaunchKernelGGL(k_search2p, dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so);
+        // filtered leaves only where the packed select path (k_group_pack) hands the filter word on
+        const u32 filt_ok = (u32)(packed && !getenv("DICEY_NO_PRE5_D2"));
+        FlatSel fs;
+        fs.sel = sel_all;
+        fs.cap = flat_cap;
+        fs.selbase = selbase;
+        fs.nsel = nsel;
+        PrepOut po;
+        po.qhits = qhits;
+        // (tests: DICEY_FUSED_LCAP lowers the list's capacity so that ordinary groups exercise the hand-over to the generic select kernels)
+        const u32 lcap2 = std::getenv("DICEY_FUSED_LCAP") ? std::max<u32>(1u, std::min<u32>(FUSED2_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP")))) : FUSED2_LCAP;
+        if (fused && prep_in) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true, true>), dim3((u32)nq), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, po, lcap2);
+        else if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true, false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, po, lcap2);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false, false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, po, lcap2);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       // edit distance 2: the walker (k_search) only serves the groups k_search2p does not take (N in the query, above 30 nt); it is
@@ -853,17 +868,20 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (packed) {
       if (generic_on) {
       u8* alive = ws[WS_SCR].as<u8>();
+      // the leaves' filter words sit behind the packed leaves: the buffer is sized for 36-byte Leaf records, PLeaf takes 32
+      static_assert(sizeof(Leaf) >= sizeof(PLeaf) + sizeof(u32), "room for the filter words");
+      u32* filt = (u32*)((u8*)ws[WS_LEAFG].p + (leaf_slots + 1) * sizeof(PLeaf));
       hipLaunchKernelGGL(k_group_pack, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, b, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr,
-                         grp_off, ws[WS_LEAFG].as<PLeaf>());
+                         grp_off, ws[WS_LEAFG].as<PLeaf>(), filt);
       // distance >= 2: groups of up to SELCAP strings are sorted by a workgroup each, the lane-per-leaf kernels keep the rest
       const u32 above = (dmax_eff >= 2 && ngrp < 0x7FFFFFFFull) ? SELCAP : 0u;
       if (above)
         // (one wavefront per group was tried: 1.95 -> 2.5 ms, the second wavefront's share of the window searches is worth more than the barriers)
-        hipLaunchKernelGGL(k_group_select, dim3((u32)ngrp), dim3(128), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, (u32)indel,
+        hipLaunchKernelGGL(k_group_select, dim3((u32)ngrp), dim3(128), 0, st, ws[WS_LEAFG].as<PLeaf>(), (const u32*)filt, grp_off, (u32)indel,
                            sel_gen, nsel, ctr);
       hipLaunchKernelGGL(k_leaf_alive, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
                          (u32)indel, alive, ctr, above);
-      hipLaunchKernelGGL(k_leaf_rank, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), grp_off, ngrp,
+      hipLaunchKernelGGL(k_leaf_rank, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAFG].as<PLeaf>(), (const u32*)filt, grp_off, ngrp,
                          (const u8*)alive, sel_gen, nsel, ctr, above);
       }
       if (!prep_in)
@@ -1093,7 +1111,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     break;
   }
   ix->shard_cap_hint = shard_cap;
-  if (b.fastK && hsum.worst_sel) ix->flat_cap_hint = (u32)std::max<unsigned long long>(ix->flat_cap_hint, hsum.worst_sel + hsum.worst_sel / 4 + 64);
+  if ((b.fastK || b.fast2K) && hsum.worst_sel) ix->flat_cap_hint = (u32)std::max<unsigned long long>(ix->flat_cap_hint, hsum.worst_sel + hsum.worst_sel / 4 + 64);
   ix->jobs_big_hint = hsum.jobs_big;
   if (b.fastK) ix->fused_leaves_hint = hsum.fused_leaves + nleaf;
   ix->hit_cap_hint = std::max<u64>(ix->hit_cap_hint, nhits + nhits / 4 + 1024);
@@ -1455,11 +1473,18 @@ struct dg_hunt_ticket {
   PinnedBlock* stage = nullptr;  // the queries, copied once at submit: bytes at 0, offsets at off_at
   uint64_t off_at = 0;
   size_t nq = 0;
+  // dg_hunt_device_submit: the queries stay where the caller has them in HBM
+  const void* d_qbytes = nullptr;
+  const void* d_qoff = nullptr;
+  uint64_t total_qbytes = 0;
+  int fetch = 0;
   int rc = DG_OK;
   std::string err;
   dg_hunt_result* res = nullptr;
   bool done = false;
 };
+static int hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
+                       const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out);
 struct dg_index::Worker {
   std::thread th;
   std::mutex mu;
@@ -1478,8 +1503,12 @@ struct dg_index::Worker {
       }
       const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
       const double t_take = tm ? host_us() : 0.0;
-      t->rc = hunt_host(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), (const uint8_t*)t->stage->p,
-                        (const uint64_t*)((const uint8_t*)t->stage->p + t->off_at), t->nq, &t->res, t->stage);
+      if (t->d_qoff)
+        t->rc = hunt_device(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), t->d_qbytes, t->d_qoff, t->nq, t->total_qbytes,
+                            t->fetch, &t->res);
+      else
+        t->rc = hunt_host(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), (const uint8_t*)t->stage->p,
+                          (const uint64_t*)((const uint8_t*)t->stage->p + t->off_at), t->nq, &t->res, t->stage);
       if (t->rc != DG_OK) t->err = dg_last_error();  // the message is thread-local: carried over to the waiting thread
       if (tm) std::fprintf(stderr, "dicey timing: worker %p took its batch at %.0f us, done at %.0f us\n", (void*)t->ix, std::fmod(t_take, 1e8), std::fmod(host_us(), 1e8));
       {
@@ -1502,11 +1531,10 @@ void dg_index::stop_worker() {
   worker = nullptr;
 }
 
-int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
-                   const uint64_t* qoff, size_t nq, dg_hunt_ticket** out) {
-  if (!ix || !p || !seqlen || !qoff || !out || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_hunt_submit: null argument");
-  *out = nullptr;
-  if (!nq) return fail(DG_EINVAL, "dg_hunt_submit: empty batch");
+// dg_hunt_submit / dg_hunt_device_submit: qoff != nullptr = host queries (copied into a pinned block here), else the device form
+static int submit_batch(const char* who, dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
+                        const uint64_t* qoff, const void* d_qbytes, const void* d_qoff, uint64_t total_qbytes, int fetch, size_t nq,
+                        dg_hunt_ticket** out) {
   const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
   const double t_sub = tm ? host_us() : 0.0;
   // two lanes per handle (ABI 5): the handle itself while it is idle, else its internal second lane (a shared handle: own stream,
@@ -1517,7 +1545,7 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     if (!owner->lane2 && dg_index_share(owner, &owner->lane2) != DG_OK) owner->lane2 = nullptr;
     ix = owner->lane2;
     if (!ix || ix->busy.exchange(true))
-      return fail(DG_EINVAL, "dg_hunt_submit: two batches are already in flight on this handle (wait for the older ticket first)");
+      return fail(DG_EINVAL, "%s: two batches are already in flight on this handle (wait for the older ticket first)", who);
   }
   dg_hunt_ticket* t = nullptr;
   try {
@@ -1526,15 +1554,22 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     t->p = *p;
     t->seqlen.assign(seqlen, seqlen + nseq);
     t->nq = nq;
-    t->off_at = (qoff[nq] + 63) & ~63ull;
-    t->stage = pinned_pool().get(t->off_at + (nq + 1) * 8 + 64);  // the caller's buffers are free again when this call returns
-    if (!t->stage) {
-      delete t;
-      ix->busy.store(false);
-      return fail(DG_ENOMEM, "dg_hunt_submit: no pinned memory for %llu query bytes", (unsigned long long)qoff[nq]);
+    if (qoff) {
+      t->off_at = (qoff[nq] + 63) & ~63ull;
+      t->stage = pinned_pool().get(t->off_at + (nq + 1) * 8 + 64);  // the caller's buffers are free again when this call returns
+      if (!t->stage) {
+        delete t;
+        ix->busy.store(false);
+        return fail(DG_ENOMEM, "%s: no pinned memory for %llu query bytes", who, (unsigned long long)qoff[nq]);
+      }
+      if (qoff[nq]) std::memcpy(t->stage->p, qbytes, qoff[nq]);
+      std::memcpy((uint8_t*)t->stage->p + t->off_at, qoff, (nq + 1) * 8);
+    } else {
+      t->d_qbytes = d_qbytes;
+      t->d_qoff = d_qoff;
+      t->total_qbytes = total_qbytes;
+      t->fetch = fetch;
     }
-    if (qoff[nq]) std::memcpy(t->stage->p, qbytes, qoff[nq]);
-    std::memcpy((uint8_t*)t->stage->p + t->off_at, qoff, (nq + 1) * 8);
     if (!ix->worker) {
       dg_index::Worker* w = new dg_index::Worker;
       try {
@@ -1554,11 +1589,27 @@ int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     if (t && t->stage) pinned_pool().put(t->stage);
     delete t;
     ix->busy.store(false);
-    return fail(DG_ENOMEM, "dg_hunt_submit: %s", e.what());
+    return fail(DG_ENOMEM, "%s: %s", who, e.what());
   }
   *out = t;
   if (tm) std::fprintf(stderr, "dicey timing: submit to %p from %.0f to %.0f us\n", (void*)ix, std::fmod(t_sub, 1e8), std::fmod(host_us(), 1e8));
   return DG_OK;
+}
+
+int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
+                   const uint64_t* qoff, size_t nq, dg_hunt_ticket** out) {
+  if (!ix || !p || !seqlen || !qoff || !out || (!qbytes && nq && qoff[nq])) return fail(DG_EINVAL, "dg_hunt_submit: null argument");
+  *out = nullptr;
+  if (!nq) return fail(DG_EINVAL, "dg_hunt_submit: empty batch");
+  return submit_batch("dg_hunt_submit", ix, p, seqlen, nseq, qbytes, qoff, nullptr, nullptr, 0, 0, nq, out);
+}
+
+int dg_hunt_device_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
+                          const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_ticket** out) {
+  if (!ix || !p || !seqlen || !d_qbytes || !d_qoff || !out) return fail(DG_EINVAL, "dg_hunt_device_submit: null argument");
+  *out = nullptr;
+  if (!nq) return fail(DG_EINVAL, "dg_hunt_device_submit: empty batch");
+  return submit_batch("dg_hunt_device_submit", ix, p, seqlen, nseq, nullptr, nullptr, d_qbytes, d_qoff, total_qbytes, fetch, nq, out);
 }
 
 int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out) {
@@ -1701,6 +1752,12 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
   *out = nullptr;
   if (!nq) return fail(DG_EINVAL, "dg_hunt_device: empty batch");
   if (ix->busy.load()) return fail(DG_EINVAL, "dg_hunt_device: a dg_hunt_submit batch is in flight on this handle (dg_hunt_wait first)");
+  return hunt_device(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, fetch, out);
+}
+
+// dg_hunt_device's body (also what a lane's helper thread runs for dg_hunt_device_submit)
+static int hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
+                       const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out) {
   DG_HIP(hipSetDevice(ix->device));
   // Query lengths are needed on the host only to size buffers and to check the supported envelope.  A repeated call with the
   // same offsets buffer, count and byte total reuses the previous maximum as an upper bound instead of reading the offsets
@@ -1738,7 +1795,7 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
     *out = nullptr;
   }
   if (rc != DG_OK && hit) hit->qoff = nullptr;  // whatever went wrong, the next call reads the offsets again
-  if (rc == DG_EINVAL && cached) return dg_hunt_device(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, fetch, out);
+  if (rc == DG_EINVAL && cached) return hunt_device(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, fetch, out);
   return rc;
 }
 

@@ -25,6 +25,8 @@ struct Sel {  // a kept neighbourhood string, in search order
 };
 
 DG_HD u32 sel_len_filtered(u32 len, u32 pre, u32 mask) { return (len & 255u) | ((pre & 7u) << 8) | ((mask & 0xFFFFu) << 11) | (1u << 31); }
+// from a leaf's filter word (mask | characters in front << 16 | 1 << 31, 0 = ordinary interval)
+DG_HD u32 sel_len_from(u32 len, u32 fword) { return (fword >> 31) ? sel_len_filtered(len, (fword >> 16) & 7u, fword & 0xFFFFu) : len; }
 DG_HD bool sel_filtered(const Sel& s) { return (s.len >> 31) != 0; }
 DG_HD u32 sel_strlen(const Sel& s) { return sel_filtered(s) ? (s.len & 255u) : s.len; }  // (an ordinary string may have 30 000 characters)
 DG_HD u32 sel_pre(const Sel& s) { return (s.len >> 8) & 7u; }
@@ -916,7 +918,16 @@ DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... ho
   p2 = (u32)a + 1;
   p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
 }
-__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o) {
+static constexpr u32 FUSED2_LCAP = 512;  // strings of ONE (query, strand) group in LDS (k_search2p<true, .>)
+// SEL (r04): the select stage inside, like k_search1s — the workgroup owns its group anyway, so the group's occurring strings stay in
+// LDS (2-bit packed, with interval and filter word), duplicates / substring-minimal filter / std::set order are settled here and the
+// kept strings go to the flat Sel region; leaves do not travel to HBM, and the scans, k_group_pack, k_group_select, k_leaf_alive and
+// k_leaf_rank (2.4 of the 12.8 ms of a step) have nothing left to do.  A group with more than FUSED2_LCAP occurring strings is searched
+// once more with its leaves written out for the generic select kernels (selbase stays "generic"; the host repeats the batch with
+// them when they were not launched).  TAKE: one workgroup per QUERY, forward strand first, which also settles take / hbase / the
+// query's hit count (k_take's work; whole batch on the flat path).
+template <bool SEL, bool TAKE>
+__global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, PrepOut po, u32 lcap2) {
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
   // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
@@ -925,155 +936,300 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
   __shared__ u32 q_ex[256 + 1];  // exclusive prefix of the lanes' survivor counts, [256] = total
   __shared__ u32 q_wave[4];
   __shared__ u32 g_slots;
-  const u32 gid = blockIdx.x;
-  const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
-  const u32 m = raw.z, d_win = raw.w;
-  if (!m || !(d_win & 1024u)) return;  // uniform for the workgroup
-  const u64 qpk = (u64)raw.y << 32 | raw.x;
-  if (threadIdx.x == 0) g_slots = 0;
-  __syncthreads();
+  constexpr u32 LN = SEL ? FUSED2_LCAP : 1u;
+  __shared__ u64 l_key[LN];
+  __shared__ u32 l_lo[LN], l_hi[LN], l_fw[LN];
+  __shared__ u16 l_meta[LN];  // length (6 bits), 0x8000 = kept
+  __shared__ u32 l_n, s_alive, s_base;
+  __shared__ unsigned long long s_occ[2];
   const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
   const u64 kmask = (1ULL << (2 * K)) - 1, mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
   const u32 lane = threadIdx.x & 63;
-  const u32 npairs = m * (m + 1) / 2 - 1;  // p2 = 1..m-1, p1 = p2..m
   const u32 shard = blockIdx.x & (NSHARD - 1);
   u32 steps = 0, nlook = 0, nprobe = 0;
-  for (u32 w0 = 0; w0 < npairs; w0 += 256) {
-    const u32 w = w0 + threadIdx.x;
-    u64 surv = 0;
-    if (w < npairs) {
-      u32 p1, p2;
-      pair_of(w, m, p2, p1);
-      const u32 R1 = m - p1;
-      const KfCopy c2 = kf_copy(f.kf2, R1 < K2 ? R1 : (K2 ? K2 - 1 : 0u));
-      const KfCopy c1 = kf_copy(f.kf, R1 < K ? R1 : K - 1);
-      const u32 qa = (u32)(qpk >> (2 * R1)) & 3u;                       // q[p1-1]
-      const u32 qb = R1 ? (u32)(qpk >> (2 * R1 - 2)) & 3u : 4u;         // q[p1], 4 = none
-      const u32 q2a = (u32)(qpk >> (2 * (m - p2))) & 3u;                // q[p2-1]
-      const u32 q2b = (u32)(qpk >> (2 * (m - p2) - 2)) & 3u;            // q[p2] (p2 < m)
+  // one pass over the group's pairs of edit positions; to_lds: occurring strings go to the LDS list, else to leaf records in HBM
+  auto search = [&](const u32 gid, const u32 m, const u64 qpk, const bool to_lds) {
+    const u32 npairs = m * (m + 1) / 2 - 1;  // p2 = 1..m-1, p1 = p2..m
+    for (u32 w0 = 0; w0 < npairs; w0 += 256) {
+      const u32 w = w0 + threadIdx.x;
+      u64 surv = 0;
+      if (w < npairs) {
+        u32 p1, p2;
+        pair_of(w, m, p2, p1);
+        const u32 R1 = m - p1;
+        const KfCopy c2 = kf_copy(f.kf2, R1 < K2 ? R1 : (K2 ? K2 - 1 : 0u));
+        const KfCopy c1 = kf_copy(f.kf, R1 < K ? R1 : K - 1);
+        const u32 qa = (u32)(qpk >> (2 * R1)) & 3u;                       // q[p1-1]
+        const u32 qb = R1 ? (u32)(qpk >> (2 * R1 - 2)) & 3u : 4u;         // q[p1], 4 = none
+        const u32 q2a = (u32)(qpk >> (2 * (m - p2))) & 3u;                // q[p2-1]
+        const u32 q2b = (u32)(qpk >> (2 * (m - p2) - 2)) & 3u;            // q[p2] (p2 < m)
 #pragma unroll
-      for (u32 op1 = 0; op1 < 8; ++op1) {
-        const bool ins1 = op1 >= 4;
-        // the first operation leaves p2 characters to its left; nothing is inserted after the last character
-        bool v1 = (p1 > p2 || ins1) && !(p1 == m && ins1);
-        if (op1 == 0) v1 = v1 && qb != qa;
-        if (ins1) v1 = v1 && !(p1 >= 2 && qa == op1 - 4 && p2 + 2 <= p1);
-        if (v1) {
-          u64 s1;
-          u32 l1, w1;
-          apply_edit(qpk, m, p1, op1, s1, l1, w1);
-          const u32 posp = ins1 ? p1 : p1 - 1;  // characters left of the first operation
-          // (r04 measured the copy of the filter picked by the SECOND operation's position instead — the inner loop's eight probes then
-          //  share three lines: 161 M instead of 175 M fabric reads per launch, but the L2 hits between neighbouring lanes' probes go
-          //  (175 M -> 46 M) and the kernel takes 8.93 instead of 8.20 ms; profiles/r04_d2b_pmc_summary.csv.  Not kept.)
-          u32 mask8 = 0;
-          // all addresses first, then the eight loads back to back, then the bits
-          const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
-          const u32* addr[8];
-          u32 bit[8], word[8], valid = 0, probe = 0;
+        for (u32 op1 = 0; op1 < 8; ++op1) {
+          const bool ins1 = op1 >= 4;
+          // the first operation leaves p2 characters to its left; nothing is inserted after the last character
+          bool v1 = (p1 > p2 || ins1) && !(p1 == m && ins1);
+          if (op1 == 0) v1 = v1 && qb != qa;
+          if (ins1) v1 = v1 && !(p1 >= 2 && qa == op1 - 4 && p2 + 2 <= p1);
+          if (v1) {
+            u64 s1;
+            u32 l1, w1;
+            apply_edit(qpk, m, p1, op1, s1, l1, w1);
+            const u32 posp = ins1 ? p1 : p1 - 1;  // characters left of the first operation
+            // (r04 measured the copy of the filter picked by the SECOND operation's position instead — the inner loop's eight probes then
+            //  share three lines: 161 M instead of 175 M fabric reads per launch, but the L2 hits between neighbouring lanes' probes go
+            //  (175 M -> 46 M) and the kernel takes 8.93 instead of 8.20 ms; profiles/r04_d2b_pmc_summary.csv.  Not kept.)
+            u32 mask8 = 0;
+            // all addresses first, then the eight loads back to back, then the bits
+            const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
+            const u32* addr[8];
+            u32 bit[8], word[8], valid = 0, probe = 0;
 #pragma unroll
-          for (u32 op2 = 0; op2 < 8; ++op2) {
-            bool v2 = true;
-            if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
-            if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
-            u64 s2;
-            u32 l2, w2;
-            apply_edit(s1, l1, p2, op2, s2, l2, w2);
-            const bool use2 = K2 && l2 >= K2;
-            const bool pr = v2 && (use2 || f.kf.nr);
-            KfCopy c;
-            c.base = use2 ? c2.base : c1.base;
-            c.s = use2 ? c2.s : c1.s;
-            const u32* a = kf_word(c, use2 ? s2 & mask2 : s2 & kmask, bit[op2]);
-            addr[op2] = pr ? a : idle;
-            valid |= (u32)v2 << op2;
-            probe |= (u32)pr << op2;
+            for (u32 op2 = 0; op2 < 8; ++op2) {
+              bool v2 = true;
+              if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
+              if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
+              u64 s2;
+              u32 l2, w2;
+              apply_edit(s1, l1, p2, op2, s2, l2, w2);
+              const bool use2 = K2 && l2 >= K2;
+              const bool pr = v2 && (use2 || f.kf.nr);
+              KfCopy c;
+              c.base = use2 ? c2.base : c1.base;
+              c.s = use2 ? c2.s : c1.s;
+              const u32* a = kf_word(c, use2 ? s2 & mask2 : s2 & kmask, bit[op2]);
+              addr[op2] = pr ? a : idle;
+              valid |= (u32)v2 << op2;
+              probe |= (u32)pr << op2;
+            }
+#pragma unroll
+            for (u32 op2 = 0; op2 < 8; ++op2) word[op2] = *addr[op2];
+#pragma unroll
+            for (u32 op2 = 0; op2 < 8; ++op2) {
+              const u32 present = ((probe >> op2) & 1u) ? (word[op2] >> bit[op2]) & 1u : 1u;
+              mask8 |= (((valid >> op2) & 1u) & present) << op2;
+            }
+            nprobe += (u32)__popc(probe);
+            surv |= (u64)mask8 << (8 * op1);
           }
+        }
+      }
+      // number the survivors: inclusive scan of the lanes' counts inside the wavefront, wavefront totals through LDS
+      const u32 mine = (u32)__popcll(surv);
+      u32 incl = mine;
+      for (int off = 1; off < 64; off <<= 1) {
+        const u32 v = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += v;
+      }
+      if (lane == 63) q_wave[threadIdx.x >> 6] = incl;
+      q_mask[threadIdx.x] = surv;
+      __syncthreads();
+      u32 before = 0;
+      for (u32 k = 0; k < (threadIdx.x >> 6); ++k) before += q_wave[k];
+      q_ex[threadIdx.x] = before + incl - mine;
+      const u32 qn = q_wave[0] + q_wave[1] + q_wave[2] + q_wave[3];
+      __syncthreads();
+      for (u32 e0 = 0; e0 < qn; e0 += 256) {
+        if (e0 + (threadIdx.x & ~63u) >= qn) break;  // wavefront without work
+        const u32 e = e0 + threadIdx.x;
+        bool leaf = false;
+        u32 lo = 0, hi = 0, w1 = 0, w2 = 0, fword = 0, len2 = 0;
+        u64 key2 = 0;
+        if (e < qn) {
+          // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
+          u32 L = 0;
 #pragma unroll
-          for (u32 op2 = 0; op2 < 8; ++op2) word[op2] = *addr[op2];
-#pragma unroll
-          for (u32 op2 = 0; op2 < 8; ++op2) {
-            const u32 present = ((probe >> op2) & 1u) ? (word[op2] >> bit[op2]) & 1u : 1u;
-            mask8 |= (((valid >> op2) & 1u) & present) << op2;
+          for (u32 step = 128; step > 0; step >>= 1)
+            if (q_ex[L + step] <= e) L += step;
+          unsigned long long mk = q_mask[L];
+          for (u32 r = e - q_ex[L]; r > 0; --r) mk &= mk - 1;
+          const u32 bitno = (u32)__ffsll((long long)mk) - 1u;
+          u32 p1, p2, l1, l2;
+          u64 s1, s2;
+          pair_of(w0 + L, m, p2, p1);
+          apply_edit(qpk, m, p1, bitno >> 3, s1, l1, w1);
+          apply_edit(s1, l1, p2, bitno & 7u, s2, l2, w2);
+          key2 = s2;
+          len2 = l2;
+          nprobe += (K2 && l2 > K2);
+          if (head_window_occurs(f, s2, l2, l1 - p2)) {
+            const uint2 iv = f.ktab[s2 & kmask];
+            ++nlook;
+            lo = iv.x;
+            hi = iv.y;
           }
-          nprobe += (u32)__popc(probe);
-          surv |= (u64)mask8 << (8 * op1);
-        }
-      }
-    }
-    // number the survivors: inclusive scan of the lanes' counts inside the wavefront, wavefront totals through LDS
-    const u32 mine = (u32)__popcll(surv);
-    u32 incl = mine;
-    for (int off = 1; off < 64; off <<= 1) {
-      const u32 v = __shfl_up(incl, off);
-      if ((int)lane >= off) incl += v;
-    }
-    if (lane == 63) q_wave[threadIdx.x >> 6] = incl;
-    q_mask[threadIdx.x] = surv;
-    __syncthreads();
-    u32 before = 0;
-    for (u32 k = 0; k < (threadIdx.x >> 6); ++k) before += q_wave[k];
-    q_ex[threadIdx.x] = before + incl - mine;
-    const u32 qn = q_wave[0] + q_wave[1] + q_wave[2] + q_wave[3];
-    __syncthreads();
-    for (u32 e0 = 0; e0 < qn; e0 += 256) {
-      if (e0 + (threadIdx.x & ~63u) >= qn) break;  // wavefront without work
-      const u32 e = e0 + threadIdx.x;
-      bool leaf = false;
-      u32 lo = 0, hi = 0, w1 = 0, w2 = 0;
-      if (e < qn) {
-        // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
-        u32 L = 0;
+          u64 rs = s2 >> (2 * K);
+          u32 nr = l2 - K;
+          // filtered interval (FmView::pre5, see k_search1s): a narrow table interval is settled with one line of the preceding-characters
+          // array instead of l2 - K dependent Occ lines; the leaf then carries (interval of its last K characters, mask, l2 - K) in ops[2]
+          if (filt_ok && f.pre5 && nr >= 1 && nr <= 5 && lo < hi && hi - lo <= 16) {
+            const u32 w = hi - lo;
+            u32 want = 0, fm = 0;
+            for (u32 k2 = 0; k2 < nr; ++k2) want |= ((u32)(rs >> (2 * k2)) & 3u) << (3 * k2);
+            const u32 wmask = (1u << (3 * nr)) - 1u;
+            u32 ent16[16];
 #pragma unroll
-        for (u32 step = 128; step > 0; step >>= 1)
-          if (q_ex[L + step] <= e) L += step;
-        unsigned long long mk = q_mask[L];
-        for (u32 r = e - q_ex[L]; r > 0; --r) mk &= mk - 1;
-        const u32 bitno = (u32)__ffsll((long long)mk) - 1u;
-        u32 p1, p2, l1, l2;
-        u64 s1, s2;
-        pair_of(w0 + L, m, p2, p1);
-        apply_edit(qpk, m, p1, bitno >> 3, s1, l1, w1);
-        apply_edit(s1, l1, p2, bitno & 7u, s2, l2, w2);
-        nprobe += (K2 && l2 > K2);
-        if (head_window_occurs(f, s2, l2, l1 - p2)) {
-          const uint2 iv = f.ktab[s2 & kmask];
-          ++nlook;
-          lo = iv.x;
-          hi = iv.y;
-        }
-        u64 rs = s2 >> (2 * K);
-        u32 nr = l2 - K;
-        while (nr && lo < hi) {
-          bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
-          rs >>= 2;
-          --nr;
-          ++steps;
-        }
-        leaf = lo < hi;
-      }
-      const unsigned long long lm = __ballot(leaf);
-      u32 lbase = 0;
-      if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
-      lbase = __shfl(lbase, 0);
-      if (leaf) {
-        const u32 slot = atomicAdd(&g_slots, 1u);
-        const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
-        if (la < o.shard_cap) {
-          Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
-          lf->qs = gid;
-          lf->slot = slot;
-          lf->lo = lo;
-          lf->hi = hi;
-          lf->nops = 2;
-          lf->ops[0] = w1;
-          lf->ops[1] = w2;
+            for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
 #pragma unroll
-          for (int k = 2; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+            for (u32 j = 0; j < 16; ++j) fm |= (u32)((ent16[j] & wmask) == want && j < w) << j;
+            ++nlook;
+            fword = fm | (nr << 16) | (1u << 31);
+            nr = 0;
+            if (!fm) lo = hi = 0;
+          }
+          while (nr && lo < hi) {
+            bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+            rs >>= 2;
+            --nr;
+            ++steps;
+          }
+          leaf = lo < hi;
         }
+        if (SEL && to_lds) {  // the string itself (2 bits per character: s2 of l2 <= 32 characters), its interval, its filter word
+          if (leaf) {
+            const u32 at = atomicAdd(&l_n, 1u);
+            if (at < FUSED2_LCAP) {
+              l_key[at] = key2;
+              l_lo[at] = lo;
+              l_hi[at] = hi;
+              l_fw[at] = fword;
+              l_meta[at] = (u16)len2;
+            }
+          }
+          continue;
+        }
+        const unsigned long long lm = __ballot(leaf);
+        u32 lbase = 0;
+        if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
+        lbase = __shfl(lbase, 0);
+        if (leaf) {
+          const u32 slot = atomicAdd(&g_slots, 1u);
+          const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
+          if (la < o.shard_cap) {
+            Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
+            lf->qs = gid;
+            lf->slot = slot;
+            lf->lo = lo;
+            lf->hi = hi;
+            lf->nops = 2;
+            lf->ops[0] = w1;
+            lf->ops[1] = w2;
+            lf->ops[2] = fword;  // 0, or the filtered form: mask | characters in front << 16 | 1 << 31 (k_group_pack hands it on)
+#pragma unroll
+            for (int k = 3; k < (int)DMAX; ++k) lf->ops[k] = 0u;
+          }
+        }
+      }
+      __syncthreads();  // the masks and prefixes of this pass are not needed any more
+    }
+  };
+  if (TAKE && threadIdx.x < 2) s_occ[threadIdx.x] = 0ULL;
+  bool room_all = true;
+  for (u32 strand = 0; strand < (TAKE ? 2u : 1u); ++strand) {
+    const u32 gid = TAKE ? 2u * blockIdx.x + strand : blockIdx.x;
+    const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
+    const u32 m = raw.z, d_win = raw.w;
+    if (!m || !(d_win & 1024u)) continue;  // uniform for the workgroup
+    const u64 qpk = (u64)raw.y << 32 | raw.x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      g_slots = 0;
+      l_n = 0;
+      s_alive = 0;
+    }
+    __syncthreads();
+    search(gid, m, qpk, SEL);
+    if (!SEL) {
+      if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
+      continue;
+    }
+    // (search ends with a barrier: the list is complete)
+    const u32 nl = l_n;
+    if (nl > lcap2) {  // (lcap2 <= FUSED2_LCAP) the generic select kernels take this group: once more, leaves to HBM
+      const u32 st0 = steps, lk0 = nlook, pr0 = nprobe;
+      search(gid, m, qpk, false);
+      steps = st0;  // counted once
+      nlook = lk0;
+      nprobe = pr0;
+      if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
+      room_all = false;
+      continue;
+    }
+    // alive: no other string of the group is a proper substring, and of equal strings the first of the list stays
+    for (u32 i = threadIdx.x; i < nl; i += 256) {
+      const u32 alen = l_meta[i] & 63u;
+      const u64 a = l_key[i];
+      bool ok = true;
+      for (u32 x = 0; x < nl && ok; ++x) {
+        if (x == i) continue;
+        const u32 xlen = l_meta[x] & 63u;
+        if (xlen > alen) continue;
+        const u64 xk = l_key[x], xm = xlen >= 32 ? ~0ULL : ((1ULL << (2 * xlen)) - 1);
+        bool hit = false;
+        for (u32 sh = 0; sh <= alen - xlen; ++sh) hit = hit || (((a >> (2 * sh)) & xm) == xk);
+        if (hit) ok = (xlen == alen) && (i < x);
+      }
+      if (ok) {
+        atomicAdd(&s_alive, 1u);
+        if (TAKE) {
+          const u32 fw = l_fw[i];
+          const u64 occ = (fw >> 31) ? (u64)__popc(fw & 0xFFFFu) : (u64)l_hi[i] - l_lo[i];
+          atomicAdd(&s_occ[strand], (unsigned long long)(occ < b.max_locations ? occ : b.max_locations));
+        }
+      }
+      if (ok) l_meta[i] = (u16)(alen | 0x8000u);  // (the length bits the other lanes read stay as they are)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_base = s_alive ? atomicAdd(&o.ctr->sel_cnt[shard], s_alive) : 0u;
+      if (nl) atomicAdd(&o.ctr->fused_leaves[shard], (unsigned long long)nl);
+    }
+    __syncthreads();
+    const u32 wbase = s_base, total = s_alive;
+    const bool room = wbase + total <= fs.cap;  // an overflowing slice repeats the batch (Summary::worst_sel) ...
+    if (!room && threadIdx.x == 0) atomicOr(&o.ctr->overflow, 1u);  // ... and the kernels behind this one do nothing
+    room_all = room_all && room;
+    // rank among the group's survivors in std::string order (A < C < G < T = code order; a proper prefix sorts first) -> Sel
+    for (u32 i = threadIdx.x; i < nl; i += 256) {
+      const u32 meta = l_meta[i];
+      if (!(meta & 0x8000u)) continue;
+      const u32 alen = meta & 63u;
+      const u64 ak = l_key[i] << (64 - 2 * alen);
+      u32 r = 0;
+      u64 before = (TAKE && strand) ? s_occ[0] : 0ULL;  // TAKE: occurrences (clamped) of the strings in front of this one in push order
+      for (u32 x = 0; x < nl; ++x) {
+        const u32 xm = l_meta[x];
+        if (x == i || !(xm & 0x8000u)) continue;
+        const u32 xlen = xm & 63u;
+        const u64 xk = l_key[x] << (64 - 2 * xlen);
+        const bool first = (xk < ak) || (xk == ak && xlen < alen);
+        r += first;
+        if (TAKE && first) {
+          const u32 fw = l_fw[x];
+          const u64 occ = (fw >> 31) ? (u64)__popc(fw & 0xFFFFu) : (u64)l_hi[x] - l_lo[x];
+          before += occ < b.max_locations ? occ : b.max_locations;
+        }
+      }
+      if (room) {
+        Sel sv;
+        sv.lo = l_lo[i];
+        sv.hi = l_hi[i];
+        sv.len = sel_len_from(alen, l_fw[i]);
+        sv.take = 0;
+        sv.hbase = 0;
+        if (TAKE) {  // hunter.h:349-357: strings are located in set order, forward strand first, while hits < max_locations
+          const u64 M = b.max_locations, occ = sel_occ(sv);
+          const u64 h0 = before < M ? before : M, h1 = before + occ < M ? before + occ : M;
+          sv.hbase = (u32)h0;
+          sv.take = (u32)(h1 - h0);
+        }
+        sv.g = gid;
+        fs.sel[(u64)shard * fs.cap + wbase + r] = sv;
       }
     }
-    __syncthreads();  // the masks and prefixes of this pass are not needed any more
+    if (threadIdx.x == 0) {
+      fs.nsel[gid] = room ? total : 0u;
+      fs.selbase[gid] = shard * fs.cap + wbase;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     steps += __shfl_xor(steps, off);
@@ -1085,8 +1241,23 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
     if (nprobe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nprobe);
   }
-  if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
+  if (TAKE) {  // k_take's per-query part: the hit count, hunter.h:434, the compact results' word
+    __syncthreads();
+    const u64 q = blockIdx.x;
+    if (threadIdx.x == 0 && q < b.nq) {
+      const u64 M = b.max_locations, tot = s_occ[0] + s_occ[1];
+      const u64 hits = room_all ? (tot < M ? tot : M) : 0ULL;
+      po.qhits[q] = (u32)hits;
+      u32 fl = b.qflags[q];
+      if (hits >= M && !(fl & DG_Q_TOO_SHORT)) {
+        fl |= DG_Q_MAX_MATCHES;
+        b.qflags[q] = fl;
+      }
+      if (b.qinfo) b.qinfo[q] = (fl & 255u) | ((b.qdist[q] & 255u) << 8) | (b.qnondna[q] << 16);
+    }
+  }
 }
+
 
 template <bool INDEL, int D>
 __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, u32 items) {

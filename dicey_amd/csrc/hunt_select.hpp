@@ -203,7 +203,8 @@ DG_DEV void p128_topmask(u64& hi, u64& lo, u32 nbits) {  // keep the top nbits (
   }
 }
 // group leaves by (query,strand) and pack their strings: dst = grp_off[qs] + slot
-__global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, PLeaf* out) {
+// filt_out[slot of the packed leaf]: the filtered form of the leaf's interval (k_search2p: Leaf::ops[2] of a two-operation leaf), 0 = none
+__global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Counters* ctr, const u64* grp_off, PLeaf* out, u32* filt_out) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || t >= (u64)NSHARD * shard_cap || (u32)(t % shard_cap) >= ctr->leaf_cnt[t / shard_cap]) return;
   Leaf lf = in[t];
@@ -244,6 +245,7 @@ __global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Count
     p.sa_hi = lf.hi;
     p.qs = lf.qs;
     out[grp_off[lf.qs] + lf.slot] = p;
+    filt_out[grp_off[lf.qs] + lf.slot] = (lf.nops == 2 && (lf.ops[2] >> 31)) ? lf.ops[2] : 0u;
     return;
   }
   LeafReader r;
@@ -270,6 +272,7 @@ __global__ void k_group_pack(Batch b, const Leaf* in, u32 shard_cap, const Count
   p.sa_hi = lf.hi;
   p.qs = lf.qs;
   out[grp_off[lf.qs] + lf.slot] = p;
+  filt_out[grp_off[lf.qs] + lf.slot] = (lf.nops == 2 && (lf.ops[2] >> 31)) ? lf.ops[2] : 0u;
 }
 DG_DEV bool pleaf_contains(const PLeaf& a, const PLeaf& x) {  // is x inside a?  (std::string::find)
   if (x.len > a.len) return false;
@@ -331,7 +334,7 @@ __global__ void k_leaf_alive(const PLeaf* G, const u64* grp_off, u64 nq2, u32 in
   }
   alive[t] = ok;
 }
-__global__ void k_leaf_rank(const PLeaf* G, const u64* grp_off, u64 nq2, const u8* alive, Sel* sel, u32* nsel,
+__global__ void k_leaf_rank(const PLeaf* G, const u32* filt, const u64* grp_off, u64 nq2, const u8* alive, Sel* sel, u32* nsel,
                             const Counters* ctr, u32 above) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || t >= grp_off[nq2]) return;
@@ -349,7 +352,7 @@ __global__ void k_leaf_rank(const PLeaf* G, const u64* grp_off, u64 nq2, const u
   Sel s;
   s.lo = a.sa_lo;
   s.hi = a.sa_hi;
-  s.len = a.len;
+  s.len = sel_len_from(a.len, filt[t]);
   s.take = 0;
   s.hbase = 0;
   sel[g0 + r] = s;
@@ -362,7 +365,7 @@ __global__ void k_leaf_rank(const PLeaf* G, const u64* grp_off, u64 nq2, const u
 // offset) window of the string — at most 14 windows at distance 2.  Survivors leave in sorted order, so the rank comes for
 // free.  Groups above SELCAP leaves stay with the lane-per-leaf kernels.
 static constexpr u32 SELCAP = 1024;
-__global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64* grp_off, u32 indel, Sel* sel, u32* nsel, const Counters* ctr) {
+__global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u32* filt, const u64* grp_off, u32 indel, Sel* sel, u32* nsel, const Counters* ctr) {
   __shared__ unsigned long long kh[SELCAP], kl[SELCAP];
   __shared__ u16 ix[SELCAP];  // bits 0-9 position in the group, bits 10-15 string length
   __shared__ u32 s_minlen, s_w[2];
@@ -378,7 +381,7 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
       Sel o;
       o.lo = a.sa_lo;
       o.hi = a.sa_hi;
-      o.len = a.len;
+      o.len = sel_len_from(a.len, filt[g0]);
       o.take = 0;
       o.hbase = 0;
       sel[g0] = o;
@@ -475,7 +478,7 @@ __global__ void __launch_bounds__(128) k_group_select(const PLeaf* G, const u64*
       Sel o;
       o.lo = a.sa_lo;
       o.hi = a.sa_hi;
-      o.len = a.len;
+      o.len = sel_len_from(a.len, filt[g0 + (ix[i] & 1023u)]);
       o.take = 0;
       o.hbase = 0;
       sel[g0 + r] = o;

@@ -259,6 +259,13 @@ int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out);
  * the offsets again by itself), so the buffers may be refilled in place between calls. */
 int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
                    const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out);
+/* Asynchronous form of dg_hunt_device (r04), on the same two lanes as dg_hunt_submit and collected with dg_hunt_wait: a caller whose
+ * batches are resident in HBM keeps two in flight — submit A, submit B, wait A, submit C, wait B, ... — so that one batch's
+ * launch-bound tail (locate, verify, the summary's read-back) runs beside the next batch's search kernel.  The device buffers must
+ * stay untouched until the ticket has been waited for; a result left in HBM (fetch = 0) is valid until the second submit after
+ * its own (the lanes alternate).  Replaces nothing in the reference: hunter.h:291 walks its queries one by one. */
+int dg_hunt_device_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
+                          const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_ticket** out);
 
 /* ---- `dicey padlock`: how often the neighbourhood of a probe arm occurs (reference src/padlock.h:392-421) ----
  * For sequence i (>= 10 nt; A/C/G/T sequences run on the search kernel, sequences with other letters are enumerated on

@@ -256,6 +256,61 @@ def test_device_pointer_view_for_the_rccl_gather(gpu_small, small_genome):
     L.dg_hunt_result_free(rp)
 
 
+def test_device_submit_keeps_two_batches_in_flight(gpu_small, small_genome):
+    """dg_hunt_device_submit / dg_hunt_wait: six different batches resident in HBM through the handle's two lanes (submit k,
+    collect k - 1), fetched hits identical to dg_hunt_device's of the same batch; a third submit before a wait is refused, and so
+    is dg_hunt_device while a ticket is open."""
+    import ctypes as C
+    import torch
+    from dicey_amd import _capi
+    L = _capi.load()
+    sl = (C.c_uint32 * 3)(*small_genome["seqlen"])
+    p = _capi.HuntParams(1, 0, 0, 1000, 10000, 0, _capi.DG_HUNT_COMPACT)
+    batches = []
+    for b in range(6):
+        qs = make_queries(70 + b, small_genome["text"], 120 + 17 * b, (14, 20, 24))
+        qb = b"".join(q.encode() for q in qs)
+        off = [0]
+        for q in qs:
+            off.append(off[-1] + len(q))
+        batches.append((torch.frombuffer(bytearray(qb), dtype=torch.uint8).cuda(), torch.tensor(off, dtype=torch.int64).cuda(), len(qs), len(qb)))
+
+    def payload(rp):
+        R = rp.contents
+        words = 2 + R.ops_per_hit
+        out = (R.nhits, bytes(C.string_at(R.chits, R.nhits * 4 * words)), bytes(C.string_at(R.qinfo, R.nq * 4)),
+               bytes(C.string_at(C.cast(R.hit_off, C.c_void_p), (R.nq + 1) * 8)))
+        L.dg_hunt_result_free(rp)
+        return out
+
+    want = []
+    for d_q, d_off, n, nb in batches:
+        rp = C.POINTER(_capi.HuntResult)()
+        _capi.check(L, L.dg_hunt_device(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()), n, nb, 1, C.byref(rp)))
+        want.append(payload(rp))
+    assert sum(w[0] for w in want) > 0
+    got, open_ = [], []
+    for k, (d_q, d_off, n, nb) in enumerate(batches):
+        tk = C.c_void_p()
+        _capi.check(L, L.dg_hunt_device_submit(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()), n, nb, 1, C.byref(tk)))
+        open_.append(tk)
+        if k == 1:  # both lanes taken
+            t3 = C.c_void_p()
+            assert L.dg_hunt_device_submit(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()), n, nb, 1,
+                                           C.byref(t3)) != 0 and not t3.value
+            rp = C.POINTER(_capi.HuntResult)()
+            assert L.dg_hunt_device(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()), n, nb, 1, C.byref(rp)) != 0
+        if len(open_) > 1:
+            rp = C.POINTER(_capi.HuntResult)()
+            _capi.check(L, L.dg_hunt_wait(open_.pop(0), C.byref(rp)))
+            got.append(payload(rp))
+    while open_:
+        rp = C.POINTER(_capi.HuntResult)()
+        _capi.check(L, L.dg_hunt_wait(open_.pop(0), C.byref(rp)))
+        got.append(payload(rp))
+    assert got == want
+
+
 def test_repeat_rich_strings_use_the_workgroup_locate(tmp_path):
     """A 20-mer present thousands of times: locate must return the max_locations SMALLEST positions in ascending order
     (hunter.h:355-357), through the radix-select kernel and through the per-lane fallback (take > 16384)."""
@@ -298,7 +353,8 @@ def test_flat_distance_two_kernel(gpu_small, small_genome, monkeypatch):
 # through the same matrix as the default
 SWITCHES = {"nofuse": {"DICEY_NO_FUSED_SELECT": "1"}, "noband": {"DICEY_NO_BAND_VERIFY": "1"}, "classic": {"DICEY_CLASSIC_RESULTS": "1"},
             "ch4": {"DICEY_VERIFY_CH": "4"}, "ch8": {"DICEY_VERIFY_CH": "8"}, "caps": {"DICEY_DEBUG_CAPS": "3"},
-            "lcap2": {"DICEY_FUSED_LCAP": "2"}, "noprep": {"DICEY_NO_PREP_FUSION": "1"}, "caphost": {"DICEY_CAP_HOST": "1"}, "nominima": {"DICEY_NO_SA_MINIMA": "1"}, "nopre5": {"DICEY_NO_PRE5": "1"}}
+            "lcap2": {"DICEY_FUSED_LCAP": "2"}, "noprep": {"DICEY_NO_PREP_FUSION": "1"}, "caphost": {"DICEY_CAP_HOST": "1"}, "nominima": {"DICEY_NO_SA_MINIMA": "1"}, "nopre5": {"DICEY_NO_PRE5": "1"},
+            "nopre5d2": {"DICEY_NO_PRE5_D2": "1"}, "nofuse2": {"DICEY_NO_FUSED_SELECT2": "1"}}
 
 
 @pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13", "K9_nolong", "K9_long10", "K10_long14"] + ["K9_long10+" + k for k in SWITCHES])

@@ -773,7 +773,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipEventRecord(ix->ev[0], st));
     // the whole batch on the flat distance-1 path: k_search1s settles the `take` values of its own queries (TAKE form);
     // DICEY_NO_PREP_FUSION keeps k_take a launch of its own (the GPU suite runs both)
-    const bool prep_in = fused && !generic_on && !group_counts && !std::getenv("DICEY_NO_PREP_FUSION");
+    const bool prep_in = fused && b.fastK && !generic_on && !group_counts && !std::getenv("DICEY_NO_PREP_FUSION");
     // the per-character arrays (fw / rv codes, normalised ASCII) are read by the generic kernels, the full-matrix verify kernels and
     // the classic result fetch only: 60 byte stores per query that the flat path with compact results does without
     const u32 write_bytes = (prep_in && band_verify && (compact || !fetch)) ? 0u : 1u;
@@ -826,13 +826,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         fs.cap = flat_cap;
         fs.selbase = selbase;
         fs.nsel = nsel;
-        PrepOut po;
-        po.qhits = qhits;
         // (tests: DICEY_FUSED_LCAP lowers the list's capacity so that ordinary groups exercise the hand-over to the generic select kernels)
         const u32 lcap2 = std::getenv("DICEY_FUSED_LCAP") ? std::max<u32>(1u, std::min<u32>(FUSED2_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP")))) : FUSED2_LCAP;
-        if (fused && prep_in) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true, true>), dim3((u32)nq), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, po, lcap2);
-        else if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true, false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, po, lcap2);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false, false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, po, lcap2);
+        if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       // edit distance 2: the walker (k_search) only serves the groups k_search2p does not take (N in the query, above 30 nt); it is

@@ -918,16 +918,17 @@ DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... ho
   p2 = (u32)a + 1;
   p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
 }
-static constexpr u32 FUSED2_LCAP = 512;  // strings of ONE (query, strand) group in LDS (k_search2p<true, .>)
+static constexpr u32 FUSED2_LCAP = 512;
+static constexpr u32 FUSED2_HCAP = 1024;  // hash slots of the select stage (distinct strings of the list)  // strings of ONE (query, strand) group in LDS (k_search2p<true, .>)
 // SEL (r04): the select stage inside, like k_search1s — the workgroup owns its group anyway, so the group's occurring strings stay in
 // LDS (2-bit packed, with interval and filter word), duplicates / substring-minimal filter / std::set order are settled here and the
 // kept strings go to the flat Sel region; leaves do not travel to HBM, and the scans, k_group_pack, k_group_select, k_leaf_alive and
 // k_leaf_rank (2.4 of the 12.8 ms of a step) have nothing left to do.  A group with more than FUSED2_LCAP occurring strings is searched
 // once more with its leaves written out for the generic select kernels (selbase stays "generic"; the host repeats the batch with
-// them when they were not launched).  TAKE: one workgroup per QUERY, forward strand first, which also settles take / hbase / the
-// query's hit count (k_take's work; whole batch on the flat path).
-template <bool SEL, bool TAKE>
-__global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, PrepOut po, u32 lcap2) {
+// them when they were not launched).  (A form with one workgroup per QUERY that also did k_take's work — both strands one after the
+// other — was measured: 9.68 against 9.28 + 0.27 ms for this kernel and k_take; removed.)
+template <bool SEL>
+__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2) {
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
   // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
@@ -940,8 +941,10 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
   __shared__ u64 l_key[LN];
   __shared__ u32 l_lo[LN], l_hi[LN], l_fw[LN];
   __shared__ u16 l_meta[LN];  // length (6 bits), 0x8000 = kept
+  __shared__ u32 l_rank[LN];  // 0xFFFFFFFF = dead, else the rank among the kept strings
+  __shared__ u32 l_hash[SEL ? FUSED2_HCAP : 1u];  // list indices of the distinct strings
+  __shared__ u16 l_ord[LN];   // the kept strings' list indices
   __shared__ u32 l_n, s_alive, s_base;
-  __shared__ unsigned long long s_occ[2];
   const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u;
   const u64 kmask = (1ULL << (2 * K)) - 1, mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
   const u32 lane = threadIdx.x & 63;
@@ -1093,6 +1096,7 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
               l_hi[at] = hi;
               l_fw[at] = fword;
               l_meta[at] = (u16)len2;
+              l_rank[at] = 0u;
             }
           }
           continue;
@@ -1122,10 +1126,8 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
       __syncthreads();  // the masks and prefixes of this pass are not needed any more
     }
   };
-  if (TAKE && threadIdx.x < 2) s_occ[threadIdx.x] = 0ULL;
-  bool room_all = true;
-  for (u32 strand = 0; strand < (TAKE ? 2u : 1u); ++strand) {
-    const u32 gid = TAKE ? 2u * blockIdx.x + strand : blockIdx.x;
+  for (u32 once = 0; once < 1u; ++once) {  // (`continue` leaves the group)
+    const u32 gid = blockIdx.x;
     const uint4 raw = *reinterpret_cast<const uint4*>(b.ginfo + gid);
     const u32 m = raw.z, d_win = raw.w;
     if (!m || !(d_win & 1024u)) continue;  // uniform for the workgroup
@@ -1137,94 +1139,128 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
       s_alive = 0;
     }
     __syncthreads();
-    search(gid, m, qpk, SEL);
-    if (!SEL) {
-      if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
-      continue;
-    }
-    // (search ends with a barrier: the list is complete)
-    const u32 nl = l_n;
-    if (nl > lcap2) {  // (lcap2 <= FUSED2_LCAP) the generic select kernels take this group: once more, leaves to HBM
-      const u32 st0 = steps, lk0 = nlook, pr0 = nprobe;
-      search(gid, m, qpk, false);
-      steps = st0;  // counted once
-      nlook = lk0;
-      nprobe = pr0;
-      if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
-      room_all = false;
-      continue;
-    }
-    // alive: no other string of the group is a proper substring, and of equal strings the first of the list stays
-    for (u32 i = threadIdx.x; i < nl; i += 256) {
-      const u32 alen = l_meta[i] & 63u;
-      const u64 a = l_key[i];
-      bool ok = true;
-      for (u32 x = 0; x < nl && ok; ++x) {
-        if (x == i) continue;
-        const u32 xlen = l_meta[x] & 63u;
-        if (xlen > alen) continue;
-        const u64 xk = l_key[x], xm = xlen >= 32 ? ~0ULL : ((1ULL << (2 * xlen)) - 1);
-        bool hit = false;
-        for (u32 sh = 0; sh <= alen - xlen; ++sh) hit = hit || (((a >> (2 * sh)) & xm) == xk);
-        if (hit) ok = (xlen == alen) && (i < x);
+    // (one call site: the search is 27 KB of code)
+    u32 st1 = 0, lk1 = 0, pr1 = 0;
+    bool over = false;
+#pragma unroll 1
+    for (u32 pass = 0; pass < (SEL ? 2u : 1u); ++pass) {
+      search(gid, m, qpk, SEL && pass == 0);
+      if (!SEL) break;
+      if (pass == 0) {  // (search ends with a barrier: the list is complete)
+        if (l_n <= lcap2) break;
+        over = true;  // (lcap2 <= FUSED2_LCAP) the generic select kernels take this group: once more, leaves to HBM
+        st1 = steps;
+        lk1 = nlook;
+        pr1 = nprobe;
+      } else {  // counted once
+        steps = st1;
+        nlook = lk1;
+        nprobe = pr1;
       }
-      if (ok) {
-        atomicAdd(&s_alive, 1u);
-        if (TAKE) {
-          const u32 fw = l_fw[i];
-          const u64 occ = (fw >> 31) ? (u64)__popc(fw & 0xFFFFu) : (u64)l_hi[i] - l_lo[i];
-          atomicAdd(&s_occ[strand], (unsigned long long)(occ < b.max_locations ? occ : b.max_locations));
+    }
+    if (!SEL || over) {
+      if (threadIdx.x == 0 && g_slots) atomicAdd(o.grp_cnt + gid, g_slots);
+      continue;
+    }
+    const u32 nl = l_n;
+    // Select without the n^2 pair loop (r04: one lane per pair took as long as the generic select kernels, 2.4 ms per batch — 48
+    // occurring strings per group, half of them repeats of another edit path's string):
+    //  (1) the list's DISTINCT strings through a hash table of list indices in LDS (compare-and-swap, linear probing; a string that
+    //      finds itself there is a duplicate and dies);
+    //  (2) a distinct string dies when one of its proper substrings of >= m - 2 characters (the shortest a group can hold) is in the
+    //      table: <= 14 look-ups (2 + 3 + 4 + 5 for a string of m + 2 characters), shared by G lanes per string;
+    //  (3) the survivors are numbered (l_ord) and ranked among themselves only.
+    for (u32 t = threadIdx.x; t < FUSED2_HCAP; t += 256) l_hash[t] = 0xFFFFFFFFu;
+    __syncthreads();
+    auto hash_of = [](u64 key, u32 len) { return (u32)(((key + len) * 0x9E3779B97F4A7C15ULL) >> 40) & (FUSED2_HCAP - 1u); };
+    for (u32 i = threadIdx.x; i < nl; i += 256) {
+      const u64 key = l_key[i];
+      const u32 len = l_meta[i] & 63u;
+      u32 sl = hash_of(key, len);
+      for (;;) {
+        const u32 old = atomicCAS(&l_hash[sl], 0xFFFFFFFFu, i);
+        if (old == 0xFFFFFFFFu) break;  // the string's representative
+        if (l_key[old] == key && (l_meta[old] & 63u) == len) {
+          l_rank[i] = 0xFFFFFFFFu;  // a repeat
+          break;
+        }
+        sl = (sl + 1u) & (FUSED2_HCAP - 1u);
+      }
+    }
+    __syncthreads();
+    const u32 G = (nl && nl < 256u) ? 256u / nl : 1u;
+    const u32 ti = threadIdx.x / G, tk = threadIdx.x - ti * G, istep = 256u / G;
+    for (u32 i = ti; i < nl; i += istep) {
+      if (l_rank[i] == 0xFFFFFFFFu) continue;
+      const u32 alen = l_meta[i] & 63u, span = alen - (m - 2u);  // 0..4 characters above the shortest
+      const u64 a = l_key[i];
+      const u32 combos = span * (span + 3u) / 2u;  // sum over k = 1..span of (k + 1) placements
+      bool dead = false;
+      for (u32 c = tk; c < combos && !dead; c += G) {
+        // c -> (k characters shorter, placement sh = 0..k): the blocks start at 0, 2, 5, 9
+        const u32 k = c < 2u ? 1u : c < 5u ? 2u : c < 9u ? 3u : 4u;
+        const u32 sh = c - (k * (k + 1u) / 2u - 1u);
+        const u32 L = alen - k;
+        const u64 sub = (a >> (2 * sh)) & (L >= 32 ? ~0ULL : ((1ULL << (2 * L)) - 1));
+        u32 sl = hash_of(sub, L);
+        for (;;) {
+          const u32 v = l_hash[sl];
+          if (v == 0xFFFFFFFFu) break;
+          if (l_key[v] == sub && (l_meta[v] & 63u) == L) {
+            dead = true;
+            break;
+          }
+          sl = (sl + 1u) & (FUSED2_HCAP - 1u);
         }
       }
-      if (ok) l_meta[i] = (u16)(alen | 0x8000u);  // (the length bits the other lanes read stay as they are)
+      if (dead) l_rank[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nl; i += 256) {
+      if (l_rank[i] == 0xFFFFFFFFu) continue;
+      l_meta[i] = (u16)(l_meta[i] | 0x8000u);
+      l_ord[atomicAdd(&s_alive, 1u)] = (u16)i;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       s_base = s_alive ? atomicAdd(&o.ctr->sel_cnt[shard], s_alive) : 0u;
       if (nl) atomicAdd(&o.ctr->fused_leaves[shard], (unsigned long long)nl);
     }
+    // rank among the group's survivors in std::string order (A < C < G < T = code order; a proper prefix sorts first): partial counts
+    // per lane, added up in LDS
+    const u32 na = s_alive;
+    const u32 G2 = (na && na < 256u) ? 256u / na : 1u;
+    const u32 ri = threadIdx.x / G2, rk = threadIdx.x - ri * G2, rstep = 256u / G2;
+    for (u32 jj = ri; jj < na; jj += rstep) {
+      const u32 i = l_ord[jj];
+      const u32 alen = l_meta[i] & 63u;
+      const u64 ak = l_key[i] << (64 - 2 * alen);
+      u32 r = 0;
+      for (u32 y = rk; y < na; y += G2) {
+        const u32 x = l_ord[y];
+        if (x == i) continue;
+        const u32 xlen = l_meta[x] & 63u;
+        const u64 xk = l_key[x] << (64 - 2 * xlen);
+        const bool first = (xk < ak) || (xk == ak && xlen < alen);
+        r += first;
+      }
+      if (r) atomicAdd(&l_rank[i], r);
+    }
     __syncthreads();
     const u32 wbase = s_base, total = s_alive;
     const bool room = wbase + total <= fs.cap;  // an overflowing slice repeats the batch (Summary::worst_sel) ...
     if (!room && threadIdx.x == 0) atomicOr(&o.ctr->overflow, 1u);  // ... and the kernels behind this one do nothing
-    room_all = room_all && room;
-    // rank among the group's survivors in std::string order (A < C < G < T = code order; a proper prefix sorts first) -> Sel
-    for (u32 i = threadIdx.x; i < nl; i += 256) {
+    for (u32 jj = threadIdx.x; jj < na && room; jj += 256) {
+      const u32 i = l_ord[jj];
       const u32 meta = l_meta[i];
-      if (!(meta & 0x8000u)) continue;
-      const u32 alen = meta & 63u;
-      const u64 ak = l_key[i] << (64 - 2 * alen);
-      u32 r = 0;
-      u64 before = (TAKE && strand) ? s_occ[0] : 0ULL;  // TAKE: occurrences (clamped) of the strings in front of this one in push order
-      for (u32 x = 0; x < nl; ++x) {
-        const u32 xm = l_meta[x];
-        if (x == i || !(xm & 0x8000u)) continue;
-        const u32 xlen = xm & 63u;
-        const u64 xk = l_key[x] << (64 - 2 * xlen);
-        const bool first = (xk < ak) || (xk == ak && xlen < alen);
-        r += first;
-        if (TAKE && first) {
-          const u32 fw = l_fw[x];
-          const u64 occ = (fw >> 31) ? (u64)__popc(fw & 0xFFFFu) : (u64)l_hi[x] - l_lo[x];
-          before += occ < b.max_locations ? occ : b.max_locations;
-        }
-      }
-      if (room) {
-        Sel sv;
-        sv.lo = l_lo[i];
-        sv.hi = l_hi[i];
-        sv.len = sel_len_from(alen, l_fw[i]);
-        sv.take = 0;
-        sv.hbase = 0;
-        if (TAKE) {  // hunter.h:349-357: strings are located in set order, forward strand first, while hits < max_locations
-          const u64 M = b.max_locations, occ = sel_occ(sv);
-          const u64 h0 = before < M ? before : M, h1 = before + occ < M ? before + occ : M;
-          sv.hbase = (u32)h0;
-          sv.take = (u32)(h1 - h0);
-        }
-        sv.g = gid;
-        fs.sel[(u64)shard * fs.cap + wbase + r] = sv;
-      }
+      Sel sv;
+      sv.lo = l_lo[i];
+      sv.hi = l_hi[i];
+      sv.len = sel_len_from(meta & 63u, l_fw[i]);
+      sv.take = 0;  // (k_take's)
+      sv.hbase = 0;
+      sv.g = gid;
+      fs.sel[(u64)shard * fs.cap + wbase + l_rank[i]] = sv;
     }
     if (threadIdx.x == 0) {
       fs.nsel[gid] = room ? total : 0u;
@@ -1240,21 +1276,6 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
     if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
     if (nprobe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nprobe);
-  }
-  if (TAKE) {  // k_take's per-query part: the hit count, hunter.h:434, the compact results' word
-    __syncthreads();
-    const u64 q = blockIdx.x;
-    if (threadIdx.x == 0 && q < b.nq) {
-      const u64 M = b.max_locations, tot = s_occ[0] + s_occ[1];
-      const u64 hits = room_all ? (tot < M ? tot : M) : 0ULL;
-      po.qhits[q] = (u32)hits;
-      u32 fl = b.qflags[q];
-      if (hits >= M && !(fl & DG_Q_TOO_SHORT)) {
-        fl |= DG_Q_MAX_MATCHES;
-        b.qflags[q] = fl;
-      }
-      if (b.qinfo) b.qinfo[q] = (fl & 255u) | ((b.qdist[q] & 255u) << 8) | (b.qnondna[q] << 16);
-    }
   }
 }
 

@@ -317,7 +317,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="hunt_d1", choices=["hunt_d1", "hunt_d2", "search", "padlock"],
                     help="which BASELINE.json configuration to run (default: configs[1], the one the metric is quoted on)")
     ap.add_argument("--genome", default="iid", choices=["iid", "repeats"],
@@ -1193,8 +1193,8 @@ def run_extra_configs(a, fm9):
     ms_per_step, roofline of its dominant kernel, cpu_baseline and parity_sample; the headline keys are untouched."""
     import subprocess
     t_start = time.time()
-    plan = [("hunt_d1_repeats", ["--config", "hunt_d1", "--genome", "repeats", "--steps", "5", "--warmup", "2", "--cpu-seconds", "6", "--parity-queries", "300"], False),
-            ("hunt_d2", ["--config", "hunt_d2", "--steps", "3", "--warmup", "1", "--cpu-seconds", "4", "--parity-queries", "300"], True),
+    plan = [("hunt_d1_repeats", ["--config", "hunt_d1", "--genome", "repeats", "--steps", "6", "--warmup", "4", "--cpu-seconds", "6", "--parity-queries", "300"], False),
+            ("hunt_d2", ["--config", "hunt_d2", "--steps", "6", "--warmup", "4", "--cpu-seconds", "4", "--parity-queries", "300"], True),
             # cap-prone primers (VERDICT r02 #9): 25-mers at distance 2 — the maxNeighborhood cap can fire, so every strand is
             # enumerated on the host in the reference's order first (nbhd_host.hpp) and searched as explicit patterns
             ("hunt_d2_25mers", ["--config", "hunt_d2", "--qlen", "25", "--queries", "2000", "--steps", "1", "--warmup", "1", "--cpu-seconds", "6",

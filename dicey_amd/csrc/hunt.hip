@@ -653,6 +653,21 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     ix->cum_cache = cum;
   }
 
+  if (dg_index::SharedHints* sh = ix->shared_hints) {  // what this lane's twin has learnt since this lane's previous batch
+    std::lock_guard<std::mutex> lk(sh->mu);
+    if (sh->valid) {
+      ix->shard_cap_hint = std::max(ix->shard_cap_hint, sh->shard_cap);
+      ix->flat_cap_hint = std::max(ix->flat_cap_hint, sh->flat_cap);
+      ix->hit_cap_hint = std::max(ix->hit_cap_hint, sh->hit_cap);
+      if (sh->fetch_hits) ix->fetch_hits_hint = sh->fetch_hits;  // (the most recent batch's, like the two below)
+      ix->generic_sticky = std::max(ix->generic_sticky, sh->generic_sticky);
+      ix->jobs_sticky = std::max(ix->jobs_sticky, sh->jobs_sticky);
+      ix->generic_hint = ix->generic_sticky > 0;
+      ix->jobs_hint = ix->jobs_sticky > 0;
+      ix->jobs_big_hint = sh->jobs_big;
+      ix->fused_leaves_hint = sh->fused_leaves;
+    }
+  }
   u32 shard_cap = std::max<u32>(ix->shard_cap_hint, (u32)std::max<u64>(64, (16 * (u64)nq + nxs / 8) / NSHARD));
   u64 hit_cap = std::max<u64>(ix->hit_cap_hint, 4 * (u64)nq + 1024);
   // slices of the flat Sel region (k_search1s): what the previous batch's fullest slice needed plus a quarter — kept strings are a
@@ -1205,6 +1220,18 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->cap_queries_device = dev_jobs.size();
   R->cap_queries_host = cs.looked_at;
   R->cap_patterns = nxs;
+  if (dg_index::SharedHints* sh = ix->shared_hints) {  // for the twin lane's next batch
+    std::lock_guard<std::mutex> lk(sh->mu);
+    sh->shard_cap = std::max(sh->shard_cap, ix->shard_cap_hint);
+    sh->flat_cap = std::max(sh->flat_cap, ix->flat_cap_hint);
+    sh->hit_cap = std::max(sh->hit_cap, ix->hit_cap_hint);
+    sh->fetch_hits = ix->fetch_hits_hint;
+    sh->generic_sticky = ix->generic_sticky;
+    sh->jobs_sticky = ix->jobs_sticky;
+    sh->jobs_big = ix->jobs_big_hint;
+    sh->fused_leaves = ix->fused_leaves_hint;
+    sh->valid = true;
+  }
   if (host_timing)
     std::fprintf(stderr, "dicey timing: batch of %zu on stream %p entered at %.0f us: host %.0f us before the synchronisation (last attempt's "
                  "launches included), %.0f us waiting, %.0f us after; device %.3f ms\n", nq, (void*)st, std::fmod(t_enter, 1e8), t_launched - t_enter,
@@ -1539,7 +1566,13 @@ static int submit_batch(const char* who, dg_index* ix, const dg_hunt_params* p, 
   // never leaves the first lane.
   dg_index* const owner = ix;
   if (ix->busy.exchange(true)) {
-    if (!owner->lane2 && dg_index_share(owner, &owner->lane2) != DG_OK) owner->lane2 = nullptr;
+    if (!owner->lane2) {
+      if (dg_index_share(owner, &owner->lane2) != DG_OK) owner->lane2 = nullptr;
+      else {
+        owner->shared_hints = new dg_index::SharedHints;
+        owner->lane2->shared_hints = owner->shared_hints;
+      }
+    }
     ix = owner->lane2;
     if (!ix || ix->busy.exchange(true))
       return fail(DG_EINVAL, "%s: two batches are already in flight on this handle (wait for the older ticket first)", who);

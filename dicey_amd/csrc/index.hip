@@ -744,6 +744,8 @@ dg_index::~dg_index() {
   if (lane2) {
     delete lane2;
     lane2 = nullptr;
+    delete shared_hints;  // (lane2 only pointed at it)
+    shared_hints = nullptr;
   }
   for (void* p : owned) dg::big_free(p, stream);
   if (stream) (void)hipStreamSynchronize(stream);

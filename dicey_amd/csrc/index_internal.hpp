@@ -1,5 +1,6 @@
 // The object behind the opaque dg_index handle.
 #pragma once
+#include <mutex>
 #include <atomic>
 #include "common.hpp"
 #include "devfm.hpp"
@@ -44,6 +45,16 @@ struct dg_index {
   // ABI 5: dg_hunt_submit keeps two batches in flight on one handle; a submission that finds the handle busy runs on this internal
   // second lane (a shared handle: own stream, workspaces, helper thread; created at the first need, closed with the handle)
   dg_index* lane2 = nullptr;
+  // The two lanes learn together (r04): capacities and kernel-family hints live per lane (each lane's batches read and write its own
+  // without locks), and a lane merges the pair's common record in when a batch starts and writes its own back when it ends — a
+  // lane that runs its first batch does not repeat it for a capacity its twin has already learnt.
+  struct SharedHints {
+    std::mutex mu;
+    uint32_t flat_cap = 0, shard_cap = 0, generic_sticky = 0, jobs_sticky = 0;
+    uint64_t hit_cap = 0, jobs_big = 0, fused_leaves = 0, fetch_hits = 0;
+    bool valid = false;
+  };
+  SharedHints* shared_hints = nullptr;  // owned by the handle that owns lane2; lane2 points at the same record
   struct Worker;                      // the helper thread that drives dg_hunt_submit batches (hunt.hip)
   Worker* worker = nullptr;
   void stop_worker();

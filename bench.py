@@ -572,7 +572,7 @@ def main():
                 if (world > 1 or a.gather_single) and not fetch:
                     gather_parts([torch.empty(0, dtype=torch.uint8, device=dev)])
                 return {k_: 0 for k_ in ("nhits", "ext", "leaves", "sa", "win", "tab", "probe", "ops_per_hit", "ms_total", "ms_search",
-                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns")}
+                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns", "t0", "t1", "gen")}
             rp = C.POINTER(_capi.HuntResult)()
             _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(params or p_compact), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
                                             C.c_void_p(bo.data_ptr()), nq, bbytes, fetch, C.byref(rp)))
@@ -580,7 +580,8 @@ def main():
             res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes,
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
-                   "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns}
+                   "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns,
+                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen}
             if (world > 1 or a.gather_single) and not fetch:
                 if R.compact:  # ABI 5 records: position, packed word, d operation words = 12 bytes per hit at distance 1
                     parts = [device_bytes(R.d_hits, R.nhits * 4 * (2 + R.ops_per_hit), dev)]
@@ -605,7 +606,8 @@ def main():
             res = {"nhits": R.nhits, "ext": R.ctr_ext_steps, "leaves": R.ctr_leaves, "sa": R.ctr_sa_reads, "win": R.ctr_win_bytes,
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
-                   "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns}
+                   "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns,
+                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen}
             if world > 1 or a.gather_single:
                 # the lane that ran this batch stays idle until the next step's submit: its result buffers are staged before that
                 gather_parts([device_bytes(R.d_hits, R.nhits * 4 * (2 + R.ops_per_hit), dev)] if R.compact else
@@ -844,6 +846,31 @@ def main():
             k2 = "k_search2p<false>" if (os.environ.get("DICEY_NO_FUSED_SELECT") or os.environ.get("DICEY_NO_FUSED_SELECT2")) else "k_search2p<true>"
             kernel = (k1 if distance == 1 else k2) if flat > 0 else f"k_search<true,{distance}>"
             kernel_ms = flat if flat > 0 else (float(np.mean([r["ms_search"] for r in acc_ph])) if acc_ph else mean("ms_search"))
+            # Two batches in flight: the launches of neighbouring batches overlap, and the sum of their durations counts that time twice.
+            # The time the kernel RAN is the union of the launches' intervals on the lanes' common timeline (dg_hunt_result::t_search_*,
+            # HIP events of the timed steps); per launch it is what the roofline divides by.  launch_ms keeps the plain duration.
+            launch_ms = kernel_ms
+            busy = None
+            if a.in_flight == 2 and flat > 0:
+                by_gen = {}
+                for r in acc:
+                    if r.get("gen"):
+                        by_gen.setdefault(r["gen"], []).append((r["t0"], r["t1"]))
+                n_iv = sum(len(v) for v in by_gen.values())
+                if n_iv >= max(2, (len(acc) * 4) // 5):
+                    union = 0.0
+                    for iv in by_gen.values():
+                        iv.sort()
+                        s0, e0 = iv[0]
+                        for s1, e1 in iv[1:]:
+                            if s1 <= e0:
+                                e0 = max(e0, e1)
+                            else:
+                                union += e0 - s0
+                                s0, e0 = s1, e1
+                        union += e0 - s0
+                    busy = {"launches": n_iv, "union_ms": union, "sum_of_durations_ms": float(sum(e - s_ for v in by_gen.values() for s_, e in v))}
+                    kernel_ms = union / n_iv
             alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
             # the same launch in SURVEY.md §8(d) units: a backward step on c = 2 L(c) rank ops of 24 B on the sdsl layout
             # (L = Huffman code length in the loaded wavelet tree), small reads by their payload
@@ -888,6 +915,9 @@ def main():
                              "table_reads_note": "K-mer table entries (8 B) and, since r04, reads of the preceding-characters array (2 B per suffix of a "
                                                  "narrow interval, <= 32 B) counted together at 8 B each",
                              "bytes_per_filter_probe": BYTES_PER_FILTER_PROBE, "kernel_ms": kernel_ms,
+                             "kernel_ms_is": ("busy time per launch: union of the timed launches' intervals (HIP events on the lanes' common timeline) / launches — "
+                                              "launches of neighbouring batches overlap with two in flight" if busy else "average launch duration (HIP events around the launch)"),
+                             "launch_ms": launch_ms, "busy": busy,
                              "survey_units": {"bytes_per_launch": survey_bytes, "avg_code_len": avg_l,
                                               "achieved": survey_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
                                               "frac": survey_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,

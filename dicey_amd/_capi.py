@@ -53,7 +53,8 @@ class HuntResult(C.Structure):
                 ("ctr_filter_probes", C.c_uint64), ("ms_search_flat", C.c_double), ("owner_", C.c_void_p),
                 ("compact", C.c_uint32), ("nseq", C.c_uint32), ("chits", C.POINTER(C.c_uint32)), ("qinfo", C.POINTER(C.c_uint32)),
                 ("seq_start", C.POINTER(C.c_uint64)), ("expanded_", C.c_void_p),
-                ("ms_cap", C.c_double), ("cap_queries_device", C.c_uint64), ("cap_queries_host", C.c_uint64), ("cap_patterns", C.c_uint64)]
+                ("ms_cap", C.c_double), ("cap_queries_device", C.c_uint64), ("cap_queries_host", C.c_uint64), ("cap_patterns", C.c_uint64),
+                ("t_search_begin_ms", C.c_double), ("t_search_end_ms", C.c_double), ("t_base_gen", C.c_uint32), ("t_reserved_", C.c_uint32)]
 
 
 class SearchParams(C.Structure):

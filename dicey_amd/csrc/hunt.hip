@@ -653,8 +653,23 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     ix->cum_cache = cum;
   }
 
+  u32 base_gen = 0;
+  hipEvent_t base_ev = nullptr;
   if (dg_index::SharedHints* sh = ix->shared_hints) {  // what this lane's twin has learnt since this lane's previous batch
     std::lock_guard<std::mutex> lk(sh->mu);
+    // the lanes' common timeline: this lane's stream is idle here (its previous batch has been synchronised), so a base recorded on it
+    // completes at once; the other base stays valid for the twin's batch in flight
+    const double now = host_us();
+    if (!sh->base_gen || now - sh->base_host_us > 4e6) {
+      const u32 g = sh->base_gen + 1;
+      if (!sh->ev_base[g & 1] && hipEventCreate(&sh->ev_base[g & 1]) != hipSuccess) sh->ev_base[g & 1] = nullptr;
+      if (sh->ev_base[g & 1] && hipEventRecord(sh->ev_base[g & 1], st) == hipSuccess) {
+        sh->base_gen = g;
+        sh->base_host_us = now;
+      }
+    }
+    base_gen = sh->base_gen;
+    base_ev = base_gen ? sh->ev_base[base_gen & 1] : nullptr;
     if (sh->valid) {
       ix->shard_cap_hint = std::max(ix->shard_cap_hint, sh->shard_cap);
       ix->flat_cap_hint = std::max(ix->flat_cap_hint, sh->flat_cap);
@@ -1220,6 +1235,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->cap_queries_device = dev_jobs.size();
   R->cap_queries_host = cs.looked_at;
   R->cap_patterns = nxs;
+  R->t_base_gen = 0;
+  R->t_search_begin_ms = R->t_search_end_ms = 0.0;
+  if (base_ev && (b.fastK || b.fast2K)) {
+    float t0 = 0.f, t1 = 0.f;
+    if (hipEventElapsedTime(&t0, base_ev, ix->ev[1]) == hipSuccess && hipEventElapsedTime(&t1, base_ev, ix->ev[8]) == hipSuccess && t0 >= 0.f) {
+      R->t_search_begin_ms = t0;
+      R->t_search_end_ms = t1;
+      R->t_base_gen = base_gen;
+    }
+  }
   if (dg_index::SharedHints* sh = ix->shared_hints) {  // for the twin lane's next batch
     std::lock_guard<std::mutex> lk(sh->mu);
     sh->shard_cap = std::max(sh->shard_cap, ix->shard_cap_hint);

@@ -744,6 +744,9 @@ dg_index::~dg_index() {
   if (lane2) {
     delete lane2;
     lane2 = nullptr;
+    if (shared_hints)
+      for (hipEvent_t e : shared_hints->ev_base)
+        if (e) (void)hipEventDestroy(e);
     delete shared_hints;  // (lane2 only pointed at it)
     shared_hints = nullptr;
   }

@@ -53,6 +53,10 @@ struct dg_index {
     uint32_t flat_cap = 0, shard_cap = 0, generic_sticky = 0, jobs_sticky = 0;
     uint64_t hit_cap = 0, jobs_big = 0, fused_leaves = 0, fetch_hits = 0;
     bool valid = false;
+    // the lanes' common timeline (dg_hunt_result::t_search_*): two base events used in turn, a new one every few seconds
+    hipEvent_t ev_base[2] = {nullptr, nullptr};
+    uint32_t base_gen = 0;
+    double base_host_us = 0;
   };
   SharedHints* shared_hints = nullptr;  // owned by the handle that owns lane2; lane2 points at the same record
   struct Worker;                      // the helper thread that drives dg_hunt_submit batches (hunt.hip)

@@ -214,6 +214,12 @@ typedef struct {
   /* measurement: the capped-neighbourhood stage in front of the batch (hunt_cap.hpp / nbhd_host.hpp), host wall clock, and what it did */
   double ms_cap;              /* 0 when no query of the batch could reach the cap */
   uint64_t cap_queries_device, cap_queries_host, cap_patterns; /* queries enumerated on the device / on the host, explicit patterns searched */
+  /* Where the batch's flat search kernel ran on the handle's timeline (r04): begin / end in ms since a base event the handle's two lanes
+   * share.  With two batches in flight the launches of neighbouring batches overlap, and the time the kernel RAN is the union of these
+   * intervals, not the sum of their lengths (bench.py's roofline).  t_base_gen: intervals of equal generation share a base (the
+   * library takes a new base every few seconds to keep float precision); 0 = no timeline (one lane only so far, or no flat kernel). */
+  double t_search_begin_ms, t_search_end_ms;
+  uint32_t t_base_gen, t_reserved_;
 } dg_hunt_result;
 
 /* One compact hit as a dg_hit (query = the query it belongs to, from hit_off) and a pointer to its ops words. */

@@ -275,8 +275,11 @@ def test_device_submit_keeps_two_batches_in_flight(gpu_small, small_genome):
             off.append(off[-1] + len(q))
         batches.append((torch.frombuffer(bytearray(qb), dtype=torch.uint8).cuda(), torch.tensor(off, dtype=torch.int64).cuda(), len(qs), len(qb)))
 
+    timeline = []
+
     def payload(rp):
         R = rp.contents
+        timeline.append((R.t_base_gen, R.t_search_begin_ms, R.t_search_end_ms))
         words = 2 + R.ops_per_hit
         out = (R.nhits, bytes(C.string_at(R.chits, R.nhits * 4 * words)), bytes(C.string_at(R.qinfo, R.nq * 4)),
                bytes(C.string_at(C.cast(R.hit_off, C.c_void_p), (R.nq + 1) * 8)))
@@ -309,6 +312,10 @@ def test_device_submit_keeps_two_batches_in_flight(gpu_small, small_genome):
         _capi.check(L, L.dg_hunt_wait(open_.pop(0), C.byref(rp)))
         got.append(payload(rp))
     assert got == want
+    # the lanes' common timeline: once the second lane exists every batch reports where its search kernel ran, in submit order per lane
+    on_line = [t for t in timeline[len(batches) + 1:] if t[0]]
+    assert len(on_line) >= len(batches) - 2 and all(0 <= b0 <= e0 for _, b0, e0 in on_line)
+    assert all(x[1] <= y[1] for x, y in zip(on_line, on_line[1:]) if x[0] == y[0])  # collected in submit order = start order
 
 
 def test_repeat_rich_strings_use_the_workgroup_locate(tmp_path):

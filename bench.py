@@ -11,6 +11,11 @@ dg_index_open — the same path a `dicey index` file takes.
 A step = one pass of the whole pipeline over the rank's batch, which is resident in HBM (hunt) or handed over as host
 buffers (search, padlock: their entry points take host buffers) when the timed region starts; hit records stay in HBM
 (N=1) or are gathered to rank 0 over RCCL (N>1, inside the timed region).  One process per GPU; weak scaling.
+Hunt configurations keep TWO batches in flight per GPU (`--in-flight 2`: dg_hunt_device_submit / dg_hunt_wait on the handle's two
+lanes; step k is submitted, step k - 1 collected; exactly K batches start and end inside the timed region).  The roofline then
+divides the dominant kernel's algorithmic bytes by its BUSY time per launch — the union of the timed launches' intervals on the
+lanes' common timeline (HIP events, dg_hunt_result::t_search_*) over the number of launches; `roofline.launch_ms` is the plain
+duration of a launch (longer: neighbouring launches overlap), `roofline.one_in_flight` the kernel alone.
 
 Other configurations of BASELINE.json, same contract, one JSON line each:
   --config hunt_d2   configs[3]: 20-mers at edit distance 2 (100 000 per GPU and step)

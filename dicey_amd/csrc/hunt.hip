@@ -655,7 +655,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
 
   u32 base_gen = 0;
   hipEvent_t base_ev = nullptr;
-  if (dg_index::SharedHints* sh = ix->shared_hints) {  // what this lane's twin has learnt since this lane's previous batch
+  if (dg_index::SharedHints* sh = ix->shared_hints.load()) {  // what this lane's twin has learnt since this lane's previous batch
     std::lock_guard<std::mutex> lk(sh->mu);
     // the lanes' common timeline: this lane's stream is idle here (its previous batch has been synchronised), so a base recorded on it
     // completes at once; the other base stays valid for the twin's batch in flight
@@ -1245,7 +1245,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       R->t_base_gen = base_gen;
     }
   }
-  if (dg_index::SharedHints* sh = ix->shared_hints) {  // for the twin lane's next batch
+  if (dg_index::SharedHints* sh = ix->shared_hints.load()) {  // for the twin lane's next batch
     std::lock_guard<std::mutex> lk(sh->mu);
     sh->shard_cap = std::max(sh->shard_cap, ix->shard_cap_hint);
     sh->flat_cap = std::max(sh->flat_cap, ix->flat_cap_hint);
@@ -1594,8 +1594,9 @@ static int submit_batch(const char* who, dg_index* ix, const dg_hunt_params* p, 
     if (!owner->lane2) {
       if (dg_index_share(owner, &owner->lane2) != DG_OK) owner->lane2 = nullptr;
       else {
-        owner->shared_hints = new dg_index::SharedHints;
-        owner->lane2->shared_hints = owner->shared_hints;
+        dg_index::SharedHints* sh = new dg_index::SharedHints;
+        owner->lane2->shared_hints = sh;
+        owner->shared_hints = sh;
       }
     }
     ix = owner->lane2;

@@ -744,11 +744,11 @@ dg_index::~dg_index() {
   if (lane2) {
     delete lane2;
     lane2 = nullptr;
-    if (shared_hints)
-      for (hipEvent_t e : shared_hints->ev_base)
+    SharedHints* sh = shared_hints.exchange(nullptr);  // (lane2 only pointed at it)
+    if (sh)
+      for (hipEvent_t e : sh->ev_base)
         if (e) (void)hipEventDestroy(e);
-    delete shared_hints;  // (lane2 only pointed at it)
-    shared_hints = nullptr;
+    delete sh;
   }
   for (void* p : owned) dg::big_free(p, stream);
   if (stream) (void)hipStreamSynchronize(stream);

@@ -58,7 +58,9 @@ struct dg_index {
     uint32_t base_gen = 0;
     double base_host_us = 0;
   };
-  SharedHints* shared_hints = nullptr;  // owned by the handle that owns lane2; lane2 points at the same record
+  // owned by the handle that owns lane2, lane2 points at the same record; atomic: created by the submitting thread while the first
+  // lane's helper thread may be finishing a batch
+  std::atomic<SharedHints*> shared_hints{nullptr};
   struct Worker;                      // the helper thread that drives dg_hunt_submit batches (hunt.hip)
   Worker* worker = nullptr;
   void stop_worker();

@@ -982,7 +982,10 @@ __global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o
             //  share three lines: 161 M instead of 175 M fabric reads per launch, but the L2 hits between neighbouring lanes' probes go
             //  (175 M -> 46 M) and the kernel takes 8.93 instead of 8.20 ms; profiles/r04_d2b_pmc_summary.csv.  Not kept.)
             u32 mask8 = 0;
-            // all addresses first, then the eight loads back to back, then the bits
+            // all addresses first, then the eight loads back to back, then the bits.  (r04 also measured the rounds as an explicit
+            // software pipeline — round k + 1's loads issued before round k's words are consumed, no branches inside a round: 155
+            // VGPRs, three wavefronts per SIMD, 10.8 ms; held to 128 VGPRs with 64 B of scratch 9.7 ms; this form 9.3 ms on the same
+            // box.  tools/r04_call19.sh.  Not kept: residency is worth more to this kernel than loads in flight per wavefront.)
             const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
             const u32* addr[8];
             u32 bit[8], word[8], valid = 0, probe = 0;

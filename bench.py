@@ -11,8 +11,8 @@ dg_index_open — the same path a `dicey index` file takes.
 A step = one pass of the whole pipeline over the rank's batch, which is resident in HBM (hunt) or handed over as host
 buffers (search, padlock: their entry points take host buffers) when the timed region starts; hit records stay in HBM
 (N=1) or are gathered to rank 0 over RCCL (N>1, inside the timed region).  One process per GPU; weak scaling.
-Hunt configurations keep TWO batches in flight per GPU (`--in-flight 2`: dg_hunt_device_submit / dg_hunt_wait on the handle's two
-lanes; step k is submitted, step k - 1 collected; exactly K batches start and end inside the timed region).  The roofline then
+Hunt configurations keep THREE batches in flight per GPU (`--in-flight 3`: dg_hunt_device_submit / dg_hunt_wait on the handle's
+lanes; step k is submitted, step k - 2 collected; exactly K batches start and end inside the timed region).  The roofline then
 divides the dominant kernel's algorithmic bytes by its BUSY time per launch — the union of the timed launches' intervals on the
 lanes' common timeline (HIP events, dg_hunt_result::t_search_*) over the number of launches; `roofline.launch_ms` is the plain
 duration of a launch (longer: neighbouring launches overlap), `roofline.one_in_flight` the kernel alone.
@@ -322,7 +322,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--config", default="hunt_d1", choices=["hunt_d1", "hunt_d2", "search", "padlock"],
                     help="which BASELINE.json configuration to run (default: configs[1], the one the metric is quoted on)")
     ap.add_argument("--genome", default="iid", choices=["iid", "repeats"],
@@ -353,9 +353,9 @@ def main():
                     help="testing aid for a 1-GPU box: a process group of ONE rank on the chosen backend, and every hunt step stages and "
                          "gathers its hit list exactly as ranks of an N > 1 job do (the RCCL path: staging on the library's stream, the "
                          "size agreement, the gather) — n_gpus stays 1")
-    ap.add_argument("--in-flight", type=int, default=2, choices=(1, 2),
-                    help="hunt configs: batches in flight per GPU in the timed region: 2 = dg_hunt_device_submit / dg_hunt_wait on the handle's "
-                         "two lanes (step k is submitted, step k - 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a)")
+    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3),
+                    help="hunt configs: batches in flight per GPU in the timed region: 2 or 3 = dg_hunt_device_submit / dg_hunt_wait on the handle's "
+                         "lanes (step k is submitted, step k - n + 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a)")
     ap.add_argument("--batches", type=int, default=16,
                     help="hunt configs: distinct query batches resident in HBM that the warm-up and timed steps cycle through (step k "
                          "searches batch k mod B; hunter.h:291 searches every query once, so the headline never replays a batch within "
@@ -630,7 +630,7 @@ def main():
             _capi.check(L, L.dg_hunt_device_submit(ix.handle, C.byref(p_compact), sl, len(seqlen), C.c_void_p(bq.data_ptr()), C.c_void_p(bo.data_ptr()),
                                                    nq, bbytes, 0, C.byref(tk)))
             inflight.append(tk)
-            return collect(inflight.pop(0)) if len(inflight) > 1 else None
+            return collect(inflight.pop(0)) if len(inflight) >= a.in_flight else None
 
         def flush_pipe():
             out_ = []
@@ -638,7 +638,7 @@ def main():
                 out_.append(collect(inflight.pop(0)))
             return out_
 
-        if a.in_flight == 2:
+        if a.in_flight >= 2:
             acc, elapsed, gathered = timed(step_pipe, flush_pipe)
         else:
             acc, elapsed, gathered = timed(step)
@@ -681,7 +681,7 @@ def main():
                                           "note": "the r01-r03 measurement: one batch replayed K times (its 310 MB of index lines are "
                                                   "re-read every step); the headline cycles through %d distinct batches" % len(dev_batches)}
             rot["on"] = True
-        if world == 1 and a.in_flight == 2:
+        if world == 1 and a.in_flight >= 2:
             # the r01-r04a form beside the headline: one batch at a time through dg_hunt_device (rotating batches)
             for _ in range(2):
                 step()
@@ -856,7 +856,7 @@ def main():
             # HIP events of the timed steps); per launch it is what the roofline divides by.  launch_ms keeps the plain duration.
             launch_ms = kernel_ms
             busy = None
-            if a.in_flight == 2 and flat > 0:
+            if a.in_flight >= 2 and flat > 0:
                 by_gen = {}
                 for r in acc:
                     if r.get("gen"):
@@ -907,8 +907,8 @@ def main():
                            "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
                            "distinct_batches": len(dev_batches),
                            "results": "compact records (DG_HUNT_COMPACT: 8 + 4 d bytes per hit) left in HBM (N = 1) / gathered to rank 0 (N > 1)",
-                           "in_flight": (f"{a.in_flight} batches per GPU (dg_hunt_device_submit / dg_hunt_wait on the handle's two lanes: step k is submitted, "
-                                         "then step k - 1 collected; K batches start and end inside the timed region)" if a.in_flight == 2
+                           "in_flight": (f"{a.in_flight} batches per GPU (dg_hunt_device_submit / dg_hunt_wait on the handle's lanes: step k is submitted, "
+                                         f"then step k - {a.in_flight - 1} collected; K batches start and end inside the timed region)" if a.in_flight >= 2
                                          else "1 batch per GPU (dg_hunt_device)"),
                            "stream": f"step k searches batch k mod {len(dev_batches)} of {len(dev_batches)} distinct batches resident in HBM "
                                      "(seeds 42 + 1000 b), warm-up included" if len(dev_batches) > 1 else "one batch replayed every step"},
@@ -1228,8 +1228,8 @@ def run_extra_configs(a, fm9):
     ms_per_step, roofline of its dominant kernel, cpu_baseline and parity_sample; the headline keys are untouched."""
     import subprocess
     t_start = time.time()
-    plan = [("hunt_d1_repeats", ["--config", "hunt_d1", "--genome", "repeats", "--steps", "6", "--warmup", "4", "--cpu-seconds", "6", "--parity-queries", "300"], False),
-            ("hunt_d2", ["--config", "hunt_d2", "--steps", "6", "--warmup", "4", "--cpu-seconds", "4", "--parity-queries", "300"], True),
+    plan = [("hunt_d1_repeats", ["--config", "hunt_d1", "--genome", "repeats", "--steps", "9", "--warmup", "6", "--cpu-seconds", "6", "--parity-queries", "300"], False),
+            ("hunt_d2", ["--config", "hunt_d2", "--steps", "9", "--warmup", "6", "--cpu-seconds", "4", "--parity-queries", "300"], True),
             # cap-prone primers (VERDICT r02 #9): 25-mers at distance 2 — the maxNeighborhood cap can fire, so every strand is
             # enumerated on the host in the reference's order first (nbhd_host.hpp) and searched as explicit patterns
             ("hunt_d2_25mers", ["--config", "hunt_d2", "--qlen", "25", "--queries", "2000", "--steps", "1", "--warmup", "1", "--cpu-seconds", "6",

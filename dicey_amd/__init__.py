@@ -204,7 +204,7 @@ class FmIndex:
     def hunt_submit(self, queries: Sequence[str], seqlen: Sequence[int], distance: int = 1, hamming: bool = False,
                     forward_only: bool = False, max_locations: int = 1000, max_neighborhood: int = 10000, compact=None,
                     max_query_len: int = 0):
-        """dg_hunt_submit: the batch runs on a helper thread of the library; collect with hunt_wait (two per handle at a time,
+        """dg_hunt_submit: the batch runs on a helper thread of the library; collect with hunt_wait (three per handle at a time,
         waited for in the order they were submitted)."""
         buf, off = _pack([q.encode("latin-1") if isinstance(q, str) else q for q in queries])
         sl = (C.c_uint32 * len(seqlen))(*seqlen)

@@ -1586,22 +1586,33 @@ static int submit_batch(const char* who, dg_index* ix, const dg_hunt_params* p, 
                         dg_hunt_ticket** out) {
   const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
   const double t_sub = tm ? host_us() : 0.0;
-  // two lanes per handle (ABI 5): the handle itself while it is idle, else its internal second lane (a shared handle: own stream,
-  // workspaces and helper thread on the same resident index; created at the first need).  A caller that keeps one batch in flight
-  // never leaves the first lane.
+  // Lanes of a handle (ABI 5: two, r04: three): the handle itself while it is idle, else the first idle internal lane (a shared
+  // handle: own stream, workspaces and helper thread on the same resident index; created at the first need).  A caller that keeps
+  // one batch in flight never leaves the first lane.  Two lanes leave the search kernel idle a quarter of the time (both batches in
+  // their launch-bound tails at once: profiles/r04c_k_search_launches.json); the third fills that.
   dg_index* const owner = ix;
   if (ix->busy.exchange(true)) {
-    if (!owner->lane2) {
-      if (dg_index_share(owner, &owner->lane2) != DG_OK) owner->lane2 = nullptr;
-      else {
-        dg_index::SharedHints* sh = new dg_index::SharedHints;
-        owner->lane2->shared_hints = sh;
-        owner->shared_hints = sh;
+    ix = nullptr;
+    for (dg_index*& l : owner->lanes) {
+      if (!l) {
+        if (dg_index_share(owner, &l) != DG_OK) {
+          l = nullptr;
+          break;
+        }
+        dg_index::SharedHints* sh = owner->shared_hints.load();
+        if (!sh) {
+          sh = new dg_index::SharedHints;
+          owner->shared_hints = sh;
+        }
+        l->shared_hints = sh;
+      }
+      if (!l->busy.exchange(true)) {
+        ix = l;
+        break;
       }
     }
-    ix = owner->lane2;
-    if (!ix || ix->busy.exchange(true))
-      return fail(DG_EINVAL, "%s: two batches are already in flight on this handle (wait for the older ticket first)", who);
+    if (!ix)
+      return fail(DG_EINVAL, "%s: %d batches are already in flight on this handle (wait for the oldest ticket first)", who, 1 + dg_index::NEXTRA);
   }
   dg_hunt_ticket* t = nullptr;
   try {

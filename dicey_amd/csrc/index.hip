@@ -741,10 +741,12 @@ using namespace dg;
 
 dg_index::~dg_index() {
   stop_worker();
-  if (lane2) {
-    delete lane2;
-    lane2 = nullptr;
-    SharedHints* sh = shared_hints.exchange(nullptr);  // (lane2 only pointed at it)
+  if (lanes[0]) {  // the owner of the internal lanes (they only point at its hints record)
+    for (dg_index*& l : lanes) {
+      delete l;
+      l = nullptr;
+    }
+    SharedHints* sh = shared_hints.exchange(nullptr);
     if (sh)
       for (hipEvent_t e : sh->ev_base)
         if (e) (void)hipEventDestroy(e);

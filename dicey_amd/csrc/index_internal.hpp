@@ -44,7 +44,8 @@ struct dg_index {
   std::atomic<bool> busy{false};      // a dg_hunt_submit batch is in flight on this handle (lane)
   // ABI 5: dg_hunt_submit keeps two batches in flight on one handle; a submission that finds the handle busy runs on this internal
   // second lane (a shared handle: own stream, workspaces, helper thread; created at the first need, closed with the handle)
-  dg_index* lane2 = nullptr;
+  static constexpr int NEXTRA = 2;            // internal lanes beside the handle itself: three batches in flight (r04: two)
+  dg_index* lanes[NEXTRA] = {nullptr, nullptr};
   // The two lanes learn together (r04): capacities and kernel-family hints live per lane (each lane's batches read and write its own
   // without locks), and a lane merges the pair's common record in when a batch starts and writes its own back when it ends — a
   // lane that runs its first batch does not repeat it for a capacity its twin has already learnt.
@@ -58,7 +59,7 @@ struct dg_index {
     uint32_t base_gen = 0;
     double base_host_us = 0;
   };
-  // owned by the handle that owns lane2, lane2 points at the same record; atomic: created by the submitting thread while the first
+  // owned by the handle that owns the internal lanes, which point at the same record; atomic: created by the submitting thread while the first
   // lane's helper thread may be finishing a batch
   std::atomic<SharedHints*> shared_hints{nullptr};
   struct Worker;                      // the helper thread that drives dg_hunt_submit batches (hunt.hip)

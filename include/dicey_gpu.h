@@ -249,9 +249,9 @@ void dg_hunt_result_free(dg_hunt_result* r);
 
 /* Asynchronous form: dg_hunt_submit returns as soon as the batch is handed to the library (the query buffers are copied, the
  * caller may reuse them at once); dg_hunt_wait blocks until the result is on the host (a pinned block, like dg_hunt's) and releases
- * the ticket.  ABI 5: up to TWO batches may be in flight on one handle (the library runs them on two internal lanes — own stream,
+ * the ticket.  ABI 5: up to THREE batches may be in flight on one handle (the library runs them on internal lanes — own stream,
  * own workspaces, own helper thread each, the same resident index — so uploads, kernels and downloads of neighbouring batches
- * overlap): submit A, submit B, wait A, submit C, wait B, ...  Tickets are waited for in the order they were submitted; a third
+ * overlap): submit A, submit B, wait A, submit C, wait B, ...  Tickets are waited for in the order they were submitted; a fourth
  * submit before the first wait fails with DG_EINVAL.  Every ticket must be waited for before its handle is closed. */
 typedef struct dg_hunt_ticket dg_hunt_ticket;
 int dg_hunt_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
@@ -266,10 +266,10 @@ int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out);
 int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
                    const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out);
 /* Asynchronous form of dg_hunt_device (r04), on the same two lanes as dg_hunt_submit and collected with dg_hunt_wait: a caller whose
- * batches are resident in HBM keeps two in flight — submit A, submit B, wait A, submit C, wait B, ... — so that one batch's
- * launch-bound tail (locate, verify, the summary's read-back) runs beside the next batch's search kernel.  The device buffers must
- * stay untouched until the ticket has been waited for; a result left in HBM (fetch = 0) is valid until the second submit after
- * its own (the lanes alternate).  Replaces nothing in the reference: hunter.h:291 walks its queries one by one. */
+ * batches are resident in HBM keeps two or three in flight — submit A, submit B, wait A, submit C, wait B, ... — so that one batch's
+ * launch-bound tail (locate, verify, the summary's read-back) runs beside another batch's search kernel.  The device buffers must
+ * stay untouched until the ticket has been waited for; a result left in HBM (fetch = 0) is valid until the next submit after its
+ * own wait (the lane that ran it is idle until then).  Replaces nothing in the reference: hunter.h:291 walks its queries one by one. */
 int dg_hunt_device_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
                           const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_ticket** out);
 

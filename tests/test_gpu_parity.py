@@ -257,8 +257,8 @@ def test_device_pointer_view_for_the_rccl_gather(gpu_small, small_genome):
 
 
 def test_device_submit_keeps_two_batches_in_flight(gpu_small, small_genome):
-    """dg_hunt_device_submit / dg_hunt_wait: six different batches resident in HBM through the handle's two lanes (submit k,
-    collect k - 1), fetched hits identical to dg_hunt_device's of the same batch; a third submit before a wait is refused, and so
+    """dg_hunt_device_submit / dg_hunt_wait: six different batches resident in HBM through the handle's three lanes (submit k,
+    collect k - 2), fetched hits identical to dg_hunt_device's of the same batch; a fourth submit before a wait is refused, and so
     is dg_hunt_device while a ticket is open."""
     import ctypes as C
     import torch
@@ -297,13 +297,13 @@ def test_device_submit_keeps_two_batches_in_flight(gpu_small, small_genome):
         tk = C.c_void_p()
         _capi.check(L, L.dg_hunt_device_submit(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()), n, nb, 1, C.byref(tk)))
         open_.append(tk)
-        if k == 1:  # both lanes taken
+        if k == 2:  # all three lanes taken
             t3 = C.c_void_p()
             assert L.dg_hunt_device_submit(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()), n, nb, 1,
                                            C.byref(t3)) != 0 and not t3.value
             rp = C.POINTER(_capi.HuntResult)()
             assert L.dg_hunt_device(gpu_small.handle, C.byref(p), sl, 3, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_off.data_ptr()), n, nb, 1, C.byref(rp)) != 0
-        if len(open_) > 1:
+        if len(open_) > 2:
             rp = C.POINTER(_capi.HuntResult)()
             _capi.check(L, L.dg_hunt_wait(open_.pop(0), C.byref(rp)))
             got.append(payload(rp))
@@ -314,7 +314,7 @@ def test_device_submit_keeps_two_batches_in_flight(gpu_small, small_genome):
     assert got == want
     # the lanes' common timeline: once the second lane exists every batch reports where its search kernel ran
     on_line = [t for t in timeline[len(batches) + 1:] if t[0]]
-    assert len(on_line) >= len(batches) - 2 and all(0 <= b0 <= e0 for _, b0, e0 in on_line)
+    assert len(on_line) >= len(batches) - 3 and all(0 <= b0 <= e0 for _, b0, e0 in on_line)
     assert max(e0 for _, _, e0 in on_line) > min(b0 for _, b0, _ in on_line)
 
 
@@ -464,8 +464,8 @@ def test_device_entry_point_rechecks_a_cached_length_bound(gpu_small, small_geno
 
 
 def test_submit_wait_on_two_handles_equals_the_blocking_call(gpu_small, small_genome):
-    """dg_hunt_submit / dg_hunt_wait: two batches in flight on ONE handle (ABI 5: the library's two internal lanes) and, as in
-    ABI 4, on a second handle of the same resident index; a third submit on a handle with two in flight is refused, a blocking
+    """dg_hunt_submit / dg_hunt_wait: three batches in flight on ONE handle (ABI 5: the library's internal lanes) and, as in
+    ABI 4, on a second handle of the same resident index; a fourth submit on a handle with three in flight is refused, a blocking
     call on a handle with a batch in flight as well; results equal dg_hunt's in both result forms."""
     import dicey_amd
     g = small_genome
@@ -483,14 +483,16 @@ def test_submit_wait_on_two_handles_equals_the_blocking_call(gpu_small, small_ge
             cpt = rnd != 1
             ta = gpu_small.hunt_submit(qa, g["seqlen"], distance=1, compact=cpt)
             tb = gpu_small.hunt_submit(qb, g["seqlen"], distance=2, compact=cpt)      # second lane of the same handle
+            te = gpu_small.hunt_submit(qc, g["seqlen"], distance=1, hamming=True, compact=cpt)  # third lane (r04)
             tc = other.hunt_submit(qc, g["seqlen"], distance=1, hamming=True, compact=cpt, max_query_len=64)
             with pytest.raises(dicey_amd.DgError):
-                gpu_small.hunt_submit(qb, g["seqlen"], distance=1)  # two batches per handle
+                gpu_small.hunt_submit(qb, g["seqlen"], distance=1)  # three batches per handle
             with pytest.raises(dicey_amd.DgError):
                 gpu_small.hunt(qb, g["seqlen"], distance=1)         # the blocking call needs an idle handle
             assert key(gpu_small.hunt_wait(ta)) == want_a
             td = gpu_small.hunt_submit(qc, g["seqlen"], distance=1, hamming=True, compact=cpt)  # lane of `ta` is free again
             assert key(gpu_small.hunt_wait(tb)) == want_b
+            assert key(gpu_small.hunt_wait(te)) == want_c
             assert key(other.hunt_wait(tc)) == want_c
             assert key(gpu_small.hunt_wait(td)) == want_c
         with pytest.raises(dicey_amd.DgError):  # a bound that does not hold fails the batch loudly
@@ -522,8 +524,8 @@ def test_fused_select_and_its_hand_over_to_the_generic_kernels(small_genome, mon
                        (pure[:200], dict(distance=1, hamming=True)), (low, dict(distance=1)), (mixed, dict(distance=1, hamming=True)),
                        (pure[:100], dict(distance=1, max_locations=2)), (pure[:64], dict(distance=1, forward_only=True))]:
             _compare(ix, orc, g, qs, **kw)
-        # edit distance 2 on the same handle (generic select kernels; r03 measured the select stage inside k_search2p as well:
-        # 10.9 ms against 8.3 + 2.4 ms, no gain, removed)
+        # edit distance 2 on the same handle (r04: the select stage inside k_search2p; DICEY_FUSED_LCAP lowers its list's capacity too,
+        # so the lcap forms hand every group over to the generic select kernels)
         O.fast_neighbors(True)
         try:
             short = [q[:m] for q, m in zip(pure[:24], [14, 16, 18, 20] * 6)]

@@ -709,7 +709,7 @@ def main():
                                                 "packed word and d operation words (dg_chit_unpack / dg_hit_rows rebuild every DnaHit), per "
                                                 "query one word of flags + its hit count, in ONE copy into a pinned block of the library's pool",
                                         "bytes_per_step": int(rlast["nhits"]) * 4 * words + 8 * nq}
-            # host to host: dg_hunt_submit / dg_hunt_wait on ONE handle, two batches in flight on the library's two internal lanes —
+            # host to host: dg_hunt_submit / dg_hunt_wait on ONE handle, as many batches in flight as the timed region keeps, on the library's internal lanes —
             # query bytes of 16 distinct host batches go up, compact results come back, every step; one Python thread drives it
             try:
                 host_batches = []
@@ -729,14 +729,15 @@ def main():
                     nh = rp2.contents.nhits
                     L.dg_hunt_result_free(rp2)
                     return nh
-                for k in range(0, 8, 2):  # warm BOTH lanes (the second one exists only once two batches are in flight: workspaces, pinned blocks)
-                    ta, tb = submit(k), submit(k + 1)
-                    wait(ta)
-                    wait(tb)
+                depth = max(2, a.in_flight)
+                for k in range(0, 4 * depth, depth):  # warm EVERY lane (a lane exists only once that many batches are in flight: workspaces, pinned blocks)
+                    ts = [submit(k + i) for i in range(depth)]
+                    for t in ts:
+                        wait(t)
                 torch.cuda.synchronize()
                 nst = max(a.steps, 2 * len(host_batches))
                 tp = time.perf_counter()
-                inflight = [submit(0), submit(1)]
+                inflight = [submit(i) for i in range(depth)]
                 for k in range(nst):
                     nh = wait(inflight[k])
                     if len(inflight) < nst:
@@ -744,9 +745,10 @@ def main():
                 dth = time.perf_counter() - tp
                 extras["host_to_host_pipelined"] = {
                     "value": nq * nst / dth, "unit": "primers/s", "ms_per_step": dth / nst * 1e3, "steps": nst, "hits_last_step": int(nh),
-                    "note": "dg_hunt_submit / dg_hunt_wait on one handle (ABI 5: two batches in flight on the library's two internal "
+                    "batches_in_flight": depth,
+                    "note": "dg_hunt_submit / dg_hunt_wait on one handle (ABI 5: %d batches in flight on the library's internal "
                             "lanes), DG_HUNT_COMPACT, max_query_len given: query bytes of %d distinct host batches up, compact results "
-                            "down into pinned blocks; one Python thread drives it" % len(host_batches)}
+                            "down into pinned blocks; one Python thread drives it" % (depth, len(host_batches))}
             except Exception as e:  # never lose the headline over an extra
                 extras["host_to_host_pipelined"] = {"error": repr(e)}
             cli_job = (queries, distance)  # measured in the common tail, after this process has released its own index

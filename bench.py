@@ -48,6 +48,23 @@ GRCH38_FREQ = (0.295, 0.205, 0.205, 0.295)  # A C G T
 METRIC = "primers/sec on GRCh38 edit-dist 1 at 1/2/4/8 GPUs; HBM GB/s vs peak"
 
 
+def union_of_intervals(iv) -> float:
+    """Total length covered by a list of (begin, end) intervals — the time a kernel RAN when its launches overlap (several batches in
+    flight): the roofline divides by this per launch, not by the sum of the launches' durations."""
+    total = 0.0
+    cur_b = cur_e = None
+    for b, e in sorted(iv):
+        if cur_e is None or b > cur_e:
+            if cur_e is not None:
+                total += cur_e - cur_b
+            cur_b, cur_e = b, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        total += cur_e - cur_b
+    return total
+
+
 def synth_genome(total_len: int, nchr: int, seed: int, device, repeats: bool = False) -> (torch.Tensor, list):
     """Text SEQ1\\nSEQ2\\n...\\n on the device (uint8) and per-sequence lengths."""
     g = torch.Generator(device=device)
@@ -865,17 +882,7 @@ def main():
                         by_gen.setdefault(r["gen"], []).append((r["t0"], r["t1"]))
                 n_iv = sum(len(v) for v in by_gen.values())
                 if n_iv >= max(2, (len(acc) * 4) // 5):
-                    union = 0.0
-                    for iv in by_gen.values():
-                        iv.sort()
-                        s0, e0 = iv[0]
-                        for s1, e1 in iv[1:]:
-                            if s1 <= e0:
-                                e0 = max(e0, e1)
-                            else:
-                                union += e0 - s0
-                                s0, e0 = s1, e1
-                        union += e0 - s0
+                    union = sum(union_of_intervals(iv) for iv in by_gen.values())
                     busy = {"launches": n_iv, "union_ms": union, "sum_of_durations_ms": float(sum(e - s_ for v in by_gen.values() for s_, e in v))}
                     kernel_ms = union / n_iv
             alg_bytes = ext * BYTES_PER_EXT + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE

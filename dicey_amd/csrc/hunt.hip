@@ -655,10 +655,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
 
   u32 base_gen = 0;
   hipEvent_t base_ev = nullptr;
-  if (dg_index::SharedHints* sh = ix->shared_hints.load()) {  // what this lane's twin has learnt since this lane's previous batch
+  if (dg_index::SharedHints* sh = ix->shared_hints.load()) {  // what the handle's other lanes have learnt since this lane's previous batch
     std::lock_guard<std::mutex> lk(sh->mu);
     // the lanes' common timeline: this lane's stream is idle here (its previous batch has been synchronised), so a base recorded on it
-    // completes at once; the other base stays valid for the twin's batch in flight
+    // completes at once; the other base stays valid for the other lanes' batches in flight
     const double now = host_us();
     if (!sh->base_gen || now - sh->base_host_us > 4e6) {
       const u32 g = sh->base_gen + 1;
@@ -1245,7 +1245,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       R->t_base_gen = base_gen;
     }
   }
-  if (dg_index::SharedHints* sh = ix->shared_hints.load()) {  // for the twin lane's next batch
+  if (dg_index::SharedHints* sh = ix->shared_hints.load()) {  // for the other lanes' next batches
     std::lock_guard<std::mutex> lk(sh->mu);
     sh->shard_cap = std::max(sh->shard_cap, ix->shard_cap_hint);
     sh->flat_cap = std::max(sh->flat_cap, ix->flat_cap_hint);

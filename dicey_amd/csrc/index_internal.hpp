@@ -42,13 +42,13 @@ struct dg_index {
   // the batch counters are left zeroed by the last kernel of a batch (hunt.hip batch_finish): the next batch skips its memset
   // when they still sit where that kernel cleaned them
   std::atomic<bool> busy{false};      // a dg_hunt_submit batch is in flight on this handle (lane)
-  // ABI 5: dg_hunt_submit keeps two batches in flight on one handle; a submission that finds the handle busy runs on this internal
-  // second lane (a shared handle: own stream, workspaces, helper thread; created at the first need, closed with the handle)
+  // ABI 5: dg_hunt_submit keeps several batches in flight on one handle; a submission that finds the handle busy runs on an internal
+  // lane (a shared handle: own stream, workspaces, helper thread; created at the first need, closed with the handle)
   static constexpr int NEXTRA = 2;            // internal lanes beside the handle itself: three batches in flight (r04: two)
   dg_index* lanes[NEXTRA] = {nullptr, nullptr};
-  // The two lanes learn together (r04): capacities and kernel-family hints live per lane (each lane's batches read and write its own
+  // The lanes learn together (r04): capacities and kernel-family hints live per lane (each lane's batches read and write its own
   // without locks), and a lane merges the pair's common record in when a batch starts and writes its own back when it ends — a
-  // lane that runs its first batch does not repeat it for a capacity its twin has already learnt.
+  // lane that runs its first batch does not repeat it for a capacity another lane has already learnt.
   struct SharedHints {
     std::mutex mu;
     uint32_t flat_cap = 0, shard_cap = 0, generic_sticky = 0, jobs_sticky = 0;

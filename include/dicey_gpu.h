@@ -37,7 +37,7 @@ extern "C" {
  * 4: hits carry their alignment in compact form (dg_hunt_result::ops; dg_hunt_rows / dg_hit_rows rebuild the two rows),
  *    result buffers come from a pinned pool, dg_hunt_submit / dg_hunt_wait
  * 5: dg_hunt_params grows by max_query_len and flags; DG_HUNT_COMPACT: 8 + 4 d bytes per hit and 8 bytes per query cross PCIe / xGMI
- *    (dg_chit_unpack, dg_hunt_expand, dg_normalize_query turn them back); dg_hunt_submit keeps two batches in flight on ONE handle */
+ *    (dg_chit_unpack, dg_hunt_expand, dg_normalize_query turn them back); dg_hunt_submit keeps up to three batches in flight on ONE handle */
 #define DG_ABI_VERSION 5
 
 enum {
@@ -214,8 +214,8 @@ typedef struct {
   /* measurement: the capped-neighbourhood stage in front of the batch (hunt_cap.hpp / nbhd_host.hpp), host wall clock, and what it did */
   double ms_cap;              /* 0 when no query of the batch could reach the cap */
   uint64_t cap_queries_device, cap_queries_host, cap_patterns; /* queries enumerated on the device / on the host, explicit patterns searched */
-  /* Where the batch's flat search kernel ran on the handle's timeline (r04): begin / end in ms since a base event the handle's two lanes
-   * share.  With two batches in flight the launches of neighbouring batches overlap, and the time the kernel RAN is the union of these
+  /* Where the batch's flat search kernel ran on the handle's timeline (r04): begin / end in ms since a base event the handle's lanes
+   * share.  With several batches in flight the launches of neighbouring batches overlap, and the time the kernel RAN is the union of these
    * intervals, not the sum of their lengths (bench.py's roofline).  t_base_gen: intervals of equal generation share a base (the
    * library takes a new base every few seconds to keep float precision); 0 = no timeline (one lane only so far, or no flat kernel). */
   double t_search_begin_ms, t_search_end_ms;
@@ -265,7 +265,7 @@ int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out);
  * the offsets again by itself), so the buffers may be refilled in place between calls. */
 int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const void* d_qbytes,
                    const void* d_qoff, size_t nq, uint64_t total_qbytes, int fetch, dg_hunt_result** out);
-/* Asynchronous form of dg_hunt_device (r04), on the same two lanes as dg_hunt_submit and collected with dg_hunt_wait: a caller whose
+/* Asynchronous form of dg_hunt_device (r04), on the same lanes as dg_hunt_submit and collected with dg_hunt_wait: a caller whose
  * batches are resident in HBM keeps two or three in flight — submit A, submit B, wait A, submit C, wait B, ... — so that one batch's
  * launch-bound tail (locate, verify, the summary's read-back) runs beside another batch's search kernel.  The device buffers must
  * stay untouched until the ticket has been waited for; a result left in HBM (fetch = 0) is valid until the next submit after its

@@ -928,7 +928,7 @@ static constexpr u32 FUSED2_HCAP = 1024;  // hash slots of the select stage (dis
 // them when they were not launched).  (A form with one workgroup per QUERY that also did k_take's work — both strands one after the
 // other — was measured: 9.68 against 9.28 + 0.27 ms for this kernel and k_take; removed.)
 template <bool SEL>
-__global__ void __launch_bounds__(256) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2) {
+__global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2) {
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
   // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum

@@ -23,7 +23,8 @@ Other configurations of BASELINE.json, same contract, one JSON line each:
   --config padlock   configs[4]: 1 000 genes, per-position arm / probe values (thal, exact and neighbourhood counts)
 
 `--gpus N` without a launcher starts the N ranks itself (python -m torch.distributed.run, 127.0.0.1).
-Prints ONE JSON line (rank 0).
+Rank 0 writes the full detail object to bench_detail.json (`--detail-out`) and prints ONE compact JSON line (< 4 KB: the
+contract keys, roofline, cpu_baseline, parity sample, a summary per other configuration) as the last line of stdout.
 """
 import argparse
 import ctypes as C
@@ -63,6 +64,120 @@ def union_of_intervals(iv) -> float:
     if cur_e is not None:
         total += cur_e - cur_b
     return total
+
+
+def build_id() -> str:
+    """Identity of the kernel sources this run was built from (sha256 over dicey_amd/csrc/*.hip|*.hpp and include/dicey_gpu.h, 16 hex
+    digits).  Numbers that come from a committed profile round (PMC traffic, instruction counters) are carried into a bench line only
+    when the profile was taken on the same sources (tools/summarize_profile.py stamps the files it writes); otherwise they are null."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "dicey_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dicey_amd", "csrc", "*.hpp")))
+    for f in files + [os.path.join(ROOT, "include", "dicey_gpu.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_of_this_build(name: str, **want):
+    """profiles/<name> (JSON) if it was taken on the sources of this build AND its fields equal `want` (exact, no substring match);
+    None otherwise."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+    if j.get("build_id") != build_id():
+        return None
+    for k, v in want.items():
+        if j.get(k) != v:
+            return None
+    return j
+
+
+CONTRACT_LINE_LIMIT = 4096  # the driver keeps a bounded tail of stdout: r04's 25.6 KB line was not parsed (VERDICT r04)
+
+
+def _short(x, n=160):
+    return x if not isinstance(x, str) or len(x) <= n else x[:n - 3] + "..."
+
+
+def _pick(d, keys):
+    return {k: _short(d[k]) for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else None
+
+
+def contract_line(out: dict, detail_path: str = "") -> str:
+    """The ONE line the driver parses: the contract's keys, roofline + cpu_baseline of the dominant kernel, the parity sample and a
+    five-field summary of every other configuration.  Everything else lives in the detail file.  Strict JSON (no NaN), < 4 KB."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out.get(k) for k in top}
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": _short(cfg.get("workload"), 200), "genome": _short(cfg.get("genome_short") or cfg.get("genome"), 120)}
+    for k in ("queries_per_gpu", "primers_per_gpu", "genes_per_gpu", "in_flight_batches", "distinct_batches", "sharding"):
+        if k in cfg:
+            line["config"][k] = _short(cfg[k], 80)
+    rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms", "launch_ms", "traffic_over_algorithmic",
+          "lines_per_strand", "stage")
+    line["roofline"] = _pick(out.get("roofline"), rk)
+    line["cpu_baseline"] = _pick(out.get("cpu_baseline"), ("value", "unit", "cores", "kind", "cpu_model", "sample"))
+    line["parity_sample"] = _pick(out.get("parity_sample"), ("queries", "mismatching", "hits"))
+    for k in ("value_one_in_flight", "value_with_d2h", "host_to_host_pipelined", "cli_end_to_end_10M"):
+        if isinstance(out.get(k), dict) and "value" in out[k]:
+            line.setdefault("delivery", {})[k] = float("%.6g" % out[k]["value"])
+    for k in sorted(out):
+        if k.startswith("summary_"):
+            line[k] = out[k]
+    for k in ("gathered_bytes_per_step", "gather_bytes_moved_per_step"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    line["build_id"] = out.get("build_id")
+    line["detail"] = detail_path
+    s = json.dumps(line, allow_nan=False)
+    for drop in ("delivery", "detail", "build_id"):  # never over the limit: optional blocks go first
+        if len(s) < CONTRACT_LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        s = json.dumps(line, allow_nan=False)
+    if len(s) >= CONTRACT_LINE_LIMIT:
+        for k in [k for k in line if k.startswith("summary_")]:
+            line[k] = _pick(line[k], ("value", "unit", "frac"))
+        s = json.dumps(line, allow_nan=False)
+    assert len(s) < CONTRACT_LINE_LIMIT, len(s)
+    return s
+
+
+def _finite(x):
+    """NaN / Infinity are not JSON: None in their place (json.dumps(allow_nan=False) then holds for the whole object)"""
+    if isinstance(x, float):
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, (np.floating, np.integer)):
+        return _finite(x.item())
+    return x
+
+
+def emit(out: dict, detail_out: str = "") -> str:
+    """Full detail -> a side file (bench_detail.json next to this script, also under gpurun_out/ when that exists; --detail-out
+    overrides), then the compact contract line as the LAST line of stdout."""
+    out = _finite(out)
+    paths = [detail_out] if detail_out else [os.path.join(ROOT, "bench_detail.json")] + \
+        ([os.path.join(ROOT, "gpurun_out", "bench_detail.json")] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])
+    written = ""
+    for p_ in paths:
+        try:
+            with open(p_, "w") as f:
+                json.dump(out, f, allow_nan=False)
+                f.write("\n")
+            written = written or os.path.relpath(p_, ROOT)
+        except OSError:
+            pass
+    s = contract_line(out, written)
+    sys.stdout.flush()
+    print(s, flush=True)
+    return s
 
 
 def synth_genome(total_len: int, nchr: int, seed: int, device, repeats: bool = False) -> (torch.Tensor, list):
@@ -306,16 +421,16 @@ def thal_counter_block(cfg, kernel, thal_calls, stage_ms):
     """k_site_wave against the fp64 vector peak and the LDS: instruction counters of the committed PMC pass
     on this workload (tools/prof_thal.sh -> profiles/r03_thal_counters.json), scaled to this run's thal() count and stage time.
     fp64 FLOP/s is an UPPER bound (every lane of every fp64 wavefront instruction counted as active; an FMA as two)."""
-    tc = k = ref_calls = src = None
-    for src in ("r04_thal_counters.json", "r03_thal_counters.json"):  # the newest committed pass that holds this kernel
-        try:
-            tc = json.load(open(os.path.join(ROOT, "profiles", src)))[cfg]
-            k = [v for n, v in tc["kernels"].items() if kernel in n][0]
-            ref_calls = (tc["bench"].get("site_stage") or {}).get("thal_calls_per_step") or \
-                (tc["bench"]["arm_thal_per_step"] + tc["bench"]["probe_thal_per_step"])
-            break
-        except Exception:
-            k = None
+    tc = profile_of_this_build("thal_counters.json")  # tools/prof_thal.sh + tools/summarize_thal.py, stamped with the sources' build_id
+    k = ref_calls = None
+    src = "thal_counters.json"
+    try:
+        tc = tc[cfg]
+        k = [v for n, v in tc["kernels"].items() if kernel in n][0]
+        ref_calls = (tc["bench"].get("site_stage") or {}).get("thal_calls_per_step") or \
+            (tc["bench"]["arm_thal_per_step"] + tc["bench"]["probe_thal_per_step"])
+    except Exception:
+        k = None
     if k is None:
         return None
     if not thal_calls or not stage_ms:
@@ -325,7 +440,8 @@ def thal_counter_block(cfg, kernel, thal_calls, stage_ms):
     flops = (k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + 2 * k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_TRANS_F64"]) * 64 * scale
     t = stage_ms * 1e-3
     valu_peak = 256 * 4 * 2.4e9 / 4  # wavefront instructions per second: 1 024 SIMDs, one wave64 instruction per four cycles
-    return {"source": "profiles/%s (rocprofv3 --pmc on this workload), scaled by thal() calls" % src,
+    return {"source": "profiles/%s (rocprofv3 --pmc on this workload and on this build's sources), scaled by thal() calls" % src,
+            "valu_wave_instructions_per_s": k["SQ_INSTS_VALU"] * scale / t, "valu_issue_peak_per_s": valu_peak,
             "fp64_wave_instructions_per_thal": f64 / thal_calls, "valu_wave_instructions_per_thal": k["SQ_INSTS_VALU"] * scale / thal_calls,
             "lds_wave_instructions_per_thal": k["SQ_INSTS_LDS"] * scale / thal_calls,
             "fp64_TFLOPs_upper_bound": flops / t / 1e12, "fp64_vector_peak_TFLOPs": 78.6, "fp64_frac_upper_bound": flops / t / 78.6e12,
@@ -333,6 +449,29 @@ def thal_counter_block(cfg, kernel, thal_calls, stage_ms):
             "lds_bank_conflict_cycles_over_active": k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"],
             "note": "the kernel issues VALU instructions at about two thirds of the chip's rate, one in nine of them fp64: bound by "
                     "instruction issue of the loop-candidate evaluation (compares, selects, address arithmetic), not by the fp64 units"}
+
+
+def padlock_replay(R, e, ln, armlen=20, mingc=0.4, maxgc=0.6, tmdiff=2, max_nb=2, exp=1):
+    """padlock.h:321-428 + :506 on dg_padlock_scan's arrays (arm mode, edit distance 1, non-overlapping; spacer / barcode GC left out):
+    the offsets inside exon e at which the reference accepts a probe"""
+    o = int(R["pos_off"][e])
+    acc = []
+    k = 0
+    while k < ln - 2 * armlen + 1:
+        g1, g2, pg = R["arm_gc"][o + k], R["arm_gc"][o + k + armlen], R["probe_gc"][o + k]
+        ok = mingc <= g1 <= maxgc and not (R["arm_tm"][o + k] > 93 + g1 - 675.0 / armlen) and mingc <= g2 <= maxgc
+        ok = ok and not (R["arm_tm"][o + k + armlen] > 93 + g2 - 675.0 / armlen) and abs(R["arm_tm"][o + k] - R["arm_tm"][o + k + armlen]) <= tmdiff
+        ok = ok and mingc <= pg <= maxgc
+        if ok:
+            lo = 81.5 + pg - 675.0 / (2 * armlen)
+            ok = lo <= R["probe_tm"][o + k] <= lo + 10
+        ok = ok and R["arm_count"][o + k] <= exp and R["arm_count"][o + k + armlen] <= exp
+        ok = ok and R["arm_nbcount"][o + k] <= max_nb and R["arm_nbcount"][o + k + armlen] <= max_nb
+        if ok:
+            acc.append(k)
+            k += 2 * armlen - 1
+        k += 1
+    return acc
 
 
 def main():
@@ -387,6 +526,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--same-device", action="store_true",
                     help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--detail-out", default="",
+                    help="where the full detail object goes (default: bench_detail.json next to this script, and gpurun_out/ when present); "
+                         "stdout's last line is the compact contract line (< 4 KB) either way")
     ap.add_argument("--dump-gather", default="",
                     help="directory: every rank writes the hit-list bytes of its last step (local_<rank>.bin) and rank 0 what the "
                          "gather delivered for every rank (gathered_<rank>.bin); used by the tests")
@@ -505,6 +647,8 @@ def main():
                     "i.i.d. background at GRCh38 base frequencies with planted repeat families (Alu-like 300-mer x 1.1 M copies, MIR-like, "
                     "L1-like 6 kb, 40 smaller families, microsatellites, segmental duplications; 0.5-30 % divergence per copy)") +
                    ", 5% N runs, seed 1 (no real genome is available offline)")
+    genome_short = (f"synthetic GRCh38-size ({st['n'] - 1} symbols, 24 sequences), " +
+                    ("i.i.d. ACGT at GRCh38 base frequencies" if a.genome == "iid" else "i.i.d. background + planted repeat families") + ", 5% N runs, seed 1")
     base_out = {"metric": METRIC, "unit": "primers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True,
                 "scaling": a.scaling, "vs_baseline": None, "data": "synthetic"}
     pipe = {"g": None}
@@ -892,29 +1036,26 @@ def main():
             avg_l = sum(f * cl.get(ord(ch), 0) for f, ch in zip(GRCH38_FREQ, "ACGT"))
             survey_bytes = ext * 2 * avg_l * 24 + tab * BYTES_PER_TAB_READ + probe * BYTES_PER_FILTER_PROBE
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-            traffic = None
-            fabric_reads = traffic_round = None
-            # HBM bytes per launch of this kernel on this workload from the committed PMC passes (tools/summarize_profile.py,
-            # tools/prof_cfg.sh): FETCH_SIZE corrected by the calibration factor + WRITE_SIZE
-            import glob
-            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_k_search*.json"))):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("workload") == f"{units}x{a.qlen}mer_d{distance}_n{int(a.genome_size)}_{a.genome}" and tj.get("kernel") == kernel:
-                        traffic = tj.get("hbm_bytes_per_launch")
-                        fabric_reads = (tj.get("tcc") or {}).get("ea_rdreq")
-                        traffic_round = tj.get("round")
-                except Exception:
-                    pass
+            # HBM bytes per launch of this kernel on this workload from the PMC passes of the profile round (tools/summarize_profile.py:
+            # FETCH_SIZE corrected by the calibration factor + WRITE_SIZE, the row of exactly this kernel instantiation) — carried only
+            # when that round profiled the sources this library was built from (build_id); a stale profile gives null, never a number
+            traffic = fabric_reads = traffic_round = write_bytes = None
+            tname = "traffic_k_search.json" if (distance == 1 and a.genome == "iid") else f"traffic_k_search_d{distance}_{a.genome}.json"
+            tj = profile_of_this_build(tname, workload=f"{units}x{a.qlen}mer_d{distance}_n{int(a.genome_size)}_{a.genome}", kernel=kernel)
+            if tj is not None:
+                traffic = tj.get("hbm_bytes_per_launch")
+                write_bytes = tj.get("write_bytes_per_launch")
+                fabric_reads = (tj.get("tcc") or {}).get("ea_rdreq")
+                traffic_round = tj.get("round")
             out = dict(base_out)
             out.update({
                 "value": (len(meta["queries"][0]) if strong else world * nq) * a.steps / elapsed, "ms_per_step": elapsed / a.steps * 1e3, "dtype": "u32",
                 "config": {"workload": f"dicey hunt, {nq} synthetic {a.qlen}-mers per GPU, edit distance {distance}, both strands, "
                                        f"-m 1000 -x 10000 (BASELINE.json configs[{1 if cfg == 'hunt_d1' else 3}])",
-                           "genome": genome_desc,
+                           "genome": genome_desc, "genome_short": genome_short,
                            "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
                            "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
-                           "distinct_batches": len(dev_batches),
+                           "distinct_batches": len(dev_batches), "in_flight_batches": a.in_flight,
                            "results": "compact records (DG_HUNT_COMPACT: 8 + 4 d bytes per hit) left in HBM (N = 1) / gathered to rank 0 (N > 1)",
                            "in_flight": (f"{a.in_flight} batches per GPU (dg_hunt_device_submit / dg_hunt_wait on the handle's lanes: step k is submitted, "
                                          f"then step k - {a.in_flight - 1} collected; K batches start and end inside the timed region)" if a.in_flight >= 2
@@ -923,6 +1064,8 @@ def main():
                                      "(seeds 42 + 1000 b), warm-up included" if len(dev_batches) > 1 else "one batch replayed every step"},
                 "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                             "traffic_over_algorithmic": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
+                             "write_bytes_per_launch": write_bytes,
                              "algorithmic_bytes_per_launch": alg_bytes, "ext_steps_per_launch": ext,
                              "bytes_per_ext_step": BYTES_PER_EXT, "table_reads_per_launch": tab,
                              "bytes_per_table_read": BYTES_PER_TAB_READ, "filter_probes_per_launch": probe,
@@ -1057,7 +1200,7 @@ def main():
             return res
 
         acc, elapsed, gathered = timed(step)
-        cpu = None
+        cpu = parity = None
         if rank == 0 and world == 1 and not a.no_cpu_baseline and host_text is not None:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
@@ -1070,11 +1213,28 @@ def main():
                 per = (time.time() - tc) / ns
                 ns = int(min(len(prim), max(4, a.cpu_seconds / max(per, 1e-3)))) & ~1
                 tc = time.time()
-                orc.search(seqlen, names, host_text, "".join(">p%d\n%s\n" % (i, s_) for i, s_ in enumerate(prim[:ns])))
+                ojs, _ = orc.search(seqlen, names, host_text, "".join(">p%d\n%s\n" % (i, s_) for i, s_ in enumerate(prim[:ns])))
                 dtc = time.time() - tc
                 cpu = {"value": ns / dtc, "unit": "primers/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model,
                        "sample": f"first {ns} primers, restated silica.h:429-640 calling the reference's own thal.h (oracle/_ref), 1 host thread, {dtc:.1f} s"}
                 orc.close()
+                # parity at full size: the binding sites of the same primers from the GPU path (dg_search_sites) against the checker's
+                # "primers" records — chromosome, position, strand, Tm and MatchTm as doubles (the JSON number round-trips), site sequence
+                try:
+                    want_ = {}
+                    for r_ in json.loads(ojs)["data"]["primers"]:
+                        want_.setdefault(r_["Name"], []).append((r_["Chrom"], r_["Pos"], r_["Ori"], float(r_["Tm"]), float(r_["MatchTm"]), r_["Genome"]))
+                    sites_, mt_, _, _ = dicey_amd.search_sites(ix, th, prim[:ns], seqlen, kmer=15, distance=distance, max_locations=10000,
+                                                               max_neighborhood=10000, cut_temp=45.0)
+                    got_ = {}
+                    for s_ in sites_:
+                        got_.setdefault("p%d" % s_["primer"], []).append((names[s_["ref"]], s_["pos"] + 1, "forward" if s_["on_for"] else "reverse",
+                                                                          float(s_["temp"]), float(s_["perf_temp"]), s_["genome"]))
+                    bad_ = sum(sorted(got_.get("p%d" % i, [])) != sorted(want_.get("p%d" % i, [])) for i in range(ns))
+                    parity = {"queries": ns, "mismatching": int(bad_), "hits": sum(len(v) for v in want_.values()),
+                              "what": "binding sites per primer (chromosome, position, strand, Tm, MatchTm, site sequence) vs the checker's JSON"}
+                except Exception as e:
+                    parity = {"error": repr(e)[:200]}
         if rank == 0:
             mean = lambda k: float(np.mean([r[k] for r in acc]))  # noqa: E731
             ext, tab, probe = mean("ext"), mean("tab"), mean("probe")
@@ -1087,17 +1247,25 @@ def main():
                 "value": world * len(prim) * a.steps / elapsed, "ms_per_step": elapsed / a.steps * 1e3, "dtype": "u32 + f64",
                 "config": {"workload": f"dicey search, {len(prim) // 2} primer pairs = {len(prim)} primers (18-25 nt) per GPU, -k 15 -d {distance} -c 45 "
                                        f"-m 10000 (BASELINE.json configs[2]); binding-site stage, host buffers in and out",
-                           "genome": genome_desc, "primers_per_gpu": len(prim), "sharding": f"primer-sharded x{world}, full index replica per GPU"},
-                "roofline": {"bound": "hbm", "kernel": "k_search1<true> (FM search of the 15-mer neighbourhoods)", "achieved": achieved,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ms_fm,
-                             "note": "the step is dominated by k_site_wave (one wavefront per located hit: f64 thal() DP in LDS); site_stage.fp64_and_lds "
-                                     "places it against the fp64 vector peak, the VALU issue rate and the LDS"},
+                           "genome": genome_desc, "genome_short": genome_short, "primers_per_gpu": len(prim), "sharding": f"primer-sharded x{world}, full index replica per GPU"},
+                # the step IS k_site_wave (one wavefront per located hit: f64 thal() DP in LDS): bound by VALU instruction issue, so the
+                # roofline block is that kernel against the chip's issue rate (1 024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction);
+                # instructions per thal() come from the PMC pass of THIS build (null when the committed pass is of other sources)
+                "roofline": (lambda tcb: {"bound": "valu", "kernel": "k_site_wave", "achieved": (tcb["valu_wave_instructions_per_s"] / 1e9) if tcb else None,
+                                          "peak": 614.4, "unit": "G wave-instructions/s", "frac": tcb["valu_issue_frac"] if tcb else None, "traffic": None,
+                                          "kernel_ms": mean("ms_site"), "thal_calls_per_launch": mean("nhits"),
+                                          "thal_per_s": mean("nhits") / (mean("ms_site") * 1e-3) if mean("ms_site") > 0 else 0.0,
+                                          "valu_wave_instructions_per_thal": tcb["valu_wave_instructions_per_thal"] if tcb else None,
+                                          "note": "HBM is not the limit (window + primer bytes in, 32 B out per hit; the DP stays in LDS)"})(
+                    thal_counter_block("search", "k_site_wave", mean("nhits"), mean("ms_site"))),
+                "roofline_fm_search": {"bound": "hbm", "kernel": "k_search1s<true, false> (FM search of the 15-mer neighbourhoods)", "achieved": achieved,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                       "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ms_fm},
                 "site_stage": {"kernel": "k_site_wave", "ms": mean("ms_site"), "thal_calls_per_step": mean("nhits"),
                                "thal_per_s": mean("nhits") / (mean("ms_site") * 1e-3) if mean("ms_site") > 0 else 0.0,
                                "binding_sites_per_step": mean("nsites"),
                                "fp64_and_lds": thal_counter_block("search", "k_site_wave", mean("nhits"), mean("ms_site"))},
-                "cpu_baseline": cpu,
+                "cpu_baseline": cpu, "parity_sample": parity,
                 "phases_ms": {"ms_device": mean("ms_device"), "ms_fm_search": ms_fm, "ms_site_stage": mean("ms_site")},
             })
     # =====================================================================================================================
@@ -1119,7 +1287,7 @@ def main():
             return res
 
         acc, elapsed, gathered = timed(step)
-        cpu = None
+        cpu = parity = None
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
@@ -1130,8 +1298,8 @@ def main():
                     sel = [e for e in range(len(exons)) if gene_of[e] < ng]
                     bars = "".join(">%d\nACGTTGCAACGTTGCAACGT\n" % i for i in range(len(sel)))
                     tc = time.time()
-                    orc.padlock(["e%d" % e for e in sel], [exons[e] for e in sel], "", bars, input_fasta=True, spacerleft="GC",
-                                spacerright="GC", anchor="GCGCGCATATGCGCGCATAT")
+                    otsv = orc.padlock(["e%d" % e for e in sel], [exons[e] for e in sel], "", bars, input_fasta=True, spacerleft="GC",
+                                       spacerright="GC", anchor="GCGCGCATATGCGCGCATAT")[0]
                     dtc = time.time() - tc
                     if dtc >= a.cpu_seconds / 2 or ng >= units:
                         break
@@ -1141,6 +1309,18 @@ def main():
                        "positions_per_s": pos / dtc,
                        "sample": f"{len(sel)} exons of the first {ng} genes ({pos} positions), restated padlock.h:321-520 calling the reference's own "
                                  f"thal.h (oracle/_ref), 1 host thread, {dtc:.1f} s"}
+                # parity at full size: the probe positions the checker accepted for these genes against a replay of the reference's
+                # per-position decisions (padlock.h:321-428, :506) on the arrays dg_padlock_scan returned for the whole batch
+                try:
+                    Rp = dicey_amd.padlock_scan(ix, th, ebytes)
+                    rows_ = [ln.split("\t") for ln in otsv.rstrip("\n").split("\n")[1:] if ln]
+                    want_ = sorted((r_[0], int(r_[3].split(":")[1]) - 1) for r_ in rows_)
+                    got_ = sorted(("e%d" % e, k_) for e in sel for k_ in padlock_replay(Rp, e, len(exons[e])))
+                    bad_genes = {gene_of[int(n_[1:])] for n_, k_ in set(want_) ^ set(got_)}
+                    parity = {"queries": ng, "mismatching": len(bad_genes), "hits": len(want_), "exons": len(sel),
+                              "what": "accepted probe positions per gene: checker's TSV vs the reference's decisions replayed on the GPU arrays"}
+                except Exception as e:
+                    parity = {"error": repr(e)[:200]}
         if rank == 0:
             mean = lambda k: float(np.mean([r[k] for r in acc]))  # noqa: E731
             npos = mean("npos")
@@ -1151,19 +1331,23 @@ def main():
                 "unit": "genes/s", "value": world * units * a.steps / elapsed, "ms_per_step": elapsed / a.steps * 1e3, "dtype": "f64 + u32",
                 "config": {"workload": f"dicey padlock, {units} synthetic genes = {len(exons)} exons = {int(npos)} arm windows per GPU, armlen 20, "
                                        f"-d {distance} (BASELINE.json configs[4]; GTF parsing and TSV writing are host work outside this step)",
-                           "genome": genome_desc, "genes_per_gpu": units, "sharding": f"gene-sharded x{world}, full index replica per GPU"},
-                "roofline": {"bound": "hbm", "kernel": "k_thal_self_wave", "achieved": win_bytes / (elapsed / a.steps) / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": win_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "algorithmic_bytes_per_launch": win_bytes,
-                             "note": "window bytes in / 8 B out per thal(): the scan is bound by VALU issue of the thal() DP (one wavefront per "
-                                     "window; thal_stage.fp64_and_lds.valu_issue_frac is the fraction that applies), not by HBM or MFMA"},
-                # what bounds the scan: the thal() wave kernel against the chip's VALU issue rate and fp64 peak (counters of the committed
-                # PMC pass on this workload, scaled by thal() calls); the HBM fraction above only says that memory is not the limit
+                           "genome": genome_desc, "genome_short": genome_short, "genes_per_gpu": units, "sharding": f"gene-sharded x{world}, full index replica per GPU"},
+                # what bounds the scan: the thal() wave kernel against the chip's VALU issue rate (counters of the PMC pass of THIS build
+                # on this workload, scaled by thal() calls; null when the committed pass is of other sources)
+                "roofline": (lambda tcb: {"bound": "valu", "kernel": "k_thal_self_wave", "achieved": (tcb["valu_wave_instructions_per_s"] / 1e9) if tcb else None,
+                                          "peak": 614.4, "unit": "G wave-instructions/s", "frac": tcb["valu_issue_frac"] if tcb else None, "traffic": None,
+                                          "kernel_ms": elapsed / a.steps * 1e3, "thal_calls_per_launch": mean("arm_thal") + mean("probe_thal"),
+                                          "thal_per_s": (mean("arm_thal") + mean("probe_thal")) / (elapsed / a.steps),
+                                          "valu_wave_instructions_per_thal": tcb["valu_wave_instructions_per_thal"] if tcb else None,
+                                          "hbm_window_bytes_per_launch": win_bytes,
+                                          "note": "kernel_ms is the whole step (thal of arm and probe windows + the counts of surviving arms); HBM is "
+                                                  "not the limit (window bytes in, 8 B out per thal())"})(
+                    thal_counter_block("padlock", "k_thal_self_wave", mean("arm_thal") + mean("probe_thal"), elapsed / a.steps * 1e3)),
                 "thal_stage": {"kernel": "k_thal_self_wave", "thal_per_s": (mean("arm_thal") + mean("probe_thal")) / (elapsed / a.steps),
                                "fp64_and_lds": thal_counter_block("padlock", "k_thal_self_wave", mean("arm_thal") + mean("probe_thal"),
                                                                   elapsed / a.steps * 1e3)},
                 "positions_per_s": world * npos * a.steps / elapsed, "arm_thal_per_step": mean("arm_thal"), "probe_thal_per_step": mean("probe_thal"),
-                "arms_counted_per_step": mean("arms_counted"), "cpu_baseline": cpu,
+                "arms_counted_per_step": mean("arms_counted"), "cpu_baseline": cpu, "parity_sample": parity,
             })
 
     # ---------------- common tail
@@ -1215,10 +1399,13 @@ def main():
                 sub_ = out["extra_configs"].get(name_)
                 if isinstance(sub_, dict) and "value" in sub_:
                     rf_ = sub_.get("roofline") or {}
-                    out["summary_" + name_] = {"value": sub_["value"], "unit": sub_.get("unit"), "ms_per_step": sub_.get("ms_per_step"),
-                                               "dominant_kernel": rf_.get("kernel"), "frac": rf_.get("frac"),
-                                               "parity": sub_.get("parity_sample")}
-        print(json.dumps(out), flush=True)
+                    out["summary_" + name_] = {"value": float("%.6g" % sub_["value"]), "unit": sub_.get("unit"),
+                                               "ms_per_step": float("%.6g" % sub_["ms_per_step"]) if sub_.get("ms_per_step") else None,
+                                               "dominant_kernel": _short(rf_.get("kernel"), 48), "bound": rf_.get("bound"),
+                                               "frac": float("%.4g" % rf_["frac"]) if rf_.get("frac") else None,
+                                               "parity": _pick(sub_.get("parity_sample"), ("queries", "mismatching"))}
+        out["build_id"] = build_id()
+        emit(out, a.detail_out)
     barrier()
     if rank == 0 and not a.fm9 and not a.keep_index:
         for f in (fm9, meta_path):
@@ -1253,17 +1440,18 @@ def run_extra_configs(a, fm9):
         if left < 25:
             res[name] = {"skipped": "extra_configs budget of %.0f s spent" % a.extra_budget_s}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extra-configs", "--no-extras"] + args
+        dpath = fm9 + ".detail_%s.json" % name
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extra-configs", "--no-extras", "--detail-out", dpath] + args
         if reuse:
             cmd += ["--fm9", fm9]
         t0 = time.time()
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=max(30.0, min(left, 150.0)))
-            line = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
-            if r.returncode != 0 or not line:
+            if r.returncode != 0 or not os.path.exists(dpath):
                 res[name] = {"error": "exit code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
                 continue
-            d = json.loads(line[-1])
+            d = json.load(open(dpath))  # the sub-run's full detail (its stdout carries only the compact line)
+            os.remove(dpath)
             sub = {k_: d[k_] for k_ in keep if k_ in d}
             sub["workload"] = d["config"]["workload"]
             sub["genome"] = "repeats" if "repeats" in args else "iid"

@@ -24,12 +24,16 @@ def test_bench_gpus2_spawns_ranks_and_gathers_hit_lists(tmp_path, batches):
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--genome-size", "2e6",
-           "--queries", "2000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--dump-gather", dump, "--batches", str(batches)]
+           "--queries", "2000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--dump-gather", dump, "--batches", str(batches),
+           "--detail-out", str(tmp_path / "detail.json"), "--cli-queries", "0"]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines) == 1 and p.stdout.rstrip("\n").splitlines()[-1] == lines[0], p.stdout[-2000:]  # the contract line is stdout's last line
+    assert len(lines[0]) < 4096
     out = json.loads(lines[0])
+    detail = json.load(open(tmp_path / "detail.json"))
+    assert detail["value"] == out["value"] and "phases_ms" in detail and "phases_ms" not in out
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["gathered_bytes_per_step"] > 0
     assert out["value"] > 0 and out["steps"] == 3
@@ -52,7 +56,8 @@ def test_bench_rccl_gather_path_with_one_rank(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gather-single", "--backend", "nccl", "--genome-size", "2e6", "--queries", "2000",
-           "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-extra-configs", "--batches", "3", "--dump-gather", dump]
+           "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-extra-configs", "--batches", "3", "--dump-gather", dump,
+           "--detail-out", str(tmp_path / "detail.json")]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])

@@ -9,15 +9,15 @@ OUT=gpurun_out/prof_$L
 rm -rf $OUT; mkdir -p $OUT
 FM9=$(ls /dev/shm/dicey_bench_*.fm9 2>/dev/null | head -1)
 if [ -z "$FM9" ]; then
-  timeout 600 python bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline --parity-queries 0 --keep-index "$@" > $OUT/build.json 2> $OUT/build.err
+  timeout 600 python bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline --parity-queries 0 --keep-index --detail-out /tmp/build_detail.json "$@" > $OUT/build.json 2> $OUT/build.err
   FM9=$(ls /dev/shm/dicey_bench_*.fm9 | head -1)
 fi
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/trace -o trace --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fm9 $FM9 --no-cpu-baseline --no-extras --parity-queries 0 --steps 5 --warmup 2 "$@" > $GRAFT_REPO_ROOT/$OUT/bench_traced.json 2> $GRAFT_REPO_ROOT/$OUT/trace.err)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/trace -o trace --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fm9 $FM9 --no-cpu-baseline --no-extras --parity-queries 0 --steps 5 --warmup 2 --detail-out $GRAFT_REPO_ROOT/$OUT/bench_detail.json "$@" > $GRAFT_REPO_ROOT/$OUT/bench_traced.json 2> $GRAFT_REPO_ROOT/$OUT/trace.err)
 i=0
 while read -r C; do
   [ -z "$C" ] && continue
   i=$((i+1))
-  (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fm9 $FM9 --no-cpu-baseline --no-extras --parity-queries 0 --steps 2 --warmup 1 "$@" > $GRAFT_REPO_ROOT/$OUT/pmc_$i.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$i.err)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fm9 $FM9 --no-cpu-baseline --no-extras --parity-queries 0 --steps 2 --warmup 1 --detail-out $GRAFT_REPO_ROOT/$OUT/pmc_detail_$i.json "$@" > $GRAFT_REPO_ROOT/$OUT/pmc_$i.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$i.err)
 done <<LIST
 FETCH_SIZE
 WRITE_SIZE

@@ -8,17 +8,17 @@ OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 R=${1:-r02}
 # 1. the bench line itself (un-profiled)
-timeout 900 python bench.py --keep-index --no-extra-configs > $OUT/bench_$R.json 2> $OUT/bench_$R.err
+timeout 900 python bench.py --keep-index --no-extra-configs --detail-out $OUT/bench_detail_$R.json > $OUT/bench_$R.json 2> $OUT/bench_$R.err
 FM9=$(ls /dev/shm/dicey_bench_*.fm9 | head -1)
 echo "index: $FM9" > $OUT/notes.txt
 # 2. kernel trace + stats of the same command (index reused so the trace holds the search path, not the builder)
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/trace -o trace --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fm9 $FM9 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$OUT/bench_traced.json 2> $GRAFT_REPO_ROOT/$OUT/trace.err)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/trace -o trace --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fm9 $FM9 --no-cpu-baseline --no-extras --detail-out $GRAFT_REPO_ROOT/$OUT/bench_detail_traced.json > $GRAFT_REPO_ROOT/$OUT/bench_traced.json 2> $GRAFT_REPO_ROOT/$OUT/trace.err)
 # 3. PMC passes (separate runs, counters only)
 i=0
 while read -r C; do
   [ -z "$C" ] && continue
   i=$((i+1))
-  (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fm9 $FM9 --no-cpu-baseline --no-extras --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/$OUT/pmc_$i.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$i.err)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fm9 $FM9 --no-cpu-baseline --no-extras --steps 6 --warmup 3 --detail-out $GRAFT_REPO_ROOT/$OUT/pmc_detail_$i.json > $GRAFT_REPO_ROOT/$OUT/pmc_$i.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$i.err)
 done <<LIST
 FETCH_SIZE
 WRITE_SIZE

@@ -204,7 +204,7 @@ struct CapScan {
 // dev_jobs != nullptr: queries that qualify for the device enumeration (k_cap_enum: edit mode, distance <= 2, A/C/G/T only,
 // length + distance <= 31) are listed there instead of being enumerated here.
 static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_params* p, bool count_mode, CapScan& cs,
-                    std::vector<u32>* dev_jobs = nullptr) {
+                    const dg_switches& sw, std::vector<u32>* dev_jobs = nullptr) {
   const bool indel = !p->hamming;
   struct Job {
     size_t q;
@@ -256,7 +256,7 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
     return DG_OK;
   }
   u64 budget = 16ull << 30;
-  if (const char* e = std::getenv("DICEY_CAP_BUDGET_MB")) budget = (u64)std::max(1, std::atoi(e)) << 20;
+  if (sw.cap_budget_mb) budget = sw.cap_budget_mb << 20;
   if (worst_bytes > budget)
     return fail(DG_ELIMIT, "%zu of the %zu sequences of this call can reach the maxNeighborhood cap (%u); their explicit neighbourhoods may need "
                 "%llu MB of host memory (budget %llu MB): pass fewer sequences per call", jobs.size(), nq, p->max_neighborhood,
@@ -297,7 +297,7 @@ static int cap_scan(const u8* qbytes, const u64* qoff, size_t nq, const dg_hunt_
   // (128 cores) a 25-mer strand at distance 2 takes 0.24 ms of wall time with 32 threads, 0.39 with 64, 0.49 with 256
   // (tools/nbhd_scaling.py)
   nthreads = (unsigned)std::min<size_t>(std::min<unsigned>(nthreads, 32u), jobs.size() * 2);
-  if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthreads = (unsigned)std::max(1, std::atoi(e));
+  if (sw.host_threads) nthreads = sw.host_threads;
   if (nthreads <= 1) work();
   else {
     std::vector<std::thread> pool;
@@ -441,7 +441,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   if (dmax_eff > DMAX) return fail(DG_ELIMIT, "distance %u exceeds the supported maximum of %u", p->distance, DMAX);
   DG_HIP(hipSetDevice(ix->device));
   hipStream_t st = ix->stream;
-  const bool host_timing = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;  // host phases of every batch to stderr
+  const dg_switches& sw = ix->sw;  // the environment switches, read by the entry point on the caller's thread
+  const bool host_timing = sw.host_timing;  // host phases of every batch to stderr
   // HIP events between the stages (ms_select / ms_locate / ms_verify of the result) only on request: every record is a marker packet
   // the next kernel waits behind; the batch's total and the flat search kernel's time are always measured (four events)
   const bool phase_events = (p->flags & DG_HUNT_PHASE_TIMES) != 0 || sx || group_counts;
@@ -457,7 +458,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   // gap columns inside the query (leading and trailing query-gap columns are stripped, hunter.h:391-401, and an optimal path has
   // score >= -d): maxlen + d bytes, rounded up to the 64-bit words it stores.  The other verify kernels build the row from the
   // end of a buffer twice as long.  (r02: 56 -> 24 bytes per row for 20-mers — what travels to the host and over xGMI.)
-  const bool no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;  // (test switches are read per batch: the GPU suite flips them inside one process)
+  const bool no_band = sw.no_band;  // (test switches are read per batch: the GPU suite flips them inside one process)
   const bool band_verify = !no_band && !sx && !group_counts && maxlen <= 32 && dmax_eff <= 2;
   // scratch rows of the full-matrix kernels (built from the end of a buffer twice the row length); the banded kernel needs none
   const u32 stride = band_verify ? 0u : ((maxlen + 3 * dmax_eff) + maxlen + 8 + 7) & ~7u;
@@ -492,11 +493,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       if (total) DG_HIP(hipMemcpyAsync(hb.data(), d_qbytes, total, hipMemcpyDeviceToHost, st));
       DG_HIP(hipMemcpyAsync(ho.data(), d_qoff, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
       DG_HIP(hipStreamSynchronize(st));
+      // read back from the device, so never seen by a host pass: cap_scan indexes with them
+      if (ho[nq] != total) return fail(DG_EINVAL, "dg_hunt_device: total_qbytes does not match qoff[nq]");
+      for (size_t i = 0; i < nq; ++i)
+        if (ho[i + 1] < ho[i] || ho[i + 1] - ho[i] > maxlen)
+          return fail(DG_EINVAL, "dg_hunt_device: qoff decreases at query %zu, or the query exceeds the %u nt this batch was sized for", i, maxlen);
       sb = hb.data();
       so = ho.data();
     }
     // DICEY_CAP_HOST: every capped neighbourhood on the host (nbhd_host.hpp), as before r04 — the GPU suite runs both
-    DG_TRY(cap_scan(sb, so, nq, p, group_counts != nullptr, cs, std::getenv("DICEY_CAP_HOST") ? nullptr : &dev_jobs));
+    DG_TRY(cap_scan(sb, so, nq, p, group_counts != nullptr, cs, sw, sw.cap_host ? nullptr : &dev_jobs));
   }
   u64 nxs = cs.xs_gid.size();
   if (nxs >= 0x0FFFFFFFull || cs.xs_bytes.size() > (48ull << 30))
@@ -506,7 +512,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   const u64 dev_bytes = dev_strings * (maxlen + dmax_eff);
   if (!dev_jobs.empty()) {
     u64 budget = 24ull << 30;
-    if (const char* e = std::getenv("DICEY_CAP_BUDGET_MB")) budget = (u64)std::max(1, std::atoi(e)) << 20;
+    if (sw.cap_budget_mb) budget = sw.cap_budget_mb << 20;
     if (dev_bytes + dev_strings * 12 > budget || nxs + dev_strings >= 0x0FFFFFFFull)
       return fail(DG_ELIMIT, "%zu of the %zu sequences of this call can reach the maxNeighborhood cap (%u); their explicit neighbourhoods may need "
                   "%llu MB of device memory (budget %llu MB): pass fewer sequences per call", dev_jobs.size(), nq, p->max_neighborhood,
@@ -638,6 +644,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   b.refused = &ctr->pad_[1];
   b.too_long = &ctr->pad_[2];
   b.maxlen_bound = maxlen;
+  b.total_qbytes = total;
   u32* qhits = (u32*)gp;  // (compact results: re-pointed into the compact block, per attempt)
   if (!ix->pinned) DG_HIP(hipHostMalloc((void**)&ix->pinned, 4096, 0));
   Summary& hsum = *(Summary*)ix->pinned;
@@ -688,7 +695,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   // slices of the flat Sel region (k_search1s): what the previous batch's fullest slice needed plus a quarter — kept strings are a
   // third of the leaf estimate above, and k_locate walks every slot of the region
   u32 flat_req = ix->flat_cap_hint ? ix->flat_cap_hint : shard_cap;
-  if (const char* e = std::getenv("DICEY_DEBUG_CAPS")) {  // tests: start from tiny capacities to exercise the retry path
+  if (sw.debug_caps) {  // tests: start from tiny capacities to exercise the retry path
+    const char* e = sw.debug_caps_s.c_str();
     shard_cap = (u32)std::max(1, std::atoi(e));
     hit_cap = (u64)std::max(1, std::atoi(e));
     flat_req = shard_cap;
@@ -769,10 +777,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     // when the previous batch of this handle had work for them; a batch that turns out to need them after all is repeated.
     // DICEY_NO_FUSED_SELECT: the search without the select stage (k_search1p + the generic select kernels) — what batches with
     // strings above 42 characters take anyway; the GPU tests run every distance-1 case both ways
-    const bool no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr;
+    const bool no_fuse = sw.no_fuse;
     // r04: the same at edit distance 2 (k_search2p<true, .>: one workgroup per group or per query); DICEY_NO_FUSED_SELECT2 keeps the
     // generic select kernels for that distance only
-    const bool fused = (b.fastK || (b.fast2K && !std::getenv("DICEY_NO_FUSED_SELECT2"))) && packed && !no_fuse;
+    const bool fused = (b.fastK || (b.fast2K && !sw.no_fuse2)) && packed && !no_fuse;
     const u32 flat_cap = fused ? flat_req : 0u;
     const u64 flat_slots = (u64)NSHARD * flat_cap;
     const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
@@ -803,7 +811,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipEventRecord(ix->ev[0], st));
     // the whole batch on the flat distance-1 path: k_search1s settles the `take` values of its own queries (TAKE form);
     // DICEY_NO_PREP_FUSION keeps k_take a launch of its own (the GPU suite runs both)
-    const bool prep_in = fused && b.fastK && !generic_on && !group_counts && !std::getenv("DICEY_NO_PREP_FUSION");
+    const bool prep_in = fused && b.fastK && !generic_on && !group_counts && !sw.no_prep_fusion;
     // the per-character arrays (fw / rv codes, normalised ASCII) are read by the generic kernels, the full-matrix verify kernels and
     // the classic result fetch only: 60 byte stores per query that the flat path with compact results does without
     const u32 write_bytes = (prep_in && band_verify && (compact || !fetch)) ? 0u : 1u;
@@ -828,7 +836,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           // LDS list of a workgroup: 256 entries unless the previous batch of this handle averaged more than 48 occurring strings
           // per workgroup (repeat-bearing genomes), then 512; a workgroup whose strings do not fit hands its groups to the generic
           // path.  tests: DICEY_FUSED_LCAP lowers the capacity so that ordinary batches exercise that hand-over
-          const u32 lcap_env = std::getenv("DICEY_FUSED_LCAP") ? std::max<u32>(1u, std::min<u32>(FUSED_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP")))) : 0u;
+          const u32 lcap_env = sw.fused_lcap ? std::max<u32>(1u, std::min<u32>(FUSED_LCAP, sw.fused_lcap)) : 0u;
           const u32 lcap = lcap_env ? lcap_env : (ix->fused_leaves_hint > 48ull * g1.x ? FUSED_LCAP : FUSED_LCAP / 2);
           const u32 lds1 = fused_lds_bytes(lcap);
           const u32 leave1 = 1u;  // idle wavefronts end behind the probe phase (r04 A/B on one box: 0.2188 ms with, 0.2194 without — harmless, kept)
@@ -850,14 +858,14 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       }
       if (b.fast2K) {  // edit distance 2: one workgroup per (query, strand) for every query that qualifies
         // filtered leaves only where the packed select path (k_group_pack) hands the filter word on
-        const u32 filt_ok = (u32)(packed && !getenv("DICEY_NO_PRE5_D2"));
+        const u32 filt_ok = (u32)(packed && !sw.no_pre5_d2);
         FlatSel fs;
         fs.sel = sel_all;
         fs.cap = flat_cap;
         fs.selbase = selbase;
         fs.nsel = nsel;
         // (tests: DICEY_FUSED_LCAP lowers the list's capacity so that ordinary groups exercise the hand-over to the generic select kernels)
-        const u32 lcap2 = std::getenv("DICEY_FUSED_LCAP") ? std::max<u32>(1u, std::min<u32>(FUSED2_LCAP, (u32)std::atoi(std::getenv("DICEY_FUSED_LCAP")))) : FUSED2_LCAP;
+        const u32 lcap2 = sw.fused_lcap ? std::max<u32>(1u, std::min<u32>(FUSED2_LCAP, sw.fused_lcap)) : FUSED2_LCAP;
         if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2);
         DG_HIP(hipEventRecord(ix->ev[8], st));
@@ -1000,7 +1008,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         va.chits = d_chits;  // the banded kernel writes compact records itself
         // hits per lane: 1 while a query has a handful of hits (every window is its own class: nothing to share, smallest LDS
         // footprint), 8 when the previous batch had dozens of hits per query (repeat families: ~240 hits per kept string)
-        const int ch_env = std::getenv("DICEY_VERIFY_CH") ? std::atoi(std::getenv("DICEY_VERIFY_CH")) : 0;
+        const int ch_env = sw.verify_ch;
         const u64 per_q = hit_cap / std::max<u64>(nq, 1);
         // (distance 2 on an i.i.d. genome: 59 hits per query from ~50 strings — nothing to share, and the wider trace of 13 diagonals
         //  leaves room for fewer workgroups: r03 measured 2.39 ms with 8 hits per lane against 1.83 ms for the lane-per-hit kernel)
@@ -1067,7 +1075,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (hsum.refused)
       return fail(DG_EINVAL, "internal error: %llu quer%s could reach the maxNeighborhood cap (%u) without having been enumerated on the host",
                   hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
-    if (const char* dj = std::getenv("DICEY_DUMP_JOBS")) {  // development aid: (lo, occs, take) of the batch's locate jobs, small then big
+    if (const char* dj = sw.dump_jobs.empty() ? nullptr : sw.dump_jobs.c_str()) {  // development aid: (lo, occs, take) of the batch's locate jobs, small then big
       const u32 jc = (u32)std::min<u64>(leaf_slots, 1u << 20);
       const u32 ns_ = (u32)std::min<u64>(hsum.jobs_small, jc), nb_ = (u32)std::min<u64>(hsum.jobs_big, jc);
       std::vector<BigJob> hj((size_t)ns_ + nb_);
@@ -1238,8 +1246,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->t_base_gen = 0;
   R->t_search_begin_ms = R->t_search_end_ms = 0.0;
   if (base_ev && (b.fastK || b.fast2K)) {
+    // the two base events are used in turn and re-recorded under the shared record's mutex: a batch that outlived two generations
+    // (cap-prone or very long batches) finds its base re-recorded and reports no interval rather than a wrong one
+    dg_index::SharedHints* shb = ix->shared_hints.load();
+    std::unique_lock<std::mutex> lkb(shb->mu);
     float t0 = 0.f, t1 = 0.f;
-    if (hipEventElapsedTime(&t0, base_ev, ix->ev[1]) == hipSuccess && hipEventElapsedTime(&t1, base_ev, ix->ev[8]) == hipSuccess && t0 >= 0.f) {
+    if (shb->base_gen - base_gen < 2 && hipEventElapsedTime(&t0, base_ev, ix->ev[1]) == hipSuccess && hipEventElapsedTime(&t1, base_ev, ix->ev[8]) == hipSuccess && t0 >= 0.f) {
       R->t_search_begin_ms = t0;
       R->t_search_end_ms = t1;
       R->t_base_gen = base_gen;
@@ -1267,6 +1279,35 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
 }  // namespace dg
 
 using namespace dg;
+
+dg_switches dg_switches::read() {
+  dg_switches w;
+  auto num = [](const char* name) -> long { const char* e = std::getenv(name); return e ? std::atol(e) : 0; };
+  w.host_timing = num("DICEY_TIMING") >= 2;
+  w.no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;
+  w.cap_host = std::getenv("DICEY_CAP_HOST") != nullptr;
+  w.no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr;
+  w.no_fuse2 = std::getenv("DICEY_NO_FUSED_SELECT2") != nullptr;
+  w.no_prep_fusion = std::getenv("DICEY_NO_PREP_FUSION") != nullptr;
+  w.no_pre5_d2 = std::getenv("DICEY_NO_PRE5_D2") != nullptr;
+  if (const char* e = std::getenv("DICEY_DEBUG_CAPS")) {
+    w.debug_caps = true;
+    w.debug_caps_s = e;
+  }
+  if (std::getenv("DICEY_FUSED_LCAP")) w.fused_lcap = (uint32_t)std::max(1L, num("DICEY_FUSED_LCAP"));
+  w.verify_ch = (int)num("DICEY_VERIFY_CH");
+  if (std::getenv("DICEY_CAP_BUDGET_MB")) w.cap_budget_mb = (uint64_t)std::max(1L, num("DICEY_CAP_BUDGET_MB"));
+  if (std::getenv("DICEY_HOST_THREADS")) w.host_threads = (unsigned)std::max(1L, num("DICEY_HOST_THREADS"));
+  if (const char* e = std::getenv("DICEY_DUMP_JOBS")) w.dump_jobs = e;
+  return w;
+}
+static bool any_lane_busy(dg_index* ix) {
+  if (ix->busy.load()) return true;
+  std::lock_guard<std::mutex> lk(ix->lanes_mu);
+  for (dg_index* l : ix->lanes)
+    if (l && l->busy.load()) return true;
+  return false;
+}
 
 extern "C" {
 
@@ -1465,14 +1506,19 @@ static int hunt_host(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
   *out = nullptr;
   if (!nq) return fail(DG_EINVAL, "dg_hunt: empty batch");
   u64 total = qoff[nq];
-  u32 maxlen = p->max_query_len;  // the caller's bound: the kernels count the queries above it (k_prepare) and the batch fails if any
-  if (!maxlen) {
-    for (size_t i = 0; i < nq; ++i) {
-      if (qoff[i + 1] < qoff[i]) return fail(DG_EINVAL, "dg_hunt: qoff must be non-decreasing");
-      u64 l = qoff[i + 1] - qoff[i];
-      if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "query %zu is too long", i);
-      maxlen = std::max<u32>(maxlen, (u32)l);
-    }
+  // The offsets are in host memory here: one pass over them (cheap beside the memcpy below) settles monotonicity and the
+  // maximum, whether or not the caller named a bound — cap_scan and the staging copy below index with them.
+  u32 maxlen = 0;
+  for (size_t i = 0; i < nq; ++i) {
+    if (qoff[i + 1] < qoff[i]) return fail(DG_EINVAL, "dg_hunt: qoff must be non-decreasing");
+    u64 l = qoff[i + 1] - qoff[i];
+    if (l > 0xFFFFFFu) return fail(DG_ELIMIT, "query %zu is too long", i);
+    maxlen = std::max<u32>(maxlen, (u32)l);
+  }
+  if (p->max_query_len) {
+    if (maxlen > p->max_query_len)
+      return fail(DG_EINVAL, "dg_hunt: a query of %u nt exceeds dg_hunt_params::max_query_len = %u", maxlen, p->max_query_len);
+    maxlen = p->max_query_len;  // the caller's bound sizes the batch (stable workspace sizes over a stream of batches)
   }
   DG_HIP(hipSetDevice(ix->device));
   DG_TRY(ix->ws[WS_QB].reserve(total + 8));
@@ -1505,8 +1551,10 @@ static int hunt_host(dg_index* ix, const dg_hunt_params* p, const uint32_t* seql
 
 int dg_hunt(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
             const uint64_t* qoff, size_t nq, dg_hunt_result** out) {
-  // a submitted batch owns the lane's stream, workspaces and hints until its ticket has been waited for
-  if (ix && ix->busy.load()) return fail(DG_EINVAL, "dg_hunt: a dg_hunt_submit batch is in flight on this handle (dg_hunt_wait first)");
+  // a submitted batch owns its lane's stream, workspaces and hints until its ticket has been waited for; the blocking call runs on
+  // the handle itself and is refused while ANY ticket of the handle is open (dicey_gpu.h)
+  if (ix && any_lane_busy(ix)) return fail(DG_EINVAL, "dg_hunt: a dg_hunt_submit batch is in flight on this handle (dg_hunt_wait first)");
+  if (ix) ix->sw = dg_switches::read();
   return hunt_host(ix, p, seqlen, nseq, qbytes, qoff, nq, out, nullptr);
 }
 
@@ -1550,7 +1598,7 @@ struct dg_index::Worker {
         t = job;
         job = nullptr;
       }
-      const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
+      const bool tm = t->ix->sw.host_timing;  // (read by the submitting thread)
       const double t_take = tm ? host_us() : 0.0;
       if (t->d_qoff)
         t->rc = hunt_device(t->ix, &t->p, t->seqlen.data(), (uint32_t)t->seqlen.size(), t->d_qbytes, t->d_qoff, t->nq, t->total_qbytes,
@@ -1584,13 +1632,15 @@ void dg_index::stop_worker() {
 static int submit_batch(const char* who, dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uint32_t nseq, const uint8_t* qbytes,
                         const uint64_t* qoff, const void* d_qbytes, const void* d_qoff, uint64_t total_qbytes, int fetch, size_t nq,
                         dg_hunt_ticket** out) {
-  const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
+  const dg_switches sw_now = dg_switches::read();  // on the submitting thread; the lane's helper thread never touches the environment
+  const bool tm = sw_now.host_timing;
   const double t_sub = tm ? host_us() : 0.0;
   // Lanes of a handle (ABI 5: two, r04: three): the handle itself while it is idle, else the first idle internal lane (a shared
   // handle: own stream, workspaces and helper thread on the same resident index; created at the first need).  A caller that keeps
   // one batch in flight never leaves the first lane.  Two lanes leave the search kernel idle a quarter of the time (both batches in
   // their launch-bound tails at once: profiles/r04c_k_search_launches.json); the third fills that.
   dg_index* const owner = ix;
+  std::unique_lock<std::mutex> lanes_lk(owner->lanes_mu);  // lanes, their shared record and their helper threads are created lazily: one submitter at a time
   if (ix->busy.exchange(true)) {
     ix = nullptr;
     for (dg_index*& l : owner->lanes) {
@@ -1614,6 +1664,7 @@ static int submit_batch(const char* who, dg_index* ix, const dg_hunt_params* p, 
     if (!ix)
       return fail(DG_EINVAL, "%s: %d batches are already in flight on this handle (wait for the oldest ticket first)", who, 1 + dg_index::NEXTRA);
   }
+  ix->sw = sw_now;
   dg_hunt_ticket* t = nullptr;
   try {
     t = new dg_hunt_ticket;
@@ -1652,6 +1703,7 @@ static int submit_batch(const char* who, dg_index* ix, const dg_hunt_params* p, 
       ix->worker->job = t;
     }
     ix->worker->cv.notify_all();
+    lanes_lk.unlock();
   } catch (const std::exception& e) {
     if (t && t->stage) pinned_pool().put(t->stage);
     delete t;
@@ -1682,7 +1734,7 @@ int dg_hunt_device_submit(dg_index* ix, const dg_hunt_params* p, const uint32_t*
 int dg_hunt_wait(dg_hunt_ticket* t, dg_hunt_result** out) {
   if (!t || !out) return fail(DG_EINVAL, "dg_hunt_wait: null argument");
   dg_index* ix = t->ix;
-  const bool tm = std::getenv("DICEY_TIMING") && std::atoi(std::getenv("DICEY_TIMING")) >= 2;
+  const bool tm = ix->sw.host_timing;
   const double t_w = tm ? host_us() : 0.0;
   {
     std::unique_lock<std::mutex> lk(ix->worker->mu);
@@ -1744,6 +1796,7 @@ int dg_neighborhood_count(dg_index* ix, uint32_t distance, int hamming, uint32_t
     const uint32_t one_seq = 1;  // chromosome lookup is not used in count mode
     std::vector<u64> counts(2 * fast.size());
     dg_hunt_result* hr = nullptr;
+    ix->sw = dg_switches::read();
     int rc = run_batch(ix, &hp, &one_seq, 1, ix->ws[WS_QB].p, ix->ws[WS_QOFF].p, fast.size(), buf.size(), maxlen, 0, &hr, nullptr, counts.data(),
                        (const uint8_t*)buf.data(), off.data());
     if (hr) dg_hunt_result_free(hr);
@@ -1818,7 +1871,8 @@ int dg_hunt_device(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen
   if (!ix || !p || !seqlen || !d_qbytes || !d_qoff || !out) return fail(DG_EINVAL, "dg_hunt_device: null argument");
   *out = nullptr;
   if (!nq) return fail(DG_EINVAL, "dg_hunt_device: empty batch");
-  if (ix->busy.load()) return fail(DG_EINVAL, "dg_hunt_device: a dg_hunt_submit batch is in flight on this handle (dg_hunt_wait first)");
+  if (any_lane_busy(ix)) return fail(DG_EINVAL, "dg_hunt_device: a dg_hunt_submit batch is in flight on this handle (dg_hunt_wait first)");
+  ix->sw = dg_switches::read();
   return hunt_device(ix, p, seqlen, nseq, d_qbytes, d_qoff, nq, total_qbytes, fetch, out);
 }
 

@@ -15,6 +15,7 @@ struct Batch {  // device pointers of one batch
   const u8* qbytes;
   const u64* qoff;
   u64 nq;
+  u64 total_qbytes;  // bytes behind qbytes: k_prepare refuses offsets that decrease, leave this range or do not end at it
   u8* fw;    // codes 0..4 (A,C,G,T,N), same offsets as qbytes
   u8* rv;    // reverse complement
   u8* qseq;  // normalised ASCII

@@ -104,6 +104,14 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
   nsel[2 * q] = nsel[2 * q + 1] = 0;
   selbase[2 * q] = selbase[2 * q + 1] = 0xFFFFFFFFu;  // "generic path" until k_search1s claims the group
   u64 s = b.qoff[q], e = b.qoff[q + 1];
+  // Offsets are checked BEFORE a byte is touched: with dg_hunt_params::max_query_len the host skips its own pass over
+  // them, and a decreasing pair would wrap m to ~4e9 and send the byte loop far outside the workspaces.  Such a query counts as
+  // "too long" (the batch fails with DG_EINVAL) and is prepared as an empty one.
+  const bool bad_len = e < s || e - s > (u64)b.maxlen_bound || e > b.total_qbytes || (q + 1 == b.nq && e != b.total_qbytes);
+  if (bad_len) {
+    atomicAdd(b.too_long, 1u);
+    e = s = 0;
+  }
   u32 m = (u32)(e - s), bad = 0, flags = 0, generic = 0;
   u64 pk_fw = 0, pk_rv = 0;  // 2-bit packed strands, q[i] at bits 2(m-1-i) (meaningful for m <= 32 without N)
   u32 pm[4] = {0u, 0u, 0u, 0u};  // position masks of the forward strand: bit i of pm[x] <=> q[i] is base x (m <= 32; an N sets none)
@@ -149,7 +157,6 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
       b.rv[s + (m - 1 - i)] = (u8)(code < 4 ? 3 - code : 4);
     }
   }
-  if (m > b.maxlen_bound) atomicAdd(b.too_long, 1u);
   u32 d = b.distance;
   if (m < 10) flags |= DG_Q_TOO_SHORT;  // hunter.h:299
   else if (d >= m) {                    // hunter.h:312-315
@@ -170,7 +177,7 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
   for (u32 strand = 0; strand < 2; ++strand) {
     GidInfo gi;
     gi.qpk = 0;
-    gi.m = ((flags & DG_Q_TOO_SHORT) || explicit_set || (strand && !b.reverse) || m > b.maxlen_bound) ? 0u : m;
+    gi.m = ((flags & DG_Q_TOO_SHORT) || explicit_set || (strand && !b.reverse) || bad_len) ? 0u : m;
     gi.d_win = d | (bad == 0 ? 256u : 0u);
     if (b.fastK && gi.m && bad == 0 && d == 1 && m <= 31 && m >= b.fastK + 1) gi.d_win |= 512u;
     if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;

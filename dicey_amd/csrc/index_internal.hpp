@@ -1,9 +1,24 @@
 // The object behind the opaque dg_index handle.
 #pragma once
 #include <mutex>
+#include <string>
 #include <atomic>
 #include "common.hpp"
 #include "devfm.hpp"
+
+// Test / development switches of the hunt pipeline (environment variables).  Read ONCE per batch, on the thread that calls the
+// library (the submitting thread for dg_hunt_submit batches) — never on the lanes' helper threads, where getenv would race with a
+// host process that writes its environment — and carried to run_batch in the handle.
+struct dg_switches {
+  bool host_timing = false, no_band = false, cap_host = false, no_fuse = false, no_fuse2 = false, no_prep_fusion = false, no_pre5_d2 = false;
+  bool debug_caps = false;
+  uint32_t fused_lcap = 0;       // DICEY_FUSED_LCAP (0 = unset)
+  int verify_ch = 0;             // DICEY_VERIFY_CH
+  uint64_t cap_budget_mb = 0;    // DICEY_CAP_BUDGET_MB (0 = unset)
+  unsigned host_threads = 0;     // DICEY_HOST_THREADS (0 = unset)
+  std::string dump_jobs, debug_caps_s;
+  static dg_switches read();     // hunt.hip
+};
 
 struct dg_index {
   int device = 0;
@@ -42,6 +57,8 @@ struct dg_index {
   // the batch counters are left zeroed by the last kernel of a batch (hunt.hip batch_finish): the next batch skips its memset
   // when they still sit where that kernel cleaned them
   std::atomic<bool> busy{false};      // a dg_hunt_submit batch is in flight on this handle (lane)
+  dg_switches sw;                     // the switches of the batch this handle (lane) runs; set by the entry point on the caller's thread
+  std::mutex lanes_mu;                // guards the lazy creation of lanes[] / shared_hints / a lane's worker (concurrent submitters)
   // ABI 5: dg_hunt_submit keeps several batches in flight on one handle; a submission that finds the handle busy runs on an internal
   // lane (a shared handle: own stream, workspaces, helper thread; created at the first need, closed with the handle)
   static constexpr int NEXTRA = 2;            // internal lanes beside the handle itself: three batches in flight (r04: two)

@@ -547,6 +547,7 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   sx.max_primer_len = maxp;
   sx.max_koff = maxk;
   dg_hunt_result* hr = nullptr;
+  ix->sw = dg_switches::read();
   int rc = run_batch(ix, &hp, seqlen, nseq, ws[WS_QB].p, ws[WS_QOFF].p, np, kq.size(), p->kmer, 0, &hr, &sx, nullptr, kq.data(), koffs.data());
   if (rc != DG_OK) {
     if (hr) dg_hunt_result_free(hr);

@@ -537,3 +537,44 @@ def test_fused_select_and_its_hand_over_to_the_generic_kernels(small_genome, mon
         for q, (gf, gr) in zip(pure[:40], ix.neighborhood_count([q.encode() for q in pure[:40]], distance=1)):
             assert gf == sum(orc.count(s.encode()) for s in O.neighbors(q, 1, True)), q
             assert gr == sum(orc.count(s.encode()) for s in O.neighbors(rc(q), 1, True)), q
+
+
+def test_decreasing_offsets_fail_loudly_even_with_a_length_bound(gpu_small, small_genome):
+    """ADVICE r04: with dg_hunt_params::max_query_len the host used to skip its pass over the offsets and k_prepare ran its byte loop
+    over qoff[q + 1] - qoff[q] wrapped to ~4e9.  Host buffers (dg_hunt), device buffers (dg_hunt_device, with and without the bound,
+    cap-prone distance included): DG_EINVAL each time, and the resident index still answers the next batch correctly."""
+    import ctypes as C
+    import numpy as np
+    import dicey_amd
+    from dicey_amd import _capi
+    L = _capi.load()
+    g = small_genome
+    qs = make_queries(77, g["text"], 64, (20,))
+    want = [[(h.score, h.chr, h.start, h.strand) for h in q.hits] for q in gpu_small.hunt(qs, g["seqlen"], distance=1).queries]
+    qbytes = "".join(qs).encode()
+    off = np.zeros(len(qs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(q) for q in qs])
+    sl = (C.c_uint32 * len(g["seqlen"]))(*g["seqlen"])
+    bad_sets = []
+    o1 = off.copy(); o1[10], o1[11] = o1[11], o1[10]                    # one decreasing pair in the middle
+    bad_sets.append(o1)
+    o2 = off.copy(); o2[5] = np.uint64(1) << np.uint64(40)              # leaves the buffer (and decreases right behind)
+    bad_sets.append(o2)
+    o3 = off.copy(); o3[-1] = o3[-1] - np.uint64(3)                     # does not end at total_qbytes (device path only: the host path takes qoff[nq] as the total)
+    for bound, dist in ((20, 1), (0, 1), (20, 2), (64, 2)):
+        for oi, o in enumerate(bad_sets + [o3]):
+            p = _capi.HuntParams(dist, 0, 0, 1000, 10000, bound, _capi.DG_HUNT_COMPACT)
+            oa = (C.c_uint64 * len(o))(*[int(x) for x in o])
+            rp = C.POINTER(_capi.HuntResult)()
+            if oi < 2:
+                rc = L.dg_hunt(gpu_small.handle, C.byref(p), sl, len(g["seqlen"]), qbytes, oa, len(qs), C.byref(rp))
+                assert rc != 0 and not rp, (bound, dist, oi, rc)
+            if torch is not None:
+                dq = torch.frombuffer(bytearray(qbytes), dtype=torch.uint8).cuda()
+                do = torch.from_numpy(o.view(np.int64).copy()).cuda()
+                torch.cuda.synchronize()
+                rp = C.POINTER(_capi.HuntResult)()
+                rc = L.dg_hunt_device(gpu_small.handle, C.byref(p), sl, len(g["seqlen"]), C.c_void_p(dq.data_ptr()), C.c_void_p(do.data_ptr()),
+                                      len(qs), len(qbytes), 0, C.byref(rp))
+                assert rc != 0 and not rp, (bound, dist, oi, rc)
+    assert [[(h.score, h.chr, h.start, h.strand) for h in q.hits] for q in gpu_small.hunt(qs, g["seqlen"], distance=1, max_query_len=20).queries] == want

@@ -681,6 +681,42 @@ def main():
             elapsed = float(t.item())
         return acc, elapsed, gathered
 
+    class CxxGather:
+        """The hunt configurations on the RCCL backend: libdiceygather.so (dicey_amd/csrc/gather.hip, include/dicey_gather.h) — the
+        C++ host's gather.  A step's whole answer ([hit counts | query words | records], ONE block in HBM: dg_hunt_result::d_block) is
+        staged on the stream its batch ran on and travels one step behind as exact-size ncclSend / ncclRecv on the communicator's own
+        stream: no host synchronisation anywhere on the submit path (r04 synchronised torch's stream every step)."""
+
+        def __init__(self, capacity):
+            from dicey_amd import _gather
+            uid = [_gather.Comm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            self.c = _gather.Comm(world, rank, int(capacity), root=0, device=local, unique_id=uid[0])
+            self.bytes_received = 0
+            self.bytes_moved = 0
+
+        def submit_block(self, ptr, nbytes, stream):
+            self.c.submit(ptr, nbytes, stream)
+
+        def finish(self):
+            b, _ = self.c.finish()
+            self.bytes_received += b
+            self.bytes_moved += b  # exact-size transfers: what travels is the payload
+            return self.bytes_received
+
+        def last_received(self):
+            return [self.c.last(r) for r in range(world)] if rank == 0 else []
+
+    def gather_block(R):
+        """hunt, backend nccl: the batch's compact block to rank 0 through the C++ gather"""
+        nb = int(R.d_block_bytes) if R is not None else 0
+        if pipe["g"] is None:
+            pipe["g"] = CxxGather(int(max(nb, 8 * units) * 1.5) + 65536)
+        pipe["g"].submit_block(R.d_block if nb else 0, nb, R.stream if nb else 0)
+        if a.dump_gather:
+            pipe["last_local"] = device_bytes(R.d_block, nb, dev).cpu().numpy().tobytes() if nb else b""
+
     def gather_parts(parts):
         """result lists to rank 0 over RCCL/xGMI, overlapped with the next step (dicey_amd/shard.py)"""
         if pipe["g"] is None:  # first (warm-up) step: agree on a capacity once
@@ -736,7 +772,10 @@ def main():
             rot["k"] += 1
             if nq == 0:  # strong scaling: a rank behind the end of the batch still takes part in every gather
                 if (world > 1 or a.gather_single) and not fetch:
-                    gather_parts([torch.empty(0, dtype=torch.uint8, device=dev)])
+                    if a.backend == "nccl":
+                        gather_block(None)
+                    else:
+                        gather_parts([torch.empty(0, dtype=torch.uint8, device=dev)])
                 return {k_: 0 for k_ in ("nhits", "ext", "leaves", "sa", "win", "tab", "probe", "ops_per_hit", "ms_total", "ms_search",
                                          "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns", "t0", "t1", "gen")}
             rp = C.POINTER(_capi.HuntResult)()
@@ -748,7 +787,9 @@ def main():
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
                    "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns,
                    "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen}
-            if (world > 1 or a.gather_single) and not fetch:
+            if (world > 1 or a.gather_single) and not fetch and a.backend == "nccl" and R.compact:
+                gather_block(R)
+            elif (world > 1 or a.gather_single) and not fetch:
                 if R.compact:  # ABI 5 records: position, packed word, d operation words = 12 bytes per hit at distance 1
                     parts = [device_bytes(R.d_hits, R.nhits * 4 * (2 + R.ops_per_hit), dev)]
                 else:
@@ -774,7 +815,9 @@ def main():
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
                    "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns,
                    "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen}
-            if world > 1 or a.gather_single:
+            if (world > 1 or a.gather_single) and a.backend == "nccl" and R.compact:
+                gather_block(R)  # staged on the lane's own stream (R.stream): ordered before that lane's next batch
+            elif world > 1 or a.gather_single:
                 # the lane that ran this batch stays idle until the next step's submit: its result buffers are staged before that
                 gather_parts([device_bytes(R.d_hits, R.nhits * 4 * (2 + R.ops_per_hit), dev)] if R.compact else
                              [device_bytes(R.d_hits, R.nhits * C.sizeof(_capi.Hit), dev)] +
@@ -1056,7 +1099,8 @@ def main():
                            "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
                            "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
                            "distinct_batches": len(dev_batches), "in_flight_batches": a.in_flight,
-                           "results": "compact records (DG_HUNT_COMPACT: 8 + 4 d bytes per hit) left in HBM (N = 1) / gathered to rank 0 (N > 1)",
+                           "results": "the batch's compact block (DG_HUNT_COMPACT: 8 B per query + 8 + 4 d B per hit) left in HBM (N = 1) / gathered to rank 0 "
+                                      "over RCCL by the C++ gather, libdiceygather.so (N > 1)",
                            "in_flight": (f"{a.in_flight} batches per GPU (dg_hunt_device_submit / dg_hunt_wait on the handle's lanes: step k is submitted, "
                                          f"then step k - {a.in_flight - 1} collected; K batches start and end inside the timed region)" if a.in_flight >= 2
                                          else "1 batch per GPU (dg_hunt_device)"),
@@ -1366,6 +1410,8 @@ def main():
             out["gathered_bytes_per_step"] = gathered / max(1, a.steps)
             if pipe["g"] is not None:
                 out["gather_bytes_moved_per_step"] = pipe.get("moved", 0) / max(1, a.steps)
+    if isinstance(pipe["g"], CxxGather):
+        pipe["g"].c.close()  # the communicator goes before the index whose streams its staging copies were queued on
     for h in shared[1:]:
         h.close()
     if th is not None:

@@ -23,6 +23,11 @@
 #include <vector>
 
 #include "../../include/dicey_gpu.h"
+#include <dlfcn.h>
+#include <unistd.h>
+#include <chrono>
+
+#include "../../include/dicey_gather.h"
 #include "cli_common.hpp"
 #include "dtoa.hpp"
 
@@ -173,6 +178,193 @@ std::vector<int> devices_from_env() {
   return out;
 }
 
+// ---------------------------------------------------------------------------- one process per GPU (DICEY_RANKS, hunter())
+// libdiceygather.so is loaded only in this mode (it brings RCCL into the process): next to the binary, like libdiceygpu.so.
+struct GatherApi {
+  void* so = nullptr;
+  int (*unique_id)(uint8_t*) = nullptr;
+  int (*open)(const uint8_t*, int, int, int, uint64_t, int, dg_comm**) = nullptr;
+  int (*open_tcp)(int, int, int, uint64_t, int, dg_comm**) = nullptr;
+  int (*close)(dg_comm*) = nullptr;
+  int (*submit)(dg_comm*, void*, const void*, uint64_t) = nullptr;
+  int (*finish)(dg_comm*, uint64_t*, uint64_t*) = nullptr;
+  int (*last_to_host)(dg_comm*, int, void*, uint64_t, uint64_t*) = nullptr;
+  int (*max_u64)(dg_comm*, uint64_t, uint64_t*) = nullptr;
+  const char* (*last_error)() = nullptr;
+  bool load(std::string& err) {
+    char exe[4096];
+    const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+    std::string dir = n > 0 ? std::string(exe, (size_t)n) : std::string("./dicey");
+    dir = dir.substr(0, dir.find_last_of('/') + 1);
+    so = dlopen((dir + "libdiceygather.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!so) {
+      err = std::string("libdiceygather.so: ") + dlerror();
+      return false;
+    }
+#define DG_SYM(field, name)                                     \
+    field = reinterpret_cast<decltype(field)>(dlsym(so, name)); \
+    if (!field) {                                               \
+      err = std::string("libdiceygather.so lacks ") + name;     \
+      return false;                                             \
+    }
+    DG_SYM(unique_id, "dg_comm_unique_id")
+    DG_SYM(open, "dg_comm_open")
+    DG_SYM(open_tcp, "dg_comm_open_tcp")
+    DG_SYM(close, "dg_comm_close")
+    DG_SYM(submit, "dg_gather_submit")
+    DG_SYM(finish, "dg_gather_finish")
+    DG_SYM(last_to_host, "dg_gather_last_to_host")
+    DG_SYM(max_u64, "dg_comm_max_u64")
+    DG_SYM(last_error, "dg_gather_last_error")
+#undef DG_SYM
+    return true;
+  }
+};
+
+template <class FormatFn>
+int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const std::vector<std::pair<std::string, std::string>>& queries,
+               const std::vector<uint32_t>& seqlen, const dg_hunt_params& hp, FormatFn& format_chunk_to) {
+  auto die = [&](const std::string& m) {
+    std::cerr << "dicey (rank " << rank << " of " << N << "): " << m << std::endl;
+    return 2;
+  };
+  if (rank < 0 || rank >= N) return die("DICEY_RANK outside [0, DICEY_RANKS)");
+  GatherApi G;
+  std::string err;
+  if (!G.load(err)) return die(err);
+  const uint64_t CAP = 64ull << 20;  // bytes per transfer; a chunk's block travels in as many pieces as the largest rank's needs
+  dg_comm* comm = nullptr;
+  // DICEY_COMM_TCP=<port>: the library's host-memory test transport (two ranks on the one GPU of a test box; RCCL does not
+  // take two ranks on one device).  The product form is RCCL: rank 0 writes the communicator id to DICEY_COMM_FILE.
+  const char* tcp = std::getenv("DICEY_COMM_TCP");
+  if (tcp) {
+    if (G.open_tcp(std::atoi(tcp), N, rank, CAP, 0, &comm) != 0) return die(G.last_error());
+  } else {
+    const char* cf = std::getenv("DICEY_COMM_FILE");
+    uint8_t id[DG_COMM_ID_BYTES];
+    if (N > 1 && !cf) return die("DICEY_COMM_FILE (where rank 0 leaves the communicator id) is not set");
+    if (rank == 0) {
+      if (G.unique_id(id) != 0) return die(G.last_error());
+      if (cf) {
+        const std::string tmp = std::string(cf) + ".tmp";
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) return die("cannot write " + tmp);
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), cf) != 0) return die(std::string("cannot create ") + cf);
+      }
+    } else {
+      bool got = false;
+      for (int attempt = 0; attempt < 1200 && !got; ++attempt) {  // the ranks start together; rank 0 writes within milliseconds
+        if (FILE* f = std::fopen(cf, "rb")) {
+          got = std::fread(id, 1, sizeof id, f) == sizeof id;
+          std::fclose(f);
+        }
+        if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      }
+      if (!got) return die(std::string("no communicator id in ") + cf);
+    }
+    if (G.open(id, N, rank, device, CAP, 0, &comm) != 0) return die(G.last_error());
+  }
+  const size_t nq = queries.size(), per = (nq + N - 1) / N;
+  const size_t CH = 1u << 17;
+  const size_t nchunks = std::max<size_t>(1, (per + CH - 1) / CH);  // the same on every rank: collectives stay in step
+  auto range_of = [&](int r, size_t k, size_t& q0, size_t& q1) {
+    const size_t s0 = std::min(nq, (size_t)r * per), s1 = std::min(nq, s0 + per);
+    q0 = std::min(s1, s0 + k * CH);
+    q1 = std::min(s1, q0 + CH);
+  };
+  std::vector<uint64_t> seq_start(seqlen.size() + 1, 0);
+  for (size_t i = 0; i < seqlen.size(); ++i) seq_start[i + 1] = seq_start[i] + seqlen[i];
+  // rank 0 keeps every (rank, chunk) block on the host until everything has arrived, then formats in query order
+  std::vector<std::vector<std::vector<uint8_t>>> got(rank == 0 ? N : 0, std::vector<std::vector<uint8_t>>(nchunks));
+  int rc_all = 0;
+  for (size_t k = 0; k < nchunks; ++k) {
+    size_t q0, q1;
+    range_of(rank, k, q0, q1);
+    dg_hunt_result* R = nullptr;
+    std::string qb;
+    std::vector<uint64_t> off(q1 - q0 + 1, 0);
+    if (q1 > q0) {
+      size_t longest = 0;
+      for (size_t i = 0; i < q1 - q0; ++i) {
+        qb += queries[q0 + i].second;
+        off[i + 1] = qb.size();
+        longest = std::max(longest, queries[q0 + i].second.size());
+      }
+      dg_hunt_params cp = hp;
+      cp.max_query_len = (uint32_t)std::min<size_t>(longest, 0xFFFFFFu);
+      cp.flags = DG_HUNT_COMPACT;
+      if (dg_hunt(ix, &cp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), q1 - q0, &R) != DG_OK) {
+        die(dg_last_error());  // outside the supported envelope: the whole job fails, never a partial answer
+        std::_Exit(2);         // (the peers' collectives cannot complete without this rank: they are ended by the launcher)
+      }
+    }
+    const uint64_t bytes = R ? R->d_block_bytes : 0;
+    uint64_t most = 0;
+    if (G.max_u64(comm, bytes, &most) != 0) return die(G.last_error());
+    const uint64_t pieces = std::max<uint64_t>(1, (most + CAP - 1) / CAP);
+    for (uint64_t pc = 0; pc < pieces; ++pc) {
+      const uint64_t b0 = std::min(bytes, pc * CAP), b1 = std::min(bytes, b0 + CAP);
+      // RCCL: out of HBM, staged on the stream the batch ran on; the TCP test transport takes the fetched copy of the same bytes
+      const uint8_t* src = !R ? nullptr : tcp ? (const uint8_t*)R->qinfo - 4 * (q1 - q0) : (const uint8_t*)R->d_block;
+      if (G.submit(comm, (R && !tcp) ? R->stream : nullptr, src ? src + b0 : nullptr, b1 - b0) != 0) return die(G.last_error());
+      if (G.finish(comm, nullptr, nullptr) != 0) return die(G.last_error());
+      if (rank == 0)
+        for (int r = 0; r < N; ++r) {
+          uint64_t n = 0;
+          if (G.last_to_host(comm, r, nullptr, 0, &n) != 0 && n == 0) return die(G.last_error());
+          std::vector<uint8_t>& dst = got[r][k];
+          const size_t at = dst.size();
+          dst.resize(at + n);
+          if (n && G.last_to_host(comm, r, dst.data() + at, n, &n) != 0) return die(G.last_error());
+        }
+    }
+    if (R) dg_hunt_result_free(R);
+  }
+  G.close(comm);
+  if (rank != 0) return 0;
+  std::function<void(std::string&&)> bulk;
+  if (!c.has_outfile)
+    bulk = [&](std::string&& blob) {
+      std::fwrite(blob.data(), 1, blob.size(), stdout);
+      std::fflush(stdout);
+    };
+  auto sink = [&](size_t, std::string&& js) { emit(c, js); };
+  for (int r = 0; r < N && !rc_all; ++r)
+    for (size_t k = 0; k < nchunks && !rc_all; ++k) {
+      size_t q0, q1;
+      range_of(r, k, q0, q1);
+      const size_t n = q1 - q0;
+      if (!n) continue;
+      const std::vector<uint8_t>& blk = got[r][k];
+      if (blk.size() < 8 * n) {
+        rc_all = die("rank " + std::to_string(r) + " sent " + std::to_string(blk.size()) + " bytes for " + std::to_string(n) + " queries");
+        break;
+      }
+      // the block as a result: [hit counts | query words | records]
+      dg_hunt_result S{};
+      std::vector<uint64_t> hit_off(n + 1, 0);
+      const uint32_t* qh = (const uint32_t*)blk.data();
+      for (size_t i = 0; i < n; ++i) hit_off[i + 1] = hit_off[i] + qh[i];
+      S.nq = n;
+      S.nhits = hit_off[n];
+      const uint64_t rec_bytes = blk.size() - 8 * n;
+      if (S.nhits && (rec_bytes % (4 * S.nhits) != 0 || rec_bytes / (4 * S.nhits) < 2)) {
+        rc_all = die("rank " + std::to_string(r) + ": " + std::to_string(rec_bytes) + " record bytes for " + std::to_string(S.nhits) + " hits");
+        break;
+      }
+      S.ops_per_hit = S.nhits ? (uint32_t)(rec_bytes / (4 * S.nhits)) - 2 : 0;
+      S.hit_off = hit_off.data();
+      S.qinfo = const_cast<uint32_t*>(qh) + n;
+      S.chits = const_cast<uint32_t*>(qh) + 2 * n;
+      S.compact = 1;
+      S.nseq = (uint32_t)seqlen.size();
+      S.seq_start = seq_start.data();
+      format_chunk_to(&S, q0, n, sink, bulk);
+    }
+  return rc_all;
+}
+
 // ------------------------------------------------------------------------------------------------ hunt (hunter.h:177-447)
 int hunter(int argc, char** argv) {
   Config c;
@@ -271,6 +463,10 @@ int hunter(int argc, char** argv) {
   // (ceil(nq/G) each): DICEY_DEVICES=0,1,... gives one host thread and one full index replica per listed
   // device; results are written in query order.  One device (DICEY_DEVICE, default 0): results stream out chunk by chunk.
   std::vector<int> devices = devices_from_env();
+  if (std::getenv("DICEY_RANKS")) {  // one process per GPU: this process's device (DICEY_DEVICE, else its rank)
+    const int one = std::getenv("DICEY_DEVICE") ? device_from_env() : (std::getenv("DICEY_RANK") ? std::atoi(std::getenv("DICEY_RANK")) : 0);
+    devices.assign(1, one);
+  }
   if (devices.size() > queries.size()) devices.resize(std::max<size_t>(1, queries.size()));
   const size_t G = devices.size();
   std::vector<dg_index*> handles(G, nullptr);
@@ -308,6 +504,89 @@ int hunter(int argc, char** argv) {
   hp.forward_only = c.forward;
   hp.max_locations = c.max_locations;
   hp.max_neighborhood = c.max_neighborhood;
+  // one JSON line per query of a finished chunk, handed to the sink in query order
+  auto format_chunk_to = [&](dg_hunt_result* R, size_t q0, size_t nq, const std::function<void(size_t, std::string&&)>& sink,
+                             const std::function<void(std::string&&)>& bulk) {
+    auto line_of = [&](size_t i) -> std::string {
+      std::vector<std::string> m;
+      std::vector<DnaHit> ht;
+      const std::string& qname = queries[q0 + i].first;
+      // compact results (DG_HUNT_COMPACT): one word per query; the normalised sequence is formed here from the query's own bytes
+      const uint32_t qw = R->qinfo[i], qfl = DG_QINFO_FLAGS(qw);
+      if (qfl & DG_Q_TOO_SHORT) {
+        m.push_back("Error: Input sequence is shorter than 10 nucleotides!");
+        return hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m);
+      }
+      const std::string& raw = queries[q0 + i].second;
+      std::string seq(raw.size(), '\0');
+      uint32_t nondna = 0;
+      (void)dg_normalize_query((const uint8_t*)raw.data(), (uint32_t)raw.size(), (uint8_t*)seq.data(), &nondna);
+      for (uint32_t k = 0; k < nondna; ++k) m.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
+      if (qfl & DG_Q_DIST_ADJUSTED) m.push_back("Warning: Distance was adjusted to sequence length!");
+      if (qfl & DG_Q_NBHD_EXCEEDED) {
+        std::string x = std::to_string(c.max_neighborhood);
+        m.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x + " neighbors are searched, results are likely incomplete!");
+      }
+      for (uint64_t h = R->hit_off[i]; h < R->hit_off[i + 1]; ++h) {
+        // the hit from its compact record (dicey_gpu.h ABI 5: position, packed word, operation words) and its two rows from the
+        // operation words — built here, on the formatting threads
+        dg_hit H;
+        const uint32_t* hops = nullptr;
+        if (dg_chit_unpack(R, h, (uint32_t)i, &H, &hops) != DG_OK) {
+          std::fprintf(stderr, "dicey hunt: %s\n", dg_last_error());
+          std::abort();
+        }
+        std::string ra(H.aln_len, '\0'), qa(H.aln_len, '\0');
+        if (dg_hit_rows(&H, hops, R->ops_per_hit, (const uint8_t*)seq.data(), (uint32_t)seq.size(), ra.data(), qa.data()) != DG_OK) {
+          std::fprintf(stderr, "dicey hunt: %s\n", dg_last_error());
+          std::abort();
+        }
+        ht.push_back(DnaHit{H.score, H.chr, H.start, (char)H.strand, std::move(ra), std::move(qa)});
+      }
+      if (qfl & DG_Q_MAX_MATCHES) {
+        std::string x = std::to_string(c.max_locations);
+        m.push_back("Warning: More than " + x + " matches found. Only first " + x + " matches are reported, results are likely incomplete!");
+      }
+      std::sort(ht.begin(), ht.end());  // hunter.h:440 — same comparator, same libstdc++ algorithm, same input order
+      return hunt_json(c, DG_QINFO_DISTANCE(qw), seq, qname, seqname, ht, m);
+    };
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthr = (unsigned)std::max(1, std::atoi(e));
+    nthr = (unsigned)std::min<size_t>(std::min<unsigned>(nthr ? nthr : 1u, 64u), nq / 32);
+    if (nthr < 1) nthr = 1;
+    if (bulk) {
+      // stdout: every formatting thread appends its lines to one buffer, the buffers go out in order with one write each (the
+      // reference flushes after every line; the bytes are the same)
+      std::vector<std::string> blobs(nthr);
+      const size_t per_thr = (nq + nthr - 1) / nthr;
+      auto work = [&](unsigned t) {
+        std::string& o = blobs[t];
+        const size_t i0 = t * per_thr, i1 = std::min(nq, i0 + per_thr);
+        o.reserve((i1 > i0 ? i1 - i0 : 0) * 700);
+        for (size_t i = i0; i < i1; ++i) o += line_of(i);
+      };
+      if (nthr > 1) {
+        std::vector<std::thread> fmt;
+        for (unsigned t = 0; t < nthr; ++t) fmt.emplace_back(work, t);
+        for (auto& th : fmt) th.join();
+      } else work(0);
+      for (std::string& o : blobs) bulk(std::move(o));
+      return;
+    }
+    if (nthr > 1) {
+      std::vector<std::string> lines(nq);
+      std::vector<std::thread> fmt;
+      const size_t per_thr = (nq + nthr - 1) / nthr;
+      for (unsigned t = 0; t < nthr; ++t)
+        fmt.emplace_back([&, t]() {
+          for (size_t i = t * per_thr, e = std::min(nq, i + per_thr); i < e; ++i) lines[i] = line_of(i);
+        });
+      for (auto& th : fmt) th.join();
+      for (size_t i = 0; i < nq; ++i) sink(q0 + i, std::move(lines[i]));
+    } else {
+      for (size_t i = 0; i < nq; ++i) sink(q0 + i, line_of(i));
+    }
+  };
   // queries [q0, q1) on one handle, chunk by chunk; sink(i, json line of query i) is called in query order
   auto run_slice = [&](dg_index* ix, size_t s0, size_t s1, const std::function<void(size_t, std::string&&)>& sink, std::string& err,
                        const std::function<void(std::string&&)>& bulk = nullptr) -> bool {
@@ -325,88 +604,7 @@ int hunter(int argc, char** argv) {
       cp.flags = DG_HUNT_COMPACT;
       return cp;
     };
-    // one JSON line per query of a finished chunk, handed to the sink in query order
-    auto format_chunk = [&](dg_hunt_result* R, size_t q0, size_t nq) {
-      auto line_of = [&](size_t i) -> std::string {
-        std::vector<std::string> m;
-        std::vector<DnaHit> ht;
-        const std::string& qname = queries[q0 + i].first;
-        // compact results (DG_HUNT_COMPACT): one word per query; the normalised sequence is formed here from the query's own bytes
-        const uint32_t qw = R->qinfo[i], qfl = DG_QINFO_FLAGS(qw);
-        if (qfl & DG_Q_TOO_SHORT) {
-          m.push_back("Error: Input sequence is shorter than 10 nucleotides!");
-          return hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m);
-        }
-        const std::string& raw = queries[q0 + i].second;
-        std::string seq(raw.size(), '\0');
-        uint32_t nondna = 0;
-        (void)dg_normalize_query((const uint8_t*)raw.data(), (uint32_t)raw.size(), (uint8_t*)seq.data(), &nondna);
-        for (uint32_t k = 0; k < nondna; ++k) m.push_back("Warning: Non-DNA character in nucleotide sequence detected and replaced by 'N'!");
-        if (qfl & DG_Q_DIST_ADJUSTED) m.push_back("Warning: Distance was adjusted to sequence length!");
-        if (qfl & DG_Q_NBHD_EXCEEDED) {
-          std::string x = std::to_string(c.max_neighborhood);
-          m.push_back("Warning: Neighborhood size exceeds " + x + " candidates. Only first " + x + " neighbors are searched, results are likely incomplete!");
-        }
-        for (uint64_t h = R->hit_off[i]; h < R->hit_off[i + 1]; ++h) {
-          // the hit from its compact record (dicey_gpu.h ABI 5: position, packed word, operation words) and its two rows from the
-          // operation words — built here, on the formatting threads
-          dg_hit H;
-          const uint32_t* hops = nullptr;
-          if (dg_chit_unpack(R, h, (uint32_t)i, &H, &hops) != DG_OK) {
-            std::fprintf(stderr, "dicey hunt: %s\n", dg_last_error());
-            std::abort();
-          }
-          std::string ra(H.aln_len, '\0'), qa(H.aln_len, '\0');
-          if (dg_hit_rows(&H, hops, R->ops_per_hit, (const uint8_t*)seq.data(), (uint32_t)seq.size(), ra.data(), qa.data()) != DG_OK) {
-            std::fprintf(stderr, "dicey hunt: %s\n", dg_last_error());
-            std::abort();
-          }
-          ht.push_back(DnaHit{H.score, H.chr, H.start, (char)H.strand, std::move(ra), std::move(qa)});
-        }
-        if (qfl & DG_Q_MAX_MATCHES) {
-          std::string x = std::to_string(c.max_locations);
-          m.push_back("Warning: More than " + x + " matches found. Only first " + x + " matches are reported, results are likely incomplete!");
-        }
-        std::sort(ht.begin(), ht.end());  // hunter.h:440 — same comparator, same libstdc++ algorithm, same input order
-        return hunt_json(c, DG_QINFO_DISTANCE(qw), seq, qname, seqname, ht, m);
-      };
-      unsigned nthr = std::thread::hardware_concurrency();
-      if (const char* e = std::getenv("DICEY_HOST_THREADS")) nthr = (unsigned)std::max(1, std::atoi(e));
-      nthr = (unsigned)std::min<size_t>(std::min<unsigned>(nthr ? nthr : 1u, 64u), nq / 32);
-      if (nthr < 1) nthr = 1;
-      if (bulk) {
-        // stdout: every formatting thread appends its lines to one buffer, the buffers go out in order with one write each (the
-        // reference flushes after every line; the bytes are the same)
-        std::vector<std::string> blobs(nthr);
-        const size_t per_thr = (nq + nthr - 1) / nthr;
-        auto work = [&](unsigned t) {
-          std::string& o = blobs[t];
-          const size_t i0 = t * per_thr, i1 = std::min(nq, i0 + per_thr);
-          o.reserve((i1 > i0 ? i1 - i0 : 0) * 700);
-          for (size_t i = i0; i < i1; ++i) o += line_of(i);
-        };
-        if (nthr > 1) {
-          std::vector<std::thread> fmt;
-          for (unsigned t = 0; t < nthr; ++t) fmt.emplace_back(work, t);
-          for (auto& th : fmt) th.join();
-        } else work(0);
-        for (std::string& o : blobs) bulk(std::move(o));
-        return;
-      }
-      if (nthr > 1) {
-        std::vector<std::string> lines(nq);
-        std::vector<std::thread> fmt;
-        const size_t per_thr = (nq + nthr - 1) / nthr;
-        for (unsigned t = 0; t < nthr; ++t)
-          fmt.emplace_back([&, t]() {
-            for (size_t i = t * per_thr, e = std::min(nq, i + per_thr); i < e; ++i) lines[i] = line_of(i);
-          });
-        for (auto& th : fmt) th.join();
-        for (size_t i = 0; i < nq; ++i) sink(q0 + i, std::move(lines[i]));
-      } else {
-        for (size_t i = 0; i < nq; ++i) sink(q0 + i, line_of(i));
-      }
-    };
+    auto format_chunk = [&](dg_hunt_result* R, size_t q0, size_t nq) { format_chunk_to(R, q0, nq, sink, bulk); };
     // a chunk through the blocking call; a chunk whose capped neighbourhoods would not fit the library's host budget (DG_ELIMIT,
     // hunt.hip cap_scan: long primers at distance 2) is answered in halves — the reference answers that input too, slowly
     std::function<bool(dg_index*, size_t, size_t)> run_sync = [&](dg_index* hx, size_t q0, size_t q1) -> bool {
@@ -498,6 +696,19 @@ int hunter(int argc, char** argv) {
     if (second) dg_index_close(second);
     return ok;
   };
+  // DICEY_RANKS=N DICEY_RANK=r DICEY_COMM_FILE=<path>: ONE PROCESS PER GPU (BASELINE.json north_star: "the primer batch shards
+  // embarrassingly across the 8 GPUs of one node with RCCL over xGMI only to gather hit lists").  Every rank reads the same input,
+  // searches its contiguous range of the queries (ceil(nq/N) each, rank order = query order) on its own index replica, and the ranks'
+  // answers — per chunk the compact block [hit counts | query words | records], dg_hunt_result::d_block, straight out of HBM — are
+  // gathered to rank 0 by libdiceygather.so (include/dicey_gather.h: exact-size ncclSend / ncclRecv), which formats and writes
+  // every line in query order.  The reference is one process; what this replaces is the concatenation of the shards' results.
+  if (const char* er = std::getenv("DICEY_RANKS")) {
+    const int N = std::max(1, std::atoi(er));
+    const int rank = std::getenv("DICEY_RANK") ? std::atoi(std::getenv("DICEY_RANK")) : 0;
+    const int rr = hunt_ranks(c, N, rank, handles[0], devices[0], queries, seqlen, hp, format_chunk_to);
+    close_all();
+    return rr;
+  }
   int rc_all = 0;
   if (G == 1) {
     std::string err;

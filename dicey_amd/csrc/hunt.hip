@@ -839,7 +839,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           const u32 lcap_env = sw.fused_lcap ? std::max<u32>(1u, std::min<u32>(FUSED_LCAP, sw.fused_lcap)) : 0u;
           const u32 lcap = lcap_env ? lcap_env : (ix->fused_leaves_hint > 48ull * g1.x ? FUSED_LCAP : FUSED_LCAP / 2);
           const u32 lds1 = fused_lds_bytes(lcap);
-          const u32 leave1 = 1u;  // idle wavefronts end behind the probe phase (r04 A/B on one box: 0.2188 ms with, 0.2194 without — harmless, kept)
+          const u32 leave1 = 1u | (sw.exp_bits << 1);  // bit 0: idle wavefronts end behind the probe phase (r04 A/B on one box: 0.2188 ms with, 0.2194 without — harmless, kept)
           PrepOut po;
           po.qhits = qhits;
           if (prep_in) {
@@ -1221,10 +1221,13 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     R->compact = 1;
     R->d_hits = ws[WS_PACK].as<u32>() + 2 * nq;  // compact records (chit_words each)
     R->d_ops = nullptr;
+    R->d_block = ws[WS_PACK].p;
+    R->d_block_bytes = 8ull * nq + nhits * (u64)chit_words * 4;
   } else {
     R->d_hits = ws[WS_HITS].p;
     R->d_ops = ops_per_hit ? ws[WS_OPS].p : nullptr;
   }
+  R->stream = (void*)st;
   R->ctr_leaves = nleaf + hsum.fused_leaves;
   R->ctr_ext_steps = hsum.steps;
   R->ctr_tab_reads = hsum.lookups;
@@ -1299,6 +1302,7 @@ dg_switches dg_switches::read() {
   if (std::getenv("DICEY_CAP_BUDGET_MB")) w.cap_budget_mb = (uint64_t)std::max(1L, num("DICEY_CAP_BUDGET_MB"));
   if (std::getenv("DICEY_HOST_THREADS")) w.host_threads = (unsigned)std::max(1L, num("DICEY_HOST_THREADS"));
   if (const char* e = std::getenv("DICEY_DUMP_JOBS")) w.dump_jobs = e;
+  w.exp_bits = (uint32_t)num("DICEY_EXP");  // measurement aid (wrong results): phases of k_search1s switched off, see the kernel
   return w;
 }
 static bool any_lane_busy(dg_index* ix) {

@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
       }
     }
   }
-  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+  nprobe = wave_sum32(nprobe);
   if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
   while (mask8) {
     const u32 op = (u32)__ffs((int)mask8) - 1u;
@@ -493,11 +493,9 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
       }
     }
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    steps += __shfl_xor(steps, off);
-    nlook += __shfl_xor(nlook, off);
-    nhead += __shfl_xor(nhead, off);
-  }
+  steps = wave_sum32(steps);
+  nlook = wave_sum32(nlook);
+  nhead = wave_sum32(nhead);
   if (lane == 0) {
     if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
@@ -608,7 +606,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       }
     }
   }
-  for (int off = 32; off > 0; off >>= 1) nprobe += __shfl_xor(nprobe, off);
+  nprobe = wave_sum32(nprobe);
   if (lane == 0 && nprobe) atomicAdd(&c_probe, nprobe);
   const u32 shard = blockIdx.x & (NSHARD - 1);
   u32 steps = 0, nlook = 0, nhead = 0;
@@ -628,7 +626,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
         (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
         u32 lo = 0, hi = 0;
         if (to_lds) nhead += (K2 && mlen > K2);
-        if (head_window_occurs(f, s_pk, mlen, raw.z - pos)) {
+        if ((leave & 2u) || head_window_occurs(f, s_pk, mlen, raw.z - pos)) {  // (leave bit 1: DICEY_EXP=1, no head probe)
           const uint2 iv = f.ktab[s_pk & kmask];
           if (to_lds) ++nlook;
           lo = iv.x;
@@ -721,13 +719,12 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       __syncthreads();
     }
   };
-  rounds(true, leave != 0);
+  if (leave & 4u) mask_all = 0;  // DICEY_EXP=2: the probe phase alone (no survivor is followed up)
+  rounds(true, (leave & 1u) != 0);
   if (gone) return;
-  for (int off = 32; off > 0; off >>= 1) {
-    steps += __shfl_xor(steps, off);
-    nlook += __shfl_xor(nlook, off);
-    nhead += __shfl_xor(nhead, off);
-  }
+  steps = wave_sum32(steps);
+  nlook = wave_sum32(nlook);
+  nhead = wave_sum32(nhead);
   if (lane == 0) {
     if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
@@ -1277,11 +1274,9 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
       fs.selbase[gid] = shard * fs.cap + wbase;
     }
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    steps += __shfl_xor(steps, off);
-    nlook += __shfl_xor(nlook, off);
-    nprobe += __shfl_xor(nprobe, off);
-  }
+  steps = wave_sum32(steps);
+  nlook = wave_sum32(nlook);
+  nprobe = wave_sum32(nprobe);
   if (lane == 0) {
     if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
     if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);

@@ -16,6 +16,7 @@ struct dg_switches {
   int verify_ch = 0;             // DICEY_VERIFY_CH
   uint64_t cap_budget_mb = 0;    // DICEY_CAP_BUDGET_MB (0 = unset)
   unsigned host_threads = 0;     // DICEY_HOST_THREADS (0 = unset)
+  uint32_t exp_bits = 0;         // DICEY_EXP: measurement aid, phases of k_search1s switched off (results are then wrong)
   std::string dump_jobs, debug_caps_s;
   static dg_switches read();     // hunt.hip
 };

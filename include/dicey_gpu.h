@@ -37,8 +37,9 @@ extern "C" {
  * 4: hits carry their alignment in compact form (dg_hunt_result::ops; dg_hunt_rows / dg_hit_rows rebuild the two rows),
  *    result buffers come from a pinned pool, dg_hunt_submit / dg_hunt_wait
  * 5: dg_hunt_params grows by max_query_len and flags; DG_HUNT_COMPACT: 8 + 4 d bytes per hit and 8 bytes per query cross PCIe / xGMI
- *    (dg_chit_unpack, dg_hunt_expand, dg_normalize_query turn them back); dg_hunt_submit keeps up to three batches in flight on ONE handle */
-#define DG_ABI_VERSION 5
+ *    (dg_chit_unpack, dg_hunt_expand, dg_normalize_query turn them back); dg_hunt_submit keeps up to three batches in flight on ONE handle
+ * 6: dg_hunt_result grows by stream / d_block / d_block_bytes (the gather over RCCL lives in libdiceygather.so, include/dicey_gather.h) */
+#define DG_ABI_VERSION 6
 
 enum {
   DG_OK = 0,
@@ -220,6 +221,15 @@ typedef struct {
    * library takes a new base every few seconds to keep float precision); 0 = no timeline (one lane only so far, or no flat kernel). */
   double t_search_begin_ms, t_search_end_ms;
   uint32_t t_base_gen, t_reserved_;
+  /* ABI 6: what a gather over RCCL needs (include/dicey_gather.h).  stream: the hipStream_t the batch ran on — the handle's own, or
+   * the internal lane's for a dg_hunt_submit / dg_hunt_device_submit batch; a device-side copy out of the result's device buffers
+   * queued on it is ordered before that lane's next batch, with no host synchronisation.  Compact results: d_block is the batch's
+   * whole answer in HBM as ONE block [hit counts u32[nq] | qinfo u32[nq] | records (nhits * DG_CHIT_WORDS words)] = d_block_bytes
+   * bytes (d_hits points at its records; hit_off is the prefix sum of the counts); after a fetch the host has the same bytes at
+   * (uint8_t*)qinfo - 4 nq.  NULL / 0 for a classic result. */
+  void* stream;
+  const void* d_block;
+  uint64_t d_block_bytes;
 } dg_hunt_result;
 
 /* One compact hit as a dg_hit (query = the query it belongs to, from hit_off) and a pointer to its ops words. */

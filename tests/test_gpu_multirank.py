@@ -135,3 +135,48 @@ print("ok")
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_cli_one_process_per_gpu_gathers_over_libdiceygather(tmp_path):
+    """`dicey hunt` with DICEY_RANKS / DICEY_RANK: one process per GPU, contiguous query shards, every rank's compact blocks gathered
+    to rank 0 by libdiceygather.so, which writes all lines in query order (BASELINE.json north_star).  On the one
+    GPU of this box: a single rank over RCCL (communicator, size exchange, staging on the batch's stream — everything but a peer),
+    and two / three ranks over the library's TCP test transport (RCCL takes one rank per device).  stdout of rank 0 must equal the
+    plain single-process run byte for byte; the other ranks print nothing."""
+    import gzip
+    import random
+    import socket
+    from conftest import genome_text, make_genome, make_queries
+    dicey = os.path.join(ROOT, "dicey_amd", "dicey")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dicey_amd", "cli"), "-s"])
+    seqs = make_genome(78, 3, 15000)
+    fa = tmp_path / "g.fa.gz"
+    with gzip.open(fa, "wt") as f:
+        for i, s in enumerate(seqs):
+            f.write(">c%d\n%s\n" % (i, s))
+    assert subprocess.run([dicey, "index", str(fa)], capture_output=True).returncode == 0
+    qs = make_queries(5, genome_text(seqs), 203, lens=(12, 20, 26)) + ["ACGTAC", "N" * 15]
+    random.Random(2).shuffle(qs)
+    qf = tmp_path / "q.fa"
+    qf.write_text("".join(">q%d\n%s\n" % (i, q) for i, q in enumerate(qs)))
+    two = tmp_path / "two.fa"
+    two.write_text(">a\n%s\n>b\n%s\n" % (qs[0], qs[1]))
+    env0 = {k: v for k, v in os.environ.items() if not k.startswith("DICEY_")}
+    for extra, inp in (([], qf), (["-d", "2", "-m", "5"], qf), ([], two)):
+        one = subprocess.run([dicey, "hunt", *extra, "-g", str(fa), str(inp)], capture_output=True, text=True, env=env0)
+        assert one.returncode == 0, one.stderr
+        r1 = subprocess.run([dicey, "hunt", *extra, "-g", str(fa), str(inp)], capture_output=True, text=True,
+                            env=dict(env0, DICEY_RANKS="1", DICEY_RANK="0"))
+        assert r1.returncode == 0, r1.stderr
+        assert r1.stdout == one.stdout
+        for nr in (2, 3):
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            ps = [subprocess.Popen([dicey, "hunt", *extra, "-g", str(fa), str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                   env=dict(env0, DICEY_RANKS=str(nr), DICEY_RANK=str(r), DICEY_DEVICE="0", DICEY_COMM_TCP=str(port)))
+                  for r in range(nr)]
+            outs = [p.communicate(timeout=600) for p in ps]
+            assert all(p.returncode == 0 for p in ps), [o[1][-500:] for o in outs]
+            assert outs[0][0] == one.stdout, (nr, extra)
+            assert all(o[0] == "" for o in outs[1:])

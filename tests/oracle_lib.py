@@ -244,6 +244,30 @@ class Index:
                 hits.append((int(f[0]), int(f[1]), int(f[2]), int(f[3]), f[4], f[5], f[6]))
         return js, hits
 
+    def hunt_parallel(self, seqlen, seqname, seqs, workers=32, **kw):
+        """hunt() over contiguous slices of the queries on host threads (ctypes releases the GIL, the handle is read-only): the
+        checker's loop is single-threaded like the reference's and a cap-firing 25-mer at distance 2 costs it seconds.  Returns
+        (json lines per query, hits per query index in push order)."""
+        from concurrent.futures import ThreadPoolExecutor
+        n = len(seqs)
+        workers = max(1, min(workers, n))
+        per = (n + workers - 1) // workers
+        parts = [(i, seqs[i:i + per]) for i in range(0, n, per)]
+
+        def run(part):
+            base, sub = part
+            js, hits = self.hunt(seqlen, seqname, sub, want_hits=True, **kw)
+            d = {}
+            for h in hits:
+                d.setdefault(base + h[0], []).append(h[1:])
+            return base, js.split("\n")[:-1], d
+        lines, allhits = [None] * n, {}
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            for base, ls, d in ex.map(run, parts):
+                lines[base:base + len(ls)] = ls
+                allhits.update(d)
+        return lines, allhits
+
     def search(self, seqlen, seqname, text: bytes, fasta: str, genome="", outfile="", hamming=False, pruneprimer=None,
                cutTemp=45.0, maxProdSize=15000, cutofPen=-1.0, penDiff=0.6, penMis=0.4, penLen=0.001, kmer=15, distance=1,
                maxNeighborhood=10000, max_locations=10000):

@@ -46,12 +46,8 @@ def compare(ix, g, qs, **kw):
     """hits (push order) and messages of every query against the oracle's restated hunter.h loop"""
     got = ix.hunt(qs, g["seqlen"], **kw)
     orc = O.Index(g["fm9"])
-    js, hits = orc.hunt(g["seqlen"], g["names"], qs, want_hits=True, **kw)
-    per = {}
-    for h in hits:
-        per.setdefault(h[0], []).append(h[1:])
-    lines = js.split("\n")[:-1]
-    assert len(lines) == len(qs)
+    lines, per = orc.hunt_parallel(g["seqlen"], g["names"], qs, workers=min(32, os.cpu_count() or 1), **kw)  # (r04: one thread, 115 s a test)
+    assert len(lines) == len(qs) and all(ln is not None for ln in lines)
     ml, mn = kw.get("max_locations", 1000), kw.get("max_neighborhood", 10000)
     for qi, qr in enumerate(got.queries):
         a = [(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in qr.hits]

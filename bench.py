@@ -488,6 +488,10 @@ def main():
                     help="units per GPU per step (default: 100000 queries / 20000 primers / 1000 genes, by --config)")
     ap.add_argument("--qlen", type=int, default=20)
     ap.add_argument("--distance", type=int, default=-1, help="override the configuration's distance")
+    ap.add_argument("--hamming", action="store_true", help="hunt configs: -n (substitutions only, neighbors.h:57-66 without the indel branches)")
+    ap.add_argument("--n-frac", type=float, default=0.0,
+                    help="hunt configs: this fraction of the queries gets one 'N' at a random position (hunter.h:306-307, util.h:208-219: "
+                         "such queries leave the flat kernels for the general k_search)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the delivery measurements after the timed region (hunt configs, N=1)")
@@ -509,7 +513,7 @@ def main():
                     help="testing aid for a 1-GPU box: a process group of ONE rank on the chosen backend, and every hunt step stages and "
                          "gathers its hit list exactly as ranks of an N > 1 job do (the RCCL path: staging on the library's stream, the "
                          "size agreement, the gather) — n_gpus stays 1")
-    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3),
+    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3, 4),
                     help="hunt configs: batches in flight per GPU in the timed region: 2 or 3 = dg_hunt_device_submit / dg_hunt_wait on the handle's "
                          "lanes (step k is submitted, step k - n + 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a)")
     ap.add_argument("--batches", type=int, default=16,
@@ -745,6 +749,16 @@ def main():
             queries = [q.encode() for q in meta["queries"][0][lo_q:hi_q]]
         else:
             queries = [q.encode() for q in meta["queries"][rank if rank < len(meta["queries"]) else 0]]
+        def with_n(arr, seed_):
+            """one 'N' at a random position in a.n_frac of the rows of a uint8 [n, m] array (in place)"""
+            if a.n_frac > 0 and arr.size:
+                r_ = np.random.default_rng(seed_)
+                rows = np.nonzero(r_.random(arr.shape[0]) < a.n_frac)[0]
+                arr[rows, r_.integers(0, arr.shape[1], size=rows.size)] = ord("N")
+            return arr
+        if a.n_frac > 0 and queries:
+            qa_ = with_n(np.frombuffer(b"".join(queries), dtype=np.uint8).reshape(len(queries), -1).copy(), 7000 + rank)
+            queries = [bytes(r_) for r_ in qa_]
         nq = len(queries)
         qbytes = b"".join(queries)
         off = np.zeros(nq + 1, dtype=np.uint64)
@@ -753,8 +767,9 @@ def main():
         d_off = torch.from_numpy(off.view(np.int64)).to(dev)
         # max_query_len: the bench knows its primers' length, like a primer-design caller does — the library then sizes the batch
         # without reading the offsets back (a host round trip per new buffer; r04a: 0.17 ms of a 0.51 ms step on unseen buffers)
-        p = _capi.HuntParams(distance, 0, 0, 1000, 10000, a.qlen, 0)
-        p_compact = _capi.HuntParams(distance, 0, 0, 1000, 10000, a.qlen, _capi.DG_HUNT_COMPACT)
+        ham = int(a.hamming)
+        p = _capi.HuntParams(distance, ham, 0, 1000, 10000, a.qlen, 0)
+        p_compact = _capi.HuntParams(distance, ham, 0, 1000, 10000, a.qlen, _capi.DG_HUNT_COMPACT)
         # The stream of distinct batches (r04): B batches resident in HBM, each with its own bytes and offsets
         # buffer; step k searches batch k mod B, warm-up included, so no batch recurs within B launches.
         dev_batches = [(d_q, d_off, len(qbytes))]
@@ -762,7 +777,7 @@ def main():
             more = np.load(batches_path, mmap_mode="r")
             more = more[0][:, lo_q:hi_q] if strong else more[rank if rank < more.shape[0] else 0]
             for bi in range(more.shape[0]):
-                arr = np.ascontiguousarray(more[bi])
+                arr = with_n(np.array(more[bi]), 7100 + 16 * rank + bi)
                 dev_batches.append((torch.from_numpy(arr.reshape(-1).copy()).to(dev), torch.from_numpy(off.view(np.int64).copy()).to(dev),
                                     int(arr.size)))
         rot = {"k": 0, "on": True}
@@ -849,7 +864,7 @@ def main():
         # the stages' times (HIP events between the kernels, DG_HUNT_PHASE_TIMES) are taken in a pass of their own behind the timed
         # region: every event record is a marker packet in the stream, and the timed steps run without them (the batch total and the
         # search kernel's own time — what roofline.kernel_ms is — are measured in every step)
-        p_phase = _capi.HuntParams(distance, 0, 0, 1000, 10000, a.qlen, _capi.DG_HUNT_COMPACT | _capi.DG_HUNT_PHASE_TIMES)
+        p_phase = _capi.HuntParams(distance, ham, 0, 1000, 10000, a.qlen, _capi.DG_HUNT_COMPACT | _capi.DG_HUNT_PHASE_TIMES)
         acc_ph = []
         if rank == 0:
             gp_saved, pipe["g"] = pipe["g"], None

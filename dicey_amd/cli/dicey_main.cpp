@@ -263,7 +263,18 @@ int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const
       }
       if (!got) return die(std::string("no communicator id in ") + cf);
     }
-    if (G.open(id, N, rank, device, CAP, 0, &comm) != 0) return die(G.last_error());
+    // RCCL greets with a version banner on stdout (rank 0, communicator creation); stdout is the JSON stream (hunter.h:160-175), so
+    // the banner goes to stderr: file descriptor 1 points there while the communicator is created
+    std::fflush(stdout);
+    const int saved_out = dup(1);
+    if (saved_out >= 0) dup2(2, 1);
+    const int orc = G.open(id, N, rank, device, CAP, 0, &comm);
+    std::fflush(stdout);
+    if (saved_out >= 0) {
+      dup2(saved_out, 1);
+      close(saved_out);
+    }
+    if (orc != 0) return die(G.last_error());
   }
   const size_t nq = queries.size(), per = (nq + N - 1) / N;
   const size_t CH = 1u << 17;

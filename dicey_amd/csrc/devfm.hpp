@@ -72,6 +72,10 @@ struct FmView {
   // K-mer jump table (derived at load): SA interval [lo,hi) of every A/C/G/T K-mer, (0,0) when it does not occur.
   // code = sum over t of code(kmer[K-1-t]) << 2t, i.e. the LAST character sits in the lowest bits — the order in which
   // backward search meets the characters.
+  // Entry format (r05): x = lo; y = the interval's WIDTH hi - lo — below 2^16 in bits 0-15 with, in bits 16-30, the preceding
+  // characters of the interval's FIRST suffix (pre5[lo], 15 bits; 0x7FFF when pre5 was not built), or bit 31 set and the width in
+  // bits 0-30.  Two thirds of the 16-mers that occur in a 3.1 Gb genome occur once: their strings are settled by the table entry
+  // alone, without the line of pre5 (k_search1s / k_search2p; ktab_entry() decodes).
   const uint2* ktab;
   u32 K;  // 0 = no table
   // Presence filters (derived at load): bit = "this k-mer occurs", kept in up to four differently permuted copies.  Copy r
@@ -99,6 +103,20 @@ struct FmView {
   const u32* samin[MAXLEV];
   u32 nlev;  // levels present, including level 0; 0 = no hierarchy
 };
+
+struct KtabEntry {
+  u32 lo, hi;
+  u32 pre_first;  // pre5[lo] when the entry carries it (narrow), else 0xFFFFFFFF
+};
+DG_DEV KtabEntry ktab_decode(uint2 e) {
+  KtabEntry k;
+  k.lo = e.x;
+  const bool wide = (e.y >> 31) != 0;
+  k.hi = e.x + (wide ? (e.y & 0x7FFFFFFFu) : (e.y & 0xFFFFu));
+  k.pre_first = wide ? 0xFFFFFFFFu : ((e.y >> 16) & 0x7FFFu);
+  return k;
+}
+DG_DEV KtabEntry ktab_entry(const FmView& f, u64 code) { return ktab_decode(f.ktab[code]); }
 
 // is the k-mer `code` present?  t = window position (0 = right-most character) of the edit the neighbouring lanes vary
 DG_DEV bool kf_present(const KFilter& kf, u64 code, u32 t) {

@@ -263,7 +263,8 @@ DG_DEV uint2 kmer_interval(const FmView& f, u64 code, u32 edit_at, u64& lookups,
     if (!kf_present(f.kf, code, edit_at)) return make_uint2(0u, 0u);
   }
   ++lookups;
-  return f.ktab[code];
+  const KtabEntry k = ktab_entry(f, code);
+  return make_uint2(k.lo, k.hi);
 }
 DG_DEV bool frame_emit(const FmView& f, Frame& fr, u32 c, u64& steps, u64& lookups, u64& probes) {
   if (fr.st & ST_WIN) {
@@ -463,10 +464,10 @@ __global__ void __launch_bounds__(256) k_search1p(FmView f, Batch b, SearchOut o
       u32 lo = 0, hi = 0;
       nhead += (K2 && mlen > K2);
       if (head_window_occurs(f, s_pk, mlen, raw.z - pos)) {
-        const uint2 iv = f.ktab[s_pk & kmask];
+        const KtabEntry iv = ktab_entry(f, s_pk & kmask);
         ++nlook;
-        lo = iv.x;
-        hi = iv.y;
+        lo = iv.lo;
+        hi = iv.hi;
       }
       u64 rs = s_pk >> (2 * K);
       u32 n = mlen - K;
@@ -624,13 +625,14 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
         u64 s_pk;
         u32 mlen, ow;
         (void)cand1<INDEL>((u64)raw.y << 32 | raw.x, raw.z, pos, op, s_pk, mlen, ow);
-        u32 lo = 0, hi = 0;
+        u32 lo = 0, hi = 0, pre_first = 0xFFFFFFFFu;
         if (to_lds) nhead += (K2 && mlen > K2);
         if ((leave & 2u) || head_window_occurs(f, s_pk, mlen, raw.z - pos)) {  // (leave bit 1: DICEY_EXP=1, no head probe)
-          const uint2 iv = f.ktab[s_pk & kmask];
+          const KtabEntry iv = ktab_entry(f, s_pk & kmask);
           if (to_lds) ++nlook;
-          lo = iv.x;
-          hi = iv.y;
+          lo = iv.lo;
+          hi = iv.hi;
+          pre_first = iv.pre_first;
         }
         u64 rs = s_pk >> (2 * K);
         u32 n = mlen - K;
@@ -644,12 +646,17 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
           u32 want = 0;
           for (u32 k2 = 0; k2 < n; ++k2) want |= ((u32)(rs >> (2 * k2)) & 3u) << (3 * k2);
           const u32 wmask = (1u << (3 * n)) - 1u;
-          u32 ent16[16];
+          if (w == 1 && pre_first != 0xFFFFFFFFu) {
+            // r05: the interval holds ONE suffix and the table entry carries its preceding characters: no line of pre5
+            fmask = (u32)((pre_first & wmask) == want);
+          } else {
+            u32 ent16[16];
 #pragma unroll
-          for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
+            for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
 #pragma unroll
-          for (u32 j = 0; j < 16; ++j) fmask |= (u32)((ent16[j] & wmask) == want && j < w) << j;
-          ++nlook;
+            for (u32 j = 0; j < 16; ++j) fmask |= (u32)((ent16[j] & wmask) == want && j < w) << j;
+            ++nlook;
+          }
           fpre = n;
           n = 0;
           if (!fmask) lo = hi = 0;
@@ -1042,7 +1049,7 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
         if (e0 + (threadIdx.x & ~63u) >= qn) break;  // wavefront without work
         const u32 e = e0 + threadIdx.x;
         bool leaf = false;
-        u32 lo = 0, hi = 0, w1 = 0, w2 = 0, fword = 0, len2 = 0;
+        u32 lo = 0, hi = 0, w1 = 0, w2 = 0, fword = 0, len2 = 0, pre_first = 0xFFFFFFFFu;
         u64 key2 = 0;
         if (e < qn) {
           // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
@@ -1062,10 +1069,11 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
           len2 = l2;
           nprobe += (K2 && l2 > K2);
           if (head_window_occurs(f, s2, l2, l1 - p2)) {
-            const uint2 iv = f.ktab[s2 & kmask];
+            const KtabEntry iv = ktab_entry(f, s2 & kmask);
             ++nlook;
-            lo = iv.x;
-            hi = iv.y;
+            lo = iv.lo;
+            hi = iv.hi;
+            pre_first = iv.pre_first;
           }
           u64 rs = s2 >> (2 * K);
           u32 nr = l2 - K;
@@ -1076,12 +1084,15 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
             u32 want = 0, fm = 0;
             for (u32 k2 = 0; k2 < nr; ++k2) want |= ((u32)(rs >> (2 * k2)) & 3u) << (3 * k2);
             const u32 wmask = (1u << (3 * nr)) - 1u;
-            u32 ent16[16];
+            if (w == 1 && pre_first != 0xFFFFFFFFu) fm = (u32)((pre_first & wmask) == want);  // (r05: from the table entry, see k_search1s)
+            else {
+              u32 ent16[16];
 #pragma unroll
-            for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
+              for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
 #pragma unroll
-            for (u32 j = 0; j < 16; ++j) fm |= (u32)((ent16[j] & wmask) == want && j < w) << j;
-            ++nlook;
+              for (u32 j = 0; j < 16; ++j) fm |= (u32)((ent16[j] & wmask) == want && j < w) << j;
+              ++nlook;
+            }
             fword = fm | (nr << 16) | (1u << 31);
             nr = 0;
             if (!fm) lo = hi = 0;
@@ -1477,10 +1488,10 @@ __global__ void __launch_bounds__(256) k_explicit(FmView f, Batch b, SearchOut o
           alive = kf_present(f.kf, code & ((1ULL << (2 * K)) - 1), 0u);
         }
         if (alive) {
-          const uint2 iv = f.ktab[code & ((1ULL << (2 * K)) - 1)];
+          const KtabEntry iv = ktab_entry(f, code & ((1ULL << (2 * K)) - 1));
           ++lookups;
-          lo = iv.x;
-          hi = iv.y;
+          lo = iv.lo;
+          hi = iv.hi;
         } else lo = hi = 0;
         k = e - K;
       }

@@ -442,6 +442,20 @@ __global__ void __launch_bounds__(256) k_pre5(const u32* sa, const u8* text, u64
   out[i] = (u16)v;
 }
 
+// The table's final entry format (FmView::ktab): (lo, hi) as the fill pass left them -> (lo, width | pre5[lo] << 16) for widths below
+// 2^16, (lo, 0x80000000 | width) above.  pre: nullptr when the preceding characters were not built (the field then reads 0x7FFF,
+// which the search kernels never consult without FmView::pre5).
+__global__ void __launch_bounds__(256) k_ktab_pack(uint2* tab, u64 entries, const u16* pre) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= entries) return;
+  const uint2 e = tab[i];
+  const u32 w = e.y - e.x;  // (absent K-mers are (0, 0))
+  u32 y;
+  if (w >= 65536u) y = 0x80000000u | w;
+  else y = w | ((w && pre ? (u32)pre[e.x] & 0x7FFFu : 0x7FFFu) << 16);
+  tab[i].y = y;
+}
+
 // Block minima of the suffix array, fan-out 8 (FmView::samin): one lane per block, two 16-byte loads.
 __global__ void __launch_bounds__(256) k_block_min8(const u32* in, u64 n_in, u32* out, u64 n_out, u64 n_out_padded) {
   const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,6 +641,11 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
         pc.lap("preceding characters");
       } else (void)hipGetLastError();
     }
+    // every reader of (lo, hi) pairs is done (the filters above were derived from them): the entries take their final form
+    hipLaunchKernelGGL(k_ktab_pack, dim3((u32)ceil_div(entries, TB)), dim3(TB), 0, ix->stream, tab, entries, f.pre5);
+    DG_HIP(hipStreamSynchronize(ix->stream));
+    DG_HIP(hipGetLastError());
+    pc.lap("table entries packed");
   }
   // block minima over the suffix array for the top-k locate (0.57 n bytes; one streaming pass over SA)
   f.samin[0] = sa;

@@ -446,14 +446,15 @@ __global__ void __launch_bounds__(256) k_pre5(const u32* sa, const u8* text, u64
 // 2^16, (lo, 0x80000000 | width) above.  pre: nullptr when the preceding characters were not built (the field then reads 0x7FFF,
 // which the search kernels never consult without FmView::pre5).
 __global__ void __launch_bounds__(256) k_ktab_pack(uint2* tab, u64 entries, const u16* pre) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= entries) return;
-  const uint2 e = tab[i];
-  const u32 w = e.y - e.x;  // (absent K-mers are (0, 0))
-  u32 y;
-  if (w >= 65536u) y = 0x80000000u | w;
-  else y = w | ((w && pre ? (u32)pre[e.x] & 0x7FFFu : 0x7FFFu) << 16);
-  tab[i].y = y;
+  // (grid-stride: a launch of entries / 256 workgroups is 2^32 threads for the order-16 table, one more than HIP takes)
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (u64)gridDim.x * blockDim.x) {
+    const uint2 e = tab[i];
+    const u32 w = e.y - e.x;  // (absent K-mers are (0, 0))
+    u32 y;
+    if (w >= 65536u) y = 0x80000000u | w;
+    else y = w | ((w && pre ? (u32)pre[e.x] & 0x7FFFu : 0x7FFFu) << 16);
+    tab[i].y = y;
+  }
 }
 
 // Block minima of the suffix array, fan-out 8 (FmView::samin): one lane per block, two 16-byte loads.
@@ -642,7 +643,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
       } else (void)hipGetLastError();
     }
     // every reader of (lo, hi) pairs is done (the filters above were derived from them): the entries take their final form
-    hipLaunchKernelGGL(k_ktab_pack, dim3((u32)ceil_div(entries, TB)), dim3(TB), 0, ix->stream, tab, entries, f.pre5);
+    hipLaunchKernelGGL(k_ktab_pack, dim3((u32)std::min<u64>(ceil_div(entries, TB), 1u << 20)), dim3(TB), 0, ix->stream, tab, entries, f.pre5);
     DG_HIP(hipStreamSynchronize(ix->stream));
     DG_HIP(hipGetLastError());
     pc.lap("table entries packed");

@@ -499,7 +499,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default run only (hunt_d1, i.i.d. genome, N=1): skip the compact sub-lines of the other configurations "
                          "(extra_configs: hunt_d1_repeats, hunt_d2, hunt_d2_25mers, search, padlock), which are measured by re-running this script")
-    ap.add_argument("--extra-budget-s", type=float, default=240.0, help="wall-clock budget of the extra_configs block")
+    ap.add_argument("--extra-budget-s", type=float, default=300.0, help="wall-clock budget of the extra_configs block")
     ap.add_argument("--big-table", action="store_true",
                     help="open the index with DG_OPEN_BIG_TABLE (K-mer table one order larger: 199 GB instead of 90 GB resident on the "
                          "GRCh38-size genome, search kernel ~5 %% faster); the default is the library's default layout")
@@ -513,7 +513,7 @@ def main():
                     help="testing aid for a 1-GPU box: a process group of ONE rank on the chosen backend, and every hunt step stages and "
                          "gathers its hit list exactly as ranks of an N > 1 job do (the RCCL path: staging on the library's stream, the "
                          "size agreement, the gather) — n_gpus stays 1")
-    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3, 4),
+    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3),
                     help="hunt configs: batches in flight per GPU in the timed region: 2 or 3 = dg_hunt_device_submit / dg_hunt_wait on the handle's "
                          "lanes (step k is submitted, step k - n + 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a)")
     ap.add_argument("--batches", type=int, default=16,
@@ -1007,13 +1007,13 @@ def main():
             info["t_oracle_load_s"] = time.time() - t3
             qstr = [q.decode() for q in queries]
             probe_n = 100 if distance < 2 else 2
-            dt, _, _ = orc.hunt_timed(seqlen, qstr[:probe_n], threads=1, distance=distance)
+            dt, _, _ = orc.hunt_timed(seqlen, qstr[:probe_n], threads=1, distance=distance, hamming=a.hamming)
             per = max(dt / probe_n, 1e-6)
             # three repeats of a third of the budget each, median reported (r02: one run, 25 % spread between lines)
             ns = int(min(nq, max(probe_n, a.cpu_seconds / 3.0 / per)))
             runs = []
             for _ in range(3 if distance < 2 else 1):
-                dt, octr, _ = orc.hunt_timed(seqlen, qstr[:ns], threads=1, distance=distance)
+                dt, octr, _ = orc.hunt_timed(seqlen, qstr[:ns], threads=1, distance=distance, hamming=a.hamming)
                 runs.append(dt)
             dt = sorted(runs)[len(runs) // 2]
             cpu = {"value": ns / dt, "unit": "primers/s", "cores": 1, "kind": "port",
@@ -1025,7 +1025,7 @@ def main():
             # the same loop on every physical core over query shards (the reference itself has no threads)
             if phys_cores > 1:
                 nsp = int(min(nq, max(phys_cores, ns * phys_cores * 0.6)))
-                dtp, _, _ = orc.hunt_timed(seqlen, qstr[:nsp], threads=phys_cores, distance=distance)
+                dtp, _, _ = orc.hunt_timed(seqlen, qstr[:nsp], threads=phys_cores, distance=distance, hamming=a.hamming)
                 cpu_par = {"value": nsp / dtp, "unit": "primers/s", "cores": phys_cores, "kind": "port", "cpu_model": cpu_model,
                            "sample": f"first {nsp} bench queries, {phys_cores} host threads (one per physical core) over query shards, {dtp:.1f} s"}
             # parity at full genome size: GPU hits (push order) == oracle hits for a sample; at distance 2 the checker
@@ -1035,7 +1035,7 @@ def main():
                 O.fast_neighbors(distance >= 2)
                 try:
                     t4 = time.time()
-                    got = ix.hunt(qstr[:npar], seqlen, distance=distance)
+                    got = ix.hunt(qstr[:npar], seqlen, distance=distance, hamming=a.hamming)
                     # the checker on the host's cores: contiguous slices of the sample on up to 32 threads (its loop is single-threaded
                     # like the reference's; a cap-firing 25-mer at distance 2 costs it 2.5 s)
                     from concurrent.futures import ThreadPoolExecutor
@@ -1047,7 +1047,7 @@ def main():
                         lo_, hi_ = t_ * per_t, min(npar, (t_ + 1) * per_t)
                         if lo_ >= hi_:
                             return []
-                        _, hh = orc.hunt(seqlen, names_, qstr[lo_:hi_], distance=distance, want_hits=True)
+                        _, hh = orc.hunt(seqlen, names_, qstr[lo_:hi_], distance=distance, hamming=a.hamming, want_hits=True)
                         return [(h[0] + lo_,) + tuple(h[1:]) for h in hh]
                     with ThreadPoolExecutor(nthr) as ex:
                         ohits = [h for part in ex.map(_slice, range(nthr)) for h in part]
@@ -1070,14 +1070,20 @@ def main():
             k1 = "k_search1p<true>" if os.environ.get("DICEY_NO_FUSED_SELECT") else "k_search1s<true, true>"
             # distance 2: k_search2p with the select stage inside (r04)
             k2 = "k_search2p<false>" if (os.environ.get("DICEY_NO_FUSED_SELECT") or os.environ.get("DICEY_NO_FUSED_SELECT2")) else "k_search2p<true>"
-            kernel = (k1 if distance == 1 else k2) if flat > 0 else f"k_search<true,{distance}>"
-            kernel_ms = flat if flat > 0 else (float(np.mean([r["ms_search"] for r in acc_ph])) if acc_ph else mean("ms_search"))
+            # the general kernel (queries with N, above 31 nt, Hamming distance >= 2, distance >= 3): dominant when the flat kernels took
+            # less than half of the search phase (phase events of the pass behind the timed region)
+            ms_phase = float(np.mean([r["ms_search"] for r in acc_ph])) if acc_ph else mean("ms_search")
+            generic_dominant = flat <= 0 or (acc_ph and float(np.mean([r["ms_search_flat"] for r in acc_ph])) < 0.5 * ms_phase)
+            kernel = f"k_search<{'false' if a.hamming else 'true'}, {distance}>" if generic_dominant else (k1 if distance == 1 else k2)
+            if a.hamming and not generic_dominant and distance == 1:
+                kernel = kernel.replace("<true,", "<false,")
+            kernel_ms = ms_phase if generic_dominant else flat
             # Two batches in flight: the launches of neighbouring batches overlap, and the sum of their durations counts that time twice.
             # The time the kernel RAN is the union of the launches' intervals on the lanes' common timeline (dg_hunt_result::t_search_*,
             # HIP events of the timed steps); per launch it is what the roofline divides by.  launch_ms keeps the plain duration.
             launch_ms = kernel_ms
             busy = None
-            if a.in_flight >= 2 and flat > 0:
+            if a.in_flight >= 2 and flat > 0 and not generic_dominant:
                 by_gen = {}
                 for r in acc:
                     if r.get("gen"):
@@ -1108,8 +1114,10 @@ def main():
             out = dict(base_out)
             out.update({
                 "value": (len(meta["queries"][0]) if strong else world * nq) * a.steps / elapsed, "ms_per_step": elapsed / a.steps * 1e3, "dtype": "u32",
-                "config": {"workload": f"dicey hunt, {nq} synthetic {a.qlen}-mers per GPU, edit distance {distance}, both strands, "
-                                       f"-m 1000 -x 10000 (BASELINE.json configs[{1 if cfg == 'hunt_d1' else 3}])",
+                "config": {"workload": f"dicey hunt, {nq} synthetic {a.qlen}-mers per GPU, {'Hamming' if a.hamming else 'edit'} distance {distance}, both strands, "
+                                       + (f"{a.n_frac:.0%} of the queries with one N, " if a.n_frac > 0 else "") +
+                                       f"-m 1000 -x 10000 (BASELINE.json configs[{1 if cfg == 'hunt_d1' else 3}]" +
+                                       (" with -n" if a.hamming else "") + ")",
                            "genome": genome_desc, "genome_short": genome_short,
                            "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
                            "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
@@ -1456,7 +1464,7 @@ def main():
                 and a.distance < 0 and a.qlen == 20):
             out["extra_configs"] = run_extra_configs(a, fm9)
             # compact top-level summaries of the sub-lines (the driver's record keeps top-level keys whole)
-            for name_ in ("hunt_d1_repeats", "hunt_d2", "hunt_d2_25mers", "search", "padlock"):
+            for name_ in ("hunt_d1_repeats", "hunt_d2", "hunt_d2_25mers", "hunt_d2_hamming", "hunt_d1_nmix", "search", "padlock"):
                 sub_ = out["extra_configs"].get(name_)
                 if isinstance(sub_, dict) and "value" in sub_:
                     rf_ = sub_.get("roofline") or {}
@@ -1491,6 +1499,10 @@ def run_extra_configs(a, fm9):
             # enumerated on the host in the reference's order first (nbhd_host.hpp) and searched as explicit patterns
             ("hunt_d2_25mers", ["--config", "hunt_d2", "--qlen", "25", "--queries", "2000", "--steps", "1", "--warmup", "1", "--cpu-seconds", "6",
                                 "--parity-queries", "100"], True),
+            # what the general kernel k_search serves: Hamming distance 2 (neighbors.h:57-66 without the indel
+            # branches) and queries with an N (hunter.h:306-307, util.h:208-219)
+            ("hunt_d2_hamming", ["--config", "hunt_d2", "--hamming", "--steps", "5", "--warmup", "3", "--cpu-seconds", "4", "--parity-queries", "300"], True),
+            ("hunt_d1_nmix", ["--config", "hunt_d1", "--n-frac", "0.05", "--steps", "9", "--warmup", "6", "--cpu-seconds", "4", "--parity-queries", "300"], True),
             ("search", ["--config", "search", "--steps", "2", "--warmup", "1", "--cpu-seconds", "6"], True),
             ("padlock", ["--config", "padlock", "--steps", "3", "--warmup", "1", "--cpu-seconds", "6"], True)]
     keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "roofline_search", "cpu_baseline", "parity_sample", "cap_stage",

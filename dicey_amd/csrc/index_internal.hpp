@@ -62,8 +62,8 @@ struct dg_index {
   std::mutex lanes_mu;                // guards the lazy creation of lanes[] / shared_hints / a lane's worker (concurrent submitters)
   // ABI 5: dg_hunt_submit keeps several batches in flight on one handle; a submission that finds the handle busy runs on an internal
   // lane (a shared handle: own stream, workspaces, helper thread; created at the first need, closed with the handle)
-  static constexpr int NEXTRA = 3;            // internal lanes beside the handle itself: up to four batches in flight (r04: three)
-  dg_index* lanes[NEXTRA] = {nullptr, nullptr, nullptr};
+  static constexpr int NEXTRA = 2;            // internal lanes beside the handle itself: three batches in flight (a fourth lane was measured in r05: 496 against 505 M primers/s)
+  dg_index* lanes[NEXTRA] = {nullptr, nullptr};
   // The lanes learn together (r04): capacities and kernel-family hints live per lane (each lane's batches read and write its own
   // without locks), and a lane merges the pair's common record in when a batch starts and writes its own back when it ends — a
   // lane that runs its first batch does not repeat it for a capacity another lane has already learnt.

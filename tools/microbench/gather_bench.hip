@@ -5,6 +5,7 @@
 //   (2) a known byte count to calibrate rocprofv3 FETCH_SIZE for this access pattern (MI355X_MICROARCH.md §HBM).
 // usage: gather_bench <buffer_GiB> <lines_per_lane> <dependent:0|1> <lanes>
 //        gather_bench filter <copy_GiB> <strands> <lines_per_strand> [rotate:0|1] [reps]   (r03; rotate r04)
+//        gather_bench filter2 <log2 lines per copy> <strands> <lines_per_strand> [reps]     (r05: cheap addresses, 8 wavefronts per SIMD)
 // `filter`: the access shape of k_search1p's probe phase — four copies of a presence filter (copy_GiB each), one lane per
 // (strand, position) with 20 positions per strand, eight independent 4-byte loads per lane; the 160 probes of a strand fall
 // into <lines_per_strand> distinct random 64-byte lines (neighbouring positions share lines, like the kernel's choice of copy
@@ -68,6 +69,60 @@ __global__ void __launch_bounds__(256) k_filter(const uint32_t* buf, uint64_t li
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// r05: the same access shape with address arithmetic as cheap as the kernel's own (~10 instructions per probe).  k_filter above spends
+// two 64-bit mixes and a 64-bit modulo per probe — ~400 instructions per lane — and is bound by THAT: 10 G lines/s where the kernel it
+// is meant to bound runs at 28 G ("the microbenchmark is slower than the kernel it is supposed to bound").  Here a lane
+// hashes its two line slots with one 32-bit multiply each (copy size a power of two: the 18-mer filter's 2^27 lines), issues its eight
+// loads back to back like hunt_search.hpp's probe phase, and the kernel is compiled for eight wavefronts per SIMD.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  return x ^ (x >> 13);
+}
+__global__ void __launch_bounds__(256, 8) k_filter2(const uint32_t* buf, uint32_t line_mask, uint32_t lines_log2, uint32_t lps, uint32_t nstrands, uint64_t* out, uint32_t salt) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t strand = t / 20u, pos = t - strand * 20u;
+  if (strand >= nstrands) return;
+  const uint32_t slotA = pos * lps / 20u, slotB = (slotA + 1u) % lps;
+  const uint32_t hA = hash32((strand + salt) * 64u + slotA + 1u), hB = hash32((strand + salt) * 64u + slotB + 1u);
+  const uint32_t* la = buf + ((uint64_t)(slotA * 4u / lps) << (lines_log2 + 4)) + (uint64_t)(hA & line_mask) * 16u;
+  const uint32_t* lb = buf + ((uint64_t)(slotB * 4u / lps) << (lines_log2 + 4)) + (uint64_t)(hB & line_mask) * 16u;
+  const uint32_t* addr[8];
+#pragma unroll
+  for (int op = 0; op < 8; ++op) addr[op] = (op < 4 ? la : lb) + ((pos * 3u + (uint32_t)op * 5u) & 15u);
+  uint32_t w[8];
+#pragma unroll
+  for (int op = 0; op < 8; ++op) w[op] = *addr[op];
+  uint32_t acc = 0;
+#pragma unroll
+  for (int op = 0; op < 8; ++op) acc += w[op];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+// filter2 <copy_log2_lines> <strands> <lines_per_strand> [reps]: four copies of 2^copy_log2_lines lines each
+static int filter2_main(int argc, char** argv) {
+  const uint32_t lg = argc > 2 ? (uint32_t)atoi(argv[2]) : 27u;
+  const uint32_t strands = argc > 3 ? (uint32_t)strtoul(argv[3], 0, 10) : 200000u;
+  const uint32_t lps = argc > 4 ? (uint32_t)atoi(argv[4]) : 12u;
+  const int reps = argc > 5 ? atoi(argv[5]) : 6;
+  const uint64_t bytes = (64ull << lg) * 4;
+  uint32_t* buf; uint64_t* out;
+  CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, 64));
+  CK(hipMemset(buf, 1, bytes));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  const uint32_t lanes = (strands * 20u + 255u) / 256u * 256u;
+  for (int rep = 0; rep < reps; ++rep) {
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL(k_filter2, dim3(lanes / 256), dim3(256), 0, 0, buf, (1u << lg) - 1u, lg, lps, strands, out, (uint32_t)rep * strands);  // fresh lines every repetition
+    CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    printf("{\"tool\":\"gather_bench filter2\",\"copies\":4,\"copy_GiB\":%.2f,\"strands\":%u,\"lines_per_strand\":%u,\"probes\":%llu,\"rep\":%d,\"ms\":%.4f,"
+           "\"Glines_per_s\":%.2f,\"Gprobes_per_s\":%.2f}\n", (double)(64ull << lg) / (1ull << 30), strands, lps, (unsigned long long)strands * 160ull, rep, ms,
+           (double)strands * lps / ms / 1e6, (double)strands * 160 / ms / 1e6);
+  }
+  return 0;
+}
+
 static int filter_main(int argc, char** argv) {
   const double gib = argc > 2 ? atof(argv[2]) : 8.0;
   const uint64_t strands = argc > 3 ? strtoull(argv[3], 0, 10) : 200000;
@@ -96,6 +151,7 @@ static int filter_main(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "filter")) return filter_main(argc, argv);
+  if (argc > 1 && !strcmp(argv[1], "filter2")) return filter2_main(argc, argv);
   double gib = argc > 1 ? atof(argv[1]) : 2.0;
   int iters = argc > 2 ? atoi(argv[2]) : 256;
   int dep_arg = argc > 3 ? atoi(argv[3]) : 1;  // 2 = both forms

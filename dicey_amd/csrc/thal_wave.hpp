@@ -45,6 +45,8 @@ struct WaveMem {  // LDS owned by one wavefront
   unsigned short* from;      // same indexing: kFromLeft / kFromStack / visiting key of the opening / kFromNone
   unsigned short* rowstart;  // [len1 + 2] first slot of each row
   unsigned char* tlist;      // [stride] columns of the current row that take openings
+  unsigned char* bcol;       // [stride + 2] r05: bcol[jj] = b[jj] (jj = 0 .. len2 + 1, the frame's sentinels included)
+  unsigned char* qcol;       // [stride + 2] r05: qcol[jj] = b[jj] * 5 + b[jj + 1]: the opening pair's column half of a four-index table entry
   unsigned cap;
 };
 constexpr unsigned short kFromNone = 0, kFromLeft = 1, kFromStack = 2;  // opening keys are >= 3*64
@@ -52,7 +54,7 @@ constexpr unsigned short kFromNone = 0, kFromLeft = 1, kFromStack = 2;  // openi
 // slots for pairing cells: 7/16 of the full table (mixed sequences need about 1/4) plus one row
 DG_HD constexpr unsigned wave_cell_cap(unsigned len1, unsigned stride) { return (len1 * stride * 7u) / 16u + stride + 16u; }
 DG_HD constexpr unsigned wave_mem_bytes(unsigned len1, unsigned stride) {
-  return (stride * (unsigned)sizeof(RowInfo) + wave_cell_cap(len1, stride) * ((unsigned)sizeof(Cell) + 2u) + (len1 + 2u) * 2u + stride + 15u) & ~15u;
+  return (stride * (unsigned)sizeof(RowInfo) + wave_cell_cap(len1, stride) * ((unsigned)sizeof(Cell) + 2u) + (len1 + 2u) * 2u + stride + 2u * (stride + 2u) + 15u) & ~15u;
 }
 __device__ inline WaveMem wave_mem_at(unsigned char* base, unsigned len1, unsigned stride) {
   WaveMem m;
@@ -62,6 +64,8 @@ __device__ inline WaveMem wave_mem_at(unsigned char* base, unsigned len1, unsign
   m.from = reinterpret_cast<unsigned short*>(m.cells + m.cap);
   m.rowstart = m.from + m.cap;
   m.tlist = reinterpret_cast<unsigned char*>(m.rowstart + len1 + 2);
+  m.bcol = m.tlist + stride;
+  m.qcol = m.bcol + stride + 2;
   return m;
 }
 
@@ -188,6 +192,20 @@ __device__ inline Result wave_end1_tm(const Tables& T, const EndTables& E, const
   uint64_t pm[4];
   for (int c = 0; c < 4; ++c) pm[c] = __ballot(myb == 3 - c);
   const int j = lane + 1;  // the column this lane owns in the per-row pass
+  // r05: the second oligo as bytes in LDS for the openings loop — its lanes ask for b[jj], b[jj + 1] at lane-varying jj, which on the
+  // wave-uniform bit planes is a dozen 64-bit shifts per candidate
+  {
+    const int nb = lane + 2 <= len2 + 1 ? b[lane + 2] : 4;
+    if (lane <= len2) {
+      m.bcol[j] = (unsigned char)(lane < len2 ? myb : 4);           // bcol[len2 + 1] = the frame's sentinel
+      m.qcol[j] = (unsigned char)((lane < len2 ? myb : 4) * 5 + (lane < len2 ? nb : 4));
+    }
+    if (lane == 0) {
+      m.bcol[0] = 4;
+      m.qcol[0] = (unsigned char)(4 * 5 + b[1]);
+    }
+  }
+  wave_sync();
   const Cell kNoPair = {kInf, -1.0};  // what initMatrix leaves in a cell whose bases do not pair (thal.h:820-835)
   auto row_mask = [&](int code) -> uint64_t { return code == 0 ? pm[0] : code == 1 ? pm[1] : code == 2 ? pm[2] : code == 3 ? pm[3] : 0; };
   unsigned rowbase = 0, prevbase = 0;  // first slot of row i / of row i-1
@@ -274,6 +292,7 @@ __device__ inline Result wave_end1_tm(const Tables& T, const EndTables& E, const
     const int R = 1 << lg, G = 64 >> lg;
     const int rr = lane & (R - 1), ii = i - 1 - rr;
     const int ca = rr < n1 ? a[ii] : 4;
+    const int ao1 = rr < n1 ? a[ii + 1] : 4;  // the opening row's inner neighbour: the same for every target of this row
     const uint64_t rowmask = row_mask(ca);
     const unsigned obase = rr < n1 ? m.rowstart[ii] : 0;  // first slot of the opening row this lane serves
     const int l1 = rr;
@@ -298,13 +317,48 @@ __device__ inline Result wave_end1_tm(const Tables& T, const EndTables& E, const
         //   1x1 loop       stackmm[ao][ao'][bo][bo'] + stackmm[bc][bc'][ac][ac']
         //   interior loop  interior[ls] + tstack[ao][ao'][bo][bo'] + tstack[bc][bc'][ac][ac'] + ILA*|l1-l2|
         // (o = opening pair (ii,jj), c = closing pair (i,tj), ' = the neighbour inside the loop); operand order as there.
-        const int ao = ca, ao1 = a[ii + 1], ac = ai, ac1 = a[i - 1], bc = b[tj], bc1 = b[tj - 1];
+        const int ao = ca, ac = ai, ac1 = a[i - 1], bc = m.bcol[tj], bc1 = m.bcol[tj - 1];
         const int q2 = ((bc * 5 + bc1) * 5 + ac) * 5 + ac1, q1hi = (ao * 5 + ao1) * 25, sthi = (ao * 5 + ac) * 25, atpc = ac * 5 + bc;
-        while (mask) {
-          const int jj = __builtin_ctzll(mask) + 1;
-          mask &= mask - 1;
-          const Cell open = m.cells[obase + (unsigned)__popcll(rowmask & low_bits(jj - 1))];
-          const int bo = b[jj], bo1 = b[jj + 1];
+        // r05: candidates are visited from the highest column down.  The table slot of the first one is a popcount; every further
+        // candidate is the next lower pairing column of the opening row, i.e. the slot before (the columns the mask leaves out lie
+        // above the first or below the last candidate).
+        unsigned slot = 0;
+        if (mask) slot = obase + (unsigned)__popcll(rowmask & low_bits(63 - __builtin_clzll(mask)));
+        auto consider = [&](double S, double H, const Cell& open, int l2, bool single) {
+          H += open.h;
+          S += open.s;
+          if (!fin(H)) {
+            H = kInf;
+            S = -1.0;
+          }
+          if (!single && H > 0 && S > 0) {
+            H = kInf;
+            S = -1.0;
+          }
+          // (-1, inf): its free energy is above the placeholder's, never taken
+          const bool valid = fin(open.h) && fin(H);
+          const bool cut = S < kMinEntropyCutoff;
+          const double g = H - kT * S;
+          if (valid && (cut ? !(g > 900000.0) : !(g < 800000.0))) amb = true;
+          const double G1 = H + ri.rH - kT * (S + ri.rS);
+          const unsigned key = (unsigned)((l1 + l2 + 2) * 64 + (i - ii));
+          if (valid && !cut && (G1 < bestG || (G1 == bestG && key < bestKey))) {
+            bestG = G1;
+            bestKey = key;
+            bestS = S;
+            bestH = H;
+          }
+        };
+        // (1) the two highest candidates with the body that knows every loop shape: a single bulge (l1 + l2 = 1) and the 1x1 loop
+        //     can only be the opening row's columns tj - 1 and tj - 2, i.e. among these two
+#pragma unroll 1
+        for (int rep = 0; rep < 2 && mask; ++rep) {
+          const int top = 63 - __builtin_clzll(mask);
+          mask &= ~(1ULL << top);
+          const int jj = top + 1;
+          const Cell open = m.cells[slot];
+          --slot;
+          const int bo = m.bcol[jj], bo1 = m.bcol[jj + 1];
           const int l2 = tj - jj - 1, ls = l1 + l2 - 1;
           const bool bulge = (l1 == 0) != (l2 == 0);
           const bool single = bulge && l1 + l2 == 1, longb = bulge && !single, one = l1 == 1 && l2 == 1;
@@ -332,29 +386,39 @@ __device__ inline Result wave_end1_tm(const Tables& T, const EndTables& E, const
             H = kInf;
             S = -1.0;
           }
-          H += open.h;
-          S += open.s;
-          if (!fin(H)) {
-            H = kInf;
-            S = -1.0;
-          }
-          if (!single && H > 0 && S > 0) {
-            H = kInf;
-            S = -1.0;
-          }
-          // (-1, inf): its free energy is above the placeholder's, never taken
-          const bool valid = fin(open.h) && fin(H);
-          const bool cut = S < kMinEntropyCutoff;
-          const double g = H - kT * S;
-          if (valid && (cut ? !(g > 900000.0) : !(g < 800000.0))) amb = true;
-          const double G1 = H + ri.rH - kT * (S + ri.rS);
-          const unsigned key = (unsigned)((l1 + l2 + 2) * 64 + (i - ii));
-          if (valid && !cut && (G1 < bestG || (G1 == bestG && key < bestKey))) {
-            bestG = G1;
-            bestKey = key;
-            bestS = S;
-            bestH = H;
-          }
+          consider(S, H, open, l2, single);
+        }
+        // (2) everything below them has l2 >= 2: interior loops for this lane's opening row when l1 >= 1, longer bulges when l1 = 0 — one
+        //     shape per LANE, so the tables, the twin distance and the closing pair's term are settled outside the loop and a
+        //     candidate costs its cell, one column byte, two table pairs and the sums (same operands, same order as above)
+        if (mask) {
+          const bool isb = l1 == 0;
+          const int base0 = isb ? kOffBulge : kOffInterior;
+          const int base1 = isb ? kOffAtp + ao * 5 : kOffTstack + q1hi;
+          const int tw12 = isb ? kTwinAtp : kTwin4;
+          const unsigned char* const col = isb ? m.bcol : m.qcol;
+          const int e2 = isb ? kOffAtp + atpc : kOffTstack + q2;
+          const double c2S = TD[e2], c2H = TD[e2 + tw12];
+          const int lsbase = l1 - 1 + tj - 1;  // ls = l1 + l2 - 1 = lsbase - jj
+          do {
+            const int top = 63 - __builtin_clzll(mask);
+            mask &= ~(1ULL << top);
+            const int jj = top + 1;
+            const Cell open = m.cells[slot];
+            --slot;
+            const int cix = col[jj];
+            const int l2 = tj - jj - 1, ls = lsbase - jj;
+            double S = TD[base0 + ls] + TD[base1 + cix];
+            double H = TD[base0 + ls + kTwinLoop] + TD[base1 + cix + tw12];
+            S = S + c2S;
+            H = H + c2H;
+            if (!isb) {
+              const int asym = l1 > l2 ? l1 - l2 : l2 - l1;
+              S = S + (kILAS * asym);
+              H = H + (kILAH * asym);
+            }
+            consider(S, H, open, l2, false);
+          } while (mask);
         }
       }
       DG_PROF_T(tB1);

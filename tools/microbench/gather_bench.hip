@@ -81,16 +81,27 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   return x ^ (x >> 13);
 }
 __global__ void __launch_bounds__(256, 8) k_filter2(const uint32_t* buf, uint32_t line_mask, uint32_t lines_log2, uint32_t lps, uint32_t nstrands, uint64_t* out, uint32_t salt) {
+  // The probe phase's shape (hunt_search.hpp k_search1s): a lane = (strand, position); its eight loads are one deletion, three
+  // substitutions and four insertions.  The strings of one operation KIND whose edit lies in the same filter field share a line, and
+  // the field's copy of the filter holds it: lps / 3 fields per strand x 3 kinds = lps lines per strand, and ONE wave instruction (one
+  // operation of every lane) touches only the lines of its kind — lps / 3 per strand.  (The first r05 form gave every position its own
+  // pair of line slots: a wave instruction then touched all lps lines of its strands, 38 lines per instruction instead of 13, and ran
+  // at 10 G lines/s where this shape runs at the kernel's rate.)
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t strand = t / 20u, pos = t - strand * 20u;
   if (strand >= nstrands) return;
-  const uint32_t slotA = pos * lps / 20u, slotB = (slotA + 1u) % lps;
-  const uint32_t hA = hash32((strand + salt) * 64u + slotA + 1u), hB = hash32((strand + salt) * 64u + slotB + 1u);
-  const uint32_t* la = buf + ((uint64_t)(slotA * 4u / lps) << (lines_log2 + 4)) + (uint64_t)(hA & line_mask) * 16u;
-  const uint32_t* lb = buf + ((uint64_t)(slotB * 4u / lps) << (lines_log2 + 4)) + (uint64_t)(hB & line_mask) * 16u;
+  const uint32_t nfield = lps / 3u ? lps / 3u : 1u;
+  const uint32_t field = pos * nfield / 20u;
+  const uint32_t* line[3];
+#pragma unroll
+  for (uint32_t kind = 0; kind < 3; ++kind) {
+    const uint32_t slot = field * 3u + kind;
+    const uint32_t h = hash32((strand + salt) * 64u + slot + 1u);
+    line[kind] = buf + ((uint64_t)(field * 4u / nfield) << (lines_log2 + 4)) + (uint64_t)(h & line_mask) * 16u;
+  }
   const uint32_t* addr[8];
 #pragma unroll
-  for (int op = 0; op < 8; ++op) addr[op] = (op < 4 ? la : lb) + ((pos * 3u + (uint32_t)op * 5u) & 15u);
+  for (int op = 0; op < 8; ++op) addr[op] = line[op == 0 ? 0 : op < 4 ? 1 : 2] + ((pos * 3u + (uint32_t)op * 5u) & 15u);
   uint32_t w[8];
 #pragma unroll
   for (int op = 0; op < 8; ++op) w[op] = *addr[op];

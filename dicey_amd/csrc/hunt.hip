@@ -597,7 +597,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   const double ms_cap = (cs.mode.empty() && dev_jobs.empty()) ? 0.0 : (host_us() - t_cap0) * 1e-3;
   Batch b;
   b.fastK = (dmax_eff == 1 && ix->view.K && maxlen > ix->view.K && ngrp * (u64)std::min(maxlen, 31u) * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
-  b.fast2K = (indel && dmax_eff == 2 && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
+  // (r05: Hamming distance 2 as well — the same kernel with "no edit" in place of the deletions)
+  b.fast2K = (dmax_eff == 2 && (indel || !sw.no_flat_ham2) && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
   b.xs_off = d_xs_off;
@@ -866,8 +867,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         fs.nsel = nsel;
         // (tests: DICEY_FUSED_LCAP lowers the list's capacity so that ordinary groups exercise the hand-over to the generic select kernels)
         const u32 lcap2 = sw.fused_lcap ? std::max<u32>(1u, std::min<u32>(FUSED2_LCAP, sw.fused_lcap)) : FUSED2_LCAP;
-        if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2);
+        const u32 ham2 = indel ? 0u : 1u;
+        if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       // edit distance 2: the walker (k_search) only serves the groups k_search2p does not take (N in the query, above 30 nt); it is
@@ -1302,6 +1304,7 @@ dg_switches dg_switches::read() {
   if (std::getenv("DICEY_CAP_BUDGET_MB")) w.cap_budget_mb = (uint64_t)std::max(1L, num("DICEY_CAP_BUDGET_MB"));
   if (std::getenv("DICEY_HOST_THREADS")) w.host_threads = (unsigned)std::max(1L, num("DICEY_HOST_THREADS"));
   if (const char* e = std::getenv("DICEY_DUMP_JOBS")) w.dump_jobs = e;
+  w.no_flat_ham2 = std::getenv("DICEY_NO_FLAT_HAMMING2") != nullptr;  // A/B and tests: Hamming distance 2 on the general kernel, as before r05
   w.exp_bits = (uint32_t)num("DICEY_EXP");  // measurement aid (wrong results): phases of k_search1s switched off, see the kernel
   return w;
 }

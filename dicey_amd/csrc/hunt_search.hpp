@@ -910,6 +910,18 @@ DG_DEV void apply_edit(u64 pk, u32 len, u32 pos, u32 op, u64& out, u32& olen, u3
   }
 }
 
+// Hamming mode of k_search2p (r05): operation 0 of either loop means "no edit here" instead of a deletion, so that the pairs of
+// positions also carry the strings with fewer than two substitutions (the Hamming ball keeps all of them, neighbors.h:57-66): the
+// sequence itself and the substitution of its first character on lane (1, 1), a single substitution at p1 >= 2 on lane (1, p1).
+static constexpr u32 OPW_NONE = 0xFFFFFFFFu;
+DG_DEV void apply_edit_h(bool ham, u64 pk, u32 len, u32 pos, u32 op, u64& out, u32& olen, u32& word) {
+  if (ham && op == 0) {
+    out = pk;
+    olen = len;
+    word = OPW_NONE;
+  } else apply_edit(pk, len, pos, op, out, olen, word);
+}
+
 // (the lane-per-operation-pair kernel described above — k_search2<U>, r02: 17.4 ms — was removed in r04; k_search2p below is the
 // same enumeration with one lane per pair of POSITIONS)
 
@@ -939,7 +951,8 @@ static constexpr u32 FUSED2_HCAP = 1024;  // hash slots of the select stage (dis
 // them when they were not launched).  (A form with one workgroup per QUERY that also did k_take's work — both strands one after the
 // other — was measured: 9.68 against 9.28 + 0.27 ms for this kernel and k_take; removed.)
 template <bool SEL>
-__global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2) {
+__global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2, u32 hamming) {
+  const bool ham = hamming != 0;  // substitutions only; strings with 0, 1 and 2 of them (r05: Hamming distance 2 used to walk k_search<false, 2>, 3.6 x slower per query than the edit form here)
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
   // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
@@ -984,10 +997,11 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
           bool v1 = (p1 > p2 || ins1) && !(p1 == m && ins1);
           if (op1 == 0) v1 = v1 && qb != qa;
           if (ins1) v1 = v1 && !(p1 >= 2 && qa == op1 - 4 && p2 + 2 <= p1);
+          if (ham) v1 = (op1 >= 1 && op1 <= 3) || (op1 == 0 && p1 == 1);  // (p1 == 1 implies p2 == 1)
           if (v1) {
             u64 s1;
             u32 l1, w1;
-            apply_edit(qpk, m, p1, op1, s1, l1, w1);
+            apply_edit_h(ham, qpk, m, p1, op1, s1, l1, w1);
             const u32 posp = ins1 ? p1 : p1 - 1;  // characters left of the first operation
             // (r04 measured the copy of the filter picked by the SECOND operation's position instead — the inner loop's eight probes then
             //  share three lines: 161 M instead of 175 M fabric reads per launch, but the L2 hits between neighbouring lanes' probes go
@@ -1005,9 +1019,11 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
               bool v2 = true;
               if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
               if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
+              // Hamming: a second substitution left of a first one; "none" on the lanes of p2 = 1 only (one lane per first edit)
+              if (ham) v2 = (op2 >= 1 && op2 <= 3) ? (p2 < p1 && op1 != 0) : (op2 == 0 && p2 == 1);
               u64 s2;
               u32 l2, w2;
-              apply_edit(s1, l1, p2, op2, s2, l2, w2);
+              apply_edit_h(ham, s1, l1, p2, op2, s2, l2, w2);
               const bool use2 = K2 && l2 >= K2;
               const bool pr = v2 && (use2 || f.kf.nr);
               KfCopy c;
@@ -1063,8 +1079,8 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
           u32 p1, p2, l1, l2;
           u64 s1, s2;
           pair_of(w0 + L, m, p2, p1);
-          apply_edit(qpk, m, p1, bitno >> 3, s1, l1, w1);
-          apply_edit(s1, l1, p2, bitno & 7u, s2, l2, w2);
+          apply_edit_h(ham, qpk, m, p1, bitno >> 3, s1, l1, w1);
+          apply_edit_h(ham, s1, l1, p2, bitno & 7u, s2, l2, w2);
           key2 = s2;
           len2 = l2;
           nprobe += (K2 && l2 > K2);
@@ -1079,7 +1095,7 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
           u32 nr = l2 - K;
           // filtered interval (FmView::pre5, see k_search1s): a narrow table interval is settled with one line of the preceding-characters
           // array instead of l2 - K dependent Occ lines; the leaf then carries (interval of its last K characters, mask, l2 - K) in ops[2]
-          if (filt_ok && f.pre5 && nr >= 1 && nr <= 5 && lo < hi && hi - lo <= 16) {
+          if (filt_ok && (!ham || to_lds) && f.pre5 && nr >= 1 && nr <= 5 && lo < hi && hi - lo <= 16) {  // (Hamming leaves with fewer than two operations carry no filter word)
             const u32 w = hi - lo;
             u32 want = 0, fm = 0;
             for (u32 k2 = 0; k2 < nr; ++k2) want |= ((u32)(rs >> (2 * k2)) & 3u) << (3 * k2);
@@ -1132,10 +1148,12 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
             lf->slot = slot;
             lf->lo = lo;
             lf->hi = hi;
-            lf->nops = 2;
-            lf->ops[0] = w1;
-            lf->ops[1] = w2;
-            lf->ops[2] = fword;  // 0, or the filtered form: mask | characters in front << 16 | 1 << 31 (k_group_pack hands it on)
+            // (Hamming: "none" operations are not recorded; the filter word is only read from two-operation leaves, k_group_pack)
+            const u32 nops = (u32)(w1 != OPW_NONE) + (u32)(w2 != OPW_NONE);
+            lf->nops = nops;
+            lf->ops[0] = w1 != OPW_NONE ? w1 : (w2 != OPW_NONE ? w2 : 0u);
+            lf->ops[1] = (w1 != OPW_NONE && w2 != OPW_NONE) ? w2 : 0u;
+            lf->ops[2] = nops == 2 ? fword : 0u;  // 0, or the filtered form: mask | characters in front << 16 | 1 << 31 (k_group_pack hands it on)
 #pragma unroll
             for (int k = 3; k < (int)DMAX; ++k) lf->ops[k] = 0u;
           }
@@ -1208,7 +1226,7 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
     __syncthreads();
     const u32 G = (nl && nl < 256u) ? 256u / nl : 1u;
     const u32 ti = threadIdx.x / G, tk = threadIdx.x - ti * G, istep = 256u / G;
-    for (u32 i = ti; i < nl; i += istep) {
+    for (u32 i = ti; i < nl && !ham; i += istep) {  // (Hamming mode keeps the whole ball: no string is another's proper substring)
       if (l_rank[i] == 0xFFFFFFFFu) continue;
       const u32 alen = l_meta[i] & 63u, span = alen - (m - 2u);  // 0..4 characters above the shortest
       const u64 a = l_key[i];

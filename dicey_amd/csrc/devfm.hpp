@@ -119,16 +119,30 @@ DG_DEV KtabEntry ktab_decode(uint2 e) {
 DG_DEV KtabEntry ktab_entry(const FmView& f, u64 code) { return ktab_decode(f.ktab[code]); }
 
 // is the k-mer `code` present?  t = window position (0 = right-most character) of the edit the neighbouring lanes vary
+// (r05) The lane's copy by SELECTS over scalars.  kf.cp[] / kf.s[] live in the kernel-argument segment; indexed by a lane-varying r the
+// compiler turned the choice into vector loads from that segment — four extra memory instructions per lane and a dependent
+// round trip in front of every probe phase (ISA of k_search1s, r04).  readfirstlane pins the eight values in scalar registers.
+DG_DEV void kf_pick(const KFilter& kf, u32 r, const u32*& base, u32& s) {
+  // (the copy's address as copy 0's plus a selected distance: pointer arithmetic on a kernel-argument pointer keeps the loads in the
+  // global address space; a pointer rebuilt from two integers becomes a flat one)
+  u32 lo[4], hi[4], sh[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long d = reinterpret_cast<const char*>(kf.cp[k]) - reinterpret_cast<const char*>(kf.cp[0]);
+    lo[k] = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)d);
+    hi[k] = (u32)__builtin_amdgcn_readfirstlane((int)(u32)((u64)d >> 32));
+    sh[k] = (u32)__builtin_amdgcn_readfirstlane((int)kf.s[k]);
+  }
+  const u32 l = r == 0 ? lo[0] : r == 1 ? lo[1] : r == 2 ? lo[2] : lo[3];
+  const u32 h = r == 0 ? hi[0] : r == 1 ? hi[1] : r == 2 ? hi[2] : hi[3];
+  s = r == 0 ? sh[0] : r == 1 ? sh[1] : r == 2 ? sh[2] : sh[3];
+  base = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(kf.cp[0]) + (long long)(((u64)h << 32) | l));
+}
 DG_DEV bool kf_present(const KFilter& kf, u64 code, u32 t) {
   const u32 r = (u32)(kf.pick >> (2 * (t < 31 ? t : 31))) & 3u;
-  const u32* base = kf.cp[0];
-  u32 s = kf.s[0];
-#pragma unroll
-  for (int k = 1; k < 4; ++k)
-    if (r == (u32)k) {
-      base = kf.cp[k];
-      s = kf.s[k];
-    }
+  const u32* base;
+  u32 s;
+  kf_pick(kf, r, base, s);
   const u32 inl = (u32)(code >> s) & 511u;
   const u64 line = (code & ((1ULL << s) - 1)) | ((code >> (s + 9)) << s);
   return (base[line * 16 + (inl >> 5)] >> (inl & 31)) & 1u;
@@ -142,14 +156,7 @@ struct KfCopy {
 DG_DEV KfCopy kf_copy(const KFilter& kf, u32 t) {
   const u32 r = (u32)(kf.pick >> (2 * (t < 31 ? t : 31))) & 3u;
   KfCopy c;
-  c.base = kf.cp[0];
-  c.s = kf.s[0];
-#pragma unroll
-  for (int k = 1; k < 4; ++k)
-    if (r == (u32)k) {
-      c.base = kf.cp[k];
-      c.s = kf.s[k];
-    }
+  kf_pick(kf, r, c.base, c.s);
   return c;
 }
 // address of the word that holds a code's bit (and the bit's number): lanes that ask about several codes compute all the

@@ -366,6 +366,69 @@ DG_DEV bool cand1(u64 qpk, u32 m, u32 pos, u32 op, u64& s_pk, u32& mlen, u32& op
   // insertion one position further left (which exists from the second position on)
   return pos < m && !(pos >= 2 && c == old);
 }
+// The eight probes of a position when every string of the neighbourhood is at least K2 characters long (the usual primer: m - 1 >= K2),
+// without building the eight strings (r05).  The strings of one KIND differ from each other only in the edited character, i.e. in two
+// bits of the window code: one base code per kind (the substituted / inserted character's bits cleared; one deletion), one (line,
+// in-line bit) pair per base code, and every variant by OR-ing the two bits' images — an in-line bit when the lane's copy of the
+// filter holds that code bit in its field, a bit of the 27-bit line index otherwise.  ~10 instead of ~35 instructions per candidate:
+// the r04 counters put k_search1s at 64 M vector instructions per launch, two thirds of its run time in issue slots.
+// Candidates, validity and order are cand1's (which still rebuilds the survivors in the dense phase).
+template <bool INDEL, u32 NOPS>
+DG_DEV void probe8_long(const FmView& f, u64 qpk, u32 m, u32 pos, const u32* (&addr)[NOPS], u32 (&bit)[NOPS], u32& valid) {
+  const u32 K2 = f.kf2.k, R = m - pos;
+  const bool inwin = R < K2;  // else the last K2 characters of every string are the query's own
+  const KfCopy c = kf_copy(f.kf2, inwin ? R : K2 - 1);
+  const u32 s = c.s;
+  const u64 mask2 = (1ULL << (2 * K2)) - 1;
+  const u32 old = (u32)(qpk >> (2 * R)) & 3u;
+  const u64 low = qpk & ((1ULL << (2 * R)) - 1);
+  const u64 wS = qpk & mask2 & ~(inwin ? (3ULL << (2 * R)) : 0ULL);
+  auto split = [&](u64 w, u32& line, u32& inl) {
+    inl = (u32)(w >> s) & 511u;
+    line = (u32)((w & ((1ULL << s) - 1)) | ((w >> (s + 9)) << s));
+  };
+  // images of the edited character's two code bits
+  u32 dl0 = 0, dl1 = 0, di0 = 0, di1 = 0;
+  if (inwin) {
+    const u32 b0 = 2 * R, b1 = b0 + 1;
+    di0 = (b0 >= s && b0 < s + 9) ? 1u << (b0 - s) : 0u;
+    dl0 = b0 < s ? 1u << b0 : (b0 >= s + 9 ? 1u << (b0 - 9) : 0u);
+    di1 = (b1 >= s && b1 < s + 9) ? 1u << (b1 - s) : 0u;
+    dl1 = b1 < s ? 1u << b1 : (b1 >= s + 9 ? 1u << (b1 - 9) : 0u);
+  }
+  auto place = [&](u32 op, u32 line0, u32 inl0, u32 ch) {
+    const u32 line = line0 | ((ch & 1u) ? dl0 : 0u) | ((ch & 2u) ? dl1 : 0u);
+    const u32 inl = inl0 | ((ch & 1u) ? di0 : 0u) | ((ch & 2u) ? di1 : 0u);
+    addr[op] = c.base + ((u64)line * 16 + (inl >> 5));
+    bit[op] = inl & 31u;
+  };
+  u32 lineS, inlS;
+  split(wS, lineS, inlS);
+  valid = 0;
+  if (INDEL) {
+    u32 lineD, inlD, lineI, inlI;
+    split((low | ((qpk >> (2 * R + 2)) << (2 * R))) & mask2, lineD, inlD);
+    split((low | ((qpk >> (2 * R)) << (2 * R + 2))) & mask2, lineI, inlI);  // the inserted character's bits are zero
+    place(0, lineD, inlD, 0u);
+    // deleting either of two equal neighbours gives the same string: the right-most character of a run does it (cand1)
+    valid |= (u32)!(R >= 1 && ((u32)(qpk >> (2 * R - 2)) & 3u) == old);
+#pragma unroll
+    for (u32 op = 4; op < 8; ++op) {
+      const u32 ch = op - 4;
+      place(op, lineI, inlI, ch);
+      valid |= (u32)(pos < m && !(pos >= 2 && ch == old)) << op;  // neighbors.h:51, and the duplicate rule of cand1
+    }
+  } else {
+    place(0, lineS, inlS, old);  // the sequence itself belongs to the Hamming set (lane of position 1)
+    valid |= (u32)(pos == 1);
+  }
+#pragma unroll
+  for (u32 op = 1; op < 4; ++op) {
+    place(op, lineS, inlS, (old + op) & 3u);
+    valid |= 1u << op;
+  }
+}
+
 // Second look at a survivor that is longer than the long filter's order: its FIRST K2 characters must occur as well.  The two
 // windows overlap in all but (length - K2) characters, yet on a 3.1 Gb genome three of four random survivors end here — for one
 // line instead of the table entry and 3-5 Occ lines.  R = characters right of the (last) edit, for the choice of the copy.
@@ -575,26 +638,33 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       const u32 m = raw.z, d_win = raw.w;
       if (m && (d_win & 512u) && pos <= m) {
         const u32 R = m - pos;
-        const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
-        const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
-        const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
         const u32* const idle = reinterpret_cast<const u32*>(f.ktab);
         const u32* addr[NOPS];
         u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
+        if (K2 && m >= K2 + (INDEL ? 1u : 0u)) {  // every string asks the long filter: addresses without building the strings (probe8_long)
+          probe8_long<INDEL, NOPS>(f, qpk, m, pos, addr, bit, valid);
+          probe = valid;
 #pragma unroll
-        for (u32 op = 0; op < NOPS; ++op) {
-          u64 s_pk;
-          u32 mlen, ow;
-          const bool ok = cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow);
-          const bool use2 = K2 && mlen >= K2;
-          const bool pr = ok && (use2 || f.kf.nr);
-          KfCopy c;
-          c.base = use2 ? c2.base : c1.base;
-          c.s = use2 ? c2.s : c1.s;
-          const u32* a = kf_word(c, use2 ? s_pk & mask2 : s_pk & kmask, bit[op]);
-          addr[op] = pr ? a : idle;
-          valid |= (u32)ok << op;
-          probe |= (u32)pr << op;
+          for (u32 op = 0; op < NOPS; ++op) addr[op] = ((valid >> op) & 1u) ? addr[op] : idle;
+        } else {
+          const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
+          const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
+          const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
+#pragma unroll
+          for (u32 op = 0; op < NOPS; ++op) {
+            u64 s_pk;
+            u32 mlen, ow;
+            const bool ok = cand1<INDEL>(qpk, m, pos, op, s_pk, mlen, ow);
+            const bool use2 = K2 && mlen >= K2;
+            const bool pr = ok && (use2 || f.kf.nr);
+            KfCopy c;
+            c.base = use2 ? c2.base : c1.base;
+            c.s = use2 ? c2.s : c1.s;
+            const u32* a = kf_word(c, use2 ? s_pk & mask2 : s_pk & kmask, bit[op]);
+            addr[op] = pr ? a : idle;
+            valid |= (u32)ok << op;
+            probe |= (u32)pr << op;
+          }
         }
 #pragma unroll
         for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];

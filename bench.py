@@ -792,7 +792,7 @@ def main():
                     else:
                         gather_parts([torch.empty(0, dtype=torch.uint8, device=dev)])
                 return {k_: 0 for k_ in ("nhits", "ext", "leaves", "sa", "win", "tab", "probe", "ops_per_hit", "ms_total", "ms_search",
-                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns", "t0", "t1", "gen")}
+                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns", "t0", "t1", "gen", "form")}
             rp = C.POINTER(_capi.HuntResult)()
             _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(params or p_compact), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
                                             C.c_void_p(bo.data_ptr()), nq, bbytes, fetch, C.byref(rp)))
@@ -801,7 +801,7 @@ def main():
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
                    "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns,
-                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen}
+                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen, "form": R.flat_kernel_form}
             if (world > 1 or a.gather_single) and not fetch and a.backend == "nccl" and R.compact:
                 gather_block(R)
             elif (world > 1 or a.gather_single) and not fetch:
@@ -829,7 +829,7 @@ def main():
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
                    "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns,
-                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen}
+                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen, "form": R.flat_kernel_form}
             if (world > 1 or a.gather_single) and a.backend == "nccl" and R.compact:
                 gather_block(R)  # staged on the lane's own stream (R.stream): ordered before that lane's next batch
             elif world > 1 or a.gather_single:
@@ -1067,16 +1067,17 @@ def main():
             ext, tab, probe = mean("ext"), mean("tab"), mean("probe")
             flat = mean("ms_search_flat")
             # distance 1: k_search1s = the flat search with the select stage inside (r03); DICEY_NO_FUSED_SELECT gives k_search1p
-            k1 = "k_search1p<true>" if os.environ.get("DICEY_NO_FUSED_SELECT") else "k_search1s<true, true>"
-            # distance 2: k_search2p with the select stage inside (r04)
-            k2 = "k_search2p<false>" if (os.environ.get("DICEY_NO_FUSED_SELECT") or os.environ.get("DICEY_NO_FUSED_SELECT2")) else "k_search2p<true>"
+            # which instantiation ran is the library's word (dg_hunt_result::flat_kernel_form of the last timed step), not a guess: on a
+            # repeat-bearing genome the generic kernels stay on and k_search1s runs without the take stage (<true, false>)
+            form = int(acc[-1].get("form", 0)) if acc else 0
+            ind = "false" if a.hamming else "true"
+            k1 = {1: f"k_search1p<{ind}>", 2: f"k_search1s<{ind}, false>", 3: f"k_search1s<{ind}, true>"}.get(form, f"k_search1s<{ind}, true>")
+            k2 = {4: "k_search2p<false>", 5: "k_search2p<true>"}.get(form, "k_search2p<true>")
             # the general kernel (queries with N, above 31 nt, Hamming distance >= 2, distance >= 3): dominant when the flat kernels took
             # less than half of the search phase (phase events of the pass behind the timed region)
             ms_phase = float(np.mean([r["ms_search"] for r in acc_ph])) if acc_ph else mean("ms_search")
             generic_dominant = flat <= 0 or (acc_ph and float(np.mean([r["ms_search_flat"] for r in acc_ph])) < 0.5 * ms_phase)
             kernel = f"k_search<{'false' if a.hamming else 'true'}, {distance}>" if generic_dominant else (k1 if distance == 1 else k2)
-            if a.hamming and not generic_dominant and distance == 1:
-                kernel = kernel.replace("<true,", "<false,")
             kernel_ms = ms_phase if generic_dominant else flat
             # Two batches in flight: the launches of neighbouring batches overlap, and the sum of their durations counts that time twice.
             # The time the kernel RAN is the union of the launches' intervals on the lanes' common timeline (dg_hunt_result::t_search_*,

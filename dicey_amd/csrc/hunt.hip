@@ -704,6 +704,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   u64 nleaf = 0, nhits = 0;
   bool force_generic = false, force_jobs = false;
+  u32 flat_form = 0;  // which flat search kernel the (last) attempt launched: dg_hunt_result::flat_kernel_form
   // Fetched results: one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh
   // hipHostMalloc per batch costs more than the copies), laid out for `capn` hits:
   // [hit_off | qoff | qdistance qflags qnondna | qseq | hits | ops].  When the previous fetched batch on this handle tells how many
@@ -813,6 +814,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     // the whole batch on the flat distance-1 path: k_search1s settles the `take` values of its own queries (TAKE form);
     // DICEY_NO_PREP_FUSION keeps k_take a launch of its own (the GPU suite runs both)
     const bool prep_in = fused && b.fastK && !generic_on && !group_counts && !sw.no_prep_fusion;
+    flat_form = b.fastK ? (fused ? (prep_in ? 3u : 2u) : 1u) : b.fast2K ? (fused ? 5u : 4u) : 0u;
     // the per-character arrays (fw / rv codes, normalised ASCII) are read by the generic kernels, the full-matrix verify kernels and
     // the classic result fetch only: 60 byte stores per query that the flat path with compact results does without
     const u32 write_bytes = (prep_in && band_verify && (compact || !fetch)) ? 0u : 1u;
@@ -1248,6 +1250,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->cap_queries_device = dev_jobs.size();
   R->cap_queries_host = cs.looked_at;
   R->cap_patterns = nxs;
+  R->flat_kernel_form = flat_form;
   R->t_base_gen = 0;
   R->t_search_begin_ms = R->t_search_end_ms = 0.0;
   if (base_ev && (b.fastK || b.fast2K)) {

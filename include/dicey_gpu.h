@@ -220,7 +220,9 @@ typedef struct {
    * intervals, not the sum of their lengths (bench.py's roofline).  t_base_gen: intervals of equal generation share a base (the
    * library takes a new base every few seconds to keep float precision); 0 = no timeline (one lane only so far, or no flat kernel). */
   double t_search_begin_ms, t_search_end_ms;
-  uint32_t t_base_gen, t_reserved_;
+  uint32_t t_base_gen;
+  uint32_t flat_kernel_form; /* measurement: the flat search kernel this batch ran — 0 none (general k_search only), 1 k_search1p, 2 k_search1s<.,
+                              * false> (select stage inside), 3 k_search1s<., true> (select and take inside), 4 k_search2p<false>, 5 k_search2p<true> */
   /* ABI 6: what a gather over RCCL needs (include/dicey_gather.h).  stream: the hipStream_t the batch ran on — the handle's own, or
    * the internal lane's for a dg_hunt_submit / dg_hunt_device_submit batch; a device-side copy out of the result's device buffers
    * queued on it is ordered before that lane's next batch, with no host synchronisation.  Compact results: d_block is the batch's

@@ -180,10 +180,7 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
     gi.m = ((flags & DG_Q_TOO_SHORT) || explicit_set || (strand && !b.reverse) || bad_len) ? 0u : m;
     gi.d_win = d | (bad == 0 ? 256u : 0u);
     if (b.fastK && gi.m && bad == 0 && d == 1 && m <= 31 && m >= b.fastK + 1) gi.d_win |= 512u;
-    if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) {
-      if (m >= b.fast2_minlen) gi.d_win |= 1024u;
-      else atomicAdd(b.short2, 1u);  // k_search2p<., true> leaves it to the walker; the handle switches to the r04 body for the next batches
-    }
+    if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
     if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
     b.ginfo[2 * q + strand] = gi;
     if (gi_out) gi_out[strand] = gi;
@@ -376,19 +373,16 @@ DG_DEV bool cand1(u64 qpk, u32 m, u32 pos, u32 op, u64& s_pk, u32& mlen, u32& op
 // filter holds that code bit in its field, a bit of the 27-bit line index otherwise.  ~10 instead of ~35 instructions per candidate:
 // the r04 counters put k_search1s at 64 M vector instructions per launch, two thirds of its run time in issue slots.
 // Candidates, validity and order are cand1's (which still rebuilds the survivors in the dense phase).
-// The core: word offsets inside the lane's copy of the long filter and the bit numbers for the operations 0 .. NOPS-1 applied at `pos`
-// to the packed string (pk, len), all of whose results are at least K2 characters long.  Operation 0 is the deletion (INDEL) or "the
-// string itself" (!INDEL: the Hamming ball's member without an edit here); 1-3 substitute the other bases; 4-7 insert A, C, G, T.
 template <bool INDEL, u32 NOPS>
-DG_DEV void probe8_core(const KfCopy& c, u32 K2, u64 pk, u32 len, u32 pos, u32 (&off)[NOPS], u32 (&bit)[NOPS], u32& old_out) {
-  const u32 R = len - pos;
-  const bool inwin = R < K2;  // else the last K2 characters of every result are the string's own
+DG_DEV void probe8_long(const FmView& f, u64 qpk, u32 m, u32 pos, const u32* (&addr)[NOPS], u32 (&bit)[NOPS], u32& valid) {
+  const u32 K2 = f.kf2.k, R = m - pos;
+  const bool inwin = R < K2;  // else the last K2 characters of every string are the query's own
+  const KfCopy c = kf_copy(f.kf2, inwin ? R : K2 - 1);
   const u32 s = c.s;
   const u64 mask2 = (1ULL << (2 * K2)) - 1;
-  const u32 old = (u32)(pk >> (2 * R)) & 3u;
-  old_out = old;
-  const u64 low = pk & ((1ULL << (2 * R)) - 1);
-  const u64 wS = pk & mask2 & ~(inwin ? (3ULL << (2 * R)) : 0ULL);
+  const u32 old = (u32)(qpk >> (2 * R)) & 3u;
+  const u64 low = qpk & ((1ULL << (2 * R)) - 1);
+  const u64 wS = qpk & mask2 & ~(inwin ? (3ULL << (2 * R)) : 0ULL);
   auto split = [&](u64 w, u32& line, u32& inl) {
     inl = (u32)(w >> s) & 511u;
     line = (u32)((w & ((1ULL << s) - 1)) | ((w >> (s + 9)) << s));
@@ -405,37 +399,34 @@ DG_DEV void probe8_core(const KfCopy& c, u32 K2, u64 pk, u32 len, u32 pos, u32 (
   auto place = [&](u32 op, u32 line0, u32 inl0, u32 ch) {
     const u32 line = line0 | ((ch & 1u) ? dl0 : 0u) | ((ch & 2u) ? dl1 : 0u);
     const u32 inl = inl0 | ((ch & 1u) ? di0 : 0u) | ((ch & 2u) ? di1 : 0u);
-    off[op] = line * 16u + (inl >> 5);  // word offset inside the copy (< 2^31: a 27-bit line index)
+    addr[op] = c.base + ((u64)line * 16 + (inl >> 5));
     bit[op] = inl & 31u;
   };
   u32 lineS, inlS;
   split(wS, lineS, inlS);
+  valid = 0;
   if (INDEL) {
     u32 lineD, inlD, lineI, inlI;
-    split((low | ((pk >> (2 * R + 2)) << (2 * R))) & mask2, lineD, inlD);
-    split((low | ((pk >> (2 * R)) << (2 * R + 2))) & mask2, lineI, inlI);  // the inserted character's bits are zero
+    split((low | ((qpk >> (2 * R + 2)) << (2 * R))) & mask2, lineD, inlD);
+    split((low | ((qpk >> (2 * R)) << (2 * R + 2))) & mask2, lineI, inlI);  // the inserted character's bits are zero
     place(0, lineD, inlD, 0u);
-#pragma unroll
-    for (u32 op = 4; op < (NOPS > 4 ? 8u : 4u); ++op) place(op < NOPS ? op : 0u, lineI, inlI, op - 4);
-  } else {
-    place(0, lineS, inlS, inwin ? old : 0u);
-  }
-#pragma unroll
-  for (u32 op = 1; op < 4; ++op) place(op, lineS, inlS, inwin ? ((old + op) & 3u) : 0u);
-}
-template <bool INDEL, u32 NOPS>
-DG_DEV void probe8_long(const FmView& f, u64 qpk, u32 m, u32 pos, KfCopy& c, u32 (&off)[NOPS], u32 (&bit)[NOPS], u32& valid) {
-  const u32 K2 = f.kf2.k, R = m - pos;
-  c = kf_copy(f.kf2, R < K2 ? R : K2 - 1);
-  u32 old;
-  probe8_core<INDEL, NOPS>(c, K2, qpk, m, pos, off, bit, old);
-  valid = 14u;  // the three substitutions
-  if (INDEL) {
     // deleting either of two equal neighbours gives the same string: the right-most character of a run does it (cand1)
     valid |= (u32)!(R >= 1 && ((u32)(qpk >> (2 * R - 2)) & 3u) == old);
 #pragma unroll
-    for (u32 op = 4; op < 8; ++op) valid |= (u32)(pos < m && !(pos >= 2 && (op - 4) == old)) << op;  // neighbors.h:51, and cand1's duplicate rule
-  } else valid |= (u32)(pos == 1);  // the sequence itself belongs to the Hamming set (lane of position 1)
+    for (u32 op = 4; op < 8; ++op) {
+      const u32 ch = op - 4;
+      place(op, lineI, inlI, ch);
+      valid |= (u32)(pos < m && !(pos >= 2 && ch == old)) << op;  // neighbors.h:51, and the duplicate rule of cand1
+    }
+  } else {
+    place(0, lineS, inlS, old);  // the sequence itself belongs to the Hamming set (lane of position 1)
+    valid |= (u32)(pos == 1);
+  }
+#pragma unroll
+  for (u32 op = 1; op < 4; ++op) {
+    place(op, lineS, inlS, (old + op) & 3u);
+    valid |= 1u << op;
+  }
 }
 
 // Second look at a survivor that is longer than the long filter's order: its FIRST K2 characters must occur as well.  The two
@@ -648,17 +639,14 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       if (m && (d_win & 512u) && pos <= m) {
         const u32 R = m - pos;
         const u32* const idle = reinterpret_cast<const u32*>(f.ktab);
+        const u32* addr[NOPS];
         u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
-        if (K2 && m >= K2 + (INDEL ? 1u : 0u)) {  // every string asks the long filter: offsets without building the strings (probe8_long)
-          KfCopy cf;
-          u32 off[NOPS];
-          probe8_long<INDEL, NOPS>(f, qpk, m, pos, cf, off, bit, valid);
+        if (K2 && m >= K2 + (INDEL ? 1u : 0u)) {  // every string asks the long filter: addresses without building the strings (probe8_long)
+          probe8_long<INDEL, NOPS>(f, qpk, m, pos, addr, bit, valid);
           probe = valid;
-          // the eight loads back to back (a lane without a probe reads the copy's first word)
 #pragma unroll
-          for (u32 op = 0; op < NOPS; ++op) word[op] = cf.base[((valid >> op) & 1u) ? off[op] : 0u];
+          for (u32 op = 0; op < NOPS; ++op) addr[op] = ((valid >> op) & 1u) ? addr[op] : idle;
         } else {
-          const u32* addr[NOPS];
           const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
           const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
           const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
@@ -677,9 +665,9 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
             valid |= (u32)ok << op;
             probe |= (u32)pr << op;
           }
-#pragma unroll
-          for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
         }
+#pragma unroll
+        for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
 #pragma unroll
         for (u32 op = 0; op < NOPS; ++op) {
           const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
@@ -1032,12 +1020,7 @@ static constexpr u32 FUSED2_HCAP = 1024;  // hash slots of the select stage (dis
 // once more with its leaves written out for the generic select kernels (selbase stays "generic"; the host repeats the batch with
 // them when they were not launched).  (A form with one workgroup per QUERY that also did k_take's work — both strands one after the
 // other — was measured: 9.68 against 9.28 + 0.27 ms for this kernel and k_take; removed.)
-// LONG2 (r05): every group this launch takes has its shortest string (two deletions; none in Hamming mode) at least K2 characters long
-// — Batch::fast2_minlen makes k_prepare leave shorter queries to the walker — so every probe asks the long filter and the eight word
-// offsets of an inner loop come from three base codes of the once-edited string and the images of the second edit's two code bits
-// (probe8_core) instead of eight built strings.  !LONG2 is the r04 body: batches that hold shorter queries (the handle remembers).
-// Two instantiations, not a runtime branch: with both bodies in one kernel 13 registers of the common path went to scratch.
-template <bool SEL, bool LONG2>
+template <bool SEL>
 __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2, u32 hamming) {
   const bool ham = hamming != 0;  // substitutions only; strings with 0, 1 and 2 of them (r05: Hamming distance 2 used to walk k_search<false, 2>, 3.6 x slower per query than the edit form here)
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
@@ -1098,34 +1081,9 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
             // software pipeline — round k + 1's loads issued before round k's words are consumed, no branches inside a round: 155
             // VGPRs, three wavefronts per SIMD, 10.8 ms; held to 128 VGPRs with 64 B of scratch 9.7 ms; this form 9.3 ms on the same
             // box.  tools/r04_call19.sh.  Not kept: residency is worth more to this kernel than loads in flight per wavefront.)
-            u32 bit[8], word[8], valid = 0, probe = 0;
-            if (LONG2) {
-              u32 oldc, off[8];
-              if (ham) {
-                u32 o4[4], b4[4];
-                probe8_core<false, 4>(c2, K2, s1, l1, p2, o4, b4, oldc);
-#pragma unroll
-                for (u32 k = 0; k < 4; ++k) {
-                  off[k] = o4[k];
-                  bit[k] = b4[k];
-                  off[k + 4] = 0;
-                  bit[k + 4] = 0;
-                }
-              } else probe8_core<true, 8>(c2, K2, s1, l1, p2, off, bit, oldc);
-#pragma unroll
-              for (u32 op2 = 0; op2 < 8; ++op2) {
-                bool v2 = true;
-                if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
-                if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
-                if (ham) v2 = (op2 >= 1 && op2 <= 3) ? (p2 < p1 && op1 != 0) : (op2 == 0 && p2 == 1);
-                valid |= (u32)v2 << op2;
-              }
-              probe = valid;
-#pragma unroll
-              for (u32 op2 = 0; op2 < 8; ++op2) word[op2] = c2.base[((valid >> op2) & 1u) ? off[op2] : 0u];
-            } else {
             const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
             const u32* addr[8];
+            u32 bit[8], word[8], valid = 0, probe = 0;
 #pragma unroll
             for (u32 op2 = 0; op2 < 8; ++op2) {
               bool v2 = true;
@@ -1148,7 +1106,6 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
             }
 #pragma unroll
             for (u32 op2 = 0; op2 < 8; ++op2) word[op2] = *addr[op2];
-            }
 #pragma unroll
             for (u32 op2 = 0; op2 < 8; ++op2) {
               const u32 present = ((probe >> op2) & 1u) ? (word[op2] >> bit[op2]) & 1u : 1u;

@@ -1155,15 +1155,22 @@ def main():
                              # what bounds this kernel: L2-to-fabric requests per second against the chip's measured rate for independent
                              # random 64-byte lines (gather_reference below, 4 GiB footprint; the byte fraction above is what the contract
                              # asks for and falls whenever the kernel is taught to need fewer bytes)
-                             "request_rate": ({"fabric_requests_per_s": fabric_reads / (kernel_ms * 1e-3), "reference_requests_per_s": 26.5e9,
-                                               "frac": fabric_reads / (kernel_ms * 1e-3) / 26.5e9} if (fabric_reads and kernel_ms > 0) else None),
+                             # r05: the reference is the kernel-SHAPED gather (tools/microbench/gather_bench filter2: four copies of 2^27
+                             # lines, a lane per (strand, position), eight loads per lane, the lines of one operation kind and filter
+                             # field shared — 12 lines per strand, 8 wavefronts per SIMD, nothing but the loads): 42.3 G lines/s,
+                             # profiles/r05_gather_filter2.jsonl.  r04 compared with 26.5 G/s of a microbenchmark that was slower
+                             # than the kernel it was meant to bound (its address arithmetic and 38 lines per wave instruction)
+                             "request_rate": ({"fabric_requests_per_s": fabric_reads / (kernel_ms * 1e-3), "reference_requests_per_s": 42.3e9,
+                                               "frac": fabric_reads / (kernel_ms * 1e-3) / 42.3e9,
+                                               "reference": "gather_bench filter2, 12 lines per strand (profiles/r05_gather_filter2.jsonl)"}
+                                              if (fabric_reads and kernel_ms > 0) else None),
                              # two batches in flight: the launches of neighbouring batches overlap each other and the other batch's
                              # locate / verify kernels, so a launch lasts longer than it does alone; its duration alone (the
                              # value_one_in_flight pass right behind the timed region: same batches, dg_hunt_device) and what follows from it
                              "one_in_flight": ({"kernel_ms": extras["value_one_in_flight"]["kernel_ms"],
                                                 "achieved": alg_bytes / (extras["value_one_in_flight"]["kernel_ms"] * 1e-3) / 1e9,
                                                 "frac": alg_bytes / (extras["value_one_in_flight"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                "request_rate_frac": (fabric_reads / (extras["value_one_in_flight"]["kernel_ms"] * 1e-3) / 26.5e9) if fabric_reads else None}
+                                                "request_rate_frac": (fabric_reads / (extras["value_one_in_flight"]["kernel_ms"] * 1e-3) / 42.3e9) if fabric_reads else None}
                                                if extras.get("value_one_in_flight", {}).get("kernel_ms") else None),
                              "index_accesses_per_query": (2 * ext + tab + probe) / nq,
                              "index_accesses_per_s": (2 * ext + tab + probe) / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
@@ -1181,7 +1188,8 @@ def main():
                                  "with_200k_lanes_only": {"4GiB": 21.8, "16GiB": 16.7, "170GiB": 16.0},
                                  "filter_geometry_4_copies_of_8.6GB": {"6_lines_per_strand": 20.8, "12_lines_per_strand": 9.4,
                                                                          "24_lines_per_strand": 11.3},
-                                 "source": "profiles/r03a_gather_matrix.jsonl, profiles/r03a_gather_filter.jsonl"}},
+                                 "kernel_shaped_filter2_Glines_per_s": {"12_lines_per_strand": 42.3, "15_lines_per_strand": 41.8},
+                                 "source": "profiles/r03a_gather_matrix.jsonl, profiles/r03a_gather_filter.jsonl, profiles/r05_gather_filter2.jsonl"}},
                 "cpu_baseline": cpu, "cpu_baseline_parallel": cpu_par, "pipelined": pipelined, "parity_sample": parity,
                 "phases_ms": ({k: float(np.mean([r[k] for r in acc_ph])) for k in ("ms_total", "ms_search", "ms_search_flat", "ms_select", "ms_locate", "ms_verify")}
                               if acc_ph else {k: mean(k) for k in ("ms_total", "ms_search", "ms_search_flat", "ms_select", "ms_locate", "ms_verify")}),

@@ -716,7 +716,29 @@ def main():
         """hunt, backend nccl: the batch's compact block to rank 0 through the C++ gather"""
         nb = int(R.d_block_bytes) if R is not None else 0
         if pipe["g"] is None:
-            pipe["g"] = CxxGather(int(max(nb, 8 * units) * 1.5) + 65536)
+            # every rank opens the communicator here, in its first (warm-up) step.  A rank that cannot (library missing, RCCL refusing the
+            # communicator) says so on stderr and the job falls back to the torch.distributed gather of r04 — agreed by all ranks, named
+            # in config.gather: a scaling run that dies in its first step measures nothing
+            err = ""
+            try:
+                g_ = CxxGather(int(max(nb, 8 * units) * 1.5) + 65536)
+            except Exception as e:
+                g_, err = None, repr(e)[:300]
+            bad = torch.tensor([1 if g_ is None else 0], dtype=torch.int32, device=dev)
+            if world > 1:
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                if err:
+                    print(f"bench.py rank {rank}: libdiceygather could not be opened ({err}); gathering through torch.distributed", file=sys.stderr)
+                if g_ is not None:
+                    g_.c.close()
+                pipe["cxx_off"] = err or "another rank could not open libdiceygather"
+            else:
+                pipe["g"] = g_
+                pipe["cxx_on"] = True
+        if pipe.get("cxx_off"):
+            parts = [device_bytes(R.d_block, nb, dev)] if nb else [torch.empty(0, dtype=torch.uint8, device=dev)]
+            return gather_parts(parts)
         pipe["g"].submit_block(R.d_block if nb else 0, nb, R.stream if nb else 0)
         if a.dump_gather:
             pipe["last_local"] = device_bytes(R.d_block, nb, dev).cpu().numpy().tobytes() if nb else b""
@@ -1434,6 +1456,9 @@ def main():
         if rank == 0:
             for r, payload in enumerate(pipe["g"].last_received()):
                 open(os.path.join(a.dump_gather, f"gathered_{r}.bin"), "wb").write(payload)
+    if rank == 0 and out is not None and (world > 1 or a.gather_single):
+        out["config"]["gather"] = ("libdiceygather.so: C++ over RCCL, exact-size ncclSend / ncclRecv one step behind the size exchange" if pipe.get("cxx_on")
+                                   else "torch.distributed (dicey_amd/shard.py)" + (" — FALLBACK: " + pipe["cxx_off"] if pipe.get("cxx_off") else ""))
     if rank == 0 and out is not None:
         out["index"] = {"n": st["n"], "file_bytes": st["file_bytes"], "hbm_bytes": st["hbm_bytes"],
                         "load_s": st["load_seconds"], "derive_s": st["derive_seconds"]}

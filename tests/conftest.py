@@ -19,6 +19,7 @@ def pytest_sessionstart(session):
     oracle.  hipcc cross-compiles without a GPU, so this works in the build container and on the GPU box alike."""
     import subprocess
     need = [(os.path.join(ROOT, "dicey_amd", "libdiceygpu.so"), ["make", "-C", os.path.join(ROOT, "dicey_amd", "csrc"), "-s", "-j4"]),
+            (os.path.join(ROOT, "dicey_amd", "libdiceygather.so"), ["make", "-C", os.path.join(ROOT, "dicey_amd", "csrc"), "-s", "-j4"]),
             (os.path.join(ROOT, "dicey_amd", "dicey"), ["make", "-C", os.path.join(ROOT, "dicey_amd", "cli"), "-s"]),
             (os.path.join(ROOT, "oracle", "liboracle.so"), ["make", "-C", os.path.join(ROOT, "oracle"), "-s"])]
     for artefact, cmd in need:

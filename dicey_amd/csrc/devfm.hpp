@@ -99,6 +99,9 @@ struct FmView {
   // the i in [lo, hi) whose entry spells its first r characters: ONE line of this array instead of r dependent Occ lines when the
   // interval is narrow (k_search1s).  nullptr = not built.
   const u16* pre5;
+  // The text's shortest run of 'N', capped at 64 (r05; 0 = unknown: no pruning).  k_search: a query with non-A/C/G/T characters whose
+  // N's are fewer than this and lie more than d characters from both ends has no neighbourhood string that keeps an N and occurs.
+  u32 nrun_min;
   static constexpr u32 MAXLEV = 10;
   const u32* samin[MAXLEV];
   u32 nlev;  // levels present, including level 0; 0 = no hierarchy

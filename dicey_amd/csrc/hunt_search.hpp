@@ -1419,6 +1419,24 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
     const bool rest = item == items - 1;
     // lanes of a split launch: without the table (or without budget) only the rest lane works, as a full search
     if (!rest && (!use_win || d == 0)) active = false;
+    // r05: a query with characters outside A,C,G,T (searched as 'N', util.h:208-219).  A neighbourhood string that keeps an N occurs only
+    // where the text has a run of N's of exactly its N-block's length when that block has other characters on both sides inside the
+    // string.  If the query has more than d other characters in front of its first and behind its last N (an outer one survives d
+    // edits on each side, so every N-block of every string is flanked) and fewer N's than the text's shortest run (FmView::nrun_min),
+    // NO string that keeps an N occurs: every N has to be substituted or deleted, and the walk is cut down to that — a node is left
+    // as soon as the N's still ahead outnumber the edits left.  (r05 measured 5 % of such queries costing a batch 20 x: one lane per
+    // strand walked ~150 strings in interval mode, ~1 500 dependent index reads, to find that none of them occurs.)
+    u64 nmask = 0;  // bit i: query character i is an N
+    bool nprune = false;
+    if (active && !(gi.d_win & 256) && m <= 64 && f.nrun_min) {
+      for (u32 i = 0; i < m; ++i) nmask |= (u64)(seq[i] >= 4) << i;
+      const u32 nN = (u32)__popcll(nmask);
+      if (nN) {
+        const u32 first = (u32)__builtin_ctzll(nmask), last = 63u - (u32)__builtin_clzll(nmask);
+        nprune = first >= d + 1 && (m - 1 - last) >= d + 1 && nN < f.nrun_min;
+        if (nprune && nN > d) active = false;  // more N's than edits: every string keeps one
+      }
+    }
     if (active) {
       const u64 qpk = gi.qpk;
       FrameStack<D> S;
@@ -1494,6 +1512,8 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
           }
           if (kind == OP_S && c == here) continue;           // a substitution changes the character (neighbors.h:63)
           if (kind == OP_I && L == 0 && pos == m) continue;   // nothing may be inserted after the last character (neighbors.h:51)
+          // N's still ahead (left of what this operation consumes) against the edits left behind it
+          if (nprune && (u32)__popcll(nmask & ((1ULL << (kind == OP_I ? pos : pos - 1)) - 1)) > budget - 1) continue;
           Frame ch = F;
           ch.st &= ~15u;
           if (kind != OP_D && !frame_emit(f, ch, c, steps, lookups, probes)) continue;
@@ -1509,7 +1529,8 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
         if (budget == 0 && (F.st & ST_WIN)) alive = frame_finish_window(f, F, seq, m, qpk, lookups, probes);  // only a d = 0 root
         else {
           F.st &= ~15u;
-          if (here < 4) alive = frame_emit(f, F, here, steps, lookups, probes);
+          if (nprune && (here >= 4 || (u32)__popcll(nmask & ((1ULL << (pos - 1)) - 1)) > budget)) alive = false;  // a kept N, or more N's ahead than edits
+          else if (here < 4) alive = frame_emit(f, F, here, steps, lookups, probes);
           else {  // an N in the query (never in window mode): through the wavelet tree like sdsl
             bs_extend_sym(f, F.lo, F.hi, 'N', here);
             ++steps;

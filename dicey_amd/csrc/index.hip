@@ -424,6 +424,19 @@ __global__ void __launch_bounds__(256) k_kmer_table_wave(FmView f, uint2* tab, u
   if (kf2 && !(me2 >> 63) && (lane == 0 || prev2 != me2)) atomicOr(&kf2[me2 >> 5], 1u << (me2 & 31));
 }
 
+// FmView::nrun_min: the length of the text's shortest run of 'N', capped at 64 (r05).  A lane per text position; the lane of a run's
+// first character looks at most 63 characters ahead.  A query character outside A,C,G,T is searched as 'N' (util.h:208-219) and
+// matches only an 'N' of the text: a neighbourhood string whose N-block has other characters on both sides needs a run of exactly
+// that length — k_search prunes such strings when no run is that short (hunt_search.hpp).
+__global__ void __launch_bounds__(256) k_nrun_min(const u8* text, u64 n, u32* out) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    if (text[i] != 'N' || (i && text[i - 1] == 'N')) continue;
+    u32 len = 1;
+    while (len < 64 && i + len < n && text[i + len] == 'N') ++len;
+    if (len < 64) atomicMin(out, len);
+  }
+}
+
 // FmView::pre5: the five characters in front of every suffix, in suffix-array order (one text gather per lane)
 __global__ void __launch_bounds__(256) k_pre5(const u32* sa, const u8* text, u64 n, u16* out) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -566,6 +579,18 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
   DG_HIP(hipStreamSynchronize(ix->stream));
   DG_HIP(hipGetLastError());
   pc.lap("text + suffix array");
+  {  // the shortest run of 'N' (one streaming pass over the text)
+    u32* d_min = nullptr;
+    u32 h_min = 64;
+    DG_HIP(hipMalloc((void**)&d_min, 4));
+    DG_HIP(hipMemcpyAsync(d_min, &h_min, 4, hipMemcpyHostToDevice, ix->stream));
+    hipLaunchKernelGGL(k_nrun_min, dim3((u32)std::min<u64>(ceil_div(n, TB), 1u << 16)), dim3(TB), 0, ix->stream, (const u8*)text, n, d_min);
+    DG_HIP(hipMemcpyAsync(&h_min, d_min, 4, hipMemcpyDeviceToHost, ix->stream));
+    DG_HIP(hipStreamSynchronize(ix->stream));
+    DG_HIP(hipFree(d_min));
+    f.nrun_min = std::getenv("DICEY_NO_NRUN_PRUNE") ? 0u : h_min;
+    pc.lap("shortest N run");
+  }
   if (!(flags & DG_OPEN_NO_KMER_TABLE)) {
     // K = ceil(log4 n) clamped to [8,16]: about one expected occurrence per K-mer; 16 -> 34 GB, which is what the
     // 288 GB of HBM are for

@@ -212,3 +212,57 @@ def test_one_and_a_quarter_million_queries_at_distance_two(genome_100mb):
         sub = ix.hunt(qs[lo:lo + 2000], g["seqlen"], distance=2)
         key = lambda R: [[(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in q.hits] for q in R]
         assert key(sub.queries) == key(got.queries[lo:lo + 2000])
+
+
+@pytest.mark.parametrize("prune", [True, False])
+def test_queries_with_n_where_the_text_has_no_short_n_run(genome_100mb, prune, monkeypatch):
+    """r05: the text's shortest run of N is >= 10 here, so k_search knows that no string which keeps a query's N can occur and walks
+    only the strings whose N's are substituted or deleted (FmView::nrun_min).  Hits, order and alignments against the oracle for
+    queries with one, two and three N's (inside, near the ends — where the pruning must stay off —, adjacent, lower case / IUPAC
+    letters), edit and Hamming mode, distance 1 and 2; DICEY_NO_NRUN_PRUNE runs the unpruned walk on the same queries."""
+    import dicey_amd
+    if not prune:
+        monkeypatch.setenv("DICEY_NO_NRUN_PRUNE", "1")
+    g = genome_100mb
+    rng = random.Random(555)
+    base, _ = _planted_queries(g, rng, 240, edits=(0, 1))
+    qs = []
+    for i, q in enumerate(base):
+        q = list(q)
+        k = i % 6
+        if k == 0:
+            q[rng.randrange(3, 17)] = "N"
+        elif k == 1:
+            a = rng.randrange(3, 16)
+            q[a] = "N"
+            q[a + 1] = "n"
+        elif k == 2:
+            q[rng.randrange(0, 2)] = "N"             # within d of the left end
+        elif k == 3:
+            q[19 - rng.randrange(0, 2)] = "R"        # within d of the right end, an IUPAC letter
+        elif k == 4:
+            for p in rng.sample(range(2, 18), 3):
+                q[p] = "N"
+        else:
+            q[rng.randrange(4, 16)] = "y"
+        qs.append("".join(q))
+    with dicey_amd.FmIndex(g["fm9"]) as ix:
+        for kw, sub in ((dict(distance=1), qs), (dict(distance=1, hamming=True), qs[:120]), (dict(distance=2, hamming=True), qs[:60])):
+            want = _oracle_hits_parallel(g["fm9"], g, sub, **kw)
+            got = ix.hunt(sub, g["seqlen"], **kw)
+            nh = 0
+            for qi, qr in enumerate(got.queries):
+                a = [(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in qr.hits]
+                assert a == want.get(qi, []), (qi, sub[qi], kw)
+                nh += len(a)
+            assert nh > 20, (kw, nh)
+        O.fast_neighbors(True)
+        try:
+            sub = qs[:36]
+            want = _oracle_hits_parallel(g["fm9"], g, sub, distance=2)
+            got = ix.hunt(sub, g["seqlen"], distance=2)
+            for qi, qr in enumerate(got.queries):
+                a = [(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in qr.hits]
+                assert a == want.get(qi, []), (qi, sub[qi])
+        finally:
+            O.fast_neighbors(False)

@@ -599,6 +599,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   b.fastK = (dmax_eff == 1 && ix->view.K && maxlen > ix->view.K && ngrp * (u64)std::min(maxlen, 31u) * 9 < 0xFFFFFF00ull && ngrp < (1u << 24)) ? ix->view.K : 0u;
   // (r05: Hamming distance 2 as well — the same kernel with "no edit" in place of the deletions)
   b.fast2K = (dmax_eff == 2 && (indel || !sw.no_flat_ham2) && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
+  b.tabK = sw.no_nwin ? 0u : ix->view.K;
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
   b.xs_off = d_xs_off;
@@ -880,7 +881,9 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       walker_on = !(b.fast2K && !ix->generic_hint && !force_generic && nxs == 0);
       if (generic_on && walker_on) {
       // root-level work split (see k_search): only with the table and with at least one edit to place
-      const u32 items = (ix->view.K && dmax_eff >= 1 && !b.fastK) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
+      // (r05: also beside the flat distance-1 kernel — the walker is only launched when a batch has groups for it, and those are the
+      // queries with N that the split turns from one 1 500-read chain per strand into lanes of a handful of reads)
+      const u32 items = (ix->view.K && dmax_eff >= 1) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
       const dim3 grid(ceil_div(ngrp * items, TB)), block(TB);
 #define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so, items)
       if (indel) {
@@ -1307,7 +1310,8 @@ dg_switches dg_switches::read() {
   if (std::getenv("DICEY_CAP_BUDGET_MB")) w.cap_budget_mb = (uint64_t)std::max(1L, num("DICEY_CAP_BUDGET_MB"));
   if (std::getenv("DICEY_HOST_THREADS")) w.host_threads = (unsigned)std::max(1L, num("DICEY_HOST_THREADS"));
   if (const char* e = std::getenv("DICEY_DUMP_JOBS")) w.dump_jobs = e;
-  w.no_flat_ham2 = std::getenv("DICEY_NO_FLAT_HAMMING2") != nullptr;  // A/B and tests: Hamming distance 2 on the general kernel, as before r05
+  w.no_flat_ham2 = std::getenv("DICEY_NO_FLAT_HAMMING2") != nullptr;
+  w.no_nwin = std::getenv("DICEY_NO_N_WINDOW") != nullptr;  // A/B and tests: N-bearing queries in interval mode, one lane per strand (r04)  // A/B and tests: Hamming distance 2 on the general kernel, as before r05
   w.exp_bits = (uint32_t)num("DICEY_EXP");  // measurement aid (wrong results): phases of k_search1s switched off, see the kernel
   return w;
 }

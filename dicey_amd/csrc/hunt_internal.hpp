@@ -33,6 +33,7 @@ struct Batch {  // device pointers of one batch
   u32* too_long;         // ... k_prepare counts the ones that are longer (only possible when the host trusted a cached bound)
   struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
   uint4* gpeq;            // [2*nq] position masks of the strand (x, y, z, w: bit i <=> character i is A, C, G, T), queries up to 32 nt
+  u32 tabK;               // order of the K-mer table (0 = none): k_prepare marks N-bearing strands whose N's stay left of every window
   u32 fastK;              // != 0: the batch runs k_search1 (distance 1, table order fastK) for the queries that qualify
   u32 fast2K;             // != 0: the batch runs k_search2 (edit distance 2) for the queries that qualify
   // Queries whose neighbourhood could reach the cap are enumerated on the host (nbhd_host.hpp) before the batch starts:

@@ -182,6 +182,18 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
     if (b.fastK && gi.m && bad == 0 && d == 1 && m <= 31 && m >= b.fastK + 1) gi.d_win |= 512u;
     if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
     if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
+    // r05: a query with N's that all lie left of every table window of its strand's strings (string index below m - K - d) walks in
+    // window mode like an N-free one — the packed copy (an N as 0) is only read inside windows — and so gets k_search's root split:
+    // one lane per first edit instead of one lane per strand with ~1 500 dependent index reads
+    if (bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
+      const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
+      const u32 lim = m - b.tabK - d;  // N's are allowed at string indices below this
+      const bool ok = !strand ? (lim < 32 && (nm >> lim) == 0u) : (nm & (m - lim >= 32 ? ~0u : ((1u << (m - lim)) - 1u))) == 0u;
+      if (ok) {
+        gi.d_win |= 2048u;
+        gi.qpk = strand ? pk_rv : pk_fw;
+      }
+    }
     b.ginfo[2 * q + strand] = gi;
     if (gi_out) gi_out[strand] = gi;
     // the banded verify takes the query as position masks (band_align_bits); the reverse strand's character j is the complement
@@ -1415,7 +1427,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
     const u32 m = gi.m;
     u32 d = gi.d_win & 255;
     if (d > (u32)D) d = D;  // cannot happen: the host instantiates D >= the largest effective distance
-    const bool use_win = f.K != 0 && m >= f.K + d && (gi.d_win & 256);
+    const bool use_win = f.K != 0 && m >= f.K + d && (gi.d_win & (256u | 2048u));  // (2048: N's, but none inside any window)
     const bool rest = item == items - 1;
     // lanes of a split launch: without the table (or without budget) only the rest lane works, as a full search
     if (!rest && (!use_win || d == 0)) active = false;

@@ -11,7 +11,7 @@
 // host process that writes its environment — and carried to run_batch in the handle.
 struct dg_switches {
   bool host_timing = false, no_band = false, cap_host = false, no_fuse = false, no_fuse2 = false, no_prep_fusion = false, no_pre5_d2 = false;
-  bool debug_caps = false, no_flat_ham2 = false;
+  bool debug_caps = false, no_flat_ham2 = false, no_nwin = false;
   uint32_t fused_lcap = 0;       // DICEY_FUSED_LCAP (0 = unset)
   int verify_ch = 0;             // DICEY_VERIFY_CH
   uint64_t cap_budget_mb = 0;    // DICEY_CAP_BUDGET_MB (0 = unset)

@@ -361,7 +361,8 @@ def test_flat_distance_two_kernel(gpu_small, small_genome, monkeypatch):
 SWITCHES = {"nofuse": {"DICEY_NO_FUSED_SELECT": "1"}, "noband": {"DICEY_NO_BAND_VERIFY": "1"}, "classic": {"DICEY_CLASSIC_RESULTS": "1"},
             "ch4": {"DICEY_VERIFY_CH": "4"}, "ch8": {"DICEY_VERIFY_CH": "8"}, "caps": {"DICEY_DEBUG_CAPS": "3"},
             "lcap2": {"DICEY_FUSED_LCAP": "2"}, "noprep": {"DICEY_NO_PREP_FUSION": "1"}, "caphost": {"DICEY_CAP_HOST": "1"}, "nominima": {"DICEY_NO_SA_MINIMA": "1"}, "nopre5": {"DICEY_NO_PRE5": "1"},
-            "nopre5d2": {"DICEY_NO_PRE5_D2": "1"}, "nofuse2": {"DICEY_NO_FUSED_SELECT2": "1"}, "noflatham2": {"DICEY_NO_FLAT_HAMMING2": "1"}}
+            "nopre5d2": {"DICEY_NO_PRE5_D2": "1"}, "nofuse2": {"DICEY_NO_FUSED_SELECT2": "1"}, "noflatham2": {"DICEY_NO_FLAT_HAMMING2": "1"},
+            "nonwin": {"DICEY_NO_N_WINDOW": "1"}}
 
 
 @pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13", "K9_nolong", "K9_long10", "K10_long14"] + ["K9_long10+" + k for k in SWITCHES])
@@ -390,6 +391,15 @@ def test_every_search_mode_gives_the_same_hits(small_genome, monkeypatch, mode):
         # lcap2 sends every group's leaves to the generic select kernels, nofuse2 all of them, noflatham2 keeps the r04 route)
         _compare(ix, orc, small_genome, qs[:150] + ["A" * 20, "ACGT" * 5, "AC" * 9], distance=2, hamming=True)
         _compare(ix, orc, small_genome, qs[150:220], distance=2, hamming=True, max_locations=2, forward_only=True)
+        # queries with N: left of every table window (window mode + root split, r05), inside the window zone, at either end, several
+        nq_ = []
+        for i, q in enumerate(q for q in qs[100:160] if len(q) >= 14):
+            p = [0, 1, 2, 3, len(q) // 2, len(q) - 3, len(q) - 1][i % 7]
+            nq_.append(q[:p] + "N" + q[p + 1:])
+        nq_ += [qs[0][:2] + "NN" + qs[0][4:], "N" + qs[1][1:-1] + "N"]
+        _compare(ix, orc, small_genome, nq_, distance=1)
+        _compare(ix, orc, small_genome, nq_[:20], distance=1, hamming=True)
+        _compare(ix, orc, small_genome, nq_[:10], distance=2, hamming=True)
         if "_" in mode:  # the flat distance-2 kernel around the long filter's order (strings of 12..18 characters)
             O.fast_neighbors(True)
             try:

@@ -645,6 +645,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   gp += ngrp * 4;
   b.refused = &ctr->pad_[1];
   b.too_long = &ctr->pad_[2];
+  b.nwin = &ctr->pad_[7];
   b.maxlen_bound = maxlen;
   b.total_qbytes = total;
   u32* qhits = (u32*)gp;  // (compact results: re-pointed into the compact block, per attempt)
@@ -883,7 +884,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       // root-level work split (see k_search): only with the table and with at least one edit to place
       // (r05: also beside the flat distance-1 kernel — the walker is only launched when a batch has groups for it, and those are the
       // queries with N that the split turns from one 1 500-read chain per strand into lanes of a handful of reads)
-      const u32 items = (ix->view.K && dmax_eff >= 1) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
+      // — while the handle's batches hold such strands (nwin_sticky): 29 M lanes that leave at once cost a repeats-genome step 0.15 ms
+      const u32 items = (ix->view.K && dmax_eff >= 1 && (!b.fastK || ix->nwin_sticky)) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
       const dim3 grid(ceil_div(ngrp * items, TB)), block(TB);
 #define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so, items)
       if (indel) {
@@ -1145,6 +1147,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       else if (ix->generic_sticky) --ix->generic_sticky;
       ix->generic_hint = ix->generic_sticky > 0;
     }
+    if (hsum.n_nwin) ix->nwin_sticky = 8;
+    else if (ix->nwin_sticky) --ix->nwin_sticky;
     if (!group_counts) {
       if (hsum.jobs_small > 0 || hsum.jobs_big > 0) ix->jobs_sticky = 8;
       else if (ix->jobs_sticky) --ix->jobs_sticky;

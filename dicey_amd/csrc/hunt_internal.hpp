@@ -34,6 +34,7 @@ struct Batch {  // device pointers of one batch
   struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
   uint4* gpeq;            // [2*nq] position masks of the strand (x, y, z, w: bit i <=> character i is A, C, G, T), queries up to 32 nt
   u32 tabK;               // order of the K-mer table (0 = none): k_prepare marks N-bearing strands whose N's stay left of every window
+  u32* nwin;              // ... and raises this flag when it marked one
   u32 fastK;              // != 0: the batch runs k_search1 (distance 1, table order fastK) for the queries that qualify
   u32 fast2K;             // != 0: the batch runs k_search2 (edit distance 2) for the queries that qualify
   // Queries whose neighbourhood could reach the cap are enumerated on the host (nbhd_host.hpp) before the batch starts:

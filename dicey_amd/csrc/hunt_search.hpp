@@ -192,6 +192,7 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
       if (ok) {
         gi.d_win |= 2048u;
         gi.qpk = strand ? pk_rv : pk_fw;
+        *b.nwin = 1u;  // (a flag: the handle gives the walker its root split while batches hold such strands)
       }
     }
     b.ginfo[2 * q + strand] = gi;

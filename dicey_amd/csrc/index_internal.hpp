@@ -39,6 +39,7 @@ struct dg_index {
   uint64_t hit_cap_hint = 0;
   bool generic_hint = true;      // the previous distance-1 batch had work for the kernels outside k_search1s (hunt.hip run_batch)
   bool jobs_hint = true;         // the previous batch queued strings for the locate job kernels
+  uint32_t nwin_sticky = 0;      // batches the walker keeps its root split beside the flat distance-1 kernel (N-bearing strands in window mode)
   uint32_t generic_sticky = 1, jobs_sticky = 1;  // batches the two hints stay on after the last batch that needed them
   uint64_t jobs_big_hint = 0;    // repeat-rich strings (workgroup locate jobs) of the previous batch
   uint64_t fused_leaves_hint = 0;  // occurring strings the previous distance-1 batch held in k_search1s' LDS lists (+ generic leaves)

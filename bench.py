@@ -1094,7 +1094,7 @@ def main():
             form = int(acc[-1].get("form", 0)) if acc else 0
             ind = "false" if a.hamming else "true"
             k1 = {1: f"k_search1p<{ind}>", 2: f"k_search1s<{ind}, false>", 3: f"k_search1s<{ind}, true>"}.get(form, f"k_search1s<{ind}, true>")
-            k2 = {4: "k_search2p<false>", 5: "k_search2p<true>"}.get(form, "k_search2p<true>")
+            k2 = {4: "k_search2p<false, false>", 5: "k_search2p<true, false>", 6: "k_search2p<false, true>", 7: "k_search2p<true, true>"}.get(form, "k_search2p<true, true>")
             # the general kernel (queries with N, above 31 nt, Hamming distance >= 2, distance >= 3): dominant when the flat kernels took
             # less than half of the search phase (phase events of the pass behind the timed region)
             ms_phase = float(np.mean([r["ms_search"] for r in acc_ph])) if acc_ph else mean("ms_search")

@@ -341,6 +341,20 @@ DG_DEV u32 wave_sum32(u32 v) {
          (u32)__builtin_amdgcn_readlane((int)v, 48);
 }
 
+// Inclusive prefix sum over the wavefront's 64 lanes, data-parallel primitives again: four shifts inside the rows of 16, then the
+// rows' totals handed on (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  The __shfl_up loop it replaces in
+// k_search2p kept seven permute addresses in registers across the whole kernel — which the compiler sent to scratch (r05).  Call with
+// the whole wavefront active.
+DG_DEV u32 wave_incl_scan32(u32 v) {
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1 (lanes without a source add 0)
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15, rows 1 and 3
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31, rows 2 and 3
+  return v;
+}
+
 DG_DEV u32 code_of_byte(u32 b) {
   return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : b == 'N' ? 4u : b == '\n' ? 5u : b == 0 ? 6u : 7u;
 }

@@ -646,6 +646,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   b.refused = &ctr->pad_[1];
   b.too_long = &ctr->pad_[2];
   b.nwin = &ctr->pad_[7];
+  b.short2 = &ctr->pad_[9];
+  b.fast2_minlen = 0;
   b.maxlen_bound = maxlen;
   b.total_qbytes = total;
   u32* qhits = (u32*)gp;  // (compact results: re-pointed into the compact block, per attempt)
@@ -705,7 +707,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     flat_req = shard_cap;
   }
   u64 nleaf = 0, nhits = 0;
-  bool force_generic = false, force_jobs = false;
+  bool force_generic = false, force_jobs = false, force_short2 = false;
   u32 flat_form = 0;  // which flat search kernel the (last) attempt launched: dg_hunt_result::flat_kernel_form
   // Fetched results: one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh
   // hipHostMalloc per batch costs more than the copies), laid out for `capn` hits:
@@ -815,8 +817,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipEventRecord(ix->ev[0], st));
     // the whole batch on the flat distance-1 path: k_search1s settles the `take` values of its own queries (TAKE form);
     // DICEY_NO_PREP_FUSION keeps k_take a launch of its own (the GPU suite runs both)
+    // distance 2: the LONG2 body of k_search2p takes queries whose shortest string still asks the long filter; the handle falls back to
+    // the r04 body while its batches hold shorter ones (short2_sticky), and a batch that turns out to hold some is repeated with it
+    const bool long2 = b.fast2K && ix->view.kf2.nr && ix->view.kf2.k <= 18 /* word offsets inside a copy stay below 2^32 */ && !ix->short2_sticky && !force_short2 && !sw.no_long2;
+    b.fast2_minlen = long2 ? ix->view.kf2.k + (indel ? 2u : 0u) : 0u;
     const bool prep_in = fused && b.fastK && !generic_on && !group_counts && !sw.no_prep_fusion;
-    flat_form = b.fastK ? (fused ? (prep_in ? 3u : 2u) : 1u) : b.fast2K ? (fused ? 5u : 4u) : 0u;
+    flat_form = b.fastK ? (fused ? (prep_in ? 3u : 2u) : 1u) : b.fast2K ? (fused ? 5u : 4u) + (long2 ? 2u : 0u) : 0u;
     // the per-character arrays (fw / rv codes, normalised ASCII) are read by the generic kernels, the full-matrix verify kernels and
     // the classic result fetch only: 60 byte stores per query that the flat path with compact results does without
     const u32 write_bytes = (prep_in && band_verify && (compact || !fetch)) ? 0u : 1u;
@@ -872,8 +878,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         // (tests: DICEY_FUSED_LCAP lowers the list's capacity so that ordinary groups exercise the hand-over to the generic select kernels)
         const u32 lcap2 = sw.fused_lcap ? std::max<u32>(1u, std::min<u32>(FUSED2_LCAP, sw.fused_lcap)) : FUSED2_LCAP;
         const u32 ham2 = indel ? 0u : 1u;
-        if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
+        if (fused && long2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true, true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
+        else if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true, false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
+        else if (long2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false, true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false, false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
         DG_HIP(hipEventRecord(ix->ev[8], st));
       }
       // edit distance 2: the walker (k_search) only serves the groups k_search2p does not take (N in the query, above 30 nt); it is
@@ -1115,6 +1123,11 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       force_generic = true;
       again = true;
     }
+    if (long2 && hsum.n_short2 > 0) {  // queries too short for the LONG2 body went to the walker (or to nobody): once more with the r04 body
+      ix->short2_sticky = 8;
+      force_short2 = true;
+      again = true;
+    }
     if (!jobs_on && !group_counts && (hsum.jobs_small > 0 || hsum.jobs_big > 0)) {  // strings were queued and nobody served them
       ix->jobs_hint = true;
       force_jobs = true;
@@ -1149,6 +1162,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     }
     if (hsum.n_nwin) ix->nwin_sticky = 8;
     else if (ix->nwin_sticky) --ix->nwin_sticky;
+    if (b.fast2K && !long2 && ix->short2_sticky && !force_short2) --ix->short2_sticky;  // (eight batches on the r04 body, then LONG2 is tried again)
     if (!group_counts) {
       if (hsum.jobs_small > 0 || hsum.jobs_big > 0) ix->jobs_sticky = 8;
       else if (ix->jobs_sticky) --ix->jobs_sticky;
@@ -1314,8 +1328,9 @@ dg_switches dg_switches::read() {
   if (std::getenv("DICEY_CAP_BUDGET_MB")) w.cap_budget_mb = (uint64_t)std::max(1L, num("DICEY_CAP_BUDGET_MB"));
   if (std::getenv("DICEY_HOST_THREADS")) w.host_threads = (unsigned)std::max(1L, num("DICEY_HOST_THREADS"));
   if (const char* e = std::getenv("DICEY_DUMP_JOBS")) w.dump_jobs = e;
-  w.no_flat_ham2 = std::getenv("DICEY_NO_FLAT_HAMMING2") != nullptr;
-  w.no_nwin = std::getenv("DICEY_NO_N_WINDOW") != nullptr;  // A/B and tests: N-bearing queries in interval mode, one lane per strand (r04)  // A/B and tests: Hamming distance 2 on the general kernel, as before r05
+  w.no_flat_ham2 = std::getenv("DICEY_NO_FLAT_HAMMING2") != nullptr;  // A/B and tests: Hamming distance 2 on the general kernel, as before r05
+  w.no_nwin = std::getenv("DICEY_NO_N_WINDOW") != nullptr;  // A/B and tests: N-bearing queries in interval mode, one lane per strand (r04)
+  w.no_long2 = std::getenv("DICEY_NO_LONG2") != nullptr;  // A/B and tests: k_search2p's r04 body for every batch
   w.exp_bits = (uint32_t)num("DICEY_EXP");  // measurement aid (wrong results): phases of k_search1s switched off, see the kernel
   return w;
 }

@@ -37,6 +37,8 @@ struct Batch {  // device pointers of one batch
   u32* nwin;              // ... and raises this flag when it marked one
   u32 fastK;              // != 0: the batch runs k_search1 (distance 1, table order fastK) for the queries that qualify
   u32 fast2K;             // != 0: the batch runs k_search2 (edit distance 2) for the queries that qualify
+  u32 fast2_minlen;       // ... of at least this length (k_search2p<., LONG2 = true>: K2 + 2, K2 in Hamming mode; 0 otherwise)
+  u32* short2;            // counter of the qualifying queries below it (they go to the walker)
   // Queries whose neighbourhood could reach the cap are enumerated on the host (nbhd_host.hpp) before the batch starts:
   // qmode[q] (nullptr = no such query in this batch): QM_KERNEL = not looked at (k_prepare's own bound must hold),
   // QM_EXPLICIT = the strings of both strands arrive as explicit patterns (xs_*) and k_search skips the query,

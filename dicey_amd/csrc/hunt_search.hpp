@@ -180,7 +180,10 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
     gi.m = ((flags & DG_Q_TOO_SHORT) || explicit_set || (strand && !b.reverse) || bad_len) ? 0u : m;
     gi.d_win = d | (bad == 0 ? 256u : 0u);
     if (b.fastK && gi.m && bad == 0 && d == 1 && m <= 31 && m >= b.fastK + 1) gi.d_win |= 512u;
-    if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) gi.d_win |= 1024u;
+    if (b.fast2K && gi.m && bad == 0 && d == 2 && m <= 30 && m >= b.fast2K + 2) {
+      if (m >= b.fast2_minlen) gi.d_win |= 1024u;
+      else atomicAdd(b.short2, 1u);  // k_search2p<., true> leaves it to the walker; the handle switches to the r04 body for the next batches
+    }
     if (bad == 0 && m <= 32) gi.qpk = strand ? pk_rv : pk_fw;
     // r05: a query with N's that all lie left of every table window of its strand's strings (string index below m - K - d) walks in
     // window mode like an N-free one — the packed copy (an N as 0) is only read inside windows — and so gets k_search's root split:
@@ -379,6 +382,19 @@ DG_DEV bool cand1(u64 qpk, u32 m, u32 pos, u32 op, u64& s_pk, u32& mlen, u32& op
   // insertion one position further left (which exists from the second position on)
   return pos < m && !(pos >= 2 && c == old);
 }
+// The place of a window code's bit in a copy of the long filter whose in-line field starts at code bit s: (word offset inside the copy,
+// bit number).  A permutation of the code's bits, so place(a | b) = place(a) | place(b): k_search2p<., true> ORs the places of a
+// string's parts.  (Word offsets fit 32 bits up to K2 = 18.)
+struct FiltPos {
+  u32 off, bit;
+};
+DG_DEV FiltPos filt_pos(u64 w, u32 s) {
+  const u32 inl = (u32)(w >> s) & 511u;
+  FiltPos r;
+  r.off = (u32)(((w >> (s + 9)) << (s + 4)) | ((w & ((1ULL << s) - 1)) << 4)) | (inl >> 5);
+  r.bit = inl & 31u;
+  return r;
+}
 // The eight probes of a position when every string of the neighbourhood is at least K2 characters long (the usual primer: m - 1 >= K2),
 // without building the eight strings (r05).  The strings of one KIND differ from each other only in the edited character, i.e. in two
 // bits of the window code: one base code per kind (the substituted / inserted character's bits cleared; one deletion), one (line,
@@ -386,16 +402,19 @@ DG_DEV bool cand1(u64 qpk, u32 m, u32 pos, u32 op, u64& s_pk, u32& mlen, u32& op
 // filter holds that code bit in its field, a bit of the 27-bit line index otherwise.  ~10 instead of ~35 instructions per candidate:
 // the r04 counters put k_search1s at 64 M vector instructions per launch, two thirds of its run time in issue slots.
 // Candidates, validity and order are cand1's (which still rebuilds the survivors in the dense phase).
+// The core: word offsets inside the lane's copy of the long filter and the bit numbers for the operations 0 .. NOPS-1 applied at `pos`
+// to the packed string (pk, len), all of whose results are at least K2 characters long.  Operation 0 is the deletion (INDEL) or "the
+// string itself" (!INDEL: the Hamming ball's member without an edit here); 1-3 substitute the other bases; 4-7 insert A, C, G, T.
 template <bool INDEL, u32 NOPS>
-DG_DEV void probe8_long(const FmView& f, u64 qpk, u32 m, u32 pos, const u32* (&addr)[NOPS], u32 (&bit)[NOPS], u32& valid) {
-  const u32 K2 = f.kf2.k, R = m - pos;
-  const bool inwin = R < K2;  // else the last K2 characters of every string are the query's own
-  const KfCopy c = kf_copy(f.kf2, inwin ? R : K2 - 1);
+DG_DEV void probe8_core(const KfCopy& c, u32 K2, u64 pk, u32 len, u32 pos, u32 (&off)[NOPS], u32 (&bit)[NOPS], u32& old_out) {
+  const u32 R = len - pos;
+  const bool inwin = R < K2;  // else the last K2 characters of every result are the string's own
   const u32 s = c.s;
   const u64 mask2 = (1ULL << (2 * K2)) - 1;
-  const u32 old = (u32)(qpk >> (2 * R)) & 3u;
-  const u64 low = qpk & ((1ULL << (2 * R)) - 1);
-  const u64 wS = qpk & mask2 & ~(inwin ? (3ULL << (2 * R)) : 0ULL);
+  const u32 old = (u32)(pk >> (2 * R)) & 3u;
+  old_out = old;
+  const u64 low = pk & ((1ULL << (2 * R)) - 1);
+  const u64 wS = pk & mask2 & ~(inwin ? (3ULL << (2 * R)) : 0ULL);
   auto split = [&](u64 w, u32& line, u32& inl) {
     inl = (u32)(w >> s) & 511u;
     line = (u32)((w & ((1ULL << s) - 1)) | ((w >> (s + 9)) << s));
@@ -412,34 +431,37 @@ DG_DEV void probe8_long(const FmView& f, u64 qpk, u32 m, u32 pos, const u32* (&a
   auto place = [&](u32 op, u32 line0, u32 inl0, u32 ch) {
     const u32 line = line0 | ((ch & 1u) ? dl0 : 0u) | ((ch & 2u) ? dl1 : 0u);
     const u32 inl = inl0 | ((ch & 1u) ? di0 : 0u) | ((ch & 2u) ? di1 : 0u);
-    addr[op] = c.base + ((u64)line * 16 + (inl >> 5));
+    off[op] = line * 16u + (inl >> 5);  // word offset inside the copy (< 2^31: a 27-bit line index at K2 = 18, the callers' bound)
     bit[op] = inl & 31u;
   };
   u32 lineS, inlS;
   split(wS, lineS, inlS);
-  valid = 0;
   if (INDEL) {
     u32 lineD, inlD, lineI, inlI;
-    split((low | ((qpk >> (2 * R + 2)) << (2 * R))) & mask2, lineD, inlD);
-    split((low | ((qpk >> (2 * R)) << (2 * R + 2))) & mask2, lineI, inlI);  // the inserted character's bits are zero
+    split((low | ((pk >> (2 * R + 2)) << (2 * R))) & mask2, lineD, inlD);
+    split((low | ((pk >> (2 * R)) << (2 * R + 2))) & mask2, lineI, inlI);  // the inserted character's bits are zero
     place(0, lineD, inlD, 0u);
+#pragma unroll
+    for (u32 op = 4; op < (NOPS > 4 ? 8u : 4u); ++op) place(op < NOPS ? op : 0u, lineI, inlI, op - 4);
+  } else {
+    place(0, lineS, inlS, inwin ? old : 0u);
+  }
+#pragma unroll
+  for (u32 op = 1; op < 4; ++op) place(op, lineS, inlS, inwin ? ((old + op) & 3u) : 0u);
+}
+template <bool INDEL, u32 NOPS>
+DG_DEV void probe8_long(const FmView& f, u64 qpk, u32 m, u32 pos, KfCopy& c, u32 (&off)[NOPS], u32 (&bit)[NOPS], u32& valid) {
+  const u32 K2 = f.kf2.k, R = m - pos;
+  c = kf_copy(f.kf2, R < K2 ? R : K2 - 1);
+  u32 old;
+  probe8_core<INDEL, NOPS>(c, K2, qpk, m, pos, off, bit, old);
+  valid = 14u;  // the three substitutions
+  if (INDEL) {
     // deleting either of two equal neighbours gives the same string: the right-most character of a run does it (cand1)
     valid |= (u32)!(R >= 1 && ((u32)(qpk >> (2 * R - 2)) & 3u) == old);
 #pragma unroll
-    for (u32 op = 4; op < 8; ++op) {
-      const u32 ch = op - 4;
-      place(op, lineI, inlI, ch);
-      valid |= (u32)(pos < m && !(pos >= 2 && ch == old)) << op;  // neighbors.h:51, and the duplicate rule of cand1
-    }
-  } else {
-    place(0, lineS, inlS, old);  // the sequence itself belongs to the Hamming set (lane of position 1)
-    valid |= (u32)(pos == 1);
-  }
-#pragma unroll
-  for (u32 op = 1; op < 4; ++op) {
-    place(op, lineS, inlS, (old + op) & 3u);
-    valid |= 1u << op;
-  }
+    for (u32 op = 4; op < 8; ++op) valid |= (u32)(pos < m && !(pos >= 2 && (op - 4) == old)) << op;  // neighbors.h:51, and cand1's duplicate rule
+  } else valid |= (u32)(pos == 1);  // the sequence itself belongs to the Hamming set (lane of position 1)
 }
 
 // Second look at a survivor that is longer than the long filter's order: its FIRST K2 characters must occur as well.  The two
@@ -652,14 +674,17 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       if (m && (d_win & 512u) && pos <= m) {
         const u32 R = m - pos;
         const u32* const idle = reinterpret_cast<const u32*>(f.ktab);
-        const u32* addr[NOPS];
         u32 bit[NOPS], word[NOPS], valid = 0, probe = 0;
-        if (K2 && m >= K2 + (INDEL ? 1u : 0u)) {  // every string asks the long filter: addresses without building the strings (probe8_long)
-          probe8_long<INDEL, NOPS>(f, qpk, m, pos, addr, bit, valid);
+        if (K2 && K2 <= 18 && m >= K2 + (INDEL ? 1u : 0u)) {  // every string asks the long filter: offsets without building the strings (probe8_long; 32-bit word offsets inside a copy: orders up to 18)
+          KfCopy cf;
+          u32 off[NOPS];
+          probe8_long<INDEL, NOPS>(f, qpk, m, pos, cf, off, bit, valid);
           probe = valid;
+          // the eight loads back to back (a lane without a probe reads the copy's first word)
 #pragma unroll
-          for (u32 op = 0; op < NOPS; ++op) addr[op] = ((valid >> op) & 1u) ? addr[op] : idle;
+          for (u32 op = 0; op < NOPS; ++op) word[op] = cf.base[((valid >> op) & 1u) ? off[op] : 0u];
         } else {
+          const u32* addr[NOPS];
           const KfCopy c2 = kf_copy(f.kf2, R < K2 ? R : (K2 ? K2 - 1 : 0u));
           const KfCopy c1 = kf_copy(f.kf, R < K ? R : K - 1);
           const u64 mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
@@ -678,9 +703,9 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
             valid |= (u32)ok << op;
             probe |= (u32)pr << op;
           }
-        }
 #pragma unroll
-        for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
+          for (u32 op = 0; op < NOPS; ++op) word[op] = *addr[op];
+        }
 #pragma unroll
         for (u32 op = 0; op < NOPS; ++op) {
           const u32 present = ((probe >> op) & 1u) ? (word[op] >> bit[op]) & 1u : 1u;
@@ -1024,6 +1049,23 @@ DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... ho
   p2 = (u32)a + 1;
   p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
 }
+static constexpr u32 LONG2_RB = 2;  // first operations whose probes are in flight together (k_search2p<., true>): 16 loads per wait
+DG_DEV u32 pair_rows4_count(u32 m) {
+  u32 n = 0;
+  for (u32 p2 = 1; p2 < m; ++p2) n += (m - p2 + 4) & ~3u;
+  return n;
+}
+DG_DEV bool pair_of_rows4(u32 w, u32 m, u32& p2, u32& p1) {
+  u32 start = 0;
+  for (p2 = 1; p2 < m; ++p2) {
+    const u32 pl = (m - p2 + 4) & ~3u;
+    if (w < start + pl) break;
+    start += pl;
+  }
+  const u32 j = w - start;
+  p1 = m - j;
+  return p2 < m && j <= m - p2;
+}
 static constexpr u32 FUSED2_LCAP = 512;
 static constexpr u32 FUSED2_HCAP = 1024;  // hash slots of the select stage (distinct strings of the list)  // strings of ONE (query, strand) group in LDS (k_search2p<true, .>)
 // SEL (r04): the select stage inside, like k_search1s — the workgroup owns its group anyway, so the group's occurring strings stay in
@@ -1033,8 +1075,13 @@ static constexpr u32 FUSED2_HCAP = 1024;  // hash slots of the select stage (dis
 // once more with its leaves written out for the generic select kernels (selbase stays "generic"; the host repeats the batch with
 // them when they were not launched).  (A form with one workgroup per QUERY that also did k_take's work — both strands one after the
 // other — was measured: 9.68 against 9.28 + 0.27 ms for this kernel and k_take; removed.)
-template <bool SEL>
-__global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2, u32 hamming) {
+// LONG2 (r05): every group this launch takes has its shortest string (two deletions; none in Hamming mode) at least K2 characters long
+// — Batch::fast2_minlen makes k_prepare leave shorter queries to the walker — so every probe asks the long filter and a probe's place in
+// the filter is an OR of parts computed once per lane (nine base places, the images of the edited characters' code bits: filt_pos, see
+// the body) instead of a string built per probe.  !LONG2 is the r04 body: batches that hold shorter queries (the handle remembers).
+// Two instantiations, not a runtime branch: with both bodies in one kernel 13 registers of the common path went to scratch.
+template <bool SEL, bool LONG2>
+__global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2, u32 hamming) {
   const bool ham = hamming != 0;  // substitutions only; strings with 0, 1 and 2 of them (r05: Hamming distance 2 used to walk k_search<false, 2>, 3.6 x slower per query than the edit form here)
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
@@ -1056,13 +1103,17 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
   const u64 kmask = (1ULL << (2 * K)) - 1, mask2 = K2 ? (1ULL << (2 * K2)) - 1 : 0ULL;
   const u32 lane = threadIdx.x & 63;
   const u32 shard = blockIdx.x & (NSHARD - 1);
-  u32 steps = 0, nlook = 0, nprobe = 0;
+  // (the launch's statistics — extension steps, table / pre5 reads, filter probes — go through LDS once per pass: as per-lane sums they
+  //  were three registers alive across the whole kernel, which the compiler kept in scratch at five wavefronts per SIMD)
+  __shared__ u32 s_cnt[3];
+  if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
   // one pass over the group's pairs of edit positions; to_lds: occurring strings go to the LDS list, else to leaf records in HBM
-  auto search = [&](const u32 gid, const u32 m, const u64 qpk, const bool to_lds) {
+  auto search = [&](const u32 gid, const u32 m, const u64 qpk, const bool to_lds, const bool count) {
     const u32 npairs = m * (m + 1) / 2 - 1;  // p2 = 1..m-1, p1 = p2..m
     for (u32 w0 = 0; w0 < npairs; w0 += 256) {
       const u32 w = w0 + threadIdx.x;
       u64 surv = 0;
+      u32 steps = 0, nlook = 0, nprobe = 0;
       if (w < npairs) {
         u32 p1, p2;
         pair_of(w, m, p2, p1);
@@ -1073,6 +1124,120 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
         const u32 qb = R1 ? (u32)(qpk >> (2 * R1 - 2)) & 3u : 4u;         // q[p1], 4 = none
         const u32 q2a = (u32)(qpk >> (2 * (m - p2))) & 3u;                // q[p2-1]
         const u32 q2b = (u32)(qpk >> (2 * (m - p2) - 2)) & 3u;            // q[p2] (p2 < m)
+        if constexpr (LONG2) {
+          // r05: the window code of a twice-edited string is (code of the string with both edited characters' bits zero) | first
+          // character's bits | second character's bits, and so is its place in the lane's copy of the filter (a permutation of the code's
+          // bits, filt_pos).  Nine base places per lane — (deletion, substitution, insertion) x the same for the second edit — and the
+          // images of the two code bits of four character slots; a probe's word offset and bit number are then one three-way OR each.
+          // ~85 vector instructions per round of eight probes, loads and bit tests included (the r04 body: ~310).  The rounds go LONG2_RB at
+          // a time: 8 * LONG2_RB loads back to back before the first word is looked at.  With the wavefront scan on data-parallel
+          // primitives and the statistics in LDS the kernel fits 80 registers: six wavefronts per SIMD (r04: five, r03: four).
+          // Measured and not kept (tools/r05_call10.sh, r05_variants.sh): the rounds as a two-deep software pipeline (spills at 96
+          // registers), rows of pairs padded to quads of lanes (same number of vector-cache look-ups), seven wavefronts (8-12 B of scratch).
+          const u32 s = c2.s;
+          const u32 b1 = 2 * R1;
+          auto slot_img = [&](u32 bpos, u32 (&io)[2], u32 (&ib)[2]) {  // (a slot left of the window has no image)
+            const FiltPos lo = filt_pos((1ULL << bpos) & mask2, s), both = filt_pos((3ULL << bpos) & mask2, s);
+            io[0] = lo.off;
+            ib[0] = lo.bit;
+            io[1] = both.off ^ lo.off;
+            ib[1] = both.bit ^ lo.bit;
+          };
+          auto img_of = [](u32 c, const u32 (&i2)[2]) { return ((c & 1u) ? i2[0] : 0u) | ((c & 2u) ? i2[1] : 0u); };
+          u32 e1o[2], e1b[2];
+          slot_img(b1, e1o, e1b);
+          const u64 low1 = qpk & ((1ULL << b1) - 1);
+          // what one kind of first operation (0 deletion — Hamming: none —, 1 substitution, 2 insertion) leaves for the second
+          struct Kind {
+            u32 boff[3];   // base word offsets: second operation deletion (Hamming: none), substitution, insertion
+            u32 so[4];     // word-offset images of the substituted characters (second operation 1..3)
+            u32 io[2];     // ... of the slot's two code bits (insertions)
+            u32 bits[2];   // bit numbers of the eight second operations, one per byte, without the first character's part
+          };
+          auto kind = [&](u32 k1) {
+            const u64 s1 = k1 == 0 ? (ham ? qpk : low1 | ((qpk >> (b1 + 2)) << b1)) : k1 == 1 ? qpk & ~(3ULL << b1) : low1 | ((qpk >> b1) << (b1 + 2));
+            const u32 l1 = k1 == 0 ? (ham ? m : m - 1) : k1 == 1 ? m : m + 1;
+            const u32 b2 = 2 * (l1 - p2);
+            const u64 low2 = s1 & ((1ULL << b2) - 1);
+            Kind kd;
+            const FiltPos pd = filt_pos((ham ? s1 : low2 | ((s1 >> (b2 + 2)) << b2)) & mask2, s);
+            const FiltPos ps = filt_pos(s1 & ~(3ULL << b2) & mask2, s);
+            const FiltPos pi = filt_pos((low2 | ((s1 >> b2) << (b2 + 2))) & mask2, s);
+            kd.boff[0] = pd.off;
+            kd.boff[1] = ps.off;
+            kd.boff[2] = pi.off;
+            u32 ib[2];
+            slot_img(b2, kd.io, ib);
+            kd.bits[0] = pd.bit;
+            kd.so[0] = 0;
+#pragma unroll
+            for (u32 op2 = 1; op2 < 4; ++op2) {
+              kd.so[op2] = img_of((q2a + op2) & 3u, kd.io);
+              kd.bits[0] |= (ps.bit | img_of((q2a + op2) & 3u, ib)) << (8 * op2);
+            }
+            kd.bits[1] = (pi.bit * 0x01010101u) | (ib[0] << 8) | (ib[1] << 16) | ((ib[0] | ib[1]) << 24);
+            return kd;
+          };
+          Kind kd[3];
+          kd[0] = kind(0);
+          kd[1] = kind(1);
+#pragma unroll
+          for (u32 g1 = 0; g1 < 8; g1 += LONG2_RB) {
+            if (g1 == 4) kd[2] = kind(2);  // (LONG2_RB divides 4: a group never mixes substitutions and insertions)
+            u32 off[LONG2_RB][8], bitn[LONG2_RB][2], valid[LONG2_RB];
+            bool any = false;
+#pragma unroll
+            for (u32 h = 0; h < LONG2_RB; ++h) {
+              const u32 op1 = g1 + h;
+              const bool ins1 = op1 >= 4;
+              const u32 k1 = op1 == 0 ? 0u : ins1 ? 2u : 1u;
+              bool v1 = (p1 > p2 || ins1) && !(p1 == m && ins1);
+              if (op1 == 0) v1 = v1 && qb != qa;
+              if (ins1) v1 = v1 && !(p1 >= 2 && qa == op1 - 4 && p2 + 2 <= p1);
+              if (ham) v1 = (op1 >= 1 && op1 <= 3) || (op1 == 0 && p1 == 1);
+              const u32 posp = ins1 ? p1 : p1 - 1;
+              const u32 c1 = k1 == 1 ? (qa + op1) & 3u : k1 == 2 ? op1 - 4 : 0u;
+              const u32 i1o = img_of(c1, e1o), i1b = img_of(c1, e1b) * 0x01010101u;
+              const Kind& kk = kd[k1];
+              u32 vm = 0;
+#pragma unroll
+              for (u32 op2 = 0; op2 < 8; ++op2) {
+                bool v2 = true;
+                if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
+                if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
+                if (ham) v2 = (op2 >= 1 && op2 <= 3) ? (p2 < p1 && op1 != 0) : (op2 == 0 && p2 == 1);
+                v2 = v2 && v1;
+                const u32 k2 = op2 == 0 ? 0u : op2 < 4 ? 1u : 2u;
+                const u32 i2o = k2 == 1 ? kk.so[op2] : k2 == 2 ? img_of(op2 - 4, kk.io) : 0u;
+                off[h][op2] = kk.boff[k2] | i1o | i2o;
+                vm |= (u32)v2 << op2;
+              }
+              bitn[h][0] = kk.bits[0] | i1b;
+              bitn[h][1] = kk.bits[1] | i1b;
+              valid[h] = vm;
+              any = any || v1;
+            }
+            if (any) {
+              u32 word[LONG2_RB][8];
+#pragma unroll
+              for (u32 h = 0; h < LONG2_RB; ++h)
+#pragma unroll
+                for (u32 k = 0; k < 8; ++k) {  // lanes without a probe do not load (reading their copy's first word instead: a quarter more look-ups in the vector cache)
+                  word[h][k] = 0;
+                  if ((valid[h] >> k) & 1u) word[h][k] = c2.base[off[h][k]];
+                }
+#pragma unroll
+              for (u32 h = 0; h < LONG2_RB; ++h) {
+                u32 mask8 = 0;
+#pragma unroll
+                for (u32 k = 0; k < 8; ++k) mask8 |= ((word[h][k] >> ((bitn[h][k >> 2] >> (8 * (k & 3u))) & 31u)) & 1u) << k;
+                mask8 &= valid[h];
+                nprobe += (u32)__popc(valid[h]);
+                surv |= (u64)mask8 << (8 * (g1 + h));
+              }
+            }
+          }
+        } else {
 #pragma unroll
         for (u32 op1 = 0; op1 < 8; ++op1) {
           const bool ins1 = op1 >= 4;
@@ -1094,9 +1259,10 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
             // software pipeline — round k + 1's loads issued before round k's words are consumed, no branches inside a round: 155
             // VGPRs, three wavefronts per SIMD, 10.8 ms; held to 128 VGPRs with 64 B of scratch 9.7 ms; this form 9.3 ms on the same
             // box.  tools/r04_call19.sh.  Not kept: residency is worth more to this kernel than loads in flight per wavefront.)
+            u32 bit[8], word[8], valid = 0, probe = 0;
+            {
             const u32* const idle = reinterpret_cast<const u32*>(f.ktab);  // what a lane without a probe reads
             const u32* addr[8];
-            u32 bit[8], word[8], valid = 0, probe = 0;
 #pragma unroll
             for (u32 op2 = 0; op2 < 8; ++op2) {
               bool v2 = true;
@@ -1119,6 +1285,7 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
             }
 #pragma unroll
             for (u32 op2 = 0; op2 < 8; ++op2) word[op2] = *addr[op2];
+            }
 #pragma unroll
             for (u32 op2 = 0; op2 < 8; ++op2) {
               const u32 present = ((probe >> op2) & 1u) ? (word[op2] >> bit[op2]) & 1u : 1u;
@@ -1128,14 +1295,11 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
             surv |= (u64)mask8 << (8 * op1);
           }
         }
+        }
       }
       // number the survivors: inclusive scan of the lanes' counts inside the wavefront, wavefront totals through LDS
       const u32 mine = (u32)__popcll(surv);
-      u32 incl = mine;
-      for (int off = 1; off < 64; off <<= 1) {
-        const u32 v = __shfl_up(incl, off);
-        if ((int)lane >= off) incl += v;
-      }
+      const u32 incl = wave_incl_scan32(mine);
       if (lane == 63) q_wave[threadIdx.x >> 6] = incl;
       q_mask[threadIdx.x] = surv;
       __syncthreads();
@@ -1242,6 +1406,16 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
           }
         }
       }
+      if (count) {  // (the wavefront is whole here)
+        steps = wave_sum32(steps);
+        nlook = wave_sum32(nlook);
+        nprobe = wave_sum32(nprobe);
+        if (lane == 0) {
+          if (steps) atomicAdd(&s_cnt[0], steps);
+          if (nlook) atomicAdd(&s_cnt[1], nlook);
+          if (nprobe) atomicAdd(&s_cnt[2], nprobe);
+        }
+      }
       __syncthreads();  // the masks and prefixes of this pass are not needed any more
     }
   };
@@ -1259,22 +1433,14 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
     }
     __syncthreads();
     // (one call site: the search is 27 KB of code)
-    u32 st1 = 0, lk1 = 0, pr1 = 0;
     bool over = false;
 #pragma unroll 1
     for (u32 pass = 0; pass < (SEL ? 2u : 1u); ++pass) {
-      search(gid, m, qpk, SEL && pass == 0);
+      search(gid, m, qpk, SEL && pass == 0, pass == 0);  // (a second pass is not counted again)
       if (!SEL) break;
       if (pass == 0) {  // (search ends with a barrier: the list is complete)
         if (l_n <= lcap2) break;
         over = true;  // (lcap2 <= FUSED2_LCAP) the generic select kernels take this group: once more, leaves to HBM
-        st1 = steps;
-        lk1 = nlook;
-        pr1 = nprobe;
-      } else {  // counted once
-        steps = st1;
-        nlook = lk1;
-        nprobe = pr1;
       }
     }
     if (!SEL || over) {
@@ -1386,13 +1552,11 @@ __global__ void __launch_bounds__(256, 5) k_search2p(FmView f, Batch b, SearchOu
       fs.selbase[gid] = shard * fs.cap + wbase;
     }
   }
-  steps = wave_sum32(steps);
-  nlook = wave_sum32(nlook);
-  nprobe = wave_sum32(nprobe);
-  if (lane == 0) {
-    if (steps) atomicAdd(&o.ctr->steps[shard], (unsigned long long)steps);
-    if (nlook) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)nlook);
-    if (nprobe) atomicAdd(&o.ctr->probes[shard], (unsigned long long)nprobe);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_cnt[0]) atomicAdd(&o.ctr->steps[shard], (unsigned long long)s_cnt[0]);
+    if (s_cnt[1]) atomicAdd(&o.ctr->lookups[shard], (unsigned long long)s_cnt[1]);
+    if (s_cnt[2]) atomicAdd(&o.ctr->probes[shard], (unsigned long long)s_cnt[2]);
   }
 }
 

@@ -11,7 +11,7 @@
 // host process that writes its environment — and carried to run_batch in the handle.
 struct dg_switches {
   bool host_timing = false, no_band = false, cap_host = false, no_fuse = false, no_fuse2 = false, no_prep_fusion = false, no_pre5_d2 = false;
-  bool debug_caps = false, no_flat_ham2 = false, no_nwin = false;
+  bool debug_caps = false, no_flat_ham2 = false, no_nwin = false, no_long2 = false;
   uint32_t fused_lcap = 0;       // DICEY_FUSED_LCAP (0 = unset)
   int verify_ch = 0;             // DICEY_VERIFY_CH
   uint64_t cap_budget_mb = 0;    // DICEY_CAP_BUDGET_MB (0 = unset)
@@ -40,6 +40,7 @@ struct dg_index {
   bool generic_hint = true;      // the previous distance-1 batch had work for the kernels outside k_search1s (hunt.hip run_batch)
   bool jobs_hint = true;         // the previous batch queued strings for the locate job kernels
   uint32_t nwin_sticky = 0;      // batches the walker keeps its root split beside the flat distance-1 kernel (N-bearing strands in window mode)
+  uint32_t short2_sticky = 0;    // distance 2: batches left on k_search2p's r04 body after one that held queries too short for LONG2
   uint32_t generic_sticky = 1, jobs_sticky = 1;  // batches the two hints stay on after the last batch that needed them
   uint64_t jobs_big_hint = 0;    // repeat-rich strings (workgroup locate jobs) of the previous batch
   uint64_t fused_leaves_hint = 0;  // occurring strings the previous distance-1 batch held in k_search1s' LDS lists (+ generic leaves)

@@ -222,7 +222,9 @@ typedef struct {
   double t_search_begin_ms, t_search_end_ms;
   uint32_t t_base_gen;
   uint32_t flat_kernel_form; /* measurement: the flat search kernel this batch ran — 0 none (general k_search only), 1 k_search1p, 2 k_search1s<.,
-                              * false> (select stage inside), 3 k_search1s<., true> (select and take inside), 4 k_search2p<false>, 5 k_search2p<true> */
+                              * false> (select stage inside), 3 k_search1s<., true> (select and take inside), 4 k_search2p<false, false>, 5 k_search2p<true, false>,
+                              * 6 k_search2p<false, true>, 7 k_search2p<true, true> (second template argument: the r05 body for batches
+                              * whose shortest strings still ask the long filter) */
   /* ABI 6: what a gather over RCCL needs (include/dicey_gather.h).  stream: the hipStream_t the batch ran on — the handle's own, or
    * the internal lane's for a dg_hunt_submit / dg_hunt_device_submit batch; a device-side copy out of the result's device buffers
    * queued on it is ordered before that lane's next batch, with no host synchronisation.  Compact results: d_block is the batch's

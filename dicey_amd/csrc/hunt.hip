@@ -877,7 +877,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         fs.nsel = nsel;
         // (tests: DICEY_FUSED_LCAP lowers the list's capacity so that ordinary groups exercise the hand-over to the generic select kernels)
         const u32 lcap2 = sw.fused_lcap ? std::max<u32>(1u, std::min<u32>(FUSED2_LCAP, sw.fused_lcap)) : FUSED2_LCAP;
-        const u32 ham2 = indel ? 0u : 1u;
+        const u32 ham2 = (indel ? 0u : 1u) | (sw.exp_bits << 8);  // (DICEY_EXP: k_search2p's measurement switches)
         if (fused && long2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true, true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
         else if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<true, false>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);
         else if (long2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search2p<false, true>), dim3((u32)ngrp), dim3(TB), 0, st, ix->view, b, so, filt_ok, fs, lcap2, ham2);

@@ -2,6 +2,8 @@
 // (k_search1p, k_search1s with the select stage inside), the flat edit-distance-2 kernel (k_search2p), the general walker (k_search)
 // and the explicit-pattern search of capped neighbourhoods (k_explicit).  neighbors.h:29-92 + hunter.h:353.
 #pragma once
+#include <type_traits>
+
 #include "hunt_internal.hpp"
 #include "iupac.hpp"
 
@@ -1030,6 +1032,18 @@ DG_DEV void apply_edit_h(bool ham, u64 pk, u32 len, u32 pos, u32 op, u64& out, u
   } else apply_edit(pk, len, pos, op, out, olen, word);
 }
 
+// The edited string alone (no operation word), the three kinds in one expression: the characters right of the position stay, the ones
+// left of it move by the kind's length change, a substituted / inserted character goes in between ("none" = the old character back).
+DG_DEV u64 edit_string(bool ham, u64 pk, u32 len, u32 pos, u32 op, u32& olen) {
+  const u32 R2 = 2 * (len - pos);
+  const bool del = op == 0 && !ham, ins = op >= 4;
+  const u32 old = (u32)(pk >> R2) & 3u;
+  const u32 c = ins ? op - 4 : (old + op) & 3u;  // (Hamming, op 0: the old character)
+  const u64 left = pk >> (ins ? R2 : R2 + 2);
+  olen = del ? len - 1 : ins ? len + 1 : len;
+  return (pk & ((1ULL << R2) - 1)) | (del ? 0ULL : (u64)c << R2) | (left << (del ? R2 : R2 + 2));
+}
+
 // (the lane-per-operation-pair kernel described above — k_search2<U>, r02: 17.4 ms — was removed in r04; k_search2p below is the
 // same enumeration with one lane per pair of POSITIONS)
 
@@ -1049,7 +1063,6 @@ DG_DEV void pair_of(u32 w, u32 m, u32& p2, u32& p1) {  // rows p2 = 1, 2, ... ho
   p2 = (u32)a + 1;
   p1 = p2 + (w - (u32)a * (2 * m + 1 - (u32)a) / 2);
 }
-static constexpr u32 LONG2_RB = 2;  // first operations whose probes are in flight together (k_search2p<., true>): 16 loads per wait
 DG_DEV u32 pair_rows4_count(u32 m) {
   u32 n = 0;
   for (u32 p2 = 1; p2 < m; ++p2) n += (m - p2 + 4) & ~3u;
@@ -1081,8 +1094,9 @@ static constexpr u32 FUSED2_HCAP = 1024;  // hash slots of the select stage (dis
 // the body) instead of a string built per probe.  !LONG2 is the r04 body: batches that hold shorter queries (the handle remembers).
 // Two instantiations, not a runtime branch: with both bodies in one kernel 13 registers of the common path went to scratch.
 template <bool SEL, bool LONG2>
-__global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2, u32 hamming) {
-  const bool ham = hamming != 0;  // substitutions only; strings with 0, 1 and 2 of them (r05: Hamming distance 2 used to walk k_search<false, 2>, 3.6 x slower per query than the edit form here)
+__global__ void __launch_bounds__(256, LONG2 ? 6 : 5) k_search2p(FmView f, Batch b, SearchOut o, u32 filt_ok, FlatSel fs, u32 lcap2, u32 hamming) {
+  const u32 expb = hamming >> 8;  // DICEY_EXP (measurement aid, wrong results): 1 = no dense phase, 2 = no head-window probe
+  const bool ham = (hamming & 1u) != 0;  // substitutions only; strings with 0, 1 and 2 of them (r05: Hamming distance 2 used to walk k_search<false, 2>, 3.6 x slower per query than the edit form here)
   // Survivors of a pass are kept as one 64-bit mask per lane (bit 8*op1 + op2) instead of a queue of entries: 3 KB of LDS
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
   // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
@@ -1090,6 +1104,9 @@ __global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOu
   __shared__ unsigned long long q_mask[256];
   __shared__ u32 q_ex[256 + 1];  // exclusive prefix of the lanes' survivor counts, [256] = total
   __shared__ u32 q_wave[4];
+  __shared__ u16 q_pair[256];   // the lanes' (p1 | p2 << 8) of the pass: the dense phase rebuilds other lanes' survivors
+  __shared__ u16 q_cand[512];   // survivors whose head window occurs as well (lane | operation pair << 8), for the dense phase's second stage
+  __shared__ u32 q_wc[2][4];    // the wavefronts' counts of them, by the parity of the first stage's round
   __shared__ u32 g_slots;
   constexpr u32 LN = SEL ? FUSED2_LCAP : 1u;
   __shared__ u64 l_key[LN];
@@ -1117,6 +1134,7 @@ __global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOu
       if (w < npairs) {
         u32 p1, p2;
         pair_of(w, m, p2, p1);
+        q_pair[threadIdx.x] = (u16)(p1 | (p2 << 8));
         const u32 R1 = m - p1;
         const KfCopy c2 = kf_copy(f.kf2, R1 < K2 ? R1 : (K2 ? K2 - 1 : 0u));
         const KfCopy c1 = kf_copy(f.kf, R1 < K ? R1 : K - 1);
@@ -1129,9 +1147,9 @@ __global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOu
           // character's bits | second character's bits, and so is its place in the lane's copy of the filter (a permutation of the code's
           // bits, filt_pos).  Nine base places per lane — (deletion, substitution, insertion) x the same for the second edit — and the
           // images of the two code bits of four character slots; a probe's word offset and bit number are then one three-way OR each.
-          // ~85 vector instructions per round of eight probes, loads and bit tests included (the r04 body: ~310).  The rounds go LONG2_RB at
-          // a time: 8 * LONG2_RB loads back to back before the first word is looked at.  With the wavefront scan on data-parallel
-          // primitives and the statistics in LDS the kernel fits 80 registers: six wavefronts per SIMD (r04: five, r03: four).
+          // ~85 vector instructions per eight probes, loads and bit tests included (the r04 body: ~310); 8 - 16 loads back to back before
+          // the first word is looked at (`batch` below).  With the wavefront scan on data-parallel primitives and the statistics in LDS
+          // the kernel fits 80 registers: six wavefronts per SIMD (r04: five, r03: four).
           // Measured and not kept (tools/r05_call10.sh, r05_variants.sh): the rounds as a two-deep software pipeline (spills at 96
           // registers), rows of pairs padded to quads of lanes (same number of vector-cache look-ups), seven wavefronts (8-12 B of scratch).
           const u32 s = c2.s;
@@ -1178,19 +1196,21 @@ __global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOu
             kd.bits[1] = (pi.bit * 0x01010101u) | (ib[0] << 8) | (ib[1] << 16) | ((ib[0] | ib[1]) << 24);
             return kd;
           };
-          Kind kd[3];
-          kd[0] = kind(0);
-          kd[1] = kind(1);
-#pragma unroll
-          for (u32 g1 = 0; g1 < 8; g1 += LONG2_RB) {
-            if (g1 == 4) kd[2] = kind(2);  // (LONG2_RB divides 4: a group never mixes substitutions and insertions)
-            u32 off[LONG2_RB][8], bitn[LONG2_RB][2], valid[LONG2_RB];
+          // Five batches of probes, each N1 first operations of ONE shape x NQ second operations: first operations of one shape differ
+          // in a character whose code bits lie inside the lane's in-line field, so a batch asks for NQ lines, N1 times each back to
+          // back — and no line is asked for in two batches.  (By rounds of one first operation x eight second ones, the lines of the
+          // substitution rounds and of the insertion rounds came round two and four times with other wavefronts' lines in between:
+          // 120 M of a launch's 277 M requests were L2 hits on lines the vector cache had held a moment before.)  One shape per batch
+          // also means one Kind alive at a time.
+          auto batch = [&](const Kind& kk, auto G1, auto N1, auto Q0, auto NQ) {
+            constexpr u32 g1 = decltype(G1)::value, n1 = decltype(N1)::value, q0 = decltype(Q0)::value, nq = decltype(NQ)::value;
+            constexpr u32 k1 = g1 == 0 ? 0u : g1 >= 4 ? 2u : 1u;
+            constexpr bool ins1 = k1 == 2;
+            u32 off[n1][nq], bitn[n1][2], valid[n1];
             bool any = false;
 #pragma unroll
-            for (u32 h = 0; h < LONG2_RB; ++h) {
+            for (u32 h = 0; h < n1; ++h) {
               const u32 op1 = g1 + h;
-              const bool ins1 = op1 >= 4;
-              const u32 k1 = op1 == 0 ? 0u : ins1 ? 2u : 1u;
               bool v1 = (p1 > p2 || ins1) && !(p1 == m && ins1);
               if (op1 == 0) v1 = v1 && qb != qa;
               if (ins1) v1 = v1 && !(p1 >= 2 && qa == op1 - 4 && p2 + 2 <= p1);
@@ -1198,10 +1218,10 @@ __global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOu
               const u32 posp = ins1 ? p1 : p1 - 1;
               const u32 c1 = k1 == 1 ? (qa + op1) & 3u : k1 == 2 ? op1 - 4 : 0u;
               const u32 i1o = img_of(c1, e1o), i1b = img_of(c1, e1b) * 0x01010101u;
-              const Kind& kk = kd[k1];
               u32 vm = 0;
 #pragma unroll
-              for (u32 op2 = 0; op2 < 8; ++op2) {
+              for (u32 q = 0; q < nq; ++q) {
+                const u32 op2 = q0 + q;
                 bool v2 = true;
                 if (op2 == 0) v2 = !(p2 < posp && q2b == q2a);
                 if (op2 >= 4) v2 = !(p2 >= 2 && q2a == op2 - 4);
@@ -1209,33 +1229,48 @@ __global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOu
                 v2 = v2 && v1;
                 const u32 k2 = op2 == 0 ? 0u : op2 < 4 ? 1u : 2u;
                 const u32 i2o = k2 == 1 ? kk.so[op2] : k2 == 2 ? img_of(op2 - 4, kk.io) : 0u;
-                off[h][op2] = kk.boff[k2] | i1o | i2o;
-                vm |= (u32)v2 << op2;
+                off[h][q] = kk.boff[k2] | i1o | i2o;
+                vm |= (u32)v2 << q;
               }
-              bitn[h][0] = kk.bits[0] | i1b;
-              bitn[h][1] = kk.bits[1] | i1b;
+              bitn[h][0] = kk.bits[q0 >> 2] | i1b;
+              bitn[h][1] = kk.bits[1] | i1b;  // (second half: batches of eight second operations only)
               valid[h] = vm;
               any = any || v1;
             }
             if (any) {
-              u32 word[LONG2_RB][8];
+              u32 word[n1][nq];
 #pragma unroll
-              for (u32 h = 0; h < LONG2_RB; ++h)
+              for (u32 q = 0; q < nq; ++q)  // (a line's probes next to each other)
 #pragma unroll
-                for (u32 k = 0; k < 8; ++k) {  // lanes without a probe do not load (reading their copy's first word instead: a quarter more look-ups in the vector cache)
-                  word[h][k] = 0;
-                  if ((valid[h] >> k) & 1u) word[h][k] = c2.base[off[h][k]];
+                for (u32 h = 0; h < n1; ++h) {  // lanes without a probe do not load (reading their copy's first word instead: a quarter more look-ups in the vector cache)
+                  word[h][q] = 0;
+                  if ((valid[h] >> q) & 1u) word[h][q] = c2.base[off[h][q]];
                 }
 #pragma unroll
-              for (u32 h = 0; h < LONG2_RB; ++h) {
-                u32 mask8 = 0;
+              for (u32 h = 0; h < n1; ++h) {
+                u32 maskq = 0;
 #pragma unroll
-                for (u32 k = 0; k < 8; ++k) mask8 |= ((word[h][k] >> ((bitn[h][k >> 2] >> (8 * (k & 3u))) & 31u)) & 1u) << k;
-                mask8 &= valid[h];
+                for (u32 q = 0; q < nq; ++q) maskq |= ((word[h][q] >> ((bitn[h][q >> 2] >> (8 * (q & 3u))) & 31u)) & 1u) << q;
+                maskq &= valid[h];
                 nprobe += (u32)__popc(valid[h]);
-                surv |= (u64)mask8 << (8 * (g1 + h));
+                surv |= (u64)maskq << (8 * (g1 + h) + q0);
               }
             }
+          };
+          using std::integral_constant;
+          {
+            const Kind kd = kind(0);
+            batch(kd, integral_constant<u32, 0>{}, integral_constant<u32, 1>{}, integral_constant<u32, 0>{}, integral_constant<u32, 8>{});
+          }
+          {
+            const Kind kd = kind(1);
+            batch(kd, integral_constant<u32, 1>{}, integral_constant<u32, 3>{}, integral_constant<u32, 0>{}, integral_constant<u32, 4>{});
+            batch(kd, integral_constant<u32, 1>{}, integral_constant<u32, 3>{}, integral_constant<u32, 4>{}, integral_constant<u32, 4>{});
+          }
+          if (!ham) {  // (uniform) no insertions in Hamming mode
+            const Kind kd = kind(2);
+            batch(kd, integral_constant<u32, 4>{}, integral_constant<u32, 4>{}, integral_constant<u32, 0>{}, integral_constant<u32, 4>{});
+            batch(kd, integral_constant<u32, 4>{}, integral_constant<u32, 4>{}, integral_constant<u32, 4>{}, integral_constant<u32, 4>{});
           }
         } else {
 #pragma unroll
@@ -1306,14 +1341,19 @@ __global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOu
       u32 before = 0;
       for (u32 k = 0; k < (threadIdx.x >> 6); ++k) before += q_wave[k];
       q_ex[threadIdx.x] = before + incl - mine;
-      const u32 qn = q_wave[0] + q_wave[1] + q_wave[2] + q_wave[3];
+      const u32 qn = (expb & 1u) ? 0u : q_wave[0] + q_wave[1] + q_wave[2] + q_wave[3];
       __syncthreads();
-      for (u32 e0 = 0; e0 < qn; e0 += 256) {
-        if (e0 + (threadIdx.x & ~63u) >= qn) break;  // wavefront without work
+      // Dense phase in two stages (r05).  Five of six survivors of the end-window probes die on the first look — the head window
+      // (the first K2 characters must occur as well) — and everything after it (table entry, preceding-characters line or Occ steps,
+      // the leaf) used to run with every sixth lane alive.  Stage 1 rebuilds a survivor's string and asks the head window only; the ones
+      // that pass are queued in LDS (two bytes each) and stage 2 runs over the queue with whole wavefronts, once 256 are waiting or the
+      // pass ends.  (Counts per wavefront through q_wc instead of an atomic: the decision to run stage 2 must be the same in every
+      // wavefront.)
+      u32 have = 0;  // queued survivors (uniform)
+      for (u32 e0 = 0, round = 0; e0 < qn; e0 += 256, ++round) {
         const u32 e = e0 + threadIdx.x;
-        bool leaf = false;
-        u32 lo = 0, hi = 0, w1 = 0, w2 = 0, fword = 0, len2 = 0, pre_first = 0xFFFFFFFFu;
-        u64 key2 = 0;
+        bool pass = false;
+        u32 ent = 0;
         if (e < qn) {
           // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
           u32 L = 0;
@@ -1323,88 +1363,117 @@ __global__ void __launch_bounds__(256, 6) k_search2p(FmView f, Batch b, SearchOu
           unsigned long long mk = q_mask[L];
           for (u32 r = e - q_ex[L]; r > 0; --r) mk &= mk - 1;
           const u32 bitno = (u32)__ffsll((long long)mk) - 1u;
-          u32 p1, p2, l1, l2;
-          u64 s1, s2;
-          pair_of(w0 + L, m, p2, p1);
-          apply_edit_h(ham, qpk, m, p1, bitno >> 3, s1, l1, w1);
-          apply_edit_h(ham, s1, l1, p2, bitno & 7u, s2, l2, w2);
-          key2 = s2;
-          len2 = l2;
+          const u32 pp = q_pair[L], p1 = pp & 255u, p2 = pp >> 8;
+          u32 l1, l2;
+          const u64 s1 = edit_string(ham, qpk, m, p1, bitno >> 3, l1);
+          const u64 s2 = edit_string(ham, s1, l1, p2, bitno & 7u, l2);
           nprobe += (K2 && l2 > K2);
-          if (head_window_occurs(f, s2, l2, l1 - p2)) {
+          pass = (expb & 2u) || head_window_occurs(f, s2, l2, l1 - p2);
+          ent = L | (bitno << 8);
+        }
+        const unsigned long long pm = __ballot(pass);
+        if (lane == 0) q_wc[round & 1u][threadIdx.x >> 6] = (u32)__popcll(pm);
+        __syncthreads();
+        u32 at = have, all = have;
+        for (u32 k = 0; k < 4; ++k) {
+          const u32 c = q_wc[round & 1u][k];
+          if (k < (threadIdx.x >> 6)) at += c;
+          all += c;
+        }
+        if (pass) q_cand[at + (u32)__popcll(pm & ((1ULL << lane) - 1))] = (u16)ent;  // (have < 256 here: at most 512 queued)
+        have = all;
+        if (have < 256 && e0 + 256 < qn) continue;
+        __syncthreads();
+        for (u32 t0 = 0; t0 < have; t0 += 256) {
+          if (t0 + (threadIdx.x & ~63u) >= have) break;  // wavefront without work
+          const u32 t = t0 + threadIdx.x;
+          bool leaf = false;
+          u32 lo = 0, hi = 0, w1 = 0, w2 = 0, fword = 0, len2 = 0, pre_first = 0xFFFFFFFFu;
+          u64 key2 = 0;
+          if (t < have) {
+            const u32 ce = q_cand[t], L = ce & 255u, bitno = ce >> 8;
+            const u32 pp = q_pair[L], p1 = pp & 255u, p2 = pp >> 8;
+            u32 l1, l2;
+            u64 s1, s2;
+            apply_edit_h(ham, qpk, m, p1, bitno >> 3, s1, l1, w1);
+            apply_edit_h(ham, s1, l1, p2, bitno & 7u, s2, l2, w2);
+            key2 = s2;
+            len2 = l2;
             const KtabEntry iv = ktab_entry(f, s2 & kmask);
             ++nlook;
             lo = iv.lo;
             hi = iv.hi;
             pre_first = iv.pre_first;
-          }
-          u64 rs = s2 >> (2 * K);
-          u32 nr = l2 - K;
-          // filtered interval (FmView::pre5, see k_search1s): a narrow table interval is settled with one line of the preceding-characters
-          // array instead of l2 - K dependent Occ lines; the leaf then carries (interval of its last K characters, mask, l2 - K) in ops[2]
-          if (filt_ok && (!ham || to_lds) && f.pre5 && nr >= 1 && nr <= 5 && lo < hi && hi - lo <= 16) {  // (Hamming leaves with fewer than two operations carry no filter word)
-            const u32 w = hi - lo;
-            u32 want = 0, fm = 0;
-            for (u32 k2 = 0; k2 < nr; ++k2) want |= ((u32)(rs >> (2 * k2)) & 3u) << (3 * k2);
-            const u32 wmask = (1u << (3 * nr)) - 1u;
-            if (w == 1 && pre_first != 0xFFFFFFFFu) fm = (u32)((pre_first & wmask) == want);  // (r05: from the table entry, see k_search1s)
-            else {
-              u32 ent16[16];
+            u64 rs = s2 >> (2 * K);
+            u32 nr = l2 - K;
+            // filtered interval (FmView::pre5, see k_search1s): a narrow table interval is settled with one line of the preceding-characters
+            // array instead of l2 - K dependent Occ lines; the leaf then carries (interval of its last K characters, mask, l2 - K) in ops[2]
+            if (filt_ok && (!ham || to_lds) && f.pre5 && nr >= 1 && nr <= 5 && lo < hi && hi - lo <= 16) {  // (Hamming leaves with fewer than two operations carry no filter word)
+              const u32 w = hi - lo;
+              u32 want = 0, fm = 0;
+              for (u32 k2 = 0; k2 < nr; ++k2) want |= ((u32)(rs >> (2 * k2)) & 3u) << (3 * k2);
+              const u32 wmask = (1u << (3 * nr)) - 1u;
+              if (w == 1 && pre_first != 0xFFFFFFFFu) fm = (u32)((pre_first & wmask) == want);  // (r05: from the table entry, see k_search1s)
+              else {
+                u32 ent16[16];
 #pragma unroll
-              for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
+                for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
 #pragma unroll
-              for (u32 j = 0; j < 16; ++j) fm |= (u32)((ent16[j] & wmask) == want && j < w) << j;
-              ++nlook;
+                for (u32 j = 0; j < 16; ++j) fm |= (u32)((ent16[j] & wmask) == want && j < w) << j;
+                ++nlook;
+              }
+              fword = fm | (nr << 16) | (1u << 31);
+              nr = 0;
+              if (!fm) lo = hi = 0;
             }
-            fword = fm | (nr << 16) | (1u << 31);
-            nr = 0;
-            if (!fm) lo = hi = 0;
+            while (nr && lo < hi) {
+              bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
+              rs >>= 2;
+              --nr;
+              ++steps;
+            }
+            leaf = lo < hi;
           }
-          while (nr && lo < hi) {
-            bs_extend_code_narrow(f, lo, hi, (u32)rs & 3u);
-            rs >>= 2;
-            --nr;
-            ++steps;
+          if (SEL && to_lds) {  // the string itself (2 bits per character: s2 of l2 <= 32 characters), its interval, its filter word
+            if (leaf) {
+              const u32 la = atomicAdd(&l_n, 1u);
+              if (la < FUSED2_LCAP) {
+                l_key[la] = key2;
+                l_lo[la] = lo;
+                l_hi[la] = hi;
+                l_fw[la] = fword;
+                l_meta[la] = (u16)len2;
+                l_rank[la] = 0u;
+              }
+            }
+            continue;
           }
-          leaf = lo < hi;
-        }
-        if (SEL && to_lds) {  // the string itself (2 bits per character: s2 of l2 <= 32 characters), its interval, its filter word
+          const unsigned long long lm = __ballot(leaf);
+          u32 lbase = 0;
+          if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
+          lbase = __shfl(lbase, 0);
           if (leaf) {
-            const u32 at = atomicAdd(&l_n, 1u);
-            if (at < FUSED2_LCAP) {
-              l_key[at] = key2;
-              l_lo[at] = lo;
-              l_hi[at] = hi;
-              l_fw[at] = fword;
-              l_meta[at] = (u16)len2;
-              l_rank[at] = 0u;
+            const u32 slot = atomicAdd(&g_slots, 1u);
+            const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
+            if (la < o.shard_cap) {
+              Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
+              lf->qs = gid;
+              lf->slot = slot;
+              lf->lo = lo;
+              lf->hi = hi;
+              // (Hamming: "none" operations are not recorded; the filter word is only read from two-operation leaves, k_group_pack)
+              const u32 nops = (u32)(w1 != OPW_NONE) + (u32)(w2 != OPW_NONE);
+              lf->nops = nops;
+              lf->ops[0] = w1 != OPW_NONE ? w1 : (w2 != OPW_NONE ? w2 : 0u);
+              lf->ops[1] = (w1 != OPW_NONE && w2 != OPW_NONE) ? w2 : 0u;
+              lf->ops[2] = nops == 2 ? fword : 0u;  // 0, or the filtered form: mask | characters in front << 16 | 1 << 31 (k_group_pack hands it on)
+#pragma unroll
+              for (int k = 3; k < (int)DMAX; ++k) lf->ops[k] = 0u;
             }
           }
-          continue;
         }
-        const unsigned long long lm = __ballot(leaf);
-        u32 lbase = 0;
-        if (lane == 0 && lm) lbase = atomicAdd(&o.ctr->leaf_cnt[shard], (u32)__popcll(lm));
-        lbase = __shfl(lbase, 0);
-        if (leaf) {
-          const u32 slot = atomicAdd(&g_slots, 1u);
-          const u32 la = lbase + (u32)__popcll(lm & ((1ULL << lane) - 1));
-          if (la < o.shard_cap) {
-            Leaf* lf = o.leaves + (u64)shard * o.shard_cap + la;
-            lf->qs = gid;
-            lf->slot = slot;
-            lf->lo = lo;
-            lf->hi = hi;
-            // (Hamming: "none" operations are not recorded; the filter word is only read from two-operation leaves, k_group_pack)
-            const u32 nops = (u32)(w1 != OPW_NONE) + (u32)(w2 != OPW_NONE);
-            lf->nops = nops;
-            lf->ops[0] = w1 != OPW_NONE ? w1 : (w2 != OPW_NONE ? w2 : 0u);
-            lf->ops[1] = (w1 != OPW_NONE && w2 != OPW_NONE) ? w2 : 0u;
-            lf->ops[2] = nops == 2 ? fword : 0u;  // 0, or the filtered form: mask | characters in front << 16 | 1 << 31 (k_group_pack hands it on)
-#pragma unroll
-            for (int k = 3; k < (int)DMAX; ++k) lf->ops[k] = 0u;
-          }
-        }
+        have = 0;
+        __syncthreads();  // (the queue is free again)
       }
       if (count) {  // (the wavefront is whole here)
         steps = wave_sum32(steps);

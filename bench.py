@@ -513,7 +513,7 @@ def main():
                     help="testing aid for a 1-GPU box: a process group of ONE rank on the chosen backend, and every hunt step stages and "
                          "gathers its hit list exactly as ranks of an N > 1 job do (the RCCL path: staging on the library's stream, the "
                          "size agreement, the gather) — n_gpus stays 1")
-    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3),
+    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3, 4, 5, 6, 7, 8),
                     help="hunt configs: batches in flight per GPU in the timed region: 2 or 3 = dg_hunt_device_submit / dg_hunt_wait on the handle's "
                          "lanes (step k is submitted, step k - n + 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a)")
     ap.add_argument("--batches", type=int, default=16,

@@ -64,8 +64,12 @@ struct dg_index {
   std::mutex lanes_mu;                // guards the lazy creation of lanes[] / shared_hints / a lane's worker (concurrent submitters)
   // ABI 5: dg_hunt_submit keeps several batches in flight on one handle; a submission that finds the handle busy runs on an internal
   // lane (a shared handle: own stream, workspaces, helper thread; created at the first need, closed with the handle)
-  static constexpr int NEXTRA = 2;            // internal lanes beside the handle itself: three batches in flight (a fourth lane was measured in r05: 496 against 505 M primers/s)
-  dg_index* lanes[NEXTRA] = {nullptr, nullptr};
+#ifndef DG_NEXTRA
+#define DG_NEXTRA 2
+#endif
+  static constexpr int NEXTRA = DG_NEXTRA;    // internal lanes beside the handle itself: 1 + NEXTRA batches in flight.  r05, same box (tools/r05_call13.sh): 3 in flight
+                                              // 0.178-0.184 ms per step at distance 1, 4: 0.193-0.195, 5: 0.186, 6: 0.181; distance 2: 6.14-6.61 / 6.34-6.68 / - / 6.05-6.31
+  dg_index* lanes[NEXTRA] = {};
   // The lanes learn together (r04): capacities and kernel-family hints live per lane (each lane's batches read and write its own
   // without locks), and a lane merges the pair's common record in when a batch starts and writes its own back when it ends — a
   // lane that runs its first batch does not repeat it for a capacity another lane has already learnt.

@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -18,6 +20,38 @@
 using namespace dg;
 
 namespace {
+
+// Host threads for the per-position loops (r05: 2.7 M positions of 1 000 genes spent 0.12 of a 0.35 s step in single-threaded loops
+// around the GPU stages): DICEY_HOST_THREADS, else up to 16.
+unsigned scan_threads() {
+  static const unsigned n = [] {
+    const char* e = std::getenv("DICEY_HOST_THREADS");
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const long v = e ? std::atol(e) : (long)std::min(16u, hw);
+    return (unsigned)std::max(1L, std::min(v, 256L));
+  }();
+  return n;
+}
+// f(chunk, begin, end) over [0, n) in nt contiguous chunks with the given boundaries (cut[0] = 0 .. cut[nt] = n)
+template <class F>
+void run_chunks(const std::vector<size_t>& cut, F f) {
+  const size_t nt = cut.size() - 1;
+  if (nt <= 1) {
+    f((size_t)0, cut.front(), cut.back());
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (size_t t = 0; t < nt; ++t)
+    if (cut[t] < cut[t + 1]) th.emplace_back([&f, &cut, t] { f(t, cut[t], cut[t + 1]); });
+  for (auto& x : th) x.join();
+}
+std::vector<size_t> even_cuts(size_t n, unsigned nt, size_t grain) {
+  const size_t parts = std::max<size_t>(1, std::min<size_t>(nt, n / std::max<size_t>(1, grain)));
+  std::vector<size_t> cut(parts + 1);
+  for (size_t t = 0; t <= parts; ++t) cut[t] = n * t / parts;
+  return cut;
+}
 
 }  // namespace
 
@@ -63,11 +97,6 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
   R->probe_tm = new double[npos ? npos : 1];
   R->arm_count = new int64_t[npos ? npos : 1];
   R->arm_nbcount = new int64_t[npos ? npos : 1];
-  for (uint64_t i = 0; i < npos; ++i) {
-    R->arm_tm[i] = R->probe_tm[i] = DG_PADLOCK_NOT_COMPUTED;
-    R->probe_gc[i] = 0;
-    R->arm_count[i] = R->arm_nbcount[i] = -1;
-  }
   static const bool timing = std::getenv("DICEY_TIMING") != nullptr;  // debugging aid: host-side phase times on stderr
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -86,27 +115,23 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     for (uint64_t i = 0; i < n; ++i) buf.push_back(complement_iupac((char)s[n - 1 - i]));
   };
   const uint64_t nbytes = nexons ? exon_off[nexons] : 0;
-  auto thal_pairs = [&](const std::vector<std::pair<uint64_t, uint64_t>>& win /* (byte offset, length) */, std::vector<double>& temps) -> int {
-    temps.assign(win.size(), 0.0);
-    if (win.empty()) return DG_OK;
-    if (win[0].second <= kSelfWindowMax) {  // pairs formed on the device from the exon bytes
-      std::vector<uint64_t> wo(win.size());
-      std::vector<uint32_t> wl(win.size());
-      for (size_t i = 0; i < win.size(); ++i) {
-        wo[i] = win[i].first;
-        wl[i] = (uint32_t)win[i].second;
-      }
-      return thal_self_windows(th, exons, nbytes, wo.data(), wl.data(), win.size(), temps.data());
+  // thal(window, its reverse complement) for windows of ONE length at the given byte offsets
+  auto thal_windows = [&](const std::vector<uint64_t>& wo, uint64_t wlen, std::vector<double>& temps) -> int {
+    temps.assign(wo.size(), 0.0);
+    if (wo.empty()) return DG_OK;
+    if (wlen <= kSelfWindowMax) {  // pairs formed on the device from the exon bytes
+      const std::vector<uint32_t> wl(wo.size(), (uint32_t)wlen);
+      return thal_self_windows(th, exons, nbytes, wo.data(), wl.data(), wo.size(), temps.data());
     }
     std::string buf;
     std::vector<uint64_t> off(1, 0);
-    for (auto& w : win) {
-      buf.append((const char*)exons + w.first, w.second);
+    for (uint64_t w : wo) {
+      buf.append((const char*)exons + w, wlen);
       off.push_back(buf.size());
-      revcomp_into(buf, exons + w.first, w.second);
+      revcomp_into(buf, exons + w, wlen);
       off.push_back(buf.size());
     }
-    return dg_thal_batch(th, (const uint8_t*)buf.data(), off.data(), win.size(), temps.data(), nullptr, nullptr);
+    return dg_thal_batch(th, (const uint8_t*)buf.data(), off.data(), wo.size(), temps.data(), nullptr, nullptr);
   };
   // gccontent() of any window from running counts: G/C so far, and N/n so far (a window with an N scores -1)
   std::vector<uint32_t> gcs(nbytes + 1, 0), nns(nbytes + 1, 0);
@@ -119,49 +144,114 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     if (nns[at + n] != nns[at]) return -1;
     return (double)(gcs[at + n] - gcs[at]) / (double)n;
   };
-  // stage 1: GC of every arm window; thal(arm, reverse complement) where the GC filter lets it through (padlock.h:323-345)
-  std::vector<std::pair<uint64_t, uint64_t>> win;
-  std::vector<uint64_t> where;
-  for (size_t e = 0; e < nexons; ++e) {
-    const uint64_t b0 = exon_off[e], len = exon_off[e + 1] - b0;
-    if (len < T) continue;
-    for (uint64_t q = 0; q + L <= len; ++q) {
-      const uint64_t at = R->pos_off[e] + q;
-      R->arm_gc[at] = gc_of(b0 + q, L);
-      if (R->arm_gc[at] < minGC || R->arm_gc[at] > maxGC) continue;
-      win.emplace_back(b0 + q, L);
-      where.push_back(at);
+  // exons in contiguous chunks of about equal numbers of positions, one host thread each (r05); a stage is two passes over a
+  // chunk — count the windows it sends to the GPU, then write them at the chunk's place of the common list: the lists come out in
+  // exon order whatever the number of threads
+  std::vector<size_t> ecut(1, 0);
+  {
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(scan_threads(), npos / 65536));
+    for (unsigned t = 1; t < nt; ++t) {
+      const uint64_t want = npos * t / nt;
+      const size_t e = (size_t)(std::upper_bound(R->pos_off, R->pos_off + nexons + 1, want) - R->pos_off) - 1;
+      ecut.push_back(std::max(ecut.back(), std::min(e, nexons)));
     }
+    ecut.push_back(nexons);
   }
+  const size_t nchunks = ecut.size() - 1;
+  std::vector<uint64_t> cnt(nchunks + 1, 0);
+  auto place = [&](std::vector<uint64_t>& wo, std::vector<uint64_t>& where) {  // counts per chunk -> first slots, lists sized
+    uint64_t total = 0;
+    for (size_t c = 0; c < nchunks; ++c) {
+      const uint64_t n = cnt[c];
+      cnt[c] = total;
+      total += n;
+    }
+    cnt[nchunks] = total;
+    wo.resize(total);
+    where.resize(total);
+  };
+  // stage 1: GC of every arm window; thal(arm, reverse complement) where the GC filter lets it through (padlock.h:323-345)
+  std::vector<uint64_t> wo, where;
+  run_chunks(ecut, [&](size_t c, size_t e0, size_t e1) {
+    uint64_t n = 0;
+    for (size_t e = e0; e < e1; ++e) {
+      const uint64_t b0 = exon_off[e], len = exon_off[e + 1] - b0;
+      if (len < T) continue;
+      for (uint64_t q = 0; q + L <= len; ++q) {
+        const uint64_t at = R->pos_off[e] + q;
+        const double gc = gc_of(b0 + q, L);
+        R->arm_gc[at] = gc;
+        R->arm_tm[at] = R->probe_tm[at] = DG_PADLOCK_NOT_COMPUTED;
+        R->probe_gc[at] = 0;
+        R->arm_count[at] = R->arm_nbcount[at] = -1;
+        n += !(gc < minGC || gc > maxGC);
+      }
+    }
+    cnt[c] = n;
+  });
+  place(wo, where);
+  run_chunks(ecut, [&](size_t c, size_t e0, size_t e1) {
+    uint64_t k = cnt[c];
+    for (size_t e = e0; e < e1; ++e) {
+      const uint64_t b0 = exon_off[e], len = exon_off[e + 1] - b0;
+      if (len < T) continue;
+      for (uint64_t q = 0; q + L <= len; ++q) {
+        const uint64_t at = R->pos_off[e] + q;
+        if (R->arm_gc[at] < minGC || R->arm_gc[at] > maxGC) continue;
+        wo[k] = b0 + q;
+        where[k++] = at;
+      }
+    }
+  });
   lap("arm GC + window list");
   std::vector<double> temps;
-  int rc = thal_pairs(win, temps);
+  int rc = thal_windows(wo, L, temps);
   lap("arm thal (pack + GPU)");
   if (rc != DG_OK) return fail_with(rc);
-  for (size_t i = 0; i < where.size(); ++i) R->arm_tm[where[i]] = temps[i];
+  const uint64_t n_arm_thal = where.size();
+  run_chunks(even_cuts(where.size(), scan_threads(), 65536), [&](size_t, size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) R->arm_tm[where[i]] = temps[i];
+  });
   // stage 2: probes whose two arms pass GC, Tm ceiling and Tm difference (padlock.h:327-362)
-  win.clear();
-  where.clear();
   auto arm_ok = [&](uint64_t at) {
     const double gc = R->arm_gc[at];
     if (gc < minGC || gc > maxGC) return false;
     return !(R->arm_tm[at] > 93 + gc - 675.0 / (double)p->armlen);  // a refused thal (-999999) is the caller's error path
   };
-  for (size_t e = 0; e < nexons; ++e) {
-    const uint64_t b0 = exon_off[e], len = exon_off[e + 1] - b0;
-    if (len < T) continue;
-    for (uint64_t k = 0; k + T <= len; ++k) {
-      const uint64_t at = R->pos_off[e] + k;
-      R->probe_gc[at] = gc_of(b0 + k, T);
-      if (!arm_ok(at) || !arm_ok(at + L)) continue;
-      if (std::abs(R->arm_tm[at] - R->arm_tm[at + L]) > (double)p->tmdiff) continue;
-      if (R->probe_gc[at] < minGC || R->probe_gc[at] > maxGC) continue;
-      win.emplace_back(b0 + k, T);
-      where.push_back(at);
+  auto probe_goes = [&](uint64_t at) {  // (probe_gc[at] is written by the first pass)
+    if (!arm_ok(at) || !arm_ok(at + L)) return false;
+    if (std::abs(R->arm_tm[at] - R->arm_tm[at + L]) > (double)p->tmdiff) return false;
+    return !(R->probe_gc[at] < minGC || R->probe_gc[at] > maxGC);
+  };
+  run_chunks(ecut, [&](size_t c, size_t e0, size_t e1) {
+    uint64_t n = 0;
+    for (size_t e = e0; e < e1; ++e) {
+      const uint64_t b0 = exon_off[e], len = exon_off[e + 1] - b0;
+      if (len < T) continue;
+      for (uint64_t k = 0; k + T <= len; ++k) {
+        const uint64_t at = R->pos_off[e] + k;
+        R->probe_gc[at] = gc_of(b0 + k, T);
+        n += probe_goes(at);
+      }
     }
-  }
+    cnt[c] = n;
+  });
+  place(wo, where);
+  run_chunks(ecut, [&](size_t c, size_t e0, size_t e1) {
+    uint64_t j = cnt[c];
+    for (size_t e = e0; e < e1; ++e) {
+      const uint64_t b0 = exon_off[e], len = exon_off[e + 1] - b0;
+      if (len < T) continue;
+      for (uint64_t k = 0; k + T <= len; ++k) {
+        const uint64_t at = R->pos_off[e] + k;
+        if (!probe_goes(at)) continue;
+        wo[j] = b0 + k;
+        where[j++] = at;
+      }
+    }
+  });
   lap("probe GC + window list");
-  rc = thal_pairs(win, temps);
+  rc = thal_windows(wo, T, temps);
   if (rc != DG_OK) return fail_with(rc);
   for (size_t i = 0; i < where.size(); ++i) R->probe_tm[where[i]] = temps[i];
   lap("probe thal (pack + GPU)");
@@ -174,30 +264,40 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     for (uint64_t a : {at, at + L})
       if (R->arm_count[a] == -1) {
         R->arm_count[a] = -2;  // queued
-        arms.emplace_back(win[i].first + (a - at), a);
+        arms.emplace_back(wo[i] + (a - at), a);
       }
   }
   if (!arms.empty()) {
-    std::string buf;
-    std::vector<uint64_t> off(1, 0);
-    for (auto& a : arms) {
-      buf.append((const char*)exons + a.first, L);
-      off.push_back(buf.size());
-      revcomp_into(buf, exons + a.first, L);
-      off.push_back(buf.size());
-    }
-    std::vector<uint64_t> cnt(2 * arms.size());
-    rc = dg_count(ix, (const uint8_t*)buf.data(), off.data(), 2 * arms.size(), cnt.data());
+    // (every record is L bytes: arm and reverse complement side by side, written by the host threads)
+    std::string buf(2 * L * arms.size(), '\0');
+    std::vector<uint64_t> off(2 * arms.size() + 1);
+    const std::vector<size_t> acut = even_cuts(arms.size(), scan_threads(), 16384);
+    run_chunks(acut, [&](size_t, size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; ++i) {
+        const uint8_t* src = exons + arms[i].first;
+        char* dst = &buf[2 * L * i];
+        std::memcpy(dst, src, L);
+        for (uint64_t k = 0; k < L; ++k) dst[L + k] = complement_iupac((char)src[L - 1 - k]);
+        off[2 * i] = 2 * L * i;
+        off[2 * i + 1] = 2 * L * i + L;
+      }
+    });
+    off[2 * arms.size()] = 2 * L * arms.size();
+    std::vector<uint64_t> cnt2(2 * arms.size());
+    rc = dg_count(ix, (const uint8_t*)buf.data(), off.data(), 2 * arms.size(), cnt2.data());
     if (rc != DG_OK) return fail_with(rc);
-    for (size_t i = 0; i < arms.size(); ++i) R->arm_count[arms[i].second] = (int64_t)(cnt[2 * i] + cnt[2 * i + 1]);
+    for (size_t i = 0; i < arms.size(); ++i) R->arm_count[arms[i].second] = (int64_t)(cnt2[2 * i] + cnt2[2 * i + 1]);
     lap("exact counts");
     if (p->distance > 0) {
-      std::string fbuf;
-      std::vector<uint64_t> foff(1, 0);
-      for (auto& a : arms) {
-        fbuf.append((const char*)exons + a.first, L);
-        foff.push_back(fbuf.size());
-      }
+      std::string fbuf(L * arms.size(), '\0');
+      std::vector<uint64_t> foff(arms.size() + 1);
+      run_chunks(acut, [&](size_t, size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+          std::memcpy(&fbuf[L * i], exons + arms[i].first, L);
+          foff[i] = L * i;
+        }
+      });
+      foff[arms.size()] = L * arms.size();
       std::vector<uint64_t> fw(arms.size()), rv(arms.size());
       rc = dg_neighborhood_count(ix, p->distance, p->hamming, 10000, (const uint8_t*)fbuf.data(), foff.data(), arms.size(), fw.data(), rv.data());
       if (rc != DG_OK) return fail_with(rc);
@@ -205,8 +305,7 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
       lap("neighbourhood counts");
     }
   }
-  R->n_arm_thal = 0;
-  for (uint64_t i = 0; i < npos; ++i) R->n_arm_thal += R->arm_tm[i] != DG_PADLOCK_NOT_COMPUTED;
+  R->n_arm_thal = n_arm_thal;  // (one thal per arm window that passed the GC filter)
   R->n_probe_thal = where.size();
   R->n_arms_counted = arms.size();
   *out = R;

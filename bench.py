@@ -426,7 +426,8 @@ def thal_counter_block(cfg, kernel, thal_calls, stage_ms):
     src = "thal_counters.json"
     try:
         tc = tc[cfg]
-        k = [v for n, v in tc["kernels"].items() if kernel in n][0]
+        ks = [v for n, v in tc["kernels"].items() if kernel in n]  # (every instantiation of the kernel: k_thal_self_wave<true> / <false>)
+        k = {c: sum(v.get(c, 0.0) for v in ks) for c in ks[0]}
         ref_calls = (tc["bench"].get("site_stage") or {}).get("thal_calls_per_step") or \
             (tc["bench"]["arm_thal_per_step"] + tc["bench"]["probe_thal_per_step"])
     except Exception:

@@ -423,7 +423,7 @@ int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSe
       sa.force_redo = force_redo ? 1 : 0;
       const u32 cells = (wmax + 1) * (maxlen + 1);
       if (wave_path) {
-        const u32 lds_total = tab_bytes + wpb * per_wave;
+        const u32 lds_total = thal::wave_lds_total(wpb, per_wave);
         static int cus = 0;
         if (!cus) DG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device));
         DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_site_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));

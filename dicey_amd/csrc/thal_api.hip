@@ -203,16 +203,18 @@ struct WinDesc {
   u64 off;
   u32 len, pad;
 };
+// INSIDE: the end tables inside the parameter tables' LDS copy (thal_wave.hpp) — chosen by the host when it buys a wavefront per CU
+template <bool INSIDE>
 __global__ void __launch_bounds__(1024) k_thal_self_wave(const thal::Tables* T, thal::Env env, const WinDesc* wd, u64 n, const u8* bytes,
                                                         double* temp, u8* redo, u32 lencap, u32 wave_bytes, u32 force_redo) {
   DG_DYNAMIC_LDS(lds_raw);
   thal::Tables* tabs = reinterpret_cast<thal::Tables*>(lds_raw);
-  thal::wave_header_init(lds_raw, T, env);
-  const thal::EndTables& ends = *thal::wave_end_tables(lds_raw);
+  thal::wave_header_init<INSIDE>(lds_raw, T, env);
+  const thal::EndTables& ends = *thal::wave_end_tables<INSIDE>(lds_raw);
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const u32 lane = threadIdx.x & 63;
   const thal::WaveMem wm =
-      thal::wave_mem_at(lds_raw + thal::wave_header_bytes() + (size_t)wave * wave_bytes, lencap, lencap);
+      thal::wave_mem_at(lds_raw + thal::wave_header_bytes<INSIDE>() + (size_t)wave * wave_bytes, lencap, lencap);
   for (u64 t = (u64)blockIdx.x * wpb + wave; t < n; t += (u64)gridDim.x * wpb) {
     const WinDesc d = wd[t];
     const u32 len = d.len;
@@ -383,7 +385,7 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
     const u32 per_wave = thal::wave_mem_bytes(wl1, wl2);
     const u32 lds_cap = 160 * 1024;
     const u32 wpb = std::max<u32>(1, std::min<u32>(16, (lds_cap - tab_bytes) / per_wave));
-    const u32 lds_total = tab_bytes + wpb * per_wave;
+    const u32 lds_total = thal::wave_lds_total(wpb, per_wave);
     int cus = 0;
     DG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, th->device));
     DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_thal_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
@@ -456,18 +458,27 @@ int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, co
     DG_TRY(th->ws[5].reserve(n + 8));
     DG_HIP(hipMemcpyAsync(th->ws[0].p, wd.data(), n * sizeof(WinDesc), hipMemcpyHostToDevice, st));
     DG_HIP(hipMemcpyAsync(th->ws[1].p, bytes, nbytes, hipMemcpyHostToDevice, st));
-    const u32 tab_bytes = thal::wave_header_bytes();
     const u32 per_wave = thal::wave_mem_bytes(maxlen, maxlen);
     const u32 lds_cap = 160 * 1024;
-    const u32 wpb = std::max<u32>(1, std::min<u32>(16, (lds_cap - tab_bytes) / per_wave));
-    const u32 lds_total = tab_bytes + wpb * per_wave;
+    auto waves_with = [&](u32 header) { return std::max<u32>(1, std::min<u32>(16, (lds_cap - header) / per_wave)); };
+    // the end tables inside the parameter tables when that buys a wavefront per CU (40-mers: 7 instead of 6), else where they always were
+    const bool inside = waves_with(thal::wave_header_bytes<true>()) > waves_with(thal::wave_header_bytes<false>());
+    const u32 wpb = waves_with(inside ? thal::wave_header_bytes<true>() : thal::wave_header_bytes<false>());
+    const u32 lds_total = inside ? thal::wave_lds_total<true>(wpb, per_wave) : thal::wave_lds_total<false>(wpb, per_wave);
     int cus = 0;
     DG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, th->device));
-    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_thal_self_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
     const u64 blocks = std::min<u64>(ceil_div(n, wpb), (u64)cus * std::max<u32>(1, lds_cap / lds_total));
-    hipLaunchKernelGGL(k_thal_self_wave, dim3((u32)blocks), dim3(wpb * 64), lds_total, st, (const thal::Tables*)th->d_tables, th->env,
-                       th->ws[0].as<WinDesc>(), (u64)n, th->ws[1].as<u8>(), th->ws[3].as<double>(), th->ws[5].as<u8>(), maxlen, per_wave,
-                       force_redo ? 1u : 0u);
+    if (inside) {
+      DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_thal_self_wave<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_thal_self_wave<true>), dim3((u32)blocks), dim3(wpb * 64), lds_total, st, (const thal::Tables*)th->d_tables, th->env,
+                         th->ws[0].as<WinDesc>(), (u64)n, th->ws[1].as<u8>(), th->ws[3].as<double>(), th->ws[5].as<u8>(), maxlen, per_wave,
+                         force_redo ? 1u : 0u);
+    } else {
+      DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_thal_self_wave<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_thal_self_wave<false>), dim3((u32)blocks), dim3(wpb * 64), lds_total, st, (const thal::Tables*)th->d_tables, th->env,
+                         th->ws[0].as<WinDesc>(), (u64)n, th->ws[1].as<u8>(), th->ws[3].as<double>(), th->ws[5].as<u8>(), maxlen, per_wave,
+                         force_redo ? 1u : 0u);
+    }
     DG_HIP(hipMemcpyAsync(temp, th->ws[3].p, n * 8, hipMemcpyDeviceToHost, st));
     DG_HIP(hipMemcpyAsync(redo.data(), th->ws[5].p, n, hipMemcpyDeviceToHost, st));
     DG_HIP(hipStreamSynchronize(st));

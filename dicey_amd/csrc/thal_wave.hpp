@@ -37,7 +37,7 @@ struct RowInfo {   // per column of the row being filled
   double G2;       // free energy of the value the cell holds before the openings are tried
   double eS, eH;   // left end at (i,j): the traceback's first test (thal.h:2143)
   double kS, kH;   // stacked continuation of (i-1,j-1): its second test (thal.h:2150)
-  double pad;
+  double pad;      // (r05: without it — 56 bytes — `search` ran 7 % slower: the record is read with 16-byte LDS loads)
 };
 struct WaveMem {  // LDS owned by one wavefront
   RowInfo* row;              // [stride]
@@ -88,13 +88,34 @@ struct EndTables {
   Cell L[2][4][5][5];  // [symmetric][x][a[i-1]][b[j-1]]  -> (eS, eH) of left_end
   Cell R[2][4][5][5];  // [symmetric][x][a[i+1]][b[j+1]]  -> (rS, rH) of right_end
 };
-DG_HD constexpr unsigned wave_header_bytes() {  // parameter tables + end tables at the start of a workgroup's LDS
-  return (((unsigned)sizeof(Tables) + 15u) & ~15u) + (((unsigned)sizeof(EndTables) + 15u) & ~15u);
+// r05: the end tables can live INSIDE the LDS copy of the parameter tables, over tstack2 — which, like the dangles, only the two end
+// functions read; once the 400 cases are worked out nothing looks at it again (the END1 step below reads the end tables too).
+// INSIDE = true saves 6 400 bytes of header: a seventh wavefront of 40-mers per CU in k_thal_self_wave (padlock probes: 148 -> 126 ms
+// per 268 000).  The kernels that hold 16 wavefronts anyway keep the tables BEHIND the parameter tables: with them inside
+// `search` (k_site_wave) ran 7 % slower, same code, same occupancy (1 267 against 1 360 ms per step, tools/r05_call10.sh with
+// DG_E_VARIANT builds) — an LDS placement effect that was measured, not explained.
+static_assert(sizeof(EndTables) <= 2 * sizeof(double[5][5][5][5]) && offsetof(Tables, tstack2H) == offsetof(Tables, tstack2S) + sizeof(double[5][5][5][5]),
+              "the end tables fit where tstack2S / tstack2H sit");
+template <bool INSIDE>
+DG_HD constexpr unsigned wave_e_offset() {
+  return INSIDE ? (unsigned)offsetof(Tables, tstack2S) : (((unsigned)sizeof(Tables) + 15u) & ~15u);
 }
+template <bool INSIDE = false>
+DG_HD constexpr unsigned wave_header_bytes() {  // parameter tables and end tables at the start of a workgroup's LDS
+  return (((unsigned)sizeof(Tables) + 15u) & ~15u) + (INSIDE ? 0u : (((unsigned)sizeof(EndTables) + 15u) & ~15u));
+}
+template <bool INSIDE = false>
 __device__ inline const EndTables* wave_end_tables(const unsigned char* lds) {
-  return reinterpret_cast<const EndTables*>(lds + (((unsigned)sizeof(Tables) + 15u) & ~15u));
+  return reinterpret_cast<const EndTables*>(lds + wave_e_offset<INSIDE>());
+}
+// dynamic LDS of a workgroup of `waves` wavefronts (wave_header_init stages the end tables behind the header before it moves them in)
+template <bool INSIDE = false>
+inline unsigned wave_lds_total(unsigned waves, unsigned per_wave) {
+  const unsigned body = waves * per_wave, stage = ((unsigned)sizeof(EndTables) + 15u) & ~15u;
+  return wave_header_bytes<INSIDE>() + (body > stage ? body : stage);
 }
 // every thread of the workgroup calls this once; ends with a barrier
+template <bool INSIDE = false>
 __device__ inline void wave_header_init(unsigned char* lds, const Tables* global_tables, const Env& env) {
   {
     const uint64_t* src = reinterpret_cast<const uint64_t*>(global_tables);
@@ -103,7 +124,11 @@ __device__ inline void wave_header_init(unsigned char* lds, const Tables* global
   }
   __syncthreads();
   const Tables& T = *reinterpret_cast<const Tables*>(lds);
-  EndTables* E = reinterpret_cast<EndTables*>(lds + (((unsigned)sizeof(Tables) + 15u) & ~15u));
+  EndTables* E = reinterpret_cast<EndTables*>(lds + wave_e_offset<INSIDE>());
+  // every case first into the LDS behind the header (the wavefronts' DP memory, not in use yet: wave_lds_total keeps it large enough),
+  // then, behind a barrier, over the table the cases were read from.  (r05: the cases held in registers instead — the loop unrolled
+  // seven times — doubled the kernel's code and `search` ran 7 % slower.)
+  EndTables* tmp = reinterpret_cast<EndTables*>(lds + wave_header_bytes<INSIDE>());
   for (unsigned k = threadIdx.x; k < 400; k += blockDim.x) {
     const unsigned right = k / 200, sym = (k / 100) & 1, x = (k / 25) & 3, n1 = (k / 5) % 5, n2 = k % 5;
     uint8_t aa[2], bb[2];
@@ -123,8 +148,8 @@ __device__ inline void wave_header_init(unsigned char* lds, const Tables* global
       p.a = aa;
       p.b = bb;
       left_end(p, 1, 1, S, H);
-      E->L[sym][x][n1][n2].s = S;
-      E->L[sym][x][n1][n2].h = H;
+      tmp->L[sym][x][n1][n2].s = S;
+      tmp->L[sym][x][n1][n2].h = H;
     } else {
       aa[0] = (uint8_t)x;
       aa[1] = (uint8_t)n1;
@@ -133,9 +158,15 @@ __device__ inline void wave_header_init(unsigned char* lds, const Tables* global
       p.a = aa;
       p.b = bb;
       right_end(p, 0, 0, S, H);
-      E->R[sym][x][n1][n2].s = S;
-      E->R[sym][x][n1][n2].h = H;
+      tmp->R[sym][x][n1][n2].s = S;
+      tmp->R[sym][x][n1][n2].h = H;
     }
+  }
+  __syncthreads();
+  {
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(tmp);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(E);
+    for (unsigned k = threadIdx.x; k < sizeof(EndTables) / 8; k += blockDim.x) dst[k] = src[k];
   }
   __syncthreads();
 }
@@ -457,8 +488,12 @@ __device__ inline Result wave_end1_tm(const Tables& T, const EndTables& E, const
   // ---- END1: the first oligo's last base takes part (thal.h:2608-2626), first minimum over j ----
   double myG = kInf;
   if (lane < len2) {
-    double rS, rH;
-    right_end(p, len1, j, rS, rH);
+    // right_end(p, len1, j) from the end tables when (len1, j) pairs; a cell that does not pair holds (inf, -1) and its free energy
+    // is inf whatever stands here
+    const int al = a[len1];
+    const bool pr = pairs(al, myb);
+    const Cell re = pr ? E.R[both_symmetric ? 1 : 0][al][a[len1 + 1]][b[j + 1]] : kNoPair;
+    double rS = pr ? re.s : -1.0, rH = pr ? re.h : kInf;
     rS = rS + 0.000001;
     rH = rH + 0.000001;
     const Cell c = ((prevmask >> lane) & 1) ? m.cells[prevbase + (unsigned)__popcll(prevmask & low_bits(lane))] : kNoPair;  // row len1
@@ -478,8 +513,15 @@ __device__ inline Result wave_end1_tm(const Tables& T, const EndTables& E, const
   int bestI = len1;
   if (bestJ == 0x7fffffff) bestJ = 0;
   if (!fin(bestG)) bestI = bestJ = 1;
-  double rS, rH;
-  right_end(p, bestI, bestJ, rS, rH);
+  double rS = -1.0, rH = kInf;  // right_end(p, bestI, bestJ): (bestI, bestJ) pairs whenever its value is used
+  {
+    const int x = a[bestI], y = b[bestJ];
+    if (pairs(x, y)) {
+      const Cell re = E.R[both_symmetric ? 1 : 0][x][a[bestI + 1]][b[bestJ + 1]];
+      rS = re.s;
+      rH = re.h;
+    }
+  }
   auto slot = [&](int ci, int cj, bool& there) -> unsigned {  // wave-uniform lookup of an arbitrary cell
     const uint64_t mk = row_mask(a[ci]);
     there = (mk >> (cj - 1)) & 1;

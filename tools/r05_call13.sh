@@ -1,26 +1,21 @@
 #!/bin/bash
 # lanes experiment: libraries with 1 + DG_NEXTRA lanes (dicey_amd/variants/libdiceygpu_n<N>.so) against the product library, bench --in-flight
+# usage: GENOME=iid|repeats bash tools/r05_call13.sh
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r05
+G=${GENOME:-iid}
 cp dicey_amd/libdiceygpu.so /tmp/libdiceygpu_product.so
-cat > /tmp/l3.list <<'L'
-d1f3|X=1|--steps 90 --warmup 12 --parity-queries 0 --in-flight 3|0
-d2f3|X=1|--config hunt_d2 --steps 40 --warmup 8 --parity-queries 0 --in-flight 3|0
-L
-cat > /tmp/l4.list <<'L'
-d1f4|X=1|--steps 90 --warmup 12 --parity-queries 0 --in-flight 4|0
-d2f4|X=1|--config hunt_d2 --steps 40 --warmup 8 --parity-queries 0 --in-flight 4|0
-L
-cat > /tmp/l6.list <<'L'
-d1f5|X=1|--steps 90 --warmup 12 --parity-queries 0 --in-flight 5|0
-d1f6|X=1|--steps 90 --warmup 12 --parity-queries 0 --in-flight 6|0
-d2f6|X=1|--config hunt_d2 --steps 40 --warmup 8 --parity-queries 0 --in-flight 6|0
-L
+rm -f /dev/shm/dicey_bench_*
+timeout 900 python bench.py --genome $G --steps 1 --warmup 0 --no-extras --no-cpu-baseline --no-extra-configs --parity-queries 0 --keep-index --detail-out /tmp/b.json > /dev/null 2> gpurun_out/r05/lanes_build.err
+FM9=$(ls /dev/shm/dicey_bench_*.fm9 | head -1)
+echo "index $FM9"
+run() {  # name, in-flight
+  timeout 600 python bench.py --genome $G --fm9 $FM9 --no-extras --no-extra-configs --no-cpu-baseline --parity-queries 0 --steps 40 --warmup 8 --in-flight $2 --detail-out gpurun_out/r05/lanes_$1.json > /dev/null 2> gpurun_out/r05/lanes_$1.err
+  python -c "import json; j=json.load(open('gpurun_out/r05/lanes_$1.json')); print('$1', round(j['value']/1e6,2), 'M', round(j['ms_per_step'],4), 'ms')"
+}
 for R in 1 2; do
-bash tools/r05_exp.sh 13 /tmp/l3.list 2>&1 | grep -E "^d[12]"
-cp dicey_amd/variants/libdiceygpu_n3.so dicey_amd/libdiceygpu.so
-bash tools/r05_exp.sh 13 /tmp/l4.list 2>&1 | grep -E "^d[12]"
-cp dicey_amd/variants/libdiceygpu_n5.so dicey_amd/libdiceygpu.so
-bash tools/r05_exp.sh 13 /tmp/l6.list 2>&1 | grep -E "^d[12]"
-cp /tmp/libdiceygpu_product.so dicey_amd/libdiceygpu.so
+  run f3 3
+  cp dicey_amd/variants/libdiceygpu_n5.so dicey_amd/libdiceygpu.so
+  run f4 4; run f6 6
+  cp /tmp/libdiceygpu_product.so dicey_amd/libdiceygpu.so
 done

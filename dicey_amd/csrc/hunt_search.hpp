@@ -1101,8 +1101,14 @@ __global__ void __launch_bounds__(256, LONG2 ? 6 : 5) k_search2p(FmView f, Batch
   // whatever survives (a queue that holds every candidate of a pass needs 32 KB and left four wavefronts per SIMD resident;
   // r02: 8.8 -> 7.6 ms with room for six), and nothing can overflow.  The dense phase numbers the set bits with a prefix sum
   // over the lanes and finds its e-th one by a binary search over the prefix plus a select inside the lane's mask.
-  __shared__ unsigned long long q_mask[256];
-  __shared__ u32 q_ex[256 + 1];  // exclusive prefix of the lanes' survivor counts, [256] = total
+  // r05: a pass with at most QS_CAP survivors (the usual case: ~ 925 of a 20-mer's 13 000 candidates) lists them in the same LDS
+  // instead — (lane | operation pair << 8), two bytes each, written by the lanes that found them — and stage 1 of the dense phase
+  // reads its survivor with one load; the masks and the search over the prefix remain for passes with more.
+  constexpr u32 QS_CAP = (256 * 8 + 257 * 4) / 2;
+  __shared__ __align__(8) unsigned char q_raw[256 * 8 + 257 * 4 + 4];
+  unsigned long long* const q_mask = reinterpret_cast<unsigned long long*>(q_raw);
+  u32* const q_ex = reinterpret_cast<u32*>(q_raw + 256 * 8);  // exclusive prefix of the lanes' survivor counts, [256] = total
+  u16* const q_surv = reinterpret_cast<u16*>(q_raw);
   __shared__ u32 q_wave[4];
   __shared__ u16 q_pair[256];   // the lanes' (p1 | p2 << 8) of the pass: the dense phase rebuilds other lanes' survivors
   __shared__ u16 q_cand[512];   // survivors whose head window occurs as well (lane | operation pair << 8), for the dense phase's second stage
@@ -1336,12 +1342,18 @@ __global__ void __launch_bounds__(256, LONG2 ? 6 : 5) k_search2p(FmView f, Batch
       const u32 mine = (u32)__popcll(surv);
       const u32 incl = wave_incl_scan32(mine);
       if (lane == 63) q_wave[threadIdx.x >> 6] = incl;
-      q_mask[threadIdx.x] = surv;
       __syncthreads();
       u32 before = 0;
       for (u32 k = 0; k < (threadIdx.x >> 6); ++k) before += q_wave[k];
-      q_ex[threadIdx.x] = before + incl - mine;
       const u32 qn = (expb & 1u) ? 0u : q_wave[0] + q_wave[1] + q_wave[2] + q_wave[3];
+      const bool listed = qn <= QS_CAP;  // (uniform)
+      if (listed) {
+        u32 at = before + incl - mine;
+        for (unsigned long long mk = surv; mk; mk &= mk - 1) q_surv[at++] = (u16)(threadIdx.x | (((u32)__ffsll((long long)mk) - 1u) << 8));
+      } else {
+        q_mask[threadIdx.x] = surv;
+        q_ex[threadIdx.x] = before + incl - mine;
+      }
       __syncthreads();
       // Dense phase in two stages (r05).  Five of six survivors of the end-window probes die on the first look — the head window
       // (the first K2 characters must occur as well) — and everything after it (table entry, preceding-characters line or Occ steps,
@@ -1355,14 +1367,20 @@ __global__ void __launch_bounds__(256, LONG2 ? 6 : 5) k_search2p(FmView f, Batch
         bool pass = false;
         u32 ent = 0;
         if (e < qn) {
-          // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
-          u32 L = 0;
+          u32 L = 0, bitno;
+          if (listed) {
+            const u32 sv = q_surv[e];
+            L = sv & 255u;
+            bitno = sv >> 8;
+          } else {
+            // the lane that holds survivor e: the last one whose exclusive prefix is <= e; then its (e - prefix)-th set bit
 #pragma unroll
-          for (u32 step = 128; step > 0; step >>= 1)
-            if (q_ex[L + step] <= e) L += step;
-          unsigned long long mk = q_mask[L];
-          for (u32 r = e - q_ex[L]; r > 0; --r) mk &= mk - 1;
-          const u32 bitno = (u32)__ffsll((long long)mk) - 1u;
+            for (u32 step = 128; step > 0; step >>= 1)
+              if (q_ex[L + step] <= e) L += step;
+            unsigned long long mk = q_mask[L];
+            for (u32 r = e - q_ex[L]; r > 0; --r) mk &= mk - 1;
+            bitno = (u32)__ffsll((long long)mk) - 1u;
+          }
           const u32 pp = q_pair[L], p1 = pp & 255u, p2 = pp >> 8;
           u32 l1, l2;
           const u64 s1 = edit_string(ham, qpk, m, p1, bitno >> 3, l1);

@@ -291,17 +291,39 @@ def padlock_scan(ix: "FmIndex", th: "Thal", exons: Sequence[bytes], armlen: int 
     p = _capi.PadlockParams(armlen, distance, 1 if hamming else 0, tmdiff, gc_min, gc_max)
     rp = C.POINTER(_capi.PadlockResult)()
     _capi.check(L, L.dg_padlock_scan(ix.handle, th._h, C.byref(p), buf, off, len(exons), C.byref(rp)))
-    try:
-        R = rp.contents
-        n = R.npos
-        take = lambda ptr, cnt, dt: np.ctypeslib.as_array(ptr, shape=(max(1, cnt),))[:cnt].astype(dt, copy=True)
-        return {"pos_off": take(R.pos_off, R.nexons + 1, np.uint64), "arm_gc": take(R.arm_gc, n, np.float64),
-                "arm_tm": take(R.arm_tm, n, np.float64), "probe_gc": take(R.probe_gc, n, np.float64),
-                "probe_tm": take(R.probe_tm, n, np.float64), "arm_count": take(R.arm_count, n, np.int64),
-                "arm_nbcount": take(R.arm_nbcount, n, np.int64), "n_arm_thal": R.n_arm_thal, "n_probe_thal": R.n_probe_thal,
-                "n_arms_counted": R.n_arms_counted}
-    finally:
-        L.dg_padlock_result_free(rp)
+    # The arrays are VIEWS of the library's result (128 MB for 1 000 genes: copying them cost a bench step 15 %): every view's buffer
+    # object holds the owner, which hands the result back to the library when the last view is gone.
+    owner = _PadlockOwner(L, rp)
+    R = rp.contents
+    n = R.npos
+
+    def view(ptr, cnt, ctype, dt):
+        if cnt == 0:
+            return np.empty(0, dt)
+        cbuf = (ctype * cnt).from_address(C.addressof(ptr.contents))
+        cbuf._dicey_owner = owner
+        arr = np.frombuffer(cbuf, dtype=dt, count=cnt)
+        arr.flags.writeable = False
+        return arr
+
+    return {"pos_off": view(R.pos_off, R.nexons + 1, C.c_uint64, np.uint64), "arm_gc": view(R.arm_gc, n, C.c_double, np.float64),
+            "arm_tm": view(R.arm_tm, n, C.c_double, np.float64), "probe_gc": view(R.probe_gc, n, C.c_double, np.float64),
+            "probe_tm": view(R.probe_tm, n, C.c_double, np.float64), "arm_count": view(R.arm_count, n, C.c_int64, np.int64),
+            "arm_nbcount": view(R.arm_nbcount, n, C.c_int64, np.int64), "n_arm_thal": int(R.n_arm_thal), "n_probe_thal": int(R.n_probe_thal),
+            "n_arms_counted": int(R.n_arms_counted)}
+
+
+class _PadlockOwner:
+    """keeps a dg_padlock_result alive for the numpy views made of it (padlock_scan)"""
+
+    def __init__(self, lib, rp):
+        self._lib, self._rp = lib, rp
+
+    def __del__(self):
+        try:
+            self._lib.dg_padlock_result_free(self._rp)
+        except Exception:
+            pass
 
 
 def build_index(text: bytes, out_fm9: str, device: int = 0, _lib=None):

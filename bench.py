@@ -1528,16 +1528,16 @@ def run_extra_configs(a, fm9):
     ms_per_step, roofline of its dominant kernel, cpu_baseline and parity_sample; the headline keys are untouched."""
     import subprocess
     t_start = time.time()
-    plan = [("hunt_d1_repeats", ["--config", "hunt_d1", "--genome", "repeats", "--steps", "9", "--warmup", "6", "--cpu-seconds", "6", "--parity-queries", "300"], False),
-            ("hunt_d2", ["--config", "hunt_d2", "--steps", "9", "--warmup", "6", "--cpu-seconds", "4", "--parity-queries", "300"], True),
+    plan = [("hunt_d1_repeats", ["--config", "hunt_d1", "--genome", "repeats", "--steps", "30", "--warmup", "8", "--cpu-seconds", "6", "--parity-queries", "300"], False),
+            ("hunt_d2", ["--config", "hunt_d2", "--steps", "30", "--warmup", "8", "--cpu-seconds", "4", "--parity-queries", "300"], True),
             # cap-prone primers (VERDICT r02 #9): 25-mers at distance 2 — the maxNeighborhood cap can fire, so every strand is
             # enumerated on the host in the reference's order first (nbhd_host.hpp) and searched as explicit patterns
             ("hunt_d2_25mers", ["--config", "hunt_d2", "--qlen", "25", "--queries", "2000", "--steps", "1", "--warmup", "1", "--cpu-seconds", "6",
                                 "--parity-queries", "100"], True),
             # what the general kernel k_search serves (VERDICT r04 #6): Hamming distance 2 (neighbors.h:57-66 without the indel
             # branches) and queries with an N (hunter.h:306-307, util.h:208-219)
-            ("hunt_d2_hamming", ["--config", "hunt_d2", "--hamming", "--steps", "5", "--warmup", "3", "--cpu-seconds", "4", "--parity-queries", "300"], True),
-            ("hunt_d1_nmix", ["--config", "hunt_d1", "--n-frac", "0.05", "--steps", "9", "--warmup", "6", "--cpu-seconds", "4", "--parity-queries", "300"], True),
+            ("hunt_d2_hamming", ["--config", "hunt_d2", "--hamming", "--steps", "30", "--warmup", "8", "--cpu-seconds", "4", "--parity-queries", "300"], True),
+            ("hunt_d1_nmix", ["--config", "hunt_d1", "--n-frac", "0.05", "--steps", "30", "--warmup", "8", "--cpu-seconds", "4", "--parity-queries", "300"], True),
             ("search", ["--config", "search", "--steps", "2", "--warmup", "1", "--cpu-seconds", "6"], True),
             ("padlock", ["--config", "padlock", "--steps", "3", "--warmup", "1", "--cpu-seconds", "6"], True)]
     keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "roofline_search", "cpu_baseline", "parity_sample", "cap_stage",

@@ -516,7 +516,8 @@ def main():
                          "size agreement, the gather) — n_gpus stays 1")
     ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3, 4, 5, 6, 7, 8),
                     help="hunt configs: batches in flight per GPU in the timed region: 2 or 3 = dg_hunt_device_submit / dg_hunt_wait on the handle's "
-                         "lanes (step k is submitted, step k - n + 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a)")
+                         "lanes (step k is submitted, step k - n + 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a); "
+                         "more than 3 need a library built with -DDG_NEXTRA=n-1 (tools/r05_call13.sh: measured, no gain)")
     ap.add_argument("--batches", type=int, default=16,
                     help="hunt configs: distinct query batches resident in HBM that the warm-up and timed steps cycle through (step k "
                          "searches batch k mod B; hunter.h:291 searches every query once, so the headline never replays a batch within "

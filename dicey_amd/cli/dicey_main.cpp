@@ -241,14 +241,20 @@ int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const
     if (G.open_tcp(std::atoi(tcp), N, rank, CAP, 0, &comm) != 0) return die(G.last_error());
   } else {
     const char* cf = std::getenv("DICEY_COMM_FILE");
-    uint8_t id[DG_COMM_ID_BYTES];
+    // the file holds the communicator id followed by a 16-byte launch token (DICEY_COMM_TOKEN, zero-padded; empty = all zero):
+    // a file another launch left behind does not carry this launch's token and is not taken.  Rank 0 removes whatever lies at the
+    // path before it writes, and removes its own file once the communicator stands (every rank has read it by then).
+    uint8_t id[DG_COMM_ID_BYTES], token[16] = {0};
+    if (const char* tk = std::getenv("DICEY_COMM_TOKEN")) std::memcpy(token, tk, std::min<size_t>(std::strlen(tk), sizeof token));
     if (N > 1 && !cf) return die("DICEY_COMM_FILE (where rank 0 leaves the communicator id) is not set");
     if (rank == 0) {
+      if (cf) std::remove(cf);
       if (G.unique_id(id) != 0) return die(G.last_error());
       if (cf) {
         const std::string tmp = std::string(cf) + ".tmp";
         FILE* f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) return die("cannot write " + tmp);
+        if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id || std::fwrite(token, 1, sizeof token, f) != sizeof token)
+          return die("cannot write " + tmp);
         std::fclose(f);
         if (std::rename(tmp.c_str(), cf) != 0) return die(std::string("cannot create ") + cf);
       }
@@ -256,12 +262,14 @@ int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const
       bool got = false;
       for (int attempt = 0; attempt < 1200 && !got; ++attempt) {  // the ranks start together; rank 0 writes within milliseconds
         if (FILE* f = std::fopen(cf, "rb")) {
-          got = std::fread(id, 1, sizeof id, f) == sizeof id;
+          uint8_t tk[sizeof token];
+          got = std::fread(id, 1, sizeof id, f) == sizeof id && std::fread(tk, 1, sizeof tk, f) == sizeof tk &&
+                std::memcmp(tk, token, sizeof tk) == 0;
           std::fclose(f);
         }
         if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
-      if (!got) return die(std::string("no communicator id in ") + cf);
+      if (!got) return die(std::string("no communicator id of this launch in ") + cf);
     }
     // RCCL greets with a version banner on stdout (rank 0, communicator creation); stdout is the JSON stream (hunter.h:160-175), so
     // the banner goes to stderr: file descriptor 1 points there while the communicator is created
@@ -275,6 +283,7 @@ int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const
       close(saved_out);
     }
     if (orc != 0) return die(G.last_error());
+    if (rank == 0 && cf) std::remove(cf);  // the communicator stands: every rank has read the id
   }
   const size_t nq = queries.size(), per = (nq + N - 1) / N;
   const size_t CH = 1u << 17;
@@ -286,51 +295,91 @@ int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const
   };
   std::vector<uint64_t> seq_start(seqlen.size() + 1, 0);
   for (size_t i = 0; i < seqlen.size(); ++i) seq_start[i + 1] = seq_start[i] + seqlen[i];
-  // rank 0 keeps every (rank, chunk) block on the host until everything has arrived, then formats in query order
-  std::vector<std::vector<std::vector<uint8_t>>> got(rank == 0 ? N : 0, std::vector<std::vector<uint8_t>>(nchunks));
+  // rank 0 keeps every (rank, chunk, piece) block on the host until everything has arrived, then formats in query order.
+  // A chunk normally is ONE piece.  When a rank's library refuses its chunk's size (DG_ELIMIT: capped neighbourhoods beyond the
+  // host budget — what run_slice answers by halves) the ranks agree, through the collective that carries the byte counts, to
+  // cut the chunk into twice as many equal pieces ON EVERY RANK and start it again: the split is a function of (range, pieces)
+  // alone, so rank 0 can rebuild every rank's pieces and the collectives stay in step.  Any other failure travels the same way
+  // and ends every rank (one rank leaving alone left its peers blocked in the next collective).
+  auto piece_of = [](size_t q0, size_t q1, uint64_t parts, uint64_t pc, size_t& a, size_t& b) {
+    const size_t n = q1 - q0;
+    a = q0 + (size_t)((unsigned __int128)n * pc / parts);
+    b = q0 + (size_t)((unsigned __int128)n * (pc + 1) / parts);
+  };
+  constexpr uint64_t ST_SHIFT = 60, ST_SPLIT = 1, ST_FAIL = 2;
+  std::vector<std::vector<std::vector<std::vector<uint8_t>>>> got(rank == 0 ? N : 0, std::vector<std::vector<std::vector<uint8_t>>>(nchunks));
+  std::vector<uint64_t> parts_of(nchunks, 1);
   int rc_all = 0;
   for (size_t k = 0; k < nchunks; ++k) {
     size_t q0, q1;
     range_of(rank, k, q0, q1);
-    dg_hunt_result* R = nullptr;
-    std::string qb;
-    std::vector<uint64_t> off(q1 - q0 + 1, 0);
-    if (q1 > q0) {
-      size_t longest = 0;
-      for (size_t i = 0; i < q1 - q0; ++i) {
-        qb += queries[q0 + i].second;
-        off[i + 1] = qb.size();
-        longest = std::max(longest, queries[q0 + i].second.size());
-      }
-      dg_hunt_params cp = hp;
-      cp.max_query_len = (uint32_t)std::min<size_t>(longest, 0xFFFFFFu);
-      cp.flags = DG_HUNT_COMPACT;
-      if (dg_hunt(ix, &cp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), q1 - q0, &R) != DG_OK) {
-        die(dg_last_error());  // outside the supported envelope: the whole job fails, never a partial answer
-        std::_Exit(2);         // (the peers' collectives cannot complete without this rank: they are ended by the launcher)
-      }
-    }
-    const uint64_t bytes = R ? R->d_block_bytes : 0;
-    uint64_t most = 0;
-    if (G.max_u64(comm, bytes, &most) != 0) return die(G.last_error());
-    const uint64_t pieces = std::max<uint64_t>(1, (most + CAP - 1) / CAP);
-    for (uint64_t pc = 0; pc < pieces; ++pc) {
-      const uint64_t b0 = std::min(bytes, pc * CAP), b1 = std::min(bytes, b0 + CAP);
-      // RCCL: out of HBM, staged on the stream the batch ran on; the TCP test transport takes the fetched copy of the same bytes
-      const uint8_t* src = !R ? nullptr : tcp ? (const uint8_t*)R->qinfo - 4 * (q1 - q0) : (const uint8_t*)R->d_block;
-      if (G.submit(comm, (R && !tcp) ? R->stream : nullptr, src ? src + b0 : nullptr, b1 - b0) != 0) return die(G.last_error());
-      if (G.finish(comm, nullptr, nullptr) != 0) return die(G.last_error());
+    for (uint64_t parts = 1;;) {
+      bool again = false;
       if (rank == 0)
-        for (int r = 0; r < N; ++r) {
-          uint64_t n = 0;
-          if (G.last_to_host(comm, r, nullptr, 0, &n) != 0 && n == 0) return die(G.last_error());
-          std::vector<uint8_t>& dst = got[r][k];
-          const size_t at = dst.size();
-          dst.resize(at + n);
-          if (n && G.last_to_host(comm, r, dst.data() + at, n, &n) != 0) return die(G.last_error());
+        for (int r = 0; r < N; ++r) got[r][k].assign(parts, std::vector<uint8_t>());
+      for (uint64_t piece = 0; piece < parts && !again; ++piece) {
+        size_t a, b;
+        piece_of(q0, q1, parts, piece, a, b);
+        dg_hunt_result* R = nullptr;
+        uint64_t status = 0;
+        if (b > a) {
+          std::string qb;
+          std::vector<uint64_t> off(b - a + 1, 0);
+          size_t longest = 0;
+          for (size_t i = 0; i < b - a; ++i) {
+            qb += queries[a + i].second;
+            off[i + 1] = qb.size();
+            longest = std::max(longest, queries[a + i].second.size());
+          }
+          dg_hunt_params cp = hp;
+          cp.max_query_len = (uint32_t)std::min<size_t>(longest, 0xFFFFFFu);
+          cp.flags = DG_HUNT_COMPACT;
+          const int rc = dg_hunt(ix, &cp, seqlen.data(), (uint32_t)seqlen.size(), (const uint8_t*)qb.data(), off.data(), b - a, &R);
+          if (rc == DG_ELIMIT && b - a > 1) status = ST_SPLIT;
+          else if (rc != DG_OK) {
+            die(dg_last_error());  // outside the supported envelope: the whole job fails, never a partial answer
+            status = ST_FAIL;
+          }
+          if (rc != DG_OK) R = nullptr;
         }
+        const uint64_t bytes = R ? R->d_block_bytes : 0;
+        uint64_t most = 0;
+        if (G.max_u64(comm, (status << ST_SHIFT) | bytes, &most) != 0) return die(G.last_error());
+        if ((most >> ST_SHIFT) >= ST_FAIL) {  // some rank cannot answer: every rank leaves, none waits for a peer that is gone
+          if (R) dg_hunt_result_free(R);
+          G.close(comm);
+          return status == ST_FAIL ? 2 : die("another rank failed; no output");
+        }
+        if ((most >> ST_SHIFT) == ST_SPLIT) {
+          if (R) dg_hunt_result_free(R);
+          parts *= 2;
+          again = true;
+          break;
+        }
+        const uint64_t pieces = std::max<uint64_t>(1, (most + CAP - 1) / CAP);
+        for (uint64_t pc = 0; pc < pieces; ++pc) {
+          const uint64_t b0 = std::min(bytes, pc * CAP), b1 = std::min(bytes, b0 + CAP);
+          // RCCL: out of HBM, staged on the stream the batch ran on; the TCP test transport takes the fetched copy of the same bytes
+          const uint8_t* src = !R ? nullptr : tcp ? (const uint8_t*)R->qinfo - 4 * (b - a) : (const uint8_t*)R->d_block;
+          if (G.submit(comm, (R && !tcp) ? R->stream : nullptr, src ? src + b0 : nullptr, b1 - b0) != 0) return die(G.last_error());
+          if (G.finish(comm, nullptr, nullptr) != 0) return die(G.last_error());
+          if (rank == 0)
+            for (int r = 0; r < N; ++r) {
+              uint64_t n = 0;
+              if (G.last_to_host(comm, r, nullptr, 0, &n) != 0 && n == 0) return die(G.last_error());
+              std::vector<uint8_t>& dst = got[r][k][piece];
+              const size_t at = dst.size();
+              dst.resize(at + n);
+              if (n && G.last_to_host(comm, r, dst.data() + at, n, &n) != 0) return die(G.last_error());
+            }
+        }
+        if (R) dg_hunt_result_free(R);
+      }
+      if (!again) {
+        parts_of[k] = parts;
+        break;
+      }
     }
-    if (R) dg_hunt_result_free(R);
   }
   G.close(comm);
   if (rank != 0) return 0;
@@ -342,37 +391,39 @@ int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const
     };
   auto sink = [&](size_t, std::string&& js) { emit(c, js); };
   for (int r = 0; r < N && !rc_all; ++r)
-    for (size_t k = 0; k < nchunks && !rc_all; ++k) {
-      size_t q0, q1;
-      range_of(r, k, q0, q1);
-      const size_t n = q1 - q0;
-      if (!n) continue;
-      const std::vector<uint8_t>& blk = got[r][k];
-      if (blk.size() < 8 * n) {
-        rc_all = die("rank " + std::to_string(r) + " sent " + std::to_string(blk.size()) + " bytes for " + std::to_string(n) + " queries");
-        break;
+    for (size_t k = 0; k < nchunks && !rc_all; ++k)
+      for (uint64_t piece = 0; piece < parts_of[k] && !rc_all; ++piece) {
+        size_t c0, c1, q0, q1;
+        range_of(r, k, c0, c1);
+        piece_of(c0, c1, parts_of[k], piece, q0, q1);
+        const size_t n = q1 - q0;
+        if (!n) continue;
+        const std::vector<uint8_t>& blk = got[r][k][piece];
+        if (blk.size() < 8 * n) {
+          rc_all = die("rank " + std::to_string(r) + " sent " + std::to_string(blk.size()) + " bytes for " + std::to_string(n) + " queries");
+          break;
+        }
+        // the block as a result: [hit counts | query words | records]
+        dg_hunt_result S{};
+        std::vector<uint64_t> hit_off(n + 1, 0);
+        const uint32_t* qh = (const uint32_t*)blk.data();
+        for (size_t i = 0; i < n; ++i) hit_off[i + 1] = hit_off[i] + qh[i];
+        S.nq = n;
+        S.nhits = hit_off[n];
+        const uint64_t rec_bytes = blk.size() - 8 * n;
+        if (S.nhits && (rec_bytes % (4 * S.nhits) != 0 || rec_bytes / (4 * S.nhits) < 2)) {
+          rc_all = die("rank " + std::to_string(r) + ": " + std::to_string(rec_bytes) + " record bytes for " + std::to_string(S.nhits) + " hits");
+          break;
+        }
+        S.ops_per_hit = S.nhits ? (uint32_t)(rec_bytes / (4 * S.nhits)) - 2 : 0;
+        S.hit_off = hit_off.data();
+        S.qinfo = const_cast<uint32_t*>(qh) + n;
+        S.chits = const_cast<uint32_t*>(qh) + 2 * n;
+        S.compact = 1;
+        S.nseq = (uint32_t)seqlen.size();
+        S.seq_start = seq_start.data();
+        format_chunk_to(&S, q0, n, sink, bulk);
       }
-      // the block as a result: [hit counts | query words | records]
-      dg_hunt_result S{};
-      std::vector<uint64_t> hit_off(n + 1, 0);
-      const uint32_t* qh = (const uint32_t*)blk.data();
-      for (size_t i = 0; i < n; ++i) hit_off[i + 1] = hit_off[i] + qh[i];
-      S.nq = n;
-      S.nhits = hit_off[n];
-      const uint64_t rec_bytes = blk.size() - 8 * n;
-      if (S.nhits && (rec_bytes % (4 * S.nhits) != 0 || rec_bytes / (4 * S.nhits) < 2)) {
-        rc_all = die("rank " + std::to_string(r) + ": " + std::to_string(rec_bytes) + " record bytes for " + std::to_string(S.nhits) + " hits");
-        break;
-      }
-      S.ops_per_hit = S.nhits ? (uint32_t)(rec_bytes / (4 * S.nhits)) - 2 : 0;
-      S.hit_off = hit_off.data();
-      S.qinfo = const_cast<uint32_t*>(qh) + n;
-      S.chits = const_cast<uint32_t*>(qh) + 2 * n;
-      S.compact = 1;
-      S.nseq = (uint32_t)seqlen.size();
-      S.seq_start = seq_start.data();
-      format_chunk_to(&S, q0, n, sink, bulk);
-    }
   return rc_all;
 }
 

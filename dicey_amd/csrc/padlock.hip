@@ -40,10 +40,14 @@ void run_chunks(const std::vector<size_t>& cut, F f) {
     f((size_t)0, cut.front(), cut.back());
     return;
   }
+  // an empty chunk (two equal boundaries: one exon longer than a chunk's share of the positions) still gets its call — the
+  // two-pass stages write a count per chunk and a chunk that kept the previous stage's value would shift every later one
   std::vector<std::thread> th;
   th.reserve(nt);
-  for (size_t t = 0; t < nt; ++t)
+  for (size_t t = 0; t < nt; ++t) {
     if (cut[t] < cut[t + 1]) th.emplace_back([&f, &cut, t] { f(t, cut[t], cut[t + 1]); });
+    else f(t, cut[t], cut[t]);
+  }
   for (auto& x : th) x.join();
 }
 std::vector<size_t> even_cuts(size_t n, unsigned nt, size_t grain) {
@@ -223,6 +227,7 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     if (std::abs(R->arm_tm[at] - R->arm_tm[at + L]) > (double)p->tmdiff) return false;
     return !(R->probe_gc[at] < minGC || R->probe_gc[at] > maxGC);
   };
+  std::fill(cnt.begin(), cnt.end(), 0);  // (stage 1 left its chunks' first slots here)
   run_chunks(ecut, [&](size_t c, size_t e0, size_t e1) {
     uint64_t n = 0;
     for (size_t e = e0; e < e1; ++e) {

@@ -180,3 +180,54 @@ def test_cli_one_process_per_gpu_gathers_over_libdiceygather(tmp_path):
             assert all(p.returncode == 0 for p in ps), [o[1][-500:] for o in outs]
             assert outs[0][0] == one.stdout, (nr, extra)
             assert all(o[0] == "" for o in outs[1:])
+
+
+def test_cli_ranks_answer_refused_chunks_in_pieces_and_fail_together(tmp_path):
+    """in DICEY_RANKS mode a chunk the library refuses with DG_ELIMIT used to end the rank (and leave its
+    peers blocked in the next collective).  Now the ranks agree — through the collective that carries the byte counts — to cut
+    the chunk into pieces, like run_slice's halves; any other failure travels the same way and every rank exits.  Two ranks over
+    the TCP test transport, cap-prone queries (-x 50) under a 1 MB budget: stdout equals the single-process run."""
+    import gzip
+    import socket
+    from conftest import genome_text, make_genome, make_queries
+    dicey = os.path.join(ROOT, "dicey_amd", "dicey")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dicey_amd", "cli"), "-s"])
+    seqs = make_genome(79, 2, 20000)
+    fa = tmp_path / "g.fa.gz"
+    with gzip.open(fa, "wt") as f:
+        for i, s in enumerate(seqs):
+            f.write(">c%d\n%s\n" % (i, s))
+    assert subprocess.run([dicey, "index", str(fa)], capture_output=True).returncode == 0
+    base = make_queries(23, genome_text(seqs), 1500, (20,))
+    qs = (base * 20)[:30000]
+    qf = tmp_path / "capped.fa"
+    qf.write_text("".join(">c%d\n%s\n" % (i, q) for i, q in enumerate(qs)))
+    env0 = {k: v for k, v in os.environ.items() if not k.startswith("DICEY_")}
+    env0.update(DICEY_KMER_K="9", DICEY_CAP_BUDGET_MB="1")
+    cmd = [dicey, "hunt", "-x", "50", "-g", str(fa), str(qf)]
+    one = subprocess.run(cmd, capture_output=True, text=True, env=env0)
+    assert one.returncode == 0, one.stderr[-1500:]
+    assert one.stdout.count("\n") == len(qs)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=dict(env0, DICEY_RANKS="2", DICEY_RANK=str(r), DICEY_DEVICE="0", DICEY_COMM_TCP=str(port)))
+          for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in ps]
+    assert all(p.returncode == 0 for p in ps), [o[1][-800:] for o in outs]
+    assert outs[0][0] == one.stdout
+    assert outs[1][0] == ""
+    # a failure that is not a size refusal (a query the library rejects: distance above its limit) ends BOTH ranks with code 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    few = tmp_path / "few.fa"
+    few.write_text("".join(">f%d\n%s\n" % (i, q) for i, q in enumerate(qs[:5])))
+    bad = [dicey, "hunt", "-d", "9", "-g", str(fa), str(few)]
+    ps = [subprocess.Popen(bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=dict(env0, DICEY_RANKS="2", DICEY_RANK=str(r), DICEY_DEVICE="0", DICEY_COMM_TCP=str(port)))
+          for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in ps]
+    assert [p.returncode for p in ps] == [2, 2], [o[1][-500:] for o in outs]
+    assert outs[0][0] == "" and outs[1][0] == ""

@@ -130,3 +130,39 @@ def test_randomised_padlock_configurations_against_oracle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_padlock.py"), "5", "5"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-1500:]
     assert "failing configurations: 0" in r.stdout, r.stdout[-1500:]
+
+
+_SCAN_SCRIPT = r"""
+import sys, random, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import oracle_lib as O, dicey_amd
+rng = random.Random(11)
+big = "".join(rng.choice("ACGT") for _ in range(220000)).encode()
+small = ["".join(rng.choice("ACGT") for _ in range(rng.randrange(60, 400))).encode() for _ in range(40)]
+exons = small[:20] + [big] + small[20:]
+with dicey_amd.FmIndex({fm9!r}) as ix:
+    th = dicey_amd.Thal(O.PRIMER3_CONFIG)
+    R = dicey_amd.padlock_scan(ix, th, exons)
+    np.savez({out!r}, **{{k: np.array(v) for k, v in R.items()}})
+    th.close()
+"""
+
+
+def test_padlock_scan_with_one_exon_longer_than_a_threads_share(scenario, tmp_path):
+    """an exon of >= 65 536 positions makes two chunk boundaries coincide; the empty chunk must not keep
+    the previous stage's count.  Same arrays with one host thread and with four."""
+    import sys
+    import numpy as np
+    outs = []
+    for nt in ("1", "4"):
+        out = str(tmp_path / f"scan_{nt}.npz")
+        src = _SCAN_SCRIPT.format(root=ROOT, tests=os.path.dirname(__file__), fm9=scenario["fm9"], out=out)
+        env = dict(os.environ, DICEY_HOST_THREADS=nt)
+        r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert int(a["n_probe_thal"]) > 0 and int(a["n_arm_thal"]) > 100000

@@ -129,3 +129,80 @@ def test_summarize_profile_matches_the_full_instantiation():
         S.pick_kernel(means, "k_search1s")
     with pytest.raises(SystemExit):
         S.pick_kernel(means, "k_search2p<false>")
+
+
+# ---- r06: the five evidence fixes the r05 verdict asked for ("Next round" item 3) -------------------------------------------------
+def test_profile_keys_tell_hamming_and_n_mix_apart():
+    """(i) a sub-line may quote PMC traffic only from a profile of ITS workload: file name and workload tag carry the mode"""
+    import bench
+    edit2 = (bench.traffic_file(2, False, 0.0, "iid"), bench.workload_tag(100000, 20, 2, False, 0.0, 3.1e9, "iid"))
+    ham2 = (bench.traffic_file(2, True, 0.0, "iid"), bench.workload_tag(100000, 20, 2, True, 0.0, 3.1e9, "iid"))
+    nmix = (bench.traffic_file(1, False, 0.05, "iid"), bench.workload_tag(100000, 20, 1, False, 0.05, 3.1e9, "iid"))
+    d1 = (bench.traffic_file(1, False, 0.0, "iid"), bench.workload_tag(100000, 20, 1, False, 0.0, 3.1e9, "iid"))
+    rep = (bench.traffic_file(1, False, 0.0, "repeats"), bench.workload_tag(100000, 20, 1, False, 0.0, 3.1e9, "repeats"))
+    assert len({x[0] for x in (edit2, ham2, nmix, d1, rep)}) == 5 and len({x[1] for x in (edit2, ham2, nmix, d1, rep)}) == 5
+    assert d1 == ("traffic_k_search.json", "100000x20mer_d1_n3100000000_iid")          # the committed r05 files keep their names
+    assert edit2[0] == "traffic_k_search_d2_iid.json" and rep[0] == "traffic_k_search_d1_repeats.json"
+    # the edit-distance-2 profile is NOT what a Hamming-distance-2 line finds, whatever build it was taken on
+    prof = os.path.join(ROOT, "profiles", edit2[0])
+    if os.path.exists(prof):
+        j = json.load(open(prof))
+        assert j["workload"] == edit2[1] and j["workload"] != ham2[1]
+
+
+def _line_with(extra):
+    import bench
+    out = {"metric": bench.METRIC, "value": 5.0e8, "unit": "primers/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.2, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": "x", "genome": "y", "queries_per_gpu": 100000},
+           "roofline": {"bound": "hbm", "kernel": "k_search1s<true, true>", "achieved": 800.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None,
+                        "algorithmic_bytes_per_launch": 1.2e8, "kernel_ms": 0.15,
+                        "kernel_ms_is": "busy time per launch: union of the timed launches' intervals (HIP events on the lanes' common timeline) / launches"},
+           "cpu_baseline": {"value": 1366.0, "unit": "primers/s", "cores": 1, "kind": "port", "sample": "s"}, "parity_sample": None}
+    out.update(extra)
+    return _strict(bench.contract_line(bench._finite(out), "d.json"))
+
+
+def test_contract_line_carries_sustained_and_the_parallel_cpu_figure():
+    """(ii) + (iii)"""
+    j = _line_with({"sustained": {"value": 5.1e8, "unit": "primers/s", "seconds": 1.18, "steps": 6000, "ms_per_step": 0.196, "note": "n" * 500},
+                    "cpu_baseline_parallel": {"value": 18100.0, "unit": "primers/s", "cores": 128, "kind": "port", "cpu_model": "m", "sample": "s" * 900}})
+    assert j["sustained"] == {"value": 5.1e8, "unit": "primers/s", "seconds": 1.18, "steps": 6000, "ms_per_step": 0.196}
+    assert j["sustained"]["seconds"] >= 1.0
+    assert j["cpu_baseline_parallel"] == {"value": 18100.0, "unit": "primers/s", "cores": 128, "kind": "port"}
+    assert j["cpu_baseline"]["cores"] == 1
+    j0 = _line_with({})
+    assert j0["sustained"] is None and j0["cpu_baseline_parallel"] is None   # the keys are always there
+
+
+def test_roofline_quotes_the_rocprof_average_next_to_the_busy_time():
+    """(iv) kernel_avg_us_rocprof / frac_rocprof_avg come from profiles/kernel_stats_<tag>.json of the same build and workload, else null"""
+    import bench
+    roof = {"bound": "hbm", "kernel": "k_search1s<true, true>", "achieved": 800.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1,
+            "algorithmic_bytes_per_launch": 122.9e6, "kernel_ms": 0.1547, "kernel_ms_is": "busy time per launch: union of ..."}
+    tag = "_test_tag"
+    prof = os.path.join(ROOT, "profiles", bench.kernel_stats_file(tag))
+    try:
+        json.dump({"build_id": bench.build_id(), "workload": tag,
+                   "kernels": {"k_search1s<true, true>": {"calls": 47, "avg_us": 195.6, "min_us": 139.4, "max_us": 425.8}}}, open(prof, "w"))
+        r = bench.rocprof_average(roof, tag)
+        assert r["kernel_avg_us_rocprof"] == 195.6 and r["kernel_ms"] == 0.1547
+        assert abs(r["frac_rocprof_avg"] - 122.9e6 / 195.6e-6 / 8e12) < 1e-9 and r["frac_rocprof_avg"] < r["frac"]
+        j = _line_with({"roofline": r})
+        assert j["roofline"]["kernel_avg_us_rocprof"] == 195.6 and abs(j["roofline"]["frac_rocprof_avg"] - 0.0785) < 1e-3
+        assert j["roofline"]["kernel_ms_is"].startswith("busy time")
+        assert bench.rocprof_average(dict(roof, kernel="k_search1s<true, false>"), tag)["kernel_avg_us_rocprof"] is None   # another instantiation
+        assert bench.rocprof_average(roof, "other_tag")["kernel_avg_us_rocprof"] is None                                  # another workload
+        json.dump({"build_id": "0" * 16, "workload": tag, "kernels": {"k_search1s<true, true>": {"calls": 1, "avg_us": 1.0}}}, open(prof, "w"))
+        assert bench.rocprof_average(roof, tag)["kernel_avg_us_rocprof"] is None                                          # another build
+    finally:
+        os.remove(prof)
+
+
+def test_cap_enum_block_is_labelled_latency_bound():
+    """(v) no fraction of the HBM peak is claimed for k_cap_enum"""
+    import bench
+    r = bench.cap_enum_roofline(4000, 25, 2, 18.3)
+    assert r["bound"] == "latency" and r["frac"] is None and r["kernel"] == "k_cap_enum" and r["traffic"] is None
+    assert r["achieved"] > 0 and 0 < r["hbm_frac_upper_bound"] < 1
+    j = _line_with({"roofline": bench.rocprof_average(r, "none")})
+    assert j["roofline"]["bound"] == "latency" and j["roofline"]["frac"] is None and j["roofline"]["frac_rocprof_avg"] is None

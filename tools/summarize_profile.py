@@ -54,7 +54,27 @@ def main():
     if os.path.exists(lp):
         line = [ln for ln in open(lp) if ln.startswith("{")][-1]
         open(os.path.join(OUT, f"{R}_bench.json"), "w").write(line)
+    import bench as B
     stats = os.path.join(P, "trace", "trace_kernel_stats.csv")
+    # the workload the profile was taken on: the profiled run's own word (config.workload_tag, r06), else rebuilt from its text
+    wtag = bench["config"].get("workload_tag")
+    if not wtag:
+        m0 = re.search(r"(\d+) synthetic (\d+)-mers per GPU, (edit|Hamming) distance (\d+)", bench["config"]["workload"])
+        n0 = re.search(r"(\d+)% of the queries with one N", bench["config"]["workload"])
+        wtag = B.workload_tag(int(m0.group(1)), int(m0.group(2)), int(m0.group(4)), m0.group(3) == "Hamming", int(n0.group(1)) / 100 if n0 else 0.0,
+                              3.1e9, "repeats" if "planted repeat" in bench["config"]["genome"] else "iid")
+    if os.path.exists(stats):
+        # the same rows as JSON, keyed by the bare instantiation name and stamped with build_id + workload: bench.py quotes the
+        # rocprofv3 AVERAGE duration of the roofline's kernel from it, next to its own busy-time figure
+        kern = {}
+        for r in csv.DictReader(open(stats)):
+            kern[bare(short_kernel_name(r["Name"]))] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                                                        "max_us": float(r["MaxNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+        traced = os.path.join(P, "bench_detail_traced.json")
+        tb = json.load(open(traced)) if os.path.exists(traced) else bench
+        json.dump({"workload": wtag, "round": R, "build_id": tb.get("build_id") or B.build_id(),
+                   "command": "rocprofv3 --kernel-trace --stats -- python bench.py --fm9 <index> --no-cpu-baseline --no-extras" , "kernels": kern},
+                  open(os.path.join(OUT, B.kernel_stats_file(wtag)), "w"), indent=1)
     if os.path.exists(stats):
         with open(os.path.join(OUT, f"{R}_bench_kernel_stats.csv"), "w") as f:  # long template names shortened, nothing dropped
             f.write("# rocprofv3 --kernel-trace --stats of the bench command on the reused index (--no-cpu-baseline --no-extras)\n")
@@ -92,10 +112,9 @@ def main():
     if gk and (gk[0], "FETCH_SIZE") in means:
         cal = dict(cal, FETCH_SIZE_bytes=means[(gk[0], "FETCH_SIZE")] * 1024, measured_in=R)
         cal["factor"] = cal["FETCH_SIZE_bytes"] / cal["known_bytes"]
-    m = re.search(r"(\d+) synthetic (\d+)-mers per GPU, edit distance (\d+)", bench["config"]["workload"])
-    gen = "repeats" if "planted repeat" in bench["config"]["genome"] else "iid"
-    import bench as B
-    t = {"workload": f"{m.group(1)}x{m.group(2)}mer_d{m.group(3)}_n3100000000_{gen}", "kernel": kernel, "pmc_row": ks,
+    if len(sys.argv) <= 3 and bench["config"].get("traffic_file"):
+        tname = bench["config"]["traffic_file"]
+    t = {"workload": wtag, "kernel": kernel, "pmc_row": ks,
          "dispatches_in_row": ndisp[(ks, "FETCH_SIZE")], "round": R,
          "build_id": bench.get("build_id") or B.build_id(),  # the sources the PROFILED run was built from (bench.py stamps its detail)
          "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,

@@ -105,7 +105,26 @@ struct FmView {
   static constexpr u32 MAXLEV = 10;
   const u32* samin[MAXLEV];
   u32 nlev;  // levels present, including level 0; 0 = no hierarchy
+  // Suffix array WITH context (derived at load, r06): sax[i] = {SA[i], context word of suffix i}.  The verify stage needs, per
+  // located hit, the <= d characters in front of and behind the neighbourhood string (hunter.h:363-378) — one random 64-byte
+  // text line per hit, which is what bounded the repeat-rich regime (17 M hits per 100 000 queries: DESIGN "repeats").  The
+  // locate job kernels read the suffix-array entries of their survivors anyway; an 8-byte entry brings the context along with
+  // the position, in the line that is being fetched.  Context word (sax_ctx_*): bits 0-3 the two characters in front of the
+  // suffix (T[p-1], T[p-2]; 2 bits each), bits 4-29 the thirteen characters T[p+16 .. p+28] (2 bits each, nearest first): the
+  // characters behind a string of 16..27 characters that starts at p, bit 31 = some character of either window is not
+  // A/C/G/T or lies outside the text (the hit then reads the text as before).  nullptr = not built.
+  const uint2* sax;
 };
+static constexpr u32 SAX_POST_OFF = 16, SAX_POST_N = 13, SAX_ESCAPE = 0x80000000u;
+// HitSeed::len of a located hit that carries its context (set by the locate job kernels, read by k_verify_memo only): bits 0-19 the
+// string's length, bit 31 "context valid", bits 20-21 / 22-23 the codes of T[pos-1] / T[pos-2], bits 24-25 / 26-27 of T[pos+len] /
+// T[pos+len+1] (0..3 = A,C,G,T).  Valid only for strings whose two following characters lie inside the context word's window.
+static constexpr u32 SEED_LEN_MASK = 0xFFFFFu, SEED_CTX_VALID = 0x80000000u;
+__host__ __device__ inline u32 seed_len_with_ctx(u32 len, u32 ctx) {
+  if ((ctx & SAX_ESCAPE) || len < SAX_POST_OFF || len + 2 > SAX_POST_OFF + SAX_POST_N) return len;
+  const u32 post = (ctx >> (4 + 2 * (len - SAX_POST_OFF))) & 15u;
+  return len | ((ctx & 15u) << 20) | (post << 24) | SEED_CTX_VALID;
+}
 
 struct KtabEntry {
   u32 lo, hi;

@@ -774,6 +774,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipMemcpyAsync(pb->p, ws[WS_PACK].p, L.bytes, hipMemcpyDeviceToHost, st));
     return DG_OK;
   };
+  std::vector<u32> dump_cnt;
   for (int attempt = 0;; ++attempt) {
     if (attempt > 8) return fail(DG_ENOMEM, "buffer overflow persists (%llu leaves, %llu hits)", (unsigned long long)nleaf, (unsigned long long)nhits);
     const u64 leaf_slots = (u64)NSHARD * shard_cap;
@@ -799,7 +800,10 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_TRY(ws[WS_SCR].reserve((leaf_slots + 1) * 5 + 64));
     DG_TRY(ws[WS_SEEDS].reserve((hit_cap + 1) * sizeof(HitSeed)));
     const u32 surv_cap = 0xFFFFFFFFu;  // (r02's survivor queue in HBM is gone with k_probe1 / k_finish1; the scan kernel's check keeps its argument)
-    DG_TRY(ws[WS_JOBS].reserve(2 * std::min<u64>(leaf_slots, 1u << 20) * sizeof(BigJob)));
+    // locate jobs: three lists of JOB_SHARDS regions each (hunt_locate.hpp); a region that fills up turns its strings away to the
+    // queueing lane, so the size is a matter of speed only
+    const u32 job_shard_cap = (u32)(std::min<u64>(leaf_slots, 1u << 20) / JOB_SHARDS * 3 / 2 + 32);
+    DG_TRY(ws[WS_JOBS].reserve(3 * (u64)JOB_SHARDS * job_shard_cap * sizeof(BigJob)));
     DG_TRY(ws[WS_HITS].reserve((hit_cap + 1) * sizeof(dg_hit)));
     if (stride && !sx && !group_counts) DG_TRY(ws[WS_ALN].reserve((hit_cap + 1) * 2 * (u64)stride));
     if (!sx && !group_counts) DG_TRY(ws[WS_OPS].reserve((hit_cap + 1) * (u64)ops_per_hit * 4 + 64));
@@ -959,45 +963,48 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_TRY(device_scan(st, qhits, nq, hit_off, scan_buf));
     if (phase_events) DG_HIP(hipEventRecord(ix->ev[5], st));
     {
-      // strings with many occurrences go to two job lists: up to 256 occurrences for a wavefront each, more for a workgroup each
-      const u32 job_cap = (u32)std::min<u64>(leaf_slots, 1u << 20);
+      // strings with many occurrences go to three job lists: up to 256 occurrences for a wavefront each, more for a workgroup each
+      // (those that fit the small buffer of k_locate_topk whole, and the rest)
+      jobs_on = ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX;
+      // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
+      const bool topk = ix->view.nlev > 1;
+      // A batch with thousands of repeat-rich strings (the previous batch of this handle tells): intervals up to 4 608 entries go
+      // to the small-buffer form of k_locate_topk.  (r03 also ran the three job kernels side by side on helper streams: each
+      // slowed down by what the others took — 114 / 220 / 228 us alone, 220 / 494 / 268 us together — and the stage gained
+      // 0.08 of 0.91 ms; not worth two more streams per handle.)
+      const bool rich = topk && ix->jobs_big_hint >= 2048;
       LocJobs lj;
-      lj.small = ws[WS_JOBS].as<BigJob>();
-      lj.big = ws[WS_JOBS].as<BigJob>() + job_cap;
-      lj.cap = job_cap;
-      lj.n_big = (u32*)&ctr->pad_[0];
-      lj.n_small = (u32*)&ctr->pad_[4];
+      for (int l = 0; l < 3; ++l) lj.list[l] = ws[WS_JOBS].as<BigJob>() + (u64)l * JOB_SHARDS * job_shard_cap;
+      lj.shard_cap = job_shard_cap;
+      lj.cnt = ctr->job_cnt;
+      lj.mid_max = rich ? 8 * TOPK_KCAP_MID : 0u;
+      // hits of the job kernels leave with their context characters (FmView::sax) when the kernel that reads the seeds is
+      // k_verify_memo — the only reader that knows the encoding (HitSeed::len, devfm.hpp)
+      const u32 with_ctx = (!sx && !group_counts && band_verify && ix->view.sax) ? 1u : 0u;
       // the record that shares a kept string's slot names its group: the packed leaf (qs behind 28 bytes) or the grouped leaf (qs first)
       const u8* slot_qs = packed ? (const u8*)ws[WS_LEAFG].p + offsetof(PLeaf, qs) : (const u8*)ws[WS_LEAFG].p + offsetof(Leaf, qs);
       const u32 slot_stride = packed ? (u32)sizeof(PLeaf) : (u32)sizeof(Leaf);
       hipLaunchKernelGGL(k_locate, dim3(ceil_div(flat_slots + (generic_on ? leaf_slots : 0), TB)), dim3(TB), 0, st, ix->view, (const Sel*)sel_all, slot_qs,
                          slot_stride, (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj,
-                         flat_slots, flat_cap, (u32)generic_on, (u32)(ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX));
+                         flat_slots, flat_cap, (u32)generic_on, (u32)jobs_on);
       // The job kernels (strings of more than 16 occurrences) are launched when the previous batch of this handle queued any job;
       // k_locate queues and counts whether or not they run, and a batch that had jobs after one that had none is repeated with
       // them (the same device as for capacity guesses).  Uniform batches on a genome without repeats never launch them.
-      jobs_on = ix->jobs_hint || force_jobs || p->max_locations > TOPK_KMAX;
       if (jobs_on) {
-        // repeat-rich strings: up to TOPK_KMAX positions through the block minima, more (hunt -m above 1 024) by radix passes
-        const bool topk = ix->view.nlev > 1;
-        // A batch with thousands of repeat-rich strings (the previous batch of this handle tells): intervals up to 4 608 entries go
-        // to the small-buffer form of k_locate_topk.  (r03 also ran the three job kernels side by side on helper streams: each
-        // slowed down by what the others took — 114 / 220 / 228 us alone, 220 / 494 / 268 us together — and the stage gained
-        // 0.08 of 0.91 ms; not worth two more streams per handle.)
-        const bool rich = topk && ix->jobs_big_hint >= 2048;
-        const u32 mid_max = rich ? 8 * TOPK_KCAP_MID : 0u;
-        hipLaunchKernelGGL(k_locate_small, dim3(8192), dim3(64), 0, st, ix->view, (const BigJob*)lj.small, (const u32*)lj.n_small, job_cap,
-                           ws[WS_SEEDS].as<HitSeed>(), ctr);
+        hipLaunchKernelGGL(k_locate_small, dim3(8192), dim3(64), 0, st, ix->view, lj, ws[WS_SEEDS].as<HitSeed>(), ctr, with_ctx);
         if (topk) {
-          if (mid_max)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_locate_topk<TOPK_KCAP_MID>), dim3(1536), dim3(256), 0, st, ix->view, (const BigJob*)lj.big,
-                               (const u32*)lj.n_big, job_cap, (u32*)&ctr->pad_[8], ws[WS_SEEDS].as<HitSeed>(), ctr, 0u, mid_max);
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_locate_topk<TOPK_KCAP>), dim3(768), dim3(256), 0, st, ix->view, (const BigJob*)lj.big,
-                             (const u32*)lj.n_big, job_cap, (u32*)&ctr->pad_[3], ws[WS_SEEDS].as<HitSeed>(), ctr, mid_max, 0xFFFFFFFFu);
+          if (lj.mid_max)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_locate_topk<TOPK_KCAP_MID>), dim3(1280), dim3(256), 0, st, ix->view, lj, (u32)JL_MID,
+                               ws[WS_SEEDS].as<HitSeed>(), ctr, with_ctx);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_locate_topk<TOPK_KCAP>), dim3(768), dim3(256), 0, st, ix->view, lj, (u32)JL_BIG,
+                             ws[WS_SEEDS].as<HitSeed>(), ctr, with_ctx);
         }
         if (!topk || p->max_locations > TOPK_KMAX)
-          hipLaunchKernelGGL(k_locate_big, dim3(1024), dim3(256), 0, st, ix->view, (const BigJob*)lj.big, (const u32*)lj.n_big, job_cap,
-                             ws[WS_SEEDS].as<HitSeed>(), ctr, topk ? TOPK_KMAX : 0u);
+          hipLaunchKernelGGL(k_locate_big, dim3(1024), dim3(256), 0, st, ix->view, lj, ws[WS_SEEDS].as<HitSeed>(), ctr, topk ? TOPK_KMAX : 0u);
+      }
+      if (!sw.dump_jobs.empty()) {  // development aid: the regions' fill counts, before the summary kernel clears them
+        dump_cnt.assign(3 * JOB_SHARDS, 0);
+        DG_HIP(hipMemcpyAsync(dump_cnt.data(), ctr->job_cnt, sizeof(u32) * 3 * JOB_SHARDS, hipMemcpyDeviceToHost, st));
       }
     }
     if (phase_events) DG_HIP(hipEventRecord(ix->ev[6], st));
@@ -1092,17 +1099,20 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     if (hsum.refused)
       return fail(DG_EINVAL, "internal error: %llu quer%s could reach the maxNeighborhood cap (%u) without having been enumerated on the host",
                   hsum.refused, hsum.refused == 1 ? "y" : "ies", p->max_neighborhood);
-    if (const char* dj = sw.dump_jobs.empty() ? nullptr : sw.dump_jobs.c_str()) {  // development aid: (lo, occs, take) of the batch's locate jobs, small then big
-      const u32 jc = (u32)std::min<u64>(leaf_slots, 1u << 20);
-      const u32 ns_ = (u32)std::min<u64>(hsum.jobs_small, jc), nb_ = (u32)std::min<u64>(hsum.jobs_big, jc);
-      std::vector<BigJob> hj((size_t)ns_ + nb_);
-      if (ns_) DG_HIP(hipMemcpy(hj.data(), ws[WS_JOBS].as<BigJob>(), (size_t)ns_ * sizeof(BigJob), hipMemcpyDeviceToHost));
-      if (nb_) DG_HIP(hipMemcpy(hj.data() + ns_, ws[WS_JOBS].as<BigJob>() + jc, (size_t)nb_ * sizeof(BigJob), hipMemcpyDeviceToHost));
+    if (const char* dj = (sw.dump_jobs.empty() || dump_cnt.empty()) ? nullptr : sw.dump_jobs.c_str()) {  // development aid: (lo, occs, take, len) of the batch's locate jobs, list after list
       if (FILE* fj = std::fopen(dj, "wb")) {
-        for (const BigJob& j : hj) {
-          const u32 rec[4] = {j.lo, j.occs, j.take, j.len};
-          std::fwrite(rec, 4, 4, fj);
-        }
+        std::vector<BigJob> hj;
+        for (u32 l = 0; l < 3; ++l)
+          for (u32 sh = 0; sh < JOB_SHARDS; ++sh) {
+            const u32 c = std::min(dump_cnt[l * JOB_SHARDS + sh], job_shard_cap);
+            if (!c) continue;
+            hj.resize(c);
+            DG_HIP(hipMemcpy(hj.data(), ws[WS_JOBS].as<BigJob>() + ((u64)l * JOB_SHARDS + sh) * job_shard_cap, (size_t)c * sizeof(BigJob), hipMemcpyDeviceToHost));
+            for (const BigJob& j : hj) {
+              const u32 rec[4] = {j.lo, j.occs, j.take, j.len | (l << 28)};
+              std::fwrite(rec, 4, 4, fj);
+            }
+          }
         std::fclose(fj);
       }
     }

@@ -74,7 +74,11 @@ struct Counters {
   u32 surv_cnt[NSHARD];  // filter survivors queued in each shard's region of the survivor buffer (k_probe1 -> k_finish1)
   u32 sel_cnt[NSHARD];   // kept strings in each shard's slice of the flat Sel region (k_search1s)
   unsigned long long fused_leaves[NSHARD];  // occurring strings k_search1s settled in LDS
+  // locate jobs queued by k_locate (hunt_locate.hpp): per list JOB_SHARDS producer counters — ONE word per list cost ~11 ns per
+  // wavefront that queued a job (40 000 of them on a repeat-rich batch: most of that kernel's 0.26 ms, r05 counters)
+  u32 job_cnt[3][64];
 };
+static constexpr u32 JOB_SHARDS = 64;
 
 struct HitSeed {  // 16 bytes, read as one uint4
   u32 pos;  // text position of the neighbourhood string

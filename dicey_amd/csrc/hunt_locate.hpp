@@ -18,13 +18,43 @@ struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_t
 // grouped leaf of the same slot (slot_qs: address of that record's `qs` field, slot_stride: record size), serves strings of up to
 // 24 occurrences itself and queues the others: up to 256 occurrences for one wavefront (k_locate_small), more for one
 // workgroup (k_locate_topk / k_locate_big).
+// r06: three lists (wavefront jobs, workgroup jobs that fit the small buffer whole, the rest), each in JOB_SHARDS regions with a
+// producer counter of their own, and consumers that take jobs by their number (static stride) — r05 had ONE word per list for the
+// producers and ONE `next job` word per consumer kernel: ~40 000 + 2 x 16 000 returning atomics on hot words per repeat-rich batch at
+// ~11 ns each, i.e. most of the stage's 0.9 ms (r05 counters: 1 800 vector instructions per job and 30 us per job).
+enum : u32 { JL_SMALL = 0, JL_MID = 1, JL_BIG = 2 };
 struct LocJobs {
-  BigJob* small;
-  BigJob* big;
-  u32 cap;  // of each list
-  u32* n_small;
-  u32* n_big;
+  BigJob* list[3];  // JOB_SHARDS regions of shard_cap jobs each
+  u32 shard_cap;
+  u32 (*cnt)[JOB_SHARDS];  // Counters::job_cnt (a region that overflows keeps counting: readers clamp to shard_cap)
+  u32 mid_max;             // workgroup jobs of up to this many occurrences (and take <= TOPK_KMAX) go to JL_MID; 0 = no such list
 };
+// flat job number -> slot of the list: the regions' fill counts as an exclusive prefix in LDS (64 counters, once per workgroup)
+struct JobIndex {
+  u32 pre[JOB_SHARDS + 1];
+};
+DG_DEV void job_index_init(JobIndex& J, const u32* cnt, u32 shard_cap) {  // every lane of the workgroup (>= 64 lanes) calls it
+  if (threadIdx.x < JOB_SHARDS) {
+    const u32 c = cnt[threadIdx.x] < shard_cap ? cnt[threadIdx.x] : shard_cap;
+    u32 incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 v = __shfl_up(incl, off);
+      if ((int)threadIdx.x >= off) incl += v;
+    }
+    J.pre[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) J.pre[0] = 0;
+  }
+  __syncthreads();
+}
+DG_DEV u32 job_slot(const JobIndex& J, u32 shard_cap, u32 j) {
+  u32 lo = 0, hi = JOB_SHARDS;
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (J.pre[mid] <= j) lo = mid;
+    else hi = mid;
+  }
+  return lo * shard_cap + (j - J.pre[lo]);
+}
 static constexpr u32 LOC_SMALL_MAX = 256;
 // A string with up to N occurrences: N loads in flight, a bitonic network on registers (every index is a compile-time constant —
 // r02's insertion sort indexed a private array dynamically, i.e. through scratch memory), `take` stores.
@@ -91,15 +121,6 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
       } else if (occs <= 16) {
         locate_in_registers<16>(f.sa + lo, occs, take, out, g, slen, (u32)t, fmask, back);
         reads += occs;
-      } else if (jobs.big && take <= 16384) {
-        bj.lo = lo;
-        bj.occs = occs;
-        bj.take = take;
-        bj.g = g;
-        bj.len = slen;
-        bj.slot = (u32)t;
-        bj.out = out0;
-        queue = occs <= LOC_SMALL_MAX ? 1u : 2u;
       } else {
         bj.lo = lo;
         bj.occs = occs;
@@ -108,30 +129,33 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
         bj.len = slen;
         bj.slot = (u32)t;
         bj.out = out0;
-        queue = 3u;  // served by this lane, below
+        // (hunt -m above 16 384: served by this lane, below)
+        queue = take > 16384 ? 4u : occs <= LOC_SMALL_MAX ? 1u : (occs <= jobs.mid_max && take <= TOPK_KMAX) ? 2u : 3u;
       }
     }
   }
   const u32 lane = threadIdx.x & 63;
-  // job slots: one atomic per wavefront and list (every lane on the two list heads was what this kernel waited for)
-  for (u32 which = 1; which <= 2; ++which) {
+  // job slots: one atomic per wavefront and list, on the counter of this wavefront's region
+  const u32 shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) & (JOB_SHARDS - 1);
+  for (u32 which = 1; which <= 3; ++which) {
     const unsigned long long mk = __ballot(queue == which);
     if (!mk) continue;
+    const u32 leader = (u32)__ffsll((long long)mk) - 1u;
     // the job kernels were left out of this attempt: nobody will write these strings' hits, so the verify kernel must not run
     // (the host sees the job counts and repeats the batch with the job kernels)
-    if (!jobs_on && lane == (u32)__ffsll((long long)mk) - 1u) atomicOr(&ctr->overflow, 4u);
+    if (!jobs_on && lane == leader) atomicOr(&ctr->overflow, 4u);
     u32 base = 0;
-    if (lane == (u32)__ffsll((long long)mk) - 1u) base = atomicAdd(which == 1 ? jobs.n_small : jobs.n_big, (u32)__popcll(mk));
-    base = __shfl(base, (int)__ffsll((long long)mk) - 1);
+    if (lane == leader) base = atomicAdd(&jobs.cnt[which - 1][shard], (u32)__popcll(mk));
+    base = __shfl(base, (int)leader);
     if (queue == which) {
       const u32 j = base + (u32)__popcll(mk & ((1ULL << lane) - 1));
-      if (j < jobs.cap) (which == 1 ? jobs.small : jobs.big)[j] = bj;
-      else queue = 3u;  // a full list (more than 2^20 repeat-rich strings in one batch): nothing is dropped, the lane serves it
+      if (j < jobs.shard_cap) jobs.list[which - 1][(u64)shard * jobs.shard_cap + j] = bj;
+      else queue = 4u;  // a full region: nothing is dropped, the lane serves it
     }
   }
-  if (queue == 3u) {
+  if (queue == 4u) {
     // correct for any size, slow: selection by repeated minimum above the previous pick (positions are distinct).  Reached with
-    // hunt -m above 16 384, with DICEY_NO_BLOCK_LOCATE, and by the strings a full job list turned away.
+    // hunt -m above 16 384 and by the strings a full job region turned away.
     u64 prev = 0;
     bool first = true;
     for (u32 i = 0; i < bj.take; ++i) {
@@ -149,19 +173,32 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
   wave_add(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], reads);
 }
 
-// One WAVEFRONT per string of 25..256 occurrences (most of the queued strings on a repeat-bearing genome: 54 k of 72 k per
+// One WAVEFRONT per string of 17..256 occurrences (most of the queued strings on a repeat-bearing genome: 54 k of 72 k per
 // 100 000 queries): the interval is read once, sorted in LDS by the wavefront alone (bitonic, no workgroup barrier to wait
-// for), the first `take` values are written.  Jobs are taken in grid order: they all cost about the same.
-__global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds, Counters* ctr) {
-  __shared__ u32 buf[LOC_SMALL_MAX];
-  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+// for), the first `take` values are written.  Jobs by number, static stride: they all cost about the same.
+// r06: keys are (position << 32 | context word) — read from FmView::sax when the verify kernel that follows takes the hits' context
+// from their seeds (with_ctx), else position << 32 | SAX_ESCAPE ("no context": the seed's length stays plain).
+__global__ void __launch_bounds__(64) k_locate_small(FmView f, LocJobs jobs, HitSeed* seeds, Counters* ctr, u32 with_ctx) {
+  __shared__ u64 buf[LOC_SMALL_MAX];
+  __shared__ JobIndex JI;
+  job_index_init(JI, jobs.cnt[JL_SMALL], jobs.shard_cap);
+  const u32 njobs = JI.pre[JOB_SHARDS];
+  const bool sax_on = with_ctx && f.sax;
   u64 reads = 0;
   for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
-    const BigJob J = jobs[jb];
+    const BigJob J = jobs.list[JL_SMALL][job_slot(JI, jobs.shard_cap, jb)];
     u32 n2 = 32;
     while (n2 < J.occs) n2 <<= 1;
-    const u32* sa = f.sa + J.lo;
-    for (u32 i = threadIdx.x; i < n2; i += 64) buf[i] = i < J.occs ? sa[i] : 0xFFFFFFFFu;
+    for (u32 i = threadIdx.x; i < n2; i += 64) {
+      u64 key = ~0ULL;
+      if (i < J.occs) {
+        if (sax_on) {
+          const uint2 r = f.sax[(u64)J.lo + i];
+          key = ((u64)r.x << 32) | r.y;
+        } else key = ((u64)f.sa[(u64)J.lo + i] << 32) | SAX_ESCAPE;
+      }
+      buf[i] = key;
+    }
     reads += J.occs;
     __syncthreads();
     for (u32 kk = 2; kk <= n2; kk <<= 1)
@@ -169,7 +206,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
         for (u32 i = threadIdx.x; i < n2; i += 64) {
           const u32 l = i ^ jj;
           if (l > i) {
-            const u32 a = buf[i], b2 = buf[l];
+            const u64 a = buf[i], b2 = buf[l];
             if ((a > b2) == ((i & kk) == 0)) {
               buf[i] = b2;
               buf[l] = a;
@@ -178,7 +215,8 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
         }
         __syncthreads();
       }
-    for (u32 i = threadIdx.x; i < J.take; i += 64) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
+    for (u32 i = threadIdx.x; i < J.take; i += 64)
+      seeds[J.out + i] = HitSeed{(u32)(buf[i] >> 32), J.g, seed_len_with_ctx(J.len, (u32)buf[i]), J.slot};
     __syncthreads();
   }
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
@@ -190,15 +228,16 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, const BigJob* job
 // of that bin fits the LDS buffer (on a genome-wide repeat family that is after the first pass: positions spread over the
 // whole text, so one top-byte bin holds occs/185 values).  One more pass collects those values, a bitonic sort orders
 // them.  2-3 coalesced passes over the interval instead of 33 (r02: 33 ms -> see DESIGN.md on the repeat-rich genome).
-__global__ void __launch_bounds__(256) k_locate_big(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, HitSeed* seeds,
-                                                    Counters* ctr, u32 topk_kmax) {
+__global__ void __launch_bounds__(256) k_locate_big(FmView f, LocJobs jobs, HitSeed* seeds, Counters* ctr, u32 topk_kmax) {
   constexpr u32 CAP = 16384;
   __shared__ u32 buf[CAP];
   __shared__ u32 hist[256];
   __shared__ u32 fill, s_prefix, s_mask, s_k, s_below, s_done;
-  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+  __shared__ JobIndex JI;
+  job_index_init(JI, jobs.cnt[JL_BIG], jobs.shard_cap);
+  const u32 njobs = JI.pre[JOB_SHARDS];
   for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
-    const BigJob J = jobs[jb];
+    const BigJob J = jobs.list[JL_BIG][job_slot(JI, jobs.shard_cap, jb)];
     if (f.nlev > 1 && J.take <= topk_kmax) continue;  // k_locate_topk's
     const u32* sa = f.sa + J.lo;
     // refine until at most `limit` values are left to sort: sorting costs n log^2 n, another pass over the interval does not
@@ -297,13 +336,15 @@ static constexpr u32 TOPK_KCAP = 1152;         // blocks kept per level: k plus 
 static constexpr u32 TOPK_PAD = 0xFFFFFFFFu;
 template <u32 KC>
 struct TopkLdsT {
+  static constexpr u32 CW = 2 * KC > 2 * TOPK_KMAX ? 2 * KC : 2 * TOPK_KMAX;  // words: both index lists, or the final TOPK_KMAX 64-bit keys
   u32 val[8 * KC + 16];
-  u32 cidx[2][KC];
+  alignas(8) u32 cidx[CW];  // [cur * KC + i]; at the entries: the survivors' (position << 32 | context word) keys
   u32 eidx[16];
   u32 hist[256];
   u32 wsum[4];
   u32 sh[4];
-  u32 n_kept, job;
+  u32 n_kept;
+  JobIndex ji;
 };
 // Bitonic sort of n2 keys (n2 a power of two <= 1024; keys behind n2 must be the type's maximum) by a 256-lane workgroup with four
 // keys per lane in registers: key i lives in lane i / 4.  Partners at distance 1-2 are in the same lane, at distance 4-128 in the
@@ -391,28 +432,27 @@ DG_DEV u32 topk_threshold(LDS& S, u32 nv, u32 k, u32 limit) {
     kk -= ex;
   }
 }
-// KC = TOPK_KCAP: any interval (walks the hierarchy).  KC = TOPK_KCAP_MID (r03): intervals that fit the smaller buffer whole (level 0
-// only, no expansion) — 24 instead of 46 KB of LDS, six instead of three workgroups per CU; on the repeats genome two thirds of the
-// 17 000 jobs of a step are of that kind.  Both walk the same job list and skip what belongs to the other (occ_lo < occs <= occ_hi).
+// KC = TOPK_KCAP: any interval (walks the hierarchy), list JL_BIG.  KC = TOPK_KCAP_MID (r03): intervals that fit the smaller buffer
+// whole (level 0 only, no expansion), list JL_MID — 26 instead of 46 KB of LDS; on the repeats genome two thirds of the 17 000
+// workgroup jobs of a step are of that kind.
+// r06: (i) jobs by number with a static stride (no `next job` word: see LocJobs); (ii) with_ctx: the entries are read from
+// FmView::sax, and the survivors leave with their context word — at the entries a survivor's slot in `val` is overwritten by its
+// index inside the interval, and once the index lists are dead the record {position, context} is read again (an L2 hit: this
+// workgroup fetched the line a moment ago) into a 64-bit key, so the sort carries the context along.
 static constexpr u32 TOPK_KCAP_MID = 576;
 template <u32 KC>
-__global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* jobs, const u32* job_count, u32 job_cap, u32* next_job,
-                                                     HitSeed* seeds, Counters* ctr, u32 occ_lo, u32 occ_hi) {
+__global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32 which, HitSeed* seeds, Counters* ctr, u32 with_ctx) {
   constexpr u32 VMAXT = 8 * KC + 16;
   __shared__ TopkLdsT<KC> S;
-  const u32 njobs = *job_count < job_cap ? *job_count : job_cap;
+  job_index_init(S.ji, jobs.cnt[which], jobs.shard_cap);
+  const u32 njobs = S.ji.pre[JOB_SHARDS];
   const u32 lane = threadIdx.x & 63;
+  const bool sax_on = with_ctx && f.sax;
   u64 reads = 0;
-  // jobs: the first gridDim.x by workgroup number, the rest from a counter (an empty list costs no atomic: 768 workgroups on one
-  // word were 8 of the 10.7 us this kernel took on a batch without repeat-rich strings)
-  for (u32 round = 0;; ++round) {
+  for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
     __syncthreads();  // the previous job's buffers are free
-    if (threadIdx.x == 0) S.job = round == 0 ? blockIdx.x : gridDim.x + atomicAdd(next_job, 1u);
-    __syncthreads();
-    const u32 jb = S.job;
-    if (jb >= njobs) break;
-    const BigJob J = jobs[jb];
-    if (J.take > TOPK_KMAX || J.occs <= occ_lo || J.occs > occ_hi) continue;  // k_locate_big's / the other buffer size's
+    const BigJob J = jobs.list[which][job_slot(S.ji, jobs.shard_cap, jb)];
+    if (J.take > TOPK_KMAX) continue;  // k_locate_big's (hunt -m above 1 024)
     const u32 k = J.take;
     const u64 lo = J.lo, hi = (u64)J.lo + J.occs;
     // full blocks of level j inside [lo, hi): [A(j), B(j))
@@ -421,47 +461,68 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
     auto N = [&](int j) -> u64 { return B(j) > A(j) ? B(j) - A(j) : 0ULL; };
     int L = 0;
     while (L + 1 < (int)f.nlev && N(L) > VMAXT - 16) ++L;  // a level left with more than 9 216 blocks has > 1 000 in the next
-    if (N(L) > VMAXT - 16) continue;  // cannot happen: the top level of FmView::samin holds <= 64 blocks
+    if (N(L) > VMAXT - 16) continue;  // cannot happen: the top level of FmView::samin holds <= 64 blocks (JL_MID: occs <= 8 KC)
     u32 nv = (u32)N(L);
-    {
+    if (L == 0 && sax_on) {
+      const uint2* src = f.sax + A(0);
+      for (u32 i = threadIdx.x; i < nv; i += 256) S.val[i] = src[i].x;
+    } else {
       const u32* src = f.samin[L] + A(L);
       for (u32 i = threadIdx.x; i < nv; i += 256) S.val[i] = src[i];
-      reads += nv;
     }
+    reads += nv;
     u32 nc_prev = 0;
-    int cur = 0;
+    u32 cur = 0;
     bool top = true;
     __syncthreads();
     for (int j = L;; --j) {
       // at the entries: up to 96 values more than asked for may survive (the sort drops them) — an exact k-th value costs the
       // radix select all four byte passes, a little slack usually ends it after two
-      const u32 limit = j == 0 ? (k + 96 < TOPK_KMAX ? k + 96 : (k > TOPK_KMAX ? k : TOPK_KMAX)) : KC;
+      const u32 limit = j == 0 ? (k + 96 < TOPK_KMAX ? k + 96 : TOPK_KMAX) : KC;
       const u32 T = nv > limit ? topk_threshold(S, nv, k, limit) : 0xFFFFFFFEu;
       if (threadIdx.x == 0) S.n_kept = 0;
       __syncthreads();
       if (j == 0) {  // the survivors are the answer: collect, sort, write
-        u32* buf = &S.cidx[0][0];
+        if (sax_on) {  // a survivor's slot takes its index inside the interval (the index lists are still alive here)
+          for (u32 p = threadIdx.x; p < nv; p += 256) {
+            const u32 x = S.val[p];
+            const bool keep = x <= T && x != TOPK_PAD;
+            u32 idx = TOPK_PAD;
+            if (keep) idx = (u32)((top ? A(0) + p : (p < 8 * nc_prev ? (u64)S.cidx[cur * KC + (p >> 3)] * 8u + (p & 7u) : (u64)S.eidx[p - 8 * nc_prev])) - lo);
+            S.val[p] = idx;
+          }
+          __syncthreads();
+        }
+        u64* keys = reinterpret_cast<u64*>(S.cidx);
         for (u32 base = 0; base < nv; base += 256) {
           const u32 p = base + threadIdx.x;
           const u32 x = p < nv ? S.val[p] : TOPK_PAD;
-          const bool keep = x <= T && x != TOPK_PAD;
+          const bool keep = sax_on ? x != TOPK_PAD : (x <= T && x != TOPK_PAD);
           const unsigned long long mk = __ballot(keep);
           u32 at = 0;
           if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
           at = __shfl(at, 0);
-          if (keep) buf[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = x;
+          if (keep) {
+            u64 key;
+            if (sax_on) {
+              const uint2 r = f.sax[lo + x];
+              key = ((u64)r.x << 32) | r.y;
+            } else key = ((u64)x << 32) | SAX_ESCAPE;
+            keys[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = key;
+          }
         }
         __syncthreads();
         const u32 have = S.n_kept;  // k .. k + 96 values (fewer when the whole interval is shorter); the k smallest are written
         u32 n2 = 4;
         while (n2 < have) n2 <<= 1;
-        u32 sv[4];
+        u64 sv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sv[r] = threadIdx.x * 4 + r < have ? buf[threadIdx.x * 4 + r] : TOPK_PAD;
-        block_sort4<u32>(buf, n2, sv);
+        for (int r = 0; r < 4; ++r) sv[r] = threadIdx.x * 4 + r < have ? keys[threadIdx.x * 4 + r] : ~0ULL;
+        block_sort4<u64>(keys, n2, sv);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (threadIdx.x * 4 + r < k) seeds[J.out + threadIdx.x * 4 + r] = HitSeed{sv[r], J.g, J.len, J.slot};
+          if (threadIdx.x * 4 + r < k)
+            seeds[J.out + threadIdx.x * 4 + r] = HitSeed{(u32)(sv[r] >> 32), J.g, seed_len_with_ctx(J.len, (u32)sv[r]), J.slot};
         break;
       }
       // blocks of level j under the threshold -> cidx[cur ^ 1]
@@ -470,12 +531,12 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
         const u32 x = p < nv ? S.val[p] : TOPK_PAD;
         const bool keep = x <= T && x != TOPK_PAD;
         u32 idx = 0;
-        if (keep) idx = top ? (u32)(A(L) + p) : (p < 8 * nc_prev ? S.cidx[cur][p >> 3] * 8u + (p & 7u) : S.eidx[p - 8 * nc_prev]);
+        if (keep) idx = top ? (u32)(A(L) + p) : (p < 8 * nc_prev ? S.cidx[cur * KC + (p >> 3)] * 8u + (p & 7u) : S.eidx[p - 8 * nc_prev]);
         const unsigned long long mk = __ballot(keep);
         u32 at = 0;
         if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
         at = __shfl(at, 0);
-        if (keep) S.cidx[cur ^ 1][at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = idx;
+        if (keep) S.cidx[(cur ^ 1) * KC + at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = idx;
       }
       __syncthreads();
       const u32 nc = S.n_kept;
@@ -483,11 +544,19 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
       top = false;
       // their children, and the blocks of level j-1 that stick out at either end of the interval
       const u32* lv = f.samin[j - 1];
+      const bool recs = j - 1 == 0 && sax_on;  // the entries themselves: from the records, whose lines the survivors read again
       const u64 nlow = j - 1 == 0 ? f.n : ~0ULL;  // level 0 is the suffix array itself: nothing beyond n
       for (u32 i = threadIdx.x; i < nc; i += 256) {
-        const u64 c8 = (u64)S.cidx[cur][i] * 8;
-        const uint4 x = *reinterpret_cast<const uint4*>(lv + c8), y = *reinterpret_cast<const uint4*>(lv + c8 + 4);
-        u32 v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        const u64 c8 = (u64)S.cidx[cur * KC + i] * 8;
+        u32 v[8];
+        if (recs) {
+          const uint4* r4 = reinterpret_cast<const uint4*>(f.sax + c8);
+          const uint4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
+          v[0] = a.x, v[1] = a.z, v[2] = b.x, v[3] = b.z, v[4] = c.x, v[5] = c.z, v[6] = d.x, v[7] = d.z;
+        } else {
+          const uint4 x = *reinterpret_cast<const uint4*>(lv + c8), y = *reinterpret_cast<const uint4*>(lv + c8 + 4);
+          v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w, v[4] = y.x, v[5] = y.y, v[6] = y.z, v[7] = y.w;
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) S.val[8 * i + t] = c8 + t < nlow ? v[t] : TOPK_PAD;
       }
@@ -496,7 +565,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, const BigJob* job
       if (threadIdx.x < nl + nr) {
         const u64 e = threadIdx.x < nl ? a0 + threadIdx.x : 8 * b1 + (threadIdx.x - nl);
         S.eidx[threadIdx.x] = (u32)e;
-        S.val[8 * nc + threadIdx.x] = lv[e];
+        S.val[8 * nc + threadIdx.x] = recs ? f.sax[e].x : lv[e];
       }
       reads += 8ULL * nc + nl + nr;
       nv = 8 * nc + nl + nr;

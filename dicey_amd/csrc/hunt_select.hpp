@@ -26,11 +26,15 @@ struct Summary {
 // before it reports in writes back its XCD's L2 — the 8 300 workgroups of a repeat-genome step went from 1.05 to 1.60 ms.  On
 // this part workgroups of one launch do not talk to each other cheaply; a 7 us kernel of its own is the better deal.)
 DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
-  constexpr int NF = 10;  // fields 1, 7 and 8 are maxima, the others sums
+  constexpr int NF = 12;  // fields 1, 7 and 8 are maxima, the others sums
   __shared__ unsigned long long acc[NF];
   if (threadIdx.x < NF) acc[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long v[NF] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long v[NF] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (threadIdx.x < JOB_SHARDS) {  // locate jobs queued by k_locate: wavefront jobs, workgroup jobs (both lists)
+    v[10] = ctr->job_cnt[0][threadIdx.x];
+    v[11] = (unsigned long long)ctr->job_cnt[1][threadIdx.x] + ctr->job_cnt[2][threadIdx.x];
+  }
   for (u32 k = threadIdx.x; k < NSHARD; k += blockDim.x) {
     const unsigned long long lc = ctr->leaf_cnt[k], sc = ctr->surv_cnt[k], sl = ctr->sel_cnt[k];
     v[8] = sl > v[8] ? sl : v[8];
@@ -70,8 +74,8 @@ DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
     host_out->overflow = ctr->overflow;
     host_out->refused = ctr->pad_[1];
     host_out->too_long = ctr->pad_[2];
-    host_out->jobs_big = ctr->pad_[0];
-    host_out->jobs_small = ctr->pad_[4];
+    host_out->jobs_big = acc[11];
+    host_out->jobs_small = acc[10];
     host_out->worst_sel = acc[8];
     host_out->fused_leaves = acc[9];
     host_out->n_generic = ctr->pad_[6];

@@ -607,11 +607,13 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
   // ---- phase 1: per hit
   HitSeed sd[CH];
   u32 dq[CH];
+  u32 sctx[CH];  // the seed's length word as the locate stage left it: bit 31 = the hit brought its context along (devfm.hpp, FmView::sax)
 #pragma unroll
   for (int j = 0; j < CH; ++j) {
     const u64 h = base + (u32)j * 256u + tid;
     const uint4 v = h < nh ? *reinterpret_cast<const uint4*>(a.seeds + h) : make_uint4(0, 0, 0, 0);
-    sd[j] = HitSeed{v.x, v.y, v.z, v.w};
+    sctx[j] = v.z;
+    sd[j] = HitSeed{v.x, v.y, v.z & SEED_LEN_MASK, v.w};
   }
 #pragma unroll
   for (int j = 0; j < CH; ++j) dq[j] = b.indel ? b.qdist[sd[j].qs >> 1] : 0u;
@@ -622,7 +624,14 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     const u64 loc = sd[j].pos, endp = loc + sd[j].len;
     const u32 d = dq[j];
     u32 x = 0;
-    if (SHARE && h < nh && !(a.debug & 2u)) {  // (the lane-per-hit path takes its context from the window band_align loads anyway)
+    if (SHARE && h < nh && !(a.debug & 2u) && (sctx[j] & SEED_CTX_VALID)) {
+      // r06: the characters came with the suffix-array entry the locate kernel read (all four exist and are A/C/G/T, or the bit
+      // would not be set): no text line for this hit
+      const u32 c = sctx[j] >> 20;
+      auto asc = [](u32 code) -> u32 { return (0x54474341u >> (8u * (code & 3u))) & 255u; };  // A C G T
+      if (d >= 1) x |= asc(c) | (asc(c >> 4) << 16);
+      if (DS >= 2 && d >= 2) x |= (asc(c >> 2) << 8) | (asc(c >> 6) << 24);
+    } else if (SHARE && h < nh && !(a.debug & 2u)) {  // (the lane-per-hit path takes its context from the window band_align loads anyway)
       if (d >= 1 && loc >= 1) x |= (u32)f.text[loc - 1];
       if (DS >= 2 && d >= 2 && loc >= 2) x |= (u32)f.text[loc - 2] << 8;
       if (d >= 1 && endp + 1 <= f.n) x |= (u32)f.text[endp] << 16;
@@ -740,7 +749,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     for (u32 c = tid; c < ncls && !(a.debug & 1u); c += 256) {
       const u32 own = cls_owner[c];
       const uint4 v = *reinterpret_cast<const uint4*>(a.seeds + base + own);
-      const AlnRes r = align(HitSeed{v.x, v.y, v.z, v.w});
+      const AlnRes r = align(HitSeed{v.x, v.y, v.z & SEED_LEN_MASK, v.w});
       cls_info[c] = r.info;
       cls_ops[c * DS] = r.op[0];
       if (DS > 1) cls_ops[c * DS + 1] = r.op[1];

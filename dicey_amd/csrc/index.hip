@@ -437,8 +437,10 @@ __global__ void __launch_bounds__(256) k_nrun_min(const u8* text, u64 n, u32* ou
   }
 }
 
-// FmView::pre5: the five characters in front of every suffix, in suffix-array order (one text gather per lane)
-__global__ void __launch_bounds__(256) k_pre5(const u32* sa, const u8* text, u64 n, u16* out) {
+// FmView::pre5: the five characters in front of every suffix, in suffix-array order (one text gather per lane) — and, with the same
+// gather, FmView::sax: {SA[i], context word} (devfm.hpp: the two characters in front of the suffix and the thirteen characters
+// T[p+16 .. p+28], two bits each, bit 31 when any of them is not A/C/G/T or lies outside the text).  sax == nullptr: pre5 only.
+__global__ void __launch_bounds__(256) k_pre5(const u32* sa, const u8* text, u64 n, u16* out, uint2* sax) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 p = sa[i];
@@ -453,6 +455,27 @@ __global__ void __launch_bounds__(256) k_pre5(const u32* sa, const u8* text, u64
     v |= c << (3 * (k - 1));
   }
   out[i] = (u16)v;
+  if (!sax) return;
+  const u32 c1 = v & 7u, c2 = (v >> 3) & 7u;
+  u32 ctx = (c1 & 3u) | ((c2 & 3u) << 2);
+  bool esc = c1 > 3u || c2 > 3u;
+  const u64 q = p + SAX_POST_OFF;
+  if (q + SAX_POST_N > n) esc = true;  // (text[n - 1] is the sentinel: it escapes by itself)
+  else {
+    // thirteen bytes from q, read as three aligned 64-bit words (the text block is 64-byte aligned and 64 bytes longer than n)
+    const u64* tw = reinterpret_cast<const u64*>(text) + (q >> 3);
+    const u32 sh = (u32)(q & 7u) * 8u;
+    const u64 a = tw[0], b = tw[1], c = tw[2];
+    const u64 w0 = sh ? (a >> sh) | (b << (64u - sh)) : a, w1 = sh ? (b >> sh) | (c << (64u - sh)) : b;
+#pragma unroll
+    for (u32 j = 0; j < SAX_POST_N; ++j) {
+      const u32 ch = (u32)((j < 8 ? w0 >> (8 * j) : w1 >> (8 * (j - 8))) & 255u);
+      const u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 7u;
+      esc = esc || code > 3u;
+      ctx |= (code & 3u) << (4 + 2 * j);
+    }
+  }
+  sax[i] = make_uint2((u32)p, esc ? (ctx | SAX_ESCAPE) : ctx);
 }
 
 // The table's final entry format (FmView::ktab): (lo, hi) as the fill pass left them -> (lo, width | pre5[lo] << 16) for widths below
@@ -660,11 +683,27 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
       if (big_alloc((void**)&pre, n * 2 + 64, ix->stream) == hipSuccess) {
         ix->owned.push_back(pre);
         ix->hbm_bytes += n * 2 + 64;
-        hipLaunchKernelGGL(k_pre5, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, (const u32*)sa, (const u8*)text, n, pre);
+        // with the same gather: the suffix array with context (8 n bytes, FmView::sax) for the locate job kernels — handles that
+        // have the block minima (i.e. the top-k locate) and the room; DICEY_NO_SAX leaves it out (the tests run both ways: hits of
+        // repeat-rich strings then read their context from the text as before r06)
+        uint2* sax = nullptr;
+        if (!std::getenv("DICEY_NO_SAX") && !std::getenv("DICEY_NO_SA_MINIMA")) {
+          size_t free_b = 0, total_b = 0;
+          if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > n * 8 + n * 2 + (4ULL << 30) &&
+              big_alloc((void**)&sax, n * 8 + 64, ix->stream) == hipSuccess) {
+            ix->owned.push_back(sax);
+            ix->hbm_bytes += n * 8 + 64;
+          } else {
+            sax = nullptr;
+            (void)hipGetLastError();
+          }
+        }
+        hipLaunchKernelGGL(k_pre5, dim3(ceil_div(n, TB)), dim3(TB), 0, ix->stream, (const u32*)sa, (const u8*)text, n, pre, sax);
         DG_HIP(hipStreamSynchronize(ix->stream));
         DG_HIP(hipGetLastError());
         f.pre5 = pre;
-        pc.lap("preceding characters");
+        f.sax = sax;
+        pc.lap(sax ? "preceding characters + suffix array with context" : "preceding characters");
       } else (void)hipGetLastError();
     }
     // every reader of (lo, hi) pairs is done (the filters above were derived from them): the entries take their final form

@@ -134,3 +134,83 @@ def test_job_kernels_come_back_after_a_batch_without_repeat_rich_strings(tmp_pat
     with dicey_amd.FmIndex(path) as ix:
         for qs in (plain, rich, plain, plain, rich, rich):
             _compare(ix, orc, g, qs, distance=1, max_locations=1000)
+
+
+def _family_genome(seed, unit_len=60, copies=420):
+    """three sequences with a repeat family whose copies also sit where a hit's context is special: at the very start of the text,
+    at the end of a sequence (the next character is the separator), at the start of one, and flanked by N runs"""
+    rng = random.Random(seed)
+    unit = "".join(rng.choice("ACGT") for _ in range(unit_len))
+    seqs = []
+    for c in range(3):
+        bg = bytearray(rng.choice(b"ACGT") for _ in range(150_000))
+        for _ in range(copies // 3):
+            p = rng.randrange(100, len(bg) - unit_len - 100)
+            bg[p:p + unit_len] = unit.encode()
+        for _ in range(6):  # N runs that touch a copy on either side, and one character away from it
+            p = rng.randrange(1000, len(bg) - 1000)
+            gap = rng.choice((0, 0, 1, 2))
+            bg[p - 40 - gap:p - gap] = b"N" * 40
+            bg[p:p + unit_len] = unit.encode()
+            bg[p + unit_len + gap:p + unit_len + gap + 30] = b"N" * 30
+        seqs.append(bg.decode())
+    seqs[0] = unit + seqs[0][unit_len:]                          # text position 0
+    seqs[0] = seqs[0][:-unit_len] + unit                         # followed by the separator
+    seqs[1] = unit + seqs[1][unit_len:-unit_len - 1] + unit + "G"  # preceded by the separator; one character before the next
+    seqs[2] = seqs[2][:-unit_len] + unit                         # the end of the text
+    return unit, seqs
+
+
+@pytest.mark.parametrize("no_sax", [False, True])
+def test_hits_of_repeat_rich_strings_carry_their_context(tmp_path, monkeypatch, no_sax):
+    """r06: the locate job kernels read {position, context word} records (FmView::sax) and k_verify_memo takes the <= d characters
+    either side of a hit from its seed instead of the text (hunter.h:363-378).  Copies at the start / end of the text and of
+    sequences, next to N runs, strings shorter and longer than the context window serves (16..27 characters), distances 0-2;
+    the same without the records (DICEY_NO_SAX: every hit reads the text)."""
+    import dicey_amd
+    if no_sax:
+        monkeypatch.setenv("DICEY_NO_SAX", "1")
+    unit, seqs = _family_genome(31)
+    path, g = _index(tmp_path, seqs, "fam.fm9")
+    orc = O.Index(path)
+    rng = random.Random(8)
+    qs = []
+    for m in (15, 17, 18, 20, 22, 25, 27, 29):
+        for off in (0, 1, 7, len(unit) - m - 1, len(unit) - m):
+            q = unit[off:off + m]
+            qs.append(q)
+            k = rng.randrange(m)
+            qs.append(q[:k] + rng.choice("ACGT") + q[k + 1:])   # a substitution
+            qs.append(q[:k] + q[k + 1:])                        # a deletion
+            qs.append(q[:k] + rng.choice("ACGT") + q[k:])       # an insertion
+    with dicey_amd.FmIndex(path) as ix:
+        for kw in (dict(distance=1, max_locations=1000), dict(distance=0, max_locations=1000), dict(distance=1, max_locations=100),
+                   dict(distance=1, hamming=True, max_locations=1000)):
+            _compare(ix, orc, g, qs, **kw)
+        short = [q for q in qs if len(q) <= 22]
+        O.fast_neighbors(True)
+        try:
+            _compare(ix, orc, g, short, distance=2, max_locations=300)
+        finally:
+            O.fast_neighbors(False)
+
+
+def test_small_buffer_topk_kernel_serves_a_batch_with_thousands_of_repeat_rich_strings(tmp_path):
+    """k_locate_topk<576> (list JL_MID) only runs when the handle's previous batch queued >= 2 048 workgroup jobs: 2 400 queries that
+    each hit a 420-copy family through several strings, twice (the first batch sets the hint)."""
+    import dicey_amd
+    unit, seqs = _family_genome(32)
+    path, g = _index(tmp_path, seqs, "fam2.fm9")
+    orc = O.Index(path)
+    rng = random.Random(9)
+    qs = []
+    while len(qs) < 2400:
+        off = rng.randrange(0, len(unit) - 20 + 1)
+        q = unit[off:off + 20]
+        k = rng.randrange(20)
+        qs.append(q[:k] + rng.choice("ACGT") + q[k + 1:])
+    with dicey_amd.FmIndex(path) as ix:
+        ix.hunt(qs, g["seqlen"], distance=1, max_locations=1000)
+        got = _compare(ix, orc, g, qs, distance=1, max_locations=1000)
+        assert sum(len(q.hits) for q in got.queries) > 400 * 2000
+        _compare(ix, orc, g, qs[:300], distance=1, max_locations=150)

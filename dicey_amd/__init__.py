@@ -330,3 +330,16 @@ def build_index(text: bytes, out_fm9: str, device: int = 0, _lib=None):
     """GPU counterpart of `dicey index` (src/index.h:97-123): text = SEQ1\\nSEQ2\\n...SEQk\\n, upper-case."""
     L = _lib or _capi.load()
     _capi.check(L, L.dg_index_build(text, len(text), device, out_fm9.encode()))
+
+
+def check_fm9(path: str, deep: bool = True) -> dict:
+    """dg_fm9_check: the acceptance check of an index file on the host (no device): every section of the sdsl csa_wt<> file accounted
+    for and held against the others (src/index.h:121-122 writes it, src/hunter.h:253-256 reads it).  Returns the report (a dict with
+    "ok", "sections", and "error" naming the first section that is off); never raises for a file that merely fails the check."""
+    import json
+    L = _capi.load()
+    buf = C.create_string_buffer(1 << 16)
+    rc = L.dg_fm9_check(path.encode(), 1 if deep else 0, buf, len(buf))
+    rep = json.loads(buf.value.decode() or "{}")
+    rep["rc"] = rc
+    return rep

@@ -98,7 +98,7 @@ SYMBOLS = ["dg_index_open", "dg_index_close", "dg_index_stats", "dg_count", "dg_
            "dg_thal_open", "dg_thal_close", "dg_thal_batch", "dg_search_sites", "dg_search_result_free",
            "dg_neighborhood_count", "dg_padlock_scan", "dg_padlock_result_free", "dg_index_share",
            "dg_neighbors", "dg_buffer_free", "dg_hit_rows", "dg_hunt_rows", "dg_hunt_submit", "dg_hunt_wait", "dg_hunt_device_submit",
-           "dg_chit_unpack", "dg_normalize_query", "dg_hunt_expand", "dg_index_stream"]
+           "dg_chit_unpack", "dg_normalize_query", "dg_hunt_expand", "dg_index_stream", "dg_fm9_check"]
 
 _lib = None
 
@@ -122,6 +122,7 @@ def load(path=None):
     vp, u64p, u8p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
     L.dg_last_error.restype = C.c_char_p
     L.dg_index_open.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(vp)]
+    L.dg_fm9_check.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_size_t]
     L.dg_index_share.argtypes = [vp, C.POINTER(vp)]
     L.dg_index_close.argtypes = [vp]
     L.dg_index_stream.argtypes = [vp]

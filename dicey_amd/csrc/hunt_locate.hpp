@@ -173,6 +173,107 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
   wave_add(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], reads);
 }
 
+// Sort of n <= 4 * LANES 64-bit keys in LDS whose high 32 bits (text positions: distinct) decide the order, by ONE distribution pass
+// instead of a comparison network (r06).  The bitonic network of 1 024 keys is 55 compare-exchange stages — ~1 300 vector
+// instructions per lane for 32-bit keys, twice that for 64-bit ones, and with 13 000 workgroup jobs per repeat-rich batch the
+// locate kernels were bound by instruction issue, not by memory (r05 counters: 78 M vector + 75 M scalar wave instructions per
+// launch of k_locate_topk<576>, 60 % of the issue slots of its duration).  Positions of a repeat family's copies are spread about
+// evenly over the range they span, so: 4 * LANES buckets of equal (power-of-two) width over [min, max], a count per bucket (LDS
+// atomics), an exclusive scan, every key to its bucket's place, and the lane that owns four neighbouring buckets orders the few
+// keys that landed there by insertion.  ~250 instructions per lane.  Returns false — keys untouched — when some lane's buckets hold
+// more than BUCKET_SKEW keys (clustered positions: tandem arrays); the caller then runs the network.
+// keys: LDS, n entries (in and out); cnt: 4 * LANES words of LDS; red: 16 words of LDS.  Every lane of the workgroup calls it.
+static constexpr u32 BUCKET_SKEW = 32;
+DG_DEV u32 wave_min32(u32 x) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const u32 o = (u32)__shfl_xor((int)x, off);
+    x = o < x ? o : x;
+  }
+  return x;
+}
+DG_DEV u32 wave_max32(u32 x) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const u32 o = (u32)__shfl_xor((int)x, off);
+    x = o > x ? o : x;
+  }
+  return x;
+}
+template <u32 LANES>
+DG_DEV bool bucket_sort_keys(u64* keys, u32* cnt, u32* red, u32 n) {
+  constexpr u32 NBK = 4 * LANES, NW = LANES / 64;
+  constexpr u32 LOGB = LANES == 64 ? 8 : 10;
+  static_assert(LANES == 64 || LANES == 256, "one wavefront or four");
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  u64 kv[4];
+  u32 mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+  for (u32 r = 0; r < 4; ++r) {
+    const u32 i = tid + r * LANES;
+    kv[r] = i < n ? keys[i] : ~0ULL;
+    if (i < n) {
+      const u32 pos = (u32)(kv[r] >> 32);
+      mn = pos < mn ? pos : mn;
+      mx = pos > mx ? pos : mx;
+    }
+    cnt[i] = 0;
+  }
+  mn = wave_min32(mn);
+  mx = wave_max32(mx);
+  if (lane == 0) {
+    red[wave] = mn;
+    red[4 + wave] = mx;
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 w = 0; w < NW; ++w) {
+    mn = red[w] < mn ? red[w] : mn;
+    mx = red[4 + w] > mx ? red[4 + w] : mx;
+  }
+  const u32 span = mx - mn;  // (n >= 1: mx >= mn)
+  const u32 sh = span < NBK ? 0u : (32u - (u32)__clz((int)span)) - LOGB;
+  u32 bk[4];
+#pragma unroll
+  for (u32 r = 0; r < 4; ++r) {
+    bk[r] = ((u32)(kv[r] >> 32) - mn) >> sh;
+    if (tid + r * LANES < n) atomicAdd(&cnt[bk[r]], 1u);
+  }
+  __syncthreads();
+  const uint4 c4 = *reinterpret_cast<const uint4*>(cnt + 4 * tid);
+  const u32 local = c4.x + c4.y + c4.z + c4.w;
+  const u32 incl = wave_incl_scan32(local);
+  const u32 wmax = wave_max32(local);
+  if (lane == 63) red[8 + wave] = incl;
+  if (lane == 0) red[12 + wave] = wmax;
+  __syncthreads();
+  u32 before = 0, worst = 0;
+#pragma unroll
+  for (u32 w = 0; w < NW; ++w) {
+    if (w < wave) before += red[8 + w];
+    worst = red[12 + w] > worst ? red[12 + w] : worst;
+  }
+  if (worst > BUCKET_SKEW) return false;  // (the same answer in every lane; keys[] has not been written)
+  const u32 e0 = before + incl - local;
+  *reinterpret_cast<uint4*>(cnt + 4 * tid) = make_uint4(e0, e0 + c4.x, e0 + c4.x + c4.y, e0 + c4.x + c4.y + c4.z);
+  __syncthreads();
+#pragma unroll
+  for (u32 r = 0; r < 4; ++r)
+    if (tid + r * LANES < n) keys[atomicAdd(&cnt[bk[r]], 1u)] = kv[r];
+  __syncthreads();
+  // cnt[b] is now the END of bucket b: this lane's four buckets hold keys[e0 .. cnt[4 tid + 3])
+  const u32 s1 = cnt[4 * tid + 3];
+  for (u32 i = e0 + 1; i < s1; ++i) {
+    const u64 key = keys[i];
+    u32 j = i;
+    while (j > e0 && keys[j - 1] > key) {
+      keys[j] = keys[j - 1];
+      --j;
+    }
+    keys[j] = key;
+  }
+  __syncthreads();
+  return true;
+}
+
 // One WAVEFRONT per string of 17..256 occurrences (most of the queued strings on a repeat-bearing genome: 54 k of 72 k per
 // 100 000 queries): the interval is read once, sorted in LDS by the wavefront alone (bitonic, no workgroup barrier to wait
 // for), the first `take` values are written.  Jobs by number, static stride: they all cost about the same.
@@ -180,6 +281,7 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
 // from their seeds (with_ctx), else position << 32 | SAX_ESCAPE ("no context": the seed's length stays plain).
 __global__ void __launch_bounds__(64) k_locate_small(FmView f, LocJobs jobs, HitSeed* seeds, Counters* ctr, u32 with_ctx) {
   __shared__ u64 buf[LOC_SMALL_MAX];
+  __shared__ u32 cnt[LOC_SMALL_MAX], red[16];
   __shared__ JobIndex JI;
   job_index_init(JI, jobs.cnt[JL_SMALL], jobs.shard_cap);
   const u32 njobs = JI.pre[JOB_SHARDS];
@@ -201,6 +303,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, LocJobs jobs, Hit
     }
     reads += J.occs;
     __syncthreads();
+    if (!bucket_sort_keys<64>(buf, cnt, red, J.occs))
     for (u32 kk = 2; kk <= n2; kk <<= 1)
       for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
         for (u32 i = threadIdx.x; i < n2; i += 64) {
@@ -513,12 +616,17 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
         }
         __syncthreads();
         const u32 have = S.n_kept;  // k .. k + 96 values (fewer when the whole interval is shorter); the k smallest are written
-        u32 n2 = 4;
-        while (n2 < have) n2 <<= 1;
         u64 sv[4];
+        if (bucket_sort_keys<256>(keys, S.val, S.hist, have)) {  // (the candidates in val are dead: its first 1 024 words count)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sv[r] = threadIdx.x * 4 + r < have ? keys[threadIdx.x * 4 + r] : ~0ULL;
-        block_sort4<u64>(keys, n2, sv);
+          for (int r = 0; r < 4; ++r) sv[r] = threadIdx.x * 4 + r < have ? keys[threadIdx.x * 4 + r] : ~0ULL;
+        } else {  // clustered positions: the comparison network
+          u32 n2 = 4;
+          while (n2 < have) n2 <<= 1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[r] = threadIdx.x * 4 + r < have ? keys[threadIdx.x * 4 + r] : ~0ULL;
+          block_sort4<u64>(keys, n2, sv);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (threadIdx.x * 4 + r < k)

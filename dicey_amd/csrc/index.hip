@@ -850,6 +850,48 @@ extern "C" {
 
 const char* dg_last_error(void) { return dg::last_error().c_str(); }
 int dg_abi_version(void) { return DG_ABI_VERSION; }
+
+// Host only (no device is touched): the file's sections accounted for byte by byte, their invariants against each other, and —
+// DG_FM9_CHECK_DEEP — the big sections read through (rank words against the bit vector, the tree's node sizes and rank offsets,
+// C[] against the leaf sizes, sample values).  The report is one JSON object; on DG_EFORMAT its "error" (= dg_last_error()) names
+// the first section that is off.
+int dg_fm9_check(const char* fm9_path, uint32_t flags, char* report, size_t report_cap) {
+  if (report && report_cap) report[0] = 0;
+  if (!fm9_path) return fail(DG_EINVAL, "dg_fm9_check: null path");
+  SdslCsa c;
+  int rc = sdsl_open(fm9_path, c);
+  if (rc == DG_OK && (flags & DG_FM9_CHECK_DEEP)) {
+    rc = sdsl_check_deep(c);
+    if (rc != DG_OK) fail(rc, "%s: %s", fm9_path, c.why.c_str());
+  }
+  if (report && report_cap) {
+    std::string j = "{\"ok\":";
+    j += rc == DG_OK ? "true" : "false";
+    j += ",\"deep\":";
+    j += (flags & DG_FM9_CHECK_DEEP) ? "true" : "false";
+    j += ",\"file_bytes\":" + std::to_string(c.len);
+    if (c.base && rc != DG_EIO) {
+      j += std::string(",\"layout\":\"") + (c.checked_layout ? "store_to_checked_file" : "store_to_file") + "\"";
+      j += ",\"n\":" + std::to_string(c.n) + ",\"sigma\":" + std::to_string(c.wt_sigma);
+      j += ",\"sa_sample_width\":" + std::to_string((unsigned)c.sa_samples.width);
+      j += ",\"sections\":[";
+      for (size_t i = 0; i < c.sections.size(); ++i) {
+        if (i) j += ",";
+        j += std::string("{\"name\":\"") + c.sections[i].name + "\",\"offset\":" + std::to_string(c.sections[i].offset) + ",\"bytes\":" + std::to_string(c.sections[i].bytes) + "}";
+      }
+      j += "]";
+    }
+    if (rc != DG_OK) {
+      std::string e = last_error();
+      for (char& ch : e)
+        if (ch == '"' || ch == '\\' || (unsigned char)ch < 32) ch = ' ';
+      j += ",\"error\":\"" + e + "\"";
+    }
+    j += "}";
+    std::snprintf(report, report_cap, "%s", j.c_str());
+  }
+  return rc;
+}
 int dg_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

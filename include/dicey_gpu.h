@@ -39,7 +39,7 @@ extern "C" {
  * 5: dg_hunt_params grows by max_query_len and flags; DG_HUNT_COMPACT: 8 + 4 d bytes per hit and 8 bytes per query cross PCIe / xGMI
  *    (dg_chit_unpack, dg_hunt_expand, dg_normalize_query turn them back); dg_hunt_submit keeps up to three batches in flight on ONE handle
  * 6: dg_hunt_result grows by stream / d_block / d_block_bytes (the gather over RCCL lives in libdiceygather.so, include/dicey_gather.h) */
-#define DG_ABI_VERSION 6
+#define DG_ABI_VERSION 7
 
 enum {
   DG_OK = 0,
@@ -402,6 +402,16 @@ typedef struct {
 int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const uint32_t* seqlen, uint32_t nseq,
                     const uint8_t* pbytes, const uint64_t* poff, size_t nprimers, dg_search_result** out);
 void dg_search_result_free(dg_search_result* r);
+
+/* ABI 7.  Acceptance check of an index file WITHOUT a device (reference: the file sdsl::store_to_checked_file writes at
+ * src/index.h:121-122 and load_from_checked_file reads at src/hunter.h:253-256).  The sections of csa_wt<wt_huff<>, 32, 64> are
+ * walked byte by byte and held against each other; with DG_FM9_CHECK_DEEP the large sections are read through as well (rank words
+ * against the bit vector's popcounts, node sizes / offsets of the Huffman tree, C[] against the leaf sizes, SA / ISA samples).
+ * `report` (may be NULL) receives one JSON object: {"ok", "layout", "n", "sigma", "sections":[{"name","offset","bytes"}...],
+ * "error"}.  Returns DG_OK, DG_EIO, or DG_EFORMAT with a message (also dg_last_error()) that NAMES the first section whose byte
+ * count or invariant is off — what a maintainer needs when the first genuine `dicey index` file does not load. */
+#define DG_FM9_CHECK_DEEP 1u
+int dg_fm9_check(const char* fm9_path, uint32_t flags, char* report, size_t report_cap);
 
 const char* dg_last_error(void);
 int dg_abi_version(void);

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_path(lib):
-    assert lib.dg_abi_version() == 6
+    assert lib.dg_abi_version() == 7
     h = ctypes.c_void_p()
     rc = lib.dg_index_open(b"/nonexistent/x.fm9", 0, 0, ctypes.byref(h))
     assert rc != 0 and not h.value  # DG_ENODEV here (no GPU) or DG_EIO on a GPU box; never a silent success

@@ -1190,11 +1190,90 @@ int silica(int argc, char** argv) {
 }
 
 // ------------------------------------------------------------------------------------------------ index (index.h:34-141)
+// `dicey index --verify genome.fa.gz`: the acceptance procedure for an index file this build did not write.  The
+// reader's layout is restated from sdsl-lite: the first genuine file decides whether it is right, and this is
+// what decides it in minutes — or names the section that is off.  1. dg_fm9_check, deep (host): byte accounting, rank words, tree,
+// C[], samples.  2. dg_index_open: the device derives BWT / text / suffix array and checks them against the file (C[] against
+// symbol totals, the file's SA samples, sampled suffix order).  3. the WHOLE text (dg_extract) against the text index.h:97-115
+// builds from the FASTA.  4. 1 000 sampled 24-mers: dg_count, and every dg_locate position spells the pattern.
+int verify_index(const std::string& fm9, const std::string& text) {
+  std::vector<char> rep(1 << 16);
+  std::cerr << "[1/4] sections of " << fm9 << " (host)" << std::endl;
+  if (dg_fm9_check(fm9.c_str(), DG_FM9_CHECK_DEEP, rep.data(), rep.size()) != DG_OK) {
+    std::cerr << "REFUSED: " << dg_last_error() << std::endl;
+    std::cout << rep.data() << std::endl;
+    return 1;
+  }
+  std::cerr << "[2/4] open on the device (derived layouts checked against the file)" << std::endl;
+  dg_index* ix = nullptr;
+  if (dg_index_open(fm9.c_str(), device_from_env(), 0, &ix) != DG_OK) {
+    std::cerr << "REFUSED: " << dg_last_error() << std::endl;
+    return 1;
+  }
+  dg_index_stats_t st;
+  dg_index_stats(ix, &st);
+  auto refuse = [&](const std::string& why) {
+    std::cerr << "REFUSED: " << why << std::endl;
+    dg_index_close(ix);
+    return 1;
+  };
+  if (st.n != text.size() + 1) return refuse("the index holds " + std::to_string(st.n - 1) + " symbols, the FASTA gives " + std::to_string(text.size()));
+  std::cerr << "[3/4] the whole text against the FASTA (" << text.size() << " symbols)" << std::endl;
+  const uint64_t CH = 64ull << 20;
+  std::vector<uint8_t> buf(std::min<uint64_t>(CH, text.size()));
+  for (uint64_t at = 0; at < text.size(); at += CH) {
+    const uint64_t lo = at, end = std::min<uint64_t>(text.size(), at + CH), hi = end - 1 /* inclusive */, off[1] = {0};
+    if (dg_extract(ix, &lo, &hi, 1, buf.data(), off) != DG_OK) return refuse(dg_last_error());
+    if (std::memcmp(buf.data(), text.data() + lo, end - lo) != 0) {
+      uint64_t k = 0;
+      while (buf[k] == (uint8_t)text[lo + k]) ++k;
+      return refuse("text position " + std::to_string(lo + k) + ": the index spells byte " + std::to_string((unsigned)buf[k]) + ", the FASTA " +
+                    std::to_string((unsigned)(uint8_t)text[lo + k]));
+    }
+  }
+  std::cerr << "[4/4] 1000 sampled 24-mers: count and locate" << std::endl;
+  const uint32_t m = 24;
+  if (text.size() > m + 1) {
+    std::string pat;
+    std::vector<uint64_t> poff(1, 0), where;
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    while (where.size() < 1000) {
+      x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+      const uint64_t p0 = x % (text.size() - m);
+      pat.append(text, p0, m);
+      poff.push_back(pat.size());
+      where.push_back(p0);
+    }
+    std::vector<uint64_t> cnt(where.size());
+    if (dg_count(ix, (const uint8_t*)pat.data(), poff.data(), where.size(), cnt.data()) != DG_OK) return refuse(dg_last_error());
+    dg_locations* loc = nullptr;
+    if (dg_locate(ix, (const uint8_t*)pat.data(), poff.data(), where.size(), &loc) != DG_OK) return refuse(dg_last_error());
+    std::string why;
+    for (size_t i = 0; i < where.size() && why.empty(); ++i) {
+      const uint64_t a = loc->off[i], b = loc->off[i + 1];
+      bool own = false;
+      if (b - a != cnt[i]) why = "pattern " + std::to_string(i) + ": count says " + std::to_string(cnt[i]) + ", locate returns " + std::to_string(b - a);
+      for (uint64_t k = a; k < b && why.empty(); ++k) {
+        own = own || loc->pos[k] == where[i];
+        if (loc->pos[k] + m > text.size() || text.compare(loc->pos[k], m, pat, poff[i], m) != 0)
+          why = "pattern " + std::to_string(i) + ": located position " + std::to_string(loc->pos[k]) + " does not spell it";
+      }
+      if (why.empty() && !own) why = "pattern " + std::to_string(i) + " was cut from text position " + std::to_string(where[i]) + ", which locate does not return";
+    }
+    dg_locations_free(loc);
+    if (!why.empty()) return refuse(why);
+  }
+  dg_index_close(ix);
+  std::cout << "Verified: " << fm9 << " is the index of this FASTA (" << text.size() << " symbols)." << std::endl;
+  return 0;
+}
+
 int indexer(int argc, char** argv) {
   std::string genome, outfile;
   bool out_given = false, help = false;
-  const OptSpec specs[] = {{"help", '?', false}, {"output", 'o', true}, {"input-file", 0, true}};
-  Parsed p = parse_options(argc, argv, specs, 3);
+  bool verify = false;
+  const OptSpec specs[] = {{"help", '?', false}, {"output", 'o', true}, {"input-file", 0, true}, {"verify", 'v', false}};
+  Parsed p = parse_options(argc, argv, specs, 4);
   if (!p.error.empty()) {
     std::cerr << p.error << std::endl;
     std::abort();
@@ -1203,11 +1282,16 @@ int indexer(int argc, char** argv) {
     if (kv.first == "help") help = true;
     else if (kv.first == "output") { outfile = kv.second; out_given = true; }
     else if (kv.first == "input-file") genome = kv.second;
+    else if (kv.first == "verify") verify = true;
   }
   if (!p.positional.empty()) genome = p.positional.back();
   if (help || genome.empty()) {
     std::cout << "Usage: dicey " << argv[0] << " [OPTIONS] genome.fa.gz" << std::endl;
-    std::cout << "Generic options:\n  -? [ --help ]                    show help message\n  -o [ --output ] arg (=genome.fm9) output file\n\n";
+    std::cout << "Generic options:\n  -? [ --help ]                    show help message\n  -o [ --output ] arg (=genome.fm9) output file\n"
+                 "  -v [ --verify ]                  do not build: accept or refuse the EXISTING index file against this FASTA\n"
+                 "                                   (every section of the sdsl file, then the whole text and sampled\n"
+                 "                                   count / locate answers on the GPU) - the check for the first\n"
+                 "                                   index that `dicey index` of the reference wrote\n\n";
     return -1;
   }
   if (!out_given) outfile = strip_last_extension(genome) + ".fm9";  // index.h:67-69
@@ -1234,6 +1318,7 @@ int indexer(int argc, char** argv) {
     }
   }
   text.push_back('\n');
+  if (verify) return verify_index(outfile, text);
   if (dg_index_build((const uint8_t*)text.data(), text.size(), device_from_env(), outfile.c_str()) != DG_OK) {
     std::cerr << "dicey: " << dg_last_error() << std::endl;
     return 1;

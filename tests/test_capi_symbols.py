@@ -20,7 +20,7 @@ def lib():
 def declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "dicey_gpu.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(dg_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(dg_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_every_declared_symbol_is_exported(lib):

@@ -12,7 +12,7 @@ import pytest
 import oracle_lib as O
 from conftest import make_genome, genome_text
 
-DG_EFORMAT = -4
+DG_EFORMAT = -3
 
 
 @pytest.fixture(scope="module")
@@ -87,7 +87,7 @@ def _perturbations(data, secs, n, sigma):
         sa, isa = bytes(b[o_sa:o_sa + l_sa]), bytes(b[o_isa:o_isa + l_isa])
         b[o_sa:o_isa + l_isa] = isa + sa
     mod("isa_samples in front of sa_samples", ["sa_samples"], swapped_samples)
-    mod("select supports absent from the file", ["byte_tree nodes"], lambda b: b[:o_s1] + b[o_nd:])
+    mod("select supports absent from the file", ["select_support_mcl<1>|byte_tree nodes"], lambda b: b[:o_s1] + b[o_nd:])
     mod("only one select support present", ["select_support_mcl<0>|byte_tree nodes"], lambda b: b[:o_s0] + b[o_nd:])
 
     def node_field(b, v, which):   # node v: bv_pos u64, bv_pos_rank u64, parent u16, child0 u16, child1 u16

@@ -191,3 +191,66 @@ def test_chunks_refused_for_their_size_are_answered_in_halves_and_none_is_droppe
     pick = list(range(0, 30)) + list(range(131060, 131090)) + list(range(269970, 270000))
     want = _oracle_json(g, [qs[i] for i in pick], ["c%d" % i for i in pick], distance=1, max_neighborhood=50).split("\n")
     assert [lines[i] for i in pick] == want[:-1]
+
+
+def test_index_verify_accepts_its_file_and_refuses_foreign_ones(cli_genome, tmp_path):
+    """`dicey index --verify genome.fa.gz` (r06, A13): the acceptance procedure for an index file — sections on the host
+    (dg_fm9_check), the device's own checks at open, the whole text against the FASTA, sampled count / locate.  The file this build
+    wrote passes; files that are well-formed but say something else (another child order in the Huffman tree, a rank word of another
+    shape, a shifted C[]) are refused BY NAME and never load (dg_index_open fails on each); an index of another genome is refused at
+    the first differing text position."""
+    import shutil
+    import struct
+    import dicey_amd
+    g = cli_genome
+    r = subprocess.run([DICEY, "index", "--verify", g["fa"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("Verified: ") and "[4/4]" in r.stderr
+    rep = dicey_amd.check_fm9(g["fm9"])
+    secs = {s["name"]: (s["offset"], s["bytes"]) for s in rep["sections"]}
+    data = open(g["fm9"], "rb").read()
+    fa2 = str(tmp_path / "genome.fa.gz")
+    shutil.copy(g["fa"], fa2)
+    fm2 = str(tmp_path / "genome.fa.fm9")
+
+    def swap_children(b):
+        o = secs["wt byte_tree nodes"][0] + 8
+        b[o + 18:o + 20], b[o + 20:o + 22] = b[o + 20:o + 22], b[o + 18:o + 20]
+
+    def rank_word(b):
+        o = secs["wt rank_support_v"][0] + 8 + 16
+        struct.pack_into("<Q", b, o, struct.unpack_from("<Q", b, o)[0] + 1)
+
+    def c_shift(b):
+        o = secs["alphabet C"][0] + 8 + 16
+        struct.pack_into("<Q", b, o, struct.unpack_from("<Q", b, o)[0] + 1)
+
+    def bv_bit(b):
+        b[secs["wt bit_vector"][0] + 8 + 100] ^= 4
+
+    def sa_sample(b):   # a sample in the middle of the vector: in range, wrong
+        o = secs["sa_samples"][0] + 9 + secs["sa_samples"][1] // 2
+        b[o] ^= 1
+
+    for name, fn, word in (("children", swap_children, "byte_tree"), ("rank", rank_word, "rank_support_v"), ("C", c_shift, "alphabet C"),
+                           ("bit", bv_bit, "rank_support_v"), ("sample", sa_sample, None)):
+        b = bytearray(data)
+        fn(b)
+        open(fm2, "wb").write(bytes(b))
+        with pytest.raises(Exception):          # none of them loads
+            dicey_amd.FmIndex(fm2).close()
+        r = subprocess.run([DICEY, "index", "--verify", fa2], capture_output=True, text=True)
+        assert r.returncode == 1 and "REFUSED" in r.stderr, (name, r.stderr)
+        if word:
+            assert word in r.stderr, (name, r.stderr)
+    # the index of another genome: well-formed, self-consistent, refused against this FASTA
+    other = make_genome(56, 3, 20000)
+    O.build_fm9(genome_text(other), fm2)
+    r = subprocess.run([DICEY, "index", "--verify", fa2], capture_output=True, text=True)
+    assert r.returncode == 1 and "text position" in r.stderr, r.stderr
+    # ... and a hunt against a perturbed file reports the reference's error line, it does not answer
+    b = bytearray(data)
+    swap_children(b)
+    open(fm2, "wb").write(bytes(b))
+    r = subprocess.run([DICEY, "hunt", "-g", fa2, g["seqs"][0][100:120]], capture_output=True, text=True)
+    assert r.returncode == 1 and "FM-Index cannot be loaded" in r.stdout

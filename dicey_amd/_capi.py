@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiceygpu.so")
+LIB_PATH = os.environ.get("DICEY_LIB") or os.path.join(_HERE, "libdiceygpu.so")  # DICEY_LIB: a development build (tools/)
 
 DG_OK = 0
 DG_OPEN_NO_SELFCHECK = 1

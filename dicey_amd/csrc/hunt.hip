@@ -1116,6 +1116,16 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         std::fclose(fj);
       }
     }
+#ifdef DG_TOPK_PROFILE
+    {
+      static const char* nm[24] = {"mid.jobs", "mid.load", "mid.threshold", "mid.keys", "mid.sort", "mid.write", "mid.levels", "mid.total",
+                                   "big.jobs", "big.load", "big.threshold", "big.keys", "big.sort", "big.write", "big.levels", "big.total",
+                                   "small.jobs", "small.load", "small.sort", "small.write", "small.total", "-", "-", "-"};
+      std::fprintf(stderr, "topk profile (us summed over workgroups):");
+      for (int i = 0; i < 21; ++i) std::fprintf(stderr, " %s=%.1f", nm[i], (i % 8 == 0 && i < 17) ? (double)hsum.prof[i] : hsum.prof[i] * 0.01);
+      std::fprintf(stderr, "\n");
+    }
+#endif
     nleaf = hsum.nleaf;
     nhits = hsum.nhits;
     // Everything this attempt found wanting is put right before the batch is repeated (one repeat usually serves several causes).

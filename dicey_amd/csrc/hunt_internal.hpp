@@ -77,7 +77,24 @@ struct Counters {
   // locate jobs queued by k_locate (hunt_locate.hpp): per list JOB_SHARDS producer counters — ONE word per list cost ~11 ns per
   // wavefront that queued a job (40 000 of them on a repeat-rich batch: most of that kernel's 0.26 ms, r05 counters)
   u32 job_cnt[3][64];
+#ifdef DG_TOPK_PROFILE  // development builds only (tools/r06_prof.sh): phase clocks of the locate job kernels, 10 ns units
+  unsigned long long prof[24];
+#endif
 };
+#ifdef DG_TOPK_PROFILE
+#define DG_LPROF_NOW() wall_clock64()
+#define DG_LPROF_ADD(slot, dt)                                                        \
+  do {                                                                               \
+    if (threadIdx.x == 0) atomicAdd(&ctr->prof[slot], (unsigned long long)(dt));     \
+  } while (0)
+#else
+#define DG_LPROF_NOW() 0ULL
+#define DG_LPROF_ADD(slot, dt) \
+  do {                         \
+    (void)(slot);              \
+    (void)(dt);                \
+  } while (0)
+#endif
 static constexpr u32 JOB_SHARDS = 64;
 
 struct HitSeed {  // 16 bytes, read as one uint4

@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, LocJobs jobs, Hit
   const bool sax_on = with_ctx && f.sax;
   u64 reads = 0;
   for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
+    const unsigned long long p0 = DG_LPROF_NOW();
     const BigJob J = jobs.list[JL_SMALL][job_slot(JI, jobs.shard_cap, jb)];
     u32 n2 = 32;
     while (n2 < J.occs) n2 <<= 1;
@@ -303,6 +304,7 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, LocJobs jobs, Hit
     }
     reads += J.occs;
     __syncthreads();
+    const unsigned long long p1 = DG_LPROF_NOW();
     if (!bucket_sort_keys<64>(buf, cnt, red, J.occs))
     for (u32 kk = 2; kk <= n2; kk <<= 1)
       for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
@@ -318,9 +320,16 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, LocJobs jobs, Hit
         }
         __syncthreads();
       }
+    const unsigned long long p2 = DG_LPROF_NOW();
     for (u32 i = threadIdx.x; i < J.take; i += 64)
       seeds[J.out + i] = HitSeed{(u32)(buf[i] >> 32), J.g, seed_len_with_ctx(J.len, (u32)buf[i]), J.slot};
     __syncthreads();
+    const unsigned long long p3 = DG_LPROF_NOW();
+    DG_LPROF_ADD(16, 1);
+    DG_LPROF_ADD(17, p1 - p0);
+    DG_LPROF_ADD(18, p2 - p1);
+    DG_LPROF_ADD(19, p3 - p2);
+    DG_LPROF_ADD(20, p3 - p0);
   }
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);
 }
@@ -554,6 +563,9 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
   u64 reads = 0;
   for (u32 jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
     __syncthreads();  // the previous job's buffers are free
+    const u32 pb = which == JL_MID ? 0u : 8u;
+    const unsigned long long p0 = DG_LPROF_NOW();
+    unsigned long long p_thr = 0, p_lev = 0;
     const BigJob J = jobs.list[which][job_slot(S.ji, jobs.shard_cap, jb)];
     if (J.take > TOPK_KMAX) continue;  // k_locate_big's (hunt -m above 1 024)
     const u32 k = J.take;
@@ -578,13 +590,17 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
     u32 cur = 0;
     bool top = true;
     __syncthreads();
+    const unsigned long long p1 = DG_LPROF_NOW();
     for (int j = L;; --j) {
       // at the entries: up to 96 values more than asked for may survive (the sort drops them) — an exact k-th value costs the
       // radix select all four byte passes, a little slack usually ends it after two
       const u32 limit = j == 0 ? (k + 96 < TOPK_KMAX ? k + 96 : TOPK_KMAX) : KC;
+      const unsigned long long pt0 = DG_LPROF_NOW();
       const u32 T = nv > limit ? topk_threshold(S, nv, k, limit) : 0xFFFFFFFEu;
       if (threadIdx.x == 0) S.n_kept = 0;
       __syncthreads();
+      const unsigned long long pt1 = DG_LPROF_NOW();
+      p_thr += pt1 - pt0;
       if (j == 0) {  // the survivors are the answer: collect, sort, write
         if (sax_on) {  // a survivor's slot takes its index inside the interval (the index lists are still alive here)
           for (u32 p = threadIdx.x; p < nv; p += 256) {
@@ -616,6 +632,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
         }
         __syncthreads();
         const u32 have = S.n_kept;  // k .. k + 96 values (fewer when the whole interval is shorter); the k smallest are written
+        const unsigned long long p3 = DG_LPROF_NOW();
         u64 sv[4];
         if (bucket_sort_keys<256>(keys, S.val, S.hist, have)) {  // (the candidates in val are dead: its first 1 024 words count)
 #pragma unroll
@@ -627,10 +644,20 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
           for (int r = 0; r < 4; ++r) sv[r] = threadIdx.x * 4 + r < have ? keys[threadIdx.x * 4 + r] : ~0ULL;
           block_sort4<u64>(keys, n2, sv);
         }
+        const unsigned long long p4 = DG_LPROF_NOW();
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (threadIdx.x * 4 + r < k)
             seeds[J.out + threadIdx.x * 4 + r] = HitSeed{(u32)(sv[r] >> 32), J.g, seed_len_with_ctx(J.len, (u32)sv[r]), J.slot};
+        const unsigned long long p5 = DG_LPROF_NOW();
+        DG_LPROF_ADD(pb + 0, 1);
+        DG_LPROF_ADD(pb + 1, p1 - p0);
+        DG_LPROF_ADD(pb + 2, p_thr);
+        DG_LPROF_ADD(pb + 3, p3 - pt1);
+        DG_LPROF_ADD(pb + 4, p4 - p3);
+        DG_LPROF_ADD(pb + 5, p5 - p4);
+        DG_LPROF_ADD(pb + 6, p_lev);
+        DG_LPROF_ADD(pb + 7, p5 - p0);
         break;
       }
       // blocks of level j under the threshold -> cidx[cur ^ 1]
@@ -679,6 +706,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
       nv = 8 * nc + nl + nr;
       nc_prev = nc;
       __syncthreads();
+      p_lev += DG_LPROF_NOW() - pt1;
     }
   }
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);

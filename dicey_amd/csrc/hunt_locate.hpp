@@ -292,15 +292,22 @@ __global__ void __launch_bounds__(64) k_locate_small(FmView f, LocJobs jobs, Hit
     const BigJob J = jobs.list[JL_SMALL][job_slot(JI, jobs.shard_cap, jb)];
     u32 n2 = 32;
     while (n2 < J.occs) n2 <<= 1;
-    for (u32 i = threadIdx.x; i < n2; i += 64) {
-      u64 key = ~0ULL;
-      if (i < J.occs) {
-        if (sax_on) {
-          const uint2 r = f.sax[(u64)J.lo + i];
-          key = ((u64)r.x << 32) | r.y;
-        } else key = ((u64)f.sa[(u64)J.lo + i] << 32) | SAX_ESCAPE;
+    {  // (the up to four entries of a lane are read together)
+      u64 key[4];
+#pragma unroll
+      for (u32 r = 0; r < 4; ++r) {
+        const u32 i = threadIdx.x + r * 64;
+        key[r] = ~0ULL;
+        if (i < J.occs) {
+          if (sax_on) {
+            const uint2 rc = f.sax[(u64)J.lo + i];
+            key[r] = ((u64)rc.x << 32) | rc.y;
+          } else key[r] = ((u64)f.sa[(u64)J.lo + i] << 32) | SAX_ESCAPE;
+        }
       }
-      buf[i] = key;
+#pragma unroll
+      for (u32 r = 0; r < 4; ++r)
+        if (threadIdx.x + r * 64 < n2) buf[threadIdx.x + r * 64] = key[r];
     }
     reads += J.occs;
     __syncthreads();
@@ -578,12 +585,38 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
     while (L + 1 < (int)f.nlev && N(L) > VMAXT - 16) ++L;  // a level left with more than 9 216 blocks has > 1 000 in the next
     if (N(L) > VMAXT - 16) continue;  // cannot happen: the top level of FmView::samin holds <= 64 blocks (JL_MID: occs <= 8 KC)
     u32 nv = (u32)N(L);
+    // (eight loads in flight per lane: one load per trip of a plain loop is one memory latency per trip — the phase clocks of a
+    //  development build showed half of a job's 60 us in this loop and in the survivors' record loads below)
     if (L == 0 && sax_on) {
       const uint2* src = f.sax + A(0);
-      for (u32 i = threadIdx.x; i < nv; i += 256) S.val[i] = src[i].x;
+      for (u32 base = 0; base < nv; base += 8 * 256) {
+        u32 r[8];
+#pragma unroll
+        for (u32 u = 0; u < 8; ++u) {
+          const u32 i = base + u * 256 + threadIdx.x;
+          r[u] = i < nv ? src[i].x : TOPK_PAD;
+        }
+#pragma unroll
+        for (u32 u = 0; u < 8; ++u) {
+          const u32 i = base + u * 256 + threadIdx.x;
+          if (i < nv) S.val[i] = r[u];
+        }
+      }
     } else {
       const u32* src = f.samin[L] + A(L);
-      for (u32 i = threadIdx.x; i < nv; i += 256) S.val[i] = src[i];
+      for (u32 base = 0; base < nv; base += 8 * 256) {
+        u32 r[8];
+#pragma unroll
+        for (u32 u = 0; u < 8; ++u) {
+          const u32 i = base + u * 256 + threadIdx.x;
+          r[u] = i < nv ? src[i] : TOPK_PAD;
+        }
+#pragma unroll
+        for (u32 u = 0; u < 8; ++u) {
+          const u32 i = base + u * 256 + threadIdx.x;
+          if (i < nv) S.val[i] = r[u];
+        }
+      }
     }
     reads += nv;
     u32 nc_prev = 0;
@@ -602,36 +635,47 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
       const unsigned long long pt1 = DG_LPROF_NOW();
       p_thr += pt1 - pt0;
       if (j == 0) {  // the survivors are the answer: collect, sort, write
-        if (sax_on) {  // a survivor's slot takes its index inside the interval (the index lists are still alive here)
-          for (u32 p = threadIdx.x; p < nv; p += 256) {
-            const u32 x = S.val[p];
-            const bool keep = x <= T && x != TOPK_PAD;
-            u32 idx = TOPK_PAD;
-            if (keep) idx = (u32)((top ? A(0) + p : (p < 8 * nc_prev ? (u64)S.cidx[cur * KC + (p >> 3)] * 8u + (p & 7u) : (u64)S.eidx[p - 8 * nc_prev])) - lo);
-            S.val[p] = idx;
-          }
-          __syncthreads();
-        }
-        u64* keys = reinterpret_cast<u64*>(S.cidx);
+        // the survivors, listed: their index inside the interval (records) or their position (plain suffix array).  The list lies in
+        // the half of the index lists that is free at this level; the other half is still read here (a survivor's index)
+        u32* const slist = S.cidx + (top ? TOPK_KMAX : (cur ^ 1u) * KC);
         for (u32 base = 0; base < nv; base += 256) {
           const u32 p = base + threadIdx.x;
           const u32 x = p < nv ? S.val[p] : TOPK_PAD;
-          const bool keep = sax_on ? x != TOPK_PAD : (x <= T && x != TOPK_PAD);
+          const bool keep = x <= T && x != TOPK_PAD;
+          u32 e = x;
+          if (keep && sax_on) e = (u32)((top ? A(0) + p : (p < 8 * nc_prev ? (u64)S.cidx[cur * KC + (p >> 3)] * 8u + (p & 7u) : (u64)S.eidx[p - 8 * nc_prev])) - lo);
           const unsigned long long mk = __ballot(keep);
           u32 at = 0;
           if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
           at = __shfl(at, 0);
-          if (keep) {
-            u64 key;
-            if (sax_on) {
-              const uint2 r = f.sax[lo + x];
-              key = ((u64)r.x << 32) | r.y;
-            } else key = ((u64)x << 32) | SAX_ESCAPE;
-            keys[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = key;
-          }
+          if (keep) slist[at + (u32)__popcll(mk & ((1ULL << lane) - 1))] = e;
         }
         __syncthreads();
         const u32 have = S.n_kept;  // k .. k + 96 values (fewer when the whole interval is shorter); the k smallest are written
+        // every lane takes up to four listed survivors, reads their records together (L2 hits: this workgroup fetched those lines a
+        // moment ago) and lays the 64-bit keys over the index lists, which are dead from here on
+        u64* keys = reinterpret_cast<u64*>(S.cidx);
+        {
+          u32 mine[4];
+#pragma unroll
+          for (u32 r = 0; r < 4; ++r) mine[r] = threadIdx.x + r * 256 < have ? slist[threadIdx.x + r * 256] : TOPK_PAD;
+          __syncthreads();
+          u64 kv[4];
+          if (sax_on) {
+            uint2 rec[4];
+#pragma unroll
+            for (u32 r = 0; r < 4; ++r) rec[r] = threadIdx.x + r * 256 < have ? f.sax[lo + mine[r]] : make_uint2(0, 0);
+#pragma unroll
+            for (u32 r = 0; r < 4; ++r) kv[r] = ((u64)rec[r].x << 32) | rec[r].y;
+          } else {
+#pragma unroll
+            for (u32 r = 0; r < 4; ++r) kv[r] = ((u64)mine[r] << 32) | SAX_ESCAPE;
+          }
+#pragma unroll
+          for (u32 r = 0; r < 4; ++r)
+            if (threadIdx.x + r * 256 < have) keys[threadIdx.x + r * 256] = kv[r];
+          __syncthreads();
+        }
         const unsigned long long p3 = DG_LPROF_NOW();
         u64 sv[4];
         if (bucket_sort_keys<256>(keys, S.val, S.hist, have)) {  // (the candidates in val are dead: its first 1 024 words count)
@@ -660,6 +704,8 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
         DG_LPROF_ADD(pb + 7, p5 - p0);
         break;
       }
+      if constexpr (KC != TOPK_KCAP) break;  // (the small-buffer form never leaves the entries: no code, no registers for the walk)
+      else {
       // blocks of level j under the threshold -> cidx[cur ^ 1]
       for (u32 base = 0; base < nv; base += 256) {
         const u32 p = base + threadIdx.x;
@@ -681,19 +727,33 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
       const u32* lv = f.samin[j - 1];
       const bool recs = j - 1 == 0 && sax_on;  // the entries themselves: from the records, whose lines the survivors read again
       const u64 nlow = j - 1 == 0 ? f.n : ~0ULL;  // level 0 is the suffix array itself: nothing beyond n
-      for (u32 i = threadIdx.x; i < nc; i += 256) {
-        const u64 c8 = (u64)S.cidx[cur * KC + i] * 8;
-        u32 v[8];
-        if (recs) {
-          const uint4* r4 = reinterpret_cast<const uint4*>(f.sax + c8);
-          const uint4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
-          v[0] = a.x, v[1] = a.z, v[2] = b.x, v[3] = b.z, v[4] = c.x, v[5] = c.z, v[6] = d.x, v[7] = d.z;
-        } else {
-          const uint4 x = *reinterpret_cast<const uint4*>(lv + c8), y = *reinterpret_cast<const uint4*>(lv + c8 + 4);
-          v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w, v[4] = y.x, v[5] = y.y, v[6] = y.z, v[7] = y.w;
+      // (the blocks of two trips are read before either is stored: the loads of a lane's blocks are in flight together)
+      for (u32 base = 0; base < nc; base += 2 * 256) {
+        u32 v[2][8];
+        u64 c8[2];
+#pragma unroll
+        for (u32 u = 0; u < 2; ++u) {
+          const u32 i = base + u * 256 + threadIdx.x;
+          c8[u] = i < nc ? (u64)S.cidx[cur * KC + i] * 8 : 0;
+          if (i < nc) {
+            if (recs) {
+              const uint4* r4 = reinterpret_cast<const uint4*>(f.sax + c8[u]);
+              const uint4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
+              v[u][0] = a.x, v[u][1] = a.z, v[u][2] = b.x, v[u][3] = b.z, v[u][4] = c.x, v[u][5] = c.z, v[u][6] = d.x, v[u][7] = d.z;
+            } else {
+              const uint4 x = *reinterpret_cast<const uint4*>(lv + c8[u]), y = *reinterpret_cast<const uint4*>(lv + c8[u] + 4);
+              v[u][0] = x.x, v[u][1] = x.y, v[u][2] = x.z, v[u][3] = x.w, v[u][4] = y.x, v[u][5] = y.y, v[u][6] = y.z, v[u][7] = y.w;
+            }
+          }
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) S.val[8 * i + t] = c8 + t < nlow ? v[t] : TOPK_PAD;
+        for (u32 u = 0; u < 2; ++u) {
+          const u32 i = base + u * 256 + threadIdx.x;
+          if (i < nc) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) S.val[8 * i + t] = c8[u] + t < nlow ? v[u][t] : TOPK_PAD;
+          }
+        }
       }
       const u64 a1 = A(j), b1 = B(j), a0 = A(j - 1), b0 = B(j - 1);
       const u32 nl = (u32)(8 * a1 - a0), nr = (u32)(b0 - 8 * b1);
@@ -707,6 +767,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
       nc_prev = nc;
       __syncthreads();
       p_lev += DG_LPROF_NOW() - pt1;
+      }
     }
   }
   if (threadIdx.x == 0 && reads) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)reads);

@@ -582,6 +582,10 @@ def main():
                     help="hunt configs: batches in flight per GPU in the timed region: 2 or 3 = dg_hunt_device_submit / dg_hunt_wait on the handle's "
                          "lanes (step k is submitted, step k - n + 1 collected), 1 = dg_hunt_device, one batch at a time (r01-r04a); "
                          "more than 3 need a library built with -DDG_NEXTRA=n-1 (tools/r05_call13.sh: measured, no gain)")
+    ap.add_argument("--stagger-us", type=float, default=0.0,
+                    help="hunt configs with batches in flight: the first submissions of the timed region (and of the sustained pass) are this many "
+                         "microseconds apart instead of back to back, so that the lanes do not start their search kernels together (measurement "
+                         "of the lanes' lock-step, DESIGN; the waits lie INSIDE the timed region)")
     ap.add_argument("--batches", type=int, default=16,
                     help="hunt configs: distinct query batches resident in HBM that the warm-up and timed steps cycle through (step k "
                          "searches batch k mod B; hunter.h:291 searches every query once, so the headline never replays a batch within "
@@ -931,6 +935,10 @@ def main():
         def step_pipe():
             if nq == 0:
                 return step()
+            if a.stagger_us > 0 and inflight and len(inflight) < a.in_flight:  # the pipeline is filling: space the lanes' starts
+                t_ = time.perf_counter() + a.stagger_us * 1e-6
+                while time.perf_counter() < t_:
+                    pass
             bq, bo, bbytes = dev_batches[rot["k"] % len(dev_batches)]
             rot["k"] += 1
             tk = C.c_void_p()
@@ -1232,7 +1240,7 @@ def main():
                            "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
                            "workload_tag": wtag, "traffic_file": tname,
                            "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
-                           "distinct_batches": len(dev_batches), "in_flight_batches": a.in_flight,
+                           "distinct_batches": len(dev_batches), "in_flight_batches": a.in_flight, "stagger_us": a.stagger_us,
                            "results": "the batch's compact block (DG_HUNT_COMPACT: 8 B per query + 8 + 4 d B per hit) left in HBM (N = 1) / gathered to rank 0 "
                                       "over RCCL by the C++ gather, libdiceygather.so (N > 1)",
                            "in_flight": (f"{a.in_flight} batches per GPU (dg_hunt_device_submit / dg_hunt_wait on the handle's lanes: step k is submitted, "

@@ -13,13 +13,17 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <functional>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <atomic>
 #include <vector>
 
 #include "../../include/dicey_gpu.h"
@@ -45,6 +49,18 @@ struct DnaHit {  // hunter.h:53-66
   }
 };
 
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline bool timing_on() {
+  static const bool on = std::getenv("DICEY_TIMING") != nullptr;
+  return on;
+}
+
+// one query of the input: name and sequence as views of the input file's bytes (r06: 10 M records as pairs of std::string were 20 M
+// heap allocations, half a second of a 3 s run); a sequence that spans several lines is joined in `owned`
+struct Query {
+  std::string_view first, second;
+};
+
 struct Config {
   std::string genome, outfile, input;
   bool has_outfile = false, hamming = false, forward = false, help = false;
@@ -53,7 +69,7 @@ struct Config {
 };
 
 // hunter.h:99-160 (r04: appended in place — at 10 M queries per run the temporaries of the first form were the run time)
-void hunt_json_append(std::string& o, const Config& c, uint32_t distance, const std::string& sequence, const std::string& qname,
+void hunt_json_append(std::string& o, const Config& c, uint32_t distance, std::string_view sequence, std::string_view qname,
                       const std::vector<std::string>& seqname, const std::vector<DnaHit>& ht, const std::vector<std::string>& msg) {
   o += "{\"errors\": [";
   bool errors = false;
@@ -81,12 +97,12 @@ void hunt_json_append(std::string& o, const Config& c, uint32_t distance, const 
     uint_append(o, c.max_locations);
     if (!qname.empty()) {
       o += ",\"name\":";
-      jstr_append(o, qname);
+      jstr_append(o, qname.data(), qname.size());
     }
     o += ",\"outfile\":";
     jstr_append(o, c.outfile);
     o += ",\"sequence\":";
-    jstr_append(o, sequence);
+    jstr_append(o, sequence.data(), sequence.size());
     o += ",\"subcommand\":\"hunt\",\"version\":\"";
     o += kVersion;
     o += "\"},\"data\":[";
@@ -121,7 +137,7 @@ void hunt_json_append(std::string& o, const Config& c, uint32_t distance, const 
   }
   o += "}\n";
 }
-std::string hunt_json(const Config& c, uint32_t distance, const std::string& sequence, const std::string& qname,
+std::string hunt_json(const Config& c, uint32_t distance, std::string_view sequence, std::string_view qname,
                       const std::vector<std::string>& seqname, const std::vector<DnaHit>& ht, const std::vector<std::string>& msg) {
   std::string o;
   hunt_json_append(o, c, distance, sequence, qname, seqname, ht, msg);
@@ -222,7 +238,7 @@ struct GatherApi {
 };
 
 template <class FormatFn>
-int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const std::vector<std::pair<std::string, std::string>>& queries,
+int hunt_ranks(const Config& c, int N, int rank, dg_index* ix, int device, const std::vector<Query>& queries,
                const std::vector<uint32_t>& seqlen, const dg_hunt_params& hp, FormatFn& format_chunk_to) {
   auto die = [&](const std::string& m) {
     std::cerr << "dicey (rank " << rank << " of " << N << "): " << m << std::endl;
@@ -476,40 +492,60 @@ int hunter(int argc, char** argv) {
   std::string index_file = strip_last_extension(c.genome) + ".fm9";
   // hunter.h:262-287: a FASTA file of queries, or the literal sequence (read before the index is opened: the shard plan
   // needs the count; a malformed input is still reported after a failing index, as in the reference)
-  std::vector<std::pair<std::string, std::string>> queries;
+  std::vector<Query> queries;
+  std::string qfile;                 // the input file's bytes: names and sequences are views of it
+  std::deque<std::string> owned;     // sequences that span several lines, joined
   bool bad_fasta = false;
+  const double t_read0 = now_ms();
   if (is_regular(c.input)) {
     if (!is_fasta(c.input)) bad_fasta = true;
     else {
       // hunter.h:272-283 over the whole file in memory (10 M records: std::getline per line was seconds)
-      std::string buf;
       if (FILE* f = std::fopen(c.input.c_str(), "rb")) {
         std::fseek(f, 0, SEEK_END);
         const long sz = std::ftell(f);
         std::fseek(f, 0, SEEK_SET);
-        buf.resize(sz > 0 ? (size_t)sz : 0);
-        if (sz > 0 && std::fread(&buf[0], 1, (size_t)sz, f) != (size_t)sz) buf.clear();
+        qfile.resize(sz > 0 ? (size_t)sz : 0);
+        if (sz > 0 && std::fread(&qfile[0], 1, (size_t)sz, f) != (size_t)sz) qfile.clear();
         std::fclose(f);
       }
-      queries.reserve(buf.size() / 28 + 16);
-      std::string fan, faseq;
-      const char* p0 = buf.data();
-      const char* const end = p0 + buf.size();
+      queries.reserve(qfile.size() / 28 + 16);
+      // a record = a name line and the non-empty lines up to the next '>' (std::getline keeps a '\r', so does this); the reference
+      // keeps a record when name and sequence are both non-empty (hunter.h:276-283)
+      std::string_view name, seq;
+      bool have = false, joined = false;
+      auto flush = [&]() {
+        if (have && !name.empty() && !seq.empty()) queries.push_back(Query{name, seq});
+        else if (joined) owned.pop_back();
+      };
+      const char* p0 = qfile.data();
+      const char* const end = p0 + qfile.size();
       while (p0 < end) {
         const char* nl = (const char*)std::memchr(p0, '\n', (size_t)(end - p0));
         const char* e = nl ? nl : end;
-        if (e > p0) {  // (empty lines are skipped; std::getline keeps a '\r', so does this)
+        if (e > p0) {  // (empty lines are skipped)
           if (*p0 == '>') {
-            if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
-            faseq.clear();
-            fan.assign(p0 + 1, e);
-          } else faseq.append(p0, e);
+            flush();
+            name = std::string_view(p0 + 1, (size_t)(e - p0 - 1));
+            seq = std::string_view();
+            have = true;
+            joined = false;
+          } else if (seq.empty() && !joined) seq = std::string_view(p0, (size_t)(e - p0));
+          else {  // a second sequence line: the record's sequence moves into a string of its own
+            if (!joined) {
+              owned.emplace_back(seq);
+              joined = true;
+            }
+            owned.back().append(p0, e);
+            seq = owned.back();
+          }
         }
         p0 = nl ? nl + 1 : end;
       }
-      if (!fan.empty() && !faseq.empty()) queries.emplace_back(fan, faseq);
+      flush();
     }
-  } else queries.emplace_back(std::string(), c.input);
+  } else queries.push_back(Query{std::string_view(), std::string_view(c.input)});
+  if (timing_on()) std::fprintf(stderr, "dicey timing: %-28s %8.1f ms\n", "input read + records", now_ms() - t_read0);
 
   // the K-mer jump table (up to 137 GB, ~1.5 s to derive) only pays off for large batches: a literal sequence or a
   // small FASTA is answered from the Occ blocks alone
@@ -572,14 +608,14 @@ int hunter(int argc, char** argv) {
     auto line_of = [&](size_t i) -> std::string {
       std::vector<std::string> m;
       std::vector<DnaHit> ht;
-      const std::string& qname = queries[q0 + i].first;
+      const std::string_view qname = queries[q0 + i].first;
       // compact results (DG_HUNT_COMPACT): one word per query; the normalised sequence is formed here from the query's own bytes
       const uint32_t qw = R->qinfo[i], qfl = DG_QINFO_FLAGS(qw);
       if (qfl & DG_Q_TOO_SHORT) {
         m.push_back("Error: Input sequence is shorter than 10 nucleotides!");
         return hunt_json(c, c.distance, queries[q0 + i].second, qname, seqname, ht, m);
       }
-      const std::string& raw = queries[q0 + i].second;
+      const std::string_view raw = queries[q0 + i].second;
       std::string seq(raw.size(), '\0');
       uint32_t nondna = 0;
       (void)dg_normalize_query((const uint8_t*)raw.data(), (uint32_t)raw.size(), (uint8_t*)seq.data(), &nondna);

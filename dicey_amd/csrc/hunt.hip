@@ -1024,7 +1024,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       va.ops = ws[WS_OPS].as<u32>();
       va.ops_per_hit = ops_per_hit;
       va.chits = nullptr;
-      va.debug = 0;
+      va.debug = (sw.exp_bits >> 4) & 3u;  // (DICEY_EXP bits 4-5, measurement aid: verify without its alignments / without the hits' context)
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
       const dim3 vgrid(ceil_div(hit_cap, VT)), vblock(VT);

@@ -929,7 +929,17 @@ int dg_index_share(dg_index* src, dg_index** out) {
   ix->jobs_hint = src->jobs_hint;
   ix->fetch_hits_hint = src->fetch_hits_hint;
   ix->fused_leaves_hint = src->fused_leaves_hint;
-  if (hipStreamCreate(&ix->stream) != hipSuccess) {
+  // DICEY_EXP_PRIO (measurement aid, r06): the shares of an index — its internal lanes — get stream priorities in turn (highest,
+  // lowest, highest, ...) while the index's own stream stays at the default, so that the lanes' search kernels do not share the chip
+  // evenly (which keeps the lanes in step: DESIGN "lanes")
+  static std::atomic<unsigned> n_shares{0};
+  hipError_t se = hipSuccess;
+  if (std::getenv("DICEY_EXP_PRIO")) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    se = hipStreamCreateWithPriority(&ix->stream, hipStreamDefault, (n_shares.fetch_add(1) & 1u) ? least : greatest);
+  } else se = hipStreamCreate(&ix->stream);
+  if (se != hipSuccess) {
     delete ix;
     return fail(DG_EHIP, "dg_index_share: cannot create a stream");
   }

@@ -185,7 +185,7 @@ def contract_line(out: dict, detail_path: str = "") -> str:
     # the witness of the headline: the same pipeline over at least a second (20 steps x 0.19 ms is a 3.7 ms measurement)
     line["sustained"] = _pick(out.get("sustained"), ("value", "unit", "seconds", "steps", "ms_per_step"))
     line["parity_sample"] = _pick(out.get("parity_sample"), ("queries", "mismatching", "hits"))
-    for k in ("value_one_in_flight", "value_with_d2h", "host_to_host_pipelined", "cli_end_to_end_10M"):
+    for k in ("value_one_in_flight", "value_with_d2h", "host_to_host_pipelined", "cli_end_to_end_10M", "cli_end_to_end_d2_1M"):
         if isinstance(out.get(k), dict) and "value" in out[k]:
             line.setdefault("delivery", {})[k] = float("%.6g" % out[k]["value"])
     for k in sorted(out):
@@ -564,7 +564,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default run only (hunt_d1, i.i.d. genome, N=1): skip the compact sub-lines of the other configurations "
                          "(extra_configs: hunt_d1_repeats, hunt_d2, hunt_d2_25mers, search, padlock), which are measured by re-running this script")
-    ap.add_argument("--extra-budget-s", type=float, default=300.0, help="wall-clock budget of the extra_configs block")
+    ap.add_argument("--extra-budget-s", type=float, default=330.0, help="wall-clock budget of the extra_configs block")
     ap.add_argument("--big-table", action="store_true",
                     help="open the index with DG_OPEN_BIG_TABLE (K-mer table one order larger: 199 GB instead of 90 GB resident on the "
                          "GRCh38-size genome, search kernel ~5 %% faster); the default is the library's default layout")
@@ -607,6 +607,18 @@ def main():
                     help="directory: every rank writes the hit-list bytes of its last step (local_<rank>.bin) and rank 0 what the "
                          "gather delivered for every rank (gathered_<rank>.bin); used by the tests")
     a = ap.parse_args()
+
+    # BASELINE configs[3] at its size on ONE GPU: `--config hunt_d2 --queries 10000000 --scaling strong --gpus 1` is one
+    # batch of --queries cut into chunks of 100 000 (the per-GPU batch of every other hunt line), a.in_flight of them in flight, every
+    # chunk distinct and all of them started and drained inside the timed region: steps = chunks, each searching its own queries.
+    a.total_queries = 0
+    if a.scaling == "strong" and a.gpus == 1 and "WORLD_SIZE" not in os.environ and a.config in ("hunt_d1", "hunt_d2") and a.queries > 131072:
+        chunk = 100000
+        a.total_queries = (a.queries + chunk - 1) // chunk * chunk
+        a.batches = a.total_queries // chunk
+        a.steps = a.batches
+        a.warmup = min(a.warmup, 6)
+        a.queries = chunk
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by hand: launch the ranks ourselves, exactly as the driver would (one process per GPU)
@@ -1239,6 +1251,9 @@ def main():
                            "genome": genome_desc, "genome_short": genome_short,
                            "index": "sdsl csa_wt<> .fm9 built by dg_index_build_device, loaded unchanged by dg_index_open",
                            "workload_tag": wtag, "traffic_file": tname,
+                           **({"total_queries": a.total_queries,
+                               "chunks": f"{a.total_queries} distinct queries as {a.batches} chunks of {nq}, {a.in_flight} in flight; every chunk is searched once, "
+                                         "inside the timed region (steps = chunks)"} if a.total_queries else {}),
                            "queries_per_gpu": nq, "sharding": f"query-sharded x{world}, full index replica per GPU",
                            "distinct_batches": len(dev_batches), "in_flight_batches": a.in_flight, "stagger_us": a.stagger_us,
                            "results": "the batch's compact block (DG_HUNT_COMPACT: 8 B per query + 8 + 4 d B per hit) left in HBM (N = 1) / gathered to rank 0 "
@@ -1315,6 +1330,9 @@ def main():
                 "hits_per_step": int(acc[-1]["nhits"]), "leaves_per_step": int(acc[-1]["leaves"]),
             })
             out.update(extras)
+            if a.total_queries:
+                out["seconds"] = elapsed
+                out["queries"] = a.total_queries
             # Capped neighbourhoods (neighbors.h:50) are settled in front of the batch: on the device (k_cap_enum) for A/C/G/T primers up to
             # 29 nt at edit distance <= 2, on the host otherwise.  When that stage is the longest of the step its kernel is the dominant one.
             cap_ms = mean("ms_cap")
@@ -1577,13 +1595,22 @@ def main():
                     out["cli_end_to_end_1M"] = cli_end_to_end(fm9, meta, big[:1000000], cli_job[1], oracle=chk, seqlen=seqlen)
                     out["cli_end_to_end_10M" if len(big) == 10000000 else "cli_end_to_end_%d" % len(big)] = \
                         cli_end_to_end(fm9, meta, big, cli_job[1], oracle=chk, seqlen=seqlen)
+                    # the same seam at edit distance 2 (BASELINE configs[3]'s distance): 59 hits and ~11 KB of JSON per query on this genome,
+                    # i.e. 110 GB for 10 M queries — the reference would write the same — so this run takes the first 1 M (11 GB)
+                    if chk is not None:
+                        O.fast_neighbors(True)
+                    try:
+                        out["cli_end_to_end_d2_1M"] = cli_end_to_end(fm9, meta, big[:1000000], 2, oracle=chk, seqlen=seqlen, bytes_per_query=12000)
+                    finally:
+                        if chk is not None:
+                            O.fast_neighbors(False)
                 except Exception as e:
                     out["cli_end_to_end_10M"] = {"error": repr(e)[:300]}
         if (world == 1 and cfg == "hunt_d1" and a.genome == "iid" and not a.no_extra_configs and not a.no_extras and not a.queries
                 and a.distance < 0 and a.qlen == 20):
             out["extra_configs"] = run_extra_configs(a, fm9)
             # compact top-level summaries of the sub-lines (the driver's record keeps top-level keys whole)
-            for name_ in ("hunt_d1_repeats", "hunt_d2", "hunt_d2_25mers", "hunt_d2_hamming", "hunt_d1_nmix", "search", "padlock"):
+            for name_ in ("hunt_d1_repeats", "hunt_d2", "hunt_d2_10M", "hunt_d2_25mers", "hunt_d2_hamming", "hunt_d1_nmix", "search", "padlock"):
                 sub_ = out["extra_configs"].get(name_)
                 if isinstance(sub_, dict) and "value" in sub_:
                     rf_ = sub_.get("roofline") or {}
@@ -1593,6 +1620,8 @@ def main():
                                                "frac": float("%.4g" % rf_["frac"]) if rf_.get("frac") else None,
                                                "traffic": float("%.4g" % rf_["traffic"]) if rf_.get("traffic") else None,
                                                "parity": _pick(sub_.get("parity_sample"), ("queries", "mismatching"))}
+                    if sub_.get("queries"):  # a run over a stated number of queries (configs[3] at its size): how many, in how long
+                        out["summary_" + name_].update({"queries": sub_["queries"], "seconds": float("%.4g" % sub_["seconds"])})
         out["build_id"] = build_id()
         emit(out, a.detail_out)
     barrier()
@@ -1621,12 +1650,14 @@ def run_extra_configs(a, fm9):
                                 "--parity-queries", "100"], True),
             # what the general kernel k_search serves: Hamming distance 2 (neighbors.h:57-66 without the indel
             # branches) and queries with an N (hunter.h:306-307, util.h:208-219)
+            # BASELINE configs[3] at its stated size on one GPU: 10 M distinct 20-mers at edit distance 2, 100 chunks, three in flight
+            ("hunt_d2_10M", ["--config", "hunt_d2", "--queries", "10000000", "--scaling", "strong", "--cpu-seconds", "2", "--parity-queries", "300"], True),
             ("hunt_d2_hamming", ["--config", "hunt_d2", "--hamming", "--steps", "30", "--warmup", "8", "--cpu-seconds", "4", "--parity-queries", "300"], True),
             ("hunt_d1_nmix", ["--config", "hunt_d1", "--n-frac", "0.05", "--steps", "30", "--warmup", "8", "--cpu-seconds", "4", "--parity-queries", "300"], True),
             ("search", ["--config", "search", "--steps", "2", "--warmup", "1", "--cpu-seconds", "6"], True),
             ("padlock", ["--config", "padlock", "--steps", "3", "--warmup", "1", "--cpu-seconds", "6"], True)]
     keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "roofline_search", "cpu_baseline", "parity_sample", "cap_stage",
-            "phases_ms", "hits_per_step", "site_stage", "positions_per_s", "value_with_d2h")
+            "phases_ms", "hits_per_step", "site_stage", "positions_per_s", "value_with_d2h", "seconds", "queries")
     res = {}
     for name, args, reuse in plan:
         left = a.extra_budget_s - (time.time() - t_start)
@@ -1639,7 +1670,7 @@ def run_extra_configs(a, fm9):
             cmd += ["--fm9", fm9]
         t0 = time.time()
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=max(30.0, min(left, 150.0)))
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=max(30.0, min(left, 240.0 if name == "hunt_d2_10M" else 150.0)))
             if r.returncode != 0 or not os.path.exists(dpath):
                 res[name] = {"error": "exit code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
                 continue
@@ -1657,7 +1688,7 @@ def run_extra_configs(a, fm9):
         except Exception as e:  # a sub-line never takes the headline down
             res[name] = {"error": str(e)[:300]}
     import glob
-    for f in glob.glob(fm9 + ".*.meta.json"):  # the sub-runs' query sets next to the reused index
+    for f in glob.glob(fm9 + ".*.meta.json") + glob.glob(fm9 + ".*.npy"):  # the sub-runs' query sets next to the reused index
         if not f.startswith(fm9 + ".hunt_d1."):
             try:
                 os.remove(f)
@@ -1667,7 +1698,7 @@ def run_extra_configs(a, fm9):
     return res
 
 
-def cli_end_to_end(fm9, meta, queries, distance, oracle=None, seqlen=None):
+def cli_end_to_end(fm9, meta, queries, distance, oracle=None, seqlen=None, bytes_per_query=700):
     """The process seam: `dicey hunt -g <genome> <queries.fa>` on the same queries, wall clock of the whole process (index
     open + derivation, search, JSON for every query).  hunt reads only <genome>.fai and the .fm9 next to the genome.
     queries: list of bytes, or a uint8 array [n, m] (the large runs).  oracle (large runs): three slices of 100 lines of THIS run's
@@ -1717,7 +1748,7 @@ def cli_end_to_end(fm9, meta, queries, distance, oracle=None, seqlen=None):
         made.append(outp)
         try:  # ~650 output bytes per query land in /dev/shm, i.e. in memory: a box short of it gets /dev/null (and no parity slices)
             avail_kb = [int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0]
-            if avail_kb * 1024 < 3 * 700 * nq + (8 << 30):
+            if avail_kb * 1024 < 3 * bytes_per_query * nq + (8 << 30):
                 outp = "/dev/null"
                 oracle = None
         except Exception:

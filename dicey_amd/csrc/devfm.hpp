@@ -114,7 +114,39 @@ struct FmView {
   // characters behind a string of 16..27 characters that starts at p, bit 31 = some character of either window is not
   // A/C/G/T or lies outside the text (the hit then reads the text as before).  nullptr = not built.
   const uint2* sax;
+  // Prefix levels (derived at load with sax, r06): for X = 2^16, 2^18, ... (below n) the suffixes whose text position lies below X,
+  // in suffix-array order — plv[l].rec[r] = sax[i] for the r-th such i — and a rank directory over the suffix-array indices
+  // (plv[l].dir: one 64-byte line per 448 indices = {count before the line, seven 64-bit words of flags}).  hunter.h:355-357 keeps the
+  // `take` SMALLEST positions of a string's occurrences: for a repeat family with 100 000 copies spread over the genome those all
+  // lie below a small X, and the entries of [lo, hi) with position < X are ONE contiguous run of plv[l].rec (two rank reads) — a few
+  // thousand records to select from instead of a walk down the block minima over the whole interval.  k_locate picks the level by
+  // the interval's density and checks that the run holds at least `take` records (then the answer is inside it); otherwise the
+  // string takes the walk as before.  nplv = 0: not built.
+  struct PrefixLevel {
+    const u64* dir;
+    const uint2* rec;
+    u64 x;
+  };
+  static constexpr u32 MAXPLV = 8, PLV_LINE = 448;
+  PrefixLevel plv[MAXPLV];
+  u32 nplv;
 };
+// entries of the suffix array below index i whose text position lies below the level's X
+DG_DEV u64 plv_rank(const FmView::PrefixLevel& L, u64 i) {
+  const u64 line = i / FmView::PLV_LINE;
+  const u32 r = (u32)(i - line * FmView::PLV_LINE), w = r >> 6, b = r & 63u;
+  const uint4* p = reinterpret_cast<const uint4*>(L.dir + line * 8);
+  const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+  const u64 word[8] = {((u64)q0.y << 32) | q0.x, ((u64)q0.w << 32) | q0.z, ((u64)q1.y << 32) | q1.x, ((u64)q1.w << 32) | q1.z,
+                       ((u64)q2.y << 32) | q2.x, ((u64)q2.w << 32) | q2.z, ((u64)q3.y << 32) | q3.x, ((u64)q3.w << 32) | q3.z};
+  u64 c = word[0];
+#pragma unroll
+  for (u32 j = 0; j < 7; ++j) {
+    const u64 m = j < w ? ~0ULL : (j == w ? ((1ULL << b) - 1ULL) : 0ULL);
+    c += (u64)__popcll(word[1 + j] & m);
+  }
+  return c;
+}
 static constexpr u32 SAX_POST_OFF = 16, SAX_POST_N = 13, SAX_ESCAPE = 0x80000000u;
 // HitSeed::len of a located hit that carries its context (set by the locate job kernels, read by k_verify_memo only): bits 0-19 the
 // string's length, bit 31 "context valid", bits 20-21 / 22-23 the codes of T[pos-1] / T[pos-2], bits 24-25 / 26-27 of T[pos+len] /

@@ -791,7 +791,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     const u32 flat_cap = fused ? flat_req : 0u;
     const u64 flat_slots = (u64)NSHARD * flat_cap;
     const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
-    bool jobs_on = false, walker_on = true;
+    bool jobs_on = false, walker_on = true, with_ctx_hits = false;
     DG_TRY(ws[WS_LEAF].reserve(leaf_slots * sizeof(Leaf)));
     DG_TRY(ws[WS_LEAFG].reserve((leaf_slots + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
     DG_TRY(ws[WS_SEL].reserve((flat_slots + leaf_slots + 1) * sizeof(Sel)));
@@ -981,6 +981,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       // hits of the job kernels leave with their context characters (FmView::sax) when the kernel that reads the seeds is
       // k_verify_memo — the only reader that knows the encoding (HitSeed::len, devfm.hpp)
       const u32 with_ctx = (!sx && !group_counts && band_verify && ix->view.sax) ? 1u : 0u;
+      with_ctx_hits = with_ctx != 0;
       // the record that shares a kept string's slot names its group: the packed leaf (qs behind 28 bytes) or the grouped leaf (qs first)
       const u8* slot_qs = packed ? (const u8*)ws[WS_LEAFG].p + offsetof(PLeaf, qs) : (const u8*)ws[WS_LEAFG].p + offsetof(Leaf, qs);
       const u32 slot_stride = packed ? (u32)sizeof(PLeaf) : (u32)sizeof(Leaf);
@@ -1037,7 +1038,11 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         // (distance 2 on an i.i.d. genome: 59 hits per query from ~50 strings — nothing to share, and the wider trace of 13 diagonals
         //  leaves room for fewer workgroups: r03 measured 2.39 ms with 8 hits per lane against 1.83 ms for the lane-per-hit kernel)
         const u64 share_at = dmax_eff > 1 ? 192 : 24;
-        const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= share_at ? 8 : (per_q >= share_at / 2 ? 4 : 1));
+        // r06: with the hits' context in their seeds (FmView::sax) the kernel no longer waits for a text line per hit, and what it
+        // answers to is residency: 4 hits per lane leave room for four workgroups per CU, 8 for two (one batch at a time on the
+        // repeats genome, verify: 0.61 ms with 8, 0.48 ms with 4)
+        const int ch_rich = (with_ctx_hits && dmax_eff <= 1) ? 4 : 8;
+        const int ch = ch_env == 1 || ch_env == 4 || ch_env == 8 ? ch_env : (per_q >= share_at ? ch_rich : (per_q >= share_at / 2 ? 4 : 1));
         const u32 rows = maxlen + 3 * dmax_eff + 2;
         const bool wide = dmax_eff > 1;
         const u32 nw_bytes = ((rows * 256 * (wide ? 4u : 2u) + 7u) & ~7u) + 6u * 256u * 8u, hash_bytes = 2u * 256u * (u32)ch * 10u;

@@ -8,8 +8,12 @@ namespace dg {
 // ------------------------------------------------------------------------------------------------------------
 // Locate: the `take` smallest SA values of [lo,hi), ascending (locate + std::sort + first min(occs,max) entries).
 static constexpr u32 TOPK_KMAX = 1024;  // largest `take` k_locate_topk serves (its LDS holds 8 * 1 152 candidate minima)
+static constexpr u32 TOPK_KCAP = 1152;      // blocks kept per level: k plus slack, so that one histogram pass usually decides
+static constexpr u32 TOPK_KCAP_MID = 576;   // the small-buffer form: intervals of up to 8 * 576 entries, read whole
 struct BigJob {  // a repeat-rich string: handled by one workgroup of k_locate_topk / k_locate_big
-  u32 lo, occs, take, g, len;
+  u32 lo, occs, take, g;
+  u32 len;   // bits 0-23 the string's length; bits 24-31: 0 = [lo, lo + occs) is its suffix-array interval, l + 1 = a run of the records
+             // of prefix level l (FmView::plv[l].rec) that holds the interval's `take` smallest positions (k_locate found it)
   u32 slot;  // of the kept string (HitSeed::sel)
   u64 out;   // first hit slot
 };
@@ -131,6 +135,26 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
         bj.out = out0;
         // (hunt -m above 16 384: served by this lane, below)
         queue = take > 16384 ? 4u : occs <= LOC_SMALL_MAX ? 1u : (occs <= jobs.mid_max && take <= TOPK_KMAX) ? 2u : 3u;
+        // r06: a string with far more occurrences than it may report (a repeat family): the occurrences below text position X are one
+        // run of level l's records; the coarsest-grained level whose run should hold about 2 take .. 8 take of them by the interval's
+        // density is asked (two rank reads), then — while the run is too short — the next ones; a run of take .. 9 216 records
+        // replaces the interval (and the walk down the block minima over it), anything else keeps it
+        if (queue == 3u && take <= TOPK_KMAX && f.nplv && occs > 2 * TOPK_KCAP_MID * 8u) {
+          u32 lv = 0;
+          while (lv < f.nplv && (u64)occs * f.plv[lv].x < 2ULL * take * f.n) ++lv;
+          for (; lv < f.nplv; ++lv) {
+            const u64 r0 = plv_rank(f.plv[lv], lo), r1 = plv_rank(f.plv[lv], (u64)lo + occs);
+            reads += 16;
+            if (r1 - r0 > 8ULL * TOPK_KCAP) break;  // denser here than on average: the walk serves it
+            if (r1 - r0 >= take) {
+              bj.lo = (u32)r0;
+              bj.occs = (u32)(r1 - r0);
+              bj.len = slen | ((lv + 1u) << 24);
+              queue = bj.occs <= jobs.mid_max ? 2u : 3u;
+              break;
+            }
+          }
+        }
       }
     }
   }
@@ -160,12 +184,13 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
     bool first = true;
     for (u32 i = 0; i < bj.take; ++i) {
       u32 best = 0xFFFFFFFFu;
+      const u32 lvq = bj.len >> 24;
       for (u32 j = 0; j < bj.occs; ++j) {
-        const u32 x = f.sa[bj.lo + j];
+        const u32 x = lvq ? f.plv[lvq - 1].rec[bj.lo + j].x : f.sa[bj.lo + j];
         if ((first || x > prev) && x < best) best = x;
       }
       reads += bj.occs;
-      seeds[bj.out + i] = HitSeed{best, bj.g, bj.len, bj.slot};
+      seeds[bj.out + i] = HitSeed{best, bj.g, bj.len & 0xFFFFFFu, bj.slot};
       prev = best;
       first = false;
     }
@@ -434,7 +459,7 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, LocJobs jobs, HitS
         }
         __syncthreads();
       }
-    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len, J.slot};
+    for (u32 i = threadIdx.x; i < J.take; i += blockDim.x) seeds[J.out + i] = HitSeed{buf[i], J.g, J.len & 0xFFFFFFu, J.slot};
     if (threadIdx.x == 0) atomicAdd(&ctr->sa_reads[blockIdx.x & (NSHARD - 1)], (unsigned long long)passes * J.occs);
     __syncthreads();
   }
@@ -451,7 +476,6 @@ __global__ void __launch_bounds__(256) k_locate_big(FmView f, LocJobs jobs, HitS
 //               loads each), plus the < 8 blocks of the finer level that stick out at either end of the interval;
 //   entries     the select is carried on to the exact k-th value, the k survivors are sorted (bitonic) and written.
 // Reads: at most the top level's blocks (<= 9 232) and 8 * KCAP + 14 words per level below, whatever the interval holds.
-static constexpr u32 TOPK_KCAP = 1152;         // blocks kept per level: k plus slack, so that one histogram pass usually decides
 static constexpr u32 TOPK_PAD = 0xFFFFFFFFu;
 template <u32 KC>
 struct TopkLdsT {
@@ -558,7 +582,6 @@ DG_DEV u32 topk_threshold(LDS& S, u32 nv, u32 k, u32 limit) {
 // FmView::sax, and the survivors leave with their context word — at the entries a survivor's slot in `val` is overwritten by its
 // index inside the interval, and once the index lists are dead the record {position, context} is read again (an L2 hit: this
 // workgroup fetched the line a moment ago) into a 64-bit key, so the sort carries the context along.
-static constexpr u32 TOPK_KCAP_MID = 576;
 template <u32 KC>
 __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32 which, HitSeed* seeds, Counters* ctr, u32 with_ctx) {
   constexpr u32 VMAXT = 8 * KC + 16;
@@ -576,19 +599,22 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
     const BigJob J = jobs.list[which][job_slot(S.ji, jobs.shard_cap, jb)];
     if (J.take > TOPK_KMAX) continue;  // k_locate_big's (hunt -m above 1 024)
     const u32 k = J.take;
+    const u32 lvj = J.len >> 24, jlen = J.len & 0xFFFFFFu;  // a run of a prefix level's records, or the suffix-array interval itself
+    const uint2* const recs = lvj ? f.plv[lvj - 1].rec : f.sax;
+    const bool use_recs = sax_on || lvj;
     const u64 lo = J.lo, hi = (u64)J.lo + J.occs;
     // full blocks of level j inside [lo, hi): [A(j), B(j))
     auto A = [&](int j) -> u64 { return (lo + ((1ULL << (3 * j)) - 1)) >> (3 * j); };
     auto B = [&](int j) -> u64 { return hi >> (3 * j); };
     auto N = [&](int j) -> u64 { return B(j) > A(j) ? B(j) - A(j) : 0ULL; };
     int L = 0;
-    while (L + 1 < (int)f.nlev && N(L) > VMAXT - 16) ++L;  // a level left with more than 9 216 blocks has > 1 000 in the next
+    while (!lvj && L + 1 < (int)f.nlev && N(L) > VMAXT - 16) ++L;  // a level left with more than 9 216 blocks has > 1 000 in the next
     if (N(L) > VMAXT - 16) continue;  // cannot happen: the top level of FmView::samin holds <= 64 blocks (JL_MID: occs <= 8 KC)
     u32 nv = (u32)N(L);
     // (eight loads in flight per lane: one load per trip of a plain loop is one memory latency per trip — the phase clocks of a
     //  development build showed half of a job's 60 us in this loop and in the survivors' record loads below)
-    if (L == 0 && sax_on) {
-      const uint2* src = f.sax + A(0);
+    if (L == 0 && use_recs) {
+      const uint2* src = recs + A(0);
       for (u32 base = 0; base < nv; base += 8 * 256) {
         u32 r[8];
 #pragma unroll
@@ -643,7 +669,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
           const u32 x = p < nv ? S.val[p] : TOPK_PAD;
           const bool keep = x <= T && x != TOPK_PAD;
           u32 e = x;
-          if (keep && sax_on) e = (u32)((top ? A(0) + p : (p < 8 * nc_prev ? (u64)S.cidx[cur * KC + (p >> 3)] * 8u + (p & 7u) : (u64)S.eidx[p - 8 * nc_prev])) - lo);
+          if (keep && use_recs) e = (u32)((top ? A(0) + p : (p < 8 * nc_prev ? (u64)S.cidx[cur * KC + (p >> 3)] * 8u + (p & 7u) : (u64)S.eidx[p - 8 * nc_prev])) - lo);
           const unsigned long long mk = __ballot(keep);
           u32 at = 0;
           if (lane == 0 && mk) at = atomicAdd(&S.n_kept, (u32)__popcll(mk));
@@ -661,12 +687,12 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
           for (u32 r = 0; r < 4; ++r) mine[r] = threadIdx.x + r * 256 < have ? slist[threadIdx.x + r * 256] : TOPK_PAD;
           __syncthreads();
           u64 kv[4];
-          if (sax_on) {
+          if (use_recs) {
             uint2 rec[4];
 #pragma unroll
-            for (u32 r = 0; r < 4; ++r) rec[r] = threadIdx.x + r * 256 < have ? f.sax[lo + mine[r]] : make_uint2(0, 0);
+            for (u32 r = 0; r < 4; ++r) rec[r] = threadIdx.x + r * 256 < have ? recs[lo + mine[r]] : make_uint2(0, 0);
 #pragma unroll
-            for (u32 r = 0; r < 4; ++r) kv[r] = ((u64)rec[r].x << 32) | rec[r].y;
+            for (u32 r = 0; r < 4; ++r) kv[r] = ((u64)rec[r].x << 32) | (sax_on ? rec[r].y : SAX_ESCAPE);
           } else {
 #pragma unroll
             for (u32 r = 0; r < 4; ++r) kv[r] = ((u64)mine[r] << 32) | SAX_ESCAPE;
@@ -692,7 +718,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (threadIdx.x * 4 + r < k)
-            seeds[J.out + threadIdx.x * 4 + r] = HitSeed{(u32)(sv[r] >> 32), J.g, seed_len_with_ctx(J.len, (u32)sv[r]), J.slot};
+            seeds[J.out + threadIdx.x * 4 + r] = HitSeed{(u32)(sv[r] >> 32), J.g, seed_len_with_ctx(jlen, (u32)sv[r]), J.slot};
         const unsigned long long p5 = DG_LPROF_NOW();
         DG_LPROF_ADD(pb + 0, 1);
         DG_LPROF_ADD(pb + 1, p1 - p0);
@@ -725,7 +751,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
       top = false;
       // their children, and the blocks of level j-1 that stick out at either end of the interval
       const u32* lv = f.samin[j - 1];
-      const bool recs = j - 1 == 0 && sax_on;  // the entries themselves: from the records, whose lines the survivors read again
+      const bool from_recs = j - 1 == 0 && sax_on;  // the entries themselves: from the records, whose lines the survivors read again
       const u64 nlow = j - 1 == 0 ? f.n : ~0ULL;  // level 0 is the suffix array itself: nothing beyond n
       // (the blocks of two trips are read before either is stored: the loads of a lane's blocks are in flight together)
       for (u32 base = 0; base < nc; base += 2 * 256) {
@@ -736,7 +762,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
           const u32 i = base + u * 256 + threadIdx.x;
           c8[u] = i < nc ? (u64)S.cidx[cur * KC + i] * 8 : 0;
           if (i < nc) {
-            if (recs) {
+            if (from_recs) {
               const uint4* r4 = reinterpret_cast<const uint4*>(f.sax + c8[u]);
               const uint4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
               v[u][0] = a.x, v[u][1] = a.z, v[u][2] = b.x, v[u][3] = b.z, v[u][4] = c.x, v[u][5] = c.z, v[u][6] = d.x, v[u][7] = d.z;
@@ -760,7 +786,7 @@ __global__ void __launch_bounds__(256) k_locate_topk(FmView f, LocJobs jobs, u32
       if (threadIdx.x < nl + nr) {
         const u64 e = threadIdx.x < nl ? a0 + threadIdx.x : 8 * b1 + (threadIdx.x - nl);
         S.eidx[threadIdx.x] = (u32)e;
-        S.val[8 * nc + threadIdx.x] = recs ? f.sax[e].x : lv[e];
+        S.val[8 * nc + threadIdx.x] = from_recs ? f.sax[e].x : lv[e];
       }
       reads += 8ULL * nc + nl + nr;
       nv = 8 * nc + nl + nr;

@@ -4,6 +4,8 @@
 
 #include "devfm.hpp"
 #include "index_internal.hpp"
+#include <rocprim/device/device_scan.hpp>
+
 #include "sdsl_file.hpp"
 
 namespace dg {
@@ -478,6 +480,37 @@ __global__ void __launch_bounds__(256) k_pre5(const u32* sa, const u8* text, u64
   sax[i] = make_uint2((u32)p, esc ? (ctx | SAX_ESCAPE) : ctx);
 }
 
+// FmView::plv, one level: the flags "text position below x" of every suffix-array index as 64-bit words (seven per 64-byte
+// line of the rank directory, one wavefront per line), the line's count aside ...
+__global__ void __launch_bounds__(256) k_plv_bits(const u32* sa, u64 n, u64 x, u64* dir, u32* cnt, u64 nlines) {
+  const u64 line = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  if (line >= nlines) return;  // (the same for a whole wavefront)
+  u32 total = 0;
+  u64 mine = 0;
+  for (u32 j = 0; j < 7; ++j) {
+    const u64 i = line * FmView::PLV_LINE + 64 * j + lane;
+    const unsigned long long w = __ballot(i < n && (u64)sa[i] < x);
+    if (lane == j) mine = w;
+    total += (u32)__popcll(w);
+  }
+  if (lane < 7) dir[line * 8 + 1 + lane] = mine;
+  if (lane == 0) cnt[line] = total;
+}
+// ... and, behind the exclusive scan of the counts: the count before every line, and the flagged suffixes' records in their order
+__global__ void __launch_bounds__(256) k_plv_fill(const uint2* sax, const u32* before, u64* dir, uint2* rec, u64 nlines) {
+  const u64 line = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  if (line >= nlines) return;
+  u64 base = before[line];
+  if (lane == 0) dir[line * 8] = base;
+  for (u32 j = 0; j < 7; ++j) {
+    const u64 w = dir[line * 8 + 1 + j];
+    if ((w >> lane) & 1ULL) rec[base + (u64)__popcll(w & ((1ULL << lane) - 1ULL))] = sax[line * FmView::PLV_LINE + 64 * j + lane];
+    base += (u64)__popcll(w);
+  }
+}
+
 // The table's final entry format (FmView::ktab): (lo, hi) as the fill pass left them -> (lo, width | pre5[lo] << 16) for widths below
 // 2^16, (lo, 0x80000000 | width) above.  pre: nullptr when the preceding characters were not built (the field then reads 0x7FFF,
 // which the search kernels never consult without FmView::pre5).
@@ -704,6 +737,46 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
         f.pre5 = pre;
         f.sax = sax;
         pc.lap(sax ? "preceding characters + suffix array with context" : "preceding characters");
+        // prefix levels over the records (FmView::plv): X = 2^16, 2^18, ... below n — 64 n / 448 bytes of directory and 8 X bytes
+        // of records per level (GRCh38: 8 levels, 3.5 + 11.5 GB); DICEY_NO_PLV leaves them out (tests: every repeat-rich string
+        // then walks the block minima)
+        if (sax && !std::getenv("DICEY_NO_PLV")) {
+          const u64 nlines = n / FmView::PLV_LINE + 1;
+          u32 *cnt = nullptr, *before = nullptr;
+          void* tmp = nullptr;
+          size_t tmp_bytes = 0;
+          (void)rocprim::exclusive_scan(nullptr, tmp_bytes, (const u32*)nullptr, (u32*)nullptr, 0u, nlines, rocprim::plus<u32>(), ix->stream);
+          if (hipMalloc((void**)&cnt, nlines * 4) == hipSuccess && hipMalloc((void**)&before, nlines * 4) == hipSuccess &&
+              hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16) == hipSuccess) {
+            for (u32 lv = 0; lv < FmView::MAXPLV; ++lv) {
+              const u64 x = 1ULL << (16 + 2 * lv);
+              if (x >= n) break;
+              size_t free_b = 0, total_b = 0;
+              if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < nlines * 64 + x * 8 + (4ULL << 30)) break;
+              u64* dir = nullptr;
+              uint2* rec = nullptr;
+              if (big_alloc((void**)&dir, nlines * 64, ix->stream) != hipSuccess) break;
+              ix->owned.push_back(dir);
+              if (big_alloc((void**)&rec, x * 8 + 64, ix->stream) != hipSuccess) break;
+              ix->owned.push_back(rec);
+              ix->hbm_bytes += nlines * 64 + x * 8 + 64;
+              hipLaunchKernelGGL(k_plv_bits, dim3(ceil_div(nlines, 4)), dim3(256), 0, ix->stream, (const u32*)sa, n, x, dir, cnt, nlines);
+              if (rocprim::exclusive_scan(tmp, tmp_bytes, (const u32*)cnt, before, 0u, nlines, rocprim::plus<u32>(), ix->stream) != hipSuccess) break;
+              hipLaunchKernelGGL(k_plv_fill, dim3(ceil_div(nlines, 4)), dim3(256), 0, ix->stream, (const uint2*)sax, (const u32*)before, dir, rec, nlines);
+              DG_HIP(hipStreamSynchronize(ix->stream));
+              DG_HIP(hipGetLastError());
+              f.plv[lv].dir = dir;
+              f.plv[lv].rec = rec;
+              f.plv[lv].x = x;
+              f.nplv = lv + 1;
+            }
+          }
+          (void)hipGetLastError();
+          if (cnt) (void)hipFree(cnt);
+          if (before) (void)hipFree(before);
+          if (tmp) (void)hipFree(tmp);
+          pc.lap("prefix levels of the suffix array");
+        }
       } else (void)hipGetLastError();
     }
     // every reader of (lo, hi) pairs is done (the filters above were derived from them): the entries take their final form

@@ -69,6 +69,18 @@ def _index(tmp_path, seqs, name):
     (-3000, 400_000, 0),       # DICEY_NO_SA_MINIMA: no block minima, repeat-rich strings by radix select over the interval (k_locate_big)
 ])
 def test_topk_locate_equals_oracle(tmp_path, monkeypatch, copies, background, tandem):
+    _topk_case(tmp_path, monkeypatch, copies, background, tandem)
+
+
+@pytest.mark.parametrize("copies,background,tandem", [(150_000, 8_000_000, 0), (20_000, 2_000_000, 30_000)])
+def test_topk_locate_without_prefix_levels(tmp_path, monkeypatch, copies, background, tandem):
+    """r06: strings with far more occurrences than they report take a run of a prefix level's records (FmView::plv) instead of the
+    walk down the block minima; DICEY_NO_PLV opens the index without the levels — the walk must give the same hits"""
+    monkeypatch.setenv("DICEY_NO_PLV", "1")
+    _topk_case(tmp_path, monkeypatch, copies, background, tandem)
+
+
+def _topk_case(tmp_path, monkeypatch, copies, background, tandem):
     import dicey_amd
     if copies < 0:
         copies = -copies

@@ -896,7 +896,7 @@ def main():
                     else:
                         gather_parts([torch.empty(0, dtype=torch.uint8, device=dev)])
                 return {k_: 0 for k_ in ("nhits", "ext", "leaves", "sa", "win", "tab", "probe", "ops_per_hit", "ms_total", "ms_search",
-                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns", "t0", "t1", "gen", "form")}
+                                         "ms_search_flat", "ms_select", "ms_locate", "ms_verify", "ms_cap", "cap_dev", "cap_host", "cap_patterns", "t0", "t1", "gen", "form", "vform")}
             rp = C.POINTER(_capi.HuntResult)()
             _capi.check(L, L.dg_hunt_device(handle or ix.handle, C.byref(params or p_compact), sl, len(seqlen), C.c_void_p(bq.data_ptr()),
                                             C.c_void_p(bo.data_ptr()), nq, bbytes, fetch, C.byref(rp)))
@@ -905,7 +905,7 @@ def main():
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
                    "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns,
-                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen, "form": R.flat_kernel_form}
+                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen, "form": R.flat_kernel_form, "vform": R.verify_kernel_form}
             if (world > 1 or a.gather_single) and not fetch and a.backend == "nccl" and R.compact:
                 gather_block(R)
             elif (world > 1 or a.gather_single) and not fetch:
@@ -933,7 +933,7 @@ def main():
                    "tab": R.ctr_tab_reads, "probe": R.ctr_filter_probes, "ops_per_hit": R.ops_per_hit, "ms_total": R.ms_total, "ms_search": R.ms_search,
                    "ms_search_flat": R.ms_search_flat, "ms_select": R.ms_select, "ms_locate": R.ms_locate, "ms_verify": R.ms_verify,
                    "ms_cap": R.ms_cap, "cap_dev": R.cap_queries_device, "cap_host": R.cap_queries_host, "cap_patterns": R.cap_patterns,
-                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen, "form": R.flat_kernel_form}
+                   "t0": R.t_search_begin_ms, "t1": R.t_search_end_ms, "gen": R.t_base_gen, "form": R.flat_kernel_form, "vform": R.verify_kernel_form}
             if (world > 1 or a.gather_single) and a.backend == "nccl" and R.compact:
                 gather_block(R)  # staged on the lane's own stream (R.stream): ordered before that lane's next batch
             elif world > 1 or a.gather_single:
@@ -1352,21 +1352,30 @@ def main():
                 hits, sa = mean("nhits"), mean("sa")
                 oph = int(acc[-1].get("ops_per_hit", 0))
                 if stage == "ms_locate":
-                    dom_kernel = "k_locate_topk (+ k_locate)"
+                    dom_kernel = "k_locate_topk<576u>"
                     dom_bytes = 4.0 * sa + 16.0 * hits
-                    terms = {"sa_or_minima_words_read": sa, "bytes_per_word": 4, "hit_seeds_written": hits, "bytes_per_seed": 16}
+                    terms = {"sa_or_minima_words_read": sa, "bytes_per_word": 4, "hit_seeds_written": hits, "bytes_per_seed": 16,
+                             "note": "the stage is four kernels (k_locate, k_locate_small, k_locate_topk<576u>, k_locate_topk<1152u>); the named one is "
+                                     "its longest on a repeat-rich genome, the bytes are the whole stage's"}
                 else:
-                    dom_kernel = "k_verify_memo<7>" if distance <= 1 else "k_verify_memo<13>"
-                    dom_bytes = mean("win") + hits * (16.0 + 20.0 + 4.0 * oph)
-                    terms = {"window_bytes": mean("win"), "hits": hits, "bytes_per_hit": 16 + 20 + 4 * oph,
-                             "note": "window bytes as the reference extracts them (hunter.h:371), 16 B seed in, 20 B hit record + 4 B "
-                                     "per unit of distance out; the kernel itself reads only the <= 2d context bytes of a hit and "
-                                     "aligns once per distinct window"}
+                    vf = int(acc[-1].get("vform", 0)) if acc else 0
+                    dom_kernel = f"k_verify_memo<{vf >> 8}, {vf & 255}>" if vf else ("k_verify_memo<7, 1>" if distance <= 1 else "k_verify_memo<13, 1>")
+                    dom_bytes = mean("win") + hits * (16.0 + 8.0 + 4.0 * oph)
+                    terms = {"window_bytes": mean("win"), "hits": hits, "bytes_per_hit": 16 + 8 + 4 * oph,
+                             "note": "window bytes as the reference extracts them (hunter.h:371), 16 B seed in, 8 B compact record + 4 B "
+                                     "per unit of distance out; the kernel itself takes the <= 2d context characters of a hit from its seed "
+                                     "(FmView::sax) or the text and aligns once per distinct window"}
                 dom_ach = dom_bytes / (ph[stage] * 1e-3) / 1e9
+                # HBM bytes of the stage's kernel from the PMC passes of a profile of THIS build on THIS workload (else null)
+                sj = profile_of_this_build("traffic_stage_" + wtag + ".json", workload=wtag, kernel=dom_kernel)
                 out["roofline_search"] = out["roofline"]
                 out["roofline"] = {"bound": "hbm", "kernel": dom_kernel, "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": dom_ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": dom_bytes,
-                                   "kernel_ms": ph[stage], "stage": stage, "terms": terms,
+                                   "frac": dom_ach / HBM_PEAK_GBS, "traffic": sj.get("hbm_bytes_per_launch") if sj else None,
+                                   "traffic_over_algorithmic": (sj["hbm_bytes_per_launch"] / dom_bytes) if (sj and dom_bytes) else None,
+                                   "fabric_reads_per_launch": ((sj.get("tcc") or {}).get("ea_rdreq")) if sj else None,
+                                   "algorithmic_bytes_per_launch": dom_bytes,
+                                   "kernel_ms": ph[stage], "kernel_ms_is": "average launch duration (HIP events around the stage, one batch at a time)",
+                                   "stage": stage, "terms": terms,
                                    "note": "dominant stage of this step by HIP events on the index stream (phases_ms); the stage's launches "
                                            "are timed together"}
             out["roofline"] = rocprof_average(out["roofline"], wtag)

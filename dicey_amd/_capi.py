@@ -55,7 +55,8 @@ class HuntResult(C.Structure):
                 ("seq_start", C.POINTER(C.c_uint64)), ("expanded_", C.c_void_p),
                 ("ms_cap", C.c_double), ("cap_queries_device", C.c_uint64), ("cap_queries_host", C.c_uint64), ("cap_patterns", C.c_uint64),
                 ("t_search_begin_ms", C.c_double), ("t_search_end_ms", C.c_double), ("t_base_gen", C.c_uint32), ("flat_kernel_form", C.c_uint32),
-                ("stream", C.c_void_p), ("d_block", C.c_void_p), ("d_block_bytes", C.c_uint64)]
+                ("stream", C.c_void_p), ("d_block", C.c_void_p), ("d_block_bytes", C.c_uint64),
+                ("verify_kernel_form", C.c_uint32), ("reserved7", C.c_uint32)]
 
 
 class SearchParams(C.Structure):

@@ -600,6 +600,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   // (r05: Hamming distance 2 as well — the same kernel with "no edit" in place of the deletions)
   b.fast2K = (dmax_eff == 2 && (indel || !sw.no_flat_ham2) && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
   b.tabK = sw.no_nwin ? 0u : ix->view.K;
+  b.nrun_min = (dmax_eff == 1 || dmax_eff == 2) ? ix->view.nrun_min : 0u;  // (non-zero: k_nres is launched with the generic kernels)
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
   b.xs_off = d_xs_off;
@@ -709,6 +710,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   u64 nleaf = 0, nhits = 0;
   bool force_generic = false, force_jobs = false, force_short2 = false;
   u32 flat_form = 0;  // which flat search kernel the (last) attempt launched: dg_hunt_result::flat_kernel_form
+  u32 verify_form = 0;  // ... and which k_verify_memo instantiation: dg_hunt_result::verify_kernel_form
   // Fetched results: one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh
   // hipHostMalloc per batch costs more than the copies), laid out for `capn` hits:
   // [hit_off | qoff | qdistance qflags qnondna | qseq | hits | ops].  When the previous fetched batch on this handle tells how many
@@ -914,6 +916,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
 #undef DG_LAUNCH_SEARCH
       if (nxs) hipLaunchKernelGGL(k_explicit, dim3(ceil_div(nxs, TB)), dim3(TB), 0, st, ix->view, b, so);
       }
+      // strands whose N's can only be substituted or deleted (k_prepare, bit 12 of GidInfo::d_win): a lane per resolved string
+      if (generic_on && b.nrun_min) {
+        const u32 per = indel ? (dmax_eff == 1 ? 5u : 25u) : (dmax_eff == 1 ? 4u : 16u);
+        if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nres<true>), dim3(ceil_div(ngrp * per, TB)), dim3(TB), 0, st, ix->view, b, so, per);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nres<false>), dim3(ceil_div(ngrp * per, TB)), dim3(TB), 0, st, ix->view, b, so, per);
+      }
     }
     if (phase_events) DG_HIP(hipEventRecord(ix->ev[2], st));
     // (r03 tried single-launch scans chained by decoupled look-back, and k_take fused with its scan: 17 us against 2 x 4.3 us, and
@@ -941,7 +949,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
                          (const u8*)alive, sel_gen, nsel, ctr, above);
       }
       if (!prep_in)
-        hipLaunchKernelGGL(k_take, dim3(ceil_div(nq, TB)), dim3(TB), 0, st, b, (const u64*)grp_off, (const u32*)selbase, flat_slots, (const u32*)nsel, sel_all,
+        hipLaunchKernelGGL(k_take, dim3(ceil_div(nq * 16, 256)), dim3(256), 0, st, b, (const u64*)grp_off, (const u32*)selbase, flat_slots, (const u32*)nsel, sel_all,
                            qhits, ctr);
     } else {
       hipLaunchKernelGGL(k_group, dim3(ceil_div(leaf_slots, TB)), dim3(TB), 0, st, ws[WS_LEAF].as<Leaf>(), shard_cap, ctr, grp_off,
@@ -1048,6 +1056,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         const u32 nw_bytes = ((rows * 256 * (wide ? 4u : 2u) + 7u) & ~7u) + 6u * 256u * 8u, hash_bytes = 2u * 256u * (u32)ch * 10u;
         const u32 lds = std::max(nw_bytes, hash_bytes);
         const dim3 mgrid(ceil_div(hit_cap, (u64)256 * ch)), mblock(256);
+        verify_form = ((wide ? 13u : 7u) << 8) | (u32)ch;
 #define DG_LAUNCH_MEMO(WBV, CHV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_memo<WBV, CHV>), mgrid, mblock, lds, st, ix->view, b, va, ctr, rows)
         if (!wide) {
           if (ch == 8) DG_LAUNCH_MEMO(7, 8);
@@ -1297,6 +1306,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   R->cap_queries_host = cs.looked_at;
   R->cap_patterns = nxs;
   R->flat_kernel_form = flat_form;
+  R->verify_kernel_form = verify_form;
   R->t_base_gen = 0;
   R->t_search_begin_ms = R->t_search_end_ms = 0.0;
   if (base_ev && (b.fastK || b.fast2K)) {

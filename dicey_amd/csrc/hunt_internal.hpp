@@ -33,6 +33,7 @@ struct Batch {  // device pointers of one batch
   u32* too_long;         // ... k_prepare counts the ones that are longer (only possible when the host trusted a cached bound)
   struct GidInfo* ginfo;  // [2*nq] what every lane of a (query, strand) needs, in one 16-byte record
   uint4* gpeq;            // [2*nq] position masks of the strand (x, y, z, w: bit i <=> character i is A, C, G, T), queries up to 32 nt
+  u32 nrun_min;           // FmView::nrun_min (0 = unknown): k_prepare marks the strands whose N's can only be substituted or deleted (k_nres)
   u32 tabK;               // order of the K-mer table (0 = none): k_prepare marks N-bearing strands whose N's stay left of every window
   u32* nwin;              // ... and raises this flag when it marked one
   u32 fastK;              // != 0: the batch runs k_search1 (distance 1, table order fastK) for the queries that qualify
@@ -55,7 +56,8 @@ static constexpr u32 LEAF_EXPLICIT = 0x80000000u;  // Leaf::nops marker: ops[0] 
 struct GidInfo {
   u64 qpk;    // the sequence 2-bit packed, q[i] at bits 2(m-1-i) (only for m <= 32 without N)
   u32 m;      // length; 0 = this (query, strand) is not searched
-  u32 d_win;  // bits 0-7 effective distance, bit 8: window mode allowed by the query (no N), bit 9: taken by k_search1, bit 10: taken by k_search2
+  u32 d_win;  // bits 0-7 effective distance, bit 8: window mode allowed by the query (no N), bit 9: taken by k_search1, bit 10: taken by k_search2,
+              // bit 11: N's left of every table window (walker in window mode), bit 12: as many N's as edits, all of them to be resolved (k_nres)
 };
 
 DG_DEV u32 ascii_rank(u32 code) { return code == 3 ? 4u : code == 4 ? 3u : code; }  // 'A'<'C'<'G'<'N'<'T'

@@ -190,7 +190,21 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
     // r05: a query with N's that all lie left of every table window of its strand's strings (string index below m - K - d) walks in
     // window mode like an N-free one — the packed copy (an N as 0) is only read inside windows — and so gets k_search's root split:
     // one lane per first edit instead of one lane per strand with ~1 500 dependent index reads
-    if (bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
+    // r06: as many N's as the query has edits, none within d characters of either end, fewer than the text's shortest run of N:
+    // no neighbourhood string that keeps an N occurs (k_search's census argument), so every N is substituted or deleted and that is
+    // the whole budget — 5^d strings per strand (4^d in Hamming mode), searched by k_nres one lane per string; the walker skips
+    // the strand.  (r05: the strand whose N sits inside the window zone walked 75-300 dependent reads in one lane.)
+    bool nres = false;
+    if (bad != 0 && bad == d && d <= 2 && m <= 32 && gi.m && b.nrun_min && bad < b.nrun_min && (mode & 15u) == QM_KERNEL) {
+      const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
+      const u32 first = (u32)__builtin_ctz(nm), last = 31u - (u32)__builtin_clz(nm);
+      nres = first >= d + 1 && (m - 1 - last) >= d + 1;  // (the same for the reverse strand: its N's are the mirror image)
+      if (nres) {
+        gi.d_win |= 4096u;
+        gi.qpk = strand ? pk_rv : pk_fw;  // (an N reads as some base: k_nres overwrites those positions)
+      }
+    }
+    if (!nres && bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
       const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
       const u32 lim = m - b.tabK - d;  // N's are allowed at string indices below this
       const bool ok = !strand ? (lim < 32 && (nm >> lim) == 0u) : (nm & (m - lim >= 32 ? ~0u : ((1u << (m - lim)) - 1u))) == 0u;
@@ -1673,7 +1687,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   gi.m = 0;
   gi.d_win = 0;
   if (active) gi = b.ginfo[gid];
-  if (gi.m == 0 || (gi.d_win & (512u | 1024u))) active = false;  // not searched, or taken by a flat kernel
+  if (gi.m == 0 || (gi.d_win & (512u | 1024u | 4096u))) active = false;  // not searched, or taken by a flat kernel / k_nres
   if (active) {
     const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
     const u32 m = gi.m;
@@ -1808,6 +1822,98 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
           continue;
         }
         S.set(L, F);
+      }
+    }
+  }
+  wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
+  wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
+  wave_add(&o.ctr->probes[blockIdx.x & (NSHARD - 1)], probes);
+}
+
+// r06: the strands k_prepare marked with bit 12 — as many N's as edits, every N to be substituted (A, C, G, T) or deleted: one lane
+// per resolution (per = 5 or 25 strings per strand in edit mode, 4 or 16 in Hamming mode), searched like an explicit pattern (long
+// presence filter on the last and the first K2 characters, table entry, extensions); a string that occurs becomes an ordinary leaf
+// of its group whose operations are the resolutions (util.h:208-219 turns non-DNA into N; neighbors.h:57-78 substitutes / deletes
+// it like any other character).  Equal strings of two resolutions (neighbouring N's) are dropped by the select stage.
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_nres(FmView f, Batch b, SearchOut o, u32 per) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 gid = t / per;
+  const u32 r = (u32)(t - gid * per);
+  constexpr u32 R1 = INDEL ? 5u : 4u;
+  u64 steps = 0, lookups = 0, probes = 0;
+  GidInfo gi;
+  gi.qpk = 0;
+  gi.m = 0;
+  gi.d_win = 0;
+  if (gid < 2 * b.nq) gi = b.ginfo[gid];
+  const u32 d = gi.d_win & 255u;
+  if (gi.m && (gi.d_win & 4096u) && (d == 2 || r < R1)) {
+    const u32 m = gi.m;
+    const uint4 pq = b.gpeq[gid];
+    const u32 nm = ~(pq.x | pq.y | pq.z | pq.w) & (m == 32 ? ~0u : ((1u << m) - 1u));
+    const u32 i0 = (u32)__builtin_ctz(nm), i1 = 31u - (u32)__builtin_clz(nm);  // (d == 1: the same position)
+    const u32 c0 = r % R1, c1 = r / R1;  // resolution of the left / right N: 0-3 a base, 4 deleted
+    u64 s = 0;
+    u32 len = 0;
+    for (u32 i = 0; i < m; ++i) {
+      u32 c = (u32)(gi.qpk >> (2 * (m - 1 - i))) & 3u;
+      if (i == i0) c = c0;
+      else if (d == 2 && i == i1) c = c1;
+      if (c < 4) {
+        s = (s << 2) | c;
+        ++len;
+      }
+    }
+    auto at = [&](u32 j) -> u32 { return (u32)(s >> (2 * (len - 1 - j))) & 3u; };
+    u32 lo = 0, hi = (u32)f.n, k = len;
+    const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u, W = K2 > K ? K2 : K;
+    if (K && len >= W && W <= 32) {
+      const u64 tail = W >= 32 ? s : (s & ((1ULL << (2 * W)) - 1));
+      bool alive = true;
+      if (K2) {
+        ++probes;
+        alive = kf_present(f.kf2, tail & ((1ULL << (2 * K2)) - 1), 0u);
+        if (alive && len > K2) {
+          ++probes;
+          alive = kf_present(f.kf2, (s >> (2 * (len - K2))) & ((1ULL << (2 * K2)) - 1), K2 - 1);
+        }
+      } else if (f.kf.nr) {
+        ++probes;
+        alive = kf_present(f.kf, tail & ((1ULL << (2 * K)) - 1), 0u);
+      }
+      if (alive) {
+        const KtabEntry iv = ktab_entry(f, tail & ((1ULL << (2 * K)) - 1));
+        ++lookups;
+        lo = iv.lo;
+        hi = iv.hi;
+      } else lo = hi = 0;
+      k = len - K;
+    }
+    for (; k > 0 && lo < hi; --k) {
+      bs_extend_code(f, lo, hi, at(k - 1));
+      ++steps;
+    }
+    if (lo < hi) {
+      const u32 shard = blockIdx.x & (NSHARD - 1);
+      const u32 a = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+      const u32 slot = atomicAdd(o.grp_cnt + gid, 1u);
+      if (a < o.shard_cap) {
+        Leaf* lf = o.leaves + (u64)shard * o.shard_cap + a;
+        lf->qs = (u32)gid;
+        lf->slot = slot;
+        lf->lo = lo;
+        lf->hi = hi;
+        lf->nops = d;
+#pragma unroll
+        for (int x = 0; x < (int)DMAX; ++x) lf->ops[x] = 0u;
+        // operations right to left (Leaf): the right N first.  position field: index + 1 for a substitution / deletion (LeafReader)
+        const u32 opl = ((i0 + 1u) << 4) | ((c0 == 4 ? (u32)OP_D : (u32)OP_S) << 2) | (c0 & 3u);
+        const u32 opr = ((i1 + 1u) << 4) | ((c1 == 4 ? (u32)OP_D : (u32)OP_S) << 2) | (c1 & 3u);
+        if (d == 2) {
+          lf->ops[0] = opr;
+          lf->ops[1] = opl;
+        } else lf->ops[0] = opl;
       }
     }
   }

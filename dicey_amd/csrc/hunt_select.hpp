@@ -507,36 +507,45 @@ DG_DEV u64 sel_base_of(const u32* selbase, const u64* grp_off, u64 flat_slots, u
   const u32 sb = selbase[g];
   return sb != 0xFFFFFFFFu ? (u64)sb : flat_slots + grp_off[g];
 }
-__global__ void k_take(Batch b, const u64* grp_off, const u32* selbase, u64 flat_slots, const u32* nsel, Sel* sel, u32* qhits, const Counters* ctr) {
-  u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.nq) return;
+// hunter.h:349-357: the kept strings of a query in push order (forward strand, then reverse) report occurrences while fewer than
+// max_locations are in: take = min(occurrences, what is left), the first hit slot = what the strings before took.  Sixteen lanes per
+// query (r06): the occurrence counts of sixteen strings are read together and their running total is a prefix sum over the lanes — one
+// lane per query walked its strings one memory latency at a time, and a query of a repeat family keeps a few hundred of them (0.1 ms
+// of a repeat-rich batch was this kernel waiting for its slowest lanes).
+__global__ void __launch_bounds__(256) k_take(Batch b, const u64* grp_off, const u32* selbase, u64 flat_slots, const u32* nsel, Sel* sel, u32* qhits, const Counters* ctr) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 q = t >> 4;
+  const u32 sub = (u32)(t & 15);
+  if (q >= b.nq) return;  // (whole sixteen-lane groups leave together)
   if (ctr->overflow) {
-    qhits[q] = 0;
+    if (sub == 0) qhits[q] = 0;
     return;
   }
-  u64 hits = 0;
+  const u64 M = b.max_locations;
+  u64 seen = 0;  // occurrences of the strings so far (not capped)
   for (u32 strand = 0; strand < 2; ++strand) {
     const u32 ns = nsel[2 * q + strand];
     if (!ns) continue;  // (grp_off is not even computed when the generic kernels were left out)
     Sel* S = sel + sel_base_of(selbase, grp_off, flat_slots, 2 * q + strand);
-    // eight strings at a time: their occurrence counts are read together, then the running total is carried through them (one
-    // string per trip — a load, then two stores the next load may not pass — was a memory latency per kept string: 0.1 ms of a
-    // repeat-rich batch, where a query keeps dozens of strings)
-    for (u32 r0 = 0; r0 < ns; r0 += 8) {
-      u64 occs[8];
+    for (u32 r0 = 0; r0 < ns; r0 += 16) {
+      const u32 r = r0 + sub;
+      const u64 occ = r < ns ? sel_occ(S[r]) : 0;
+      u64 incl = occ;
 #pragma unroll
-      for (u32 u = 0; u < 8; ++u) occs[u] = r0 + u < ns ? sel_occ(S[r0 + u]) : 0;
-#pragma unroll
-      for (u32 u = 0; u < 8; ++u)
-        if (r0 + u < ns) {
-          u64 take = 0;
-          if (hits < b.max_locations) take = occs[u] < b.max_locations - hits ? occs[u] : b.max_locations - hits;
-          S[r0 + u].take = (u32)take;
-          S[r0 + u].hbase = (u32)hits;
-          hits += take;
-        }
+      for (int off = 1; off < 16; off <<= 1) {
+        const u64 v = __shfl_up((unsigned long long)incl, off, 16);
+        if ((int)sub >= off) incl += v;
+      }
+      const u64 before = seen + incl - occ, hb = before < M ? before : M;
+      if (r < ns) {
+        S[r].take = (u32)(occ < M - hb ? occ : M - hb);
+        S[r].hbase = (u32)hb;
+      }
+      seen += __shfl((unsigned long long)incl, 15, 16);
     }
   }
+  if (sub) return;
+  const u64 hits = seen < M ? seen : M;
   qhits[q] = (u32)hits;
   u32 fl = b.qflags[q];
   if (hits >= b.max_locations && !(fl & DG_Q_TOO_SHORT)) {  // hunter.h:434

@@ -234,6 +234,11 @@ typedef struct {
   void* stream;
   const void* d_block;
   uint64_t d_block_bytes;
+  /* ABI 7, measurement: which verify kernel served the batch — band width << 8 | hits per lane of k_verify_memo (7 << 8 | 4 is
+   * k_verify_memo<7, 4>), 0 for the full-matrix / long-query kernels and for `search` (k_site); and how many of the batch's locate
+   * jobs (strings with more than 16 occurrences) took a run of a prefix level's records instead of a walk down the block minima */
+  uint32_t verify_kernel_form;
+  uint32_t reserved7;
 } dg_hunt_result;
 
 /* One compact hit as a dg_hit (query = the query it belongs to, from hit_off) and a pointer to its ops words. */

@@ -102,6 +102,23 @@ def main():
             f.write('"%s",%s,%d,%g,%g,%g\n' % r)
     rf = bench.get("roofline_search") or bench["roofline"]
     kernel = rf["kernel"]
+    # the step's dominant stage is another kernel than the search (repeat-rich genome: verify / locate): its traffic goes to a file of
+    # its own, which bench.py reads for that block (traffic_stage_<workload>.json)
+    if bench.get("roofline_search") and bench["roofline"].get("stage") in ("ms_locate", "ms_verify"):
+        sk = bench["roofline"]["kernel"]
+        try:
+            sks = pick_kernel(means, sk)
+            sf, sw_ = means[(sks, "FETCH_SIZE")] * 1024, means[(sks, "WRITE_SIZE")] * 1024
+            st = {"workload": wtag, "kernel": sk, "pmc_row": sks, "dispatches_in_row": ndisp[(sks, "FETCH_SIZE")], "round": R,
+                  "build_id": bench.get("build_id") or B.build_id(), "fetch_bytes_per_launch": sf, "write_bytes_per_launch": sw_,
+                  "hbm_bytes_per_launch": sf + sw_, "stage": bench["roofline"]["stage"],
+                  "tcc": {"hit": means.get((sks, "TCC_HIT_sum")), "miss": means.get((sks, "TCC_MISS_sum")), "ea_rdreq": means.get((sks, "TCC_EA0_RDREQ_sum")),
+                          "req": means.get((sks, "TCC_REQ_sum"))},
+                  "sq": {"insts_valu": means.get((sks, "SQ_INSTS_VALU")), "insts_salu": means.get((sks, "SQ_INSTS_SALU")), "waves": means.get((sks, "SQ_WAVES"))}}
+            json.dump(st, open(os.path.join(OUT, "traffic_stage_" + wtag + ".json"), "w"), indent=1)
+            print("stage:", json.dumps(st)[:500])
+        except SystemExit as e:
+            print("summarize_profile: no PMC row for the dominant stage's kernel:", e, file=sys.stderr)
     ks = pick_kernel(means, kernel)
     gk = [k for (k, c) in means if "gather" in k]
     fetch, write = means[(ks, "FETCH_SIZE")] * 1024, means[(ks, "WRITE_SIZE")] * 1024

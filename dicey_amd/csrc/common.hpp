@@ -79,7 +79,7 @@ static inline u32 ceil_div(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 // 137 GB K-mer table, tools/microbench/malloc_bench.hip), hipMallocAsync 0.1-0.3 s for the same block.  Memory obtained
 // here is released with big_free on the same stream; the caller synchronises the stream before other streams use it.
 static inline hipError_t big_alloc(void** p, size_t bytes, hipStream_t st) {
-  if (bytes >= ((size_t)64 << 20) && !std::getenv("DICEY_PLAIN_MALLOC")) {  // (DICEY_PLAIN_MALLOC: A/B of the pool against hipMalloc)
+  if (bytes >= ((size_t)64 << 20)) {  // (r05 A/B of the pool against hipMalloc: no difference in kernel time, 0.157 ms either way)
     const hipError_t e = hipMallocAsync(p, bytes, st);
     if (e == hipSuccess) return hipSuccess;
     if (std::getenv("DICEY_TIMING")) std::fprintf(stderr, "dicey timing: hipMallocAsync(%zu) failed: %s\n", bytes, hipGetErrorString(e));

@@ -1346,27 +1346,29 @@ using namespace dg;
 
 dg_switches dg_switches::read() {
   dg_switches w;
-  auto num = [](const char* name) -> long { const char* e = std::getenv(name); return e ? std::atol(e) : 0; };
-  w.host_timing = num("DICEY_TIMING") >= 2;
-  w.no_band = std::getenv("DICEY_NO_BAND_VERIFY") != nullptr;
-  w.cap_host = std::getenv("DICEY_CAP_HOST") != nullptr;
-  w.no_fuse = std::getenv("DICEY_NO_FUSED_SELECT") != nullptr;
-  w.no_fuse2 = std::getenv("DICEY_NO_FUSED_SELECT2") != nullptr;
-  w.no_prep_fusion = std::getenv("DICEY_NO_PREP_FUSION") != nullptr;
-  w.no_pre5_d2 = std::getenv("DICEY_NO_PRE5_D2") != nullptr;
-  if (const char* e = std::getenv("DICEY_DEBUG_CAPS")) {
+  auto num = [](const char* e) -> long { return e ? std::atol(e) : 0; };
+  // deployment (every build)
+  w.host_timing = num(std::getenv("DICEY_TIMING")) >= 2;
+  if (const char* e = std::getenv("DICEY_CAP_BUDGET_MB")) w.cap_budget_mb = (uint64_t)std::max(1L, num(e));
+  if (const char* e = std::getenv("DICEY_HOST_THREADS")) w.host_threads = (unsigned)std::max(1L, num(e));
+  // development builds only (experiments.hpp: nullptr in the product library)
+  w.no_band = exp_env("DICEY_NO_BAND_VERIFY") != nullptr;
+  w.cap_host = exp_env("DICEY_CAP_HOST") != nullptr;
+  w.no_fuse = exp_env("DICEY_NO_FUSED_SELECT") != nullptr;
+  w.no_fuse2 = exp_env("DICEY_NO_FUSED_SELECT2") != nullptr;
+  w.no_prep_fusion = exp_env("DICEY_NO_PREP_FUSION") != nullptr;
+  w.no_pre5_d2 = exp_env("DICEY_NO_PRE5_D2") != nullptr;
+  w.no_flat_ham2 = exp_env("DICEY_NO_FLAT_HAMMING2") != nullptr;
+  w.no_nwin = exp_env("DICEY_NO_N_WINDOW") != nullptr;
+  w.no_long2 = exp_env("DICEY_NO_LONG2") != nullptr;
+  if (const char* e = exp_env("DICEY_DEBUG_CAPS")) {
     w.debug_caps = true;
     w.debug_caps_s = e;
   }
-  if (std::getenv("DICEY_FUSED_LCAP")) w.fused_lcap = (uint32_t)std::max(1L, num("DICEY_FUSED_LCAP"));
-  w.verify_ch = (int)num("DICEY_VERIFY_CH");
-  if (std::getenv("DICEY_CAP_BUDGET_MB")) w.cap_budget_mb = (uint64_t)std::max(1L, num("DICEY_CAP_BUDGET_MB"));
-  if (std::getenv("DICEY_HOST_THREADS")) w.host_threads = (unsigned)std::max(1L, num("DICEY_HOST_THREADS"));
-  if (const char* e = std::getenv("DICEY_DUMP_JOBS")) w.dump_jobs = e;
-  w.no_flat_ham2 = std::getenv("DICEY_NO_FLAT_HAMMING2") != nullptr;  // A/B and tests: Hamming distance 2 on the general kernel, as before r05
-  w.no_nwin = std::getenv("DICEY_NO_N_WINDOW") != nullptr;  // A/B and tests: N-bearing queries in interval mode, one lane per strand (r04)
-  w.no_long2 = std::getenv("DICEY_NO_LONG2") != nullptr;  // A/B and tests: k_search2p's r04 body for every batch
-  w.exp_bits = (uint32_t)num("DICEY_EXP");  // measurement aid (wrong results): phases of k_search1s switched off, see the kernel
+  if (const char* e = exp_env("DICEY_FUSED_LCAP")) w.fused_lcap = (uint32_t)std::max(1L, num(e));
+  w.verify_ch = (int)num(exp_env("DICEY_VERIFY_CH"));
+  if (const char* e = exp_env("DICEY_DUMP_JOBS")) w.dump_jobs = e;
+  w.exp_bits = (uint32_t)num(exp_env("DICEY_EXP"));  // measurement aid (wrong results): phases of the search / verify kernels switched off
   return w;
 }
 static bool any_lane_busy(dg_index* ix) {

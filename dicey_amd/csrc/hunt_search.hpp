@@ -194,15 +194,17 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
     // no neighbourhood string that keeps an N occurs (k_search's census argument), so every N is substituted or deleted and that is
     // the whole budget — 5^d strings per strand (4^d in Hamming mode), searched by k_nres one lane per string; the walker skips
     // the strand.  (r05: the strand whose N sits inside the window zone walked 75-300 dependent reads in one lane.)
+    // One N, one edit, the N within a character of an end (bit 13 on top): the strings that substitute or delete it are k_nres's all
+    // the same, and the walker is left with the strings that KEEP it — which occur only with the N as their first or last character
+    // (a text whose shortest run of N has two or more holds no single N between two bases), so it leaves every other path at once.
     bool nres = false;
     if (bad != 0 && bad == d && d <= 2 && m <= 32 && gi.m && b.nrun_min && bad < b.nrun_min && (mode & 15u) == QM_KERNEL) {
       const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
       const u32 first = (u32)__builtin_ctz(nm), last = 31u - (u32)__builtin_clz(nm);
       nres = first >= d + 1 && (m - 1 - last) >= d + 1;  // (the same for the reverse strand: its N's are the mirror image)
-      if (nres) {
-        gi.d_win |= 4096u;
-        gi.qpk = strand ? pk_rv : pk_fw;  // (an N reads as some base: k_nres overwrites those positions)
-      }
+      if (nres) gi.d_win |= 4096u;
+      else if (d == 1 && b.nrun_min >= 2) gi.d_win |= 4096u | 8192u;
+      if (gi.d_win & 4096u) gi.qpk = strand ? pk_rv : pk_fw;  // (an N reads as some base: k_nres overwrites those positions)
     }
     if (!nres && bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
       const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
@@ -1687,7 +1689,8 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   gi.m = 0;
   gi.d_win = 0;
   if (active) gi = b.ginfo[gid];
-  if (gi.m == 0 || (gi.d_win & (512u | 1024u | 4096u))) active = false;  // not searched, or taken by a flat kernel / k_nres
+  if (gi.m == 0 || (gi.d_win & (512u | 1024u)) || (gi.d_win & (4096u | 8192u)) == 4096u) active = false;  // not searched, or taken by a flat kernel / k_nres
+  const bool konly = (gi.d_win & 8192u) != 0;  // only the strings that keep the strand's N (k_nres has the others)
   if (active) {
     const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
     const u32 m = gi.m;
@@ -1790,6 +1793,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
           }
           if (kind == OP_S && c == here) continue;           // a substitution changes the character (neighbors.h:63)
           if (kind == OP_I && L == 0 && pos == m) continue;   // nothing may be inserted after the last character (neighbors.h:51)
+          if (konly && here >= 4 && kind != OP_I) continue;   // the N substituted or deleted: k_nres's strings
           // N's still ahead (left of what this operation consumes) against the edits left behind it
           if (nprune && (u32)__popcll(nmask & ((1ULL << (kind == OP_I ? pos : pos - 1)) - 1)) > budget - 1) continue;
           Frame ch = F;
@@ -1808,6 +1812,9 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
         else {
           F.st &= ~15u;
           if (nprune && (here >= 4 || (u32)__popcll(nmask & ((1ULL << (pos - 1)) - 1)) > budget)) alive = false;  // a kept N, or more N's ahead than edits
+          // a kept N with a character behind it and more characters in front than the edits left could delete: a single N between
+          // two bases, which this text lacks
+          else if (konly && here >= 4 && pos - 1 > budget && !(F.lo == 0 && F.hi == (u32)f.n)) alive = false;
           else if (here < 4) alive = frame_emit(f, F, here, steps, lookups, probes);
           else {  // an N in the query (never in window mode): through the wavelet tree like sdsl
             bs_extend_sym(f, F.lo, F.hi, 'N', here);

@@ -366,7 +366,7 @@ static void kf_layout(KFilter& kf, u32 k) {
 // (copy0: the long filter, whose bits the table-fill kernel sets); the others are bit-matrix transposes of copy 0.
 static int build_filter(dg_index* ix, KFilter& kf, u32 k, const uint2* tab, u32* copy0) {
   const u32 bits = 2 * k;
-  if (bits < 17 || std::getenv("DICEY_NO_KMER_FILTER")) return DG_OK;  // a table this small is cache resident anyway
+  if (bits < 17 || exp_env("DICEY_NO_KMER_FILTER")) return DG_OK;  // a table this small is cache resident anyway
   const u64 entries = 1ULL << bits, nwords = entries >> 5;
   kf_layout(kf, k);
   const u32 nr = kf.nr;
@@ -644,7 +644,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
     DG_HIP(hipMemcpyAsync(&h_min, d_min, 4, hipMemcpyDeviceToHost, ix->stream));
     DG_HIP(hipStreamSynchronize(ix->stream));
     DG_HIP(hipFree(d_min));
-    f.nrun_min = std::getenv("DICEY_NO_NRUN_PRUNE") ? 0u : h_min;
+    f.nrun_min = exp_env("DICEY_NO_NRUN_PRUNE") ? 0u : h_min;
     pc.lap("shortest N run");
   }
   if (!(flags & DG_OPEN_NO_KMER_TABLE)) {
@@ -681,7 +681,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
       int v = std::atoi(ek);
       K2 = (v > (int)K && v <= 20) ? (u32)v : 0u;
     }
-    if (std::getenv("DICEY_NO_KMER_FILTER") || 2 * K2 < 17) K2 = 0;
+    if (exp_env("DICEY_NO_KMER_FILTER") || 2 * K2 < 17) K2 = 0;
     pc.lap("table order (hipMemGetInfo)");
     uint2* tab = nullptr;
     u64 entries = 1ULL << (2 * K);
@@ -711,7 +711,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
       pc.lap("long presence filter");
     }
     // the characters in front of every suffix (2 n bytes): built with the table, i.e. for handles that search batches
-    if (!std::getenv("DICEY_NO_PRE5")) {
+    if (!exp_env("DICEY_NO_PRE5")) {
       u16* pre = nullptr;
       if (big_alloc((void**)&pre, n * 2 + 64, ix->stream) == hipSuccess) {
         ix->owned.push_back(pre);
@@ -720,7 +720,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
         // have the block minima (i.e. the top-k locate) and the room; DICEY_NO_SAX leaves it out (the tests run both ways: hits of
         // repeat-rich strings then read their context from the text as before r06)
         uint2* sax = nullptr;
-        if (!std::getenv("DICEY_NO_SAX") && !std::getenv("DICEY_NO_SA_MINIMA")) {
+        if (!exp_env("DICEY_NO_SAX") && !exp_env("DICEY_NO_SA_MINIMA")) {
           size_t free_b = 0, total_b = 0;
           if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > n * 8 + n * 2 + (4ULL << 30) &&
               big_alloc((void**)&sax, n * 8 + 64, ix->stream) == hipSuccess) {
@@ -740,7 +740,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
         // prefix levels over the records (FmView::plv): X = 2^16, 2^18, ... below n — 64 n / 448 bytes of directory and 8 X bytes
         // of records per level (GRCh38: 8 levels, 3.5 + 11.5 GB); DICEY_NO_PLV leaves them out (tests: every repeat-rich string
         // then walks the block minima)
-        if (sax && !std::getenv("DICEY_NO_PLV")) {
+        if (sax && !exp_env("DICEY_NO_PLV")) {
           const u64 nlines = n / FmView::PLV_LINE + 1;
           u32 *cnt = nullptr, *before = nullptr;
           void* tmp = nullptr;
@@ -788,7 +788,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
   // block minima over the suffix array for the top-k locate (0.57 n bytes; one streaming pass over SA)
   f.samin[0] = sa;
   f.nlev = 1;
-  if (!std::getenv("DICEY_NO_SA_MINIMA")) {
+  if (!exp_env("DICEY_NO_SA_MINIMA")) {
     u64 cnt = n;
     const u32* prev = sa;
     while (cnt > 8 && f.nlev < FmView::MAXLEV) {
@@ -1007,7 +1007,7 @@ int dg_index_share(dg_index* src, dg_index** out) {
   // evenly (which keeps the lanes in step: DESIGN "lanes")
   static std::atomic<unsigned> n_shares{0};
   hipError_t se = hipSuccess;
-  if (std::getenv("DICEY_EXP_PRIO")) {
+  if (exp_env("DICEY_EXP_PRIO")) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     se = hipStreamCreateWithPriority(&ix->stream, hipStreamDefault, (n_shares.fetch_add(1) & 1u) ? least : greatest);

@@ -5,6 +5,7 @@
 #include <atomic>
 #include "common.hpp"
 #include "devfm.hpp"
+#include "experiments.hpp"
 
 // Test / development switches of the hunt pipeline (environment variables).  Read ONCE per batch, on the thread that calls the
 // library (the submitting thread for dg_hunt_submit batches) — never on the lanes' helper threads, where getenv would race with a

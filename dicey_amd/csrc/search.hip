@@ -383,8 +383,8 @@ int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSe
       const u32 wmax = sx->max_primer_len + 3 * dmax_eff + 2;  // k + overhang + context on both sides + edits
       const u32 wstride = (wmax + 15) & ~15u;
       const u64 dp_stride = (u64)sx->max_primer_len * wmax;
-      static const bool no_lds = std::getenv("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
-      static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential thal only
+      static const bool no_lds = exp_env("DICEY_NO_LDS_TABLES") != nullptr;  // debugging aid (no barrier in the kernel)
+      static const bool no_wave = exp_env("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential thal only
       // wave-per-hit path: LDS holds the tables once per workgroup and one DP table per wavefront
       const u32 tab_bytes = thal::wave_header_bytes();
       const u32 per_wave = thal::wave_mem_bytes(sx->max_primer_len, wmax);
@@ -419,7 +419,7 @@ int launch_site_stage(dg_index* ix, SearchExtra* sx, const Batch& b, const HitSe
       sa.dp_row = wmax;
       sa.only_flagged = 0;
       sa.wave_len1 = sa.wave_stride = sa.wave_bytes = 0;
-      static const bool force_redo = std::getenv("DICEY_DEBUG_THAL_REDO") != nullptr;
+      static const bool force_redo = exp_env("DICEY_DEBUG_THAL_REDO") != nullptr;
       sa.force_redo = force_redo ? 1 : 0;
       const u32 cells = (wmax + 1) * (maxlen + 1);
       if (wave_path) {
@@ -560,7 +560,7 @@ int dg_search_sites(dg_index* ix, dg_thal* th, const dg_search_params* p, const 
   std::vector<u32> qfl(np);
   DG_HIP(hipMemcpyAsync(qfl.data(), sx.d_qflags, np * 4, hipMemcpyDeviceToHost, st));
   // stable compaction on the device (debugging aid DICEY_DEBUG_DUMP_RAW keeps every record)
-  const char* dump = std::getenv("DICEY_DEBUG_DUMP_RAW");
+  const char* dump = exp_env("DICEY_DEBUG_DUMP_RAW");
   u64 nkeep = 0;
   std::vector<SiteRaw> raw;
   std::vector<u8> win;

@@ -324,8 +324,8 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
   auto t_start = std::chrono::steady_clock::now();
   std::vector<PairDesc> pd(npairs);
   u64 ncode = 0, ndp = 0;
-  static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;       // debugging aids: sequential kernel only /
-  static const bool force_redo = std::getenv("DICEY_DEBUG_THAL_REDO") != nullptr;  // recompute every pair sequentially too
+  static const bool no_wave = exp_env("DICEY_NO_WAVE_THAL") != nullptr;       // debugging aids: sequential kernel only /
+  static const bool force_redo = exp_env("DICEY_DEBUG_THAL_REDO") != nullptr;  // recompute every pair sequentially too
   const u64 kWaveLenCap = 48;  // two 48 x 48 tables still fit a workgroup's LDS next to the parameter tables
   u32 wl1 = 0, wl2 = 0;
   u64 nwave = 0;
@@ -437,7 +437,7 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
 int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, const uint64_t* win_off, const uint32_t* win_len, size_t n,
                           double* temp) {
   if (!n) return DG_OK;
-  static const bool force_redo = std::getenv("DICEY_DEBUG_THAL_REDO") != nullptr;
+  static const bool force_redo = exp_env("DICEY_DEBUG_THAL_REDO") != nullptr;
   u32 maxlen = 0;
   std::vector<WinDesc> wd(n);
   for (size_t k = 0; k < n; ++k) {
@@ -447,7 +447,7 @@ int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, co
     wd[k].pad = 0;
     maxlen = std::max(maxlen, win_len[k]);
   }
-  static const bool no_wave = std::getenv("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential kernel only
+  static const bool no_wave = exp_env("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential kernel only
   std::vector<u8> redo(n, 1);
   if (!no_wave) {
     DG_HIP(hipSetDevice(th->device));

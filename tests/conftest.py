@@ -27,6 +27,44 @@ def pytest_sessionstart(session):
             subprocess.call(cmd)
 
 
+# The development build that reads the test switches (dicey_amd/csrc/experiments.hpp): the product library ignores them, so every test
+# that forces a code path through an environment variable opens its index on this library (open_index / exp_lib).
+EXP_LIB = os.path.join(ROOT, "dicey_amd", "variants", "libdiceygpu_exp.so")
+EXP_VARS = ("DICEY_NO_BAND_VERIFY", "DICEY_CAP_HOST", "DICEY_NO_FUSED_SELECT", "DICEY_NO_FUSED_SELECT2", "DICEY_NO_PREP_FUSION", "DICEY_NO_PRE5_D2",
+            "DICEY_NO_FLAT_HAMMING2", "DICEY_NO_N_WINDOW", "DICEY_NO_LONG2", "DICEY_DEBUG_CAPS", "DICEY_FUSED_LCAP", "DICEY_VERIFY_CH", "DICEY_EXP",
+            "DICEY_NO_KMER_FILTER", "DICEY_NO_NRUN_PRUNE", "DICEY_NO_PRE5", "DICEY_NO_SAX", "DICEY_NO_PLV", "DICEY_NO_SA_MINIMA",
+            "DICEY_NO_LDS_TABLES", "DICEY_NO_WAVE_THAL", "DICEY_DEBUG_THAL_REDO")
+_exp = {"lib": None}
+
+
+def _sources_mtime():
+    import glob
+    files = glob.glob(os.path.join(ROOT, "dicey_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dicey_amd", "csrc", "*.hpp")) + \
+        [os.path.join(ROOT, "include", "dicey_gpu.h")]
+    return max(os.path.getmtime(f) for f in files)
+
+
+def build_exp_lib():
+    """tools/build_variant.sh exp -DDG_EXPERIMENTS when the library is missing or older than the kernel sources"""
+    import subprocess
+    if not os.path.exists(EXP_LIB) or os.path.getmtime(EXP_LIB) < _sources_mtime():
+        subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), "exp", "-DDG_EXPERIMENTS"], stdout=subprocess.DEVNULL)
+    return EXP_LIB
+
+
+def exp_lib():
+    if _exp["lib"] is None:
+        from dicey_amd import _capi
+        _exp["lib"] = _capi.load(build_exp_lib())
+    return _exp["lib"]
+
+
+def open_index(fm9, **kw):
+    """dicey_amd.FmIndex on the product library — or, when a test switch is set in the environment, on the development build"""
+    import dicey_amd
+    return dicey_amd.FmIndex(fm9, _lib=exp_lib() if any(k in os.environ for k in EXP_VARS) else None, **kw)
+
+
 def pytest_collection_modifyitems(config, items):
     """`gpu` tests need an MI355X: on a box without a HIP device they are skipped (not failed), so a plain `pytest` run is
     green wherever it runs.  (DICEY_LIB — a development build of the library — lifts the skip.)"""

@@ -23,11 +23,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ix(small_genome):
     import dicey_amd
-    lib = None
-    if os.environ.get("DICEY_LIB"):
-        from dicey_amd import _capi
-        lib = _capi.load(os.environ["DICEY_LIB"])
-    h = dicey_amd.FmIndex(small_genome["fm9"], device=0, _lib=lib)
+    from conftest import exp_lib
+    # (the development build: DICEY_CAP_HOST — read per batch — is a test switch the product library ignores, experiments.hpp)
+    h = dicey_amd.FmIndex(small_genome["fm9"], device=0, _lib=exp_lib())
     yield h
     h.close()
 

@@ -19,7 +19,7 @@ except Exception:  # pragma: no cover
     torch = None
 
 import oracle_lib as O
-from conftest import genome_text, make_genome, make_queries, revcomp
+from conftest import open_index, genome_text, make_genome, make_queries, revcomp
 
 pytestmark = pytest.mark.gpu
 
@@ -246,7 +246,7 @@ def test_queries_with_n_where_the_text_has_no_short_n_run(genome_100mb, prune, m
         else:
             q[rng.randrange(4, 16)] = "y"
         qs.append("".join(q))
-    with dicey_amd.FmIndex(g["fm9"]) as ix:
+    with open_index(g["fm9"]) as ix:
         for kw, sub in ((dict(distance=1), qs), (dict(distance=1, hamming=True), qs[:120]), (dict(distance=2, hamming=True), qs[:60])):
             want = _oracle_hits_parallel(g["fm9"], g, sub, **kw)
             got = ix.hunt(sub, g["seqlen"], **kw)

@@ -13,7 +13,7 @@ except Exception:  # pragma: no cover
     torch = None
 
 import oracle_lib as O
-from conftest import genome_text
+from conftest import genome_text, open_index
 
 pytestmark = pytest.mark.gpu
 
@@ -90,7 +90,7 @@ def _topk_case(tmp_path, monkeypatch, copies, background, tandem):
     orc = O.Index(path)
     sub = unit[:19] + ("A" if unit[19] != "A" else "C")
     qs = [unit, sub, unit[1:] + "G", unit[:10] + unit[11:] + "T", seqs[0][5000:5020], unit[2:] + "AC"]
-    with dicey_amd.FmIndex(path) as ix:
+    with open_index(path) as ix:
         for kw in (dict(distance=0, max_locations=1000), dict(distance=1, max_locations=1000), dict(distance=1, max_locations=3),
                    dict(distance=0, max_locations=1024), dict(distance=0, max_locations=1025), dict(distance=1, max_locations=700),
                    dict(distance=1, hamming=True, max_locations=40), dict(distance=0, max_locations=1, forward_only=True),
@@ -119,7 +119,7 @@ def test_topk_locate_million_copy_family(tmp_path):
     while p >= 0 and len(want) < 1000:
         want.append(p)
         p = text.find(unit.encode(), p + 1)
-    with dicey_amd.FmIndex(path) as ix:
+    with open_index(path) as ix:
         for m in (1000, 7):
             R = ix.hunt([unit], g["seqlen"], distance=0, max_locations=m, forward_only=True)
             hits = R.queries[0].hits
@@ -143,7 +143,7 @@ def test_job_kernels_come_back_after_a_batch_without_repeat_rich_strings(tmp_pat
     rng = random.Random(12)
     plain = ["".join(rng.choice("ACGT") for _ in range(20)) for _ in range(64)]  # random 20-mers: at most a stray hit, no job
     rich = [unit, unit[1:] + "A", seqs[1][777:797]]
-    with dicey_amd.FmIndex(path) as ix:
+    with open_index(path) as ix:
         for qs in (plain, rich, plain, plain, rich, rich):
             _compare(ix, orc, g, qs, distance=1, max_locations=1000)
 
@@ -195,7 +195,7 @@ def test_hits_of_repeat_rich_strings_carry_their_context(tmp_path, monkeypatch, 
             qs.append(q[:k] + rng.choice("ACGT") + q[k + 1:])   # a substitution
             qs.append(q[:k] + q[k + 1:])                        # a deletion
             qs.append(q[:k] + rng.choice("ACGT") + q[k:])       # an insertion
-    with dicey_amd.FmIndex(path) as ix:
+    with open_index(path) as ix:
         for kw in (dict(distance=1, max_locations=1000), dict(distance=0, max_locations=1000), dict(distance=1, max_locations=100),
                    dict(distance=1, hamming=True, max_locations=1000)):
             _compare(ix, orc, g, qs, **kw)
@@ -221,7 +221,7 @@ def test_small_buffer_topk_kernel_serves_a_batch_with_thousands_of_repeat_rich_s
         q = unit[off:off + 20]
         k = rng.randrange(20)
         qs.append(q[:k] + rng.choice("ACGT") + q[k + 1:])
-    with dicey_amd.FmIndex(path) as ix:
+    with open_index(path) as ix:
         ix.hunt(qs, g["seqlen"], distance=1, max_locations=1000)
         got = _compare(ix, orc, g, qs, distance=1, max_locations=1000)
         assert sum(len(q.hits) for q in got.queries) > 400 * 2000

@@ -13,7 +13,7 @@ except Exception:  # pragma: no cover
     torch = None
 
 import oracle_lib as O
-from conftest import genome_text, make_genome, make_queries
+from conftest import open_index, genome_text, make_genome, make_queries
 
 pytestmark = pytest.mark.gpu
 
@@ -203,7 +203,7 @@ def test_capacity_retry_path(small_genome, monkeypatch):
     import dicey_amd
     monkeypatch.setenv("DICEY_DEBUG_CAPS", "2")
     orc = O.Index(small_genome["fm9"])
-    with dicey_amd.FmIndex(small_genome["fm9"]) as ix:
+    with open_index(small_genome["fm9"]) as ix:
         qs = make_queries(77, small_genome["text"], 400)
         _compare(ix, orc, small_genome, qs, distance=1)
         # distance 2 under the same tiny capacities (leaf regions overflow several times before they fit)
@@ -383,7 +383,7 @@ def test_every_search_mode_gives_the_same_hits(small_genome, monkeypatch, mode):
     elif "_long" in mode:         # long filter right above the table order / well above it
         monkeypatch.setenv("DICEY_KMER_K2", mode.split("_long")[1])
     orc = O.Index(small_genome["fm9"])
-    with dicey_amd.FmIndex(small_genome["fm9"], kmer_table=(mode != "no_table")) as ix:
+    with open_index(small_genome["fm9"], kmer_table=(mode != "no_table")) as ix:
         qs = make_queries(31, small_genome["text"], 300, (10, 11, 14, 20, 33))
         _compare(ix, orc, small_genome, qs, distance=1)
         _compare(ix, orc, small_genome, qs[:120], distance=1, hamming=True)
@@ -546,7 +546,7 @@ def test_fused_select_and_its_hand_over_to_the_generic_kernels(small_genome, mon
     mixed = pure[:150] + ["ACGTNACGTACGTACGTACG", g["seqs"][1][50:90], "acgtacgtacgtacgtacgtnn", g["seqs"][2][7:19]] + pure[150:200]
     rng.shuffle(mixed)
     monkeypatch.setenv("DICEY_KMER_K", "9")
-    with dicey_amd.FmIndex(g["fm9"]) as ix:
+    with open_index(g["fm9"]) as ix:
         for qs, kw in [(pure, dict(distance=1)), (pure[:300], dict(distance=1)), (mixed, dict(distance=1)), (pure[300:], dict(distance=1)),
                        (pure[:200], dict(distance=1, hamming=True)), (low, dict(distance=1)), (mixed, dict(distance=1, hamming=True)),
                        (pure[:100], dict(distance=1, max_locations=2)), (pure[:64], dict(distance=1, forward_only=True))]:

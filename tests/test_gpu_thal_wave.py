@@ -68,7 +68,8 @@ def run_child(tmp, name, env_extra):
 def test_wave_kernel_equals_sequential_kernel(tmp_path):
     tmp = str(tmp_path)
     wave = run_child(tmp, "wave", {})
-    seq = run_child(tmp, "seq", {"DICEY_DEBUG_THAL_REDO": "1"})
+    from conftest import build_exp_lib
+    seq = run_child(tmp, "seq", {"DICEY_DEBUG_THAL_REDO": "1", "DICEY_LIB": build_exp_lib()})  # (a test switch: the development build reads it)
     assert wave.keys() == seq.keys()
     for k in wave:
         assert wave[k] == seq[k], k

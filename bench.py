@@ -483,7 +483,7 @@ def host_cpu_info():
 
 def thal_counter_block(cfg, kernel, thal_calls, stage_ms):
     """k_site_wave against the fp64 vector peak and the LDS: instruction counters of the committed PMC pass
-    on this workload (tools/prof_thal.sh -> profiles/r03_thal_counters.json), scaled to this run's thal() count and stage time.
+    on this workload (tools/prof_thal.sh -> profiles/thal_counters.json), scaled to this run's thal() count and stage time.
     fp64 FLOP/s is an UPPER bound (every lane of every fp64 wavefront instruction counted as active; an FMA as two)."""
     tc = profile_of_this_build("thal_counters.json")  # tools/prof_thal.sh + tools/summarize_thal.py, stamped with the sources' build_id
     k = ref_calls = None
@@ -1322,7 +1322,7 @@ def main():
                                  "filter_geometry_4_copies_of_8.6GB": {"6_lines_per_strand": 20.8, "12_lines_per_strand": 9.4,
                                                                          "24_lines_per_strand": 11.3},
                                  "kernel_shaped_filter2_Glines_per_s": {"12_lines_per_strand": 42.3, "15_lines_per_strand": 41.8},
-                                 "source": "profiles/r03a_gather_matrix.jsonl, profiles/r03a_gather_filter.jsonl, profiles/r05_gather_filter2.jsonl"}},
+                                 "source": "docs/history/profiles/r03a_gather_matrix.jsonl, docs/history/profiles/r03a_gather_filter.jsonl, profiles/r05_gather_filter2.jsonl"}},
                 "cpu_baseline": cpu, "cpu_baseline_parallel": cpu_par, "pipelined": pipelined, "parity_sample": parity,
                 "phases_ms": ({k: float(np.mean([r[k] for r in acc_ph])) for k in ("ms_total", "ms_search", "ms_search_flat", "ms_select", "ms_locate", "ms_verify")}
                               if acc_ph else {k: mean(k) for k in ("ms_total", "ms_search", "ms_search_flat", "ms_select", "ms_locate", "ms_verify")}),

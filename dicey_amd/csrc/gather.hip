@@ -11,6 +11,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -234,12 +235,23 @@ struct TcpTransport : Transport {
       if (lfd < 0) return fail(G_ECOMM, "socket failed");
       ::setsockopt(lfd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
       if (::bind(lfd, (sockaddr*)&a, sizeof a) != 0 || ::listen(lfd, n) != 0) return fail(G_ECOMM, "cannot listen on 127.0.0.1:%d", port);
+      // a peer that dies at start-up must not leave the root in accept() / recv() for ever: 60 s for a peer to
+      // connect, 60 s for its hello
+      timeval tmo{};
+      tmo.tv_sec = 60;
+      ::setsockopt(lfd, SOL_SOCKET, SO_RCVTIMEO, &tmo, sizeof tmo);
       for (int k = 0; k < n - 1; ++k) {
         int s = ::accept(lfd, nullptr, nullptr);
-        if (s < 0) return fail(G_ECOMM, "accept failed");
+        if (s < 0) return fail(G_ECOMM, "no peer connected within 60 s (%d of %d are here)", k, n - 1);
         ::setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        ::setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &tmo, sizeof tmo);
         int32_t who = -1;
-        if (!xrecv(s, &who, 4) || who < 0 || who >= n || who == root || fd[who] != -1) return fail(G_ECOMM, "bad hello from a peer");
+        if (!xrecv(s, &who, 4) || who < 0 || who >= n || who == root || fd[who] != -1) {
+          ::close(s);
+          return fail(G_ECOMM, "bad hello from a peer");
+        }
+        timeval none{};
+        ::setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);  // (the payload transfers wait as long as the peers compute)
         fd[who] = s;
       }
     } else {

@@ -206,7 +206,9 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
       else if (d == 1 && b.nrun_min >= 2) gi.d_win |= 4096u | 8192u;
       if (gi.d_win & 4096u) gi.qpk = strand ? pk_rv : pk_fw;  // (an N reads as some base: k_nres overwrites those positions)
     }
-    if (!nres && bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
+    // (not for a strand k_nres serves: what is left of its walk — the strings that keep the N — dies within a few steps, and the
+    //  flag below gives EVERY group of the batch the walker's root split, 29 M lanes that leave at once)
+    if (!(gi.d_win & 4096u) && bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
       const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
       const u32 lim = m - b.tabK - d;  // N's are allowed at string indices below this
       const bool ok = !strand ? (lim < 32 && (nm >> lim) == 0u) : (nm & (m - lim >= 32 ? ~0u : ((1u << (m - lim)) - 1u))) == 0u;

@@ -12,17 +12,18 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <string_view>
 #include <thread>
 #include <functional>
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <atomic>
 #include <vector>
@@ -238,41 +239,61 @@ struct GatherApi {
   }
 };
 
-// stdout as a regular file (a shell redirection, the bench's output file): the formatting threads copy their lines straight into a
-// mapping of the file's next stretch instead of handing them to ONE thread that write()s 5 GB (r05: the writes of a 10 M-query run
-// were half of its wall clock; write() to one file serialises on the inode, page faults of a shared mapping do not).  Anything
-// else — a pipe, a terminal, append mode — keeps the ordered write().
-struct StdoutMap {
-  bool usable = false;
-  long page = 4096;
-  int fdm = -1;  // the same file opened for reading and writing (a redirection opens it write-only, which a shared mapping refuses)
-  StdoutMap() {
-    struct stat st;
-    const int fl = fcntl(1, F_GETFL);
-    if (fstat(1, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND) && !std::getenv("DICEY_NO_MAPPED_OUTPUT"))
-      fdm = open("/proc/self/fd/1", O_RDWR);
-    usable = fdm >= 0;
-    page = sysconf(_SC_PAGESIZE) > 0 ? sysconf(_SC_PAGESIZE) : 4096;
+// stdout behind a writer thread (r06): the formatting threads of chunk k + 1 work while chunk k's buffers are written, in order.
+// A 10 M-query run writes 5.2 GB of JSON; one write() stream into a file runs at ~2.8 GB/s (page allocation + copy), which was
+// spent AFTER each chunk's formatting.  (Measured and dropped: the formatting threads copying their lines into a shared mapping of
+// the file — page faults of a mapping are slower than write() and do not scale — and parallel pwrite(), which serialises on the
+// inode: 1.7 / 3.1 against 2.8 GB/s on 8 cores.)  At most 512 MB wait in the queue.
+class AsyncWriter {
+ public:
+  ~AsyncWriter() { finish(); }
+  void push(std::string&& blob) {
+    if (blob.empty()) return;
+    std::unique_lock<std::mutex> lk(mu_);
+    if (!th_.joinable()) th_ = std::thread([this] { run(); });
+    cv_room_.wait(lk, [this] { return queued_ < kMax; });
+    queued_ += blob.size();
+    q_.push_back(std::move(blob));
+    cv_work_.notify_one();
   }
-  // maps [offset of fd 1, + total): returns where byte 0 of the stretch lies, or nullptr (then nothing was changed)
-  char* begin(size_t total, void*& base, size_t& maplen, off_t& off0) {
-    std::fflush(stdout);
-    off0 = lseek(1, 0, SEEK_CUR);
-    if (off0 < 0 || total == 0) return nullptr;
-    if (ftruncate(fdm, off0 + (off_t)total) != 0) return nullptr;
-    const off_t lo = off0 & ~(off_t)(page - 1);
-    maplen = (size_t)(off0 - lo) + total;
-    base = mmap(nullptr, maplen, PROT_READ | PROT_WRITE, MAP_SHARED, fdm, lo);
-    if (base == MAP_FAILED) {
-      (void)!ftruncate(fdm, off0);
-      return nullptr;
+  void finish() {  // everything handed over so far is on stdout when this returns
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_ = true;
+      cv_work_.notify_one();
     }
-    return (char*)base + (off0 - lo);
+    if (th_.joinable()) th_.join();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_ = false;
+    std::fflush(stdout);
   }
-  void end(void* base, size_t maplen, off_t off0, size_t total) {
-    munmap(base, maplen);
-    lseek(1, off0 + (off_t)total, SEEK_SET);
+
+ private:
+  void run() {
+    for (;;) {
+      std::string blob;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_work_.wait(lk, [this] { return done_ || !q_.empty(); });
+        if (q_.empty()) return;
+        blob = std::move(q_.front());
+        q_.pop_front();
+      }
+      std::fwrite(blob.data(), 1, blob.size(), stdout);
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        queued_ -= blob.size();
+        cv_room_.notify_all();
+      }
+    }
   }
+  static constexpr size_t kMax = 512u << 20;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_room_;
+  std::deque<std::string> q_;
+  size_t queued_ = 0;
+  bool done_ = false;
+  std::thread th_;
 };
 
 template <class FormatFn>
@@ -589,7 +610,9 @@ int hunter(int argc, char** argv) {
   // small FASTA is answered from the Occ blocks alone
   // a process that opens the index for one input keeps the table compact (DG_OPEN_COMPACT): the 137 GB form saves microseconds
   // per batch and costs seconds to allocate when the driver still has to wipe memory another process released
-  uint32_t open_flags = std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_BIG_TABLE : DG_OPEN_DEFAULT;
+  // (DG_OPEN_COMPACT since ABI 7: without the layouts that only pay for a resident index — the suffix array with context and its
+  //  prefix levels are 40 GB, 0.36 s to derive and a second of driver wipe at exit, against 0.3 ms per 100 000 queries of a repeat-rich batch)
+  uint32_t open_flags = (std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_BIG_TABLE : DG_OPEN_DEFAULT) | (std::getenv("DICEY_RESIDENT_LAYOUTS") ? 0u : DG_OPEN_COMPACT);
   {
     struct stat ist;
     if (!(stat(c.input.c_str(), &ist) == 0 && S_ISREG(ist.st_mode) && ist.st_size > (1 << 20)) && !std::getenv("DICEY_KMER_K"))
@@ -695,39 +718,18 @@ int hunter(int argc, char** argv) {
       // reference flushes after every line; the bytes are the same)
       std::vector<std::string> blobs(nthr);
       const size_t per_thr = (nq + nthr - 1) / nthr;
-      // r06: when stdout is a regular file the last thread to finish its lines maps the file's next stretch and every thread copies
-      // its own lines into place (StdoutMap); otherwise the buffers go out in order, one write each
-      static StdoutMap smap;
-      std::atomic<unsigned> finished{0};
-      std::atomic<int> go{0};  // 1: copy into dst, -1: no mapping
-      char* dst = nullptr;
-      void* mbase = nullptr;
-      size_t mlen = 0, total = 0;
-      off_t off0 = 0;
-      std::vector<size_t> at(nthr + 1, 0);
       auto work = [&](unsigned t) {
         std::string& o = blobs[t];
         const size_t i0 = t * per_thr, i1 = std::min(nq, i0 + per_thr);
         o.reserve((i1 > i0 ? i1 - i0 : 0) * 700);
         for (size_t i = i0; i < i1; ++i) o += line_of(i);
-        if (!smap.usable) return;
-        if (finished.fetch_add(1, std::memory_order_acq_rel) + 1 == nthr) {
-          for (unsigned k = 0; k < nthr; ++k) at[k + 1] = at[k] + blobs[k].size();
-          total = at[nthr];
-          dst = smap.begin(total, mbase, mlen, off0);
-          go.store(dst ? 1 : -1, std::memory_order_release);
-        } else
-          while (go.load(std::memory_order_acquire) == 0) std::this_thread::yield();
-        if (go.load(std::memory_order_acquire) == 1 && !o.empty()) std::memcpy(dst + at[t], o.data(), o.size());
       };
       if (nthr > 1) {
         std::vector<std::thread> fmt;
         for (unsigned t = 0; t < nthr; ++t) fmt.emplace_back(work, t);
         for (auto& th : fmt) th.join();
       } else work(0);
-      if (go.load() == 1) smap.end(mbase, mlen, off0, total);
-      else
-        for (std::string& o : blobs) bulk(std::move(o));
+      for (std::string& o : blobs) bulk(std::move(o));  // (the writer thread's queue: the next chunk is formatted while these go out)
       return;
     }
     if (nthr > 1) {
@@ -870,12 +872,14 @@ int hunter(int argc, char** argv) {
   if (G == 1) {
     std::string err;
     std::function<void(std::string&&)> bulk;
+    AsyncWriter writer;
     if (!c.has_outfile)  // (the gzip outfile is one member per query, hunter.h:162-170: written line by line)
-      bulk = [&](std::string&& blob) {
-        std::fwrite(blob.data(), 1, blob.size(), stdout);
-        std::fflush(stdout);
-      };
-    if (!run_slice(handles[0], 0, queries.size(), [&](size_t, std::string&& js) { emit(c, js); }, err, bulk)) {
+      bulk = [&](std::string&& blob) { writer.push(std::move(blob)); };
+    const double t_run0 = now_ms();
+    const bool ran = run_slice(handles[0], 0, queries.size(), [&](size_t, std::string&& js) { emit(c, js); }, err, bulk);
+    writer.finish();
+    if (timing_on()) std::fprintf(stderr, "dicey timing: %-28s %8.1f ms\n", "search + format + write", now_ms() - t_run0);
+    if (!ran) {
       std::cerr << "dicey: " << err << std::endl;
       rc_all = 2;
     }
@@ -1090,7 +1094,7 @@ int silica(int argc, char** argv) {
   }
   if (!seq_len_name(c.genome, seqlen, seqname)) return bail("Error: Could not retrieve sequence lengths!");
   const int dev = device_from_env();
-  if (dg_index_open((strip_last_extension(c.genome) + ".fm9").c_str(), dev, std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_BIG_TABLE : DG_OPEN_DEFAULT, &ix) != DG_OK) {
+  if (dg_index_open((strip_last_extension(c.genome) + ".fm9").c_str(), dev, (std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_BIG_TABLE : DG_OPEN_DEFAULT) | DG_OPEN_COMPACT, &ix) != DG_OK) {
     std::cerr << "dicey: " << dg_last_error() << std::endl;
     ix = nullptr;
     return bail("Error: FM-Index cannot be loaded!");

@@ -456,7 +456,7 @@ int run_padlock(PadlockConfig& c) {  // padlock.h:147-531
   const std::string index_file = strip_last_extension(c.genome) + ".fm9";
   struct stat ist;
   const bool big = stat(index_file.c_str(), &ist) == 0 && ist.st_size > (64 << 20);
-  if (dg_index_open(index_file.c_str(), device, (big || std::getenv("DICEY_KMER_K")) ? (std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_BIG_TABLE : DG_OPEN_DEFAULT) : DG_OPEN_NO_KMER_TABLE, &run.ix) != DG_OK) {
+  if (dg_index_open(index_file.c_str(), device, ((big || std::getenv("DICEY_KMER_K")) ? (std::getenv("DICEY_FULL_TABLE") ? DG_OPEN_BIG_TABLE : DG_OPEN_DEFAULT) : DG_OPEN_NO_KMER_TABLE) | DG_OPEN_COMPACT, &run.ix) != DG_OK) {
     std::cerr << "Error: FM-Index cannot be loaded!" << std::endl;
     return 1;
   }

@@ -709,6 +709,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   }
   u64 nleaf = 0, nhits = 0;
   bool force_generic = false, force_jobs = false, force_short2 = false;
+  u64 walk_cap = 0;  // room of the walker's group list (k_walk_list)
   u32 flat_form = 0;  // which flat search kernel the (last) attempt launched: dg_hunt_result::flat_kernel_form
   u32 verify_form = 0;  // ... and which k_verify_memo instantiation: dg_hunt_result::verify_kernel_form
   // Fetched results: one pinned block from the pool (pageable copies run at a fraction of the link's speed, and a fresh
@@ -900,8 +901,21 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       // queries with N that the split turns from one 1 500-read chain per strand into lanes of a handful of reads)
       // — while the handle's batches hold such strands (nwin_sticky): 29 M lanes that leave at once cost a repeats-genome step 0.15 ms
       const u32 items = (ix->view.K && dmax_eff >= 1 && (!b.fastK || ix->nwin_sticky)) ? ix->view.K * (indel ? 9u : 4u) + 1u : 1u;
-      const dim3 grid(ceil_div(ngrp * items, TB)), block(TB);
-#define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so, items)
+      // beside a flat kernel the walker serves a few strands of the batch: with the root split its lanes cover a LIST of them
+      // (k_walk_list; room for what the previous batch listed plus a quarter — a list that overflows repeats the batch)
+      WalkList wl{nullptr, nullptr, 0u};
+      u64 wgroups = ngrp;
+      if (items > 1 && (b.fastK || b.fast2K) && ngrp < 0x7FFFFFFFull) {
+        walk_cap = std::max<u64>(walk_cap, std::min<u64>(ngrp, (u64)ix->walk_hint + ix->walk_hint / 4 + 4096));
+        DG_TRY(ws[WS_WALK].reserve((walk_cap + 1) * 4));
+        wl.gid = ws[WS_WALK].as<u32>();
+        wl.count = &ctr->pad_[10];
+        wl.cap = (u32)walk_cap;
+        wgroups = walk_cap;
+        hipLaunchKernelGGL(k_walk_list, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, b, ws[WS_WALK].as<u32>(), &ctr->pad_[10], wl.cap, ctr);
+      }
+      const dim3 grid(ceil_div(wgroups * items, TB)), block(TB);
+#define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so, items, wl)
       if (indel) {
         if (dmax_eff == 0) DG_LAUNCH_SEARCH(true, 0);
         else if (dmax_eff == 1) DG_LAUNCH_SEARCH(true, 1);
@@ -1180,6 +1194,11 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       hit_cap = nhits + nhits / 4 + 1024;
       again = true;
     }
+    if (hsum.overflow & 8u) {  // the walker's group list was too short
+      walk_cap = std::min<u64>(ngrp, hsum.n_walk + hsum.n_walk / 4 + 4096);
+      again = true;
+    }
+    ix->walk_hint = (u32)std::min<u64>(hsum.n_walk, 0xFFFFFFFFull);
     if (again) continue;
     // The hints are sticky: a kernel family that a batch needed stays on for the next eight batches of the handle, so that a stream
     // that alternates (chunks with and without N-containing queries, with and without repeat-rich strings) does not pay a repeated

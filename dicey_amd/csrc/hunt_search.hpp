@@ -206,9 +206,9 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
       else if (d == 1 && b.nrun_min >= 2) gi.d_win |= 4096u | 8192u;
       if (gi.d_win & 4096u) gi.qpk = strand ? pk_rv : pk_fw;  // (an N reads as some base: k_nres overwrites those positions)
     }
-    // (not for a strand k_nres serves: what is left of its walk — the strings that keep the N — dies within a few steps, and the
-    //  flag below gives EVERY group of the batch the walker's root split, 29 M lanes that leave at once)
-    if (!(gi.d_win & 4096u) && bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
+    // (also for a strand whose N-keeping strings are the walker's: with its N at the left end the walk crosses every edit right of
+    //  it before it meets the N — ~145 strings; in window mode with the root split that is a lane per first edit)
+    if (!nres && bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
       const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
       const u32 lim = m - b.tabK - d;  // N's are allowed at string indices below this
       const bool ok = !strand ? (lim < 32 && (nm >> lim) == 0u) : (nm & (m - lim >= 32 ? ~0u : ((1u << (m - lim)) - 1u))) == 0u;
@@ -1666,13 +1666,42 @@ __global__ void __launch_bounds__(256, LONG2 ? 6 : 5) k_search2p(FmView f, Batch
 }
 
 
+// the groups the walker serves, listed (one atomic per wavefront); a list that does not fit raises bit 3 of Counters::overflow
+// and the batch is repeated with room
+__global__ void __launch_bounds__(256) k_walk_list(Batch b, u32* list, u32* count, u32 cap, Counters* ctr) {
+  const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  bool need = false;
+  if (g < 2 * b.nq) {
+    const GidInfo gi = b.ginfo[g];
+    need = gi.m != 0 && !(gi.d_win & (512u | 1024u)) && (gi.d_win & (4096u | 8192u)) != 4096u;
+  }
+  const unsigned long long mk = __ballot(need);
+  if (!mk) return;
+  const u32 lane = threadIdx.x & 63, leader = (u32)__ffsll((long long)mk) - 1u;
+  u32 base = 0;
+  if (lane == leader) base = atomicAdd(count, (u32)__popcll(mk));
+  base = __shfl(base, (int)leader);
+  if (need) {
+    const u32 at = base + (u32)__popcll(mk & ((1ULL << lane) - 1));
+    if (at < cap) list[at] = (u32)g;
+    else atomicOr(&ctr->overflow, 8u);
+  }
+}
+// r06: wlist / wcount (may be null) — the groups the walker has work for, listed by k_walk_list: with the root split a launch over
+// EVERY group is (groups x 145) lanes, 29 M for a batch of 100 000 queries of which a few thousand strands need the walker
+// (queries with an N next to 95 % for the flat kernel); the lanes then cover the listed groups only.
+struct WalkList {
+  const u32* gid;
+  const u32* count;
+  u32 cap;
+};
 template <bool INDEL, int D>
-__global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, u32 items) {
+__global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, u32 items, WalkList wl) {
   // lane layout: the long-running "rest" lanes come first, packed densely (a rest lane among 63 short item lanes
   // would pin its whole wavefront); item lanes follow, (items-1) consecutive lanes per (query, strand)
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u64 ngrp = b.nq * 2;
-  u64 gid;   // 2*query + strand
+  const u64 ngrp = wl.gid ? (u64)(*wl.count < wl.cap ? *wl.count : wl.cap) : b.nq * 2;
+  u64 gid;   // 2*query + strand (or its number in the list)
   u32 item;  // items-1 = the rest lane
   if (t < ngrp || items == 1) {
     gid = t;
@@ -1684,6 +1713,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   u64 steps = 0, lookups = 0, probes = 0;
   constexpr u32 NOPS = INDEL ? 9u : 4u;  // INDEL: D, S(A,C,G,T), I(A,C,G,T);  Hamming: S(A,C,G,T)
   bool active = gid < ngrp;
+  if (wl.gid) gid = active ? wl.gid[gid] : 0;
   const u64 q = gid >> 1;
   const u32 strand = (u32)(gid & 1);
   GidInfo gi;

@@ -18,6 +18,7 @@ struct Summary {
   unsigned long long n_generic;             // groups searched outside the flat distance-1 kernel (k_prepare)
   unsigned long long n_nwin;                // flag: N-bearing strands that walk in window mode (k_prepare)
   unsigned long long n_short2;              // distance 2: queries k_search2p<., true> left to the walker for their length (k_prepare)
+  unsigned long long n_walk;                // groups listed for the walker (k_walk_list)
 #ifdef DG_TOPK_PROFILE
   unsigned long long prof[24];
 #endif
@@ -84,6 +85,7 @@ DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
     host_out->n_generic = ctr->pad_[6];
     host_out->n_nwin = ctr->pad_[7];
     host_out->n_short2 = ctr->pad_[9];
+    host_out->n_walk = ctr->pad_[10];
 #ifdef DG_TOPK_PROFILE
     for (int i = 0; i < 24; ++i) host_out->prof[i] = ctr->prof[i];
 #endif

@@ -720,7 +720,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
         // have the block minima (i.e. the top-k locate) and the room; DICEY_NO_SAX leaves it out (the tests run both ways: hits of
         // repeat-rich strings then read their context from the text as before r06)
         uint2* sax = nullptr;
-        if (!exp_env("DICEY_NO_SAX") && !exp_env("DICEY_NO_SA_MINIMA")) {
+        if (!(flags & DG_OPEN_COMPACT) && !exp_env("DICEY_NO_SAX") && !exp_env("DICEY_NO_SA_MINIMA")) {
           size_t free_b = 0, total_b = 0;
           if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > n * 8 + n * 2 + (4ULL << 30) &&
               big_alloc((void**)&sax, n * 8 + 64, ix->stream) == hipSuccess) {

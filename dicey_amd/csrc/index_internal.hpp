@@ -32,7 +32,7 @@ struct dg_index {
   uint64_t file_bytes = 0, hbm_bytes = 0;
   double load_seconds = 0, derive_seconds = 0;
   // grow-only batch workspaces (see hunt.hip / seam.hip for the slot meaning)
-  static constexpr int NWS = 24;
+  static constexpr int NWS = 25;
   dg::DevBuf ws[NWS];
   hipEvent_t ev[9] = {nullptr};  // [8]: end of the flat distance-1 kernel
   uint32_t flat_cap_hint = 0;   // slice capacity of the flat Sel region that was enough so far (hunt.hip)
@@ -40,6 +40,7 @@ struct dg_index {
   uint64_t hit_cap_hint = 0;
   bool generic_hint = true;      // the previous distance-1 batch had work for the kernels outside k_search1s (hunt.hip run_batch)
   bool jobs_hint = true;         // the previous batch queued strings for the locate job kernels
+  uint32_t walk_hint = 0;        // groups the previous batch listed for the walker (k_walk_list)
   uint32_t nwin_sticky = 0;      // batches the walker keeps its root split beside the flat distance-1 kernel (N-bearing strands in window mode)
   uint32_t short2_sticky = 0;    // distance 2: batches left on k_search2p's r04 body after one that held queries too short for LONG2
   uint32_t generic_sticky = 1, jobs_sticky = 1;  // batches the two hints stay on after the last batch that needed them

@@ -58,7 +58,10 @@ typedef struct dg_index dg_index;
 #define DG_OPEN_DEFAULT 0u
 #define DG_OPEN_NO_SELFCHECK 1u /* skip the load-time self validation (C[] vs Occ totals, SA permutation spot checks) */
 #define DG_OPEN_NO_KMER_TABLE 2u /* do not derive the K-mer jump table (saves up to 34 GB of HBM; search is slower) */
-#define DG_OPEN_COMPACT 4u       /* accepted, no effect since ABI 4: the compact table is the default */
+#define DG_OPEN_COMPACT 4u       /* ABI 7: a process that opens the index for ONE input — skip the layouts that only pay for a resident index: the suffix
+                                  * array with context records and its prefix levels (40 GB of HBM on a 3.1 Gb genome, 0.36 s to derive, and as much again for
+                                  * the driver to wipe at exit); hits of repeat-rich strings then read their context from the text and walk the block minima,
+                                  * results are the same.  (ABI 4-6: accepted, no effect.)  `dicey hunt|search|padlock` pass it. */
 #define DG_OPEN_BIG_TABLE 8u     /* table of order ceil(log4 n) + 1 when the device has room (137 GB instead of 34 GB on a 3.1 Gb genome):
                                     the distance-1 search kernel gains ~5 % (0.175 -> 0.166 ms per 100 000 20-mers), the open takes longer
                                     and the process holds 199 GB instead of 90 GB — for resident servers with HBM to spare */

@@ -257,9 +257,10 @@ def test_index_verify_accepts_its_file_and_refuses_foreign_ones(cli_genome, tmp_
 
 
 def test_output_to_a_regular_file_equals_the_piped_output(cli_genome):
-    """r06: with stdout redirected to a regular file the formatting threads copy their lines into a mapping of the file (no single
-    writer); through a pipe the buffers are written in order.  Both must be the same bytes — also behind bytes that were already in
-    the file (the mapping starts at the descriptor's offset, not at a page boundary), and with multi-line FASTA records in the input."""
+    """r06: stdout goes through a writer thread (the next chunk is formatted while the previous one is written); a pipe and a regular
+    file — also one that already holds bytes — must receive the same bytes, in query order; multi-line FASTA records in the input
+    (sequences joined, empty lines skipped: hunter.h:272-283).  DICEY_RESIDENT_LAYOUTS opens the index with the layouts a one-shot
+    process leaves out (DG_OPEN_COMPACT): same output."""
     g = cli_genome
     base = make_queries(29, g["text"], 3000, (18, 20, 23))
     qs = (base * 100)[:280000]
@@ -276,15 +277,14 @@ def test_output_to_a_regular_file_equals_the_piped_output(cli_genome):
     assert piped.stdout.count(b"\n") == len(qs)
     out = g["dir"] / "redirected.jsonl"
     with open(out, "wb") as o:
-        o.write(b"x" * 1234)            # the descriptor's offset is not page aligned
+        o.write(b"x" * 1234)
         o.flush()
         r = subprocess.run([DICEY, "hunt", "-g", g["fa"], str(fa)], stdout=o, stderr=subprocess.PIPE, env=env)
     assert r.returncode == 0, r.stderr[-1000:]
     data = open(out, "rb").read()
     assert data[:1234] == b"x" * 1234 and data[1234:] == piped.stdout
-    # the ordered writer on the same file (the switch that turns the mapping off)
     with open(out, "wb") as o:
-        r = subprocess.run([DICEY, "hunt", "-g", g["fa"], str(fa)], stdout=o, stderr=subprocess.PIPE, env=dict(env, DICEY_NO_MAPPED_OUTPUT="1"))
+        r = subprocess.run([DICEY, "hunt", "-g", g["fa"], str(fa)], stdout=o, stderr=subprocess.PIPE, env=dict(env, DICEY_RESIDENT_LAYOUTS="1"))
     assert r.returncode == 0 and open(out, "rb").read() == piped.stdout
     want = _oracle_json(g, [qs[i] for i in range(0, 21)], ["m%d" % i for i in range(0, 21)], distance=1).encode().split(b"\n")
     assert piped.stdout.split(b"\n")[:21] == want[:21]

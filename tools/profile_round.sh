@@ -33,5 +33,5 @@ if [ -x tools/microbench/gather_bench ]; then
   tools/microbench/gather_bench 4 256 1 200000 > $OUT/gather_dep.txt 2>&1
   (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_gather -o pmc --output-format csv -- $GRAFT_REPO_ROOT/tools/microbench/gather_bench 4 256 1 200000 > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_gather.err)
 fi
-rm -f /dev/shm/dicey_bench_*
+[ -n "${KEEP_INDEX:-}" ] || rm -f /dev/shm/dicey_bench_*
 du -sh $OUT

@@ -837,6 +837,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     DG_HIP(hipEventRecord(ix->ev[1], st));
     {
       SearchOut so;
+      WalkList kl{nullptr, nullptr, 0u};  // the strands of k_nkeep (k_walk_list)
       so.leaves = ws[WS_LEAF].as<Leaf>();
       so.shard_cap = shard_cap;
       so.ctr = ctr;
@@ -905,14 +906,18 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       // (k_walk_list; room for what the previous batch listed plus a quarter — a list that overflows repeats the batch)
       WalkList wl{nullptr, nullptr, 0u};
       u64 wgroups = ngrp;
-      if (items > 1 && (b.fastK || b.fast2K) && ngrp < 0x7FFFFFFFull) {
+      if ((b.fastK || b.fast2K) && ngrp < 0x7FFFFFFFull) {
         walk_cap = std::max<u64>(walk_cap, std::min<u64>(ngrp, (u64)ix->walk_hint + ix->walk_hint / 4 + 4096));
-        DG_TRY(ws[WS_WALK].reserve((walk_cap + 1) * 4));
+        DG_TRY(ws[WS_WALK].reserve(2 * (walk_cap + 1) * 4));
         wl.gid = ws[WS_WALK].as<u32>();
         wl.count = &ctr->pad_[10];
         wl.cap = (u32)walk_cap;
         wgroups = walk_cap;
-        hipLaunchKernelGGL(k_walk_list, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, b, ws[WS_WALK].as<u32>(), &ctr->pad_[10], wl.cap, ctr);
+        kl.gid = ws[WS_WALK].as<u32>() + walk_cap + 1;  // the strands of k_nkeep, behind the walker's groups
+        kl.count = &ctr->pad_[11];
+        kl.cap = (u32)walk_cap;
+        hipLaunchKernelGGL(k_walk_list, dim3(ceil_div(ngrp, TB)), dim3(TB), 0, st, b, ws[WS_WALK].as<u32>(), &ctr->pad_[10],
+                           ws[WS_WALK].as<u32>() + walk_cap + 1, &ctr->pad_[11], wl.cap, ctr);
       }
       const dim3 grid(ceil_div(wgroups * items, TB)), block(TB);
 #define DG_LAUNCH_SEARCH(IND, DD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<IND, DD>), grid, block, 0, st, ix->view, b, so, items, wl)
@@ -935,6 +940,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         const u32 per = indel ? (dmax_eff == 1 ? 5u : 25u) : (dmax_eff == 1 ? 4u : 16u);
         if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nres<true>), dim3(ceil_div(ngrp * per, TB)), dim3(TB), 0, st, ix->view, b, so, per);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nres<false>), dim3(ceil_div(ngrp * per, TB)), dim3(TB), 0, st, ix->view, b, so, per);
+        // ... and the strings of the listed bit-13 strands that keep their N: a lane per candidate edit
+        if (kl.gid) {
+          const u32 kper = 1u + (indel ? 8u : 3u) * std::min(maxlen, 32u);
+          if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nkeep<true>), dim3(ceil_div((u64)kl.cap * kper, TB)), dim3(TB), 0, st, ix->view, b, so, kl, kper);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nkeep<false>), dim3(ceil_div((u64)kl.cap * kper, TB)), dim3(TB), 0, st, ix->view, b, so, kl, kper);
+        }
       }
     }
     if (phase_events) DG_HIP(hipEventRecord(ix->ev[2], st));

@@ -195,8 +195,8 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
     // the whole budget — 5^d strings per strand (4^d in Hamming mode), searched by k_nres one lane per string; the walker skips
     // the strand.  (r05: the strand whose N sits inside the window zone walked 75-300 dependent reads in one lane.)
     // One N, one edit, the N within a character of an end (bit 13 on top): the strings that substitute or delete it are k_nres's all
-    // the same, and the walker is left with the strings that KEEP it — which occur only with the N as their first or last character
-    // (a text whose shortest run of N has two or more holds no single N between two bases), so it leaves every other path at once.
+    // the same; the strings that KEEP it occur only with the N as their first or last character (a text whose shortest run of N has
+    // two or more holds no single N between two bases) — k_nkeep searches those, a lane per edit of the rest.
     bool nres = false;
     if (bad != 0 && bad == d && d <= 2 && m <= 32 && gi.m && b.nrun_min && bad < b.nrun_min && (mode & 15u) == QM_KERNEL) {
       const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
@@ -206,9 +206,7 @@ DG_DEV PreparedQuery prepare_query(const Batch& b, u64 q, u32* grp_cnt, u32* nse
       else if (d == 1 && b.nrun_min >= 2) gi.d_win |= 4096u | 8192u;
       if (gi.d_win & 4096u) gi.qpk = strand ? pk_rv : pk_fw;  // (an N reads as some base: k_nres overwrites those positions)
     }
-    // (also for a strand whose N-keeping strings are the walker's: with its N at the left end the walk crosses every edit right of
-    //  it before it meets the N — ~145 strings; in window mode with the root split that is a lane per first edit)
-    if (!nres && bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {
+    if (!(gi.d_win & 4096u) && bad != 0 && m <= 32 && b.tabK && m >= b.tabK + d && gi.m) {  // (a strand of k_nres / k_nkeep does not walk)
       const u32 nm = ~(pm[0] | pm[1] | pm[2] | pm[3]) & (m == 32 ? ~0u : ((1u << m) - 1u));  // bit i: forward character i is an N
       const u32 lim = m - b.tabK - d;  // N's are allowed at string indices below this
       const bool ok = !strand ? (lim < 32 && (nm >> lim) == 0u) : (nm & (m - lim >= 32 ? ~0u : ((1u << (m - lim)) - 1u))) == 0u;
@@ -1666,25 +1664,30 @@ __global__ void __launch_bounds__(256, LONG2 ? 6 : 5) k_search2p(FmView f, Batch
 }
 
 
-// the groups the walker serves, listed (one atomic per wavefront); a list that does not fit raises bit 3 of Counters::overflow
-// and the batch is repeated with room
-__global__ void __launch_bounds__(256) k_walk_list(Batch b, u32* list, u32* count, u32 cap, Counters* ctr) {
+// the groups the walker serves, and the strands of k_nkeep, listed (one atomic per wavefront and list); a list that does not fit
+// raises bit 3 of Counters::overflow and the batch is repeated with room
+__global__ void __launch_bounds__(256) k_walk_list(Batch b, u32* list, u32* count, u32* klist, u32* kcount, u32 cap, Counters* ctr) {
   const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  bool need = false;
+  bool need = false, keep = false;
   if (g < 2 * b.nq) {
     const GidInfo gi = b.ginfo[g];
-    need = gi.m != 0 && !(gi.d_win & (512u | 1024u)) && (gi.d_win & (4096u | 8192u)) != 4096u;
+    need = gi.m != 0 && !(gi.d_win & (512u | 1024u | 4096u));
+    keep = gi.m != 0 && (gi.d_win & 8192u);
   }
-  const unsigned long long mk = __ballot(need);
-  if (!mk) return;
-  const u32 lane = threadIdx.x & 63, leader = (u32)__ffsll((long long)mk) - 1u;
-  u32 base = 0;
-  if (lane == leader) base = atomicAdd(count, (u32)__popcll(mk));
-  base = __shfl(base, (int)leader);
-  if (need) {
-    const u32 at = base + (u32)__popcll(mk & ((1ULL << lane) - 1));
-    if (at < cap) list[at] = (u32)g;
-    else atomicOr(&ctr->overflow, 8u);
+  const u32 lane = threadIdx.x & 63;
+  for (u32 which = 0; which < 2; ++which) {
+    const bool mine = which ? keep : need;
+    const unsigned long long mk = __ballot(mine);
+    if (!mk) continue;
+    const u32 leader = (u32)__ffsll((long long)mk) - 1u;
+    u32 base = 0;
+    if (lane == leader) base = atomicAdd(which ? kcount : count, (u32)__popcll(mk));
+    base = __shfl(base, (int)leader);
+    if (mine) {
+      const u32 at = base + (u32)__popcll(mk & ((1ULL << lane) - 1));
+      if (at < cap) (which ? klist : list)[at] = (u32)g;
+      else atomicOr(&ctr->overflow, 8u);
+    }
   }
 }
 // r06: wlist / wcount (may be null) — the groups the walker has work for, listed by k_walk_list: with the root split a launch over
@@ -1721,8 +1724,7 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
   gi.m = 0;
   gi.d_win = 0;
   if (active) gi = b.ginfo[gid];
-  if (gi.m == 0 || (gi.d_win & (512u | 1024u)) || (gi.d_win & (4096u | 8192u)) == 4096u) active = false;  // not searched, or taken by a flat kernel / k_nres
-  const bool konly = (gi.d_win & 8192u) != 0;  // only the strings that keep the strand's N (k_nres has the others)
+  if (gi.m == 0 || (gi.d_win & (512u | 1024u | 4096u))) active = false;  // not searched, or taken by a flat kernel / k_nres + k_nkeep
   if (active) {
     const u8* seq = (strand ? b.rv : b.fw) + b.qoff[q];
     const u32 m = gi.m;
@@ -1825,7 +1827,6 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
           }
           if (kind == OP_S && c == here) continue;           // a substitution changes the character (neighbors.h:63)
           if (kind == OP_I && L == 0 && pos == m) continue;   // nothing may be inserted after the last character (neighbors.h:51)
-          if (konly && here >= 4 && kind != OP_I) continue;   // the N substituted or deleted: k_nres's strings
           // N's still ahead (left of what this operation consumes) against the edits left behind it
           if (nprune && (u32)__popcll(nmask & ((1ULL << (kind == OP_I ? pos : pos - 1)) - 1)) > budget - 1) continue;
           Frame ch = F;
@@ -1844,9 +1845,6 @@ __global__ void __launch_bounds__(256) k_search(FmView f, Batch b, SearchOut o, 
         else {
           F.st &= ~15u;
           if (nprune && (here >= 4 || (u32)__popcll(nmask & ((1ULL << (pos - 1)) - 1)) > budget)) alive = false;  // a kept N, or more N's ahead than edits
-          // a kept N with a character behind it and more characters in front than the edits left could delete: a single N between
-          // two bases, which this text lacks
-          else if (konly && here >= 4 && pos - 1 > budget && !(F.lo == 0 && F.hi == (u32)f.n)) alive = false;
           else if (here < 4) alive = frame_emit(f, F, here, steps, lookups, probes);
           else {  // an N in the query (never in window mode): through the wavelet tree like sdsl
             bs_extend_sym(f, F.lo, F.hi, 'N', here);
@@ -1953,6 +1951,141 @@ __global__ void __launch_bounds__(256) k_nres(FmView f, Batch b, SearchOut o, u3
           lf->ops[0] = opr;
           lf->ops[1] = opl;
         } else lf->ops[0] = opl;
+      }
+    }
+  }
+  wave_add(&o.ctr->steps[blockIdx.x & (NSHARD - 1)], steps);
+  wave_add(&o.ctr->lookups[blockIdx.x & (NSHARD - 1)], lookups);
+  wave_add(&o.ctr->probes[blockIdx.x & (NSHARD - 1)], probes);
+}
+
+// r06: the strings of a bit-13 strand that KEEP its N (one N, one edit, the N within a character of an end): the query with one
+// edit elsewhere — or none in Hamming mode — such that the N is the string's first or last character; one lane per candidate edit
+// (per = 1 + 8 m in edit mode, 1 + 3 m in Hamming mode), over the strands k_walk_list listed.  N last: the search starts from the
+// N's own interval and dies within a few steps almost everywhere; N first: the rest is searched like any N-free string and only
+// what occurs is extended by the N (through the wavelet tree, like sdsl).  An occurring string becomes a leaf whose operation is
+// the edit (neighbors.h:57-78; the N itself stays in the query the leaf reader applies it to).
+template <bool INDEL>
+__global__ void __launch_bounds__(256) k_nkeep(FmView f, Batch b, SearchOut o, WalkList wl, u32 per) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 slot = t / per;
+  const u32 e = (u32)(t - slot * per);  // 0: no edit; 1 + 8 i + k (edit mode): k = 0 delete q[i], 1-4 substitute, 5-8 insert in front of q[i]
+  const u32 nl = *wl.count < wl.cap ? *wl.count : wl.cap;
+  u64 steps = 0, lookups = 0, probes = 0;
+  if (slot < nl) {
+    const u32 gid = wl.gid[slot];
+    const GidInfo gi = b.ginfo[gid];
+    const u32 m = gi.m;
+    const uint4 pq = b.gpeq[gid];
+    const u32 nm = ~(pq.x | pq.y | pq.z | pq.w) & (m == 32 ? ~0u : ((1u << m) - 1u));
+    const u32 iN = (u32)__builtin_ctz(nm);
+    constexpr u32 PER_POS = INDEL ? 8u : 3u;
+    bool ok = m != 0 && (gi.d_win & 8192u) != 0;
+    u32 kind = 3u /* none */, i = 0, c = 0;
+    if (e) {
+      i = (e - 1) / PER_POS;
+      const u32 k = (e - 1) % PER_POS;
+      if (i >= m) ok = false;
+      const u32 qi = ok ? (u32)(gi.qpk >> (2 * (m - 1 - i))) & 3u : 0u;
+      if (INDEL) {
+        if (k == 0) kind = OP_D;
+        else if (k <= 4) {
+          kind = OP_S;
+          c = k - 1;
+        } else {
+          kind = OP_I;
+          c = k - 5;
+        }
+      } else {  // the three other bases
+        kind = OP_S;
+        c = (qi + 1 + k) & 3u;
+      }
+      if (i == iN && kind != OP_I) ok = false;          // the N substituted or deleted: k_nres's strings
+      if (kind == OP_S && i != iN && c == qi) ok = false;  // a substitution changes the character (neighbors.h:63)
+    } else if (INDEL) ok = false;  // edit mode: the unedited string contains the string without its N, which then occurs too
+    // the string, left to right; where the N ends up
+    u64 s = 0;  // the characters other than the N, 2 bits each, first character on top
+    u32 len = 0, posN = 0;
+    if (ok) {
+      for (u32 j = 0; j < m; ++j) {
+        if (kind == OP_I && j == i) {
+          s = (s << 2) | c;
+          ++len;
+        }
+        if (j == iN) {
+          posN = len;
+          ++len;
+          s <<= 2;  // (a placeholder: never read)
+          continue;
+        }
+        if (kind == OP_D && j == i) continue;
+        s = (s << 2) | ((kind == OP_S && j == i) ? c : (u32)(gi.qpk >> (2 * (m - 1 - j))) & 3u);
+        ++len;
+      }
+      if (posN != 0 && posN != len - 1) ok = false;  // a single N between two bases: not in this text
+      if (len < 2) ok = false;
+    }
+    if (ok) {
+      auto at = [&](u32 j) -> u32 { return (u32)(s >> (2 * (len - 1 - j))) & 3u; };
+      u32 lo = 0, hi = (u32)f.n;
+      if (posN == len - 1) {  // N last: from the N's interval, then the rest right to left
+        bs_extend_sym(f, lo, hi, 'N', 4u);
+        ++steps;
+        for (u32 k = len - 1; k > 0 && lo < hi; --k) {
+          bs_extend_code(f, lo, hi, at(k - 1));
+          ++steps;
+        }
+      } else {  // N first: the N-free rest s[1 .. len) like an explicit pattern, then the N
+        const u32 L2 = len - 1;
+        const u64 rest = L2 >= 32 ? s : (s & ((1ULL << (2 * L2)) - 1));
+        const u32 K = f.K, K2 = f.kf2.nr ? f.kf2.k : 0u, W = K2 > K ? K2 : K;
+        u32 k = L2;
+        if (K && L2 >= W && W <= 32) {
+          bool alive = true;
+          const u64 tail = rest & (W >= 32 ? ~0ULL : ((1ULL << (2 * W)) - 1));
+          if (K2) {
+            ++probes;
+            alive = kf_present(f.kf2, tail & ((1ULL << (2 * K2)) - 1), 0u);
+            if (alive && L2 > K2) {
+              ++probes;
+              alive = kf_present(f.kf2, (rest >> (2 * (L2 - K2))) & ((1ULL << (2 * K2)) - 1), K2 - 1);
+            }
+          } else if (f.kf.nr) {
+            ++probes;
+            alive = kf_present(f.kf, tail & ((1ULL << (2 * K)) - 1), 0u);
+          }
+          if (alive) {
+            const KtabEntry iv = ktab_entry(f, tail & ((1ULL << (2 * K)) - 1));
+            ++lookups;
+            lo = iv.lo;
+            hi = iv.hi;
+          } else lo = hi = 0;
+          k = L2 - K;
+        }
+        for (; k > 0 && lo < hi; --k) {  // characters 1 .. of the string: at(j) with j >= 1
+          bs_extend_code(f, lo, hi, at(k));
+          ++steps;
+        }
+        if (lo < hi) {
+          bs_extend_sym(f, lo, hi, 'N', 4u);
+          ++steps;
+        }
+      }
+      if (lo < hi) {
+        const u32 shard = blockIdx.x & (NSHARD - 1);
+        const u32 a = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
+        const u32 sl = atomicAdd(o.grp_cnt + gid, 1u);
+        if (a < o.shard_cap) {
+          Leaf* lf = o.leaves + (u64)shard * o.shard_cap + a;
+          lf->qs = gid;
+          lf->slot = sl;
+          lf->lo = lo;
+          lf->hi = hi;
+          lf->nops = e ? 1u : 0u;
+#pragma unroll
+          for (int x = 0; x < (int)DMAX; ++x) lf->ops[x] = 0u;
+          if (e) lf->ops[0] = ((kind == OP_I ? i : i + 1u) << 4) | (kind << 2) | (kind == OP_D ? 0u : c);  // (LeafReader: index + 1 for S / D, index for I)
+        }
       }
     }
   }

@@ -85,7 +85,7 @@ DG_DEV void batch_finish(Counters* ctr, const u64* nhits, Summary* host_out) {
     host_out->n_generic = ctr->pad_[6];
     host_out->n_nwin = ctr->pad_[7];
     host_out->n_short2 = ctr->pad_[9];
-    host_out->n_walk = ctr->pad_[10];
+    host_out->n_walk = ctr->pad_[10] > ctr->pad_[11] ? ctr->pad_[10] : ctr->pad_[11];  // (the longer of the two lists: they share a capacity)
 #ifdef DG_TOPK_PROFILE
     for (int i = 0; i < 24; ++i) host_out->prof[i] = ctr->prof[i];
 #endif

@@ -199,7 +199,7 @@ def test_hits_of_repeat_rich_strings_carry_their_context(tmp_path, monkeypatch, 
         for kw in (dict(distance=1, max_locations=1000), dict(distance=0, max_locations=1000), dict(distance=1, max_locations=100),
                    dict(distance=1, hamming=True, max_locations=1000)):
             _compare(ix, orc, g, qs, **kw)
-        short = [q for q in qs if len(q) <= 22]
+        short = [q for q in qs if len(q) <= 22][::3]   # (the checker needs a third of a second for each of these)
         O.fast_neighbors(True)
         try:
             _compare(ix, orc, g, short, distance=2, max_locations=300)

@@ -556,6 +556,8 @@ int hunter(int argc, char** argv) {
   std::deque<std::string> owned;     // sequences that span several lines, joined
   bool bad_fasta = false;
   const double t_read0 = now_ms();
+  // (r06: on a thread of its own beside the index open — 0.3 s for a 10 M-record file; joined before anything looks at the queries)
+  std::thread reader([&]() {
   if (is_regular(c.input)) {
     if (!is_fasta(c.input)) bad_fasta = true;
     else {
@@ -605,6 +607,11 @@ int hunter(int argc, char** argv) {
     }
   } else queries.push_back(Query{std::string_view(), std::string_view(c.input)});
   if (timing_on()) std::fprintf(stderr, "dicey timing: %-28s %8.1f ms\n", "input read + records", now_ms() - t_read0);
+  });
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } reader_joiner{reader};
 
   // the K-mer jump table (up to 137 GB, ~1.5 s to derive) only pays off for large batches: a literal sequence or a
   // small FASTA is answered from the Occ blocks alone
@@ -626,7 +633,10 @@ int hunter(int argc, char** argv) {
     const int one = std::getenv("DICEY_DEVICE") ? device_from_env() : (std::getenv("DICEY_RANK") ? std::atoi(std::getenv("DICEY_RANK")) : 0);
     devices.assign(1, one);
   }
-  if (devices.size() > queries.size()) devices.resize(std::max<size_t>(1, queries.size()));
+  if (devices.size() > 1) {  // the shard plan needs the count
+    reader.join();
+    if (devices.size() > queries.size()) devices.resize(std::max<size_t>(1, queries.size()));
+  }
   const size_t G = devices.size();
   std::vector<dg_index*> handles(G, nullptr);
   std::vector<std::string> open_err(G);
@@ -638,9 +648,12 @@ int hunter(int argc, char** argv) {
       });
     for (auto& t : pool) t.join();
   }
+  if (reader.joinable()) reader.join();
   auto close_all = [&]() {
+    const double t_close0 = now_ms();
     for (dg_index* h : handles)
       if (h) dg_index_close(h);
+    if (timing_on()) std::fprintf(stderr, "dicey timing: %-28s %8.1f ms\n", "index close", now_ms() - t_close0);
   };
   for (size_t g = 0; g < G; ++g)
     if (!handles[g]) {
@@ -1454,7 +1467,12 @@ int main(int argc, char** argv) {
     display_usage();
     return 0;
   }
-  if (cmd == "hunt") return hunter(argc - 1, argv + 1);
+  if (cmd == "hunt") {
+    const double t_main0 = now_ms();
+    const int rc = hunter(argc - 1, argv + 1);
+    if (timing_on()) std::fprintf(stderr, "dicey timing: %-28s %8.1f ms\n", "hunt, entry to return", now_ms() - t_main0);
+    return rc;
+  }
   if (cmd == "index") return indexer(argc - 1, argv + 1);
   if (cmd == "search") return silica(argc - 1, argv + 1);
   if (cmd == "padlock") return padlock_main(argc - 1, argv + 1);

@@ -1707,7 +1707,7 @@ def run_extra_configs(a, fm9):
     return res
 
 
-def cli_end_to_end(fm9, meta, queries, distance, oracle=None, seqlen=None, bytes_per_query=700):
+def cli_end_to_end(fm9, meta, queries, distance, oracle=None, seqlen=None, bytes_per_query=700, extra_env=None):
     """The process seam: `dicey hunt -g <genome> <queries.fa>` on the same queries, wall clock of the whole process (index
     open + derivation, search, JSON for every query).  hunt reads only <genome>.fai and the .fm9 next to the genome.
     queries: list of bytes, or a uint8 array [n, m] (the large runs).  oracle (large runs): three slices of 100 lines of THIS run's
@@ -1765,7 +1765,7 @@ def cli_end_to_end(fm9, meta, queries, distance, oracle=None, seqlen=None, bytes
         t = time.time()
         with open(outp, "wb") as o:
             r = subprocess.run([binary, "hunt", "-d", str(distance), "-g", base + ".gz", qf], stdout=o, stderr=subprocess.PIPE, timeout=900,
-                               env=dict(os.environ, DICEY_TIMING="1"))
+                               env=dict(os.environ, DICEY_TIMING="1", **(extra_env or {})))
         dt = time.time() - t
         out_bytes = os.path.getsize(outp) if outp != "/dev/null" else None
         lines = 0

@@ -71,11 +71,12 @@ def _pack(items: Sequence[bytes]):
 class FmIndex:
     """The FM-index `dicey index` wrote, resident in one GPU's HBM."""
 
-    def __init__(self, fm9_path: str, device: int = 0, selfcheck: bool = True, kmer_table: bool = True, big_table: bool = False, _lib=None):
+    def __init__(self, fm9_path: str, device: int = 0, selfcheck: bool = True, kmer_table: bool = True, big_table: bool = False, compact: bool = False,
+                 pre5: bool = True, _lib=None):
         self._L = _lib or _capi.load()
         self._h = C.c_void_p()
         flags = (0 if selfcheck else _capi.DG_OPEN_NO_SELFCHECK) | (0 if kmer_table else _capi.DG_OPEN_NO_KMER_TABLE) | \
-            (_capi.DG_OPEN_BIG_TABLE if big_table else 0)
+            (_capi.DG_OPEN_BIG_TABLE if big_table else 0) | (_capi.DG_OPEN_COMPACT if compact else 0) | (0 if pre5 else _capi.DG_OPEN_NO_PRE5)
         _capi.check(self._L, self._L.dg_index_open(fm9_path.encode(), device, flags, C.byref(self._h)))
 
     def share(self) -> "FmIndex":

@@ -13,6 +13,7 @@ DG_OK = 0
 DG_OPEN_NO_SELFCHECK = 1
 DG_OPEN_NO_KMER_TABLE = 2
 DG_OPEN_COMPACT = 4
+DG_OPEN_NO_PRE5 = 16
 DG_OPEN_BIG_TABLE = 8
 DG_Q_TOO_SHORT, DG_Q_DIST_ADJUSTED, DG_Q_MAX_MATCHES, DG_Q_NBHD_EXCEEDED = 1, 2, 4, 8
 DG_HUNT_COMPACT = 1

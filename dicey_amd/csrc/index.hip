@@ -711,7 +711,7 @@ static int derive_layouts(dg_index* ix, const SdslCsa& c, u32 flags) {
       pc.lap("long presence filter");
     }
     // the characters in front of every suffix (2 n bytes): built with the table, i.e. for handles that search batches
-    if (!exp_env("DICEY_NO_PRE5")) {
+    if (!(flags & DG_OPEN_NO_PRE5) && !exp_env("DICEY_NO_PRE5")) {
       u16* pre = nullptr;
       if (big_alloc((void**)&pre, n * 2 + 64, ix->stream) == hipSuccess) {
         ix->owned.push_back(pre);

@@ -62,6 +62,10 @@ typedef struct dg_index dg_index;
                                   * array with context records and its prefix levels (40 GB of HBM on a 3.1 Gb genome, 0.36 s to derive, and as much again for
                                   * the driver to wipe at exit); hits of repeat-rich strings then read their context from the text and walk the block minima,
                                   * results are the same.  (ABI 4-6: accepted, no effect.)  `dicey hunt|search|padlock` pass it. */
+#define DG_OPEN_NO_PRE5 16u      /* ABI 7: do not derive the preceding-characters array (6.2 GB, 0.19 s on a 3.1 Gb genome): narrow table intervals are then
+                                  * extended character by character through the Occ blocks — the distance-1 search kernel takes a quarter longer per
+                                  * batch (0.146 -> 0.183 ms per 100 000 20-mers; distance 2: + 5 %), which a process that answers a few million
+                                  * queries and exits never earns back.  Same results.  `dicey hunt` passes it unless the input is very large. */
 #define DG_OPEN_BIG_TABLE 8u     /* table of order ceil(log4 n) + 1 when the device has room (137 GB instead of 34 GB on a 3.1 Gb genome):
                                     the distance-1 search kernel gains ~5 % (0.175 -> 0.166 ms per 100 000 20-mers), the open takes longer
                                     and the process holds 199 GB instead of 90 GB — for resident servers with HBM to spare */

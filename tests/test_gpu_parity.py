@@ -607,3 +607,15 @@ def test_decreasing_offsets_fail_loudly_even_with_a_length_bound(gpu_small, smal
     assert [[(h.score, h.chr, h.start, h.strand) for h in q.hits] for q in gpu_small.hunt(qs, g["seqlen"], distance=1, max_query_len=22).queries] == want
     with pytest.raises(Exception):   # a bound that does not hold is refused on the host, before anything is uploaded
         gpu_small.hunt(qs, g["seqlen"], distance=1, max_query_len=19)
+
+
+def test_one_shot_open_flags_answer_the_same(small_genome):
+    """DG_OPEN_COMPACT (no suffix-array records with context, no prefix levels) and DG_OPEN_NO_PRE5 (narrow table intervals extended
+    through the Occ blocks instead of filtered by the preceding-characters array) — what `dicey hunt` passes for one input — against
+    the oracle: distance 1 and 2, edit and Hamming, and the footprint really is smaller."""
+    import dicey_amd
+    with dicey_amd.FmIndex(small_genome["fm9"], device=0) as full, dicey_amd.FmIndex(small_genome["fm9"], device=0, compact=True, pre5=False) as lean:
+        assert lean.stats()["hbm_bytes"] < full.stats()["hbm_bytes"] - 2 * len(small_genome["text"])
+        for kw, nq, lens in [(dict(distance=1), 600, (20, 18, 25)), (dict(distance=2), 120, (20,)), (dict(distance=1, hamming=True), 200, (20,)),
+                             (dict(distance=1, max_locations=3), 200, (12, 16, 17))]:
+            test_hunt_hits_equal_oracle_push_order(lean, small_genome, kw, nq, lens)

@@ -1,6 +1,6 @@
 """GPU box: `dicey hunt` on a 10 M-query FASTA against the bench genome, three runs, every phase the binary reports (DICEY_TIMING).
     python bench.py --keep-index --steps 2 --warmup 1 --no-extra-configs --no-cpu-baseline --parity-queries 0 --cli-queries 0
-    python tools/cli_10m.py /dev/shm/dicey_bench_*.fm9 [n_queries] [runs]"""
+    python tools/cli_10m.py /dev/shm/dicey_bench_*.fm9 [n_queries] [runs] [NAME=value ...]"""
 import json
 import os
 import sys
@@ -20,8 +20,9 @@ big = np.concatenate([bench.synth_query_batch(text, 100000, 20, seed=5000 + i) f
 del text
 torch.cuda.empty_cache()
 meta = {"lens": lens}
+extra = dict(kv.split("=", 1) for kv in sys.argv[4:])  # NAME=value ... for the binary's environment only
 for r in range(runs):
-    res = bench.cli_end_to_end(fm9, meta, big, 1)
+    res = bench.cli_end_to_end(fm9, meta, big, 1, extra_env=extra)
     ph = res.pop("index_open_phases_ms", {})
     res.pop("note", None)
     print(json.dumps(res))

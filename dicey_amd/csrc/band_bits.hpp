@@ -51,9 +51,55 @@ struct QMasks {
 DG_BB u64 qmask_of(const QMasks& m, u32 byte) {
   return byte == 'A' ? m.a : byte == 'C' ? m.c : byte == 'G' ? m.g : byte == 'T' ? m.t : byte == 'N' ? m.n : 0ULL;
 }
+// r06: a hit that brings along the string it spells (2 bits per character, the FIRST character in the highest pair) and the one
+// character either side of it — all A/C/G/T — needs no text line: the window's bytes are spread out of those codes.
+struct KeyWindow {
+  u64 key;      // the kept string (Sel::key)
+  u32 pre, post;  // codes of T[loc - 1] / T[loc + mlen] (0..3); used when d >= 1
+};
+constexpr int BAND_GW = (32 + 3 * 2 + 7) / 8 + 1;  // 38 bytes at any byte offset
+DG_BB u64 band_bytes_of_codes8(u32 codes16) {  // eight 2-bit codes (the first in the lowest pair) -> eight ASCII bytes
+  u64 x = codes16;
+  x = (x | (x << 24)) & 0x000000FF000000FFULL;
+  x = (x | (x << 12)) & 0x000F000F000F000FULL;
+  x = (x | (x << 6)) & 0x0303030303030303ULL;
+  const u64 b0 = x & 0x0101010101010101ULL, b1 = (x >> 1) & 0x0101010101010101ULL;
+  return 0x4141414141414141ULL + 2 * b0 + 6 * b1 + 11 * (b0 & b1);  // A 0x41, C 0x43, G 0x47, T 0x54
+}
+// the maximal window [loc - pre, loc + mlen + post) of a key hit with mlen + 2 <= 24 characters, d <= 1, as band_align_bits reads it
+DG_BB void band_window_from_key(const KeyWindow& kw, u32 mlen, u32 d, u64 (&gw)[BAND_GW], u64& pre, u64& post) {
+  pre = post = d ? 1u : 0u;
+  u64 r = kw.key << (64 - 2 * mlen);  // first character in the top pair
+  // reverse the order of the pairs: character i to bits 2i
+  r = ((r >> 2) & 0x3333333333333333ULL) | ((r & 0x3333333333333333ULL) << 2);
+  r = ((r >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((r & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  r = ((r >> 8) & 0x00FF00FF00FF00FFULL) | ((r & 0x00FF00FF00FF00FFULL) << 8);
+  r = ((r >> 16) & 0x0000FFFF0000FFFFULL) | ((r & 0x0000FFFF0000FFFFULL) << 16);
+  r = (r >> 32) | (r << 32);
+  u64 s = r;
+  if (d) s = (u64)(kw.pre & 3u) | (r << 2) | ((u64)(kw.post & 3u) << (2 * (mlen + 1)));
+#pragma unroll
+  for (int i = 0; i < BAND_GW; ++i) gw[i] = i < 3 ? band_bytes_of_codes8((u32)(s >> (16 * i)) & 0xFFFFu) : 0ULL;
+}
+DG_BB void band_window_from_text(const u8* text, u64 text_n, u64 loc, u32 mlen, u32 d, u64 (&gw)[BAND_GW], u64& pre, u64& post) {
+  constexpr int GW = BAND_GW;
+  pre = post = d;
+  if (pre > loc) pre = loc;
+  if (loc + mlen + post > text_n) post = text_n - loc - mlen;
+  const u64 g0 = loc - pre, a0 = g0 & ~7ULL;
+  const u32 sh = (u32)(g0 & 7) * 8;
+  const u64* src = reinterpret_cast<const u64*>(text + a0);
+  u64 w[GW + 1];
+#pragma unroll
+  for (int i = 0; i <= GW; ++i) w[i] = (u32)(8 * i) < (u32)(g0 & 7) + (u32)(pre + mlen + post) ? src[i] : 0ULL;
+#pragma unroll
+  for (int i = 0; i < GW; ++i) gw[i] = sh ? (w[i] >> sh) | (w[i + 1] << (64 - sh)) : w[i];
+}
+// from_key: the window comes from the hit's own codes (band_window_from_key), else from the text
 template <int WB, typename TR, int TRS>
 DG_BB AlnRes band_align_bits(const u8* text, u64 text_n, bool indel, u64 loc, u32 mlen, u32 n, u32 d, PosMasks peq, TR* tr /* [row * TRS] */,
-                             u64* win /* [6 words * TRS]: the window's bytes for reads at computed offsets */, u32& fault) {
+                             u64* win /* [6 words * TRS]: the window's bytes for reads at computed offsets */, u32& fault,
+                             const bool from_key = false, const KeyWindow kw = KeyWindow{0ULL, 0u, 0u}) {
   constexpr u32 NP = WB <= 7 ? 2u : 3u;   // planes = largest distance served + 1
   constexpr u32 WBM = (1u << WB) - 1u, TOP = 1u << (WB - 1);
   constexpr u32 VSH = WB <= 8 ? 8u : 16u;  // the vertical mask's place in a trace word
@@ -63,21 +109,11 @@ DG_BB AlnRes band_align_bits(const u8* text, u64 text_n, bool indel, u64 loc, u3
     fault = 1;
     d = NP - 1;
   }
-  u64 pre = d, post = d;
-  if (pre > loc) pre = loc;
-  if (loc + mlen + post > text_n) post = text_n - loc - mlen;
-  constexpr int GW = (32 + 3 * 2 + 7) / 8 + 1;  // 38 bytes at any byte offset
+  u64 pre, post;
+  constexpr int GW = BAND_GW;
   u64 gw[GW];
-  {
-    const u64 g0 = loc - pre, a0 = g0 & ~7ULL;
-    const u32 sh = (u32)(g0 & 7) * 8;
-    const u64* src = reinterpret_cast<const u64*>(text + a0);
-    u64 w[GW + 1];
-#pragma unroll
-    for (int i = 0; i <= GW; ++i) w[i] = (u32)(8 * i) < (u32)(g0 & 7) + (u32)(pre + mlen + post) ? src[i] : 0ULL;
-#pragma unroll
-    for (int i = 0; i < GW; ++i) gw[i] = sh ? (w[i] >> sh) | (w[i + 1] << (64 - sh)) : w[i];
-  }
+  if (from_key && d <= 1 && mlen + 2 <= 24) band_window_from_key(kw, mlen, d, gw, pre, post);
+  else band_window_from_text(text, text_n, loc, mlen, d, gw, pre, post);
   // bytes at computed offsets come from the copy in `win` (LDS on the device): indexing the register array by a computed
   // offset sends it to scratch memory (r04b ISA: 96 bytes of scratch per lane, loads on the traceback's critical path)
 #pragma unroll

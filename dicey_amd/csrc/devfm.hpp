@@ -152,6 +152,7 @@ static constexpr u32 SAX_POST_OFF = 16, SAX_POST_N = 13, SAX_ESCAPE = 0x80000000
 // string's length, bit 31 "context valid", bits 20-21 / 22-23 the codes of T[pos-1] / T[pos-2], bits 24-25 / 26-27 of T[pos+len] /
 // T[pos+len+1] (0..3 = A,C,G,T).  Valid only for strings whose two following characters lie inside the context word's window.
 static constexpr u32 SEED_LEN_MASK = 0xFFFFFu, SEED_CTX_VALID = 0x80000000u;
+static constexpr u32 SEED_KEY_VALID = 0x40000000u;  // r06, set by k_locate: the hit's string lies in FlatSel::key at the seed's slot, its context holds ONE character either side
 __host__ __device__ inline u32 seed_len_with_ctx(u32 len, u32 ctx) {
   if ((ctx & SAX_ESCAPE) || len < SAX_POST_OFF || len + 2 > SAX_POST_OFF + SAX_POST_N) return len;
   const u32 post = (ctx >> (4 + 2 * (len - SAX_POST_OFF))) & 15u;

@@ -12,7 +12,7 @@
 // derived layouts (a device short of memory) ... — so that the GPU suite can hold every path against the checker on the same
 // small inputs (tests/test_gpu_parity.py SWITCHES), and a few measurement aids whose results are deliberately wrong (DICEY_EXP).
 //   hunt.hip      DICEY_NO_BAND_VERIFY DICEY_CAP_HOST DICEY_NO_FUSED_SELECT DICEY_NO_FUSED_SELECT2 DICEY_NO_PREP_FUSION DICEY_NO_PRE5_D2
-//                 DICEY_NO_FLAT_HAMMING2 DICEY_NO_N_WINDOW DICEY_NO_LONG2 DICEY_DEBUG_CAPS DICEY_FUSED_LCAP DICEY_VERIFY_CH DICEY_DUMP_JOBS DICEY_EXP
+//                 DICEY_NO_FLAT_HAMMING2 DICEY_NO_N_WINDOW DICEY_NO_LONG2 DICEY_NO_DIRECT_CTX DICEY_DEBUG_CAPS DICEY_FUSED_LCAP DICEY_VERIFY_CH DICEY_DUMP_JOBS DICEY_EXP
 //   index.hip     DICEY_NO_KMER_FILTER DICEY_NO_NRUN_PRUNE DICEY_NO_PRE5 DICEY_NO_SAX DICEY_NO_PLV DICEY_NO_SA_MINIMA DICEY_EXP_PRIO
 //   search.hip / thal_api.hip   DICEY_NO_LDS_TABLES DICEY_NO_WAVE_THAL DICEY_DEBUG_THAL_REDO DICEY_DEBUG_DUMP_RAW
 #pragma once

@@ -795,6 +795,8 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
     const u64 flat_slots = (u64)NSHARD * flat_cap;
     const bool generic_on = !fused || ix->generic_hint || nxs > 0 || force_generic;
     bool jobs_on = false, walker_on = true, with_ctx_hits = false;
+    u32 direct_ctx = 0;
+    bool keys_on = false;  // this attempt's k_search1s wrote the kept strings' keys (FlatSel::key)
     DG_TRY(ws[WS_LEAF].reserve(leaf_slots * sizeof(Leaf)));
     DG_TRY(ws[WS_LEAFG].reserve((leaf_slots + 1) * (sizeof(Leaf) > sizeof(PLeaf) ? sizeof(Leaf) : sizeof(PLeaf))));
     DG_TRY(ws[WS_SEL].reserve((flat_slots + leaf_slots + 1) * sizeof(Sel)));
@@ -851,6 +853,14 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
           fs.cap = flat_cap;
           fs.selbase = selbase;
           fs.nsel = nsel;
+          // r06: strings with one occurrence leave with their characters when the locate / verify stages of this batch can use them
+          // (direct_ctx below: the records are resident, distance <= 1, banded verify)
+          fs.key = nullptr;
+          if (!sx && !group_counts && band_verify && ix->view.sax && indel && dmax_eff <= 1 && !sw.no_direct_ctx) {
+            DG_TRY(ws[WS_SELKEY].reserve((flat_slots + 1) * 8));
+            fs.key = ws[WS_SELKEY].as<u64>();
+            keys_on = true;
+          }
           const dim3 g1(ceil_div(ngrp, gpw)), b1(256);
           // LDS list of a workgroup: 256 entries unless the previous batch of this handle averaged more than 48 occurring strings
           // per workgroup (repeat-bearing genomes), then 512; a workgroup whose strings do not fit hands its groups to the generic
@@ -883,6 +893,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         fs.cap = flat_cap;
         fs.selbase = selbase;
         fs.nsel = nsel;
+        fs.key = nullptr;
         // (tests: DICEY_FUSED_LCAP lowers the list's capacity so that ordinary groups exercise the hand-over to the generic select kernels)
         const u32 lcap2 = sw.fused_lcap ? std::max<u32>(1u, std::min<u32>(FUSED2_LCAP, sw.fused_lcap)) : FUSED2_LCAP;
         const u32 ham2 = (indel ? 0u : 1u) | (sw.exp_bits << 8);  // (DICEY_EXP: k_search2p's measurement switches)
@@ -1015,12 +1026,15 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       // k_verify_memo — the only reader that knows the encoding (HitSeed::len, devfm.hpp)
       const u32 with_ctx = (!sx && !group_counts && band_verify && ix->view.sax) ? 1u : 0u;
       with_ctx_hits = with_ctx != 0;
+      // r06: the same for a string with ONE occurrence that k_locate serves itself, when the search kernel knew the character in front
+      // of it (Sel::key / SEL_CTX_VALID): one context character either side, i.e. batches at distance <= 1 (DICEY_NO_DIRECT_CTX: tests)
+      direct_ctx = (with_ctx && keys_on && ix->view.K >= SAX_POST_OFF && ix->view.K + 1 <= SAX_POST_OFF + SAX_POST_N) ? 1u : 0u;
       // the record that shares a kept string's slot names its group: the packed leaf (qs behind 28 bytes) or the grouped leaf (qs first)
       const u8* slot_qs = packed ? (const u8*)ws[WS_LEAFG].p + offsetof(PLeaf, qs) : (const u8*)ws[WS_LEAFG].p + offsetof(Leaf, qs);
       const u32 slot_stride = packed ? (u32)sizeof(PLeaf) : (u32)sizeof(Leaf);
       hipLaunchKernelGGL(k_locate, dim3(ceil_div(flat_slots + (generic_on ? leaf_slots : 0), TB)), dim3(TB), 0, st, ix->view, (const Sel*)sel_all, slot_qs,
                          slot_stride, (const u64*)grp_off, (const u32*)nsel, ngrp, (const u64*)hit_off, ws[WS_SEEDS].as<HitSeed>(), ctr, hit_cap, lj,
-                         flat_slots, flat_cap, (u32)generic_on, (u32)jobs_on);
+                         flat_slots, flat_cap, (u32)generic_on, (u32)jobs_on, direct_ctx);
       // The job kernels (strings of more than 16 occurrences) are launched when the previous batch of this handle queued any job;
       // k_locate queues and counts whether or not they run, and a batch that had jobs after one that had none is repeated with
       // them (the same device as for capacity guesses).  Uniform batches on a genome without repeats never launch them.
@@ -1058,6 +1072,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       va.ops = ws[WS_OPS].as<u32>();
       va.ops_per_hit = ops_per_hit;
       va.chits = nullptr;
+      va.selkey = direct_ctx ? (const u64*)ws[WS_SELKEY].p : nullptr;
       va.debug = (sw.exp_bits >> 4) & 3u;  // (DICEY_EXP bits 4-5, measurement aid: verify without its alignments / without the hits' context)
       const u32 cells = (maxlen + 3 * dmax_eff + 1) * (maxlen + 1);
       const u32 VT = 128;
@@ -1391,6 +1406,7 @@ dg_switches dg_switches::read() {
   w.no_flat_ham2 = exp_env("DICEY_NO_FLAT_HAMMING2") != nullptr;
   w.no_nwin = exp_env("DICEY_NO_N_WINDOW") != nullptr;
   w.no_long2 = exp_env("DICEY_NO_LONG2") != nullptr;
+  w.no_direct_ctx = exp_env("DICEY_NO_DIRECT_CTX") != nullptr;
   if (const char* e = exp_env("DICEY_DEBUG_CAPS")) {
     w.debug_caps = true;
     w.debug_caps_s = e;

@@ -106,7 +106,7 @@ struct HitSeed {  // 16 bytes, read as one uint4
   u32 sel;  // slot of the kept string (Sel) the hit stems from: hits of one slot share query, strand and string
 };
 
-enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO, WS_XS, WS_OPS, WS_PACK, WS_CAP, WS_WALK };
+enum WsSlot { WS_QB = 0, WS_QOFF, WS_FW, WS_RV, WS_QSEQ, WS_QMETA, WS_LEAF, WS_LEAFG, WS_SEL, WS_GRP, WS_MISC, WS_SEEDS, WS_HITS, WS_ALN, WS_CUM, WS_SCR, WS_JOBS, WS_DP, WS_PRIM, WS_GINFO, WS_XS, WS_OPS, WS_PACK, WS_CAP, WS_WALK, WS_SELKEY };
 
 // one located hit after the `dicey search` stage
 struct SiteRaw {

@@ -90,7 +90,7 @@ DG_DEV void locate_in_registers(const u32* sa, u32 occs, u32 take, HitSeed* out,
 // each naming its group); slots behind it: the generic path's (grp_off based; only when generic_on).
 __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const u8* slot_qs, u32 slot_stride, const u64* grp_off, const u32* nsel,
                                                 u64 ngroups, const u64* hit_off, HitSeed* seeds, Counters* ctr, u64 hit_cap, LocJobs jobs,
-                                                u64 flat_slots, u32 flat_cap, u32 generic_on, u32 jobs_on) {
+                                                u64 flat_slots, u32 flat_cap, u32 generic_on, u32 jobs_on, u32 direct_ctx) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ctr->overflow || hit_off[ngroups >> 1] > hit_cap) return;
   u64 reads = 0;
@@ -119,7 +119,17 @@ __global__ void __launch_bounds__(256) k_locate(FmView f, const Sel* sel, const 
       const u32 fmask = sel_filtered(S) ? sel_mask(S) : 0xFFFFFFFFu, back = sel_filtered(S) ? sel_pre(S) : 0u, slen = sel_strlen(S);
       const u64 out0 = hit_off[g >> 1] + S.hbase;
       HitSeed* out = seeds + out0;
-      if (occs <= 4) {
+      if (direct_ctx && (S.len & SEL_CTX_VALID) && sel_filtered(S)) {
+        // r06: ONE occurrence, and the search kernel knew the character in front of it (Sel): its record brings the position and the
+        // character behind the string (the table window's suffix starts `back` characters into the string and ends with it, so that
+        // character is the record's T[q + K]) — the verify stage then aligns the hit without a line of the text
+        const u32 j = (u32)__ffs((int)fmask) - 1u;
+        const uint2 rec = f.sax[(u64)lo + j];
+        u32 lw = slen;
+        if (!(rec.y & SAX_ESCAPE)) lw |= (((S.len >> SEL_CTX_SHIFT) & 3u) << 20) | (((rec.y >> (4u + 2u * (f.K - SAX_POST_OFF))) & 3u) << 24) | SEED_CTX_VALID | SEED_KEY_VALID;
+        out[0] = HitSeed{rec.x - back, g, lw, (u32)t};
+        reads += 2;
+      } else if (occs <= 4) {
         locate_in_registers<4>(f.sa + lo, occs, take, out, g, slen, (u32)t, fmask, back);
         reads += occs;
       } else if (occs <= 16) {

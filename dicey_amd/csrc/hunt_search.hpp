@@ -25,6 +25,11 @@ struct Sel {  // a kept neighbourhood string, in search order
   u32 hbase;  // first hit slot, relative to the query's first hit
   u32 g;      // 2*query + strand (set for the strings of the flat region, where no leaf record names the group)
 };
+// r06, filtered form with ONE suffix in its mask and <= 4 characters in front of the table window: bit 30 of `len` is set and bits 27-28 hold
+// the code of the text character in front of that occurrence; the string itself (2 bits per character, the first character in the highest
+// pair) lies in FlatSel::key at the string's slot.  With the character behind the occurrence, which the locate stage finds in the suffix's
+// record (FmView::sax), the verify stage aligns the hit without reading the text.
+static constexpr u32 SEL_CTX_SHIFT = 27, SEL_CTX_VALID = 1u << 30;
 
 DG_HD u32 sel_len_filtered(u32 len, u32 pre, u32 mask) { return (len & 255u) | ((pre & 7u) << 8) | ((mask & 0xFFFFu) << 11) | (1u << 31); }
 // from a leaf's filter word (mask | characters in front << 16 | 1 << 31, 0 = ordinary interval)
@@ -632,6 +637,7 @@ struct FlatSel {
   u32 cap;
   u32* selbase;    // [2 nq] first Sel slot of a group served here (0xFFFFFFFF: generic path, grp_off based)
   u32* nsel;       // [2 nq]
+  u64* key;        // [flat slots] r06: the kept strings themselves (see SEL_CTX_VALID); nullptr = not wanted
 };
 // r04: (i) the three wavefronts that have nothing to do behind the probe phase END there instead of waiting at the barrier behind
 // the dense phase (the usual workgroup has ~40 survivors, one wavefront's worth): the r04a counters showed the kernel resident at
@@ -641,7 +647,7 @@ struct FlatSel {
 // freed slots can be taken by new workgroups.
 static constexpr u32 FUSED_LCAP = 512;   // largest LDS list
 static constexpr u32 FUSED_QCAP = 512;   // survivor queue entries per round
-static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u + 2u); }
+static inline u32 fused_lds_bytes(u32 lcap) { return lcap * (8u + 4u + 4u + 2u + 2u + 2u + 2u + 1u); }  // (+ 1: l_ctx, r06)
 // TAKE (r04): the workgroup also does k_take's work for its own queries (the occurrences of a query's kept strings in push order:
 // take = what hunter.h:349-357 still accepts, a saturating prefix sum) — k_take, 12 us of a 0.34 ms step, is not launched.  Used
 // when the whole batch is on the flat path (no generic kernels); gpw is even then, so that both strands of a query sit in one
@@ -664,6 +670,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
   u16* const l_pos = l_meta + lcap;
   u16* const l_ord = l_pos + lcap;
   u16* const l_mask = l_ord + lcap;  // filtered intervals (FmView::pre5): which entries of [lo, hi) spell the string's first characters
+  u8* const l_ctx = reinterpret_cast<u8*>(l_mask + lcap);  // r06: 8 | code of the character in front of a filtered string's ONE occurrence, 0 = not known
   constexpr u32 NOPS = INDEL ? 8u : 4u;
   if (threadIdx.x == 0) {
     q_n = 0;
@@ -766,23 +773,30 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
         // character — mlen - K dependent Occ lines — but FILTERED: the entries of FmView::pre5 say which of its suffixes are
         // preceded by the string's first mlen - K characters (one line, two when the interval straddles); the string then
         // occurs at SA[i] - (mlen - K) for exactly those i, and travels as (interval, mask) instead of its own interval
-        u32 fmask = 0, fpre = 0;
+        u32 fmask = 0, fpre = 0, cx = 0;
         if (to_lds && f.pre5 && n >= 1 && n <= 5 && lo < hi && hi - lo <= 16) {
           const u32 w = hi - lo;
           u32 want = 0;
           for (u32 k2 = 0; k2 < n; ++k2) want |= ((u32)(rs >> (2 * k2)) & 3u) << (3 * k2);
           const u32 wmask = (1u << (3 * n)) - 1u;
+          u32 before = 7u;  // the character in front of the string's (single) occurrence: the entry's character n + 1, when it has one
           if (w == 1 && pre_first != 0xFFFFFFFFu) {
             // r05: the interval holds ONE suffix and the table entry carries its preceding characters: no line of pre5
             fmask = (u32)((pre_first & wmask) == want);
+            before = (pre_first >> (3 * n)) & 7u;
           } else {
             u32 ent16[16];
 #pragma unroll
             for (u32 j = 0; j < 16; ++j) ent16[j] = j < w ? (u32)f.pre5[(u64)lo + j] : 0xFFFFu;
 #pragma unroll
-            for (u32 j = 0; j < 16; ++j) fmask |= (u32)((ent16[j] & wmask) == want && j < w) << j;
+            for (u32 j = 0; j < 16; ++j) {
+              const bool hit = (ent16[j] & wmask) == want && j < w;
+              fmask |= (u32)hit << j;
+              before = hit ? (ent16[j] >> (3 * n)) & 7u : before;
+            }
             ++nlook;
           }
+          if (n <= 4 && before < 4u && (fmask & (fmask - 1u)) == 0u) cx = 8u | before;  // (one occurrence; five characters per entry)
           fpre = n;
           n = 0;
           if (!fmask) lo = hi = 0;
@@ -802,6 +816,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
               l_hi[at] = hi;
               l_meta[at] = (u16)(mlen | (lg << 6) | (fpre << 10) | (fpre ? 0x2000u : 0u));
               l_mask[at] = (u16)fmask;
+              l_ctx[at] = (u8)cx;
             }
           } else {
             const u32 at = atomicAdd(&o.ctr->leaf_cnt[shard], 1u);
@@ -959,7 +974,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       Sel sv;
       sv.lo = l_lo[i];
       sv.hi = l_hi[i];
-      sv.len = (meta & 0x2000u) ? sel_len_filtered(alen, (meta >> 10) & 7u, (u32)l_mask[i]) : alen;
+      sv.len = (meta & 0x2000u) ? sel_len_filtered(alen, (meta >> 10) & 7u, (u32)l_mask[i]) | ((u32)l_ctx[i] << SEL_CTX_SHIFT) : alen;
       sv.take = 0;
       sv.hbase = 0;
       if (TAKE) {  // hunter.h:349-357: strings are located in set order, forward strand first, while hits < max_locations
@@ -970,6 +985,7 @@ __global__ void __launch_bounds__(256, 8) k_search1s(FmView f, Batch b, SearchOu
       }
       sv.g = g_first + lg;
       fs.sel[(u64)shard * fs.cap + wbase + g_base[lg] + r] = sv;
+      if (fs.key && (sv.len & SEL_CTX_VALID)) fs.key[(u64)shard * fs.cap + wbase + g_base[lg] + r] = l_key[i];
     }
   }
   if (threadIdx.x < gpw && g_first + threadIdx.x < ngrp2) {

@@ -22,6 +22,8 @@ struct VerifyArgs {
   u32 ops_per_hit;   // the batch's largest effective distance
   u32 debug;              // DICEY_DBG_VERIFY (measurements only: 1 = skip the alignments, 2 = skip the context reads; results are wrong)
   u32* chits;             // != nullptr: compact records (dicey_gpu.h ABI 5: position, meta, ops) instead of dg_hit + ops
+  const u64* selkey;      // != nullptr (r06, batches at distance <= 1): a hit whose seed says so (SEED_KEY_VALID) is aligned from its kept string's
+                          // codes (FlatSel::key at the seed's slot) and the seed's context codes, without a line of the text
 };
 // the compact record's second word (dicey_gpu.h DG_CHIT_*): delta = DnaHit::start - 1 - (position - start of its sequence)
 DG_DEV u32 chit_meta(int score, u32 strand, int delta, u32 aln_len) {
@@ -730,16 +732,25 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
   TR* const tr = reinterpret_cast<TR*>(u_lds) + tid;
   u64* const win = reinterpret_cast<u64*>(u_lds + ((rows * 256 * sizeof(TR) + 7) & ~(size_t)7)) + tid;  // 6 words per lane, word-major
   u32 fault = 0;
-  auto align = [&](const HitSeed& s0) -> AlnRes {
+  auto align = [&](const HitSeed& s0, const u32 lenword) -> AlnRes {
     const u64 q = s0.qs >> 1;
     const uint4 pq = b.gpeq[s0.qs];
-    return band_align_bits<WB, TR, 256>(f.text, f.n, b.indel != 0, (u64)s0.pos, s0.len, b.qlen[q], b.indel ? b.qdist[q] : 0u,
-                                        PosMasks{pq.x, pq.y, pq.z, pq.w}, tr, win, fault);
+    const u32 d = b.indel ? b.qdist[q] : 0u;
+    KeyWindow kw{0ULL, 0u, 0u};
+    bool from_key = false;
+    if (a.selkey && (lenword & SEED_KEY_VALID) && b.indel && d <= 1u && !(a.debug & 2u)) {
+      kw.key = a.selkey[s0.sel];
+      kw.pre = (lenword >> 20) & 3u;
+      kw.post = (lenword >> 24) & 3u;
+      from_key = true;
+    }
+    return band_align_bits<WB, TR, 256>(f.text, f.n, b.indel != 0, (u64)s0.pos, s0.len, b.qlen[q], d, PosMasks{pq.x, pq.y, pq.z, pq.w}, tr, win, fault,
+                                        from_key, kw);
   };
   if (!SHARE) {
     cls[0] = tid;
     if (base + tid < nh && !(a.debug & 1u)) {
-      const AlnRes r = align(sd[0]);
+      const AlnRes r = align(sd[0], sctx[0]);
       if (r.pre_eff < cpos[0]) cpos[0] -= r.pre_eff;  // hunter.h:382 (strict <)
       cls_info[tid] = r.info;
       cls_ops[tid * DS] = r.op[0];
@@ -749,7 +760,7 @@ DG_DEV void verify_memo_block(const FmView& f, const Batch& b, const VerifyArgs&
     for (u32 c = tid; c < ncls && !(a.debug & 1u); c += 256) {
       const u32 own = cls_owner[c];
       const uint4 v = *reinterpret_cast<const uint4*>(a.seeds + base + own);
-      const AlnRes r = align(HitSeed{v.x, v.y, v.z & SEED_LEN_MASK, v.w});
+      const AlnRes r = align(HitSeed{v.x, v.y, v.z & SEED_LEN_MASK, v.w}, v.z);
       cls_info[c] = r.info;
       cls_ops[c * DS] = r.op[0];
       if (DS > 1) cls_ops[c * DS + 1] = r.op[1];

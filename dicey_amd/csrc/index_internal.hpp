@@ -12,7 +12,7 @@
 // host process that writes its environment — and carried to run_batch in the handle.
 struct dg_switches {
   bool host_timing = false, no_band = false, cap_host = false, no_fuse = false, no_fuse2 = false, no_prep_fusion = false, no_pre5_d2 = false;
-  bool debug_caps = false, no_flat_ham2 = false, no_nwin = false, no_long2 = false;
+  bool debug_caps = false, no_flat_ham2 = false, no_nwin = false, no_long2 = false, no_direct_ctx = false;
   uint32_t fused_lcap = 0;       // DICEY_FUSED_LCAP (0 = unset)
   int verify_ch = 0;             // DICEY_VERIFY_CH
   uint64_t cap_budget_mb = 0;    // DICEY_CAP_BUDGET_MB (0 = unset)
@@ -32,7 +32,7 @@ struct dg_index {
   uint64_t file_bytes = 0, hbm_bytes = 0;
   double load_seconds = 0, derive_seconds = 0;
   // grow-only batch workspaces (see hunt.hip / seam.hip for the slot meaning)
-  static constexpr int NWS = 25;
+  static constexpr int NWS = 26;
   dg::DevBuf ws[NWS];
   hipEvent_t ev[9] = {nullptr};  // [8]: end of the flat distance-1 kernel
   uint32_t flat_cap_hint = 0;   // slice capacity of the flat Sel region that was enough so far (hunt.hip)

@@ -22,6 +22,8 @@ def bb():
     L.bb_align.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.bb_align.restype = C.c_int
+    L.bb_align_kw.argtypes = L.bb_align.argtypes + [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.bb_align_kw.restype = C.c_int
     return L
 
 
@@ -126,3 +128,50 @@ def test_hamming_mode_counts_mismatches(bb):
         mm = [(i, s[i]) for i in range(n) if s[i] != q[i]]
         assert fault == 0 and info == (((-len(mm)) & 255) | (n << 16))
         assert ops == [i | (MISMATCH << 16) | (ord(c) << 24) for i, c in mm][:2]
+
+
+@pytest.mark.parametrize("d,wide", [(0, 0), (1, 0), (1, 1)])
+def test_window_from_the_hits_own_codes_equals_the_window_from_the_text(bb, d, wide):
+    """r06: a hit whose string and neighbouring characters are all A/C/G/T can bring them along as 2-bit codes (Sel::key, the seed's
+    context bits); band_window_from_key spreads them into the bytes band_align_bits would have read from the text.  Same result as
+    the text path — the text handed to the key path is garbage, so a stray read of it would show."""
+    rng = random.Random(77 + d + wide)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    checked = 0
+    for _ in range(4000):
+        n = rng.randrange(12, 23)
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        s = list(q)
+        for _e in range(rng.randrange(0, d + 1)):
+            k = rng.randrange(len(s))
+            r = rng.random()
+            if r < 0.4:
+                s[k] = rng.choice("ACGT")
+            elif r < 0.7 and len(s) > 11:
+                del s[k]
+            else:
+                s.insert(k, rng.choice("ACGT"))
+        s = "".join(s)
+        if len(s) + 2 > 24:
+            continue
+        left = (s[:1] * 3 if rng.random() < 0.3 else "".join(rng.choice("ACGT") for _ in range(3)))
+        right = (s[-1:] * 3 if rng.random() < 0.3 else "".join(rng.choice("ACGT") for _ in range(3)))
+        text = left + s + right + "\n"
+        loc, mlen = len(left), len(s)
+        score, ra, qa, lead, pre_eff = expected(text, loc, mlen, q, d)
+        if -score > d:
+            continue
+        want = run(bb, text, loc, mlen, q, d, True, wide)
+        key = 0
+        for ch in s:
+            key = (key << 2) | code[ch]
+        buf = b"\n" * (len(text) + 17)
+        info, pe = C.c_uint32(), C.c_uint32()
+        ops = (C.c_uint32 * 2)()
+        m = (C.c_uint32 * 4)(*masks_of(q))
+        fault = bb.bb_align_kw(buf, len(text) + 1, loc, mlen, len(q), d, 1, int(wide), m, C.byref(info), ops, C.byref(pe), 1, key,
+                               code[text[loc - 1]], code[text[loc + mlen]])
+        got = (fault, info.value, [x for x in ops if x != NONE], pe.value)
+        assert got == want and fault == 0, (q, text, loc, mlen, d, want, got)
+        checked += 1
+    assert checked > 2500

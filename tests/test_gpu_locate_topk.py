@@ -226,3 +226,58 @@ def test_small_buffer_topk_kernel_serves_a_batch_with_thousands_of_repeat_rich_s
         got = _compare(ix, orc, g, qs, distance=1, max_locations=1000)
         assert sum(len(q.hits) for q in got.queries) > 400 * 2000
         _compare(ix, orc, g, qs[:300], distance=1, max_locations=150)
+
+
+@pytest.mark.parametrize("K,K2", [(16, 18), (17, 18)])
+def test_single_occurrence_hits_are_aligned_from_their_own_codes(tmp_path, monkeypatch, K, K2):
+    """r06: a kept string with ONE occurrence found through a filtered table interval leaves k_search1s with its characters (Sel::key)
+    and the character in front of the occurrence; k_locate takes the position and the character behind it from the suffix's record
+    (FmView::sax) and k_verify_memo aligns the hit without a text line (band_window_from_key).  Unique windows of many short
+    sequences — at their first and last positions (the neighbour is the separator: no context), one and two characters inside,
+    next to N runs and to lower-case / IUPAC characters — as exact queries and with one edit, table orders 16 and 17 (the default
+    layouts of a 3 Gb genome, forced on this small one); DICEY_NO_DIRECT_CTX (read per batch by the development build): the same hits
+    with the text read as before — and fewer record reads, i.e. the path under test really ran."""
+    monkeypatch.setenv("DICEY_KMER_K", str(K))
+    monkeypatch.setenv("DICEY_KMER_K2", str(K2))
+    monkeypatch.setenv("DICEY_NO_DIRECT_CTX", "1")   # (also makes open_index load the development build)
+    rng = random.Random(40 + K)
+    seqs = []
+    for c in range(40):
+        s = bytearray(rng.choice(b"ACGT") for _ in range(rng.randrange(300, 900)))
+        for _ in range(3):
+            p = rng.randrange(40, len(s) - 60)
+            s[p:p + rng.randrange(1, 12)] = b"N" * rng.randrange(1, 12)
+        for _ in range(3):
+            p = rng.randrange(40, len(s) - 60)
+            s[p] = rng.choice(b"RYKMacgt")
+        seqs.append(s.decode())
+    path, g = _index(tmp_path, seqs, "uniq%d.fm9" % K)
+    orc = O.Index(path)
+    qs = []
+    for s in seqs:
+        n = len(s)
+        starts = [0, 1, 2, 3, n - 20, n - 21, n - 22, n - 23] + [rng.randrange(0, n - 25) for _ in range(10)]
+        npos = [i for i, ch in enumerate(s) if ch == "N"]
+        for p in npos[:2] + npos[-2:]:   # windows that end / start right at an N run, and one character away
+            starts += [p - 20, p - 21, p + 1, p + 2]
+        for st in starts:
+            for m in (18, 20, 21, 23):
+                if st < 0 or st + m > n:
+                    continue
+                q = s[st:st + m].upper()
+                if any(ch not in "ACGT" for ch in q):
+                    continue
+                k = rng.randrange(m)
+                qs.append(rng.choice([q, q[:k] + rng.choice("ACGT") + q[k + 1:], q[:k] + q[k + 1:], q[:k] + rng.choice("ACGT") + q[k:]]))
+    qs = qs[:6000]
+    with open_index(path) as ix:
+        plain = _compare(ix, orc, g, qs, distance=1)
+        monkeypatch.delenv("DICEY_NO_DIRECT_CTX")
+        got = _compare(ix, orc, g, qs, distance=1)
+        nh = sum(len(q.hits) for q in got.queries)
+        assert nh > len(qs)
+        # a hit of the new path counts its 8-byte record as two suffix-array reads: most hits of this batch take it
+        assert got.counters["sa_reads"] - plain.counters["sa_reads"] > nh // 2, (got.counters, plain.counters, nh)
+        _compare(ix, orc, g, qs[::5], distance=1, max_locations=1)
+        _compare(ix, orc, g, qs[::7], distance=0)
+        _compare(ix, orc, g, qs[::9], distance=1, forward_only=True)

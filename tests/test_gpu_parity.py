@@ -363,7 +363,7 @@ SWITCHES = {"nofuse": {"DICEY_NO_FUSED_SELECT": "1"}, "noband": {"DICEY_NO_BAND_
             "lcap2": {"DICEY_FUSED_LCAP": "2"}, "noprep": {"DICEY_NO_PREP_FUSION": "1"}, "caphost": {"DICEY_CAP_HOST": "1"}, "nominima": {"DICEY_NO_SA_MINIMA": "1"}, "nopre5": {"DICEY_NO_PRE5": "1"},
             "nopre5d2": {"DICEY_NO_PRE5_D2": "1"}, "nofuse2": {"DICEY_NO_FUSED_SELECT2": "1"}, "noflatham2": {"DICEY_NO_FLAT_HAMMING2": "1"},
             "nonwin": {"DICEY_NO_N_WINDOW": "1"},
-            "nolong2": {"DICEY_NO_LONG2": "1"}}
+            "nolong2": {"DICEY_NO_LONG2": "1"}, "nodirectctx": {"DICEY_NO_DIRECT_CTX": "1"}}
 
 
 @pytest.mark.parametrize("mode", ["no_table", "K8", "K11", "K13", "K9_nolong", "K9_long10", "K10_long14"] + ["K9_long10+" + k for k in SWITCHES])

@@ -163,6 +163,13 @@ def _pick(d, keys):
     return {k: _short(d[k]) for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else None
 
 
+def _sig(d, digits=7):
+    """floats of a (flat) block at `digits` significant digits: the contract line's sub-blocks, not its headline keys"""
+    if not isinstance(d, dict):
+        return d
+    return {k: (float("%.*g" % (digits, v)) if isinstance(v, float) and v == v and abs(v) != float("inf") else v) for k, v in d.items()}
+
+
 def contract_line(out: dict, detail_path: str = "") -> str:
     """The ONE line the driver parses: the contract's keys, roofline + cpu_baseline of the dominant kernel, the parity sample and a
     five-field summary of every other configuration.  Everything else lives in the detail file.  Strict JSON (no NaN), < 4 KB."""
@@ -196,6 +203,11 @@ def contract_line(out: dict, detail_path: str = "") -> str:
             line[k] = out[k]
     line["build_id"] = out.get("build_id")
     line["detail"] = detail_path
+    for k in ("roofline", "cpu_baseline", "cpu_baseline_parallel", "sustained"):
+        line[k] = _sig(line.get(k))
+    rf = line.get("roofline")
+    if isinstance(rf, dict) and isinstance(rf.get("achieved"), float) and rf.get("peak") and rf.get("frac") is not None:
+        rf["frac"] = rf["achieved"] / rf["peak"]  # (of the rounded figure: frac == achieved / peak holds to the last digit)
     s = json.dumps(line, allow_nan=False)
     for drop in ("delivery", "detail", "build_id", "cpu_baseline_parallel"):  # never over the limit: optional blocks go first
         if len(s) < CONTRACT_LINE_LIMIT:
@@ -1601,13 +1613,18 @@ def main():
                         sys.path.insert(0, os.path.join(ROOT, "tests"))
                         import oracle_lib as O
                         chk = O.Index(fm9)
+                    # (every run below starts 5 s after the previous process left: the 98 GB it released are wiped by then — r06's final
+                    #  call saw `text + suffix array` take 4.3 s instead of 0.3 s in a process started a second after another one's exit)
+                    time.sleep(5)
                     out["cli_end_to_end_1M"] = cli_end_to_end(fm9, meta, big[:1000000], cli_job[1], oracle=chk, seqlen=seqlen)
+                    time.sleep(5)
                     out["cli_end_to_end_10M" if len(big) == 10000000 else "cli_end_to_end_%d" % len(big)] = \
                         cli_end_to_end(fm9, meta, big, cli_job[1], oracle=chk, seqlen=seqlen)
                     # the same seam at edit distance 2 (BASELINE configs[3]'s distance): 59 hits and ~11 KB of JSON per query on this genome,
                     # i.e. 110 GB for 10 M queries — the reference would write the same — so this run takes the first 1 M (11 GB)
                     if chk is not None:
                         O.fast_neighbors(True)
+                    time.sleep(5)
                     try:
                         out["cli_end_to_end_d2_1M"] = cli_end_to_end(fm9, meta, big[:1000000], 2, oracle=chk, seqlen=seqlen, bytes_per_query=12000)
                     finally:

@@ -616,6 +616,6 @@ def test_one_shot_open_flags_answer_the_same(small_genome):
     import dicey_amd
     with dicey_amd.FmIndex(small_genome["fm9"], device=0) as full, dicey_amd.FmIndex(small_genome["fm9"], device=0, compact=True, pre5=False) as lean:
         assert lean.stats()["hbm_bytes"] < full.stats()["hbm_bytes"] - 2 * len(small_genome["text"])
-        for kw, nq, lens in [(dict(distance=1), 600, (20, 18, 25)), (dict(distance=2), 120, (20,)), (dict(distance=1, hamming=True), 200, (20,)),
+        for kw, nq, lens in [(dict(distance=1), 600, (20, 18, 25)), (dict(distance=2), 24, (20,)), (dict(distance=1, hamming=True), 200, (20,)),
                              (dict(distance=1, max_locations=3), 200, (12, 16, 17))]:
             test_hunt_hits_equal_oracle_push_order(lean, small_genome, kw, nq, lens)

@@ -741,8 +741,10 @@ int hunter(int argc, char** argv) {
       auto work = [&](unsigned t) {
         std::string& o = blobs[t];
         const size_t i0 = t * per_thr, i1 = std::min(nq, i0 + per_thr);
-        o.reserve((i1 > i0 ? i1 - i0 : 0) * 700);
+        static std::atomic<size_t> per_line{700};  // bytes per line of the last buffer formatted (distance 2: ~8 KB): the next one is sized for it
+        o.reserve((i1 > i0 ? i1 - i0 : 0) * per_line.load(std::memory_order_relaxed));
         for (size_t i = i0; i < i1; ++i) o += line_of(i);
+        if (i1 > i0 + 16) per_line.store(o.size() / (i1 - i0) + o.size() / (i1 - i0) / 8 + 64, std::memory_order_relaxed);
       };
       if (nthr > 1) {
         std::vector<std::thread> fmt;
@@ -806,7 +808,9 @@ int hunter(int argc, char** argv) {
     };
     // Large inputs go chunk by chunk with TWO batches in flight (dg_hunt_submit / dg_hunt_wait on this handle and on a second
     // one that shares the resident index): while the host formats the lines of chunk k, chunk k+1 is on the GPU.
-    const size_t CHUNK = (s1 - s0) > (1u << 18) ? (1u << 17) : (1u << 20);
+    // (distance >= 2: a query's line is ~8 KB on a 3 Gb genome — 131 072 of them are a gigabyte, twice what the writer's queue takes,
+    //  and the formatting threads stood still while it drained; 16 384 keep both sides busy: 1 M queries 4.1 -> see DESIGN §9)
+    const size_t CHUNK = c.distance >= 2 ? (1u << 14) : (s1 - s0) > (1u << 18) ? (1u << 17) : (1u << 20);
     std::vector<std::pair<size_t, size_t>> chunks;
     for (size_t q0 = s0; q0 < s1; q0 += CHUNK) chunks.emplace_back(q0, std::min(s1, q0 + CHUNK));
     if (chunks.size() < 2 || std::getenv("DICEY_NO_PIPELINE")) {

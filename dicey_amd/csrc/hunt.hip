@@ -600,7 +600,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
   // (r05: Hamming distance 2 as well — the same kernel with "no edit" in place of the deletions)
   b.fast2K = (dmax_eff == 2 && (indel || !sw.no_flat_ham2) && ix->view.K && maxlen >= ix->view.K + 2 && ngrp < 0x7FFFFFFFull) ? ix->view.K : 0u;
   b.tabK = sw.no_nwin ? 0u : ix->view.K;
-  b.nrun_min = (dmax_eff == 1 || dmax_eff == 2) ? ix->view.nrun_min : 0u;  // (non-zero: k_nres is launched with the generic kernels)
+  b.nrun_min = ((dmax_eff == 1 || dmax_eff == 2) && ngrp < 0x7FFFFFFFull) ? ix->view.nrun_min : 0u;  // (non-zero: k_nres is launched with the generic kernels)
   b.qmode = d_qmode;
   b.xs_bytes = d_xs_bytes;
   b.xs_off = d_xs_off;
@@ -917,8 +917,12 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
       // (k_walk_list; room for what the previous batch listed plus a quarter — a list that overflows repeats the batch)
       WalkList wl{nullptr, nullptr, 0u};
       u64 wgroups = ngrp;
-      if ((b.fastK || b.fast2K) && ngrp < 0x7FFFFFFFull) {
-        walk_cap = std::max<u64>(walk_cap, std::min<u64>(ngrp, (u64)ix->walk_hint + ix->walk_hint / 4 + 4096));
+      // (r06 fix: also for a batch WITHOUT a flat kernel — queries shorter than the table order — when k_prepare may mark strands for
+      //  k_nkeep (b.nrun_min): they are found through this list only; the list then simply holds every group, no hint involved.
+      //  tools/fuzz_hunt.py in the full-size layout found a 12-mer ending in N that lost its two exact hits in Hamming mode)
+      const bool flat_on = b.fastK || b.fast2K;
+      if ((flat_on || b.nrun_min) && ngrp < 0x7FFFFFFFull) {
+        walk_cap = std::max<u64>(walk_cap, flat_on ? std::min<u64>(ngrp, (u64)ix->walk_hint + ix->walk_hint / 4 + 4096) : ngrp);
         DG_TRY(ws[WS_WALK].reserve(2 * (walk_cap + 1) * 4));
         wl.gid = ws[WS_WALK].as<u32>();
         wl.count = &ctr->pad_[10];

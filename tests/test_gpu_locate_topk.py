@@ -281,3 +281,46 @@ def test_single_occurrence_hits_are_aligned_from_their_own_codes(tmp_path, monke
         _compare(ix, orc, g, qs[::5], distance=1, max_locations=1)
         _compare(ix, orc, g, qs[::7], distance=0)
         _compare(ix, orc, g, qs[::9], distance=1, forward_only=True)
+
+
+@pytest.mark.parametrize("K", [16, 0])
+def test_short_queries_that_end_in_n_keep_their_hits_next_to_n_runs(tmp_path, monkeypatch, K):
+    """r06 regression (found by tools/fuzz_hunt.py in the full-size layout): a batch whose queries are all shorter than the table
+    order has no flat kernel; a strand with one N at an end is marked for k_nkeep all the same, and k_nkeep used to be launched only
+    beside a flat kernel — the strings that keep the N (the unedited query in Hamming mode: exact hits where the text continues with
+    an N run) were never searched.  Queries of 10-15 nt ending / starting at the N runs of a small text, table order 16 and the
+    small text's own order, edit and Hamming mode, alone in the batch and next to 20-mers (which bring the flat kernel along)."""
+    if K:
+        monkeypatch.setenv("DICEY_KMER_K", str(K))
+        monkeypatch.setenv("DICEY_KMER_K2", "18")
+    rng = random.Random(77)
+    seqs = []
+    for c in range(6):
+        s = bytearray(rng.choice(b"ACGT") for _ in range(4000))
+        for _ in range(12):
+            p = rng.randrange(100, len(s) - 100)
+            n = rng.randrange(2, 25)
+            s[p:p + n] = b"N" * n
+        seqs.append(s.decode())
+    path, g = _index(tmp_path, seqs, "nruns%d.fm9" % K)
+    orc = O.Index(path)
+    short, long_ = [], []
+    for s in seqs:
+        for p in [i for i in range(20, len(s) - 20) if s[i] == "N" and s[i - 1] != "N"][:8]:   # first N of a run
+            for m in (10, 12, 15):
+                w = s[p - m + 1:p + 1]
+                if "N" in w[:-1]:
+                    continue
+                short += [w, w[:3] + rng.choice("ACGT") + w[4:]]
+            long_.append(s[p - 19:p + 1])
+        for p in [i for i in range(20, len(s) - 20) if s[i] == "N" and s[i + 1] != "N"][:8]:   # last N of a run
+            for m in (10, 13):
+                w = s[p:p + m]
+                if "N" in w[1:]:
+                    continue
+                short += [w, w[:-4] + rng.choice("ACGT") + w[-3:]]
+    with open_index(path) as ix:
+        for kw in (dict(distance=1, hamming=True), dict(distance=1), dict(distance=1, hamming=True, forward_only=True, max_locations=2)):
+            got = _compare(ix, orc, g, short, **kw)
+            assert sum(len(q.hits) for q in got.queries) >= len(short) // 3, kw
+            _compare(ix, orc, g, short[::3] + long_, **kw)

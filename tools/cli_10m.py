@@ -20,9 +20,10 @@ big = np.concatenate([bench.synth_query_batch(text, 100000, 20, seed=5000 + i) f
 del text
 torch.cuda.empty_cache()
 meta = {"lens": lens}
-extra = dict(kv.split("=", 1) for kv in sys.argv[4:])  # NAME=value ... for the binary's environment only
+extra = dict(kv.split("=", 1) for kv in sys.argv[4:])  # NAME=value ... for the binary's environment only (DIST=2: hunt -d 2)
+dist = int(extra.pop("DIST", "1"))
 for r in range(runs):
-    res = bench.cli_end_to_end(fm9, meta, big, 1, extra_env=extra)
+    res = bench.cli_end_to_end(fm9, meta, big, dist, extra_env=extra, bytes_per_query=12000 if dist >= 2 else 700)
     ph = res.pop("index_open_phases_ms", {})
     res.pop("note", None)
     print(json.dumps(res))

@@ -59,6 +59,8 @@ for c in range(nconf):
         q = "".join(q)[:maxlen]
         if rng.random() < 0.1: q = q.lower()
         qs.append(q)
+    if os.environ.get("FUZZ_ONLY") and c != int(os.environ["FUZZ_ONLY"]):  # (the generator has advanced as in a full run)
+        continue
     try:
         got = ix.hunt(qs, seqlen, **kw)
     except Exception as e:
@@ -71,4 +73,11 @@ for c in range(nconf):
     nh = sum(len(q.hits) for q in got.queries)
     print("conf", c, kw, "queries", len(qs), "hits", nh, "MISMATCH %d first %r" % (len(mism), qs[mism[0]]) if mism else "ok")
     bad += bool(mism)
+    if mism and os.environ.get("FUZZ_VERBOSE"):
+        for qi in mism[:3]:
+            print("  query", qi, repr(qs[qi]), "flags", got.queries[qi].flags)
+            print("    got ", [(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in got.queries[qi].hits][:6])
+            print("    want", per.get(qi, [])[:6])
+            alone = ix.hunt([qs[qi]], seqlen, **kw)
+            print("    alone", [(h.score, h.chr, h.start, h.strand, h.refalign, h.queryalign) for h in alone.queries[0].hits][:6])
 print("failing configurations:", bad)

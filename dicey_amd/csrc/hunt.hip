@@ -957,7 +957,7 @@ int run_batch(dg_index* ix, const dg_hunt_params* p, const uint32_t* seqlen, uin
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nres<false>), dim3(ceil_div(ngrp * per, TB)), dim3(TB), 0, st, ix->view, b, so, per);
         // ... and the strings of the listed bit-13 strands that keep their N: a lane per candidate edit
         if (kl.gid) {
-          const u32 kper = 1u + (indel ? 8u : 3u) * std::min(maxlen, 32u);
+          const u32 kper = 1u + (indel ? 9u : 3u) * std::min(maxlen, 32u);
           if (indel) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nkeep<true>), dim3(ceil_div((u64)kl.cap * kper, TB)), dim3(TB), 0, st, ix->view, b, so, kl, kper);
           else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nkeep<false>), dim3(ceil_div((u64)kl.cap * kper, TB)), dim3(TB), 0, st, ix->view, b, so, kl, kper);
         }

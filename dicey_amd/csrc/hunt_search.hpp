@@ -1977,7 +1977,7 @@ __global__ void __launch_bounds__(256) k_nres(FmView f, Batch b, SearchOut o, u3
 
 // r06: the strings of a bit-13 strand that KEEP its N (one N, one edit, the N within a character of an end): the query with one
 // edit elsewhere — or none in Hamming mode — such that the N is the string's first or last character; one lane per candidate edit
-// (per = 1 + 8 m in edit mode, 1 + 3 m in Hamming mode), over the strands k_walk_list listed.  N last: the search starts from the
+// (per = 1 + 9 m in edit mode, 1 + 3 m in Hamming mode), over the strands k_walk_list listed.  N last: the search starts from the
 // N's own interval and dies within a few steps almost everywhere; N first: the rest is searched like any N-free string and only
 // what occurs is extended by the N (through the wavelet tree, like sdsl).  An occurring string becomes a leaf whose operation is
 // the edit (neighbors.h:57-78; the N itself stays in the query the leaf reader applies it to).
@@ -1985,7 +1985,7 @@ template <bool INDEL>
 __global__ void __launch_bounds__(256) k_nkeep(FmView f, Batch b, SearchOut o, WalkList wl, u32 per) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 slot = t / per;
-  const u32 e = (u32)(t - slot * per);  // 0: no edit; 1 + 8 i + k (edit mode): k = 0 delete q[i], 1-4 substitute, 5-8 insert in front of q[i]
+  const u32 e = (u32)(t - slot * per);  // 0: no edit; 1 + 9 i + k (edit mode): k = 0 delete q[i], 1-4 substitute, 5-8 insert in front of q[i]
   const u32 nl = *wl.count < wl.cap ? *wl.count : wl.cap;
   u64 steps = 0, lookups = 0, probes = 0;
   if (slot < nl) {
@@ -1995,7 +1995,7 @@ __global__ void __launch_bounds__(256) k_nkeep(FmView f, Batch b, SearchOut o, W
     const uint4 pq = b.gpeq[gid];
     const u32 nm = ~(pq.x | pq.y | pq.z | pq.w) & (m == 32 ? ~0u : ((1u << m) - 1u));
     const u32 iN = (u32)__builtin_ctz(nm);
-    constexpr u32 PER_POS = INDEL ? 8u : 3u;
+    constexpr u32 PER_POS = INDEL ? 9u : 3u;  // (r06 fix: nine operations per position in edit mode — with 8 the insertion of T was never enumerated; tools/fuzz_n.py)
     bool ok = m != 0 && (gi.d_win & 8192u) != 0;
     u32 kind = 3u /* none */, i = 0, c = 0;
     if (e) {

@@ -289,7 +289,9 @@ def test_short_queries_that_end_in_n_keep_their_hits_next_to_n_runs(tmp_path, mo
     order has no flat kernel; a strand with one N at an end is marked for k_nkeep all the same, and k_nkeep used to be launched only
     beside a flat kernel — the strings that keep the N (the unedited query in Hamming mode: exact hits where the text continues with
     an N run) were never searched.  Queries of 10-15 nt ending / starting at the N runs of a small text, table order 16 and the
-    small text's own order, edit and Hamming mode, alone in the batch and next to 20-mers (which bring the flat kernel along)."""
+    small text's own order, edit and Hamming mode, alone in the batch and next to 20-mers (which bring the flat kernel along).
+    Second regression of the same round (tools/fuzz_n.py): queries with one character FEWER than the text next to the run — the string
+    that occurs is an insertion that keeps the N, and k_nkeep tried only eight of the nine operations per position."""
     if K:
         monkeypatch.setenv("DICEY_KMER_K", str(K))
         monkeypatch.setenv("DICEY_KMER_K2", "18")
@@ -312,6 +314,12 @@ def test_short_queries_that_end_in_n_keep_their_hits_next_to_n_runs(tmp_path, mo
                 if "N" in w[:-1]:
                     continue
                 short += [w, w[:3] + rng.choice("ACGT") + w[4:]]
+                # the text holds one character MORE than the query (the neighbourhood string is an insertion that keeps the N): every
+                # inserted base must be tried — k_nkeep enumerated eight of the nine operations per position and never inserted a T
+                w1 = s[p - m:p + 1]
+                if "N" not in w1[:-1]:
+                    k = rng.randrange(2, m - 2)
+                    short.append(w1[:k] + w1[k + 1:])
             long_.append(s[p - 19:p + 1])
         for p in [i for i in range(20, len(s) - 20) if s[i] == "N" and s[i + 1] != "N"][:8]:   # last N of a run
             for m in (10, 13):
@@ -319,6 +327,10 @@ def test_short_queries_that_end_in_n_keep_their_hits_next_to_n_runs(tmp_path, mo
                 if "N" in w[1:]:
                     continue
                 short += [w, w[:-4] + rng.choice("ACGT") + w[-3:]]
+                w1 = s[p:p + m + 1]
+                if "N" not in w1[1:]:
+                    k = rng.randrange(3, m - 1)
+                    short.append(w1[:k] + w1[k + 1:])
     with open_index(path) as ix:
         for kw in (dict(distance=1, hamming=True), dict(distance=1), dict(distance=1, hamming=True, forward_only=True, max_locations=2)):
             got = _compare(ix, orc, g, short, **kw)

@@ -36,7 +36,7 @@ _lib = None
 if "DICEY_LIB" in os.environ:
     from dicey_amd import _capi
     _lib = _capi.load(os.environ["DICEY_LIB"])
-ix = dicey_amd.FmIndex(fm9, _lib=_lib)
+ix = dicey_amd.FmIndex(fm9, _lib=_lib, **({"compact": True, "pre5": False} if os.environ.get("FUZZ_ONE_SHOT") else {}))  # FUZZ_ONE_SHOT: the open flags of `dicey hunt`
 names = ["c%d" % i for i in range(nseq)]
 seqlen = [len(s) + 1 for s in seqs]
 bad = 0

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <algorithm>
 #include <string>
 #include <thread>
@@ -57,20 +58,50 @@ std::vector<size_t> even_cuts(size_t n, unsigned nt, size_t grain) {
   return cut;
 }
 
+// r06: the six per-position arrays of a result are ONE block that goes back to a small pool when the result is freed: a caller that
+// scans batch after batch (the binary over a gene list, bench.py) gets memory its threads have touched before — 128 MB of
+// first-touch page faults per 2.7 M positions were a tenth of the step
+struct ResultBox {
+  dg_padlock_result pub;  // (first member: the public pointer is the box's)
+  void* block = nullptr;
+  size_t cap = 0;         // positions the block holds
+};
+std::mutex g_pool_mu;
+std::vector<std::pair<void*, size_t>> g_pool;  // (block, positions); at most two wait here
+void* pool_take(size_t npos, size_t& cap) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); ++i)
+      if (g_pool[i].second >= npos && g_pool[i].second <= 2 * npos + 4096) {
+        void* p = g_pool[i].first;
+        cap = g_pool[i].second;
+        g_pool.erase(g_pool.begin() + (long)i);
+        return p;
+      }
+  }
+  cap = npos + npos / 16 + 64;
+  return std::malloc(cap * 6 * 8);
+}
+void pool_give(void* p, size_t cap) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_pool.size() >= 2) {
+    std::free(g_pool.front().first);
+    g_pool.erase(g_pool.begin());
+  }
+  g_pool.emplace_back(p, cap);
+}
+
 }  // namespace
 
 extern "C" {
 
 void dg_padlock_result_free(dg_padlock_result* r) {
   if (!r) return;
+  ResultBox* box = reinterpret_cast<ResultBox*>(r);
   delete[] r->pos_off;
-  delete[] r->arm_gc;
-  delete[] r->arm_tm;
-  delete[] r->probe_gc;
-  delete[] r->probe_tm;
-  delete[] r->arm_count;
-  delete[] r->arm_nbcount;
-  delete r;
+  pool_give(box->block, box->cap);
+  delete box;
 }
 
 int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const uint8_t* exons, const uint64_t* exon_off, size_t nexons,
@@ -79,7 +110,8 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
   *out = nullptr;
   const uint64_t L = p->armlen, T = 2 * L;
   if (L == 0) return fail(DG_EINVAL, "dg_padlock_scan: arm length 0");
-  dg_padlock_result* R = new dg_padlock_result;
+  ResultBox* box = new ResultBox;
+  dg_padlock_result* R = &box->pub;
   std::memset(R, 0, sizeof *R);
   R->nexons = nexons;
   R->pos_off = new uint64_t[nexons + 1];
@@ -95,12 +127,22 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
   }
   R->pos_off[nexons] = npos;
   R->npos = npos;
-  R->arm_gc = new double[npos ? npos : 1];
-  R->arm_tm = new double[npos ? npos : 1];
-  R->probe_gc = new double[npos ? npos : 1];
-  R->probe_tm = new double[npos ? npos : 1];
-  R->arm_count = new int64_t[npos ? npos : 1];
-  R->arm_nbcount = new int64_t[npos ? npos : 1];
+  box->block = pool_take(npos ? npos : 1, box->cap);
+  if (!box->block) {
+    delete[] R->pos_off;
+    delete box;
+    return fail(DG_ENOMEM, "dg_padlock_scan: out of host memory (%llu positions)", (unsigned long long)npos);
+  }
+  {
+    double* d = static_cast<double*>(box->block);
+    const size_t c = box->cap;
+    R->arm_gc = d;
+    R->arm_tm = d + c;
+    R->probe_gc = d + 2 * c;
+    R->probe_tm = d + 3 * c;
+    R->arm_count = reinterpret_cast<int64_t*>(d + 4 * c);
+    R->arm_nbcount = reinterpret_cast<int64_t*>(d + 5 * c);
+  }
   static const bool timing = std::getenv("DICEY_TIMING") != nullptr;  // debugging aid: host-side phase times on stderr
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -124,8 +166,7 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     temps.assign(wo.size(), 0.0);
     if (wo.empty()) return DG_OK;
     if (wlen <= kSelfWindowMax) {  // pairs formed on the device from the exon bytes
-      const std::vector<uint32_t> wl(wo.size(), (uint32_t)wlen);
-      return thal_self_windows(th, exons, nbytes, wo.data(), wl.data(), wo.size(), temps.data());
+      return thal_self_windows(th, exons, nbytes, wo.data(), nullptr, wo.size(), temps.data(), (uint32_t)wlen);
     }
     std::string buf;
     std::vector<uint64_t> off(1, 0);
@@ -138,15 +179,21 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     return dg_thal_batch(th, (const uint8_t*)buf.data(), off.data(), wo.size(), temps.data(), nullptr, nullptr);
   };
   // gccontent() of any window from running counts: G/C so far, and N/n so far (a window with an N scores -1)
-  std::vector<uint32_t> gcs(nbytes + 1, 0), nns(nbytes + 1, 0);
-  for (uint64_t i = 0; i < nbytes; ++i) {
-    const char ch = (char)exons[i];
-    gcs[i + 1] = gcs[i] + (ch == 'C' || ch == 'G' || ch == 'c' || ch == 'g');
-    nns[i + 1] = nns[i] + (ch == 'N' || ch == 'n');
+  // (r06: buffers this thread keeps between calls; the counts restart at every exon — a window never leaves its exon — so that the
+  //  exons' chunks can be counted by the host threads that scan them: entry i + e + 1 = characters of exon e in front of byte i)
+  static thread_local std::vector<uint32_t> gcs_buf, nns_buf;
+  if (gcs_buf.size() < nbytes + nexons + 1) {
+    gcs_buf.resize(nbytes + nexons + 1);
+    nns_buf.resize(nbytes + nexons + 1);
   }
-  auto gc_of = [&](uint64_t at, uint64_t n) -> double {
-    if (nns[at + n] != nns[at]) return -1;
-    return (double)(gcs[at + n] - gcs[at]) / (double)n;
+  // (plain pointers: the lambdas below run on other threads, where a thread_local NAME would mean that thread's own, empty vector)
+  uint32_t* const gcs_p = gcs_buf.data();
+  uint32_t* const nns_p = nns_buf.data();
+  auto gc_of = [&](size_t e, uint64_t at, uint64_t n) -> double {  // window [at, at + n) of exon e (byte offsets)
+    const uint32_t* g = gcs_p + e;
+    const uint32_t* nn = nns_p + e;
+    if (nn[at + n] != nn[at]) return -1;
+    return (double)(g[at + n] - g[at]) / (double)n;
   };
   // exons in contiguous chunks of about equal numbers of positions, one host thread each (r05); a stage is two passes over a
   // chunk — count the windows it sends to the GPU, then write them at the chunk's place of the common list: the lists come out in
@@ -175,15 +222,29 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     where.resize(total);
   };
   // stage 1: GC of every arm window; thal(arm, reverse complement) where the GC filter lets it through (padlock.h:323-345)
-  std::vector<uint64_t> wo, where;
+  static thread_local std::vector<uint64_t> wo_buf, where_buf;  // (kept between calls: 24 MB of value-initialisation and page faults per stage otherwise)
+  std::vector<uint64_t>&wo = wo_buf, &where = where_buf;
   run_chunks(ecut, [&](size_t c, size_t e0, size_t e1) {
     uint64_t n = 0;
     for (size_t e = e0; e < e1; ++e) {
       const uint64_t b0 = exon_off[e], len = exon_off[e + 1] - b0;
       if (len < T) continue;
+      {  // the exon's running counts (G/C, N) — see gc_of
+        uint32_t* g = gcs_p + e + b0;
+        uint32_t* nn = nns_p + e + b0;
+        uint32_t cg = 0, cn = 0;
+        g[0] = nn[0] = 0;
+        for (uint64_t i = 0; i < len; ++i) {
+          const char ch = (char)exons[b0 + i];
+          cg += (ch == 'C' || ch == 'G' || ch == 'c' || ch == 'g');
+          cn += (ch == 'N' || ch == 'n');
+          g[i + 1] = cg;
+          nn[i + 1] = cn;
+        }
+      }
       for (uint64_t q = 0; q + L <= len; ++q) {
         const uint64_t at = R->pos_off[e] + q;
-        const double gc = gc_of(b0 + q, L);
+        const double gc = gc_of(e, b0 + q, L);
         R->arm_gc[at] = gc;
         R->arm_tm[at] = R->probe_tm[at] = DG_PADLOCK_NOT_COMPUTED;
         R->probe_gc[at] = 0;
@@ -208,7 +269,8 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
     }
   });
   lap("arm GC + window list");
-  std::vector<double> temps;
+  static thread_local std::vector<double> temps_buf;
+  std::vector<double>& temps = temps_buf;
   int rc = thal_windows(wo, L, temps);
   lap("arm thal (pack + GPU)");
   if (rc != DG_OK) return fail_with(rc);
@@ -235,7 +297,7 @@ int dg_padlock_scan(dg_index* ix, dg_thal* th, const dg_padlock_params* p, const
       if (len < T) continue;
       for (uint64_t k = 0; k + T <= len; ++k) {
         const uint64_t at = R->pos_off[e] + k;
-        R->probe_gc[at] = gc_of(b0 + k, T);
+        R->probe_gc[at] = gc_of(e, b0 + k, T);
         n += probe_goes(at);
       }
     }

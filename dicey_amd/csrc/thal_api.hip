@@ -1,7 +1,10 @@
 // dg_thal_open / dg_thal_batch: primer3's thermodynamic alignment for `dicey search`, one GPU lane per (oligo, target)
 // pair.  Replaces primer3thal::get_thermodynamic_values (reference src/silica.h:320-323, src/thal.h:2374-2397) and
 // primer3thal::thal() with type = thal_end1, temponly = 1 (src/silica.h:437,511; src/thal.h:2409-2655).
+#include <atomic>
 #include <chrono>
+#include <thread>
+#include <vector>
 #include <cmath>
 #include <fstream>
 #include <sstream>
@@ -434,21 +437,51 @@ int dg_thal_batch(dg_thal* th, const uint8_t* seqs, const uint64_t* off, size_t 
 
 // thal(window, its reverse complement) for n windows of `bytes` (host), every window at most kSelfWindowMax nt: the pairs
 // are formed on the device (k_thal_self_wave).  Hand-backs of the wave kernel are recomputed through dg_thal_batch.
+// win_len == nullptr: every window has `uniform_len` characters (r06: `padlock` passed a vector of 1.5 M equal lengths)
 int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, const uint64_t* win_off, const uint32_t* win_len, size_t n,
-                          double* temp) {
+                          double* temp, uint32_t uniform_len) {
   if (!n) return DG_OK;
   static const bool force_redo = exp_env("DICEY_DEBUG_THAL_REDO") != nullptr;
-  u32 maxlen = 0;
-  std::vector<WinDesc> wd(n);
-  for (size_t k = 0; k < n; ++k) {
-    if (win_len[k] == 0 || win_len[k] > kSelfWindowMax || win_off[k] + win_len[k] > nbytes) return fail(DG_EINVAL, "thal_self_windows: window %zu out of range", k);
-    wd[k].off = win_off[k];
-    wd[k].len = win_len[k];
-    wd[k].pad = 0;
-    maxlen = std::max(maxlen, win_len[k]);
+  // the descriptors are written by up to eight host threads into a buffer this thread keeps between calls (r06: 24 MB per 1.5 M
+  // windows were value-initialised and filled by one thread, ~8 ms of a 0.27 s padlock step)
+  static thread_local std::vector<WinDesc> wd;
+  if (wd.size() < n) wd.resize(n);
+  std::atomic<u32> maxlen_a{0};
+  std::atomic<size_t> bad_at{(size_t)-1};
+  {
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(8, n / 65536));
+    WinDesc* const wdp = wd.data();
+    auto fill = [&, wdp](size_t k0, size_t k1) {
+      u32 mx = 0;
+      for (size_t k = k0; k < k1; ++k) {
+        const u32 len = win_len ? win_len[k] : uniform_len;
+        if (len == 0 || len > kSelfWindowMax || win_off[k] + len > nbytes) {
+          size_t cur = bad_at.load();
+          while (k < cur && !bad_at.compare_exchange_weak(cur, k)) {
+          }
+          return;
+        }
+        wdp[k].off = win_off[k];
+        wdp[k].len = len;
+        wdp[k].pad = 0;
+        mx = std::max(mx, len);
+      }
+      u32 cur = maxlen_a.load();
+      while (mx > cur && !maxlen_a.compare_exchange_weak(cur, mx)) {
+      }
+    };
+    if (nt <= 1) fill(0, n);
+    else {
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < nt; ++t) pool.emplace_back(fill, n * t / nt, n * (t + 1) / nt);
+      for (auto& x : pool) x.join();
+    }
   }
+  if (bad_at.load() != (size_t)-1) return fail(DG_EINVAL, "thal_self_windows: window %zu out of range", bad_at.load());
+  const u32 maxlen = maxlen_a.load();
   static const bool no_wave = exp_env("DICEY_NO_WAVE_THAL") != nullptr;  // debugging aid: sequential kernel only
-  std::vector<u8> redo(n, 1);
+  static thread_local std::vector<u8> redo;
+  redo.assign(n, 1);
   if (!no_wave) {
     DG_HIP(hipSetDevice(th->device));
     hipStream_t st = th->stream;
@@ -492,7 +525,7 @@ int dg::thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, co
     std::vector<uint64_t> off(1, 0);
     for (size_t k : again) {
       const uint8_t* w = bytes + win_off[k];
-      const uint32_t len = win_len[k];
+      const uint32_t len = win_len ? win_len[k] : uniform_len;
       buf.append((const char*)w, len);
       off.push_back(buf.size());
       for (uint32_t i = 0; i < len; ++i) buf.push_back(complement_iupac((char)w[len - 1 - i]));

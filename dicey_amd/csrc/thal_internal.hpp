@@ -22,5 +22,5 @@ namespace dg {
 constexpr uint32_t kSelfWindowMax = 48;  // longest window of thal_self_windows (two tables per workgroup still fit LDS)
 // thal_api.hip: thal(window, reverse complement of the window) for many windows of one byte buffer
 int thal_self_windows(dg_thal* th, const uint8_t* bytes, uint64_t nbytes, const uint64_t* win_off, const uint32_t* win_len, size_t n,
-                      double* temp);
+                      double* temp, uint32_t uniform_len = 0);
 }  // namespace dg
